@@ -1,0 +1,113 @@
+"""Pin the CPU oracle (oracle/ddrl_oracle.py) to golden vectors produced by importing the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from ddrl4nav_amd.utils.recipe import make_weights, param_specs, flatten
+from oracle import ddrl_oracle as O
+
+
+@pytest.fixture(scope="module")
+def net():
+    torch.set_num_threads(1)
+    n = O.OraclePPO()
+    n.load_weights(make_weights(0))
+    return n
+
+
+def test_param_order_and_size(net):
+    names = [k for k, _ in net.named_parameters()]
+    assert names == [n for n, _, _ in param_specs()]
+    assert flatten(make_weights(0)).size == 3371847
+
+
+def test_f5_lut(golden):
+    assert np.array_equal(O.u8_lut(), golden("f5_u8_lut")["lut"])
+
+
+def test_f1_forward(net, golden):
+    g = golden("f1_forward")
+    x = O.frames_to_f32(g["frames"])
+    with torch.no_grad():
+        probs, p_hat, logits, v = net(x)
+        logp = O.categorical_log_prob(logits, torch.from_numpy(g["actions"]))
+        ent = O.categorical_entropy(p_hat, logits)
+        h_a = net.actor.pre(x)
+    # same torch ops, same thread count -> bit-exact
+    assert np.array_equal(probs.numpy(), g["probs"])
+    assert np.array_equal(p_hat.numpy(), g["p_hat"])
+    assert np.array_equal(logits.numpy(), g["logits"])
+    assert np.array_equal(logp.numpy(), g["logp"])
+    assert np.array_equal(v.numpy()[:, 0], g["value"])
+    assert np.array_equal(ent.numpy(), g["entropy"])
+    assert np.array_equal(h_a.numpy()[:, :16], g["h_actor"])
+
+
+def test_f2_gae_bit_exact(golden):
+    g = golden("f2_gae")
+    T = 256
+    adv1, ret1 = O.gae(g["values"][:T + 1], g["rewards"][:T + 1], g["dones"][:T + 1])
+    assert np.array_equal(adv1, g["adv1"]) and np.array_equal(ret1, g["ret1"])
+    # carry-over of the last stored step into the next rollout (agent.py:289-291)
+    adv2, ret2 = O.gae(g["values"][T:], g["rewards"][T:], g["dones"][T:])
+    assert np.array_equal(adv2, g["adv2"]) and np.array_equal(ret2, g["ret2"])
+
+
+def _batch(golden):
+    g3 = golden("f3_loss")
+    x = O.frames_to_f32(g3["frames"])
+    t = lambda k: torch.from_numpy(g3[k])
+    return g3, x, t("actions"), t("old_logps"), t("advs"), t("rets")
+
+
+def test_f3_losses_and_grads(net, golden):
+    g, x, a, ol, adv, ret = _batch(golden)
+    net.load_weights(make_weights(0))
+    net.zero_grad()
+    total, al, vl, ent = O.ppo_losses(net, x, a, ol, adv, ret)
+    assert np.float32(al.item()) == g["actor_loss"]
+    assert np.float32(vl.item()) == g["v_loss"]
+    assert np.float32(ent.item()) == g["ent"]
+    assert np.float32(total.item()) == g["total"]
+    al.backward()
+    vl.backward()
+    sd = dict(net.named_parameters())
+    assert np.array_equal(sd["actor.actor_linear.weight"].grad.numpy(), g["grad_actor_linear_w"])
+    assert np.array_equal(sd["critic.critic_linear.bias"].grad.numpy(), g["grad_critic_linear_b"])
+    for k, p in sd.items():
+        np.testing.assert_allclose(p.grad.numpy().reshape(-1)[:64], g["ghead/" + k], rtol=0, atol=0)
+
+
+def test_f4_learn_sequence(golden):
+    g, x, a, ol, adv, ret = _batch(golden)
+    g4 = golden("f4_learn")
+    torch.set_num_threads(1)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    opt = net.make_optims()
+    for it, (ld, ut, last) in enumerate(O.learn(net, opt, x, a, ol, adv, ret), 1):
+        row = g4["losses"][it - 1]
+        assert ut == it and last
+        got = [ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]]
+        np.testing.assert_allclose(got, row, rtol=1e-6, atol=1e-7)
+        if it in (1, 10):
+            for k, p in net.named_parameters():
+                np.testing.assert_allclose(p.detach().numpy().reshape(-1)[:8], g4["it%d/head/%s" % (it, k)],
+                                           rtol=1e-6, atol=2e-8)
+                arr = p.detach().numpy().reshape(-1)
+                np.testing.assert_allclose(arr[::max(1, arr.size // 257)][:257], g4["it%d/stride/%s" % (it, k)],
+                                           rtol=1e-6, atol=2e-8)
+    assert it == 10
+
+
+def test_f6_episode_returns(golden):
+    g = golden("f6_returns")
+    trace, rsum = O.episode_returns(g["rewards"], g["dones"])
+    assert np.array_equal(trace, g["trace"]) and np.array_equal(rsum, g["final_sum"])
+
+
+def test_inverse_cdf_sampler_contract():
+    p = np.array([[0.1, 0.2, 0.3, 0.4], [0.25, 0.25, 0.25, 0.25]], np.float32)
+    assert list(O.inverse_cdf_sample(p, np.array([0.05, 0.99], np.float32))) == [0, 3]
+    assert list(O.inverse_cdf_sample(p, np.array([0.1, 0.5], np.float32))) == [1, 2]
