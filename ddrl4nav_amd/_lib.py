@@ -1,0 +1,102 @@
+"""ctypes binding of libddrl_hip.so (include/ddrl.h).  There is NO fallback: if the HIP
+library is missing or a call fails this module raises."""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_float, c_int32, c_int64, c_uint64,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libddrl_hip.so")
+
+STATS_FLOATS = 8
+
+
+class DdrlError(RuntimeError):
+    pass
+
+
+class Config(Structure):
+    """ddrl_config (include/ddrl.h) == the ConfigNN contract (reference config/config_nn.py)."""
+    _fields_ = [
+        ("n_actions", c_int32), ("in_channels", c_int32), ("max_batch", c_int32), ("share_cnn_net", c_int32),
+        ("clip_grad", c_int32), ("clip_grad_norm", c_float), ("actor_lr", c_float), ("critic_lr", c_float),
+        ("adam_beta1", c_float), ("adam_beta2", c_float), ("adam_eps", c_float), ("ppo_clip", c_float),
+        ("dual_clip", c_float), ("v_loss_theta", c_float), ("ent_loss_theta", c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ddrl.h declares
+SIGNATURES = {
+    "ddrl_abi_version": (c_int32, []),
+    "ddrl_status_string": (c_char_p, [c_int32]),
+    "ddrl_config_default": (c_int32, [POINTER(Config)]),
+    "ddrl_param_count": (c_int32, [POINTER(Config), POINTER(c_int64), POINTER(c_int64)]),
+    "ddrl_workspace_bytes": (c_int32, [POINTER(Config), POINTER(c_int64)]),
+    "ddrl_ctx_create": (c_int32, [POINTER(Config), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  POINTER(c_void_p)]),
+    "ddrl_ctx_destroy": (c_int32, [c_void_p]),
+    "ddrl_params_changed": (c_int32, [c_void_p]),
+    "ddrl_get_step": (c_int32, [c_void_p, POINTER(c_int64)]),
+    "ddrl_set_step": (c_int32, [c_void_p, c_int64]),
+    "ddrl_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
+    "ddrl_categorical_stats": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_last_features": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ddrl_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p,
+                           c_void_p]),
+    "ddrl_ppo_iter": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                c_void_p]),
+    "ddrl_clip_adam_step": (c_int32, [c_void_p, c_void_p]),
+    "ddrl_u8_table": (c_int32, [c_void_p, c_void_p]),
+    "ddrl_debug_buffer": (c_int32, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64)]),
+    "ddrl_ring_create": (c_int32, [c_int64, c_int32, POINTER(c_void_p)]),
+    "ddrl_ring_destroy": (c_int32, [c_void_p]),
+    "ddrl_ring_acquire": (c_int32, [c_void_p, POINTER(c_void_p), c_int32]),
+    "ddrl_ring_commit": (c_int32, [c_void_p]),
+    "ddrl_ring_pop_to_device": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32]),
+    "ddrl_ring_pending": (c_int32, [c_void_p, POINTER(c_int32)]),
+    "ddrl_timer_create": (c_int32, [POINTER(c_void_p)]),
+    "ddrl_timer_destroy": (c_int32, [c_void_p]),
+    "ddrl_timer_start": (c_int32, [c_void_p, c_void_p]),
+    "ddrl_timer_stop": (c_int32, [c_void_p, c_void_p]),
+    "ddrl_timer_elapsed_ms": (c_int32, [c_void_p, POINTER(c_float)]),
+    "ddrl_profile_enable": (c_int32, [c_void_p, c_int32]),
+    "ddrl_profile_read": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises DdrlError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DdrlError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C ddrl4nav_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ddrl_abi_version() != 1:
+        raise DdrlError("libddrl_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().ddrl_status_string(status)
+        raise DdrlError("libddrl_hip: %s (status %d)" % (msg.decode() if msg else "?", status))
+
+
+def default_config(**overrides):
+    cfg = Config()
+    check(load().ddrl_config_default(byref(cfg)))
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg

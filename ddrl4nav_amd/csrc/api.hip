@@ -1,0 +1,511 @@
+// extern "C" boundary of libddrl_hip.so (see include/ddrl.h).  Host-side only: argument
+// validation, workspace carving, kernel sequencing, the pinned-host ring and HIP-event timers.
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace ddrl;
+
+struct ProfEntry {
+  std::string name;
+  hipEvent_t a, b;
+};
+
+struct ddrl_ctx {
+  ddrl_config cfg;
+  ParamLayout L;
+  Workspace ws;
+  Splits splits;
+  float *params, *grads, *m, *v;
+  int64_t step;
+  bool dirty;
+  int last_n;
+  bool profile;
+  std::vector<ProfEntry> prof_pending;
+  std::vector<std::string> prof_names;
+  std::vector<double> prof_ms;
+  std::vector<int> prof_calls;
+};
+
+#define HIP_TRY(expr)                        \
+  do {                                       \
+    hipError_t _e = (expr);                  \
+    if (_e != hipSuccess) return DDRL_ERR_HIP; \
+  } while (0)
+
+static int32_t check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DDRL_OK : DDRL_ERR_HIP;
+}
+
+namespace {
+struct ProfScope {
+  ddrl_ctx* c;
+  hipStream_t st;
+  ProfEntry e;
+  bool on;
+  ProfScope(ddrl_ctx* ctx, const char* name, hipStream_t s) : c(ctx), st(s), on(ctx->profile) {
+    if (!on) return;
+    e.name = name;
+    hipEventCreate(&e.a);
+    hipEventCreate(&e.b);
+    hipEventRecord(e.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(e.b, st);
+    c->prof_pending.push_back(e);
+  }
+};
+}  // namespace
+
+extern "C" {
+
+int32_t ddrl_abi_version(void) { return DDRL_ABI_VERSION; }
+
+const char* ddrl_status_string(int32_t s) {
+  switch (s) {
+    case DDRL_OK: return "ok";
+    case DDRL_ERR_INVALID_ARG: return "invalid argument";
+    case DDRL_ERR_UNSUPPORTED: return "unsupported configuration";
+    case DDRL_ERR_WORKSPACE: return "workspace too small";
+    case DDRL_ERR_HIP: return "HIP runtime error";
+    case DDRL_ERR_NO_DEVICE: return "no HIP device";
+    case DDRL_ERR_TIMEOUT: return "timeout";
+    default: return "unknown status";
+  }
+}
+
+int32_t ddrl_config_default(ddrl_config* c) {
+  if (!c) return DDRL_ERR_INVALID_ARG;
+  c->n_actions = 6;
+  c->in_channels = 4;
+  c->max_batch = 1024;
+  c->share_cnn_net = 0;
+  c->clip_grad = 1;
+  c->clip_grad_norm = 0.5f;
+  c->actor_lr = 5e-5f;
+  c->critic_lr = 1e-3f;
+  c->adam_beta1 = 0.9f;
+  c->adam_beta2 = 0.999f;
+  c->adam_eps = 1e-8f;
+  c->ppo_clip = 0.2f;
+  c->dual_clip = 3.0f;
+  c->v_loss_theta = 1.0f;
+  c->ent_loss_theta = 0.05f;
+  return DDRL_OK;
+}
+
+static int32_t validate(const ddrl_config* c) {
+  if (!c) return DDRL_ERR_INVALID_ARG;
+  if (c->max_batch < 1) return DDRL_ERR_INVALID_ARG;
+  if (c->n_actions < 2 || c->n_actions > 8) return DDRL_ERR_UNSUPPORTED;  // heads kernels: A <= 8
+  if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // int_frame_stack = 4
+  if (c->share_cnn_net != 0) return DDRL_ERR_UNSUPPORTED;                 // SHARE_CNN_NET=False only
+  // 32-bit element indexing inside one encoder's activation tensor
+  if ((int64_t)c->max_batch * 32 * 400 >= (int64_t)1 << 31) return DDRL_ERR_UNSUPPORTED;
+  return DDRL_OK;
+}
+
+int32_t ddrl_param_count(const ddrl_config* c, int64_t* n_params, int64_t* n_actor) {
+  int32_t s = validate(c);
+  if (s != DDRL_OK) return s;
+  ParamLayout L = make_layout(c->n_actions, c->in_channels);
+  if (n_params) *n_params = L.n_params;
+  if (n_actor) *n_actor = L.n_actor;
+  return DDRL_OK;
+}
+
+int32_t ddrl_workspace_bytes(const ddrl_config* c, int64_t* bytes) {
+  int32_t s = validate(c);
+  if (s != DDRL_OK) return s;
+  if (!bytes) return DDRL_ERR_INVALID_ARG;
+  Workspace w;
+  *bytes = carve(w, *c, nullptr);
+  return DDRL_OK;
+}
+
+int32_t ddrl_ctx_create(const ddrl_config* c, float* params, float* grads, float* m, float* v, void* workspace,
+                        int64_t workspace_bytes, ddrl_ctx** out) {
+  int32_t s = validate(c);
+  if (s != DDRL_OK) return s;
+  if (!params || !grads || !m || !v || !workspace || !out) return DDRL_ERR_INVALID_ARG;
+  if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) return DDRL_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DDRL_ERR_NO_DEVICE;
+  ddrl_ctx* ctx = new (std::nothrow) ddrl_ctx();
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  ctx->cfg = *c;
+  ctx->L = make_layout(c->n_actions, c->in_channels);
+  const int64_t need = carve(ctx->ws, *c, workspace);
+  if (need > workspace_bytes) {
+    delete ctx;
+    return DDRL_ERR_WORKSPACE;
+  }
+  ctx->splits = choose_splits(c->max_batch);
+  ctx->params = params;
+  ctx->grads = grads;
+  ctx->m = m;
+  ctx->v = v;
+  ctx->step = 0;
+  ctx->dirty = true;
+  ctx->last_n = 0;
+  ctx->profile = false;
+  *out = ctx;
+  return DDRL_OK;
+}
+
+int32_t ddrl_ctx_destroy(ddrl_ctx* ctx) {
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  for (auto& e : ctx->prof_pending) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  delete ctx;
+  return DDRL_OK;
+}
+
+int32_t ddrl_params_changed(ddrl_ctx* ctx) {
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  ctx->dirty = true;
+  return DDRL_OK;
+}
+
+int32_t ddrl_get_step(const ddrl_ctx* ctx, int64_t* step) {
+  if (!ctx || !step) return DDRL_ERR_INVALID_ARG;
+  *step = ctx->step;
+  return DDRL_OK;
+}
+int32_t ddrl_set_step(ddrl_ctx* ctx, int64_t step) {
+  if (!ctx || step < 0) return DDRL_ERR_INVALID_ARG;
+  ctx->step = step;
+  return DDRL_OK;
+}
+
+static void ensure_packed(ddrl_ctx* ctx, hipStream_t st) {
+  if (!ctx->dirty) return;
+  ProfScope ps(ctx, "pack_weights", st);
+  launch_pack_weights(ctx->ws, ctx->L, ctx->params, st);
+  ctx->dirty = false;
+}
+
+int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const float* act_in, uint64_t seed,
+                     uint64_t stream_id, float* probs, float* value, float* action_out, float* logp_out, void* stream) {
+  if (!ctx || !frames || !value) return DDRL_ERR_INVALID_ARG;
+  if (n < 1 || n > ctx->cfg.max_batch) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  ensure_packed(ctx, st);
+  EncCall ec{&ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  {
+    ProfScope ps(ctx, "encoder_forward", st);
+    launch_encoder_forward(ec, st);
+  }
+  HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, n, ctx->cfg.max_batch};
+  {
+    ProfScope ps(ctx, "heads_act", st);
+    launch_heads_act(hc, act_in, seed, stream_id, probs, value, action_out, logp_out, st);
+  }
+  ctx->last_n = n;
+  return check_launch();
+}
+
+int32_t ddrl_categorical_stats(const float* probs, int32_t n, int32_t A, float* p_hat, float* logits, float* entropy,
+                               void* stream) {
+  if (!probs || n < 1 || A < 1) return DDRL_ERR_INVALID_ARG;
+  launch_categorical_stats(probs, n, A, p_hat, logits, entropy, (hipStream_t)stream);
+  return check_launch();
+}
+
+int32_t ddrl_last_features(ddrl_ctx* ctx, int32_t n, float* h_actor, float* h_critic, void* stream) {
+  if (!ctx || n < 1 || n > ctx->last_n) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bytes = (size_t)n * FEAT * sizeof(float);
+  if (h_actor) HIP_TRY(hipMemcpyAsync(h_actor, ctx->ws.h, bytes, hipMemcpyDeviceToDevice, st));
+  if (h_critic)
+    HIP_TRY(hipMemcpyAsync(h_critic, ctx->ws.h + (int64_t)ctx->cfg.max_batch * FEAT, bytes, hipMemcpyDeviceToDevice, st));
+  return DDRL_OK;
+}
+
+int32_t ddrl_gae(const float* values, const float* rewards, const uint8_t* dones, int32_t T, int32_t N, float gamma,
+                 float landa, float* adv, float* ret, void* stream) {
+  if (!values || !rewards || !dones || !adv || !ret || T < 0 || N < 1) return DDRL_ERR_INVALID_ARG;
+  if (T == 0) return DDRL_OK;  // len(experiences) <= 1 -> nothing to do (agent.py:125-126)
+  launch_gae(values, rewards, dones, T, N, gamma, landa, adv, ret, (hipStream_t)stream);
+  return check_launch();
+}
+
+int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions, const float* old_logps,
+                      const float* advs, const float* rets, int32_t B, int64_t B_global, void* stream) {
+  if (!ctx || !frames || !actions || !old_logps || !advs || !rets) return DDRL_ERR_INVALID_ARG;
+  if (B < 1 || B > ctx->cfg.max_batch || B_global < B) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  ensure_packed(ctx, st);
+  EncCall ec{&ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
+  {
+    ProfScope ps(ctx, "encoder_forward", st);
+    launch_encoder_forward(ec, st);
+  }
+  HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, B, ctx->cfg.max_batch};
+  {
+    ProfScope ps(ctx, "heads_loss", st);
+    launch_heads_loss(hc, actions, old_logps, advs, rets, (float)(1.0 / (double)B_global), ctx->grads, st);
+  }
+  {
+    ProfScope ps(ctx, "encoder_backward", st);
+    launch_encoder_backward(ec, ctx->grads, st);
+  }
+  ctx->last_n = B;
+  return check_launch();
+}
+
+int32_t ddrl_clip_adam_step(ddrl_ctx* ctx, void* stream) {
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  ctx->step += 1;
+  {
+    ProfScope ps(ctx, "clip_adam", st);
+    launch_clip_adam(ctx->cfg, ctx->L, ctx->ws, ctx->params, ctx->grads, ctx->m, ctx->v, ctx->step, st);
+  }
+  ctx->dirty = true;
+  return check_launch();
+}
+
+int32_t ddrl_u8_table(float* out256, void* stream) {
+  if (!out256) return DDRL_ERR_INVALID_ARG;
+  launch_fill_lut(out256, (hipStream_t)stream);
+  return check_launch();
+}
+
+// Diagnostic views into the workspace (tests): which = 0 a1,1 a2,2 a3,3 h,4 dz1,5 dz2,6 dz3,7 dh,
+// 8 dlogits, 9 dvalue.  Returns the device pointer and the encoder stride in floats.
+int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* enc_stride) {
+  if (!ctx || !ptr || !enc_stride) return DDRL_ERR_INVALID_ARG;
+  const int64_t MB = ctx->cfg.max_batch;
+  const Workspace& w = ctx->ws;
+  switch (which) {
+    case 0: *ptr = w.a1; *enc_stride = MB * 32 * 400; break;
+    case 1: *ptr = w.a2; *enc_stride = MB * 64 * 81; break;
+    case 2: *ptr = w.a3; *enc_stride = MB * FLAT; break;
+    case 3: *ptr = w.h; *enc_stride = MB * FEAT; break;
+    case 4: *ptr = w.dz1; *enc_stride = MB * 32 * 400; break;
+    case 5: *ptr = w.dz2; *enc_stride = MB * 64 * 81; break;
+    case 6: *ptr = w.dz3; *enc_stride = MB * FLAT; break;
+    case 7: *ptr = w.dh; *enc_stride = MB * FEAT; break;
+    case 8: *ptr = w.dlogits; *enc_stride = 0; break;
+    case 9: *ptr = w.dvalue; *enc_stride = 0; break;
+    default: return DDRL_ERR_INVALID_ARG;
+  }
+  return DDRL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pinned-host ring
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct ddrl_ring {
+  int64_t slot_bytes;
+  int32_t n_slots;
+  char* base;
+  // slot states: 0 free, 1 being written, 2 committed, 3 copy in flight
+  std::vector<int> state;
+  std::vector<hipEvent_t> ev;
+  int64_t head;    // next slot the producer acquires
+  int64_t commit;  // next slot to be committed
+  int64_t tail;    // next slot the consumer pops
+  int64_t reclaim; // oldest slot whose copy may still be in flight
+  std::mutex mu;
+  std::condition_variable cv;
+};
+
+static void ring_reclaim_locked(ddrl_ring* r) {
+  while (r->reclaim < r->tail) {
+    const int s = (int)(r->reclaim % r->n_slots);
+    if (r->state[s] != 3) break;
+    if (hipEventQuery(r->ev[s]) != hipSuccess) break;
+    r->state[s] = 0;
+    r->reclaim++;
+  }
+}
+
+extern "C" {
+
+int32_t ddrl_ring_create(int64_t slot_bytes, int32_t n_slots, ddrl_ring** out) {
+  if (slot_bytes < 1 || n_slots < 2 || !out) return DDRL_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DDRL_ERR_NO_DEVICE;
+  ddrl_ring* r = new (std::nothrow) ddrl_ring();
+  if (!r) return DDRL_ERR_INVALID_ARG;
+  r->slot_bytes = (slot_bytes + 255) / 256 * 256;
+  r->n_slots = n_slots;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)r->slot_bytes * n_slots, hipHostMallocDefault) != hipSuccess) {
+    delete r;
+    return DDRL_ERR_HIP;
+  }
+  r->base = (char*)p;
+  r->state.assign(n_slots, 0);
+  r->ev.resize(n_slots);
+  for (auto& e : r->ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  r->head = r->commit = r->tail = r->reclaim = 0;
+  *out = r;
+  return DDRL_OK;
+}
+
+int32_t ddrl_ring_destroy(ddrl_ring* r) {
+  if (!r) return DDRL_ERR_INVALID_ARG;
+  for (auto& e : r->ev) {
+    hipEventSynchronize(e);
+    hipEventDestroy(e);
+  }
+  hipHostFree(r->base);
+  delete r;
+  return DDRL_OK;
+}
+
+int32_t ddrl_ring_acquire(ddrl_ring* r, void** slot_host, int32_t timeout_ms) {
+  if (!r || !slot_host) return DDRL_ERR_INVALID_ARG;
+  std::unique_lock<std::mutex> lk(r->mu);
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+  for (;;) {
+    ring_reclaim_locked(r);
+    const int s = (int)(r->head % r->n_slots);
+    if (r->head - r->reclaim < r->n_slots && r->state[s] == 0) {
+      r->state[s] = 1;
+      r->head++;
+      *slot_host = r->base + (int64_t)s * r->slot_bytes;
+      return DDRL_OK;
+    }
+    if (std::chrono::steady_clock::now() >= deadline) return DDRL_ERR_TIMEOUT;
+    r->cv.wait_for(lk, std::chrono::microseconds(200));
+  }
+}
+
+int32_t ddrl_ring_commit(ddrl_ring* r) {
+  if (!r) return DDRL_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(r->mu);
+  if (r->commit >= r->head) return DDRL_ERR_INVALID_ARG;
+  const int s = (int)(r->commit % r->n_slots);
+  if (r->state[s] != 1) return DDRL_ERR_INVALID_ARG;
+  r->state[s] = 2;
+  r->commit++;
+  r->cv.notify_all();
+  return DDRL_OK;
+}
+
+int32_t ddrl_ring_pop_to_device(ddrl_ring* r, void* dst, int64_t bytes, void* stream, int32_t timeout_ms) {
+  if (!r || !dst || bytes < 1 || bytes > r->slot_bytes) return DDRL_ERR_INVALID_ARG;
+  std::unique_lock<std::mutex> lk(r->mu);
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+  while (r->tail >= r->commit) {
+    if (std::chrono::steady_clock::now() >= deadline) return DDRL_ERR_TIMEOUT;
+    r->cv.wait_for(lk, std::chrono::microseconds(200));
+  }
+  const int s = (int)(r->tail % r->n_slots);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(dst, r->base + (int64_t)s * r->slot_bytes, (size_t)bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+    return DDRL_ERR_HIP;
+  if (hipEventRecord(r->ev[s], st) != hipSuccess) return DDRL_ERR_HIP;
+  r->state[s] = 3;
+  r->tail++;
+  r->cv.notify_all();
+  return DDRL_OK;
+}
+
+int32_t ddrl_ring_pending(ddrl_ring* r, int32_t* n) {
+  if (!r || !n) return DDRL_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(r->mu);
+  *n = (int32_t)(r->commit - r->tail);
+  return DDRL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// timers / profile
+// ------------------------------------------------------------------------------------------
+struct ddrl_timer {
+  hipEvent_t a, b;
+};
+
+int32_t ddrl_timer_create(void** t) {
+  if (!t) return DDRL_ERR_INVALID_ARG;
+  ddrl_timer* x = new (std::nothrow) ddrl_timer();
+  if (!x) return DDRL_ERR_INVALID_ARG;
+  if (hipEventCreate(&x->a) != hipSuccess || hipEventCreate(&x->b) != hipSuccess) {
+    delete x;
+    return DDRL_ERR_HIP;
+  }
+  *t = x;
+  return DDRL_OK;
+}
+int32_t ddrl_timer_destroy(void* t) {
+  if (!t) return DDRL_ERR_INVALID_ARG;
+  ddrl_timer* x = (ddrl_timer*)t;
+  hipEventDestroy(x->a);
+  hipEventDestroy(x->b);
+  delete x;
+  return DDRL_OK;
+}
+int32_t ddrl_timer_start(void* t, void* stream) {
+  if (!t) return DDRL_ERR_INVALID_ARG;
+  HIP_TRY(hipEventRecord(((ddrl_timer*)t)->a, (hipStream_t)stream));
+  return DDRL_OK;
+}
+int32_t ddrl_timer_stop(void* t, void* stream) {
+  if (!t) return DDRL_ERR_INVALID_ARG;
+  HIP_TRY(hipEventRecord(((ddrl_timer*)t)->b, (hipStream_t)stream));
+  return DDRL_OK;
+}
+int32_t ddrl_timer_elapsed_ms(void* t, float* ms) {
+  if (!t || !ms) return DDRL_ERR_INVALID_ARG;
+  ddrl_timer* x = (ddrl_timer*)t;
+  HIP_TRY(hipEventSynchronize(x->b));
+  HIP_TRY(hipEventElapsedTime(ms, x->a, x->b));
+  return DDRL_OK;
+}
+
+int32_t ddrl_profile_enable(ddrl_ctx* ctx, int32_t on) {
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  ctx->profile = on != 0;
+  return DDRL_OK;
+}
+
+int32_t ddrl_profile_read(ddrl_ctx* ctx, char (*names)[48], float* ms, int32_t* calls, int32_t cap, int32_t* n) {
+  if (!ctx || !n) return DDRL_ERR_INVALID_ARG;
+  for (auto& e : ctx->prof_pending) {
+    hipEventSynchronize(e.b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, e.a, e.b);
+    size_t i = 0;
+    for (; i < ctx->prof_names.size(); ++i)
+      if (ctx->prof_names[i] == e.name) break;
+    if (i == ctx->prof_names.size()) {
+      ctx->prof_names.push_back(e.name);
+      ctx->prof_ms.push_back(0.0);
+      ctx->prof_calls.push_back(0);
+    }
+    ctx->prof_ms[i] += t;
+    ctx->prof_calls[i] += 1;
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  ctx->prof_pending.clear();
+  const int32_t cnt = (int32_t)ctx->prof_names.size();
+  *n = cnt;
+  for (int32_t i = 0; i < cnt && i < cap; ++i) {
+    if (names) {
+      std::strncpy(names[i], ctx->prof_names[i].c_str(), 47);
+      names[i][47] = 0;
+    }
+    if (ms) ms[i] = (float)ctx->prof_ms[i];
+    if (calls) calls[i] = ctx->prof_calls[i];
+  }
+  return DDRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// Shared definitions for the DDRL4NAV hot-path kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ddrl.h"
+
+namespace ddrl {
+
+// ---- AtariPreNet geometry (reference USTC_lab/nn/atari_encoder.py:16-21) -------------------
+constexpr int IMG = 84;
+constexpr int FEAT = 512;   // AC_INPUT_DIM (config_nn.py:23)
+constexpr int FLAT = 3136;  // 64*7*7
+struct ConvGeom {
+  int cin, hin, oc, ks, stride, ow, pix, kred;
+};
+// conv1: C x84x84 -> 32x20x20, k8 s4 ; conv2: 32x20x20 -> 64x9x9, k4 s2 ; conv3: 64x9x9 -> 64x7x7, k3 s1
+constexpr int C1_OC = 32, C1_KS = 8, C1_S = 4, C1_OW = 20, C1_P = 400;
+constexpr int C2_IC = 32, C2_OC = 64, C2_KS = 4, C2_S = 2, C2_IW = 20, C2_OW = 9, C2_P = 81, C2_K = 512;
+constexpr int C3_IC = 64, C3_OC = 64, C3_KS = 3, C3_S = 1, C3_IW = 9, C3_OW = 7, C3_P = 49, C3_K = 576;
+constexpr float LEAKY = 0.01f;  // F.leaky_relu default negative_slope
+
+// ---- flat parameter arena (named_parameters() order, reference nn/base.py:60-66) ----------
+struct EncLayout {  // offsets relative to the encoder's base
+  int64_t c1w, c1b, c2w, c2b, c3w, c3b, lw, lb, size;
+};
+struct ParamLayout {
+  int A, C;
+  EncLayout enc;
+  int64_t enc_base[2];  // [0]=actor.pre, [1]=critic.pre
+  int64_t actor_w, actor_b, critic_w, critic_b;
+  int64_t n_params, n_actor;
+};
+
+inline ParamLayout make_layout(int A, int C) {
+  ParamLayout L;
+  L.A = A;
+  L.C = C;
+  int64_t o = 0;
+  L.enc.c1w = o; o += (int64_t)C1_OC * C * 64;
+  L.enc.c1b = o; o += C1_OC;
+  L.enc.c2w = o; o += (int64_t)C2_OC * C2_K;
+  L.enc.c2b = o; o += C2_OC;
+  L.enc.c3w = o; o += (int64_t)C3_OC * C3_K;
+  L.enc.c3b = o; o += C3_OC;
+  L.enc.lw = o; o += (int64_t)FEAT * FLAT;
+  L.enc.lb = o; o += FEAT;
+  L.enc.size = o;
+  int64_t p = 0;
+  L.enc_base[0] = p; p += L.enc.size;
+  L.actor_w = p; p += (int64_t)A * FEAT;
+  L.actor_b = p; p += A;
+  L.n_actor = p;
+  L.critic_w = p; p += FEAT;
+  L.critic_b = p; p += 1;
+  L.enc_base[1] = p; p += L.enc.size;
+  L.n_params = p;
+  return L;
+}
+
+// ---- device workspace carved out of the caller's buffer ------------------------------------
+struct Workspace {
+  // derived weight layouts, [e] major
+  float* wt1;  // [2][K1][32]       conv1 fwd A operand (k-major)
+  float* wt2;  // [2][512][64]
+  float* wt3;  // [2][576][64]
+  float* wd3;  // [2][576 (oc,ky,kx)][64 ic]    conv3 dgrad A operand
+  float* wd2;  // [2][4 cls][256 (oc,u,v)][32 ic] conv2 dgrad A operand per parity class
+  float* wlt;  // [2][3136][512]    FC fwd B operand
+  // activations (post leaky-relu) and their gradients, [e][max_batch][...]
+  float *a1, *a2, *a3, *h;
+  float *dz1, *dz2, *dz3, *dh;
+  float* dlogits;  // [max_batch][A] (diagnostics / tests)
+  float* dvalue;   // [max_batch]
+  float* wpart;    // split-K partial slabs for the weight gradients
+  int64_t wpart_floats;
+  float* hpart;    // heads partials [HEAD_WG][HPART]
+  float* bpart;    // bias-gradient partials [2][512][32]
+  double* npart;   // grad-norm partials [NORM_WG]
+  float* lut;      // [256] float32(u8/255.0)
+  int64_t total_bytes;
+};
+
+constexpr int HEAD_WG = 512;   // workgroups of the heads/loss kernel (fixed -> deterministic)
+constexpr int NORM_WG = 1024;  // workgroups of the grad-norm kernel
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// split counts for the weight-gradient GEMMs (fixed per context -> deterministic sums)
+struct Splits {
+  int c1, c2, c3, fc;
+};
+inline Splits choose_splits(int max_batch) {
+  auto pick = [&](int64_t red, int tiles, int target_wg) {
+    int64_t kblocks = (red + 31) / 32;
+    int s = (target_wg + tiles - 1) / tiles;
+    if (s > kblocks) s = (int)kblocks;
+    if (s < 1) s = 1;
+    return s;
+  };
+  Splits s;
+  s.c1 = pick((int64_t)max_batch * C1_P, 2 * 2, 1024);   // cols 256/128 = 2 tiles x 2 enc
+  s.c2 = pick((int64_t)max_batch * C2_P, 4 * 2, 1024);   // 512/128 = 4
+  s.c3 = pick((int64_t)max_batch * C3_P, 5 * 2, 1024);   // 576/128 -> 5
+  s.fc = pick((int64_t)max_batch, 4 * 25 * 2, 1024);     // rows 512/128 x cols 3136/128
+  return s;
+}
+
+inline int64_t hpart_stride(int A) { return align_up((int64_t)(A + 1) * FEAT + A + 1 + 4, 64); }
+
+inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
+  const int64_t MB = c.max_batch, C = c.in_channels, A = c.n_actions;
+  int64_t off = 0;
+  auto take = [&](int64_t floats) -> float* {
+    float* p = base ? (float*)((char*)base + off) : nullptr;
+    off += align_up(floats * 4, 256);
+    return p;
+  };
+  w.wt1 = take(2 * C * 64 * 32);
+  w.wt2 = take(2 * 512 * 64);
+  w.wt3 = take(2 * 576 * 64);
+  w.wd3 = take(2 * 576 * 64);
+  w.wd2 = take(2 * 4 * 256 * 32);
+  w.wlt = take(2 * (int64_t)FLAT * FEAT);
+  w.a1 = take(2 * MB * 32 * 400);
+  w.a2 = take(2 * MB * 64 * 81);
+  w.a3 = take(2 * MB * FLAT);
+  w.h = take(2 * MB * FEAT);
+  w.dz1 = take(2 * MB * 32 * 400);
+  w.dz2 = take(2 * MB * 64 * 81);
+  w.dz3 = take(2 * MB * FLAT);
+  w.dh = take(2 * MB * FEAT);
+  w.dlogits = take(MB * A);
+  w.dvalue = take(MB);
+  Splits s = choose_splits(c.max_batch);
+  int64_t p1 = (int64_t)s.c1 * 2 * (32 * C * 64);
+  int64_t p2 = (int64_t)s.c2 * 2 * (64 * 512);
+  int64_t p3 = (int64_t)s.c3 * 2 * (64 * 576);
+  int64_t pf = (int64_t)s.fc * 2 * ((int64_t)FEAT * FLAT);
+  int64_t pm = p1;
+  if (p2 > pm) pm = p2;
+  if (p3 > pm) pm = p3;
+  if (pf > pm) pm = pf;
+  w.wpart_floats = pm;
+  w.wpart = take(pm);
+  w.hpart = take((int64_t)HEAD_WG * hpart_stride(A));
+  w.bpart = take(2 * 512 * 32);
+  w.npart = (double*)take(NORM_WG * 2);
+  w.lut = take(256);
+  w.total_bytes = off;
+  return off;
+}
+
+// counter-based uniform in [0,1): identical to ddrl4nav_amd/utils/recipe.py:hash_uniform
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline float hash_uniform(uint64_t seed, uint64_t stream, uint64_t idx) {
+  uint64_t base = splitmix64(seed ^ (stream << 40));
+  uint64_t z = splitmix64(base + idx);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+}  // namespace ddrl

@@ -1,0 +1,384 @@
+// Actor / critic heads, Categorical bookkeeping, PPO dual-clip loss and its gradient, fused with
+// the backward of the two head layers.  One wavefront per sample: the 512-wide dot products
+// are 8 elements per lane + a wave64 xor-shuffle butterfly; the A (<= 8) logits then live
+// redundantly in every lane so softmax / loss / gradient need no further communication.
+//
+// Reference arithmetic replaced:
+//   CategoricalActor._distribution / log_prob  USTC_lab/nn/actor.py:90-101
+//   Critic.forward                             USTC_lab/nn/critic.py:14-21
+//   ForwardThread.run sampling + log_prob      USTC_lab/server/forward.py:132-138
+//   PPO.learn loss block + autograd            USTC_lab/nn/ppo.py:82-108,122-123
+#include "kernels.h"
+
+namespace ddrl {
+
+constexpr int MAXA = 8;
+constexpr float CAT_EPS = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct HeadRegs {
+  float wa[MAXA][8];
+  float wc[8];
+  float ba[MAXA];
+  float bc;
+};
+
+__device__ __forceinline__ void load_head_weights(HeadRegs& R, const float* params, const ParamLayout& L, int lane) {
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) {
+    if (j < L.A) {
+      const float4* src = (const float4*)(params + L.actor_w + (int64_t)j * FEAT + lane * 8);
+      const float4 x = src[0], y = src[1];
+      R.wa[j][0] = x.x; R.wa[j][1] = x.y; R.wa[j][2] = x.z; R.wa[j][3] = x.w;
+      R.wa[j][4] = y.x; R.wa[j][5] = y.y; R.wa[j][6] = y.z; R.wa[j][7] = y.w;
+      R.ba[j] = params[L.actor_b + j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) R.wa[j][i] = 0.0f;
+      R.ba[j] = 0.0f;
+    }
+  }
+  // the flat arena is only 4-byte aligned at critic_w in general -> scalar loads
+#pragma unroll
+  for (int i = 0; i < 8; ++i) R.wc[i] = params[L.critic_w + lane * 8 + i];
+  R.bc = params[L.critic_b];
+}
+
+__device__ __forceinline__ void load8(const float* p, float* o) {
+  const float4 x = ((const float4*)p)[0], y = ((const float4*)p)[1];
+  o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
+  o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
+}
+__device__ __forceinline__ void store8(float* p, const float* o) {
+  ((float4*)p)[0] = make_float4(o[0], o[1], o[2], o[3]);
+  ((float4*)p)[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+struct Dist {
+  float p[MAXA];    // softmax output
+  float q[MAXA];    // p / sum(p)                      (Categorical.probs)
+  float lc[MAXA];   // log(clamp(q, eps, 1-eps))       (Categorical.logits)
+  float ps;
+};
+
+__device__ __forceinline__ void softmax_categorical(const float* z, int A, Dist& d) {
+  float m = z[0];
+#pragma unroll
+  for (int j = 1; j < MAXA; ++j)
+    if (j < A) m = fmaxf(m, z[j]);
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) {
+    d.p[j] = (j < A) ? expf(z[j] - m) : 0.0f;
+    s += d.p[j];
+  }
+  d.ps = 0.0f;
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) {
+    d.p[j] = d.p[j] / s;
+    d.ps += d.p[j];
+  }
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) {
+    d.q[j] = d.p[j] / d.ps;
+    d.lc[j] = logf(fminf(fmaxf(d.q[j], CAT_EPS), 1.0f - CAT_EPS));
+  }
+}
+
+__device__ __forceinline__ float pick(const float* a, int idx) {
+  float r = a[0];
+#pragma unroll
+  for (int j = 1; j < MAXA; ++j) r = (idx == j) ? a[j] : r;
+  return r;
+}
+
+// --------------------------------------------------------------------------------------------
+// acting: probs / value / sample-or-evaluate
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict__ h, int64_t h_es,
+                                                        const float* __restrict__ params, ParamLayout L, int n,
+                                                        const float* __restrict__ act_in, uint64_t seed,
+                                                        uint64_t stream_id, float* __restrict__ probs,
+                                                        float* __restrict__ value, float* __restrict__ action_out,
+                                                        float* __restrict__ logp_out) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  HeadRegs R;
+  load_head_weights(R, params, L, lane);
+  for (int b = gw; b < n; b += nw) {
+    float ha[8], hc[8];
+    load8(h + (int64_t)b * FEAT + lane * 8, ha);
+    load8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+    float z[MAXA];
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], R.wa[j][i], s);
+      z[j] = wave_sum(s) + R.ba[j];
+    }
+    float sv = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
+    const float v = wave_sum(sv) + R.bc;
+    Dist d;
+    softmax_categorical(z, L.A, d);
+    int a;
+    if (act_in != nullptr) {
+      a = (int)act_in[b];
+    } else {
+      const float u = hash_uniform(seed, stream_id, (uint64_t)b);
+      float c = 0.0f;
+      a = L.A - 1;
+      bool done = false;
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) {
+        if (j < L.A) {
+          c += d.q[j];
+          if (!done && u < c) {
+            a = j;
+            done = true;
+          }
+        }
+      }
+    }
+    if (lane == 0) {
+      value[b] = v;
+      if (action_out) action_out[b] = (float)a;
+      if (logp_out) logp_out[b] = pick(d.lc, a);
+    }
+    if (probs && lane < L.A) probs[(int64_t)b * L.A + lane] = pick(d.p, lane);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// training: loss terms, d(loss)/d(logits, value), backward of both head layers
+// hpart layout per workgroup: [A*512 dWa][512 dwc][A dba][1 dbc][actor_sum, v_sum, ent_sum]
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heads_loss_kernel(
+    const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
+    const float* __restrict__ actions, const float* __restrict__ old_logps, const float* __restrict__ advs,
+    const float* __restrict__ rets, float inv_b, float* __restrict__ dh, int64_t dh_es, float* __restrict__ dlogits,
+    float* __restrict__ dvalue, float* __restrict__ hpart, int64_t hstride) {
+  __shared__ float red[(MAXA + 1) * FEAT + 2 * MAXA + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + wave;
+  const int nw = gridDim.x * 4;
+  const int A = L.A;
+  HeadRegs R;
+  load_head_weights(R, params, L, lane);
+  float gwa[MAXA][8], gwc[8], gba[MAXA], gbc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) {
+    gba[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gwa[j][i] = 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gwc[i] = 0.0f;
+  double s_actor = 0.0, s_v = 0.0, s_ent = 0.0;
+  const float lo = 1.0f - cfg.ppo_clip, hi = 1.0f + cfg.ppo_clip;
+
+  for (int b = gw; b < n; b += nw) {
+    float ha[8], hc[8];
+    load8(h + (int64_t)b * FEAT + lane * 8, ha);
+    load8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+    float z[MAXA];
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], R.wa[j][i], s);
+      z[j] = wave_sum(s) + R.ba[j];
+    }
+    float sv = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
+    const float v = wave_sum(sv) + R.bc;
+    Dist d;
+    softmax_categorical(z, A, d);
+    const int a = (int)actions[b];
+    const float adv = advs[b];
+    const float logp = pick(d.lc, a);
+    const float ratio = expf(logp - old_logps[b]);
+    const float surr1 = ratio * adv;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float surr2 = rc * adv;
+    const float mn = fminf(surr1, surr2);
+    const float dual = cfg.dual_clip * adv;
+    const float term = (adv > 0.0f) ? mn : fmaxf(mn, dual);
+    s_actor += (double)term;
+    const float err = rets[b] - v;
+    s_v += (double)err * (double)err;
+    float ent = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j)
+      if (j < A) ent += d.lc[j] * d.q[j];
+    s_ent += (double)(-ent);
+
+    // ---- backward through the surrogate (torch min/max tie rule: split evenly) ----
+    const float g_term = -inv_b;
+    float g_mn;
+    if (adv > 0.0f) g_mn = g_term;
+    else g_mn = (mn > dual) ? g_term : ((mn == dual) ? 0.5f * g_term : 0.0f);
+    const float g_s1 = (surr1 < surr2) ? g_mn : ((surr1 == surr2) ? 0.5f * g_mn : 0.0f);
+    const float g_s2 = (surr2 < surr1) ? g_mn : ((surr1 == surr2) ? 0.5f * g_mn : 0.0f);
+    const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+    const float g_ratio = g_s1 * adv + g_s2 * adv * inrange;
+    const float g_logp = g_ratio * ratio;
+    // ---- log(clamp(q_a)) , q = p / sum(p) , softmax ----
+    const float qa = pick(d.q, a), pa = pick(d.p, a);
+    const float qa_c = fminf(fmaxf(qa, CAT_EPS), 1.0f - CAT_EPS);
+    const float g_qa = (qa >= CAT_EPS && qa <= 1.0f - CAT_EPS) ? g_logp / qa_c : 0.0f;
+    const float g_ps = -g_qa * pa / (d.ps * d.ps);
+    float gp[MAXA], dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      gp[j] = ((j == a) ? g_qa / d.ps : 0.0f) + g_ps;
+      if (j < A) dot += gp[j] * d.p[j];
+    }
+    float gz[MAXA];
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) gz[j] = (j < A) ? (gp[j] - dot) * d.p[j] : 0.0f;
+    const float gv = -err * inv_b;
+
+    // ---- head layers backward ----
+    float da[8], dc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) s = __builtin_fmaf(gz[j], R.wa[j][i], s);
+      da[i] = s;
+      dc[i] = gv * R.wc[i];
+      gwc[i] = __builtin_fmaf(gv, hc[i], gwc[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      gba[j] += gz[j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gwa[j][i] = __builtin_fmaf(gz[j], ha[i], gwa[j][i]);
+    }
+    gbc += gv;
+    store8(dh + (int64_t)b * FEAT + lane * 8, da);
+    store8(dh + dh_es + (int64_t)b * FEAT + lane * 8, dc);
+    if (lane < A) dlogits[(int64_t)b * A + lane] = pick(gz, lane);
+    if (lane == 0) dvalue[b] = gv;
+  }
+
+  // ---- workgroup reduction, waves accumulate in turn (fixed order) -> hpart[blockIdx.x] ----
+  constexpr int SCAL = (MAXA + 1) * FEAT;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      const bool first = (w == 0);
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = j * FEAT + lane * 8 + i;
+          red[idx] = first ? gwa[j][i] : red[idx] + gwa[j][i];
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = MAXA * FEAT + lane * 8 + i;
+        red[idx] = first ? gwc[i] : red[idx] + gwc[i];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) red[SCAL + j] = first ? gba[j] : red[SCAL + j] + gba[j];
+        red[SCAL + MAXA] = first ? gbc : red[SCAL + MAXA] + gbc;
+        red[SCAL + MAXA + 1] = first ? (float)s_actor : red[SCAL + MAXA + 1] + (float)s_actor;
+        red[SCAL + MAXA + 2] = first ? (float)s_v : red[SCAL + MAXA + 2] + (float)s_v;
+        red[SCAL + MAXA + 3] = first ? (float)s_ent : red[SCAL + MAXA + 3] + (float)s_ent;
+      }
+    }
+    __syncthreads();
+  }
+  float* out = hpart + (int64_t)blockIdx.x * hstride;
+  for (int i = threadIdx.x; i < A * FEAT; i += 256) out[i] = red[i];
+  for (int i = threadIdx.x; i < FEAT; i += 256) out[A * FEAT + i] = red[MAXA * FEAT + i];
+  if (threadIdx.x < A) out[(A + 1) * FEAT + threadIdx.x] = red[SCAL + threadIdx.x];
+  if (threadIdx.x == 0) out[(A + 1) * FEAT + A] = red[SCAL + MAXA];
+  if (threadIdx.x < 3) out[(A + 1) * FEAT + A + 1 + threadIdx.x] = red[SCAL + MAXA + 1 + threadIdx.x];
+}
+
+// grads[head params] = sum over workgroups (fixed order); grads[n_params+0..2] = loss shares
+__global__ __launch_bounds__(256) void heads_reduce_kernel(const float* __restrict__ hpart, int64_t hstride, int nwg,
+                                                           ParamLayout L, ddrl_config cfg, float inv_b,
+                                                           float* __restrict__ grads) {
+  const int A = L.A;
+  const int total = (A + 1) * FEAT + A + 1 + 3;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int nloss0 = (A + 1) * FEAT + A + 1;
+  if (i >= nloss0) {
+    double s = 0.0;
+    for (int w = 0; w < nwg; ++w) s += (double)hpart[(int64_t)w * hstride + i];
+    const int k = i - nloss0;
+    double r;
+    if (k == 0) r = -s * (double)inv_b;            // actor_loss = -mean(term)
+    else if (k == 1) r = s * (double)inv_b * 0.5;  // v_loss = mean(err^2)/2
+    else r = s * (double)inv_b;                    // entropy = mean(H)
+    grads[L.n_params + k] = (float)r;
+    return;
+  }
+  float s = 0.0f;
+  for (int w = 0; w < nwg; ++w) s += hpart[(int64_t)w * hstride + i];
+  int64_t dst;
+  if (i < A * FEAT) dst = L.actor_w + i;
+  else if (i < (A + 1) * FEAT) dst = L.critic_w + (i - A * FEAT);
+  else if (i < (A + 1) * FEAT + A) dst = L.actor_b + (i - (A + 1) * FEAT);
+  else dst = L.critic_b;
+  grads[dst] = s;
+}
+
+__global__ __launch_bounds__(256) void categorical_stats_kernel(const float* __restrict__ probs, int n, int A,
+                                                                float* __restrict__ p_hat, float* __restrict__ logits,
+                                                                float* __restrict__ entropy) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  float ps = 0.0f;
+  for (int j = 0; j < A; ++j) ps += probs[(int64_t)b * A + j];
+  float ent = 0.0f;
+  for (int j = 0; j < A; ++j) {
+    const float q = probs[(int64_t)b * A + j] / ps;
+    const float lc = logf(fminf(fmaxf(q, CAT_EPS), 1.0f - CAT_EPS));
+    if (p_hat) p_hat[(int64_t)b * A + j] = q;
+    if (logits) logits[(int64_t)b * A + j] = lc;
+    ent += lc * q;
+  }
+  if (entropy) entropy[b] = -ent;
+}
+
+void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id, float* probs,
+                      float* value, float* action_out, float* logp_out, hipStream_t st) {
+  int wgs = (c.n + 3) / 4;
+  if (wgs > 1024) wgs = 1024;
+  hipLaunchKernelGGL(heads_act_kernel, dim3(wgs), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT, c.params, *c.L, c.n,
+                     act_in, seed, stream_id, probs, value, action_out, logp_out);
+}
+
+void launch_heads_loss(const HeadsCall& c, const float* actions, const float* old_logps, const float* advs,
+                       const float* rets, float inv_b, float* grads, hipStream_t st) {
+  const int64_t hs = hpart_stride(c.L->A);
+  hipLaunchKernelGGL(heads_loss_kernel, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT, c.params, *c.L,
+                     *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh, c.max_batch * FEAT, c.ws->dlogits,
+                     c.ws->dvalue, c.ws->hpart, hs);
+  const int total = (c.L->A + 1) * FEAT + c.L->A + 1 + 3;
+  hipLaunchKernelGGL(heads_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, c.ws->hpart, hs, HEAD_WG, *c.L,
+                     *c.cfg, inv_b, grads);
+}
+
+void launch_categorical_stats(const float* probs, int n, int A, float* p_hat, float* logits, float* entropy,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(categorical_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, st, probs, n, A, p_hat, logits,
+                     entropy);
+}
+
+}  // namespace ddrl

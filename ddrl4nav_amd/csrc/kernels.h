@@ -1,0 +1,51 @@
+// Internal launcher interface between the translation units of libddrl_hip.so.
+#pragma once
+#include "common.h"
+
+namespace ddrl {
+
+struct EncCall {
+  const Workspace* ws;
+  const ParamLayout* L;
+  const Splits* splits;
+  const float* params;
+  const uint8_t* frames;  // [n][4][84][84]
+  int n;
+  int64_t max_batch;
+};
+
+// igemm.hip
+void launch_encoder_forward(const EncCall& c, hipStream_t st);
+void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
+
+// optim.hip
+void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st);
+void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0,
+                            int64_t off1, hipStream_t st);
+// grads[off_e + c] = sum over n samples and `inner` positions of src[e][i][c][inner]
+void launch_colsum(const float* src, int64_t es, int n, int channels, int inner, float* bpart, float* grads,
+                   int64_t off0, int64_t off1, hipStream_t st);
+void launch_clip_adam(const ddrl_config& cfg, const ParamLayout& L, const Workspace& w, float* params,
+                      float* grads, float* m, float* v, int64_t step, hipStream_t st);
+void launch_gae(const float* values, const float* rewards, const uint8_t* dones, int T, int N,
+                float gamma, float landa, float* adv, float* ret, hipStream_t st);
+void launch_fill_lut(float* lut, hipStream_t st);
+
+// heads.hip
+struct HeadsCall {
+  const Workspace* ws;
+  const ParamLayout* L;
+  const ddrl_config* cfg;
+  const float* params;
+  int n;
+  int64_t max_batch;
+};
+void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id,
+                      float* probs, float* value, float* action_out, float* logp_out, hipStream_t st);
+void launch_heads_loss(const HeadsCall& c, const float* actions, const float* old_logps,
+                       const float* advs, const float* rets, float inv_bglobal, float* grads,
+                       hipStream_t st);
+void launch_categorical_stats(const float* probs, int n, int A, float* p_hat, float* logits,
+                              float* entropy, hipStream_t st);
+
+}  // namespace ddrl

@@ -1,0 +1,280 @@
+// HBM-bound support kernels: derived weight layouts, split-K partial reduction, bias
+// gradients, global grad-norm + clip + two-group Adam, the GAE scan and the u8->f32 table.
+//
+// Reference arithmetic replaced:
+//   clip_grad_norm_ + two torch.optim.Adam steps   USTC_lab/nn/ppo.py:40-42,125-129
+//   Agents._accumulate_rewards                     USTC_lab/agent/agent.py:124-140
+#include "kernels.h"
+
+namespace ddrl {
+
+// --------------------------------------------------------------------------------------------
+// derived weight layouts (rebuilt after every optimiser step; 13.5 MB read, ~13.5 MB written)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_small_kernel(const float* __restrict__ params, ParamLayout L, Workspace w) {
+  const int K1 = L.C * 64;
+  const int n1 = 2 * K1 * 32, n2 = 2 * 512 * 64, n3 = 2 * 576 * 64, n4 = 2 * 576 * 64, n5 = 2 * 4 * 256 * 32;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n1) {  // wt1[e][k][oc] = W1[oc][k]
+    const int e = i / (K1 * 32), r = i % (K1 * 32), k = r / 32, oc = r % 32;
+    w.wt1[i] = params[L.enc_base[e] + L.enc.c1w + oc * K1 + k];
+    return;
+  }
+  i -= n1;
+  if (i < n2) {  // wt2[e][k][oc] = W2[oc][k]
+    const int e = i / (512 * 64), r = i % (512 * 64), k = r / 64, oc = r % 64;
+    w.wt2[i] = params[L.enc_base[e] + L.enc.c2w + oc * 512 + k];
+    return;
+  }
+  i -= n2;
+  if (i < n3) {
+    const int e = i / (576 * 64), r = i % (576 * 64), k = r / 64, oc = r % 64;
+    w.wt3[i] = params[L.enc_base[e] + L.enc.c3w + oc * 576 + k];
+    return;
+  }
+  i -= n3;
+  if (i < n4) {  // wd3[e][(oc,ky,kx)][ic] = W3[oc][ic][ky][kx]
+    const int e = i / (576 * 64), r = i % (576 * 64), kq = r / 64, ic = r % 64;
+    const int oc = kq / 9, t = kq % 9;
+    w.wd3[i] = params[L.enc_base[e] + L.enc.c3w + (oc * 64 + ic) * 9 + t];
+    return;
+  }
+  i -= n4;
+  if (i < n5) {  // wd2[e][cls][(oc,u,v)][ic] = W2[oc][ic][2u+a][2v+c],  cls = a*2 + c
+    const int e = i / (4 * 256 * 32), r = i % (4 * 256 * 32);
+    const int cls = r / (256 * 32), r2 = r % (256 * 32), kq = r2 / 32, ic = r2 % 32;
+    const int oc = kq >> 2, u = (kq >> 1) & 1, v = kq & 1;
+    const int ky = 2 * u + (cls >> 1), kx = 2 * v + (cls & 1);
+    w.wd2[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + ky * 4 + kx];
+  }
+}
+
+// wlt[e][k][n] = Wl[n][k]   (512 x 3136 -> 3136 x 512), 32x32 LDS tiles
+__global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt) {
+  __shared__ float tile[32][33];
+  const int e = blockIdx.z;
+  const float* src = params + L.enc_base[e] + L.enc.lw;
+  float* dst = wlt + (int64_t)e * FLAT * FEAT;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + ty + 8 * j;
+    tile[ty + 8 * j][tx] = src[(int64_t)n * FLAT + k0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + ty + 8 * j;
+    dst[(int64_t)k * FEAT + n0 + tx] = tile[tx][ty + 8 * j];
+  }
+}
+
+void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  const int total = 2 * L.C * 64 * 32 + 2 * 512 * 64 + 2 * 576 * 64 * 2 + 2 * 4 * 256 * 32;
+  hipLaunchKernelGGL(pack_small_kernel, dim3((total + 255) / 256), dim3(256), 0, st, params, L, w);
+  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, 2), dim3(256), 0, st, params, L, w.wlt);
+}
+
+// --------------------------------------------------------------------------------------------
+// grads[off_e + i] = sum_s part[s][e][i]   (fixed order)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nsplit, int64_t count,
+                                                              float* __restrict__ grads, int64_t off0, int64_t off1) {
+  const int e = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.0f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)sp * 2 + e) * count + i];
+  grads[(e ? off1 : off0) + i] = s;
+}
+void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0, int64_t off1,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256), 2), dim3(256), 0, st, part, nsplit,
+                     count, grads, off0, off1);
+}
+
+// --------------------------------------------------------------------------------------------
+// bias gradients: grads[off_e + c] = sum_{i<n} sum_{t<inner} src[e][i][c][t]
+// stage 1: COLSUM_SPLITS partial sums per channel, stage 2: ordered sum of the partials
+// --------------------------------------------------------------------------------------------
+constexpr int COLSUM_SPLITS = 32;
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ src, int64_t es, int n, int channels,
+                                                            int inner, float* __restrict__ bpart) {
+  __shared__ float red[256];
+  const int e = blockIdx.z, sp = blockIdx.y;
+  const int per = (n + COLSUM_SPLITS - 1) / COLSUM_SPLITS;
+  const int i0 = sp * per, i1 = min(n, i0 + per);
+  const float* base = src + e * es;
+  float s = 0.0f;
+  if (inner == 1) {
+    // one thread per channel, coalesced across channels
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < channels) {
+      for (int i = i0; i < i1; ++i) s += base[(int64_t)i * channels + c];
+      bpart[((int64_t)e * channels + c) * COLSUM_SPLITS + sp] = s;
+    }
+    return;
+  }
+  const int c = blockIdx.x;
+  const int64_t total = (int64_t)(i1 - i0) * inner;
+  for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
+    const int i = i0 + (int)(idx / inner), t = (int)(idx % inner);
+    s += base[((int64_t)i * channels + c) * inner + t];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bpart[((int64_t)e * channels + c) * COLSUM_SPLITS + sp] = red[0];
+}
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ bpart, int channels,
+                                                            float* __restrict__ grads, int64_t off0, int64_t off1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * channels) return;
+  const int e = i / channels, c = i % channels;
+  float s = 0.0f;
+  for (int sp = 0; sp < COLSUM_SPLITS; ++sp) s += bpart[(int64_t)i * COLSUM_SPLITS + sp];
+  grads[(e ? off1 : off0) + c] = s;
+}
+void launch_colsum(const float* src, int64_t es, int n, int channels, int inner, float* bpart, float* grads,
+                   int64_t off0, int64_t off1, hipStream_t st) {
+  const int gx = (inner == 1) ? (channels + 255) / 256 : channels;
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3(gx, COLSUM_SPLITS, 2), dim3(256), 0, st, src, es, n, channels, inner,
+                     bpart);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((2 * channels + 255) / 256), dim3(256), 0, st, bpart, channels, grads,
+                     off0, off1);
+}
+
+// --------------------------------------------------------------------------------------------
+// grad-norm partials -> clip coefficient -> Adam (actor lr for the first n_actor parameters)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = (double)g[i];
+    s += x * x;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+struct AdamArgs {
+  float lr_step[2];   // lr / (1 - beta1^t) per group
+  float bc2_sqrt;     // sqrt(1 - beta2^t)
+  float beta1, beta2, eps;
+  float max_norm;
+  int clip;
+  float v_theta, ent_theta;
+};
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n, int64_t n_actor,
+                                                        const double* __restrict__ part, int nparts, AdamArgs a) {
+  __shared__ float s_coef;
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) {
+      const float norm = (float)sqrt(s);
+      float coef = a.max_norm / (norm + 1e-6f);  // torch.nn.utils.clip_grad_norm_
+      coef = fminf(coef, 1.0f);
+      if (!a.clip) coef = 1.0f;
+      s_coef = coef;
+      if (blockIdx.x == 0) {
+        g[n + 4] = norm;
+        g[n + 5] = coef;
+        g[n + 3] = g[n + 0] + g[n + 1] * a.v_theta - g[n + 2] * a.ent_theta;  // PpoTotalLoss, ppo.py:108
+      }
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.0f - a.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * a.beta2 + ((1.0f - a.beta2) * gi) * gi;  // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    const float step = (i < n_actor) ? a.lr_step[0] : a.lr_step[1];
+    p[i] = p[i] + (-step) * (mi / denom);              // addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mi;
+    v[i] = vi;
+    g[i] = gi;  // clip_grad_norm_ scales .grad in place
+  }
+}
+
+void launch_clip_adam(const ddrl_config& cfg, const ParamLayout& L, const Workspace& w, float* params, float* grads,
+                      float* m, float* v, int64_t step, hipStream_t st) {
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(NORM_WG), dim3(256), 0, st, grads, L.n_params, w.npart);
+  AdamArgs a;
+  const double bc1 = 1.0 - pow((double)cfg.adam_beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)cfg.adam_beta2, (double)step);
+  a.lr_step[0] = (float)((double)cfg.actor_lr / bc1);
+  a.lr_step[1] = (float)((double)cfg.critic_lr / bc1);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.beta1 = cfg.adam_beta1;
+  a.beta2 = cfg.adam_beta2;
+  a.eps = cfg.adam_eps;
+  a.max_norm = cfg.clip_grad_norm;
+  a.clip = cfg.clip_grad;
+  a.v_theta = cfg.v_loss_theta;
+  a.ent_theta = cfg.ent_loss_theta;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(2048), dim3(256), 0, st, params, grads, m, v, L.n_params, L.n_actor, w.npart,
+                     NORM_WG, a);
+}
+
+// --------------------------------------------------------------------------------------------
+// GAE reverse scan, one lane per env column, reference operation order (no fma contraction)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ values, const float* __restrict__ rewards,
+                                                 const uint8_t* __restrict__ dones, int T, int N, float gamma, float landa,
+                                                 float* __restrict__ adv, float* __restrict__ ret) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  const float gl = __fmul_rn(gamma, landa);  // (discounts * landa)
+  float g = 0.0f;
+  float nv = values[(int64_t)T * N + n];
+#pragma unroll 8
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t i = (int64_t)t * N + n;
+    const float d = (float)(uint8_t)(1 - dones[i]);  // (1 - dones) evaluated in uint8
+    const float v = values[i];
+    const float r = rewards[i];
+    g = __fmul_rn(g, d);                                        // rewards_sum *= (1 - dones)
+    const float t1 = __fmul_rn(gl, g);                          // discounts*landa*rewards_sum
+    const float t2 = __fmul_rn(__fmul_rn(gamma, nv), d);        // discounts*next_v*(1-dones)
+    const float t3 = __fadd_rn(__fsub_rn(t2, v), r);            // ... - values + rewards
+    g = __fadd_rn(t1, t3);
+    nv = v;
+    ret[i] = __fadd_rn(v, g);
+    adv[i] = g;
+  }
+}
+void launch_gae(const float* values, const float* rewards, const uint8_t* dones, int T, int N, float gamma, float landa,
+                float* adv, float* ret, hipStream_t st) {
+  hipLaunchKernelGGL(gae_kernel, dim3((N + 63) / 64), dim3(64), 0, st, values, rewards, dones, T, N, gamma, landa, adv,
+                     ret);
+}
+
+// float32(u8/255.0) table via the same arithmetic the conv1 loader uses
+__global__ void fill_lut_kernel(float* lut) {
+  const float x = (float)threadIdx.x;
+  const float r = 1.0f / 255.0f;
+  const float q = x * r;
+  const float e = __builtin_fmaf(-255.0f, q, x);
+  lut[threadIdx.x] = __builtin_fmaf(e, r, q);
+}
+void launch_fill_lut(float* lut, hipStream_t st) { hipLaunchKernelGGL(fill_lut_kernel, dim3(1), dim3(256), 0, st, lut); }
+
+}  // namespace ddrl

@@ -1,0 +1,213 @@
+"""HotPath: owner of the device arenas and the libddrl_hip context.
+
+PyTorch is used here for device memory, streams and (optionally) torch.distributed only; all
+arithmetic on the path runs in the HIP kernels behind the C ABI (include/ddrl.h).
+"""
+from ctypes import byref, c_float, c_int32, c_int64, c_void_p, create_string_buffer
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import STATS_FLOATS, Config, check
+
+
+def _ptr(t):
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HotPath:
+    """One per GPU.  Holds params / grads / Adam state as flat fp32 tensors in the reference's
+    named_parameters() order (reference nn/base.py:60-66) and the kernel workspace."""
+
+    def __init__(self, max_batch, device=None, n_actions=6, in_channels=4, process_group=None, **cfg_overrides):
+        if not torch.cuda.is_available():
+            raise _lib.DdrlError("ddrl4nav_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.cfg = _lib.default_config(max_batch=int(max_batch), n_actions=int(n_actions),
+                                       in_channels=int(in_channels), **cfg_overrides)
+        n, na, wb = c_int64(), c_int64(), c_int64()
+        check(self.lib.ddrl_param_count(byref(self.cfg), byref(n), byref(na)))
+        check(self.lib.ddrl_workspace_bytes(byref(self.cfg), byref(wb)))
+        self.n_params, self.n_actor, self.workspace_bytes = n.value, na.value, wb.value
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.n_params + STATS_FLOATS, dtype=torch.float32, device=self.device)
+            self.adam_m = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.adam_v = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+        ctx = c_void_p()
+        check(self.lib.ddrl_ctx_create(byref(self.cfg), _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+                                       _ptr(self.adam_v), _ptr(self.workspace), self.workspace_bytes, byref(ctx)))
+        self.ctx = ctx
+        self.process_group = process_group
+        self.n_actions = int(n_actions)
+        self.max_batch = int(max_batch)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ddrl_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------
+    def set_params(self, flat):
+        """Copy a flat float32 array/tensor (reference blob order) into the arena."""
+        t = torch.as_tensor(flat, dtype=torch.float32).reshape(-1)
+        if t.numel() != self.n_params:
+            raise ValueError("expected %d parameters, got %d" % (self.n_params, t.numel()))
+        self.params.copy_(t, non_blocking=False)
+        self.params_changed()
+
+    def params_changed(self):
+        check(self.lib.ddrl_params_changed(self.ctx))
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        check(self.lib.ddrl_set_step(self.ctx, 0))
+
+    @property
+    def step(self):
+        s = c_int64()
+        check(self.lib.ddrl_get_step(self.ctx, byref(s)))
+        return s.value
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, frames, act=None, seed=0, stream_id=0, probs=None, value=None, action=None, logp=None):
+        """frames uint8 [n,4,84,84] on device.  Returns (probs [n,A], value [n], action [n], logp [n])."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.is_contiguous()
+        n = frames.shape[0]
+        dev = frames.device
+        probs = torch.empty((n, self.n_actions), dtype=torch.float32, device=dev) if probs is None else probs
+        value = torch.empty(n, dtype=torch.float32, device=dev) if value is None else value
+        logp = torch.empty(n, dtype=torch.float32, device=dev) if logp is None else logp
+        if act is None:
+            action = torch.empty(n, dtype=torch.float32, device=dev) if action is None else action
+        else:
+            assert act.dtype == torch.float32 and act.is_contiguous() and act.numel() == n
+            action = act
+        check(self.lib.ddrl_forward(self.ctx, _ptr(frames), n, _ptr(act), int(seed) & (2 ** 64 - 1),
+                                    int(stream_id) & (2 ** 64 - 1), _ptr(probs), _ptr(value),
+                                    _ptr(action) if act is None else c_void_p(0), _ptr(logp), _stream()))
+        return probs, value, action, logp
+
+    def categorical_stats(self, probs):
+        n, A = probs.shape
+        p_hat = torch.empty_like(probs)
+        logits = torch.empty_like(probs)
+        ent = torch.empty(n, dtype=torch.float32, device=probs.device)
+        check(self.lib.ddrl_categorical_stats(_ptr(probs), n, A, _ptr(p_hat), _ptr(logits), _ptr(ent), _stream()))
+        return p_hat, logits, ent
+
+    def last_features(self, n):
+        ha = torch.empty((n, 512), dtype=torch.float32, device=self.device)
+        hc = torch.empty((n, 512), dtype=torch.float32, device=self.device)
+        check(self.lib.ddrl_last_features(self.ctx, n, _ptr(ha), _ptr(hc), _stream()))
+        return ha, hc
+
+    # ---- GAE --------------------------------------------------------------------------------
+    def gae(self, values, rewards, dones, gamma=0.99, landa=0.95, adv=None, ret=None):
+        """values [T+1,N] f32, rewards [T,N] f32, dones [T,N] u8 (device) -> adv, ret [T,N]."""
+        T, N = rewards.shape
+        assert values.shape == (T + 1, N) and dones.shape == (T, N)
+        assert values.dtype == torch.float32 and rewards.dtype == torch.float32 and dones.dtype == torch.uint8
+        assert values.is_contiguous() and rewards.is_contiguous() and dones.is_contiguous()
+        adv = torch.empty((T, N), dtype=torch.float32, device=values.device) if adv is None else adv
+        ret = torch.empty((T, N), dtype=torch.float32, device=values.device) if ret is None else ret
+        check(self.lib.ddrl_gae(_ptr(values), _ptr(rewards), _ptr(dones), T, N, float(np.float32(gamma)),
+                                float(np.float32(landa)), _ptr(adv), _ptr(ret), _stream()))
+        return adv, ret
+
+    # ---- learner ----------------------------------------------------------------------------
+    def ppo_iter(self, frames, actions, old_logps, advs, rets, b_global=None):
+        B = frames.shape[0]
+        for t in (actions, old_logps, advs, rets):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == B
+        assert frames.dtype == torch.uint8 and frames.is_contiguous()
+        check(self.lib.ddrl_ppo_iter(self.ctx, _ptr(frames), _ptr(actions), _ptr(old_logps), _ptr(advs), _ptr(rets),
+                                     B, int(b_global if b_global is not None else B), _stream()))
+
+    def allreduce_grads(self):
+        """One RCCL all-reduce (sum) of the flat gradient arena + loss tail per PPO iteration
+        (SURVEY.md section 8e); gradients were pre-scaled by 1/B_global."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def clip_adam_step(self):
+        check(self.lib.ddrl_clip_adam_step(self.ctx, _stream()))
+
+    def stats(self):
+        """Host copy of (actor_loss, v_loss, entropy, total, grad_norm, clip_coef) -- one sync."""
+        s = self.grads[self.n_params:self.n_params + 6].cpu().numpy()
+        return {"ActorLoss": float(s[0]), "VLoss": float(s[1]), "EntLoss": float(s[2]), "PpoTotalLoss": float(s[3]),
+                "GradNorm": float(s[4]), "ClipCoef": float(s[5])}
+
+    # ---- diagnostics ------------------------------------------------------------------------
+    def debug_buffer(self, which, shape_per_sample, n, enc):
+        """Copy of a workspace tensor: [n, *shape_per_sample] for encoder `enc`."""
+        p, es = c_void_p(), c_int64()
+        check(self.lib.ddrl_debug_buffer(self.ctx, which, byref(p), byref(es)))
+        count = int(np.prod(shape_per_sample)) * n
+        off = (p.value - self.workspace.data_ptr()) // 4 + enc * es.value
+        flat = self.workspace.view(torch.float32)[off:off + count]
+        return flat.clone().reshape((n,) + tuple(shape_per_sample))
+
+    def u8_table(self):
+        out = torch.empty(256, dtype=torch.float32, device=self.device)
+        check(self.lib.ddrl_u8_table(_ptr(out), _stream()))
+        return out
+
+    def profile(self, on=True):
+        check(self.lib.ddrl_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self):
+        cap = 64
+        names = create_string_buffer(48 * cap)
+        ms = (c_float * cap)()
+        calls = (c_int32 * cap)()
+        n = c_int32()
+        check(self.lib.ddrl_profile_read(self.ctx, names, ms, calls, cap, byref(n)))
+        out = {}
+        for i in range(min(n.value, cap)):
+            nm = names.raw[48 * i:48 * (i + 1)].split(b"\0")[0].decode()
+            out[nm] = (float(ms[i]), int(calls[i]))
+        return out
+
+
+class Timer:
+    """HIP-event pair recorded on the caller's stream (bench.py roofline measurement)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.h = c_void_p()
+        check(self.lib.ddrl_timer_create(byref(self.h)))
+
+    def start(self):
+        check(self.lib.ddrl_timer_start(self.h, _stream()))
+
+    def stop(self):
+        check(self.lib.ddrl_timer_stop(self.h, _stream()))
+
+    def elapsed_ms(self):
+        ms = c_float()
+        check(self.lib.ddrl_timer_elapsed_ms(self.h, byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            self.lib.ddrl_timer_destroy(self.h)
+        except Exception:
+            pass

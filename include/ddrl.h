@@ -1,0 +1,179 @@
+/*
+ * ddrl.h -- C ABI of the MI355X-native DDRL4NAV actor-learner hot path (libddrl_hip.so).
+ *
+ * The reference has no FFI on this path: its boundary is a Python object protocol
+ * (USTC_lab.nn.PPO called by USTC_lab/server/forward.py:107-182 and
+ * USTC_lab/server/backward.py:168-217).  This header is what a cgo/ctypes/N-API binding of
+ * that path would bind; every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns an int32 status (0 = DDRL_OK, negative = error); nothing throws;
+ *   - all tensor pointers are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm tensors)
+ *     unless the name ends in _host; the library allocates no device memory after
+ *     ddrl_ctx_create (it allocates none at all: the caller passes the arenas and workspace);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are
+ *     asynchronous on that stream and may be captured into a hipGraph;
+ *   - one caller thread per context.
+ *
+ * Layouts (C-contiguous):
+ *   frames   uint8  [n, C=4, 84, 84]   stacked frames exactly as the env wrapper emits them
+ *                                      before the /255.0 (reference warputils.py:274-301);
+ *                                      the kernels apply float32(u8/255.0) themselves.
+ *   params / grads / adam_m / adam_v   float32 flat arenas in the reference's
+ *                                      named_parameters() order (USTC_lab/nn/base.py:60-66):
+ *                                      actor.pre.{conv1,conv2,conv3,linear}.{weight,bias},
+ *                                      actor.actor_linear.{weight,bias},
+ *                                      critic.critic_linear.{weight,bias},
+ *                                      critic.pre.{conv1,conv2,conv3,linear}.{weight,bias}.
+ *                                      `grads` has DDRL_STATS_FLOATS extra floats at its tail
+ *                                      (loss partial sums) so one all-reduce covers both.
+ */
+#ifndef DDRL_H_
+#define DDRL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDRL_OK 0
+#define DDRL_ERR_INVALID_ARG (-1)
+#define DDRL_ERR_UNSUPPORTED (-2)
+#define DDRL_ERR_WORKSPACE (-3)
+#define DDRL_ERR_HIP (-4)
+#define DDRL_ERR_NO_DEVICE (-5)
+#define DDRL_ERR_TIMEOUT (-6)
+
+#define DDRL_ABI_VERSION 1
+#define DDRL_STATS_FLOATS 8 /* tail of the grad arena, see ddrl_ppo_iter */
+
+typedef struct ddrl_ctx ddrl_ctx;
+typedef struct ddrl_ring ddrl_ring;
+
+/* Hyper-parameters: the ConfigNN contract (USTC_lab/config/config_nn.py:19-57). */
+typedef struct ddrl_config {
+  int32_t n_actions;      /* ACTION_OUTPUT_DIM, 6 for Pong                       */
+  int32_t in_channels;    /* int_frame_stack, 4                                   */
+  int32_t max_batch;      /* largest n / B any call will pass (sizes workspace)   */
+  int32_t share_cnn_net;  /* SHARE_CNN_NET; only 0 is implemented                 */
+  int32_t clip_grad;      /* CLIP_GRID                                            */
+  float clip_grad_norm;   /* CLIP_GRID_NUM = 0.5                                  */
+  float actor_lr;         /* ACTOR_LEARNING_RATE = 5e-5                           */
+  float critic_lr;        /* CRITIC_LEARNING_RATE = 1e-3                          */
+  float adam_beta1;       /* torch.optim.Adam default 0.9                         */
+  float adam_beta2;       /* 0.999                                                */
+  float adam_eps;         /* 1e-8                                                 */
+  float ppo_clip;         /* PPO_CLIP = 0.2                                       */
+  float dual_clip;        /* DUEL_PPO_CLIP = 3                                    */
+  float v_loss_theta;     /* V_LOSS_THETA = 1.0                                   */
+  float ent_loss_theta;   /* ENTROPY_LOSS_THETA = 0.05                            */
+} ddrl_config;
+
+int32_t ddrl_abi_version(void);
+const char* ddrl_status_string(int32_t status);
+
+/* Fill `cfg` with the reference defaults (config_nn.py) for Pong. */
+int32_t ddrl_config_default(ddrl_config* cfg);
+
+/* Number of fp32 parameters (3,371,847 for the default net) and of the actor-side prefix
+ * (the parameters stepped with actor_lr; the remainder is stepped with critic_lr --
+ * USTC_lab/nn/ppo.py:41-42). */
+int32_t ddrl_param_count(const ddrl_config* cfg, int64_t* n_params, int64_t* n_actor_params);
+
+/* Bytes of caller-provided device workspace needed for cfg->max_batch. */
+int32_t ddrl_workspace_bytes(const ddrl_config* cfg, int64_t* bytes);
+
+/* Create a context over caller-owned device arenas.  grads must hold n_params +
+ * DDRL_STATS_FLOATS floats; params/adam_m/adam_v hold n_params floats.  adam_m/adam_v must be
+ * zeroed by the caller for a fresh optimiser.  Replaces PPO.__init__ (ppo.py:18-59). */
+int32_t ddrl_ctx_create(const ddrl_config* cfg, float* params, float* grads, float* adam_m,
+                        float* adam_v, void* workspace, int64_t workspace_bytes, ddrl_ctx** out);
+int32_t ddrl_ctx_destroy(ddrl_ctx* ctx);
+
+/* Tell the context that `params` was rewritten by the caller (load_state_dict /
+ * updatenn_by_redis, USTC_lab/nn/base.py:68-95): derived weight layouts are rebuilt lazily. */
+int32_t ddrl_params_changed(ddrl_ctx* ctx);
+
+/* Adam step counter (torch keeps it in optimizer state; not saved by the reference's
+ * checkpoints, backward.py:208-209). */
+int32_t ddrl_get_step(const ddrl_ctx* ctx, int64_t* step);
+int32_t ddrl_set_step(ddrl_ctx* ctx, int64_t step);
+
+/* PPO.forward (ppo.py:72-75) + the acting glue of ForwardThread.run (forward.py:128-149).
+ *   act_in == NULL : sample  action ~ Categorical(probs)  with the counter-based stream
+ *                    u = U(seed, stream, sample_index)  and inverse-CDF over p_hat; write the
+ *                    action (as float, like `.to(tensortype)`) to action_out.
+ *   act_in != NULL : evaluate log-prob of the given actions (PPO.forward(states, act)).
+ * Outputs (any may be NULL except value/probs): probs [n,A] = softmax output (what play_mode
+ * returns, actor.py:94-96); value [n]; logp_out [n] = log(clamp(p_hat[a], eps, 1-eps)). */
+int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const float* act_in,
+                     uint64_t seed, uint64_t stream_id, float* probs, float* value,
+                     float* action_out, float* logp_out, void* stream);
+
+/* torch.distributions.Categorical(probs) derived quantities (actor.py:97 + forward.py:137-138,
+ * ppo.py:106): p_hat = p/sum(p), logits = log(clamp(p_hat, eps, 1-eps)), entropy. */
+int32_t ddrl_categorical_stats(const float* probs, int32_t n, int32_t n_actions, float* p_hat,
+                               float* logits, float* entropy, void* stream);
+
+/* Encoder outputs of the last ddrl_forward / ddrl_ppo_iter call: h[e][i][512], e = 0 actor,
+ * 1 critic (AtariPreNet.forward, atari_encoder.py:25-32).  Copies n*512 floats each. */
+int32_t ddrl_last_features(ddrl_ctx* ctx, int32_t n, float* h_actor, float* h_critic, void* stream);
+
+/* Agents._accumulate_rewards (USTC_lab/agent/agent.py:124-140), one value head.
+ *   values [T+1, N] (row T = bootstrap), rewards [T, N], dones uint8 [T, N]
+ *   adv [T, N], ret [T, N]   (ret = old value + advantage; no advantage normalisation). */
+int32_t ddrl_gae(const float* values, const float* rewards, const uint8_t* dones, int32_t T,
+                 int32_t N, float gamma, float landa, float* adv, float* ret, void* stream);
+
+/* One iteration of the loss + backward half of PPO.learn (ppo.py:82-126, non-shared branch):
+ * forward both encoders on B samples, dual-clip surrogate / value / entropy terms, backward
+ * into the grad arena.  Gradients and loss sums are scaled by 1/B_global so that a SUM over
+ * data-parallel ranks equals the full-batch mean (B_global == B on one GPU).
+ * grads[n_params + 0..2] receive this rank's share of (actor_loss, v_loss, entropy). */
+int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions,
+                      const float* old_logps, const float* advs, const float* rets, int32_t B,
+                      int64_t B_global, void* stream);
+
+/* clip_grad_norm_(all params, clip_grad_norm) + actor Adam + critic Adam (ppo.py:125-129).
+ * Run after the (optional) all-reduce of the grad arena.  grads[n_params + 4] <- global grad
+ * norm, grads[n_params + 5] <- clip coefficient, grads[n_params + 3] <- total loss. */
+int32_t ddrl_clip_adam_step(ddrl_ctx* ctx, void* stream);
+
+/* float32(uint8/255.0) for all 256 byte values, computed with the conv1 loader's arithmetic
+ * (reference: warputils.py:300 divides in float64, forward.py:102-104 casts to float32). */
+int32_t ddrl_u8_table(float* out256, void* stream);
+
+/* Diagnostic view into the workspace, for parity tests of intermediate tensors:
+ * which = 0 a1, 1 a2, 2 a3, 3 h, 4 dz1, 5 dz2, 6 dz3, 7 dh (all [e][max_batch][...], e stride
+ * returned in floats), 8 dlogits [B,A], 9 dvalue [B]. */
+int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* enc_stride);
+
+/* ---- pinned-host ring: replaces the Redis LPUSH/BRPOP shuttle of frames between env workers
+ * and the learner (USTC_lab/agent/multiqueue.py:83-130, server/backward.py:145-151). --------- */
+int32_t ddrl_ring_create(int64_t slot_bytes, int32_t n_slots, ddrl_ring** out);
+int32_t ddrl_ring_destroy(ddrl_ring* ring);
+/* Producer: get the next free pinned slot (blocks up to timeout_ms, DDRL_ERR_TIMEOUT). */
+int32_t ddrl_ring_acquire(ddrl_ring* ring, void** slot_host, int32_t timeout_ms);
+int32_t ddrl_ring_commit(ddrl_ring* ring);
+/* Consumer: hipMemcpyAsync the oldest committed slot to dst (device) on `stream`; the slot is
+ * recycled when the copy has completed. */
+int32_t ddrl_ring_pop_to_device(ddrl_ring* ring, void* dst, int64_t bytes, void* stream, int32_t timeout_ms);
+int32_t ddrl_ring_pending(ddrl_ring* ring, int32_t* n_committed);
+
+/* ---- measurement hooks (bench.py): HIP-event timing on the caller's stream -------------- */
+int32_t ddrl_timer_create(void** timer);
+int32_t ddrl_timer_destroy(void* timer);
+int32_t ddrl_timer_start(void* timer, void* stream);
+int32_t ddrl_timer_stop(void* timer, void* stream);
+int32_t ddrl_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
+
+/* Enable per-kernel HIP-event timing inside ddrl_ppo_iter/ddrl_forward (diagnostic; off by
+ * default).  names/ms arrays are filled up to `cap` entries; returns the count in *n. */
+int32_t ddrl_profile_enable(ddrl_ctx* ctx, int32_t on);
+int32_t ddrl_profile_read(ddrl_ctx* ctx, char (*names)[48], float* ms, int32_t* calls, int32_t cap, int32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDRL_H_ */

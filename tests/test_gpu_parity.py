@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors generated from the reference.  Run with `-m gpu` on an MI355X.
+
+Stated tolerances (fp32 path; summation order differs from torch-CPU):
+  forward probs/value/logp     rtol 1e-5, atol 1e-6
+  encoder activations          rtol 1e-5, atol 2e-6
+  GAE                          bit-exact
+  losses                       rtol 1e-5, atol 1e-6
+  gradients                    |d| <= 2e-5 * max|g| per tensor  (+ cosine > 1 - 1e-9)
+  parameters after k Adam steps  |d| <= 0.02 * lr * k  (Adam's first steps are sign-like:
+                               an element whose gradient is at the fp32 summation-noise
+                               floor moves by O(lr) either way -- see DESIGN.md)
+"""
+import numpy as np
+import pytest
+import torch
+
+from ddrl4nav_amd.utils.recipe import flatten, hash_uniform, make_weights, param_specs
+from oracle import ddrl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from ddrl4nav_amd.engine import HotPath
+    h = HotPath(max_batch=512)
+    h.set_params(flatten(make_weights(0)))
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def onet():
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    n = O.OraclePPO()
+    n.load_weights(make_weights(0))
+    return n
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def test_u8_table_matches_reference_division(hp, golden):
+    assert np.array_equal(hp.u8_table().cpu().numpy(), golden("f5_u8_lut")["lut"])
+
+
+def test_forward_golden_f1(hp, golden):
+    g = golden("f1_forward")
+    frames = dev(g["frames"])
+    probs, value, _, logp = hp.forward(frames, act=dev(g["actions"]))
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(value.cpu().numpy(), g["value"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    ha, hc = hp.last_features(8)
+    np.testing.assert_allclose(ha.cpu().numpy()[:, :16], g["h_actor"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(hc.cpu().numpy()[:, :16], g["h_critic"], rtol=1e-5, atol=2e-6)
+    p_hat, logits, ent = hp.categorical_stats(probs)
+    np.testing.assert_allclose(p_hat.cpu().numpy(), g["p_hat"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ent.cpu().numpy(), g["entropy"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 5, 33, 300])
+def test_forward_and_activations_vs_oracle(hp, onet, n):
+    rng = np.random.default_rng(100 + n)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    if n > 4:
+        frames[3] = 0
+        frames[4] = 255
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    probs, value, _, logp = hp.forward(dev(frames), act=dev(acts))
+    x = O.frames_to_f32(frames)
+    with torch.no_grad():
+        oprobs, _, ologits, ov = onet(x)
+        ologp = O.categorical_log_prob(ologits, torch.from_numpy(acts))
+        enc = onet.actor.pre
+        a1 = torch.nn.functional.leaky_relu(enc.conv1(x))
+        a2 = torch.nn.functional.leaky_relu(enc.conv2(a1))
+        a3 = torch.nn.functional.leaky_relu(enc.conv3(a2))
+        encc = onet.critic.pre
+        c1 = torch.nn.functional.leaky_relu(encc.conv1(x))
+    np.testing.assert_allclose(hp.debug_buffer(0, (32, 20, 20), n, 0).cpu().numpy(), a1.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(hp.debug_buffer(0, (32, 20, 20), n, 1).cpu().numpy(), c1.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(hp.debug_buffer(1, (64, 9, 9), n, 0).cpu().numpy(), a2.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(hp.debug_buffer(2, (64, 7, 7), n, 0).cpu().numpy(), a3.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(probs.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(value.cpu().numpy(), ov.numpy()[:, 0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), ologp.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_forward_is_batch_independent(hp):
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=(40, 4, 84, 84), dtype=np.uint8)
+    acts = dev(rng.integers(0, 6, size=40).astype(np.float32))
+    p_all, v_all, _, l_all = [t.clone() for t in hp.forward(dev(frames), act=acts)]
+    perm = rng.permutation(40)
+    p_p, v_p, _, l_p = hp.forward(dev(frames[perm]), act=acts[torch.from_numpy(perm).cuda()].contiguous())
+    assert torch.equal(p_all[perm], p_p) and torch.equal(v_all[perm], v_p) and torch.equal(l_all[perm], l_p)
+
+
+def test_sampler_inverse_cdf_contract(hp):
+    rng = np.random.default_rng(11)
+    n = 257
+    frames = dev(rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8))
+    probs, value, action, logp = hp.forward(frames, act=None, seed=1234, stream_id=77)
+    p_hat, logits, _ = hp.categorical_stats(probs)
+    u = hash_uniform(1234, 77, n)
+    want = O.inverse_cdf_sample(p_hat.cpu().numpy(), u)
+    got = action.cpu().numpy()
+    assert np.array_equal(got, want.astype(np.float32))
+    np.testing.assert_allclose(logp.cpu().numpy(), logits.cpu().numpy()[np.arange(n), want], rtol=1e-6, atol=1e-7)
+    # statistical check of the stream itself: many draws from one distribution
+    one = frames[:1].expand(200, -1, -1, -1).contiguous()
+    counts = np.zeros(6)
+    for s in range(20):
+        _, _, a, _ = hp.forward(one, act=None, seed=5, stream_id=s)
+        counts += np.bincount(a.cpu().numpy().astype(int), minlength=6)
+    p = p_hat.cpu().numpy()[0]
+    expected = p * counts.sum()
+    chi2 = ((counts - expected) ** 2 / np.maximum(expected, 1e-9)).sum()
+    assert chi2 < 40.0, (counts, expected)
+
+
+def test_gae_golden_f2_bit_exact(hp, golden):
+    g = golden("f2_gae")
+    T = 256
+    for lo, ka, kr in ((0, "adv1", "ret1"), (T, "adv2", "ret2")):
+        adv, ret = hp.gae(dev(g["values"][lo:lo + T + 1]), dev(g["rewards"][lo:lo + T]), dev(g["dones"][lo:lo + T]))
+        assert np.array_equal(adv.cpu().numpy(), g[ka])
+        assert np.array_equal(ret.cpu().numpy(), g[kr])
+
+
+@pytest.mark.parametrize("T,N", [(256, 256), (1, 3), (7, 65), (256, 2048)])
+def test_gae_vs_oracle_bit_exact(hp, T, N):
+    rng = np.random.default_rng(T * 1000 + N)
+    v = rng.normal(0, 2, size=(T + 1, N)).astype(np.float32)
+    r = rng.choice(np.array([-1, 0, 1], np.float32), size=(T, N)).astype(np.float32)
+    d = (rng.random((T, N)) < 0.05).astype(np.uint8)
+    adv, ret = hp.gae(dev(v), dev(r), dev(d))
+    oadv, oret = O.gae(v, r, d)
+    assert np.array_equal(adv.cpu().numpy(), oadv) and np.array_equal(ret.cpu().numpy(), oret)
+
+
+def test_gae_all_done_property(hp):
+    # every step terminal -> advantage = r - V, return = r   (size-independent property)
+    T, N = 256, 4096
+    rng = np.random.default_rng(9)
+    v = dev(rng.normal(size=(T + 1, N)).astype(np.float32))
+    r = dev(rng.normal(size=(T, N)).astype(np.float32))
+    d = torch.ones((T, N), dtype=torch.uint8, device="cuda")
+    adv, ret = hp.gae(v, r, d)
+    assert torch.equal(adv, (0.0 - v[:T]) + r)
+    assert torch.equal(ret, v[:T] + adv)
+
+
+def _load_batch(golden):
+    g = golden("f3_loss")
+    return g, dev(g["frames"]), dev(g["actions"]), dev(g["old_logps"]), dev(g["advs"]), dev(g["rets"])
+
+
+def _grad_views(hp):
+    flat = hp.grads[:hp.n_params].cpu().numpy()
+    out, off = {}, 0
+    for name, shape, _ in param_specs():
+        n = int(np.prod(shape))
+        out[name] = flat[off:off + n].reshape(shape)
+        off += n
+    return out
+
+
+def test_loss_and_gradients_golden_f3(hp, onet, golden):
+    g, frames, actions, old_logps, advs, rets = _load_batch(golden)
+    hp.set_params(flatten(make_weights(0)))
+    hp.ppo_iter(frames, actions, old_logps, advs, rets)
+    tail = hp.grads[hp.n_params:hp.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail[0], g["actor_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tail[1], g["v_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tail[2], g["ent"], rtol=1e-5, atol=1e-6)
+    # d(loss)/d(value) straight from the reference's autograd
+    dval = hp.debug_buffer(9, (), 64, 0).cpu().numpy()
+    np.testing.assert_allclose(dval, g["dvalue"], rtol=1e-5, atol=1e-8)
+    # full gradient vs oracle autograd (oracle == reference bit-for-bit, test_oracle_golden.py)
+    onet.load_weights(make_weights(0))
+    onet.zero_grad()
+    x = O.frames_to_f32(g["frames"])
+    t = lambda k: torch.from_numpy(g[k])
+    _, al, vl, _ = O.ppo_losses(onet, x, t("actions"), t("old_logps"), t("advs"), t("rets"))
+    al.backward()
+    vl.backward()
+    got = _grad_views(hp)
+    for name, p in onet.named_parameters():
+        want = p.grad.numpy()
+        scale = np.abs(want).max()
+        assert scale > 0
+        err = np.abs(got[name] - want).max()
+        assert err <= 2e-5 * scale, (name, err, scale)
+        cos = (got[name].astype(np.float64) * want).sum() / (
+            np.linalg.norm(got[name].astype(np.float64)) * np.linalg.norm(want.astype(np.float64)))
+        assert cos > 1 - 1e-9, (name, cos)
+        # golden (reference) spot values
+        np.testing.assert_allclose(got[name].reshape(-1)[:64], g["ghead/" + name], rtol=0, atol=2e-5 * scale)
+
+
+def test_gradient_is_additive_over_shards(hp, golden):
+    """Data-parallel property: grads(full batch) == grads(shard 0) + grads(shard 1) when every
+    shard scales by 1/B_global -- exactly what the RCCL all-reduce sums."""
+    g, frames, actions, old_logps, advs, rets = _load_batch(golden)
+    hp.set_params(flatten(make_weights(0)))
+    hp.ppo_iter(frames, actions, old_logps, advs, rets)
+    full = hp.grads.clone()
+    acc = torch.zeros_like(full)
+    for sl in (slice(0, 40), slice(40, 64)):
+        hp.ppo_iter(frames[sl].contiguous(), actions[sl].contiguous(), old_logps[sl].contiguous(),
+                    advs[sl].contiguous(), rets[sl].contiguous(), b_global=64)
+        acc += hp.grads
+    n = hp.n_params
+    scale = full[:n].abs().max().item()
+    assert (acc[:n] - full[:n]).abs().max().item() <= 2e-6 * scale
+    np.testing.assert_allclose(acc[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_learn_sequence_golden_f4(hp, golden):
+    g, frames, actions, old_logps, advs, rets = _load_batch(golden)
+    g4 = golden("f4_learn")
+    hp.set_params(flatten(make_weights(0)))
+    hp.reset_optimizer()
+    lrs = {}
+    for name, _, _ in param_specs():
+        lrs[name] = 5e-5 if name.startswith("actor.") else 1e-3
+    for it in range(1, 11):
+        hp.ppo_iter(frames, actions, old_logps, advs, rets)
+        hp.clip_adam_step()
+        s = hp.stats()
+        row = g4["losses"][it - 1]
+        np.testing.assert_allclose([s["PpoTotalLoss"], s["ActorLoss"], s["VLoss"], s["EntLoss"]], row,
+                                   rtol=2e-4, atol=2e-5)
+        if it in (1, 10):
+            flat = hp.params.cpu().numpy()
+            off = 0
+            for name, shape, _ in param_specs():
+                n = int(np.prod(shape))
+                arr = flat[off:off + n]
+                off += n
+                tol = 0.02 * lrs[name] * it
+                want = g4["it%d/stride/%s" % (it, name)]
+                got = arr[::max(1, arr.size // 257)][:257]
+                bad = np.abs(got - want) > tol + 1e-6 * np.abs(want)
+                # Adam normalises by |g|: allow a handful of noise-floor elements to differ by O(lr)
+                assert bad.mean() <= 0.02, (name, it, np.abs(got - want).max(), tol)
+                assert np.abs(got - want).max() <= 2.5 * lrs[name] * it
+                np.testing.assert_allclose(arr.astype(np.float64).sum(), g4["it%d/sum/%s" % (it, name)],
+                                           rtol=1e-3, atol=max(1.0, arr.size ** 0.5) * lrs[name] * it)
+    assert hp.step == 10
+
+
+def test_clip_coefficient_and_norm(hp, onet, golden):
+    g, frames, actions, old_logps, advs, rets = _load_batch(golden)
+    hp.set_params(flatten(make_weights(0)))
+    hp.reset_optimizer()
+    hp.ppo_iter(frames, actions, old_logps, advs, rets)
+    gn = float(torch.linalg.vector_norm(hp.grads[:hp.n_params].double()).item())
+    hp.clip_adam_step()
+    s = hp.stats()
+    np.testing.assert_allclose(s["GradNorm"], gn, rtol=1e-6)
+    np.testing.assert_allclose(s["ClipCoef"], min(1.0, 0.5 / (gn + 1e-6)), rtol=1e-6)
