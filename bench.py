@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDRL4NAV actor-learner hot path on MI355X.
+
+One "step" = one full pass of the path over one rollout of synthetic Pong-shaped input, per GPU:
+  T=256 acting steps (forward both encoders + heads + sample) over N=256 envs,
+  one bootstrap forward, the GAE scan, and one PPO update = TRAINING_ITER_TIME=10 full-batch
+  iterations (forward + loss + backward + [all-reduce] + grad-norm clip + 2x Adam) on
+  B = N*T = 65,536 samples.  Frames are already resident in HBM (uint8 [T+1,N,4,84,84]).
+
+metric: env-steps/s for the whole job = n_gpus * N * T * steps / wall time (max over ranks).
+Prints ONE JSON line on rank 0 (see the contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work (restated in DESIGN.md)
+MAC = {"ConvFwd1": 32 * 400 * 256, "ConvFwd2": 64 * 81 * 512, "ConvFwd3": 64 * 49 * 576, "FcFwd": 512 * 3136,
+       "ConvWgrad1": 32 * 400 * 256, "ConvWgrad2": 64 * 81 * 512, "ConvWgrad3": 64 * 49 * 576, "FcWgrad": 512 * 3136,
+       "ConvDgrad2": 64 * 81 * 512, "ConvDgrad3": 64 * 49 * 576, "FcDgrad": 512 * 3136}
+FLOP_ACT_PER_STEP = 37_379_072          # per env-step, both encoders + heads
+FLOP_TRAIN_PER_SAMPLE = 99_030_016      # per sample per PPO iteration
+PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense f32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Reference-equivalent CPU path (the oracle: torch-CPU restatement pinned to the reference
+    by tests/golden) timed on this host: forward at n=256 and PPO iterations at B=1024."""
+    from ddrl4nav_amd.utils.recipe import make_weights
+    from oracle import ddrl_oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(1234)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    nf, B = 256, 1024
+    x = O.frames_to_f32(rng.integers(0, 256, size=(B, 4, 84, 84), dtype=np.uint8))
+    with torch.no_grad():
+        net(x[:nf])
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 or (time.perf_counter() - t0 < seconds_budget * 0.2 and reps < 20):
+            net(x[:nf])
+            reps += 1
+        t_fwd = (time.perf_counter() - t0) / reps / nf  # s per env-step
+    acts = torch.from_numpy(rng.integers(0, 6, size=B).astype(np.float32))
+    old = torch.full((B,), -1.79, dtype=torch.float32)
+    adv = torch.from_numpy(rng.normal(size=B).astype(np.float32))
+    ret = torch.from_numpy(rng.normal(size=B).astype(np.float32))
+    opt = net.make_optims()
+    gen = O.learn(net, opt, x, acts, old, adv, ret, iters=100)
+    next(gen)  # warm-up iteration
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 2 or (time.perf_counter() - t0 < seconds_budget * 0.8 and iters < 40):
+        next(gen)
+        iters += 1
+    t_iter = (time.perf_counter() - t0) / iters / B  # s per sample per iteration
+    per_env_step = t_fwd + 10 * t_iter
+    return {"value": 1.0 / per_env_step, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch-CPU fp32 restatement of PPO.forward/learn): forward n=256 x%d, "
+                      "PPO iteration B=1024 x%d; per env-step = 1 forward + 10 iterations" % (reps, iters),
+            "forward_samples_per_s": 1.0 / t_fwd, "ppo_iter_ms_B1024": t_iter * B * 1e3, "host_cpus": cores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=256, help="envs per GPU (BASELINE config 2/3)")
+    ap.add_argument("--horizon", type=int, default=256, help="TIME_MAX")
+    ap.add_argument("--iters", type=int, default=10, help="TRAINING_ITER_TIME")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from ddrl4nav_amd.engine import HotPath, Timer
+    from ddrl4nav_amd.utils.recipe import flatten, make_weights
+
+    N, T, ITERS = args.envs, args.horizon, args.iters
+    B = N * T
+    hp = HotPath(max_batch=B, device=dev)
+    hp.set_params(flatten(make_weights(0)))
+    hp.profile(True)
+
+    # ---- synthetic rollout inputs, resident in HBM before the timed region ----
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    frames = torch.randint(0, 256, (T + 1, N, 4, 84, 84), dtype=torch.uint8, device=dev, generator=g)
+    u = torch.rand((T, N), device=dev, generator=g)
+    rewards = torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)).to(torch.float32).contiguous()
+    dones = (torch.rand((T, N), device=dev, generator=g) < (1.0 / 800)).to(torch.uint8).contiguous()
+    values = torch.empty((T + 1, N), dtype=torch.float32, device=dev)
+    actions = torch.empty((T, N), dtype=torch.float32, device=dev)
+    logps = torch.empty((T, N), dtype=torch.float32, device=dev)
+    probs = torch.empty((N, 6), dtype=torch.float32, device=dev)
+    adv = torch.empty((T, N), dtype=torch.float32, device=dev)
+    ret = torch.empty((T, N), dtype=torch.float32, device=dev)
+    frames_flat = frames[:T].reshape(B, 4, 84, 84)
+
+    t_act, t_gae, t_upd = Timer(), Timer(), Timer()
+    phase = {"act_ms": 0.0, "gae_ms": 0.0, "update_ms": 0.0}
+
+    def one_step(step_idx, timed):
+        t_act.start()
+        for t in range(T):
+            hp.forward(frames[t], seed=step_idx, stream_id=t, probs=probs, value=values[t], action=actions[t],
+                       logp=logps[t])
+        hp.forward(frames[T], seed=step_idx, stream_id=T, probs=probs, value=values[T], action=actions[0].clone(),
+                   logp=logps[0].clone())
+        t_act.stop()
+        t_gae.start()
+        hp.gae(values, rewards, dones, adv=adv, ret=ret)
+        t_gae.stop()
+        t_upd.start()
+        for _ in range(ITERS):
+            hp.ppo_iter(frames_flat, actions.view(-1), logps.view(-1), adv.view(-1), ret.view(-1), b_global=B * world)
+            hp.allreduce_grads()
+            hp.clip_adam_step()
+        t_upd.stop()
+        if timed:
+            torch.cuda.synchronize()
+            phase["act_ms"] += t_act.elapsed_ms()
+            phase["gae_ms"] += t_gae.elapsed_ms()
+            phase["update_ms"] += t_upd.elapsed_ms()
+
+    for w in range(args.warmup):
+        one_step(w, False)
+    torch.cuda.synchronize()
+    hp.profile(False)
+    hp.profile_read()
+    hp.profile(True)  # reset accumulators: per-kernel times cover the timed region only
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(args.warmup + s, True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    stats = hp.stats()
+    prof = hp.profile_read()
+
+    if rank == 0:
+        steps = args.steps
+        env_steps = world * N * T * steps
+        value = env_steps / elapsed
+        # dominant kernel = largest accumulated time among the GEMM-shaped kernels
+        gemm = {k: v for k, v in prof.items() if k in MAC}
+        dom = max(gemm, key=lambda k: gemm[k][0]) if gemm else None
+        kernels = {}
+        for k, (ms, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+            ent = {"ms_total": round(ms, 3), "calls": calls, "ms_avg": round(ms / max(calls, 1), 4)}
+            if k in MAC:
+                # launches inside ppo_iter process B samples, acting launches N samples; both encoders
+                train_calls = steps * ITERS
+                act_calls = calls - train_calls if k.endswith(("Fwd1", "Fwd2", "Fwd3", "FcFwd")) else 0
+                flop = 2.0 * 2 * MAC[k] * (B * train_calls + N * max(act_calls, 0))
+                ent["tflops"] = round(flop / (ms * 1e-3) / 1e12, 2)
+            kernels[k] = ent
+        roofline = None
+        if dom is not None:
+            ms, calls = gemm[dom]
+            is_fwd = dom.endswith(("Fwd1", "Fwd2", "Fwd3", "FcFwd"))
+            flop_total = 2.0 * 2 * MAC[dom] * (B * steps * ITERS + (N * (calls - steps * ITERS) if is_fwd else 0))
+            achieved = flop_total / (ms * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(ms / calls, 4), "launches": calls,
+                        "flop_per_sample_per_launch": 2 * 2 * MAC[dom]}
+        upd_ms = phase["update_ms"] / steps
+        total_flop = env_steps / world * (FLOP_ACT_PER_STEP + ITERS * FLOP_TRAIN_PER_SAMPLE)
+        out = {
+            "metric": "env-steps/sec (whole node) + PPO update ms, Pong 256 envs at 1/2/4/8 GPUs",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PongNoFrameskip-v4 shape, %d envs/GPU x T=%d, %d PPO iterations on B=%d samples/GPU, "
+                                   "2 AtariPreNet encoders (SHARE_CNN_NET=False), A=6" % (N, T, ITERS, B),
+                       "envs_per_gpu": N, "horizon": T, "ppo_iters": ITERS, "parallelism": "dp%d" % world},
+            "ppo_update_ms": round(upd_ms, 2), "ppo_iter_ms": round(upd_ms / ITERS, 3),
+            "acting_ms_per_rollout": round(phase["act_ms"] / steps, 2), "gae_ms": round(phase["gae_ms"] / steps, 4),
+            "acting_env_steps_per_s_per_gpu": round(N * (T + 1) / (phase["act_ms"] / steps * 1e-3), 1),
+            "whole_step_tflops_per_gpu": round(total_flop / elapsed / 1e12, 2),
+            "last_losses": stats, "roofline": roofline, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    hp.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

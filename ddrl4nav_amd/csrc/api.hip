@@ -17,7 +17,7 @@ struct ProfEntry {
   hipEvent_t a, b;
 };
 
-struct ddrl_ctx {
+struct ddrl_ctx : public ddrl::Profiler {
   ddrl_config cfg;
   ParamLayout L;
   Workspace ws;
@@ -31,6 +31,17 @@ struct ddrl_ctx {
   std::vector<std::string> prof_names;
   std::vector<double> prof_ms;
   std::vector<int> prof_calls;
+  ProfEntry cur;
+  void begin(const char* name, hipStream_t st) override {
+    cur.name = name;
+    hipEventCreate(&cur.a);
+    hipEventCreate(&cur.b);
+    hipEventRecord(cur.a, st);
+  }
+  void end(hipStream_t st) override {
+    hipEventRecord(cur.b, st);
+    prof_pending.push_back(cur);
+  }
 };
 
 #define HIP_TRY(expr)                        \
@@ -44,26 +55,6 @@ static int32_t check_launch() {
   return e == hipSuccess ? DDRL_OK : DDRL_ERR_HIP;
 }
 
-namespace {
-struct ProfScope {
-  ddrl_ctx* c;
-  hipStream_t st;
-  ProfEntry e;
-  bool on;
-  ProfScope(ddrl_ctx* ctx, const char* name, hipStream_t s) : c(ctx), st(s), on(ctx->profile) {
-    if (!on) return;
-    e.name = name;
-    hipEventCreate(&e.a);
-    hipEventCreate(&e.b);
-    hipEventRecord(e.a, st);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    hipEventRecord(e.b, st);
-    c->prof_pending.push_back(e);
-  }
-};
-}  // namespace
 
 extern "C" {
 
@@ -190,7 +181,7 @@ int32_t ddrl_set_step(ddrl_ctx* ctx, int64_t step) {
 
 static void ensure_packed(ddrl_ctx* ctx, hipStream_t st) {
   if (!ctx->dirty) return;
-  ProfScope ps(ctx, "pack_weights", st);
+  ProfRange ps(ctx->profile ? ctx : nullptr, "pack_weights", st);
   launch_pack_weights(ctx->ws, ctx->L, ctx->params, st);
   ctx->dirty = false;
 }
@@ -201,14 +192,11 @@ int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const floa
   if (n < 1 || n > ctx->cfg.max_batch) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
-  EncCall ec{&ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
-  {
-    ProfScope ps(ctx, "encoder_forward", st);
-    launch_encoder_forward(ec, st);
-  }
+  EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  launch_encoder_forward(ec, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, n, ctx->cfg.max_batch};
   {
-    ProfScope ps(ctx, "heads_act", st);
+    ProfRange ps(ctx->profile ? ctx : nullptr, "heads_act", st);
     launch_heads_act(hc, act_in, seed, stream_id, probs, value, action_out, logp_out, st);
   }
   ctx->last_n = n;
@@ -246,20 +234,14 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   if (B < 1 || B > ctx->cfg.max_batch || B_global < B) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
-  EncCall ec{&ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
-  {
-    ProfScope ps(ctx, "encoder_forward", st);
-    launch_encoder_forward(ec, st);
-  }
+  EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
+  launch_encoder_forward(ec, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, B, ctx->cfg.max_batch};
   {
-    ProfScope ps(ctx, "heads_loss", st);
+    ProfRange ps(ctx->profile ? ctx : nullptr, "heads_loss", st);
     launch_heads_loss(hc, actions, old_logps, advs, rets, (float)(1.0 / (double)B_global), ctx->grads, st);
   }
-  {
-    ProfScope ps(ctx, "encoder_backward", st);
-    launch_encoder_backward(ec, ctx->grads, st);
-  }
+  launch_encoder_backward(ec, ctx->grads, st);
   ctx->last_n = B;
   return check_launch();
 }
@@ -269,7 +251,7 @@ int32_t ddrl_clip_adam_step(ddrl_ctx* ctx, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   ctx->step += 1;
   {
-    ProfScope ps(ctx, "clip_adam", st);
+    ProfRange ps(ctx->profile ? ctx : nullptr, "clip_adam", st);
     launch_clip_adam(ctx->cfg, ctx->L, ctx->ws, ctx->params, ctx->grads, ctx->m, ctx->v, ctx->step, st);
   }
   ctx->dirty = true;
@@ -471,6 +453,11 @@ int32_t ddrl_timer_elapsed_ms(void* t, float* ms) {
 
 int32_t ddrl_profile_enable(ddrl_ctx* ctx, int32_t on) {
   if (!ctx) return DDRL_ERR_INVALID_ARG;
+  if (on && !ctx->profile) {
+    ctx->prof_names.clear();
+    ctx->prof_ms.clear();
+    ctx->prof_calls.clear();
+  }
   ctx->profile = on != 0;
   return DDRL_OK;
 }

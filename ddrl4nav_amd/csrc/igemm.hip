@@ -630,27 +630,37 @@ void launch_encoder_forward(const EncCall& c, hipStream_t st) {
   {
     ConvFwdOp<1>::Params p{c.frames, 0, w.wt1, c.params, {c.L->enc_base[0] + c.L->enc.c1b, c.L->enc_base[1] + c.L->enc.c1b},
                            w.a1, MB * 32 * 400, n};
+    ProfRange pr(c.prof, "ConvFwd1", st);
     hipLaunchKernelGGL(igemm_kernel<ConvFwdOp<1>>, dim3(cdiv((int64_t)n * C1_P, 256), 1, 2), dim3(256), 0, st, p);
   }
   {
     ConvFwdOp<2>::Params p{w.a1, MB * 32 * 400, w.wt2, c.params, {c.L->enc_base[0] + c.L->enc.c2b, c.L->enc_base[1] + c.L->enc.c2b},
                            w.a2, MB * 64 * 81, n};
+    ProfRange pr(c.prof, "ConvFwd2", st);
     hipLaunchKernelGGL(igemm_kernel<ConvFwdOp<2>>, dim3(cdiv((int64_t)n * C2_P, 256), 1, 2), dim3(256), 0, st, p);
   }
   {
     ConvFwdOp<3>::Params p{w.a2, MB * 64 * 81, w.wt3, c.params, {c.L->enc_base[0] + c.L->enc.c3b, c.L->enc_base[1] + c.L->enc.c3b},
                            w.a3, MB * FLAT, n};
+    ProfRange pr(c.prof, "ConvFwd3", st);
     hipLaunchKernelGGL(igemm_kernel<ConvFwdOp<3>>, dim3(cdiv((int64_t)n * C3_P, 256), 1, 2), dim3(256), 0, st, p);
   }
   {
     FcFwdOp::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
                       w.h, MB * FEAT, n};
+    ProfRange pr(c.prof, "FcFwd", st);
     hipLaunchKernelGGL(igemm_kernel<FcFwdOp>, dim3(FEAT / 128, cdiv(n, 128), 2), dim3(256), 0, st, p);
   }
 }
 
 // Backward of both encoders given dh[e][n][512]; leaves split-K partial slabs reduced into the
 // grad arena by reduce_partials (optim.hip).
+#define PROF(name, stmt)              \
+  do {                                 \
+    ProfRange _pr(c.prof, name, st);   \
+    stmt;                              \
+  } while (0)
+
 void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -660,42 +670,42 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
   // ---- FC ----
   {
     FcWgradOp::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, n, S.fc};
-    hipLaunchKernelGGL(igemm_kernel<FcWgradOp>, dim3(cdiv(FLAT, 128), FEAT / 128, 2 * S.fc), dim3(256), 0, st, p);
-    launch_reduce_partials(w.wpart, S.fc, (int64_t)FEAT * FLAT, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
-    launch_colsum(w.dh, MB * FEAT, n, FEAT, 1, w.bpart, grads, L.enc_base[0] + L.enc.lb, L.enc_base[1] + L.enc.lb, st);
+    PROF("FcWgrad", hipLaunchKernelGGL(igemm_kernel<FcWgradOp>, dim3(cdiv(FLAT, 128), FEAT / 128, 2 * S.fc), dim3(256), 0, st, p));
+    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.fc, (int64_t)FEAT * FLAT, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st));
+    PROF("bias_colsum", launch_colsum(w.dh, MB * FEAT, n, FEAT, 1, w.bpart, grads, L.enc_base[0] + L.enc.lb, L.enc_base[1] + L.enc.lb, st));
   }
   {
     FcDgradOp::Params p{w.dh, MB * FEAT, c.params, {L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw}, w.a3, w.dz3, MB * FLAT, n};
-    hipLaunchKernelGGL(igemm_kernel<FcDgradOp>, dim3(cdiv(FLAT, 128), cdiv(n, 128), 2), dim3(256), 0, st, p);
+    PROF("FcDgrad", hipLaunchKernelGGL(igemm_kernel<FcDgradOp>, dim3(cdiv(FLAT, 128), cdiv(n, 128), 2), dim3(256), 0, st, p));
   }
   // ---- conv3 ----
   {
     ConvWgradOp<3>::Params p{w.a2, MB * 64 * 81, w.dz3, MB * FLAT, w.wpart, n, S.c3};
-    hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<3>>, dim3(cdiv(C3_K, 128), S.c3, 2), dim3(256), 0, st, p);
-    launch_reduce_partials(w.wpart, S.c3, (int64_t)64 * C3_K, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);
-    launch_colsum(w.dz3, MB * FLAT, n, 64, C3_P, w.bpart, grads, L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b, st);
+    PROF("ConvWgrad3", hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<3>>, dim3(cdiv(C3_K, 128), S.c3, 2), dim3(256), 0, st, p));
+    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c3, (int64_t)64 * C3_K, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st));
+    PROF("bias_colsum", launch_colsum(w.dz3, MB * FLAT, n, 64, C3_P, w.bpart, grads, L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b, st));
   }
   {
     ConvDgrad3Op::Params p{w.dz3, MB * FLAT, w.wd3, w.a2, w.dz2, MB * 64 * 81, n};
-    hipLaunchKernelGGL(igemm_kernel<ConvDgrad3Op>, dim3(cdiv((int64_t)n * C2_P, 256), 1, 2), dim3(256), 0, st, p);
+    PROF("ConvDgrad3", hipLaunchKernelGGL(igemm_kernel<ConvDgrad3Op>, dim3(cdiv((int64_t)n * C2_P, 256), 1, 2), dim3(256), 0, st, p));
   }
   // ---- conv2 ----
   {
     ConvWgradOp<2>::Params p{w.a1, MB * 32 * 400, w.dz2, MB * 64 * 81, w.wpart, n, S.c2};
-    hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<2>>, dim3(cdiv(C2_K, 128), S.c2, 2), dim3(256), 0, st, p);
-    launch_reduce_partials(w.wpart, S.c2, (int64_t)64 * C2_K, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
-    launch_colsum(w.dz2, MB * 64 * 81, n, 64, C2_P, w.bpart, grads, L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b, st);
+    PROF("ConvWgrad2", hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<2>>, dim3(cdiv(C2_K, 128), S.c2, 2), dim3(256), 0, st, p));
+    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c2, (int64_t)64 * C2_K, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st));
+    PROF("bias_colsum", launch_colsum(w.dz2, MB * 64 * 81, n, 64, C2_P, w.bpart, grads, L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b, st));
   }
   {
     ConvDgrad2Op::Params p{w.dz2, MB * 64 * 81, w.wd2, w.a1, w.dz1, MB * 32 * 400, n};
-    hipLaunchKernelGGL(igemm_kernel<ConvDgrad2Op>, dim3(cdiv((int64_t)n * 100, 256), 4, 2), dim3(256), 0, st, p);
+    PROF("ConvDgrad2", hipLaunchKernelGGL(igemm_kernel<ConvDgrad2Op>, dim3(cdiv((int64_t)n * 100, 256), 4, 2), dim3(256), 0, st, p));
   }
   // ---- conv1 (no data gradient: the frames are leaves) ----
   {
     ConvWgradOp<1>::Params p{c.frames, 0, w.dz1, MB * 32 * 400, w.wpart, n, S.c1};
-    hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<1>>, dim3(cdiv(256, 128), S.c1, 2), dim3(256), 0, st, p);
-    launch_reduce_partials(w.wpart, S.c1, (int64_t)32 * 256, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
-    launch_colsum(w.dz1, MB * 32 * 400, n, 32, C1_P, w.bpart, grads, L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b, st);
+    PROF("ConvWgrad1", hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<1>>, dim3(cdiv(256, 128), S.c1, 2), dim3(256), 0, st, p));
+    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c1, (int64_t)32 * 256, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st));
+    PROF("bias_colsum", launch_colsum(w.dz1, MB * 32 * 400, n, 32, C1_P, w.bpart, grads, L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b, st));
   }
 }
 

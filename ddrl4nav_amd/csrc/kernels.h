@@ -4,7 +4,25 @@
 
 namespace ddrl {
 
+// per-kernel HIP-event ranges (diagnostic; null when profiling is off)
+struct Profiler {
+  virtual void begin(const char* name, hipStream_t st) = 0;
+  virtual void end(hipStream_t st) = 0;
+  virtual ~Profiler() {}
+};
+struct ProfRange {
+  Profiler* p;
+  hipStream_t st;
+  ProfRange(Profiler* p_, const char* name, hipStream_t s) : p(p_), st(s) {
+    if (p) p->begin(name, s);
+  }
+  ~ProfRange() {
+    if (p) p->end(st);
+  }
+};
+
 struct EncCall {
+  Profiler* prof;
   const Workspace* ws;
   const ParamLayout* L;
   const Splits* splits;

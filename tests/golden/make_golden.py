@@ -231,6 +231,25 @@ def main():
                 a = p.detach().numpy().reshape(-1)
                 out["it%d/stride/%s" % (it, k)] = a[::max(1, a.size // 257)][:257].copy()
     out["losses"] = np.asarray(losses, np.float64)
+    # The same reference code in float64 and with another intra-op thread count: the spread
+    # between these runs is the reference's OWN sensitivity to summation order over the 10
+    # Adam steps, and is what bounds the tolerance of the sequence test.
+    for tag, dtype, threads in (("f64", torch.float64, 1), ("f32t8", torch.float32, 8)):
+        torch.set_num_threads(threads)
+        net.to(torch.float32)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.items()}, strict=True)
+        net.to(dtype)
+        net.update_time = 0
+        net.actor_optim = torch.optim.Adam(net.actor.parameters(), cfg_nn.ACTOR_LEARNING_RATE)
+        net.critic_optim = torch.optim.Adam(net.critic.parameters(), cfg_nn.CRITIC_LEARNING_RATE)
+        exp2 = Experience(states=[xb.numpy()], advs=advs.numpy(), actions=actions.numpy(),
+                          old_logps=old_logps.numpy(), values=rets.numpy().reshape(1, B))
+        exp2.to_tensor(dtype=dtype, device="cpu")
+        rows = [[ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]] for ld, _, _ in net.learn(exp2)]
+        out["losses_" + tag] = np.asarray(rows, np.float64)
+    torch.set_num_threads(1)
+    net.to(torch.float32)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.items()}, strict=True)
     np.savez(os.path.join(HERE, "f4_learn.npz"), **out)
 
     # ---------------- F6: episode-return accumulator ---------------------------------------
