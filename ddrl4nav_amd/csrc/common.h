@@ -67,6 +67,9 @@ struct Workspace {
   float* wd3;  // [2][576 (oc,ky,kx)][64 ic]    conv3 dgrad A operand
   float* wd2;  // [2][4 cls][256 (oc,u,v)][32 ic] conv2 dgrad A operand per parity class
   float* wlt;  // [2][3136][512]    FC fwd B operand
+  // v2 packed weights: [k-block][k-step][lane half][row], see conv2.hip / wgrad2.hip
+  float *wp1, *wp2, *wp3, *wd3p, *wd2p;
+  float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
   float *dz1, *dz2, *dz3, *dh;
@@ -122,6 +125,12 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wd3 = take(2 * 576 * 64);
   w.wd2 = take(2 * 4 * 256 * 32);
   w.wlt = take(2 * (int64_t)FLAT * FEAT);
+  w.wln = take(2 * (int64_t)FLAT * FEAT);
+  w.wp1 = take(4 * 32 * 2 * 64);
+  w.wp2 = take(2 * 16 * 16 * 2 * 64);
+  w.wp3 = take(2 * 16 * 18 * 2 * 64);
+  w.wd3p = take(2 * 16 * 18 * 2 * 64);
+  w.wd2p = take(2 * 8 * 16 * 2 * 128);
   w.a1 = take(2 * MB * 32 * 400);
   w.a2 = take(2 * MB * 64 * 81);
   w.a3 = take(2 * MB * FLAT);
@@ -133,10 +142,11 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.dlogits = take(MB * A);
   w.dvalue = take(MB);
   Splits s = choose_splits(c.max_batch);
-  int64_t p1 = (int64_t)s.c1 * 2 * (32 * C * 64);
-  int64_t p2 = (int64_t)s.c2 * 2 * (64 * 512);
-  int64_t p3 = (int64_t)s.c3 * 2 * (64 * 576);
-  int64_t pf = (int64_t)s.fc * 2 * ((int64_t)FEAT * FLAT);
+  // slabs hold weights followed by bias, like the arena
+  int64_t p1 = (int64_t)s.c1 * 2 * (32 * C * 64 + 32);
+  int64_t p2 = (int64_t)s.c2 * 2 * (64 * 512 + 64);
+  int64_t p3 = (int64_t)s.c3 * 2 * (64 * 576 + 64);
+  int64_t pf = (int64_t)s.fc * 2 * ((int64_t)FEAT * FLAT + FEAT);
   int64_t pm = p1;
   if (p2 > pm) pm = p2;
   if (p3 > pm) pm = p3;

@@ -1,0 +1,574 @@
+// v2 convolution kernels: forward and data-gradient as "direct convolution from an LDS image",
+// on the pipelined f32-MFMA engine (engine2.h).
+//
+// Instead of gathering an im2col tile, a workgroup stages the RAW input planes it needs
+// (coalesced 16-byte loads, each element fetched once per k-block) and every MFMA B operand is
+// one ds_read_b32 at  lane_base + immediate :
+//     lane_base  = position of the lane's output pixel inside the staged planes (+ hi * delta)
+//     immediate  = offset of the (channel, tap) of k-step s          (compile-time constant)
+// The two k indices of one 32x32x2 MFMA (lane halves) are always two adjacent input CHANNELS
+// of the same tap (delta = plane size), or two adjacent taps for conv1 (delta = one x-plane),
+// so a single per-lane base serves the whole k loop.  Weights are pre-packed per k-block in
+// exactly that order by pack_weights2 (optim.hip).
+//
+// Reference arithmetic: F.conv2d + F.leaky_relu (USTC_lab/nn/atari_encoder.py:26-28) and the
+// autograd data-gradients of conv3 / conv2 (ppo.py:122-123).
+#include "engine2.h"
+
+namespace ddrl {
+
+__device__ __forceinline__ void st4(float* p, const float4& v) { *(float4*)p = v; }
+
+// ================================================================================================
+// conv2 forward: a1 [e][n][32][20][20] -> a2 [e][n][64][9][9], k4 s2.   rows = oc (64),
+// cols = b*81+pix (256 per workgroup, <= 5 samples), k-block = 2 input channels x 16 taps.
+// ================================================================================================
+struct ConvFwd2v2 {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
+  static constexpr int NS = 5, W_FLOATS = 32 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 2 * 400;
+  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  struct Params {
+    const float* in;  // a1
+    int64_t in_es;
+    const float* wp;  // [e][16][16][2][64]
+    const float* params;
+    int64_t bias_off[2];
+    float* out;  // a2
+    int64_t out_es;
+    int n;
+  };
+  struct Regs {
+    float4 w[2], im[4];
+  };
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int e, c0, b_first, l31, hi, wc;
+  const float* in;
+  const float* wp;
+  static constexpr int aoff(int s) { return 2 * s * 64; }
+  static constexpr int boff(int s) { return (s / 4) * 20 + (s % 4); }
+  __device__ void init(const Params& p, int tid, float*) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    e = blockIdx.z;
+    c0 = blockIdx.x * 256;
+    b_first = c0 / 81;
+    kb_begin = 0;
+    kb_end = 16;
+    in = p.in + e * p.in_es;
+    wp = p.wp + (int64_t)e * 16 * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 81) c = c0;
+      const int b = c / 81, pix = c % 81;
+      bbase[j] = IMG_OFF + (b - b_first) * 800 + (pix / 9) * 40 + (pix % 9) * 2 + hi * 400;
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r.w[j] = *(const float4*)(wp + kb * 2048 + (tid + 256 * j) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      const int bl = idx / 200, q = idx % 200;
+      const int b = b_first + bl;
+      r.im[j] = (idx < NS * 200 && b < p.n) ? *(const float4*)(in + (int64_t)b * 12800 + kb * 800 + q * 4)
+                                            : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NS * 200) st4(buf + IMG_OFF + idx * 4, r.im[j]);
+    }
+  }
+  __device__ void extra(const float*) {}
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 81) continue;
+      const int b = c / 81, pix = c % 81;
+      float* dst = p.out + e * p.out_es + (int64_t)b * 5184 + pix;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int oc = i * 32 + acc_row(r, hi);
+          dst[oc * 81] = leaky_f(acc[i][j][r] + p.params[p.bias_off[e] + oc]);
+        }
+    }
+  }
+};
+
+// ================================================================================================
+// conv3 forward: a2 [e][n][64][9][9] -> a3 [e][n][64][7][7], k3 s1.   rows = oc (64),
+// cols = b*49+pix (<= 7 samples), k-block = 4 input channels x 9 taps (pairs = channels).
+// ================================================================================================
+struct ConvFwd3v2 {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 18;
+  static constexpr int NS = 7, W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = 2272;  // 7*4*81 = 2268
+  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  struct Params {
+    const float* in;  // a2
+    int64_t in_es;
+    const float* wp;  // [e][16][18][2][64]
+    const float* params;
+    int64_t bias_off[2];
+    float* out;  // a3
+    int64_t out_es;
+    int n;
+  };
+  struct Regs {
+    float4 w[3], im[3];
+  };
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int e, c0, b_first, l31, hi, wc;
+  const float* in;
+  const float* wp;
+  static constexpr int aoff(int s) { return 2 * s * 64; }
+  static constexpr int boff(int s) { return (s / 9) * 162 + ((s % 9) / 3) * 9 + (s % 3); }
+  __device__ void init(const Params& p, int tid, float*) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    e = blockIdx.z;
+    c0 = blockIdx.x * 256;
+    b_first = c0 / 49;
+    kb_begin = 0;
+    kb_end = 16;
+    in = p.in + e * p.in_es;
+    wp = p.wp + (int64_t)e * 16 * 2304;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 49) c = c0;
+      const int b = c / 49, pix = c % 49;
+      bbase[j] = IMG_OFF + (b - b_first) * 324 + (pix / 7) * 9 + (pix % 7) + hi * 81;
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      r.w[j] = (idx < 576) ? *(const float4*)(wp + kb * 2304 + idx * 4) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      const int bl = idx / 81, q = idx % 81;
+      const int b = b_first + bl;
+      r.im[j] = (idx < NS * 81 && b < p.n) ? *(const float4*)(in + (int64_t)b * 5184 + kb * 324 + q * 4)
+                                           : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 576) st4(buf + idx * 4, r.w[j]);
+      if (idx < NS * 81) st4(buf + IMG_OFF + idx * 4, r.im[j]);
+    }
+  }
+  __device__ void extra(const float*) {}
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 49) continue;
+      const int b = c / 49, pix = c % 49;
+      float* dst = p.out + e * p.out_es + (int64_t)b * FLAT + pix;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int oc = i * 32 + acc_row(r, hi);
+          dst[oc * 49] = leaky_f(acc[i][j][r] + p.params[p.bias_off[e] + oc]);
+        }
+    }
+  }
+};
+
+// ================================================================================================
+// conv1 forward, BOTH encoders in one GEMM (they read the same frames): rows = (e, oc) = 64,
+// cols = b*400+pix (256 per workgroup, <= 2 samples), k-block = one input channel (64 taps),
+// MFMA k pairs = (kx, kx+1).  The uint8 rows are converted with u8_unit() while being written to
+// LDS, de-interleaved by x mod 4 so that a stride-4 tap walk is bank-conflict free:
+//     pixel (row lr, x)  ->  lr*84 + (x&3)*21 + (x>>2)
+// ================================================================================================
+struct ConvFwd1v2 {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 32;
+  static constexpr int W_FLOATS = 64 * 64, IMG_OFF = W_FLOATS, IMG_ROWS = 64, IMG_FLOATS = IMG_ROWS * 84;
+  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  struct Params {
+    const uint8_t* frames;
+    const float* wp;  // [4][32][2][64]
+    const float* params;
+    int64_t bias_off[2];
+    float* out;  // a1 [e][n][32][400]
+    int64_t out_es;
+    int n;
+  };
+  struct Regs {
+    float4 w[4];
+    unsigned im[6];
+  };
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int c0, l31, hi, wc;
+  int b0, nd0, nd_total;     // dwords of part 0 / both parts
+  int64_t src0, src1;        // byte offsets of the two row ranges inside channel 0
+  static constexpr int aoff(int s) { return 2 * s * 64; }
+  static constexpr int boff(int s) { return (s / 4) * 84 + ((2 * (s % 4)) & 3) * 21 + ((2 * (s % 4)) >> 2); }
+  __device__ void init(const Params& p, int tid, float*) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    c0 = blockIdx.x * 256;
+    kb_begin = 0;
+    kb_end = 4;
+    const int ctot = p.n * 400;
+    const int clast = min(c0 + 255, ctot - 1);
+    b0 = c0 / 400;
+    const int b1 = clast / 400;
+    const int oyf0 = (c0 % 400) / 20;
+    int iy0_start = 4 * oyf0, nrows0, nrows1 = 0;
+    if (b1 == b0) {
+      nrows0 = 4 * ((clast % 400) / 20 - oyf0) + 8;
+    } else {
+      nrows0 = 84 - iy0_start;
+      nrows1 = 4 * ((clast % 400) / 20) + 8;
+    }
+    nd0 = nrows0 * 21;
+    nd_total = nd0 + nrows1 * 21;
+    src0 = (int64_t)b0 * 28224 + iy0_start * 84;
+    src1 = (int64_t)b1 * 28224;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= ctot) c = c0;
+      const int b = c / 400, pix = c % 400;
+      const int oy = pix / 20, ox = pix % 20;
+      const int lr = (b == b0) ? (4 * oy - iy0_start) : (nrows0 + 4 * oy);
+      bbase[j] = IMG_OFF + lr * 84 + ox + hi * 21;
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.w[j] = *(const float4*)(p.wp + kb * 4096 + (tid + 256 * j) * 4);
+    const uint8_t* ch = p.frames + kb * 7056;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = tid + 256 * j;
+      unsigned v = 0;
+      if (idx < nd_total) v = (idx < nd0) ? *(const unsigned*)(ch + src0 + idx * 4) : *(const unsigned*)(ch + src1 + (idx - nd0) * 4);
+      r.im[j] = v;
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < nd_total) {
+        const int lr = idx / 21, xq = idx % 21;
+        float* d = buf + IMG_OFF + lr * 84 + xq;
+        const unsigned v = r.im[j];
+        d[0] = u8_unit(v & 255u);
+        d[21] = u8_unit((v >> 8) & 255u);
+        d[42] = u8_unit((v >> 16) & 255u);
+        d[63] = u8_unit(v >> 24);
+      }
+    }
+  }
+  __device__ void extra(const float*) {}
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 400) continue;
+      const int b = c / 400, pix = c % 400;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {  // i = encoder
+        float* dst = p.out + i * p.out_es + (int64_t)b * 12800 + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int oc = acc_row(r, hi);
+          dst[oc * 400] = leaky_f(acc[i][j][r] + p.params[p.bias_off[i] + oc]);
+        }
+      }
+    }
+  }
+};
+
+// ================================================================================================
+// conv3 data gradient: dz3 [e][n][64][7][7] -> dz2 [e][n][64][9][9]
+//   dz2[b][ic][iy][ix] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][iy-ky][ix-kx] W3[oc][ic][ky][kx]
+// rows = ic (64), cols = b*81 + iy*9 + ix (<= 5 samples), k-block = 4 oc x 9 taps; the dz3 planes
+// sit in zero-padded 11x11 LDS images (data at +2,+2), so no tap needs a bounds test.
+// ================================================================================================
+struct ConvDgrad3v2 {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 18;
+  static constexpr int NS = 5, W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = 2432;  // 5*4*121 = 2420
+  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  struct Params {
+    const float* dz;  // dz3
+    int64_t dz_es;
+    const float* wp;   // [e][16][18][2][64 ic]
+    const float* act;  // a2
+    float* out;        // dz2
+    int64_t out_es;
+    int n;
+  };
+  struct Regs {
+    float4 w[3], im;
+  };
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int e, c0, b_first, l31, hi, wc;
+  const float* dz;
+  const float* wp;
+  static constexpr int aoff(int s) { return 2 * s * 64; }
+  static constexpr int boff(int s) { return (s / 9) * 242 + (2 - (s % 9) / 3) * 11 + (2 - (s % 3)); }
+  __device__ void init(const Params& p, int tid, float* lds) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    e = blockIdx.z;
+    c0 = blockIdx.x * 256;
+    b_first = c0 / 81;
+    kb_begin = 0;
+    kb_end = 16;
+    dz = p.dz + e * p.dz_es;
+    wp = p.wp + (int64_t)e * 16 * 2304;
+    for (int i = tid; i < IMG_FLOATS; i += 256) {
+      lds[IMG_OFF + i] = 0.0f;
+      lds[STAGE + IMG_OFF + i] = 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 81) c = c0;
+      const int b = c / 81, pix = c % 81;
+      bbase[j] = IMG_OFF + (b - b_first) * 484 + (pix / 9) * 11 + (pix % 9) + hi * 121;
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      r.w[j] = (idx < 576) ? *(const float4*)(wp + kb * 2304 + idx * 4) : make_float4(0, 0, 0, 0);
+    }
+    const int bl = tid / 49, q = tid % 49;
+    const int b = b_first + bl;
+    r.im = (tid < NS * 49 && b < p.n) ? *(const float4*)(dz + (int64_t)b * FLAT + kb * 196 + q * 4) : make_float4(0, 0, 0, 0);
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 576) st4(buf + idx * 4, r.w[j]);
+    }
+    if (tid < NS * 49) {
+      const int bl = tid / 49, q = tid % 49;
+      const float v[4] = {r.im.x, r.im.y, r.im.z, r.im.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int el = q * 4 + i;
+        const int cc = el / 49, rr = el % 49;
+        buf[IMG_OFF + (bl * 4 + cc) * 121 + (rr / 7 + 2) * 11 + (rr % 7) + 2] = v[i];
+      }
+    }
+  }
+  __device__ void extra(const float*) {}
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 81) continue;
+      const int b = c / 81, pix = c % 81;
+      const int64_t base = e * p.out_es + (int64_t)b * 5184 + pix;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t idx = base + (i * 32 + acc_row(r, hi)) * 81;
+          p.out[idx] = leaky_g(p.act[idx], acc[i][j][r]);
+        }
+    }
+  }
+};
+
+// ================================================================================================
+// conv2 data gradient, the four input-parity classes in ONE GEMM (they share the dz2 image and
+// the tap offsets; only the weights differ):
+//   dz1[b][ic][2p+a][2q+c] = leaky'(a1) * sum_{oc,u,v} dz2[b][oc][p-u][q-v] W2[oc][ic][2u+a][2v+c]
+// rows = (cls=a*2+c, ic) = 128, cols = b*100 + p*10 + q (<= 4 samples), k-block = 8 oc x 4 taps.
+// dz2 planes sit in zero-padded 11x11 LDS images (data at +1,+1).
+// ================================================================================================
+struct ConvDgrad2v2 {
+  static constexpr int THREADS = 256, TM = 4, TN = 2, KSTEPS = 16;
+  static constexpr int NS = 4, W_FLOATS = 32 * 128, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 8 * 121;
+  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  struct Params {
+    const float* dz;  // dz2
+    int64_t dz_es;
+    const float* wp;   // [e][8][16][2][128]
+    const float* act;  // a1
+    float* out;        // dz1
+    int64_t out_es;
+    int n;
+  };
+  struct Regs {
+    float4 w[4], im[3];
+  };
+  int abase[4], bbase[2], kb_begin, kb_end;
+  int e, c0, b_first, l31, hi, wc;
+  const float* dz;
+  const float* wp;
+  static constexpr int aoff(int s) { return 2 * s * 128; }
+  static constexpr int boff(int s) { return (s / 4) * 242 + (1 - ((s % 4) >> 1)) * 11 + (1 - (s & 1)); }
+  __device__ void init(const Params& p, int tid, float* lds) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    e = blockIdx.z;
+    c0 = blockIdx.x * 256;
+    b_first = c0 / 100;
+    kb_begin = 0;
+    kb_end = 8;
+    dz = p.dz + e * p.dz_es;
+    wp = p.wp + (int64_t)e * 8 * 4096;
+    for (int i = tid; i < IMG_FLOATS; i += 256) {
+      lds[IMG_OFF + i] = 0.0f;
+      lds[STAGE + IMG_OFF + i] = 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abase[i] = hi * 128 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 100) c = c0;
+      const int b = c / 100, pq = c % 100;
+      bbase[j] = IMG_OFF + (b - b_first) * 968 + (pq / 10) * 11 + (pq % 10) + hi * 121;
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.w[j] = *(const float4*)(wp + kb * 4096 + (tid + 256 * j) * 4);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      const int bl = idx / 162, q = idx % 162;
+      const int b = b_first + bl;
+      r.im[j] = (idx < NS * 162 && b < p.n) ? *(const float4*)(dz + (int64_t)b * 5184 + kb * 648 + q * 4)
+                                            : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NS * 162) {
+        const int bl = idx / 162, q = idx % 162;
+        const float v[4] = {r.im[j].x, r.im[j].y, r.im[j].z, r.im[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int el = q * 4 + i;
+          const int cc = el / 81, rr = el % 81;
+          buf[IMG_OFF + (bl * 8 + cc) * 121 + (rr / 9 + 1) * 11 + (rr % 9) + 1] = v[i];
+        }
+      }
+    }
+  }
+  __device__ void extra(const float*) {}
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[4][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + wc * 64 + j * 32 + l31;
+      if (c >= p.n * 100) continue;
+      const int b = c / 100, pq = c % 100;
+      const int pp = pq / 10, qq = pq % 10;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // i = parity class (a = i>>1, c = i&1)
+        const int64_t base = e * p.out_es + (int64_t)b * 12800 + (2 * pp + (i >> 1)) * 20 + 2 * qq + (i & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t idx = base + acc_row(r, hi) * 400;
+          p.out[idx] = leaky_g(p.act[idx], acc[i][j][r]);
+        }
+      }
+    }
+  }
+};
+
+// ================================================================================================
+void launch_conv_forward2(const EncCall& c, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  const ParamLayout& L = *c.L;
+  const int n = c.n;
+  {
+    ConvFwd1v2::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b}, w.a1, MB * 12800, n};
+    ProfRange pr(c.prof, "ConvFwd1", st);
+    launch_engine2<ConvFwd1v2>(dim3((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1), p, st);
+  }
+  {
+    ConvFwd2v2::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
+    ProfRange pr(c.prof, "ConvFwd2", st);
+    launch_engine2<ConvFwd2v2>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, 2), p, st);
+  }
+  {
+    ConvFwd3v2::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
+    ProfRange pr(c.prof, "ConvFwd3", st);
+    launch_engine2<ConvFwd3v2>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, 2), p, st);
+  }
+}
+
+void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  ConvDgrad3v2::Params p{w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n};
+  ProfRange pr(c.prof, "ConvDgrad3", st);
+  launch_engine2<ConvDgrad3v2>(dim3((unsigned)(((int64_t)c.n * 81 + 255) / 256), 1, 2), p, st);
+}
+
+void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  ConvDgrad2v2::Params p{w.dz2, MB * 5184, w.wd2p, w.a1, w.dz1, MB * 12800, c.n};
+  ProfRange pr(c.prof, "ConvDgrad2", st);
+  launch_engine2<ConvDgrad2v2>(dim3((unsigned)(((int64_t)c.n * 100 + 255) / 256), 1, 2), p, st);
+}
+
+}  // namespace ddrl

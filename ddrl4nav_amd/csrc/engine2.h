@@ -1,0 +1,110 @@
+// Pipelined f32-MFMA tile engine (v2).
+//
+//   C[row][col] = sum_k A(row,k) * B(k,col),  rows -> MFMA A operand -> accumulator registers,
+//   cols -> MFMA B operand -> lanes (stores are coalesced along cols).
+//
+// Differences from the v1 engine in igemm.hip:
+//   * operands are read from LDS as  lds[lane_base + compile-time immediate]  (one ds_read_b32
+//     with an offset field per operand, zero address VALU inside the k loop);
+//   * LDS is double buffered and the next k-block is prefetched global -> registers while the
+//     current one feeds the matrix pipe (one barrier per k-block);
+//   * ops stage RAW tensors (input planes, weight slabs) with wide coalesced loads instead of
+//     gathering an im2col tile element by element.
+//
+// An Op provides:
+//   constants  THREADS, TM, TN, KSTEPS, STAGE (floats per LDS buffer)
+//   struct Params, struct Regs (prefetch registers)
+//   bool  init(P, tid, lds)            tile coordinates, lane bases abase[TM], bbase[TN], kb range
+//   void  fetch(P, kb, regs)           issue global loads of k-block kb
+//   void  commit(regs, buf)            registers -> LDS buffer
+//   static constexpr int aoff(s), boff(s)   immediates of k-step s (in floats)
+//   void  epilogue(P, acc)
+#pragma once
+#include "kernels.h"
+
+namespace ddrl {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float leaky_f(float v) { return v > 0.0f ? v : v * LEAKY; }
+__device__ __forceinline__ float leaky_g(float act, float g) { return act > 0.0f ? g : g * LEAKY; }
+
+// float32(u8/255.0) for the four bytes of a dword (same arithmetic as ddrl_u8_table)
+__device__ __forceinline__ float u8_unit(unsigned b) {
+  const float x = (float)b;
+  const float r = 1.0f / 255.0f;
+  const float q = x * r;
+  const float e = __builtin_fmaf(-255.0f, q, x);
+  return __builtin_fmaf(e, r, q);
+}
+
+template <class Op>
+__device__ __forceinline__ void compute_block(const Op& op, const float* __restrict__ cur,
+                                              f32x16 (&acc)[Op::TM][Op::TN]) {
+#pragma unroll
+  for (int s = 0; s < Op::KSTEPS; ++s) {
+    float a[Op::TM], b[Op::TN];
+#pragma unroll
+    for (int i = 0; i < Op::TM; ++i) a[i] = cur[op.abase[i] + Op::aoff(s)];
+#pragma unroll
+    for (int j = 0; j < Op::TN; ++j) b[j] = cur[op.bbase[j] + Op::boff(s)];
+#pragma unroll
+    for (int i = 0; i < Op::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Op::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <class Op>
+__global__ __launch_bounds__(Op::THREADS) void engine2_kernel(typename Op::Params P) {
+  extern __shared__ __attribute__((aligned(16))) float lds2[];
+  Op op;
+  const int tid = threadIdx.x;
+  op.init(P, tid, lds2);
+  typename Op::Regs regs;
+  f32x16 acc[Op::TM][Op::TN];
+#pragma unroll
+  for (int i = 0; i < Op::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Op::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  int kb = op.kb_begin;
+  const int kbe = op.kb_end;
+  if (kb < kbe) {
+    op.fetch(P, kb, regs);
+    op.commit(regs, lds2);
+    if (kb + 1 < kbe) op.fetch(P, kb + 1, regs);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; kb < kbe; ++kb) {
+    compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
+    if (kb + 1 < kbe) {
+      op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
+      if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  op.epilogue(P, acc, lds2);
+}
+
+template <class Op>
+inline void launch_engine2(dim3 grid, const typename Op::Params& p, hipStream_t st) {
+  constexpr size_t bytes = (size_t)2 * Op::STAGE * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    if (bytes > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)engine2_kernel<Op>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    configured = true;
+  }
+  hipLaunchKernelGGL(engine2_kernel<Op>, grid, dim3(Op::THREADS), bytes, st, p);
+}
+
+// accumulator element r of tile (i,j) of this lane -> (row, col) inside the wave tile
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+}  // namespace ddrl

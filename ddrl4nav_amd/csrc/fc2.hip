@@ -1,0 +1,305 @@
+// v2 kernels of the 3136 -> 512 linear layer (forward, weight gradient, data gradient) on the
+// pipelined f32-MFMA engine.  Reference: nn.Linear(3136, 512) in USTC_lab/nn/atari_encoder.py:22,31
+// and its autograd backward (ppo.py:122-123).
+#include "engine2.h"
+
+namespace ddrl {
+
+// Loader helpers --------------------------------------------------------------------------------
+// "row-major odd": tile X[128 rows][32 k] of a K-contiguous matrix, stored in LDS as [row][33]
+// so that lanes (= rows) hit 32 different banks.  4 float4 per thread.
+struct RowMajorTile {
+  static constexpr int LD = 33;
+  static constexpr int FLOATS = 128 * LD;
+  __device__ static void fetch(const float* __restrict__ src, int64_t row_stride, int row0, int nrows, int kcol0, int tid,
+                               float4 (&r)[4]) {
+    const int k4 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row0 + rr + 32 * j;
+      r[j] = (row < nrows) ? *(const float4*)(src + (int64_t)row * row_stride + kcol0 + k4 * 4) : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ static void commit(float* __restrict__ dst, int tid, const float4 (&r)[4]) {
+    const int k4 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* p = dst + (rr + 32 * j) * LD + k4 * 4;
+      p[0] = r[j].x; p[1] = r[j].y; p[2] = r[j].z; p[3] = r[j].w;
+    }
+  }
+};
+// "k-major": tile X[32 k][128 cols] of a col-contiguous matrix, stored as is.  4 float4 per thread.
+struct KMajorTile {
+  static constexpr int LD = 128;
+  static constexpr int FLOATS = 32 * LD;
+  __device__ static void fetch(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
+                               float4 (&r)[4]) {
+    const int c4 = tid & 31, kk = tid >> 5;
+    const bool cok = (col0 + c4 * 4) < ncols;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + kk + 8 * j;
+      r[j] = (cok && k < nk) ? *(const float4*)(src + (int64_t)k * k_stride + col0 + c4 * 4) : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ static void commit(float* __restrict__ dst, int tid, const float4 (&r)[4]) {
+    const int c4 = tid & 31, kk = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(float4*)(dst + (kk + 8 * j) * LD + c4 * 4) = r[j];
+  }
+};
+
+struct FcCommon {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
+  int abase[2], bbase[2];
+  int kb_begin, kb_end;
+  int wr, wc, l31, hi;
+  __device__ void lanes(int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    wr = wave >> 1;
+    wc = wave & 1;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+//  h[b][n] = sum_k a3[b][k] Wl[n][k] + bl[n]          rows = b, cols = n, reduction = k (3136)
+// ------------------------------------------------------------------------------------------------
+struct FcFwd2 : FcCommon {
+  static constexpr int A_OFF = 0, B_OFF = RowMajorTile::FLOATS, STAGE = RowMajorTile::FLOATS + KMajorTile::FLOATS;
+  struct Params {
+    const float* a3;
+    int64_t a3_es;
+    const float* wlt;  // [e][3136][512]
+    const float* params;
+    int64_t bias_off[2];
+    float* h;
+    int64_t h_es;
+    int n;
+  };
+  struct Regs {
+    float4 a[4], b[4];
+  };
+  int e, b0, n0;
+  const float* a3;
+  const float* wlt;
+  static constexpr int aoff(int s) { return 2 * s; }
+  static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
+  __device__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    e = blockIdx.z;
+    n0 = blockIdx.x * 128;
+    b0 = blockIdx.y * 128;
+    kb_begin = 0;
+    kb_end = FLAT / 32;
+    a3 = p.a3 + e * p.a3_es;
+    wlt = p.wlt + (int64_t)e * FLAT * FEAT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowMajorTile::LD + hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    RowMajorTile::fetch(a3, FLAT, b0, p.n, kb * 32, threadIdx.x, r.a);
+    KMajorTile::fetch(wlt, FEAT, kb * 32, FLAT, n0, FEAT, threadIdx.x, r.b);
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
+    KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
+  }
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + l31;
+      const float bias = p.params[p.bias_off[e] + n];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+          if (b < p.n) p.h[e * p.h_es + (int64_t)b * FEAT + n] = acc[i][j][r] + bias;
+        }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+//  dz3[b][k] = leaky'(a3[b][k]) * sum_n dh[b][n] Wl[n][k]   rows = b, cols = k (3136), red = n (512)
+// ------------------------------------------------------------------------------------------------
+struct FcDgrad2 : FcCommon {
+  static constexpr int A_OFF = 0, B_OFF = RowMajorTile::FLOATS, STAGE = RowMajorTile::FLOATS + KMajorTile::FLOATS;
+  struct Params {
+    const float* dh;
+    int64_t dh_es;
+    const float* wln;  // [e][512][3136] 16-byte aligned copy of linear.weight
+    const float* a3;
+    float* dz3;
+    int64_t a3_es;
+    int n;
+  };
+  struct Regs {
+    float4 a[4], b[4];
+  };
+  int e, b0, k0;
+  const float* dh;
+  const float* wln;
+  static constexpr int aoff(int s) { return 2 * s; }
+  static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
+  __device__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    e = blockIdx.z;
+    k0 = blockIdx.x * 128;
+    b0 = blockIdx.y * 128;
+    kb_begin = 0;
+    kb_end = FEAT / 32;
+    dh = p.dh + e * p.dh_es;
+    wln = p.wln + (int64_t)e * FLAT * FEAT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowMajorTile::LD + hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    RowMajorTile::fetch(dh, FEAT, b0, p.n, kb * 32, threadIdx.x, r.a);
+    KMajorTile::fetch(wln, FLAT, kb * 32, FEAT, k0, FLAT, threadIdx.x, r.b);
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
+    KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
+  }
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wc * 64 + j * 32 + l31;
+      if (k >= FLAT) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+          if (b < p.n) {
+            const int64_t idx = e * p.a3_es + (int64_t)b * FLAT + k;
+            p.dz3[idx] = leaky_g(p.a3[idx], acc[i][j][r]);
+          }
+        }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+//  part[s][e][n][k] = sum_{b in split s} dh[b][n] a3[b][k] ; bias partial appended per slab
+//  rows = n (512), cols = k (3136), reduction = b
+// ------------------------------------------------------------------------------------------------
+struct FcWgrad2 : FcCommon {
+  static constexpr int A_OFF = 0, B_OFF = KMajorTile::FLOATS, STAGE = 2 * KMajorTile::FLOATS;
+  static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena
+  struct Params {
+    const float* dh;
+    int64_t dh_es;
+    const float* a3;
+    int64_t a3_es;
+    float* part;  // [nsplit][e][SLAB]
+    int n, nsplit;
+  };
+  struct Regs {
+    float4 a[4], b[4];
+  };
+  int e, split, n0, k0;
+  const float* dh;
+  const float* a3;
+  float4 bsum;
+  static constexpr int aoff(int s) { return 2 * s * KMajorTile::LD; }
+  static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
+  __device__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    e = blockIdx.z % 2;
+    split = blockIdx.z / 2;
+    k0 = blockIdx.x * 128;
+    n0 = blockIdx.y * 128;
+    const int nkb = (p.n + 31) / 32;
+    const int per = (nkb + p.nsplit - 1) / p.nsplit;
+    kb_begin = split * per;
+    kb_end = min(nkb, kb_begin + per);
+    dh = p.dh + e * p.dh_es;
+    a3 = p.a3 + e * p.a3_es;
+    bsum = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + hi * KMajorTile::LD + wr * 64 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    KMajorTile::fetch(dh, FEAT, kb * 32, p.n, n0, FEAT, threadIdx.x, r.a);
+    KMajorTile::fetch(a3, FLAT, kb * 32, p.n, k0, FLAT, threadIdx.x, r.b);
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    KMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
+    KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
+    // bias gradient rides along: this thread always holds the same 4 columns of dh
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bsum.x += r.a[j].x; bsum.y += r.a[j].y; bsum.z += r.a[j].z; bsum.w += r.a[j].w;
+    }
+  }
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+    float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wc * 64 + j * 32 + l31;
+      if (k >= FLAT) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wr * 64 + i * 32 + acc_row(r, hi);
+          slab[(int64_t)n * FLAT + k] = acc[i][j][r];
+        }
+    }
+    if (blockIdx.x == 0) {  // one column tile per (row tile, split, e) owns the bias partial
+      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
+      *(float4*)(lds + kk * 128 + c4 * 4) = bsum;
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += lds[q * 128 + threadIdx.x];
+        slab[(int64_t)FEAT * FLAT + n0 + threadIdx.x] = s;
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+void launch_fc_forward2(const EncCall& c, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  FcFwd2::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
+                   w.h, MB * FEAT, c.n};
+  ProfRange pr(c.prof, "FcFwd", st);
+  launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, 2), p, st);
+}
+
+void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  const ParamLayout& L = *c.L;
+  const int S = c.splits->fc;
+  {
+    FcWgrad2::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S};
+    ProfRange pr(c.prof, "FcWgrad", st);
+    launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, 2 * S), p, st);
+  }
+  {
+    ProfRange pr(c.prof, "reduce_partials", st);
+    launch_reduce_partials(w.wpart, S, FcWgrad2::SLAB, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
+  }
+  {
+    FcDgrad2::Params p{w.dh, MB * FEAT, w.wln, w.a3, w.dz3, MB * FLAT, c.n};
+    ProfRange pr(c.prof, "FcDgrad", st);
+    launch_engine2<FcDgrad2>(dim3((FLAT + 127) / 128, (c.n + 127) / 128, 2), p, st);
+  }
+}
+
+}  // namespace ddrl

@@ -624,33 +624,8 @@ struct FcDgradOp {
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void launch_encoder_forward(const EncCall& c, hipStream_t st) {
-  const Workspace& w = *c.ws;
-  const int64_t MB = c.max_batch;
-  const int n = c.n;
-  {
-    ConvFwdOp<1>::Params p{c.frames, 0, w.wt1, c.params, {c.L->enc_base[0] + c.L->enc.c1b, c.L->enc_base[1] + c.L->enc.c1b},
-                           w.a1, MB * 32 * 400, n};
-    ProfRange pr(c.prof, "ConvFwd1", st);
-    hipLaunchKernelGGL(igemm_kernel<ConvFwdOp<1>>, dim3(cdiv((int64_t)n * C1_P, 256), 1, 2), dim3(256), 0, st, p);
-  }
-  {
-    ConvFwdOp<2>::Params p{w.a1, MB * 32 * 400, w.wt2, c.params, {c.L->enc_base[0] + c.L->enc.c2b, c.L->enc_base[1] + c.L->enc.c2b},
-                           w.a2, MB * 64 * 81, n};
-    ProfRange pr(c.prof, "ConvFwd2", st);
-    hipLaunchKernelGGL(igemm_kernel<ConvFwdOp<2>>, dim3(cdiv((int64_t)n * C2_P, 256), 1, 2), dim3(256), 0, st, p);
-  }
-  {
-    ConvFwdOp<3>::Params p{w.a2, MB * 64 * 81, w.wt3, c.params, {c.L->enc_base[0] + c.L->enc.c3b, c.L->enc_base[1] + c.L->enc.c3b},
-                           w.a3, MB * FLAT, n};
-    ProfRange pr(c.prof, "ConvFwd3", st);
-    hipLaunchKernelGGL(igemm_kernel<ConvFwdOp<3>>, dim3(cdiv((int64_t)n * C3_P, 256), 1, 2), dim3(256), 0, st, p);
-  }
-  {
-    FcFwdOp::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
-                      w.h, MB * FEAT, n};
-    ProfRange pr(c.prof, "FcFwd", st);
-    hipLaunchKernelGGL(igemm_kernel<FcFwdOp>, dim3(FEAT / 128, cdiv(n, 128), 2), dim3(256), 0, st, p);
-  }
+  launch_conv_forward2(c, st);
+  launch_fc_forward2(c, st);
 }
 
 // Backward of both encoders given dh[e][n][512]; leaves split-K partial slabs reduced into the
@@ -667,17 +642,8 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
   const int n = c.n;
   const ParamLayout& L = *c.L;
   const Splits& S = *c.splits;
-  // ---- FC ----
-  {
-    FcWgradOp::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, n, S.fc};
-    PROF("FcWgrad", hipLaunchKernelGGL(igemm_kernel<FcWgradOp>, dim3(cdiv(FLAT, 128), FEAT / 128, 2 * S.fc), dim3(256), 0, st, p));
-    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.fc, (int64_t)FEAT * FLAT, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st));
-    PROF("bias_colsum", launch_colsum(w.dh, MB * FEAT, n, FEAT, 1, w.bpart, grads, L.enc_base[0] + L.enc.lb, L.enc_base[1] + L.enc.lb, st));
-  }
-  {
-    FcDgradOp::Params p{w.dh, MB * FEAT, c.params, {L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw}, w.a3, w.dz3, MB * FLAT, n};
-    PROF("FcDgrad", hipLaunchKernelGGL(igemm_kernel<FcDgradOp>, dim3(cdiv(FLAT, 128), cdiv(n, 128), 2), dim3(256), 0, st, p));
-  }
+  // ---- FC (v2 engine, fc2.hip) ----
+  launch_fc_backward2(c, grads, st);
   // ---- conv3 ----
   {
     ConvWgradOp<3>::Params p{w.a2, MB * 64 * 81, w.dz3, MB * FLAT, w.wpart, n, S.c3};
@@ -685,10 +651,7 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
     PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c3, (int64_t)64 * C3_K, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st));
     PROF("bias_colsum", launch_colsum(w.dz3, MB * FLAT, n, 64, C3_P, w.bpart, grads, L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b, st));
   }
-  {
-    ConvDgrad3Op::Params p{w.dz3, MB * FLAT, w.wd3, w.a2, w.dz2, MB * 64 * 81, n};
-    PROF("ConvDgrad3", hipLaunchKernelGGL(igemm_kernel<ConvDgrad3Op>, dim3(cdiv((int64_t)n * C2_P, 256), 1, 2), dim3(256), 0, st, p));
-  }
+  launch_conv_dgrad3_2(c, st);
   // ---- conv2 ----
   {
     ConvWgradOp<2>::Params p{w.a1, MB * 32 * 400, w.dz2, MB * 64 * 81, w.wpart, n, S.c2};
@@ -696,10 +659,7 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
     PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c2, (int64_t)64 * C2_K, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st));
     PROF("bias_colsum", launch_colsum(w.dz2, MB * 64 * 81, n, 64, C2_P, w.bpart, grads, L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b, st));
   }
-  {
-    ConvDgrad2Op::Params p{w.dz2, MB * 64 * 81, w.wd2, w.a1, w.dz1, MB * 32 * 400, n};
-    PROF("ConvDgrad2", hipLaunchKernelGGL(igemm_kernel<ConvDgrad2Op>, dim3(cdiv((int64_t)n * 100, 256), 4, 2), dim3(256), 0, st, p));
-  }
+  launch_conv_dgrad2_2(c, st);
   // ---- conv1 (no data gradient: the frames are leaves) ----
   {
     ConvWgradOp<1>::Params p{c.frames, 0, w.dz1, MB * 32 * 400, w.wpart, n, S.c1};

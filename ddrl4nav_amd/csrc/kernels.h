@@ -36,6 +36,15 @@ struct EncCall {
 void launch_encoder_forward(const EncCall& c, hipStream_t st);
 void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
 
+// fc2.hip (v2 engine)
+void launch_fc_forward2(const EncCall& c, hipStream_t st);
+void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st);
+
+// conv2.hip (v2 engine)
+void launch_conv_forward2(const EncCall& c, hipStream_t st);
+void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st);
+void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st);
+
 // optim.hip
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st);
 void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0,

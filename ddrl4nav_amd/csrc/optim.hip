@@ -50,17 +50,21 @@ __global__ __launch_bounds__(256) void pack_small_kernel(const float* __restrict
 }
 
 // wlt[e][k][n] = Wl[n][k]   (512 x 3136 -> 3136 x 512), 32x32 LDS tiles
-__global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt) {
+__global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt,
+                                                      float* __restrict__ wln) {
   __shared__ float tile[32][33];
   const int e = blockIdx.z;
   const float* src = params + L.enc_base[e] + L.enc.lw;
   float* dst = wlt + (int64_t)e * FLAT * FEAT;
+  float* nat = wln + (int64_t)e * FLAT * FEAT;
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + ty + 8 * j;
-    tile[ty + 8 * j][tx] = src[(int64_t)n * FLAT + k0 + tx];
+    const float v = src[(int64_t)n * FLAT + k0 + tx];
+    tile[ty + 8 * j][tx] = v;
+    nat[(int64_t)n * FLAT + k0 + tx] = v;
   }
   __syncthreads();
 #pragma unroll
@@ -70,10 +74,55 @@ __global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ 
   }
 }
 
+// v2 layouts: [k-block][k-step s][lane half hi][row] -- the order in which the engine's MFMA
+// k indices walk (channel pairs on the lane halves; tap pairs for conv1).
+__global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ params, ParamLayout L, Workspace w) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  const int n1 = 4 * 32 * 2 * 64, n2 = 2 * 16 * 16 * 2 * 64, n3 = 2 * 16 * 18 * 2 * 64, n4 = n3, n5 = 2 * 8 * 16 * 2 * 128;
+  if (i < n1) {  // wp1[kb=ic][s][hi][e*32+oc] = W1_e[oc][ic][ky=s/4][kx=2*(s%4)+hi]
+    const int row = i & 63, hi = (i >> 6) & 1, s = (i >> 7) & 31, kb = i >> 12;
+    const int e = row >> 5, oc = row & 31;
+    w.wp1[i] = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + kb) * 8 + (s >> 2)) * 8 + 2 * (s & 3) + hi];
+    return;
+  }
+  i -= n1;
+  if (i < n2) {  // wp2[e][kb][s][hi][oc] = W2[oc][2kb+hi][s/4][s%4]
+    const int oc = i & 63, hi = (i >> 6) & 1, s = (i >> 7) & 15, kb = (i >> 11) & 15, e = i >> 15;
+    w.wp2[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + 2 * kb + hi) * 16 + s];
+    return;
+  }
+  i -= n2;
+  if (i < n3) {  // wp3[e][kb][s][hi][oc] = W3[oc][4kb+2(s/9)+hi][s%9]
+    const int oc = i & 63, hi = (i >> 6) & 1, r = i >> 7;
+    const int s = r % 18, kb = (r / 18) % 16, e = r / (18 * 16);
+    w.wp3[i] = params[L.enc_base[e] + L.enc.c3w + (oc * 64 + 4 * kb + 2 * (s / 9) + hi) * 9 + s % 9];
+    return;
+  }
+  i -= n3;
+  if (i < n4) {  // wd3p[e][kb][s][hi][ic] = W3[oc=4kb+2(s/9)+hi][ic][s%9]
+    const int ic = i & 63, hi = (i >> 6) & 1, r = i >> 7;
+    const int s = r % 18, kb = (r / 18) % 16, e = r / (18 * 16);
+    w.wd3p[i] = params[L.enc_base[e] + L.enc.c3w + ((4 * kb + 2 * (s / 9) + hi) * 64 + ic) * 9 + s % 9];
+    return;
+  }
+  i -= n4;
+  if (i < n5) {  // wd2p[e][kb][s][hi][cls*32+ic] = W2[oc=8kb+2(s/4)+hi][ic][2u+a][2v+c]
+    const int row = i & 127, hi = (i >> 7) & 1, s = (i >> 8) & 15, kb = (i >> 12) & 7, e = i >> 15;
+    const int cls = row >> 5, ic = row & 31;
+    const int u = (s & 3) >> 1, v = s & 1;
+    const int oc = 8 * kb + 2 * (s >> 2) + hi;
+    w.wd2p[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + (2 * u + (cls >> 1)) * 4 + 2 * v + (cls & 1)];
+  }
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  {
+    const int total2 = 4 * 32 * 2 * 64 + 2 * 16 * 16 * 2 * 64 + 2 * 2 * 16 * 18 * 2 * 64 + 2 * 8 * 16 * 2 * 128;
+    hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);
+  }
   const int total = 2 * L.C * 64 * 32 + 2 * 512 * 64 + 2 * 576 * 64 * 2 + 2 * 4 * 256 * 32;
   hipLaunchKernelGGL(pack_small_kernel, dim3((total + 255) / 256), dim3(256), 0, st, params, L, w);
-  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, 2), dim3(256), 0, st, params, L, w.wlt);
+  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, 2), dim3(256), 0, st, params, L, w.wlt, w.wln);
 }
 
 // --------------------------------------------------------------------------------------------
