@@ -94,18 +94,14 @@ struct Splits {
   int c1, c2, c3, fc;
 };
 inline Splits choose_splits(int max_batch) {
-  auto pick = [&](int64_t red, int tiles, int target_wg) {
-    int64_t kblocks = (red + 31) / 32;
-    int s = (target_wg + tiles - 1) / tiles;
-    if (s > kblocks) s = (int)kblocks;
-    if (s < 1) s = 1;
-    return s;
-  };
+  // ~1024 workgroups per weight-gradient launch (2 resident per CU x 256 CUs x 2 rounds)
+  const int pairs = (max_batch + 1) / 2;
+  auto cap = [&](int want, int limit) { return want < limit ? (want < 1 ? 1 : want) : (limit < 1 ? 1 : limit); };
   Splits s;
-  s.c1 = pick((int64_t)max_batch * C1_P, 2 * 2, 1024);   // cols 256/128 = 2 tiles x 2 enc
-  s.c2 = pick((int64_t)max_batch * C2_P, 4 * 2, 1024);   // 512/128 = 4
-  s.c3 = pick((int64_t)max_batch * C3_P, 5 * 2, 1024);   // 576/128 -> 5
-  s.fc = pick((int64_t)max_batch, 4 * 25 * 2, 1024);     // rows 512/128 x cols 3136/128
+  s.c1 = cap(1024, pairs);      // 1 column tile, encoders fused
+  s.c2 = cap(256, pairs);       // 2 column tiles x 2 encoders
+  s.c3 = cap(171, pairs);       // 3 column tiles x 2 encoders
+  s.fc = cap(5, (max_batch + 31) / 32);  // 25 x 4 tiles x 2 encoders
   return s;
 }
 

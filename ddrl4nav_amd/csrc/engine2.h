@@ -17,6 +17,7 @@
 //   bool  init(P, tid, lds)            tile coordinates, lane bases abase[TM], bbase[TN], kb range
 //   void  fetch(P, kb, regs)           issue global loads of k-block kb
 //   void  commit(regs, buf)            registers -> LDS buffer
+//   void  extra(cur)                   optional side work on the published buffer (bias sums)
 //   static constexpr int aoff(s), boff(s)   immediates of k-step s (in floats)
 //   void  epilogue(P, acc)
 #pragma once
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(Op::THREADS) void engine2_kernel(typename Op::Param
   __syncthreads();
   int buf = 0;
   for (; kb < kbe; ++kb) {
+    op.extra(lds2 + buf * Op::STAGE);
     compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
     if (kb + 1 < kbe) {
       op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);

@@ -55,6 +55,7 @@ struct FcCommon {
   int abase[2], bbase[2];
   int kb_begin, kb_end;
   int wr, wc, l31, hi;
+  __device__ void extra(const float*) {}
   __device__ void lanes(int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     l31 = lane & 31;

@@ -637,36 +637,12 @@ void launch_encoder_forward(const EncCall& c, hipStream_t st) {
   } while (0)
 
 void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
-  const Workspace& w = *c.ws;
-  const int64_t MB = c.max_batch;
-  const int n = c.n;
-  const ParamLayout& L = *c.L;
-  const Splits& S = *c.splits;
-  // ---- FC (v2 engine, fc2.hip) ----
   launch_fc_backward2(c, grads, st);
-  // ---- conv3 ----
-  {
-    ConvWgradOp<3>::Params p{w.a2, MB * 64 * 81, w.dz3, MB * FLAT, w.wpart, n, S.c3};
-    PROF("ConvWgrad3", hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<3>>, dim3(cdiv(C3_K, 128), S.c3, 2), dim3(256), 0, st, p));
-    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c3, (int64_t)64 * C3_K, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st));
-    PROF("bias_colsum", launch_colsum(w.dz3, MB * FLAT, n, 64, C3_P, w.bpart, grads, L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b, st));
-  }
+  launch_conv_wgrad3_2(c, grads, st);
   launch_conv_dgrad3_2(c, st);
-  // ---- conv2 ----
-  {
-    ConvWgradOp<2>::Params p{w.a1, MB * 32 * 400, w.dz2, MB * 64 * 81, w.wpart, n, S.c2};
-    PROF("ConvWgrad2", hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<2>>, dim3(cdiv(C2_K, 128), S.c2, 2), dim3(256), 0, st, p));
-    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c2, (int64_t)64 * C2_K, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st));
-    PROF("bias_colsum", launch_colsum(w.dz2, MB * 64 * 81, n, 64, C2_P, w.bpart, grads, L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b, st));
-  }
+  launch_conv_wgrad2_2(c, grads, st);
   launch_conv_dgrad2_2(c, st);
-  // ---- conv1 (no data gradient: the frames are leaves) ----
-  {
-    ConvWgradOp<1>::Params p{c.frames, 0, w.dz1, MB * 32 * 400, w.wpart, n, S.c1};
-    PROF("ConvWgrad1", hipLaunchKernelGGL(igemm_kernel<ConvWgradOp<1>>, dim3(cdiv(256, 128), S.c1, 2), dim3(256), 0, st, p));
-    PROF("reduce_partials", launch_reduce_partials(w.wpart, S.c1, (int64_t)32 * 256, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st));
-    PROF("bias_colsum", launch_colsum(w.dz1, MB * 32 * 400, n, 32, C1_P, w.bpart, grads, L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b, st));
-  }
+  launch_conv_wgrad1_2(c, grads, st);  // no data gradient for conv1: the frames are leaves
 }
 
 }  // namespace ddrl

@@ -45,6 +45,11 @@ void launch_conv_forward2(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st);
 
+// wgrad2.hip (v2 engine)
+void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st);
+void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st);
+void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st);
+
 // optim.hip
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st);
 void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0,

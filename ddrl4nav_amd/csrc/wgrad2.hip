@@ -1,0 +1,400 @@
+// v2 convolution weight-gradient kernels on the pipelined f32-MFMA engine (engine2.h).
+//
+//   part[split][e][oc][tap] = sum over the split's samples and output pixels of
+//                             dz[b][oc][pix] * in[b][ic][oy*S+ky][ox*S+kx]
+//   rows = oc (MFMA A operand, from the staged dz block), cols = taps (ic,ky,kx) (B operand, read
+//   straight out of the staged RAW input planes), reduction = (sample, pixel).
+// The two k indices of one 32x32x2 MFMA are the SAME pixel of two consecutive samples, so the
+// lane halves differ by a constant (one staged sample) and every operand address is again
+// lane_base + compile-time immediate.  The bias gradient (sum of dz) rides along: half of the
+// threads add up their dz row from LDS once per k-block.  Slabs are laid out like the arena
+// (weights then bias) so that one reduce_partials launch finishes both.
+//
+// Reference: autograd weight/bias gradients of conv1..conv3 (atari_encoder.py:16-18 through
+// actor_loss.backward(); v_loss.backward(), ppo.py:122-123).
+#include "engine2.h"
+
+namespace ddrl {
+
+__device__ __forceinline__ void st4w(float* p, const float4& v) { *(float4*)p = v; }
+
+struct WgradSplit {
+  int pair_begin, pair_end;
+  __device__ void set(int n, int nsplit, int split) {
+    const int npairs = (n + 1) >> 1;
+    const int per = (npairs + nsplit - 1) / nsplit;
+    pair_begin = min(npairs, split * per);
+    pair_end = min(npairs, pair_begin + per);
+  }
+};
+
+// ================================================================================================
+// conv1, both encoders fused: rows = (e, oc) = 64, cols = 256 taps (4 ch x 8 x 8),
+// k-block = (sample pair, output row oy): 20 k-steps (ox).
+// ================================================================================================
+struct ConvWgrad1v2 {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 20;
+  static constexpr int A_FLOATS = 2 * 64 * 21, B_OFF = A_FLOATS, B_FLOATS = 2 * 4 * 672, STAGE = A_FLOATS + B_FLOATS;
+  static constexpr int64_t SLAB = 32 * 256 + 32;
+  struct Params {
+    const uint8_t* frames;
+    const float* dz;  // dz1 [e][n][32][400]
+    int64_t dz_es;
+    float* part;  // [nsplit][e][SLAB]
+    int n, nsplit;
+  };
+  struct Regs {
+    float4 dzr[3];
+    unsigned im[6];
+  };
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int split, l31, hi, wc;
+  float bacc;
+  static constexpr int aoff(int s) { return s; }
+  static constexpr int boff(int s) { return 4 * s; }
+  __device__ void init(const Params& p, int tid, float*) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    split = blockIdx.y;
+    WgradSplit sp;
+    sp.set(p.n, p.nsplit, split);
+    kb_begin = sp.pair_begin * 20;
+    kb_end = sp.pair_end * 20;
+    bacc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * 1344 + (i * 32 + l31) * 21;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wc * 64 + j * 32 + l31;
+      bbase[j] = B_OFF + hi * 2688 + (col >> 6) * 672 + ((col >> 3) & 7) * 84 + (col & 7);
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+    const int pair = kb / 20, oy = kb % 20;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / 5, q4 = idx % 5;
+      const int smp = row >> 6, e = (row >> 5) & 1, oc = row & 31;
+      const int b = 2 * pair + smp;
+      r.dzr[j] = (idx < 640 && b < p.n)
+                     ? *(const float4*)(p.dz + e * p.dz_es + (int64_t)b * 12800 + oc * 400 + oy * 20 + q4 * 4)
+                     : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = tid + 256 * j;
+      const int smp = idx / 672, rr = idx % 672;
+      const int ch = rr / 168, d = rr % 168;
+      const int b = 2 * pair + smp;
+      r.im[j] = (idx < 1344 && b < p.n) ? *(const unsigned*)(p.frames + (int64_t)b * 28224 + ch * 7056 + oy * 336 + d * 4) : 0u;
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 640) {
+        float* d = buf + (idx / 5) * 21 + (idx % 5) * 4;
+        d[0] = r.dzr[j].x; d[1] = r.dzr[j].y; d[2] = r.dzr[j].z; d[3] = r.dzr[j].w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 1344) {
+        const unsigned v = r.im[j];
+        st4w(buf + B_OFF + idx * 4, make_float4(u8_unit(v & 255u), u8_unit((v >> 8) & 255u), u8_unit((v >> 16) & 255u), u8_unit(v >> 24)));
+      }
+    }
+  }
+  __device__ void extra(const float* cur) {
+    if (threadIdx.x < 128) {
+      const float* row = cur + threadIdx.x * 21;
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 20; ++q) s += row[q];
+      bacc += s;
+    }
+  }
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* slab = p.part + ((int64_t)split * 2 + i) * SLAB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wc * 64 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[acc_row(r, hi) * 256 + col] = acc[i][j][r];
+      }
+    }
+    if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int e = threadIdx.x >> 5, oc = threadIdx.x & 31;
+      p.part[((int64_t)split * 2 + e) * SLAB + 8192 + oc] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+    }
+  }
+};
+
+// ================================================================================================
+// conv2: rows = oc (64), cols = 256 taps = 16 input channels x 4 x 4 (blockIdx.x = channel group),
+// k-block = (sample pair, band of 3 output rows): 27 k-steps.
+// ================================================================================================
+struct ConvWgrad2v2 {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 27;
+  static constexpr int A_FLOATS = 2 * 64 * 27, B_OFF = A_FLOATS, B_FLOATS = 2 * 16 * 160, STAGE = A_FLOATS + B_FLOATS;
+  static constexpr int64_t SLAB = 64 * 512 + 64;
+  struct Params {
+    const float* in;  // a1
+    int64_t in_es;
+    const float* dz;  // dz2
+    int64_t dz_es;
+    float* part;
+    int n, nsplit;
+  };
+  struct Regs {
+    float dzr[14];
+    float4 im[5];
+  };
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int e, g, split, l31, hi, wc;
+  const float* in;
+  const float* dz;
+  float bacc;
+  static constexpr int aoff(int s) { return s; }
+  static constexpr int boff(int s) { return (s / 9) * 40 + (s % 9) * 2; }
+  __device__ void init(const Params& p, int tid, float*) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    g = blockIdx.x;
+    split = blockIdx.y;
+    e = blockIdx.z;
+    WgradSplit sp;
+    sp.set(p.n, p.nsplit, split);
+    kb_begin = sp.pair_begin * 3;
+    kb_end = sp.pair_end * 3;
+    in = p.in + e * p.in_es + g * 16 * 400;
+    dz = p.dz + e * p.dz_es;
+    bacc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * 1728 + (i * 32 + l31) * 27;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wc * 64 + j * 32 + l31;
+      bbase[j] = B_OFF + hi * 2560 + (col >> 4) * 160 + ((col >> 2) & 3) * 20 + (col & 3);
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+    const int pair = kb / 3, band = kb % 3;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / 27, q = idx % 27;
+      const int b = 2 * pair + (row >> 6);
+      r.dzr[j] = (idx < 3456 && b < p.n) ? dz[(int64_t)b * 5184 + (row & 63) * 81 + band * 27 + q] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int idx = tid + 256 * j;
+      const int smp = idx / 640, rr = idx % 640;
+      const int ch = rr / 40, q4 = rr % 40;
+      const int b = 2 * pair + smp;
+      r.im[j] = (b < p.n) ? *(const float4*)(in + (int64_t)b * 12800 + ch * 400 + band * 120 + q4 * 4) : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 3456) buf[idx] = r.dzr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) st4w(buf + B_OFF + (tid + 256 * j) * 4, r.im[j]);
+  }
+  __device__ void extra(const float* cur) {
+    if (g == 0 && threadIdx.x < 128) {
+      const float* row = cur + threadIdx.x * 27;
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 27; ++q) s += row[q];
+      bacc += s;
+    }
+  }
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+    float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = g * 256 + wc * 64 + j * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(i * 32 + acc_row(r, hi)) * 512 + col] = acc[i][j][r];
+    }
+    if (g == 0) {
+      if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+      __syncthreads();
+      if (threadIdx.x < 64) slab[32768 + threadIdx.x] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+    }
+  }
+};
+
+// ================================================================================================
+// conv3: rows = oc (64, split over 2 wave rows), cols = 192 taps per workgroup (blockIdx.x = 0..2
+// over the 576 = 64 ch x 3 x 3 taps; 24 staged channels cover any 192-tap window),
+// k-block = one sample pair: 49 k-steps.
+// ================================================================================================
+struct ConvWgrad3v2 {
+  static constexpr int THREADS = 256, TM = 1, TN = 3, KSTEPS = 49;
+  static constexpr int A_FLOATS = 2 * 64 * 49, B_OFF = A_FLOATS, B_FLOATS = 2 * 24 * 81, STAGE = A_FLOATS + B_FLOATS;
+  static constexpr int64_t SLAB = 64 * 576 + 64;
+  struct Params {
+    const float* in;  // a2
+    int64_t in_es;
+    const float* dz;  // dz3
+    int64_t dz_es;
+    float* part;
+    int n, nsplit;
+  };
+  struct Regs {
+    float4 dzr[7], im[4];
+  };
+  int abase[1], bbase[3], kb_begin, kb_end;
+  int e, g, split, l31, hi, wr, wc;
+  const float* in;
+  const float* dz;
+  float bacc;
+  static constexpr int aoff(int s) { return s; }
+  static constexpr int boff(int s) { return (s / 7) * 9 + (s % 7); }
+  __device__ void init(const Params& p, int tid, float*) {
+    const int lane = tid & 63, wave = tid >> 6;
+    wr = wave >> 1;
+    wc = wave & 1;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    g = blockIdx.x;
+    split = blockIdx.y;
+    e = blockIdx.z;
+    WgradSplit sp;
+    sp.set(p.n, p.nsplit, split);
+    kb_begin = sp.pair_begin;
+    kb_end = sp.pair_end;
+    const int ch0 = g * 20;
+    in = p.in + e * p.in_es + ch0 * 81;
+    dz = p.dz + e * p.dz_es;
+    bacc = 0.0f;
+    abase[0] = hi * 3136 + (wr * 32 + l31) * 49;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = g * 192 + wc * 96 + j * 32 + l31;
+      const int ch = col / 9, t = col % 9;
+      bbase[j] = B_OFF + hi * 1944 + (ch - ch0) * 81 + (t / 3) * 9 + (t % 3);
+    }
+  }
+  __device__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int idx = tid + 256 * j;
+      const int smp = idx / 784, q = idx % 784;
+      const int b = 2 * kb + smp;
+      r.dzr[j] = (idx < 1568 && b < p.n) ? *(const float4*)(dz + (int64_t)b * FLAT + q * 4) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      const int smp = idx / 486, q = idx % 486;
+      const int b = 2 * kb + smp;
+      r.im[j] = (idx < 972 && b < p.n) ? *(const float4*)(in + (int64_t)b * 5184 + q * 4) : make_float4(0, 0, 0, 0);
+    }
+  }
+  __device__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 1568) st4w(buf + idx * 4, r.dzr[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 972) st4w(buf + B_OFF + idx * 4, r.im[j]);
+    }
+  }
+  __device__ void extra(const float* cur) {
+    if (g == 0 && threadIdx.x < 128) {
+      const float* row = cur + threadIdx.x * 49;
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 49; ++q) s += row[q];
+      bacc += s;
+    }
+  }
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[1][3], float* lds) {
+    float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = g * 192 + wc * 96 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(wr * 32 + acc_row(r, hi)) * 576 + col] = acc[0][j][r];
+    }
+    if (g == 0) {
+      if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+      __syncthreads();
+      if (threadIdx.x < 64) slab[36864 + threadIdx.x] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+    }
+  }
+};
+
+// ================================================================================================
+void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  const ParamLayout& L = *c.L;
+  const int S = c.splits->c3;
+  {
+    ConvWgrad3v2::Params p{w.a2, MB * 5184, w.dz3, MB * FLAT, w.wpart, c.n, S};
+    ProfRange pr(c.prof, "ConvWgrad3", st);
+    launch_engine2<ConvWgrad3v2>(dim3(3, S, 2), p, st);
+  }
+  ProfRange pr(c.prof, "reduce_partials", st);
+  launch_reduce_partials(w.wpart, S, ConvWgrad3v2::SLAB, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);
+}
+
+void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  const ParamLayout& L = *c.L;
+  const int S = c.splits->c2;
+  {
+    ConvWgrad2v2::Params p{w.a1, MB * 12800, w.dz2, MB * 5184, w.wpart, c.n, S};
+    ProfRange pr(c.prof, "ConvWgrad2", st);
+    launch_engine2<ConvWgrad2v2>(dim3(2, S, 2), p, st);
+  }
+  ProfRange pr(c.prof, "reduce_partials", st);
+  launch_reduce_partials(w.wpart, S, ConvWgrad2v2::SLAB, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
+}
+
+void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const int64_t MB = c.max_batch;
+  const ParamLayout& L = *c.L;
+  const int S = c.splits->c1;
+  {
+    ConvWgrad1v2::Params p{c.frames, w.dz1, MB * 12800, w.wpart, c.n, S};
+    ProfRange pr(c.prof, "ConvWgrad1", st);
+    launch_engine2<ConvWgrad1v2>(dim3(1, S, 1), p, st);
+  }
+  ProfRange pr(c.prof, "reduce_partials", st);
+  launch_reduce_partials(w.wpart, S, ConvWgrad1v2::SLAB, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
+}
+
+}  // namespace ddrl
