@@ -193,7 +193,7 @@ int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const floa
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
-  launch_encoder_forward(ec, st);
+  launch_encoder_forward(ec, true, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, n, ctx->cfg.max_batch};
   {
     ProfRange ps(ctx->profile ? ctx : nullptr, "heads_act", st);
@@ -235,7 +235,7 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
-  launch_encoder_forward(ec, st);
+  launch_encoder_forward(ec, false, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, B, ctx->cfg.max_batch};
   {
     ProfRange ps(ctx->profile ? ctx : nullptr, "heads_loss", st);

@@ -147,6 +147,9 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   if (p2 > pm) pm = p2;
   if (p3 > pm) pm = p3;
   if (pf > pm) pm = pf;
+  // the acting path parks the split-K partial sums of the FC forward here (fc_forward_splits)
+  const int64_t pact = (int64_t)14 * 2 * (MB < 1024 ? MB : 1024) * FEAT;
+  if (pact > pm) pm = pact;
   w.wpart_floats = pm;
   w.wpart = take(pm);
   w.hpart = take((int64_t)HEAD_WG * hpart_stride(A));

@@ -432,6 +432,7 @@ struct ConvDgrad3v2 {
 // ================================================================================================
 struct ConvDgrad2v2 {
   static constexpr int THREADS = 256, TM = 4, TN = 2, KSTEPS = 16;
+  static constexpr int OCC = 2;  // 128 accumulators: keep the total <= 256 VGPRs for 2 waves/SIMD
   static constexpr int NS = 4, W_FLOATS = 32 * 128, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 8 * 121;
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
   struct Params {
@@ -519,13 +520,16 @@ struct ConvDgrad2v2 {
       if (c >= p.n * 100) continue;
       const int b = c / 100, pq = c % 100;
       const int pp = pq / 10, qq = pq % 10;
+      // classes (a,0) and (a,1) of one (p,q) are horizontally adjacent pixels: pair them into one
+      // 8-byte access so that a wave writes whole contiguous output rows
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {  // i = parity class (a = i>>1, c = i&1)
-        const int64_t base = e * p.out_es + (int64_t)b * 12800 + (2 * pp + (i >> 1)) * 20 + 2 * qq + (i & 1);
+      for (int a = 0; a < 2; ++a) {
+        const int64_t base = e * p.out_es + (int64_t)b * 12800 + (2 * pp + a) * 20 + 2 * qq;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t idx = base + acc_row(r, hi) * 400;
-          p.out[idx] = leaky_g(p.act[idx], acc[i][j][r]);
+          const float2 act = *(const float2*)(p.act + idx);
+          *(float2*)(p.out + idx) = make_float2(leaky_g(act.x, acc[2 * a][j][r]), leaky_g(act.y, acc[2 * a + 1][j][r]));
         }
       }
     }

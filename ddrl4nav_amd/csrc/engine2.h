@@ -57,8 +57,19 @@ __device__ __forceinline__ void compute_block(const Op& op, const float* __restr
   }
 }
 
+// Ops may declare `static constexpr int OCC` = waves per SIMD the register allocator must leave
+// room for (second __launch_bounds__ argument); default 1.
+template <class Op, class = void>
+struct OccOf {
+  static constexpr int v = 1;
+};
 template <class Op>
-__global__ __launch_bounds__(Op::THREADS) void engine2_kernel(typename Op::Params P) {
+struct OccOf<Op, decltype((void)Op::OCC)> {
+  static constexpr int v = Op::OCC;
+};
+
+template <class Op>
+__global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(typename Op::Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds2[];
   Op op;
   const int tid = threadIdx.x;

@@ -79,22 +79,26 @@ struct FcFwd2 : FcCommon {
     float* h;
     int64_t h_es;
     int n;
+    int nsplit;   // > 1: write bias-free partial sums part[split][e][n][512] (acting path)
+    float* part;
   };
   struct Regs {
     float4 a[4], b[4];
   };
-  int e, b0, n0;
+  int e, split, b0, n0;
   const float* a3;
   const float* wlt;
   static constexpr int aoff(int s) { return 2 * s; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
   __device__ void init(const Params& p, int tid, float*) {
     lanes(tid);
-    e = blockIdx.z;
+    e = blockIdx.z % 2;
+    split = blockIdx.z / 2;
     n0 = blockIdx.x * 128;
     b0 = blockIdx.y * 128;
-    kb_begin = 0;
-    kb_end = FLAT / 32;
+    const int per = (FLAT / 32) / p.nsplit;
+    kb_begin = split * per;
+    kb_end = kb_begin + per;
     a3 = p.a3 + e * p.a3_es;
     wlt = p.wlt + (int64_t)e * FLAT * FEAT;
 #pragma unroll
@@ -114,13 +118,14 @@ struct FcFwd2 : FcCommon {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wc * 64 + j * 32 + l31;
-      const float bias = p.params[p.bias_off[e] + n];
+      const float bias = (p.nsplit > 1) ? 0.0f : p.params[p.bias_off[e] + n];
+      float* dst = (p.nsplit > 1) ? p.part + ((int64_t)split * 2 + e) * p.n * FEAT : p.h + e * p.h_es;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-          if (b < p.n) p.h[e * p.h_es + (int64_t)b * FEAT + n] = acc[i][j][r] + bias;
+          if (b < p.n) dst[(int64_t)b * FEAT + n] = acc[i][j][r] + bias;
         }
     }
   }
@@ -273,13 +278,14 @@ struct FcWgrad2 : FcCommon {
 };
 
 // ------------------------------------------------------------------------------------------------
-void launch_fc_forward2(const EncCall& c, hipStream_t st) {
+void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
+  const int nsplit = allow_split ? fc_forward_splits(c.n) : 1;  // 98 k-blocks = 14 x 7
   FcFwd2::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
-                   w.h, MB * FEAT, c.n};
-  ProfRange pr(c.prof, "FcFwd", st);
-  launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, 2), p, st);
+                   w.h, MB * FEAT, c.n, nsplit, w.wpart};
+  ProfRange pr(c.prof, nsplit > 1 ? "FcFwdSplit" : "FcFwd", st);
+  launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, 2 * nsplit), p, st);
 }
 
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {

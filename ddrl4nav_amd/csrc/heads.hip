@@ -100,7 +100,11 @@ __device__ __forceinline__ float pick(const float* a, int idx) {
 // --------------------------------------------------------------------------------------------
 // acting: probs / value / sample-or-evaluate
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict__ h, int64_t h_es,
+// When fc_nsplit > 0 the encoder outputs arrive as split-K partial sums of the FC layer,
+// fc_part[s][e][n][512] without bias (small-batch acting path, fc2.hip); they are summed here in
+// split order, the linear bias is added and the finished h is written back to `h`.
+__global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, int64_t h_es,
+                                                        const float* __restrict__ fc_part, int fc_nsplit,
                                                         const float* __restrict__ params, ParamLayout L, int n,
                                                         const float* __restrict__ act_in, uint64_t seed,
                                                         uint64_t stream_id, float* __restrict__ probs,
@@ -113,8 +117,33 @@ __global__ __launch_bounds__(256) void heads_act_kernel(const float* __restrict_
   load_head_weights(R, params, L, lane);
   for (int b = gw; b < n; b += nw) {
     float ha[8], hc[8];
-    load8(h + (int64_t)b * FEAT + lane * 8, ha);
-    load8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+    if (fc_nsplit > 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ha[i] = 0.0f;
+        hc[i] = 0.0f;
+      }
+      for (int sp = 0; sp < fc_nsplit; ++sp) {
+        float ta[8], tc[8];
+        load8(fc_part + (((int64_t)sp * 2 + 0) * n + b) * FEAT + lane * 8, ta);
+        load8(fc_part + (((int64_t)sp * 2 + 1) * n + b) * FEAT + lane * 8, tc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ha[i] += ta[i];
+          hc[i] += tc[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ha[i] += params[L.enc_base[0] + L.enc.lb + lane * 8 + i];
+        hc[i] += params[L.enc_base[1] + L.enc.lb + lane * 8 + i];
+      }
+      store8(h + (int64_t)b * FEAT + lane * 8, ha);
+      store8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+    } else {
+      load8(h + (int64_t)b * FEAT + lane * 8, ha);
+      load8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+    }
     float z[MAXA];
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
@@ -360,7 +389,9 @@ void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, ui
                       float* value, float* action_out, float* logp_out, hipStream_t st) {
   int wgs = (c.n + 3) / 4;
   if (wgs > 1024) wgs = 1024;
-  hipLaunchKernelGGL(heads_act_kernel, dim3(wgs), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT, c.params, *c.L, c.n,
+  const int nsplit = fc_forward_splits(c.n);
+  hipLaunchKernelGGL(heads_act_kernel, dim3(wgs), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT,
+                     nsplit > 1 ? c.ws->wpart : nullptr, nsplit > 1 ? nsplit : 0, c.params, *c.L, c.n,
                      act_in, seed, stream_id, probs, value, action_out, logp_out);
 }
 

@@ -623,9 +623,9 @@ struct FcDgradOp {
 // ============================================================================================
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-void launch_encoder_forward(const EncCall& c, hipStream_t st) {
+void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st) {
   launch_conv_forward2(c, st);
-  launch_fc_forward2(c, st);
+  launch_fc_forward2(c, acting, st);
 }
 
 // Backward of both encoders given dh[e][n][512]; leaves split-K partial slabs reduced into the

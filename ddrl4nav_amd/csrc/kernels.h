@@ -33,11 +33,14 @@ struct EncCall {
 };
 
 // igemm.hip
-void launch_encoder_forward(const EncCall& c, hipStream_t st);
+void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st);
 void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
 
 // fc2.hip (v2 engine)
-void launch_fc_forward2(const EncCall& c, hipStream_t st);
+// Split-K factor of the FC forward for a batch of n samples (1 = plain; >1 only on the acting
+// path, where heads_act sums the partials).  7 k-blocks of 32 per split.
+inline int fc_forward_splits(int n) { return n <= 1024 ? 14 : 1; }
+void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st);
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st);
 
 // conv2.hip (v2 engine)
