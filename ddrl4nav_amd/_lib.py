@@ -41,6 +41,7 @@ SIGNATURES = {
     "ddrl_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
     "ddrl_categorical_stats": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_categorical_sample": (c_int32, [c_void_p, c_int32, c_int32, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "ddrl_last_features": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p,
                            c_void_p]),

@@ -1,0 +1,4 @@
+from ddrl4nav_amd.agent.agent import Agents, gae_device
+from ddrl4nav_amd.agent.rollout import DeviceRollout
+
+__all__ = ["Agents", "gae_device", "DeviceRollout"]

@@ -1,0 +1,82 @@
+"""Agents: the env-worker side of the hot path (mirror of the pieces of
+USTC_lab/agent/agent.py:24-160 that compute anything).
+
+``_accumulate_rewards`` keeps the reference's call contract -- a list of T+1 per-step
+``Experience`` records plus ``rewards_step [T+1, n_reward_dims, N]`` in, the first T records
+rewritten in place (values <- old value + advantage, advs <- advantage) and returned -- but the
+reverse scan itself runs in the GAE HIP kernel (ddrl_gae).  Device-resident rollouts skip the
+per-step records altogether: see ``DeviceRollout`` (rollout.py)."""
+from typing import List
+
+import numpy as np
+import torch
+
+from ddrl4nav_amd import _lib
+from ddrl4nav_amd._lib import check
+from ddrl4nav_amd.data import Experience
+
+
+def gae_device(values, rewards, dones, gamma, landa, adv=None, ret=None):
+    """values [T+1,N] f32, rewards [T,N] f32, dones [T,N] u8 device tensors -> (adv, ret) [T,N]."""
+    from ctypes import c_void_p
+    lib = _lib.load()
+    T, N = rewards.shape
+    assert values.shape == (T + 1, N) and dones.shape == (T, N)
+    assert values.is_cuda and values.dtype == torch.float32 and rewards.dtype == torch.float32 and dones.dtype == torch.uint8
+    assert values.is_contiguous() and rewards.is_contiguous() and dones.is_contiguous()
+    adv = torch.empty((T, N), dtype=torch.float32, device=values.device) if adv is None else adv
+    ret = torch.empty((T, N), dtype=torch.float32, device=values.device) if ret is None else ret
+    p = lambda t: c_void_p(t.data_ptr())
+    check(lib.ddrl_gae(p(values), p(rewards), p(dones), T, N, float(np.float32(gamma)), float(np.float32(landa)),
+                       p(adv), p(ret), c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return adv, ret
+
+
+class Agents:
+    """Holds what the reference's Agents(Process) holds for the GAE step (agent.py:76-117); the
+    process / Redis / env plumbing of the reference is out of scope."""
+
+    def __init__(self, process_env_id: str = "127.0.0.1_0", logger=None, easy_bytes=None, vector_envs=None,
+                 pre_queue=None, train_queue=None, exit_flag=None, mimic_w=None, config=None, config_nn=None,
+                 config_env=None, device=None):
+        self.config, self.config_nn, self.config_env = config, config_nn, config_env or {}
+        self.str_process_env_id = process_env_id
+        self.agent_num_per_env = self.config_env.get("agent_num_per_env", 1)
+        self.batch_num_per_env = self.config_env.get("batch_num_per_env", 1)
+        self.all_num = self.agent_num_per_env * self.batch_num_per_env
+        self.model_dtype = config_nn.MODULE_NUMPY_DTYPE
+        self.discounts_tmp, self.landa = [config_nn.EXTRINSIC_DISCOUNT], config_nn.LANDA
+        self.discounts = np.array(self.discounts_tmp, dtype=self.model_dtype).reshape([len(self.discounts_tmp), 1])
+        self.T = getattr(config, "TIME_MAX", 256)
+        self.value_dim_num = self.reward_dim_num = 1
+        self.network_type = 'ppo'
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+
+    def _accumulate_rewards(self, experiences: List[Experience], rewards_step: np.ndarray) -> List[Experience]:
+        if len(experiences) == 0:
+            return []
+        T = len(experiences) - 1
+        if T == 0:
+            return experiences[:-1]
+        # [T+1, n_heads, N] host records -> per-head [T+1, N] device arrays
+        values = np.stack([np.asarray(e.values, dtype=np.float32) for e in experiences])
+        dones = np.stack([np.asarray(e.dones, dtype=np.uint8) for e in experiences[:T]])
+        rewards = np.asarray(rewards_step[:T], dtype=np.float32)
+        heads = values.shape[1]
+        advs, rets = [], []
+        for k in range(heads):
+            v = torch.from_numpy(np.ascontiguousarray(values[:, k])).to(self.device)
+            r = torch.from_numpy(np.ascontiguousarray(rewards[:, k])).to(self.device)
+            d = torch.from_numpy(np.ascontiguousarray(dones[:, min(k, dones.shape[1] - 1)])).to(self.device)
+            a, g = gae_device(v, r, d, float(self.discounts[k, 0]), self.landa)
+            advs.append(a.cpu().numpy())
+            rets.append(g.cpu().numpy())
+        for t in range(T):
+            experiences[t].values = np.stack([rets[k][t] for k in range(heads)])
+            experiences[t].advs = advs[0][t] * 1.0
+        return experiences[:-1]
+
+    def adv_reshape(self, adv):
+        if self.reward_dim_num == 1:
+            return adv[0] * 1.0
+        raise NotImplementedError("multi-reward advantage mixing (GAIL / RND) is out of scope")

@@ -210,6 +210,13 @@ int32_t ddrl_categorical_stats(const float* probs, int32_t n, int32_t A, float* 
   return check_launch();
 }
 
+int32_t ddrl_categorical_sample(const float* probs, int32_t n, int32_t A, uint64_t seed, uint64_t stream_id,
+                                float* action_out, float* logp_out, void* stream) {
+  if (!probs || !action_out || n < 1 || A < 1) return DDRL_ERR_INVALID_ARG;
+  launch_categorical_sample(probs, n, A, seed, stream_id, action_out, logp_out, (hipStream_t)stream);
+  return check_launch();
+}
+
 int32_t ddrl_last_features(ddrl_ctx* ctx, int32_t n, float* h_actor, float* h_critic, void* stream) {
   if (!ctx || n < 1 || n > ctx->last_n) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;

@@ -11,9 +11,6 @@ namespace ddrl {
 constexpr int IMG = 84;
 constexpr int FEAT = 512;   // AC_INPUT_DIM (config_nn.py:23)
 constexpr int FLAT = 3136;  // 64*7*7
-struct ConvGeom {
-  int cin, hin, oc, ks, stride, ow, pix, kred;
-};
 // conv1: C x84x84 -> 32x20x20, k8 s4 ; conv2: 32x20x20 -> 64x9x9, k4 s2 ; conv3: 64x9x9 -> 64x7x7, k3 s1
 constexpr int C1_OC = 32, C1_KS = 8, C1_S = 4, C1_OW = 20, C1_P = 400;
 constexpr int C2_IC = 32, C2_OC = 64, C2_KS = 4, C2_S = 2, C2_IW = 20, C2_OW = 9, C2_P = 81, C2_K = 512;
@@ -61,11 +58,6 @@ inline ParamLayout make_layout(int A, int C) {
 // ---- device workspace carved out of the caller's buffer ------------------------------------
 struct Workspace {
   // derived weight layouts, [e] major
-  float* wt1;  // [2][K1][32]       conv1 fwd A operand (k-major)
-  float* wt2;  // [2][512][64]
-  float* wt3;  // [2][576][64]
-  float* wd3;  // [2][576 (oc,ky,kx)][64 ic]    conv3 dgrad A operand
-  float* wd2;  // [2][4 cls][256 (oc,u,v)][32 ic] conv2 dgrad A operand per parity class
   float* wlt;  // [2][3136][512]    FC fwd B operand
   // v2 packed weights: [k-block][k-step][lane half][row], see conv2.hip / wgrad2.hip
   float *wp1, *wp2, *wp3, *wd3p, *wd2p;
@@ -78,7 +70,6 @@ struct Workspace {
   float* wpart;    // split-K partial slabs for the weight gradients
   int64_t wpart_floats;
   float* hpart;    // heads partials [HEAD_WG][HPART]
-  float* bpart;    // bias-gradient partials [2][512][32]
   double* npart;   // grad-norm partials [NORM_WG]
   float* lut;      // [256] float32(u8/255.0)
   int64_t total_bytes;
@@ -115,11 +106,6 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
     off += align_up(floats * 4, 256);
     return p;
   };
-  w.wt1 = take(2 * C * 64 * 32);
-  w.wt2 = take(2 * 512 * 64);
-  w.wt3 = take(2 * 576 * 64);
-  w.wd3 = take(2 * 576 * 64);
-  w.wd2 = take(2 * 4 * 256 * 32);
   w.wlt = take(2 * (int64_t)FLAT * FEAT);
   w.wln = take(2 * (int64_t)FLAT * FEAT);
   w.wp1 = take(4 * 32 * 2 * 64);
@@ -153,7 +139,6 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wpart_floats = pm;
   w.wpart = take(pm);
   w.hpart = take((int64_t)HEAD_WG * hpart_stride(A));
-  w.bpart = take(2 * 512 * 32);
   w.npart = (double*)take(NORM_WG * 2);
   w.lut = take(256);
   w.total_bytes = off;

@@ -385,6 +385,37 @@ __global__ __launch_bounds__(256) void categorical_stats_kernel(const float* __r
   if (entropy) entropy[b] = -ent;
 }
 
+// fresh draws from Categorical(probs) with the same inverse-CDF contract as heads_act
+__global__ __launch_bounds__(256) void categorical_sample_kernel(const float* __restrict__ probs, int n, int A,
+                                                                 uint64_t seed, uint64_t stream_id,
+                                                                 float* __restrict__ action, float* __restrict__ logp) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n) return;
+  float ps = 0.0f;
+  for (int j = 0; j < A; ++j) ps += probs[(int64_t)b * A + j];
+  const float u = hash_uniform(seed, stream_id, (uint64_t)b);
+  float c = 0.0f, qa = 0.0f;
+  int a = A - 1;
+  bool done = false;
+  for (int j = 0; j < A; ++j) {
+    const float q = probs[(int64_t)b * A + j] / ps;
+    c += q;
+    if (!done && u < c) {
+      a = j;
+      qa = q;
+      done = true;
+    }
+    if (!done && j == A - 1) qa = q;
+  }
+  action[b] = (float)a;
+  if (logp) logp[b] = logf(fminf(fmaxf(qa, CAT_EPS), 1.0f - CAT_EPS));
+}
+void launch_categorical_sample(const float* probs, int n, int A, uint64_t seed, uint64_t stream_id, float* action,
+                               float* logp, hipStream_t st) {
+  hipLaunchKernelGGL(categorical_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, st, probs, n, A, seed, stream_id,
+                     action, logp);
+}
+
 void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id, float* probs,
                       float* value, float* action_out, float* logp_out, hipStream_t st) {
   int wgs = (c.n + 3) / 4;

@@ -57,9 +57,6 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st);
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st);
 void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0,
                             int64_t off1, hipStream_t st);
-// grads[off_e + c] = sum over n samples and `inner` positions of src[e][i][c][inner]
-void launch_colsum(const float* src, int64_t es, int n, int channels, int inner, float* bpart, float* grads,
-                   int64_t off0, int64_t off1, hipStream_t st);
 void launch_clip_adam(const ddrl_config& cfg, const ParamLayout& L, const Workspace& w, float* params,
                       float* grads, float* m, float* v, int64_t step, hipStream_t st);
 void launch_gae(const float* values, const float* rewards, const uint8_t* dones, int T, int N,
@@ -80,6 +77,8 @@ void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, ui
 void launch_heads_loss(const HeadsCall& c, const float* actions, const float* old_logps,
                        const float* advs, const float* rets, float inv_bglobal, float* grads,
                        hipStream_t st);
+void launch_categorical_sample(const float* probs, int n, int A, uint64_t seed, uint64_t stream_id, float* action,
+                               float* logp, hipStream_t st);
 void launch_categorical_stats(const float* probs, int n, int A, float* p_hat, float* logits,
                               float* entropy, hipStream_t st);
 

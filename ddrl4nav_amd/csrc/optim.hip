@@ -1,5 +1,4 @@
-// HBM-bound support kernels: derived weight layouts, split-K partial reduction, bias
-// gradients, global grad-norm + clip + two-group Adam, the GAE scan and the u8->f32 table.
+// HBM-bound support kernels: derived weight layouts, split-K partial reduction, global grad-norm + clip + two-group Adam, the GAE scan and the u8->f32 table.
 //
 // Reference arithmetic replaced:
 //   clip_grad_norm_ + two torch.optim.Adam steps   USTC_lab/nn/ppo.py:40-42,125-129
@@ -11,44 +10,6 @@ namespace ddrl {
 // --------------------------------------------------------------------------------------------
 // derived weight layouts (rebuilt after every optimiser step; 13.5 MB read, ~13.5 MB written)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_small_kernel(const float* __restrict__ params, ParamLayout L, Workspace w) {
-  const int K1 = L.C * 64;
-  const int n1 = 2 * K1 * 32, n2 = 2 * 512 * 64, n3 = 2 * 576 * 64, n4 = 2 * 576 * 64, n5 = 2 * 4 * 256 * 32;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n1) {  // wt1[e][k][oc] = W1[oc][k]
-    const int e = i / (K1 * 32), r = i % (K1 * 32), k = r / 32, oc = r % 32;
-    w.wt1[i] = params[L.enc_base[e] + L.enc.c1w + oc * K1 + k];
-    return;
-  }
-  i -= n1;
-  if (i < n2) {  // wt2[e][k][oc] = W2[oc][k]
-    const int e = i / (512 * 64), r = i % (512 * 64), k = r / 64, oc = r % 64;
-    w.wt2[i] = params[L.enc_base[e] + L.enc.c2w + oc * 512 + k];
-    return;
-  }
-  i -= n2;
-  if (i < n3) {
-    const int e = i / (576 * 64), r = i % (576 * 64), k = r / 64, oc = r % 64;
-    w.wt3[i] = params[L.enc_base[e] + L.enc.c3w + oc * 576 + k];
-    return;
-  }
-  i -= n3;
-  if (i < n4) {  // wd3[e][(oc,ky,kx)][ic] = W3[oc][ic][ky][kx]
-    const int e = i / (576 * 64), r = i % (576 * 64), kq = r / 64, ic = r % 64;
-    const int oc = kq / 9, t = kq % 9;
-    w.wd3[i] = params[L.enc_base[e] + L.enc.c3w + (oc * 64 + ic) * 9 + t];
-    return;
-  }
-  i -= n4;
-  if (i < n5) {  // wd2[e][cls][(oc,u,v)][ic] = W2[oc][ic][2u+a][2v+c],  cls = a*2 + c
-    const int e = i / (4 * 256 * 32), r = i % (4 * 256 * 32);
-    const int cls = r / (256 * 32), r2 = r % (256 * 32), kq = r2 / 32, ic = r2 % 32;
-    const int oc = kq >> 2, u = (kq >> 1) & 1, v = kq & 1;
-    const int ky = 2 * u + (cls >> 1), kx = 2 * v + (cls & 1);
-    w.wd2[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + ky * 4 + kx];
-  }
-}
-
 // wlt[e][k][n] = Wl[n][k]   (512 x 3136 -> 3136 x 512), 32x32 LDS tiles
 __global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt,
                                                       float* __restrict__ wln) {
@@ -120,8 +81,6 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
     const int total2 = 4 * 32 * 2 * 64 + 2 * 16 * 16 * 2 * 64 + 2 * 2 * 16 * 18 * 2 * 64 + 2 * 8 * 16 * 2 * 128;
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);
   }
-  const int total = 2 * L.C * 64 * 32 + 2 * 512 * 64 + 2 * 576 * 64 * 2 + 2 * 4 * 256 * 32;
-  hipLaunchKernelGGL(pack_small_kernel, dim3((total + 255) / 256), dim3(256), 0, st, params, L, w);
   hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, 2), dim3(256), 0, st, params, L, w.wlt, w.wln);
 }
 
@@ -141,60 +100,6 @@ void launch_reduce_partials(const float* part, int nsplit, int64_t count, float*
                             hipStream_t st) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256), 2), dim3(256), 0, st, part, nsplit,
                      count, grads, off0, off1);
-}
-
-// --------------------------------------------------------------------------------------------
-// bias gradients: grads[off_e + c] = sum_{i<n} sum_{t<inner} src[e][i][c][t]
-// stage 1: COLSUM_SPLITS partial sums per channel, stage 2: ordered sum of the partials
-// --------------------------------------------------------------------------------------------
-constexpr int COLSUM_SPLITS = 32;
-__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ src, int64_t es, int n, int channels,
-                                                            int inner, float* __restrict__ bpart) {
-  __shared__ float red[256];
-  const int e = blockIdx.z, sp = blockIdx.y;
-  const int per = (n + COLSUM_SPLITS - 1) / COLSUM_SPLITS;
-  const int i0 = sp * per, i1 = min(n, i0 + per);
-  const float* base = src + e * es;
-  float s = 0.0f;
-  if (inner == 1) {
-    // one thread per channel, coalesced across channels
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < channels) {
-      for (int i = i0; i < i1; ++i) s += base[(int64_t)i * channels + c];
-      bpart[((int64_t)e * channels + c) * COLSUM_SPLITS + sp] = s;
-    }
-    return;
-  }
-  const int c = blockIdx.x;
-  const int64_t total = (int64_t)(i1 - i0) * inner;
-  for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
-    const int i = i0 + (int)(idx / inner), t = (int)(idx % inner);
-    s += base[((int64_t)i * channels + c) * inner + t];
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) bpart[((int64_t)e * channels + c) * COLSUM_SPLITS + sp] = red[0];
-}
-__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ bpart, int channels,
-                                                            float* __restrict__ grads, int64_t off0, int64_t off1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * channels) return;
-  const int e = i / channels, c = i % channels;
-  float s = 0.0f;
-  for (int sp = 0; sp < COLSUM_SPLITS; ++sp) s += bpart[(int64_t)i * COLSUM_SPLITS + sp];
-  grads[(e ? off1 : off0) + c] = s;
-}
-void launch_colsum(const float* src, int64_t es, int n, int channels, int inner, float* bpart, float* grads,
-                   int64_t off0, int64_t off1, hipStream_t st) {
-  const int gx = (inner == 1) ? (channels + 255) / 256 : channels;
-  hipLaunchKernelGGL(colsum_stage1_kernel, dim3(gx, COLSUM_SPLITS, 2), dim3(256), 0, st, src, es, n, channels, inner,
-                     bpart);
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((2 * channels + 255) / 256), dim3(256), 0, st, bpart, channels, grads,
-                     off0, off1);
 }
 
 // --------------------------------------------------------------------------------------------

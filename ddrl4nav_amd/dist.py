@@ -1,0 +1,63 @@
+"""Data-parallel plumbing: one process per GPU, envs sharded, ONE all-reduce of the flat fp32
+gradient arena (+ loss tail) per PPO iteration -- RCCL over xGMI on the GPU box (backend "nccl"),
+gloo in the CPU tests.  The reference has no multi-GPU path (`# TODO support mutil GPU CARD`,
+USTC_lab/server/backward.py:167); the partitioning is SURVEY.md section 8e.
+
+Because every rank scales its loss terms and gradients by 1/B_global inside the kernels
+(ddrl_ppo_iter), a plain SUM makes every rank hold the full-batch mean gradient; clip + Adam then
+run identically everywhere and the replicas stay in step without a parameter broadcast."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def shard_envs(n_envs_total, world, rank):
+    """Contiguous env shard [lo, hi) of rank `rank` (GPU r owns envs [r*256, (r+1)*256) in the
+    2048-env config).  Uneven totals give the first ranks one extra env."""
+    base, extra = divmod(int(n_envs_total), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def global_batch(local_batch, group=None):
+    """Sum of the per-rank batch sizes (B_global of ddrl_ppo_iter)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(local_batch)
+    t = torch.tensor([int(local_batch)], dtype=torch.int64,
+                     device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
+def allreduce_flat(flat, group=None):
+    """In-place SUM all-reduce of the flat gradient arena (13,487,388 B + 32 B tail per call)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def broadcast_params(flat, src=0, group=None):
+    """Make the replicas bit-identical at start-up (weights come from rank 0)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat

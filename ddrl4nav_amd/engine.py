@@ -111,6 +111,14 @@ class HotPath:
         check(self.lib.ddrl_categorical_stats(_ptr(probs), n, A, _ptr(p_hat), _ptr(logits), _ptr(ent), _stream()))
         return p_hat, logits, ent
 
+    def categorical_sample(self, probs, seed, stream_id):
+        n, A = probs.shape
+        action = torch.empty(n, dtype=torch.float32, device=probs.device)
+        logp = torch.empty(n, dtype=torch.float32, device=probs.device)
+        check(self.lib.ddrl_categorical_sample(_ptr(probs), n, A, int(seed) & (2 ** 64 - 1),
+                                               int(stream_id) & (2 ** 64 - 1), _ptr(action), _ptr(logp), _stream()))
+        return action, logp
+
     def last_features(self, n):
         ha = torch.empty((n, 512), dtype=torch.float32, device=self.device)
         hc = torch.empty((n, 512), dtype=torch.float32, device=self.device)
@@ -142,9 +150,8 @@ class HotPath:
     def allreduce_grads(self):
         """One RCCL all-reduce (sum) of the flat gradient arena + loss tail per PPO iteration
         (SURVEY.md section 8e); gradients were pre-scaled by 1/B_global."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.process_group)
+        from .dist import allreduce_flat
+        allreduce_flat(self.grads, self.process_group)
 
     def clip_adam_step(self):
         check(self.lib.ddrl_clip_adam_step(self.ctx, _stream()))

@@ -1,0 +1,12 @@
+"""ddrl4nav_amd.nn -- mirror of the USTC_lab.nn names the Pong hot path uses."""
+from ddrl4nav_amd.nn.base import Basenn, PreNet
+from ddrl4nav_amd.nn.critic import Critic
+from ddrl4nav_amd.nn.actor import Actor, CategoricalActor, GaussionActor
+from ddrl4nav_amd.nn.atari_encoder import AtariPreNet
+from ddrl4nav_amd.nn.distribution import HipCategorical
+from ddrl4nav_amd.nn.ppo import PPO
+
+NETWORK_MAP = {"ppo": PPO}
+
+__all__ = ["PPO", "Basenn", "PreNet", "NETWORK_MAP", "CategoricalActor", "GaussionActor", "Critic", "AtariPreNet",
+           "Actor", "HipCategorical"]

@@ -1,0 +1,36 @@
+"""Actor heads (mirror of USTC_lab/nn/actor.py:10-101): parameter holders + the
+log_prob_from_distribution hook the Forward server calls (forward.py:138)."""
+from torch import nn
+
+
+class Actor(nn.Module):
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.pre = kwargs['pre']
+        self.device = kwargs['device']
+
+    def _log_prob_from_distribution(self, pi, act):
+        raise NotImplementedError
+
+    def log_prob_from_distribution(self, pi, act):
+        return self._log_prob_from_distribution(pi, act)
+
+    def forward(self, x, act=None, play_mode=False):
+        raise RuntimeError("actor heads run inside ddrl4nav_amd.nn.PPO (HIP kernels)")
+
+
+class CategoricalActor(Actor):
+    def __init__(self, action_output_dim, device='cpu', soft_max_grid=True, last_input_dim=512, pre=None, nn_dtype=None):
+        super().__init__(pre=pre, device=device)
+        self.logits_net = None
+        self.action_output_dim = action_output_dim
+        self.actor_linear = nn.Linear(last_input_dim, action_output_dim)
+        self.soft_max_grid = soft_max_grid
+
+    def _log_prob_from_distribution(self, pi, act):
+        return pi.log_prob(act)
+
+
+class GaussionActor(Actor):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("GaussionActor belongs to the nav-encoder configs (SURVEY.md section 8f row 3)")

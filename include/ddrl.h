@@ -116,6 +116,11 @@ int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const floa
 int32_t ddrl_categorical_stats(const float* probs, int32_t n, int32_t n_actions, float* p_hat,
                                float* logits, float* entropy, void* stream);
 
+/* dist.sample() (forward.py:137) for an existing probs tensor: fresh inverse-CDF draws with the
+ * counter-based stream U(seed, stream_id, i); logp_out may be NULL. */
+int32_t ddrl_categorical_sample(const float* probs, int32_t n, int32_t n_actions, uint64_t seed,
+                                uint64_t stream_id, float* action_out, float* logp_out, void* stream);
+
 /* Encoder outputs of the last ddrl_forward / ddrl_ppo_iter call: h[e][i][512], e = 0 actor,
  * 1 critic (AtariPreNet.forward, atari_encoder.py:25-32).  Copies n*512 floats each. */
 int32_t ddrl_last_features(ddrl_ctx* ctx, int32_t n, float* h_actor, float* h_critic, void* stream);

@@ -273,6 +273,37 @@ def main():
     blob = b"".join(net._encode_wb(v.detach().numpy()) for k, v in list(net.named_parameters())[8:12])
     np.savez(os.path.join(HERE, "f7_codec.npz"), enc=np.frombuffer(enc, np.uint8),
              fwd=np.frombuffer(fwd, np.uint8), blob_heads=np.frombuffer(blob, np.uint8))
+    # ---- F8: drop-in surface: ConfigNN contract values + Experience.batch_data -------------
+    import json
+    contract = {}
+    for k in ("NETWORK_TYPE", "USE_RND", "AC_INPUT_DIM", "EXTRINSIC_DISCOUNT", "LANDA", "LEARNING_RATE",
+              "ACTOR_LEARNING_RATE", "CRITIC_LEARNING_RATE", "V_LOSS_THETA", "ENTROPY_LOSS_THETA", "PPO_CLIP",
+              "DUEL_PPO_CLIP", "TRAINING_ITER_TIME", "TRAINING_MIN_BATCH", "SOFT_MAX_GRID", "CLIP_GRID", "CLIP_GRID_NUM",
+              "SMOOTH_L1_LOSS", "SHARE_CNN_NET", "HALF", "MODULE_BITS", "MODEL_TO_REDIS_FREQUENCY", "ACTION_OUTPUT_DIM",
+              "ACTIONS_DIM"):
+        contract[k] = getattr(cfg_nn, k)
+    with open(os.path.join(HERE, "f8_config_nn.json"), "w") as f:
+        json.dump(contract, f, indent=1, sort_keys=True)
+    rng = np.random.default_rng(8)
+    steps = []
+    for t in range(5):
+        m = 3
+        steps.append(dict(states=[rng.integers(0, 256, size=(m, 2, 4, 4), dtype=np.uint8)],
+                          advs=rng.normal(size=m).astype(np.float32), actions=rng.integers(0, 6, size=m).astype(np.float32),
+                          old_logps=rng.normal(size=m).astype(np.float32), values=rng.normal(size=(1, m)).astype(np.float32),
+                          is_clean=rng.random(m) < 0.7))
+    ref_exps = [Experience(**s) for s in steps]
+    b_all = Experience.batch_data(ref_exps)
+    b_clean = Experience.batch_data(ref_exps, clean=False)
+    f8 = {}
+    for i, s in enumerate(steps):
+        for k, v in s.items():
+            f8["in%d/%s" % (i, k)] = v[0] if k == "states" else v
+    for tag, b in (("all", b_all), ("clean", b_clean)):
+        f8[tag + "/states"] = b.states[0]
+        f8[tag + "/advs"], f8[tag + "/actions"], f8[tag + "/old_logps"], f8[tag + "/values"] = b.advs, b.actions, b.old_logps, b.values
+    np.savez(os.path.join(HERE, "f8_experience.npz"), **f8)
+
     print("golden vectors written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

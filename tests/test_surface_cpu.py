@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirror of the reference's plug-in surface: ConfigNN contract,
+Experience batching, weight-blob format, env sharding and the gloo all-reduce path."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from ddrl4nav_amd.utils.recipe import flatten, make_weights, param_specs
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_config_nn_contract_matches_reference():
+    from ddrl4nav_amd.config import ConfigNN
+    want = json.load(open(os.path.join(GOLDEN, "f8_config_nn.json")))
+    cfg = ConfigNN({"discrete_action": True, "discrete_actions": list(range(6))})
+    for k, v in want.items():
+        assert getattr(cfg, k) == v, k
+    from ddrl4nav_amd.nn import CategoricalActor
+    assert cfg.ACTOR_CLASS is CategoricalActor
+    with pytest.raises(NotImplementedError):
+        ConfigNN({"discrete_action": False, "act_dim": 2})
+
+
+def test_base_config_and_game_type():
+    from ddrl4nav_amd.config import BaseConfig, game_type
+    assert game_type("PongNoFrameskip-v4") == "atari" and game_type("CartPole-v1") == "classical"
+    with pytest.raises(NameError):
+        game_type("NoSuchGame")
+    parse = types.SimpleNamespace(task="t", ip="localhost")
+    c = BaseConfig(parse, {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8})
+    assert c.TASK_TYPE == "atari" and c.PREDICTING_MIN_BATCH == 4 and c.TIME_MAX == 256 and c.TASK_NAME == "t-127.0.0.1"
+
+
+def test_experience_batch_data_golden(golden):
+    from ddrl4nav_amd.data import Experience
+    g = golden("f8_experience")
+    exps = [Experience(states=[g["in%d/states" % i]], advs=g["in%d/advs" % i], actions=g["in%d/actions" % i],
+                       old_logps=g["in%d/old_logps" % i], values=g["in%d/values" % i], is_clean=g["in%d/is_clean" % i])
+            for i in range(5)]
+    for tag, clean in (("all", True), ("clean", False)):
+        b = Experience.batch_data(exps, clean=clean)
+        assert np.array_equal(b.states[0], g[tag + "/states"])
+        for k in ("advs", "actions", "old_logps", "values"):
+            assert np.array_equal(getattr(b, k), g[tag + "/" + k]), (tag, k)
+    assert len(Experience.batch_data(exps)) == 15
+    chunks = list(Experience.batch_data_gene(exps * 30))  # 150 records -> 64 + 64 + 22
+    assert [len(c.is_clean) > 0 for c in chunks] == [True] * 3
+    # to_tensor keeps uint8 frames uint8 and casts the rest
+    b = Experience.batch_data(exps)
+    b.to_tensor(dtype=torch.float32, device="cpu")
+    assert b.states[0].dtype == torch.uint8 and b.advs.dtype == torch.float32 and b.values.shape == (1, 15)
+
+
+def test_weight_blob_format_golden(golden):
+    """nn2redis blob: >I ndim, >I dims, raw fp32, named_parameters() order (reference base.py:38-66)."""
+    from ddrl4nav_amd.nn.base import Basenn
+    w = make_weights(0)
+    names = [n for n, _, _ in param_specs()][8:12]
+    enc = Basenn._encode_wb(None, w[names[0]])
+    assert enc[:4] == b"\x00\x00\x00\x02" and enc[4:12] == b"\x00\x00\x00\x06\x00\x00\x02\x00"
+    blob = b"".join(Basenn._encode_wb(None, w[n]) for n in names)
+    assert np.array_equal(np.frombuffer(blob, np.uint8), golden("f7_codec")["blob_heads"])
+    me = types.SimpleNamespace(model_dtype=np.float32, model_dtype_bytes=4, device="cpu")
+    t, used = Basenn._decode_wb(me, blob)
+    assert tuple(t.shape) == (6, 512) and used == 12 + 6 * 512 * 4
+    assert np.array_equal(t.numpy(), w[names[0]])
+
+
+def test_shard_envs():
+    from ddrl4nav_amd.dist import shard_envs
+    assert [shard_envs(2048, 8, r) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+    spans = [shard_envs(10, 4, r) for r in range(4)]
+    assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from ddrl4nav_amd.dist import allreduce_flat, global_batch, init_from_env, shard_envs
+    from oracle import ddrl_oracle as O
+    torch.set_num_threads(1)
+    init_from_env(backend="gloo")
+    g = np.load(os.path.join(GOLDEN, "f3_loss.npz"))
+    B = 16
+    lo, hi = shard_envs(B, world, rank)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    x = O.frames_to_f32(g["frames"][lo:hi])
+    t = lambda k: torch.from_numpy(g[k][lo:hi])
+    bg = global_batch(hi - lo)
+    # what ddrl_ppo_iter does on each rank: local sums scaled by 1/B_global
+    _, al, vl, ent = O.ppo_losses(net, x, t("actions"), t("old_logps"), t("advs"), t("rets"))
+    scale = (hi - lo) / bg
+    (al * scale).backward()
+    (vl * scale).backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()] +
+                     [torch.stack([al.detach() * scale, vl.detach() * scale, ent.detach() * scale])])
+    allreduce_flat(flat)
+    q.put((rank, bg, flat.numpy()))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_allreduce_equals_full_batch():
+    """world_size 2 on CPU: shard the batch, scale by 1/B_global, SUM all-reduce the flat arena ->
+    the full-batch gradient and loss means (the N>1 path of bench.py / PPO.learn)."""
+    import torch.multiprocessing as mp
+    from oracle import ddrl_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[0][1] == 16 and np.array_equal(outs[0][2], outs[1][2])  # replicas agree bit for bit
+    g = np.load(os.path.join(GOLDEN, "f3_loss.npz"))
+    torch.set_num_threads(1)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    t = lambda k: torch.from_numpy(g[k][:16])
+    _, al, vl, ent = O.ppo_losses(net, O.frames_to_f32(g["frames"][:16]), t("actions"), t("old_logps"), t("advs"), t("rets"))
+    al.backward()
+    vl.backward()
+    full = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    got = outs[0][2]
+    assert np.abs(got[:-3] - full).max() <= 2e-6 * np.abs(full).max()
+    np.testing.assert_allclose(got[-3:], [al.item(), vl.item(), ent.item()], rtol=1e-5, atol=1e-7)

@@ -1,0 +1,218 @@
+"""GPU tests of the drop-in surface: create_net / PPO.forward / PPO.learn protocol, state_dict
+and Redis-blob interchange, Agents._accumulate_rewards, the device-resident rollout and the
+pinned-host ring.  Run with `-m gpu`."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from ddrl4nav_amd.utils.recipe import flatten, make_weights, param_specs
+from oracle import ddrl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _configs(n_actions=6):
+    from ddrl4nav_amd.config import BaseConfig, ConfigNN
+    env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "int_frame_stack": 4,
+           "discrete_action": True, "discrete_actions": list(range(n_actions)), "agent_num_per_env": 1, "batch_num_per_env": 8}
+    parse = types.SimpleNamespace(task="test", ip="127.0.0.1")
+    return {"config": BaseConfig(parse, env), "config_nn": ConfigNN(env), "config_env": env}
+
+
+@pytest.fixture(scope="module")
+def net():
+    from ddrl4nav_amd.runner import create_net
+    n = create_net(_configs(), max_batch=128)
+    n.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    return n
+
+
+def test_create_net_param_names_and_arena_aliasing(net):
+    names = [k for k, _ in net.named_parameters()]
+    assert names == [n for n, _, _ in param_specs()]
+    assert list(net.state_dict().keys()) == names  # .pt checkpoints interchange with the reference
+    flat = net.hot_path.params
+    assert flat.numel() == 3371847
+    np.testing.assert_array_equal(flat.cpu().numpy(), flatten(make_weights(0)))
+    # parameters are views of the flat arena
+    p = dict(net.named_parameters())["critic.critic_linear.bias"]
+    p.data.fill_(0.25)
+    assert float(flat[1687206 + 512].item()) == 0.25
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    assert net.rnd is None
+
+
+def test_forward_protocol_matches_reference_shapes(net, golden):
+    g = golden("f1_forward")
+    # the reference callers pass float32 frames = uint8/255 (forward.py:102-104)
+    x = torch.from_numpy(O.u8_lut()[g["frames"]])
+    (dist, logp), values = net([x], torch.from_numpy(g["actions"]))
+    assert isinstance(values, list) and values[0].shape == (8, 1)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(values[0].cpu().numpy()[:, 0], g["value"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dist.probs.cpu().numpy(), g["p_hat"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dist.logits.cpu().numpy(), g["logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dist.entropy().cpu().numpy(), g["entropy"], rtol=1e-5, atol=1e-6)
+    # acting call pattern of ForwardThread.run (forward.py:132-138)
+    (dist, none), values = net([torch.from_numpy(g["frames"])])
+    assert none is None
+    actions = dist.sample().to(torch.float32)
+    logps = net.actor.log_prob_from_distribution(dist, actions)
+    want = dist.logits.gather(-1, actions.long().unsqueeze(-1)).squeeze(-1)
+    np.testing.assert_allclose(logps.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert actions.shape == (8,) and float(actions.min()) >= 0 and float(actions.max()) <= 5
+    again = dist.sample()
+    assert again.shape == (8,)
+    # play_mode returns the raw softmax (actor.py:94-96)
+    (probs, _), _ = net([torch.from_numpy(g["frames"])], play_mode=True)
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+    assert torch.argmax(probs, dim=1).shape == (8,)
+
+
+def test_learn_generator_protocol_golden_f4(net, golden):
+    from ddrl4nav_amd.data import Experience
+    g3, g4 = golden("f3_loss"), golden("f4_learn")
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    net.hot_path.reset_optimizer()
+    net.update_time = 0
+    exp = Experience(states=[g3["frames"]], advs=g3["advs"], actions=g3["actions"], old_logps=g3["old_logps"],
+                     values=g3["rets"].reshape(1, -1))
+    exp.to_tensor(dtype=torch.float32, device="cuda")
+    ref = g4["losses"]
+    spread = np.maximum(np.abs(ref - g4["losses_f64"]), np.abs(ref - g4["losses_f32t8"]))
+    env = np.maximum.accumulate(spread, axis=0)
+    seen = 0
+    for loss_items, update_time, last in net.learn(exp):
+        seen += 1
+        assert update_time == seen and last is True
+        assert set(loss_items) == {"PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss", "PpoBackUpTime"}
+        got = np.array([loss_items[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
+        tol = 10.0 * env[seen - 1] + 1e-5 * np.abs(ref[seen - 1]) + 2e-6
+        assert np.all(np.abs(got - ref[seen - 1]) <= tol), (seen, got, ref[seen - 1])
+    assert seen == 10 and net.update_time == 10
+
+
+def test_redis_blob_and_checkpoint_roundtrip(net, tmp_path):
+    store = {}
+
+    class Pipe:
+        def set(self, k, v):
+            store[k] = v
+
+        def incr(self, k):
+            store[k] = store.get(k, 0) + 1
+
+        def execute(self):
+            pass
+
+    class Conn:
+        def get(self, k):
+            return store[k]
+
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    net.nn2redis(Pipe(), "TAG")
+    assert store["TAG"] == 1 and len(store[net.model_key]) == 13487388 + sum(4 + 4 * len(s) for _, s, _ in param_specs())
+    before = net.hot_path.params.clone()
+    net.hot_path.params.zero_()
+    net.updatenn_by_redis(Conn())
+    assert torch.equal(net.hot_path.params, before)
+    path = str(tmp_path / "m_10.pt")
+    torch.save(net.state_dict(), path)
+    net.hot_path.params.zero_()
+    net.updatenn("file://" + path)
+    assert torch.equal(net.hot_path.params, before)
+    # derived weight layouts follow the reload: forward still matches the oracle
+    frames = np.random.default_rng(0).integers(0, 256, size=(4, 4, 84, 84), dtype=np.uint8)
+    (probs, _), values = net([torch.from_numpy(frames)], play_mode=True)
+    onet = O.OraclePPO()
+    onet.load_weights(make_weights(0))
+    with torch.no_grad():
+        oprobs, _, _, ov = onet(O.frames_to_f32(frames))
+    np.testing.assert_allclose(probs.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_agents_accumulate_rewards_golden_f2(golden):
+    from ddrl4nav_amd.agent import Agents
+    from ddrl4nav_amd.data import Experience
+    cfgs = _configs()
+    ag = Agents(config=cfgs["config"], config_nn=cfgs["config_nn"], config_env=cfgs["config_env"])
+    g = golden("f2_gae")
+    T, N = 256, 8
+    exps = [Experience(states=[np.zeros((N, 1), np.float32)], values=g["values"][t:t + 1].copy(),
+                       dones=g["dones"][t:t + 1].copy()) for t in range(T + 1)]
+    out = ag._accumulate_rewards(exps, g["rewards"][:T + 1].reshape(T + 1, 1, N).copy())
+    assert len(out) == T and out[0] is exps[0]
+    assert np.array_equal(np.stack([e.advs for e in out]), g["adv1"])
+    assert np.array_equal(np.stack([e.values[0] for e in out]), g["ret1"])
+    assert ag._accumulate_rewards([], None) == []
+
+
+def test_device_rollout_end_to_end_vs_oracle(net):
+    """T acting steps + bootstrap + GAE + one learn() on the pool, against the oracle run on the
+    same frames with the actions the HIP sampler drew."""
+    from ddrl4nav_amd.agent import DeviceRollout
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    net.hot_path.reset_optimizer()
+    N, T = 6, 5
+    rng = np.random.default_rng(42)
+    frames = rng.integers(0, 256, size=(T + 1, N, 4, 84, 84), dtype=np.uint8)
+    rewards = rng.choice(np.array([-1, 0, 1], np.float32), size=(T, N)).astype(np.float32)
+    dones = (rng.random((T, N)) < 0.2).astype(np.uint8)
+    ro = DeviceRollout(net, N, horizon=T, seed=3)
+    for t in range(T):
+        ro.put_frames(t, torch.from_numpy(frames[t]).cuda())
+        ro.act(t)
+        ro.record(t, torch.from_numpy(rewards[t]).cuda(), torch.from_numpy(dones[t]).cuda())
+    ro.put_frames(T, torch.from_numpy(frames[T]).cuda())
+    ro.bootstrap()
+    ro.finish()
+    onet = O.OraclePPO()
+    onet.load_weights(make_weights(0))
+    x_all = O.frames_to_f32(frames.reshape(-1, 4, 84, 84))
+    with torch.no_grad():
+        _, _, ologits, ov = onet(x_all)
+    ov = ov.numpy()[:, 0].reshape(T + 1, N)
+    np.testing.assert_allclose(ro.values.cpu().numpy(), ov, rtol=1e-5, atol=1e-6)
+    acts = ro.actions.cpu().numpy()
+    ologp = O.categorical_log_prob(ologits[:T * N], torch.from_numpy(acts.reshape(-1))).numpy().reshape(T, N)
+    np.testing.assert_allclose(ro.logps.cpu().numpy(), ologp, rtol=1e-5, atol=1e-6)
+    oadv, oret = O.gae(ro.values.cpu().numpy(), rewards, dones)  # same values in -> bit-exact scan
+    assert np.array_equal(ro.adv.cpu().numpy(), oadv) and np.array_equal(ro.ret.cpu().numpy(), oret)
+    batch = ro.batch()
+    assert len(batch) == N * T and batch.values.shape == (1, N * T)
+    first = next(net.learn(batch))[0]
+    opt = onet.make_optims()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a.reshape(-1)))
+    old = t(ro.logps.cpu().numpy())
+    ld = next(O.learn(onet, opt, x_all[:T * N], t(acts), old, t(oadv), t(oret), iters=1))[0]
+    for k in ("ActorLoss", "VLoss", "EntLoss", "PpoTotalLoss"):
+        np.testing.assert_allclose(first[k], ld[k], rtol=1e-4, atol=1e-5)
+    ro.carry_over()
+    assert torch.equal(ro.frames[0], ro.frames[T])
+
+
+def test_pinned_ring_feeds_pool():
+    from ddrl4nav_amd.data import PinnedRing
+    from ddrl4nav_amd._lib import DdrlError
+    slot = 8 * 4 * 84 * 84
+    ring = PinnedRing(slot, n_slots=3)
+    rng = np.random.default_rng(1)
+    dst = torch.zeros((5, 8, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    sent = []
+    copy_stream = torch.cuda.Stream()
+    for i in range(5):  # more messages than slots: exercises recycling
+        buf = ring.acquire(timeout_ms=2000)
+        data = rng.integers(0, 256, size=slot, dtype=np.uint8)
+        buf[:slot] = data
+        sent.append(data)
+        ring.commit()
+        assert ring.pending() == 1
+        ring.pop_to(dst[i], stream=copy_stream)
+    copy_stream.synchronize()
+    for i in range(5):
+        assert np.array_equal(dst[i].cpu().numpy().reshape(-1), sent[i])
+    with pytest.raises(DdrlError):
+        ring.pop_to(dst[0], timeout_ms=10)  # nothing committed -> timeout, not a hang
+    ring.close()
