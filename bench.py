@@ -6,6 +6,9 @@ One "step" = one full pass of the path over one rollout of synthetic Pong-shaped
   one bootstrap forward, the GAE scan, and one PPO update = TRAINING_ITER_TIME=10 full-batch
   iterations (forward + loss + backward + [all-reduce] + grad-norm clip + 2x Adam) on
   B = N*T = 65,536 samples.  Frames are already resident in HBM (uint8 [T+1,N,4,84,84]).
+The loop is driven through the product surface: runner.create_net -> nn.PPO,
+agent.DeviceRollout (device-resident experience pool) and net.learn() (the reference's generator
+protocol, one host sync per iteration for the loss dict).
 
 metric: env-steps/s for the whole job = n_gpus * N * T * steps / wall time (max over ranks).
 Prints ONE JSON line on rank 0 (see the contract in the task statement).
@@ -15,6 +18,7 @@ import json
 import os
 import sys
 import time
+import types
 
 import numpy as np
 import torch
@@ -23,14 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic work (restated in DESIGN.md)
+# algorithmic work per sample and encoder (restated in DESIGN.md), in MACs
 MAC = {"ConvFwd1": 32 * 400 * 256, "ConvFwd2": 64 * 81 * 512, "ConvFwd3": 64 * 49 * 576, "FcFwd": 512 * 3136,
        "ConvWgrad1": 32 * 400 * 256, "ConvWgrad2": 64 * 81 * 512, "ConvWgrad3": 64 * 49 * 576, "FcWgrad": 512 * 3136,
        "ConvDgrad2": 64 * 81 * 512, "ConvDgrad3": 64 * 49 * 576, "FcDgrad": 512 * 3136}
 FLOP_ACT_PER_STEP = 37_379_072          # per env-step, both encoders + heads
 FLOP_TRAIN_PER_SAMPLE = 99_030_016      # per sample per PPO iteration
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense f32-input MFMA = fp32 vector peak
-PEAK_HBM_GBS = 8000.0
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -68,10 +71,24 @@ def cpu_baseline(seconds_budget=20.0):
         iters += 1
     t_iter = (time.perf_counter() - t0) / iters / B  # s per sample per iteration
     per_env_step = t_fwd + 10 * t_iter
-    return {"value": 1.0 / per_env_step, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / per_env_step, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": "oracle (torch-CPU fp32 restatement of PPO.forward/learn): forward n=256 x%d, "
                       "PPO iteration B=1024 x%d; per env-step = 1 forward + 10 iterations" % (reps, iters),
-            "forward_samples_per_s": 1.0 / t_fwd, "ppo_iter_ms_B1024": t_iter * B * 1e3, "host_cpus": cores}
+            "forward_samples_per_s": round(1.0 / t_fwd, 1), "ppo_iter_ms_B1024": round(t_iter * B * 1e3, 2),
+            "host_cpus": cores}
+
+
+def build_net(n_envs, horizon, iters):
+    from ddrl4nav_amd.config import BaseConfig, ConfigNN
+    from ddrl4nav_amd.runner import create_net
+    env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": n_envs, "int_frame_stack": 4,
+           "discrete_action": True, "discrete_actions": list(range(6)), "agent_num_per_env": 1, "batch_num_per_env": n_envs}
+    parse = types.SimpleNamespace(task="bench", ip="127.0.0.1")
+    config_nn = ConfigNN(env)
+    config_nn.TRAINING_ITER_TIME = iters
+    config = BaseConfig(parse, env)
+    config.TIME_MAX = horizon
+    return create_net({"config": config, "config_nn": config_nn, "config_env": env}, max_batch=n_envs * horizon), config_nn
 
 
 def main():
@@ -85,62 +102,51 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
+    from ddrl4nav_amd.dist import broadcast_params, init_from_env
+    rank, world, local_rank = init_from_env()
+    if world == 1:
         torch.cuda.set_device(0)
+    import torch.distributed as dist
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    from ddrl4nav_amd.engine import HotPath, Timer
-    from ddrl4nav_amd.utils.recipe import flatten, make_weights
+    from ddrl4nav_amd.agent import DeviceRollout
+    from ddrl4nav_amd.engine import Timer
+    from ddrl4nav_amd.utils.recipe import make_weights
 
     N, T, ITERS = args.envs, args.horizon, args.iters
     B = N * T
-    hp = HotPath(max_batch=B, device=dev)
-    hp.set_params(flatten(make_weights(0)))
+    net, config_nn = build_net(N, T, ITERS)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    hp = net.hot_path
+    broadcast_params(hp.params)
+    hp.params_changed()
     hp.profile(True)
 
-    # ---- synthetic rollout inputs, resident in HBM before the timed region ----
+    # ---- synthetic rollout inputs, resident in HBM before the timed region (SURVEY.md section 8d) ----
+    ro = DeviceRollout(net, N, horizon=T, gamma=config_nn.EXTRINSIC_DISCOUNT, landa=config_nn.LANDA, seed=rank * 1000003)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    frames = torch.randint(0, 256, (T + 1, N, 4, 84, 84), dtype=torch.uint8, device=dev, generator=g)
+    ro.frames.copy_(torch.randint(0, 256, ro.frames.shape, dtype=torch.uint8, device=dev, generator=g))
     u = torch.rand((T, N), device=dev, generator=g)
-    rewards = torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)).to(torch.float32).contiguous()
-    dones = (torch.rand((T, N), device=dev, generator=g) < (1.0 / 800)).to(torch.uint8).contiguous()
-    values = torch.empty((T + 1, N), dtype=torch.float32, device=dev)
-    actions = torch.empty((T, N), dtype=torch.float32, device=dev)
-    logps = torch.empty((T, N), dtype=torch.float32, device=dev)
-    probs = torch.empty((N, 6), dtype=torch.float32, device=dev)
-    adv = torch.empty((T, N), dtype=torch.float32, device=dev)
-    ret = torch.empty((T, N), dtype=torch.float32, device=dev)
-    frames_flat = frames[:T].reshape(B, 4, 84, 84)
+    ro.rewards.copy_(torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)))
+    ro.dones.copy_((torch.rand((T, N), device=dev, generator=g) < (1.0 / 800)).to(torch.uint8))
 
     t_act, t_gae, t_upd = Timer(), Timer(), Timer()
     phase = {"act_ms": 0.0, "gae_ms": 0.0, "update_ms": 0.0}
+    last = {}
 
-    def one_step(step_idx, timed):
+    def one_step(timed):
         t_act.start()
         for t in range(T):
-            hp.forward(frames[t], seed=step_idx, stream_id=t, probs=probs, value=values[t], action=actions[t],
-                       logp=logps[t])
-        hp.forward(frames[T], seed=step_idx, stream_id=T, probs=probs, value=values[T], action=actions[0].clone(),
-                   logp=logps[0].clone())
+            ro.act(t)
+        ro.bootstrap()
         t_act.stop()
         t_gae.start()
-        hp.gae(values, rewards, dones, adv=adv, ret=ret)
+        ro.finish()
         t_gae.stop()
         t_upd.start()
-        for _ in range(ITERS):
-            hp.ppo_iter(frames_flat, actions.view(-1), logps.view(-1), adv.view(-1), ret.view(-1), b_global=B * world)
-            hp.allreduce_grads()
-            hp.clip_adam_step()
+        for loss_items, _, _ in net.learn(ro.batch()):
+            last.update(loss_items)
         t_upd.stop()
         if timed:
             torch.cuda.synchronize()
@@ -148,24 +154,24 @@ def main():
             phase["gae_ms"] += t_gae.elapsed_ms()
             phase["update_ms"] += t_upd.elapsed_ms()
 
-    for w in range(args.warmup):
-        one_step(w, False)
+    for _ in range(args.warmup):
+        one_step(False)
     torch.cuda.synchronize()
     hp.profile(False)
     hp.profile_read()
     hp.profile(True)  # reset accumulators: per-kernel times cover the timed region only
-    if dist is not None:
+    if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        one_step(args.warmup + s, True)
+    for _ in range(args.steps):
+        one_step(True)
     torch.cuda.synchronize()
-    if dist is not None:
+    if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
+    if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -176,29 +182,31 @@ def main():
         steps = args.steps
         env_steps = world * N * T * steps
         value = env_steps / elapsed
-        # dominant kernel = largest accumulated time among the GEMM-shaped kernels
-        gemm = {k: v for k, v in prof.items() if k in MAC}
-        dom = max(gemm, key=lambda k: gemm[k][0]) if gemm else None
         kernels = {}
         for k, (ms, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
             ent = {"ms_total": round(ms, 3), "calls": calls, "ms_avg": round(ms / max(calls, 1), 4)}
             if k in MAC:
-                # launches inside ppo_iter process B samples, acting launches N samples; both encoders
+                # training launches process B samples, acting launches N samples; both encoders
                 train_calls = steps * ITERS
-                act_calls = calls - train_calls if k.endswith(("Fwd1", "Fwd2", "Fwd3", "FcFwd")) else 0
-                flop = 2.0 * 2 * MAC[k] * (B * train_calls + N * max(act_calls, 0))
+                act_calls = max(calls - train_calls, 0) if k.startswith("ConvFwd") else 0
+                if k == "FcFwd":
+                    train_calls = calls
+                flop = 2.0 * 2 * MAC[k] * (B * train_calls + N * act_calls)
                 ent["tflops"] = round(flop / (ms * 1e-3) / 1e12, 2)
+                ent["flop_per_launch_train"] = 2 * 2 * MAC[k] * B
             kernels[k] = ent
+        # dominant kernel = largest accumulated time among the GEMM-shaped kernels
+        gemm = {k: v for k, v in kernels.items() if k in MAC}
         roofline = None
-        if dom is not None:
-            ms, calls = gemm[dom]
-            is_fwd = dom.endswith(("Fwd1", "Fwd2", "Fwd3", "FcFwd"))
-            flop_total = 2.0 * 2 * MAC[dom] * (B * steps * ITERS + (N * (calls - steps * ITERS) if is_fwd else 0))
-            achieved = flop_total / (ms * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                        "avg_launch_ms": round(ms / calls, 4), "launches": calls,
-                        "flop_per_sample_per_launch": 2 * 2 * MAC[dom]}
+        if gemm:
+            dom = max(gemm, key=lambda k: gemm[k]["ms_total"])
+            d = gemm[dom]
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
+                        "algorithmic_flop_per_sample_per_launch": 2 * 2 * MAC[dom],
+                        "note": "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32; HIP events around each launch on the "
+                                "launch stream; acting-size launches of forward kernels are folded in by their own FLOPs"}
         upd_ms = phase["update_ms"] / steps
         total_flop = env_steps / world * (FLOP_ACT_PER_STEP + ITERS * FLOP_TRAIN_PER_SAMPLE)
         out = {
@@ -213,13 +221,15 @@ def main():
             "acting_ms_per_rollout": round(phase["act_ms"] / steps, 2), "gae_ms": round(phase["gae_ms"] / steps, 4),
             "acting_env_steps_per_s_per_gpu": round(N * (T + 1) / (phase["act_ms"] / steps * 1e-3), 1),
             "whole_step_tflops_per_gpu": round(total_flop / elapsed / 1e12, 2),
-            "last_losses": stats, "roofline": roofline, "kernels": kernels,
+            "whole_step_frac_of_f32_peak": round(total_flop / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
+            "roofline": roofline, "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     hp.close()
-    if dist is not None:
+    if world > 1:
         dist.destroy_process_group()
 
 
