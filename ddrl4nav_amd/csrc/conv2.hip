@@ -27,6 +27,7 @@ struct ConvFwd2v2 {
   static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
   static constexpr int NS = 5, W_FLOATS = 32 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 2 * 400;
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  static constexpr int EXTRA = 64;  // bias vector, read by the epilogue from LDS
   struct Params {
     const float* in;  // a1
     int64_t in_es;
@@ -46,7 +47,7 @@ struct ConvFwd2v2 {
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 4) * 20 + (s % 4); }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -58,6 +59,7 @@ struct ConvFwd2v2 {
     kb_end = 16;
     in = p.in + e * p.in_es;
     wp = p.wp + (int64_t)e * 16 * 2048;
+    if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
@@ -92,7 +94,7 @@ struct ConvFwd2v2 {
     }
   }
   __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -104,7 +106,7 @@ struct ConvFwd2v2 {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int oc = i * 32 + acc_row(r, hi);
-          dst[oc * 81] = leaky_f(acc[i][j][r] + p.params[p.bias_off[e] + oc]);
+          dst[oc * 81] = leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]);
         }
     }
   }
@@ -118,6 +120,7 @@ struct ConvFwd3v2 {
   static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 18;
   static constexpr int NS = 7, W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = 2272;  // 7*4*81 = 2268
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  static constexpr int EXTRA = 64;  // bias vector
   struct Params {
     const float* in;  // a2
     int64_t in_es;
@@ -137,7 +140,7 @@ struct ConvFwd3v2 {
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 9) * 162 + ((s % 9) / 3) * 9 + (s % 3); }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -149,6 +152,7 @@ struct ConvFwd3v2 {
     kb_end = 16;
     in = p.in + e * p.in_es;
     wp = p.wp + (int64_t)e * 16 * 2304;
+    if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
@@ -185,7 +189,7 @@ struct ConvFwd3v2 {
     }
   }
   __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -197,7 +201,7 @@ struct ConvFwd3v2 {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int oc = i * 32 + acc_row(r, hi);
-          dst[oc * 49] = leaky_f(acc[i][j][r] + p.params[p.bias_off[e] + oc]);
+          dst[oc * 49] = leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]);
         }
     }
   }
@@ -214,6 +218,7 @@ struct ConvFwd1v2 {
   static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 32;
   static constexpr int W_FLOATS = 64 * 64, IMG_OFF = W_FLOATS, IMG_ROWS = 64, IMG_FLOATS = IMG_ROWS * 84;
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  static constexpr int EXTRA = 64;  // bias of both encoders
   struct Params {
     const uint8_t* frames;
     const float* wp;  // [4][32][2][64]
@@ -233,7 +238,7 @@ struct ConvFwd1v2 {
   int64_t src0, src1;        // byte offsets of the two row ranges inside channel 0
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 4) * 84 + ((2 * (s % 4)) & 3) * 21 + ((2 * (s % 4)) >> 2); }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -257,6 +262,7 @@ struct ConvFwd1v2 {
     nd_total = nd0 + nrows1 * 21;
     src0 = (int64_t)b0 * 28224 + iy0_start * 84;
     src1 = (int64_t)b1 * 28224;
+    if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[tid >> 5] + (tid & 31)];
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
@@ -301,7 +307,7 @@ struct ConvFwd1v2 {
     }
   }
   __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -313,7 +319,7 @@ struct ConvFwd1v2 {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int oc = acc_row(r, hi);
-          dst[oc * 400] = leaky_f(acc[i][j][r] + p.params[p.bias_off[i] + oc]);
+          dst[oc * 400] = leaky_f(acc[i][j][r] + lds[2 * STAGE + i * 32 + oc]);
         }
       }
     }

@@ -105,9 +105,20 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
   op.epilogue(P, acc, lds2);
 }
 
+// Ops may declare `static constexpr int EXTRA` = floats of LDS behind the two stage buffers that
+// live for the whole kernel (e.g. the bias vector for the epilogue); default 0.
+template <class Op, class = void>
+struct ExtraOf {
+  static constexpr int v = 0;
+};
+template <class Op>
+struct ExtraOf<Op, decltype((void)Op::EXTRA)> {
+  static constexpr int v = Op::EXTRA;
+};
+
 template <class Op>
 inline void launch_engine2(dim3 grid, const typename Op::Params& p, hipStream_t st) {
-  constexpr size_t bytes = (size_t)2 * Op::STAGE * sizeof(float);
+  constexpr size_t bytes = (size_t)(2 * Op::STAGE + ExtraOf<Op>::v) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     if (bytes > 64 * 1024)
