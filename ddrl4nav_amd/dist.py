@@ -22,10 +22,12 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DDRL_DIST_BACKEND=gloo lets several ranks share one GPU (single-GPU test boxes)
+            backend = os.environ.get("DDRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
