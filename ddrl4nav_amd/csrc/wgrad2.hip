@@ -38,13 +38,14 @@ struct ConvWgrad1v2 {
   static constexpr int64_t SLAB = 32 * 256 + 32;
   struct Params {
     const uint8_t* frames;
-    const float* dz;  // dz1 [e][n][32][400]
+    const float* dz;   // da1 [e][n][32][400], raw output of ConvDgrad2 (no leaky' yet)
+    const float* act;  // a1, same layout: dz1 = leaky'(a1) * da1 is formed while staging
     int64_t dz_es;
     float* part;  // [nsplit][e][SLAB]
     int n, nsplit;
   };
   struct Regs {
-    float4 dzr[3];
+    float4 dzr[3], actr[3];
     unsigned im[6];
   };
   int abase[2], bbase[2], kb_begin, kb_end;
@@ -80,9 +81,10 @@ struct ConvWgrad1v2 {
       const int row = idx / 5, q4 = idx % 5;
       const int smp = row >> 6, e = (row >> 5) & 1, oc = row & 31;
       const int b = 2 * pair + smp;
-      r.dzr[j] = (idx < 640 && b < p.n)
-                     ? *(const float4*)(p.dz + e * p.dz_es + (int64_t)b * 12800 + oc * 400 + oy * 20 + q4 * 4)
-                     : make_float4(0, 0, 0, 0);
+      const bool ok = idx < 640 && b < p.n;
+      const int64_t off = e * p.dz_es + (int64_t)b * 12800 + oc * 400 + oy * 20 + q4 * 4;
+      r.dzr[j] = ok ? *(const float4*)(p.dz + off) : make_float4(0, 0, 0, 0);
+      r.actr[j] = ok ? *(const float4*)(p.act + off) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -100,7 +102,10 @@ struct ConvWgrad1v2 {
       const int idx = tid + 256 * j;
       if (idx < 640) {
         float* d = buf + (idx / 5) * 21 + (idx % 5) * 4;
-        d[0] = r.dzr[j].x; d[1] = r.dzr[j].y; d[2] = r.dzr[j].z; d[3] = r.dzr[j].w;
+        d[0] = leaky_g(r.actr[j].x, r.dzr[j].x);
+        d[1] = leaky_g(r.actr[j].y, r.dzr[j].y);
+        d[2] = leaky_g(r.actr[j].z, r.dzr[j].z);
+        d[3] = leaky_g(r.actr[j].w, r.dzr[j].w);
       }
     }
 #pragma unroll
@@ -389,7 +394,7 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
   const ParamLayout& L = *c.L;
   const int S = c.splits->c1;
   {
-    ConvWgrad1v2::Params p{c.frames, w.dz1, MB * 12800, w.wpart, c.n, S};
+    ConvWgrad1v2::Params p{c.frames, w.dz1, w.a1, MB * 12800, w.wpart, c.n, S};
     ProfRange pr(c.prof, "ConvWgrad1", st);
     launch_engine2<ConvWgrad1v2>(dim3(1, S, 1), p, st);
   }
