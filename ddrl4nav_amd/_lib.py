@@ -25,6 +25,16 @@ class Config(Structure):
     ]
 
 
+class EbArray(Structure):
+    _fields_ = [("dtype", c_int32), ("ndim", c_int32), ("dims", c_int64 * 8), ("count", c_int64),
+                ("data_offset", c_int64), ("nbytes", c_int64)]
+
+
+class EbMsg(Structure):
+    _fields_ = [("ip", c_int32 * 4), ("process_env_id", ctypes.c_uint32), ("payload_offset", c_int64),
+                ("payload_len", c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/ddrl.h declares
 SIGNATURES = {
     "ddrl_abi_version": (c_int32, []),
@@ -56,6 +66,15 @@ SIGNATURES = {
     "ddrl_ring_commit": (c_int32, [c_void_p]),
     "ddrl_ring_pop_to_device": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32]),
     "ddrl_ring_pending": (c_int32, [c_void_p, POINTER(c_int32)]),
+    "ddrl_eb_array_bytes": (c_int32, [c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
+    "ddrl_eb_encode_array": (c_int32, [c_int32, c_int32, POINTER(c_int64), c_void_p, c_void_p, c_int64, POINTER(c_int64)]),
+    "ddrl_eb_scan": (c_int32, [c_void_p, c_int64, POINTER(EbArray), c_int32, POINTER(c_int32)]),
+    "ddrl_eb_forward_header": (c_int32, [POINTER(c_int32), ctypes.c_uint32, c_uint64, c_void_p]),
+    "ddrl_eb_scan_forward_states": (c_int32, [c_void_p, c_int64, POINTER(EbMsg), c_int32, POINTER(c_int32)]),
+    "ddrl_eb_frames_to_u8": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64)]),
+    "ddrl_eb_scan_backward": (c_int32, [c_void_p, c_int64, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
+                                        POINTER(c_int64), POINTER(c_int64)]),
+    "ddrl_eb_put_u64": (c_int32, [c_uint64, c_void_p]),
     "ddrl_timer_create": (c_int32, [POINTER(c_void_p)]),
     "ddrl_timer_destroy": (c_int32, [c_void_p]),
     "ddrl_timer_start": (c_int32, [c_void_p, c_void_p]),

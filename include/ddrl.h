@@ -166,6 +166,38 @@ int32_t ddrl_ring_commit(ddrl_ring* ring);
 int32_t ddrl_ring_pop_to_device(ddrl_ring* ring, void* dst, int64_t bytes, void* stream, int32_t timeout_ms);
 int32_t ddrl_ring_pending(ddrl_ring* ring, int32_t* n_committed);
 
+/* ---- EasyBytes wire codec, host memory only -------------------
+ * Byte-exact with USTC_lab/data/easybytes.py: array record = >h dtype code (1 u8, 2 f16, 3 f32,
+ * 4 f64), >I count, >I ndim, ndim x >I dims, raw payload (:21-26,:63-75); forward-states message =
+ * >Q payload length, 4 x >H ip, >I process_env_id, arrays (:141-149); backward blob = >Q len +
+ * states arrays, >Q len + other-4 arrays, marshal tail (:151-162). */
+typedef struct ddrl_eb_array {
+  int32_t dtype, ndim;
+  int64_t dims[8];
+  int64_t count;
+  int64_t data_offset; /* of the raw payload inside the scanned buffer */
+  int64_t nbytes;
+} ddrl_eb_array;
+typedef struct ddrl_eb_msg {
+  int32_t ip[4];
+  uint32_t process_env_id;
+  int64_t payload_offset, payload_len;
+} ddrl_eb_msg;
+int32_t ddrl_eb_array_bytes(int32_t dtype, int32_t ndim, const int64_t* dims, int64_t* nbytes);
+int32_t ddrl_eb_encode_array(int32_t dtype, int32_t ndim, const int64_t* dims, const void* data,
+                             uint8_t* out, int64_t cap, int64_t* written); /* encode_data, one array */
+int32_t ddrl_eb_scan(const uint8_t* buf, int64_t len, ddrl_eb_array* out, int32_t cap, int32_t* n); /* decode_data */
+int32_t ddrl_eb_forward_header(const int32_t ip[4], uint32_t process_env_id, uint64_t payload_len, uint8_t* out20);
+int32_t ddrl_eb_scan_forward_states(const uint8_t* buf, int64_t len, ddrl_eb_msg* out, int32_t cap, int32_t* n);
+/* Frames (array `state_index`) of every message of a batched forward-states item -> contiguous
+ * uint8 in dst (e.g. a pinned ring slot); float payloads hold uint8/255.0 and are mapped back
+ * exactly with round(x*255).  Replaces decode_forward_states + state2tensor for the frames. */
+int32_t ddrl_eb_frames_to_u8(const uint8_t* buf, int64_t len, int32_t state_index, uint8_t* dst,
+                             int64_t dst_cap, int64_t* n_samples, int64_t* sample_elems);
+int32_t ddrl_eb_scan_backward(const uint8_t* buf, int64_t len, int64_t* states_off, int64_t* states_len,
+                              int64_t* other_off, int64_t* other_len, int64_t* tail_off);
+int32_t ddrl_eb_put_u64(uint64_t v, uint8_t* out8); /* big-endian >Q */
+
 /* ---- measurement hooks (bench.py): HIP-event timing on the caller's stream -------------- */
 int32_t ddrl_timer_create(void** timer);
 int32_t ddrl_timer_destroy(void* timer);

@@ -304,6 +304,36 @@ def main():
         f8[tag + "/advs"], f8[tag + "/actions"], f8[tag + "/old_logps"], f8[tag + "/values"] = b.advs, b.actions, b.old_logps, b.values
     np.savez(os.path.join(HERE, "f8_experience.npz"), **f8)
 
+    # ---- F9: EasyBytes message framings driven through the reference's own codec ---------------
+    rng = np.random.default_rng(9)
+    eb2 = EasyBytes("10.2.3.4")
+    fr_a = rng.integers(0, 256, size=(2, 4, 6, 6), dtype=np.uint8)
+    fr_b = rng.integers(0, 256, size=(3, 4, 6, 6), dtype=np.uint8)
+    vec_a = rng.normal(size=(2, 5)).astype(np.float32)
+    vec_b = rng.normal(size=(3, 5)).astype(np.float32)
+    # frames travel as float64 = uint8/255.0 (warputils.py:300), the second state as float32
+    msg = eb2.encode_forward_states(3, [fr_a / 255.0, vec_a]) + eb2.encode_forward_states(70000, [fr_b / 255.0, vec_b])
+    ids, states = eb2.decode_forward_states(msg)
+    actions = rng.integers(0, 6, size=5).astype(np.float32)
+    logps = rng.normal(size=5).astype(np.float32)
+    values = rng.normal(size=(1, 5, 1)).astype(np.float32)
+    replies = eb2.encode_forward_return_data([actions, logps, values], [2, 3])
+    st_list = [rng.integers(0, 256, size=(4, 2, 3, 3), dtype=np.uint8), rng.normal(size=(4, 2)).astype(np.float16)]
+    other = [rng.normal(size=4).astype(np.float32), rng.integers(0, 6, size=4).astype(np.float32),
+             rng.normal(size=4).astype(np.float32), rng.normal(size=(1, 4)).astype(np.float32)]
+    stats = {"RewardEpisode": 1.5, "steps": 7}
+    blob = eb2.encode_backward_data([st_list] + other, stats)
+    d_states, d_other, d_stats = eb2.decode_backward_data(blob)
+    import marshal
+    tail = len(marshal.dumps(stats))
+    np.savez(os.path.join(HERE, "f9_easybytes.npz"), fr_a=fr_a, fr_b=fr_b, vec_a=vec_a, vec_b=vec_b,
+             msg=np.frombuffer(msg, np.uint8), ids=np.array(ids), dec_frames=states[0], dec_vec=states[1],
+             actions=actions, logps=logps, values=values, reply0=np.frombuffer(replies[0], np.uint8),
+             reply1=np.frombuffer(replies[1], np.uint8), st0=st_list[0], st1=st_list[1], o0=other[0], o1=other[1],
+             o2=other[2], o3=other[3], blob_head=np.frombuffer(blob[:-tail], np.uint8), tail_len=np.int64(tail),
+             machine_bytes=np.frombuffer(eb2.machine_bytes, np.uint8))
+    assert d_stats == stats and np.array_equal(d_states[0], st_list[0]) and np.array_equal(d_other[3], other[3])
+
     print("golden vectors written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -216,3 +216,33 @@ def test_pinned_ring_feeds_pool():
     with pytest.raises(DdrlError):
         ring.pop_to(dst[0], timeout_ms=10)  # nothing committed -> timeout, not a hang
     ring.close()
+
+
+def test_redis_message_to_device_pool_via_codec_and_ring(net):
+    """A reference env worker's forward-states message (float64 frames) -> C codec -> pinned ring
+    -> hipMemcpyAsync -> forward: the drop-in ingest path of INTEGRATION.md."""
+    from ddrl4nav_amd.data import EasyBytes, PinnedRing
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    rng = np.random.default_rng(21)
+    fa = rng.integers(0, 256, size=(3, 4, 84, 84), dtype=np.uint8)
+    fb = rng.integers(0, 256, size=(2, 4, 84, 84), dtype=np.uint8)
+    eb = EasyBytes("127.0.0.1")
+    item = eb.encode_forward_states(0, [fa / 255.0]) + eb.encode_forward_states(1, [fb / 255.0])
+    ring = PinnedRing(5 * 4 * 84 * 84, n_slots=2)
+    slot = ring.acquire()
+    n, per = eb.frames_to_u8(item, slot)
+    assert (n, per) == (5, 4 * 84 * 84)
+    ring.commit()
+    dst = torch.empty((5, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    ring.pop_to(dst)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), np.concatenate([fa, fb]))
+    (probs, _), values = net([dst], play_mode=True)
+    # same result as feeding the reference's decoded float64 states
+    ids, states = eb.decode_forward_states(item)
+    (probs2, _), values2 = net([torch.from_numpy(states[0])], play_mode=True)
+    assert torch.equal(probs, probs2) and torch.equal(values[0], values2[0]) and ids == ["127.0.0.1_0", "127.0.0.1_1"]
+    replies = eb.encode_forward_return_data([torch.argmax(probs, 1).float(), torch.zeros(5), torch.stack(values, 0)], [3, 2])
+    a, lp, v = eb.decode_data(replies[1])
+    assert a.shape == (2,) and v.shape == (1, 2, 1)
+    ring.close()
