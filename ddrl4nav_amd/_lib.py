@@ -95,6 +95,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DdrlError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(or `make -C ddrl4nav_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    # PyTorch ships its own libamdhip64; load it FIRST so that this library's libamdhip64.so.7
+    # dependency resolves to the same runtime (device pointers and streams are shared between
+    # the two).  Loading in the other order leaves two HIP runtimes in one process.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
