@@ -224,6 +224,47 @@ def test_gradient_is_additive_over_shards(hp, golden):
     np.testing.assert_allclose(acc[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_full_size_properties_B65536():
+    """BASELINE config 2 size (256 envs x T=256 = 65,536 samples): size-independent properties.
+    (a) data-parallel additivity: grads(B) == grads(shard 0) + grads(shard 1) with 1/B_global;
+    (b) a sample's forward does not depend on its position in the batch;
+    (c) duplicating the batch leaves the mean losses and the mean gradient unchanged."""
+    from ddrl4nav_amd.engine import HotPath
+    B = 65536
+    big = HotPath(max_batch=B)
+    big.set_params(flatten(make_weights(0)))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    base = torch.randint(0, 256, (B // 2, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    frames = torch.cat([base, base])  # second half duplicates the first
+    half = lambda t: torch.cat([t, t]).contiguous()
+    acts = half(torch.randint(0, 6, (B // 2,), device="cuda", generator=g).float())
+    old = half(torch.full((B // 2,), -1.79, device="cuda") + 0.2 * torch.randn(B // 2, device="cuda", generator=g))
+    adv = half(torch.randn(B // 2, device="cuda", generator=g))
+    ret = half(torch.randn(B // 2, device="cuda", generator=g))
+    n = big.n_params
+    big.ppo_iter(frames, acts, old, adv, ret)
+    full = big.grads.clone()
+    acc = torch.zeros_like(full)
+    cut = 40000  # uneven shards
+    for sl in (slice(0, cut), slice(cut, B)):
+        big.ppo_iter(frames[sl], acts[sl], old[sl], adv[sl], ret[sl], b_global=B)
+        acc += big.grads
+    scale = full[:n].abs().max().item()
+    assert (acc[:n] - full[:n]).abs().max().item() <= 1e-4 * scale
+    np.testing.assert_allclose(acc[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-4, atol=1e-7)
+    # (c): the duplicated batch has the same mean gradient as one copy
+    big.ppo_iter(frames[:B // 2], acts[:B // 2], old[:B // 2], adv[:B // 2], ret[:B // 2])
+    one = big.grads.clone()
+    assert (one[:n] - full[:n]).abs().max().item() <= 1e-4 * scale
+    np.testing.assert_allclose(one[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-4, atol=1e-7)
+    # (b): forward of the two copies is bit-identical although they sit in different tiles
+    probs, value, _, logp = big.forward(frames[B // 2 - 300:B // 2 + 300].contiguous(), act=acts[B // 2 - 300:B // 2 + 300].contiguous())
+    p2, v2, _, l2 = big.forward(frames[:300].contiguous(), act=acts[:300].contiguous())
+    assert torch.equal(probs[300:], p2) and torch.equal(value[300:], v2) and torch.equal(logp[300:], l2)
+    big.close()
+
+
 def test_learn_sequence_golden_f4(hp, golden):
     g, frames, actions, old_logps, advs, rets = _load_batch(golden)
     g4 = golden("f4_learn")
@@ -278,3 +319,34 @@ def test_clip_coefficient_and_norm(hp, onet, golden):
     s = hp.stats()
     np.testing.assert_allclose(s["GradNorm"], gn, rtol=1e-6)
     np.testing.assert_allclose(s["ClipCoef"], min(1.0, 0.5 / (gn + 1e-6)), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 37, 200, 511])
+def test_gradients_ragged_batches_vs_oracle(hp, onet, n):
+    """Odd sample counts exercise the zero-padded half of a sample pair in the weight-gradient
+    kernels, partial column tiles and empty split-K slabs."""
+    rng = np.random.default_rng(700 + n)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    old = (np.full(n, -1.79) + rng.normal(0, 0.3, n)).astype(np.float32)
+    adv = rng.normal(size=n).astype(np.float32)
+    ret = rng.normal(size=n).astype(np.float32)
+    hp.set_params(flatten(make_weights(0)))
+    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    onet.load_weights(make_weights(0))
+    onet.zero_grad()
+    t = torch.from_numpy
+    _, al, vl, ent = O.ppo_losses(onet, O.frames_to_f32(frames), t(acts), t(old), t(adv), t(ret))
+    al.backward()
+    vl.backward()
+    tail = hp.grads[hp.n_params:hp.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail, [al.item(), vl.item(), ent.item()], rtol=2e-5, atol=2e-6)
+    got = _grad_views(hp)
+    for name, p in onet.named_parameters():
+        want = p.grad.numpy()
+        scale = np.abs(want).max()
+        # up to 200 x 400 products per element with heavy cancellation: both sides carry fp32
+        # summation noise of ~sqrt(N) * 6e-8 of the partial sums, so the bound is looser than at B=64
+        assert np.abs(got[name] - want).max() <= 1e-4 * scale + 1e-12, (name, n)
+        g64, w64 = got[name].astype(np.float64).ravel(), want.astype(np.float64).ravel()
+        assert g64 @ w64 / (np.linalg.norm(g64) * np.linalg.norm(w64) + 1e-300) > 1 - 1e-8, (name, n)
