@@ -17,7 +17,6 @@
 
 namespace ddrl {
 
-__device__ __forceinline__ void st4(float* p, const float4& v) { *(float4*)p = v; }
 
 // ================================================================================================
 // conv2 forward: a1 [e][n][32][20][20] -> a2 [e][n][64][9][9], k4 s2.   rows = oc (64),
@@ -39,15 +38,16 @@ struct ConvFwd2v2 {
     int n;
   };
   struct Regs {
-    float4 w[2], im[4];
+    f4 w[2], im[4];
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int e, c0, b_first, l31, hi, wc;
+  int imoff[4];  // per-thread source offsets of the staged planes (k-block independent part)
   const float* in;
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 4) * 20 + (s % 4); }
-  __device__ void init(const Params& p, int tid, float* lds) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -60,6 +60,16 @@ struct ConvFwd2v2 {
     in = p.in + e * p.in_es;
     wp = p.wp + (int64_t)e * 16 * 2048;
     if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
+    // Loads in fetch() are UNCONDITIONAL (a guarded load makes hipcc branch and wait per load):
+    // out-of-range threads / samples read clamped, valid addresses; what they stage is either
+    // not stored (idx guard in commit) or only feeds output columns that are discarded.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      const bool has = idx < NS * 200;
+      const int b = min(b_first + (has ? idx / 200 : 0), p.n - 1);
+      imoff[j] = b * 12800 + (has ? (idx % 200) * 4 : 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
@@ -70,20 +80,14 @@ struct ConvFwd2v2 {
       bbase[j] = IMG_OFF + (b - b_first) * 800 + (pix / 9) * 40 + (pix % 9) * 2 + hi * 400;
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) r.w[j] = *(const float4*)(wp + kb * 2048 + (tid + 256 * j) * 4);
+    for (int j = 0; j < 2; ++j) r.w[j] = ld4(wp + kb * 2048 + (tid + 256 * j) * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = tid + 256 * j;
-      const int bl = idx / 200, q = idx % 200;
-      const int b = b_first + bl;
-      r.im[j] = (idx < NS * 200 && b < p.n) ? *(const float4*)(in + (int64_t)b * 12800 + kb * 800 + q * 4)
-                                            : make_float4(0, 0, 0, 0);
-    }
+    for (int j = 0; j < 4; ++j) r.im[j] = ld4(in + imoff[j] + kb * 800);
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 2; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
@@ -93,8 +97,8 @@ struct ConvFwd2v2 {
       if (idx < NS * 200) st4(buf + IMG_OFF + idx * 4, r.im[j]);
     }
   }
-  __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -132,15 +136,16 @@ struct ConvFwd3v2 {
     int n;
   };
   struct Regs {
-    float4 w[3], im[3];
+    f4 w[3], im[3];
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int e, c0, b_first, l31, hi, wc;
+  int imoff[3];
   const float* in;
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 9) * 162 + ((s % 9) / 3) * 9 + (s % 3); }
-  __device__ void init(const Params& p, int tid, float* lds) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -154,6 +159,13 @@ struct ConvFwd3v2 {
     wp = p.wp + (int64_t)e * 16 * 2304;
     if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
 #pragma unroll
+    for (int j = 0; j < 3; ++j) {  // unconditional, clamped loads (see ConvFwd2v2::init)
+      const int idx = tid + 256 * j;
+      const bool has = idx < NS * 81;
+      const int b = min(b_first + (has ? idx / 81 : 0), p.n - 1);
+      imoff[j] = b * 5184 + (has ? (idx % 81) * 4 : 0);
+    }
+#pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -163,23 +175,14 @@ struct ConvFwd3v2 {
       bbase[j] = IMG_OFF + (b - b_first) * 324 + (pix / 7) * 9 + (pix % 7) + hi * 81;
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      r.w[j] = (idx < 576) ? *(const float4*)(wp + kb * 2304 + idx * 4) : make_float4(0, 0, 0, 0);
-    }
+    for (int j = 0; j < 3; ++j) r.w[j] = ld4(wp + kb * 2304 + min(tid + 256 * j, 575) * 4);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      const int bl = idx / 81, q = idx % 81;
-      const int b = b_first + bl;
-      r.im[j] = (idx < NS * 81 && b < p.n) ? *(const float4*)(in + (int64_t)b * 5184 + kb * 324 + q * 4)
-                                           : make_float4(0, 0, 0, 0);
-    }
+    for (int j = 0; j < 3; ++j) r.im[j] = ld4(in + imoff[j] + kb * 324);
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -188,8 +191,8 @@ struct ConvFwd3v2 {
       if (idx < NS * 81) st4(buf + IMG_OFF + idx * 4, r.im[j]);
     }
   }
-  __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -229,16 +232,17 @@ struct ConvFwd1v2 {
     int n;
   };
   struct Regs {
-    float4 w[4];
+    f4 w[4];
     unsigned im[6];
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int c0, l31, hi, wc;
   int b0, nd0, nd_total;     // dwords of part 0 / both parts
   int64_t src0, src1;        // byte offsets of the two row ranges inside channel 0
+  int64_t imsrc[6];          // per-thread byte offset of its j-th staged dword (clamped when unused)
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 4) * 84 + ((2 * (s % 4)) & 3) * 21 + ((2 * (s % 4)) >> 2); }
-  __device__ void init(const Params& p, int tid, float* lds) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -264,6 +268,11 @@ struct ConvFwd1v2 {
     src1 = (int64_t)b1 * 28224;
     if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[tid >> 5] + (tid & 31)];
 #pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = tid + 256 * j;
+      imsrc[j] = (idx >= nd_total) ? src0 : (idx < nd0 ? src0 + idx * 4 : src1 + (idx - nd0) * 4);
+    }
+#pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -275,20 +284,15 @@ struct ConvFwd1v2 {
       bbase[j] = IMG_OFF + lr * 84 + ox + hi * 21;
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.w[j] = *(const float4*)(p.wp + kb * 4096 + (tid + 256 * j) * 4);
+    for (int j = 0; j < 4; ++j) r.w[j] = ld4(p.wp + kb * 4096 + (tid + 256 * j) * 4);
     const uint8_t* ch = p.frames + kb * 7056;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int idx = tid + 256 * j;
-      unsigned v = 0;
-      if (idx < nd_total) v = (idx < nd0) ? *(const unsigned*)(ch + src0 + idx * 4) : *(const unsigned*)(ch + src1 + (idx - nd0) * 4);
-      r.im[j] = v;
-    }
+    for (int j = 0; j < 6; ++j) r.im[j] = *(const unsigned*)(ch + imsrc[j]);  // unconditional, clamped
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
@@ -306,8 +310,8 @@ struct ConvFwd1v2 {
       }
     }
   }
-  __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -346,15 +350,16 @@ struct ConvDgrad3v2 {
     int n;
   };
   struct Regs {
-    float4 w[3], im;
+    f4 w[3], im;
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int e, c0, b_first, l31, hi, wc;
+  int imoff;
   const float* dz;
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
   static constexpr int boff(int s) { return (s / 9) * 242 + (2 - (s % 9) / 3) * 11 + (2 - (s % 3)); }
-  __device__ void init(const Params& p, int tid, float* lds) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -371,6 +376,11 @@ struct ConvDgrad3v2 {
       lds[STAGE + IMG_OFF + i] = 0.0f;
     }
     __syncthreads();
+    {
+      const bool has = tid < NS * 49;
+      const int b = min(b_first + (has ? tid / 49 : 0), p.n - 1);
+      imoff = b * FLAT + (has ? (tid % 49) * 4 : 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
@@ -381,18 +391,13 @@ struct ConvDgrad3v2 {
       bbase[j] = IMG_OFF + (b - b_first) * 484 + (pix / 9) * 11 + (pix % 9) + hi * 121;
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      r.w[j] = (idx < 576) ? *(const float4*)(wp + kb * 2304 + idx * 4) : make_float4(0, 0, 0, 0);
-    }
-    const int bl = tid / 49, q = tid % 49;
-    const int b = b_first + bl;
-    r.im = (tid < NS * 49 && b < p.n) ? *(const float4*)(dz + (int64_t)b * FLAT + kb * 196 + q * 4) : make_float4(0, 0, 0, 0);
+    for (int j = 0; j < 3; ++j) r.w[j] = ld4(wp + kb * 2304 + min(tid + 256 * j, 575) * 4);
+    r.im = ld4(dz + imoff + kb * 196);  // unconditional, clamped (see ConvFwd2v2::init)
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -410,8 +415,8 @@ struct ConvDgrad3v2 {
       }
     }
   }
-  __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
@@ -451,15 +456,16 @@ struct ConvDgrad2v2 {
     int n;
   };
   struct Regs {
-    float4 w[4], im[3];
+    f4 w[4], im[3];
   };
   int abase[4], bbase[2], kb_begin, kb_end;
   int e, c0, b_first, l31, hi, wc;
+  int imoff[3];
   const float* dz;
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 128; }
   static constexpr int boff(int s) { return (s / 4) * 242 + (1 - ((s % 4) >> 1)) * 11 + (1 - (s & 1)); }
-  __device__ void init(const Params& p, int tid, float* lds) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -477,6 +483,13 @@ struct ConvDgrad2v2 {
     }
     __syncthreads();
 #pragma unroll
+    for (int j = 0; j < 3; ++j) {  // unconditional, clamped loads (see ConvFwd2v2::init)
+      const int idx = tid + 256 * j;
+      const bool has = idx < NS * 162;
+      const int b = min(b_first + (has ? idx / 162 : 0), p.n - 1);
+      imoff[j] = b * 5184 + (has ? (idx % 162) * 4 : 0);
+    }
+#pragma unroll
     for (int i = 0; i < 4; ++i) abase[i] = hi * 128 + i * 32 + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -486,20 +499,14 @@ struct ConvDgrad2v2 {
       bbase[j] = IMG_OFF + (b - b_first) * 968 + (pq / 10) * 11 + (pq % 10) + hi * 121;
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.w[j] = *(const float4*)(wp + kb * 4096 + (tid + 256 * j) * 4);
+    for (int j = 0; j < 4; ++j) r.w[j] = ld4(wp + kb * 4096 + (tid + 256 * j) * 4);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      const int bl = idx / 162, q = idx % 162;
-      const int b = b_first + bl;
-      r.im[j] = (idx < NS * 162 && b < p.n) ? *(const float4*)(dz + (int64_t)b * 5184 + kb * 648 + q * 4)
-                                            : make_float4(0, 0, 0, 0);
-    }
+    for (int j = 0; j < 3; ++j) r.im[j] = ld4(dz + imoff[j] + kb * 648);
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
@@ -518,8 +525,8 @@ struct ConvDgrad2v2 {
       }
     }
   }
-  __device__ void extra(const float*) {}
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[4][2], float*) {
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[4][2], float*) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;

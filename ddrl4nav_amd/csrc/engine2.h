@@ -26,6 +26,13 @@
 namespace ddrl {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// 16-byte register vector for staged data.  NOT HIP's float4: that is a struct, a whole-struct copy
+// lowers to llvm.memcpy, and an alloca touched only by memcpys is never promoted to registers
+// (the prefetch buffers then live in scratch and every load is waited for immediately).
+using f4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f4 ld4(const float* p) { return *(const f4*)p; }
+__device__ __forceinline__ void st4(float* p, f4 v) { *(f4*)p = v; }
+__device__ __forceinline__ f4 zero4() { return (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
 
 __device__ __forceinline__ float leaky_f(float v) { return v > 0.0f ? v : v * LEAKY; }
 __device__ __forceinline__ float leaky_g(float act, float g) { return act > 0.0f ? g : g * LEAKY; }

@@ -7,20 +7,22 @@ namespace ddrl {
 
 // Loader helpers --------------------------------------------------------------------------------
 // "row-major odd": tile X[128 rows][32 k] of a K-contiguous matrix, stored in LDS as [row][33]
-// so that lanes (= rows) hit 32 different banks.  4 float4 per thread.
+// so that lanes (= rows) hit 32 different banks.  4 f4 per thread.
 struct RowMajorTile {
   static constexpr int LD = 33;
   static constexpr int FLOATS = 128 * LD;
-  __device__ static void fetch(const float* __restrict__ src, int64_t row_stride, int row0, int nrows, int kcol0, int tid,
-                               float4 (&r)[4]) {
+  __device__ __forceinline__ static void fetch(const float* __restrict__ src, int64_t row_stride, int row0, int nrows, int kcol0, int tid,
+                               f4 (&r)[4]) {
     const int k4 = tid & 7, rr = tid >> 3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = row0 + rr + 32 * j;
-      r[j] = (row < nrows) ? *(const float4*)(src + (int64_t)row * row_stride + kcol0 + k4 * 4) : make_float4(0, 0, 0, 0);
+      // unconditional load from a clamped row: rows >= nrows only feed output rows that the
+      // epilogue discards (a guarded load would make hipcc branch and wait per load)
+      const int row = min(row0 + rr + 32 * j, nrows - 1);
+      r[j] = ld4(src + (int64_t)row * row_stride + kcol0 + k4 * 4);
     }
   }
-  __device__ static void commit(float* __restrict__ dst, int tid, const float4 (&r)[4]) {
+  __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4]) {
     const int k4 = tid & 7, rr = tid >> 3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -29,24 +31,35 @@ struct RowMajorTile {
     }
   }
 };
-// "k-major": tile X[32 k][128 cols] of a col-contiguous matrix, stored as is.  4 float4 per thread.
+// "k-major": tile X[32 k][128 cols] of a col-contiguous matrix, stored as is.  4 f4 per thread.
 struct KMajorTile {
   static constexpr int LD = 128;
   static constexpr int FLOATS = 32 * LD;
-  __device__ static void fetch(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
-                               float4 (&r)[4]) {
+  // Unconditional loads from clamped (k, col); returns a 4-bit mask of the j whose k is in range.
+  // Out-of-range columns only feed discarded output columns; out-of-range k (the reduction index)
+  // must contribute zero, which commit_masked() enforces for ONE of the two operands.
+  __device__ __forceinline__ static unsigned fetch(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
+                               f4 (&r)[4]) {
     const int c4 = tid & 31, kk = tid >> 5;
-    const bool cok = (col0 + c4 * 4) < ncols;
+    const int col = (col0 + c4 * 4) < ncols ? col0 + c4 * 4 : 0;
+    unsigned ok = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + kk + 8 * j;
-      r[j] = (cok && k < nk) ? *(const float4*)(src + (int64_t)k * k_stride + col0 + c4 * 4) : make_float4(0, 0, 0, 0);
+      ok |= (k < nk ? 1u : 0u) << j;
+      r[j] = ld4(src + (int64_t)min(k, nk - 1) * k_stride + col);
     }
+    return ok;
   }
-  __device__ static void commit(float* __restrict__ dst, int tid, const float4 (&r)[4]) {
+  __device__ __forceinline__ static void commit_masked(float* __restrict__ dst, int tid, const f4 (&r)[4], unsigned ok) {
     const int c4 = tid & 31, kk = tid >> 5;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(float4*)(dst + (kk + 8 * j) * LD + c4 * 4) = r[j];
+    for (int j = 0; j < 4; ++j) st4(dst + (kk + 8 * j) * LD + c4 * 4, ((ok >> j) & 1u) ? r[j] : zero4());
+  }
+  __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4]) {
+    const int c4 = tid & 31, kk = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(dst + (kk + 8 * j) * LD + c4 * 4, r[j]);
   }
 };
 
@@ -55,8 +68,8 @@ struct FcCommon {
   int abase[2], bbase[2];
   int kb_begin, kb_end;
   int wr, wc, l31, hi;
-  __device__ void extra(const float*) {}
-  __device__ void lanes(int tid) {
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void lanes(int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     l31 = lane & 31;
     hi = lane >> 5;
@@ -83,14 +96,14 @@ struct FcFwd2 : FcCommon {
     float* part;
   };
   struct Regs {
-    float4 a[4], b[4];
+    f4 a[4], b[4];
   };
   int e, split, b0, n0;
   const float* a3;
   const float* wlt;
   static constexpr int aoff(int s) { return 2 * s; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
     e = blockIdx.z % 2;
     split = blockIdx.z / 2;
@@ -106,15 +119,15 @@ struct FcFwd2 : FcCommon {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     RowMajorTile::fetch(a3, FLAT, b0, p.n, kb * 32, threadIdx.x, r.a);
     KMajorTile::fetch(wlt, FEAT, kb * 32, FLAT, n0, FEAT, threadIdx.x, r.b);
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
     KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
   }
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wc * 64 + j * 32 + l31;
@@ -146,14 +159,14 @@ struct FcDgrad2 : FcCommon {
     int n;
   };
   struct Regs {
-    float4 a[4], b[4];
+    f4 a[4], b[4];
   };
   int e, b0, k0;
   const float* dh;
   const float* wln;
   static constexpr int aoff(int s) { return 2 * s; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
     e = blockIdx.z;
     k0 = blockIdx.x * 128;
@@ -167,15 +180,15 @@ struct FcDgrad2 : FcCommon {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     RowMajorTile::fetch(dh, FEAT, b0, p.n, kb * 32, threadIdx.x, r.a);
     KMajorTile::fetch(wln, FLAT, kb * 32, FEAT, k0, FLAT, threadIdx.x, r.b);
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
     KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
   }
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = k0 + wc * 64 + j * 32 + l31;
@@ -210,15 +223,16 @@ struct FcWgrad2 : FcCommon {
     int n, nsplit;
   };
   struct Regs {
-    float4 a[4], b[4];
+    f4 a[4], b[4];
+    unsigned ok;
   };
   int e, split, n0, k0;
   const float* dh;
   const float* a3;
-  float4 bsum;
+  f4 bsum;
   static constexpr int aoff(int s) { return 2 * s * KMajorTile::LD; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
     e = blockIdx.z % 2;
     split = blockIdx.z / 2;
@@ -230,26 +244,25 @@ struct FcWgrad2 : FcCommon {
     kb_end = min(nkb, kb_begin + per);
     dh = p.dh + e * p.dh_es;
     a3 = p.a3 + e * p.a3_es;
-    bsum = make_float4(0, 0, 0, 0);
+    bsum = zero4();
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = A_OFF + hi * KMajorTile::LD + wr * 64 + i * 32 + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
-    KMajorTile::fetch(dh, FEAT, kb * 32, p.n, n0, FEAT, threadIdx.x, r.a);
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    r.ok = KMajorTile::fetch(dh, FEAT, kb * 32, p.n, n0, FEAT, threadIdx.x, r.a);
     KMajorTile::fetch(a3, FLAT, kb * 32, p.n, k0, FLAT, threadIdx.x, r.b);
   }
-  __device__ void commit(const Regs& r, float* buf) {
-    KMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    KMajorTile::commit_masked(buf + A_OFF, threadIdx.x, r.a, r.ok);  // samples >= n contribute zero
     KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
     // bias gradient rides along: this thread always holds the same 4 columns of dh
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bsum.x += r.a[j].x; bsum.y += r.a[j].y; bsum.z += r.a[j].z; bsum.w += r.a[j].w;
-    }
+    for (int j = 0; j < 4; ++j)
+      if ((r.ok >> j) & 1u) bsum += r.a[j];
   }
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
     float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -265,7 +278,7 @@ struct FcWgrad2 : FcCommon {
     }
     if (blockIdx.x == 0) {  // one column tile per (row tile, split, e) owns the bias partial
       const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
-      *(float4*)(lds + kk * 128 + c4 * 4) = bsum;
+      st4(lds + kk * 128 + c4 * 4, bsum);
       __syncthreads();
       if (threadIdx.x < 128) {
         float s = 0.0f;

@@ -16,11 +16,10 @@
 
 namespace ddrl {
 
-__device__ __forceinline__ void st4w(float* p, const float4& v) { *(float4*)p = v; }
 
 struct WgradSplit {
   int pair_begin, pair_end;
-  __device__ void set(int n, int nsplit, int split) {
+  __device__ __forceinline__ void set(int n, int nsplit, int split) {
     const int npairs = (n + 1) >> 1;
     const int per = (npairs + nsplit - 1) / nsplit;
     pair_begin = min(npairs, split * per);
@@ -45,15 +44,16 @@ struct ConvWgrad1v2 {
     int n, nsplit;
   };
   struct Regs {
-    float4 dzr[3], actr[3];
+    f4 dzr[3], actr[3];
     unsigned im[6];
+    unsigned ok;  // bit j: dz element j belongs to a sample < n
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int split, l31, hi, wc;
   float bacc;
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return 4 * s; }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -72,40 +72,44 @@ struct ConvWgrad1v2 {
       bbase[j] = B_OFF + hi * 2688 + (col >> 6) * 672 + ((col >> 3) & 7) * 84 + (col & 7);
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
     const int pair = kb / 20, oy = kb % 20;
+    // All loads are unconditional from clamped addresses (a guarded load makes hipcc branch and
+    // wait per load); a sample >= n contributes zero because its dz is zeroed in commit().
+    r.ok = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
+      const int idx = min(tid + 256 * j, 639);
       const int row = idx / 5, q4 = idx % 5;
       const int smp = row >> 6, e = (row >> 5) & 1, oc = row & 31;
       const int b = 2 * pair + smp;
-      const bool ok = idx < 640 && b < p.n;
-      const int64_t off = e * p.dz_es + (int64_t)b * 12800 + oc * 400 + oy * 20 + q4 * 4;
-      r.dzr[j] = ok ? *(const float4*)(p.dz + off) : make_float4(0, 0, 0, 0);
-      r.actr[j] = ok ? *(const float4*)(p.act + off) : make_float4(0, 0, 0, 0);
+      r.ok |= (b < p.n ? 1u : 0u) << j;
+      const int64_t off = e * p.dz_es + (int64_t)min(b, p.n - 1) * 12800 + oc * 400 + oy * 20 + q4 * 4;
+      r.dzr[j] = ld4(p.dz + off);
+      r.actr[j] = ld4(p.act + off);
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const int idx = tid + 256 * j;
+      const int idx = min(tid + 256 * j, 1343);
       const int smp = idx / 672, rr = idx % 672;
       const int ch = rr / 168, d = rr % 168;
-      const int b = 2 * pair + smp;
-      r.im[j] = (idx < 1344 && b < p.n) ? *(const unsigned*)(p.frames + (int64_t)b * 28224 + ch * 7056 + oy * 336 + d * 4) : 0u;
+      const int b = min(2 * pair + smp, p.n - 1);
+      r.im[j] = *(const unsigned*)(p.frames + (int64_t)b * 28224 + ch * 7056 + oy * 336 + d * 4);
     }
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int idx = tid + 256 * j;
       if (idx < 640) {
         float* d = buf + (idx / 5) * 21 + (idx % 5) * 4;
-        d[0] = leaky_g(r.actr[j].x, r.dzr[j].x);
-        d[1] = leaky_g(r.actr[j].y, r.dzr[j].y);
-        d[2] = leaky_g(r.actr[j].z, r.dzr[j].z);
-        d[3] = leaky_g(r.actr[j].w, r.dzr[j].w);
+        const f4 dzv = ((r.ok >> j) & 1u) ? r.dzr[j] : zero4();
+        d[0] = leaky_g(r.actr[j].x, dzv.x);
+        d[1] = leaky_g(r.actr[j].y, dzv.y);
+        d[2] = leaky_g(r.actr[j].z, dzv.z);
+        d[3] = leaky_g(r.actr[j].w, dzv.w);
       }
     }
 #pragma unroll
@@ -113,11 +117,11 @@ struct ConvWgrad1v2 {
       const int idx = tid + 256 * j;
       if (idx < 1344) {
         const unsigned v = r.im[j];
-        st4w(buf + B_OFF + idx * 4, make_float4(u8_unit(v & 255u), u8_unit((v >> 8) & 255u), u8_unit((v >> 16) & 255u), u8_unit(v >> 24)));
+        st4(buf + B_OFF + idx * 4, (f4){u8_unit(v & 255u), u8_unit((v >> 8) & 255u), u8_unit((v >> 16) & 255u), u8_unit(v >> 24)});
       }
     }
   }
-  __device__ void extra(const float* cur) {
+  __device__ __forceinline__ void extra(const float* cur) {
     if (threadIdx.x < 128) {
       const float* row = cur + threadIdx.x * 21;
       float s = 0.0f;
@@ -126,7 +130,7 @@ struct ConvWgrad1v2 {
       bacc += s;
     }
   }
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float* slab = p.part + ((int64_t)split * 2 + i) * SLAB;
@@ -164,7 +168,8 @@ struct ConvWgrad2v2 {
   };
   struct Regs {
     float dzr[14];
-    float4 im[5];
+    f4 im[5];
+    unsigned ok;
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int e, g, split, l31, hi, wc;
@@ -173,7 +178,7 @@ struct ConvWgrad2v2 {
   float bacc;
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return (s / 9) * 40 + (s % 9) * 2; }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     const int lane = tid & 63;
     wc = tid >> 6;
     l31 = lane & 31;
@@ -196,36 +201,38 @@ struct ConvWgrad2v2 {
       bbase[j] = B_OFF + hi * 2560 + (col >> 4) * 160 + ((col >> 2) & 3) * 20 + (col & 3);
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
     const int pair = kb / 3, band = kb % 3;
+    r.ok = 0;  // unconditional, clamped loads; dz of a sample >= n is zeroed in commit()
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
-      const int idx = tid + 256 * j;
+      const int idx = min(tid + 256 * j, 3455);
       const int row = idx / 27, q = idx % 27;
       const int b = 2 * pair + (row >> 6);
-      r.dzr[j] = (idx < 3456 && b < p.n) ? dz[(int64_t)b * 5184 + (row & 63) * 81 + band * 27 + q] : 0.0f;
+      r.ok |= (b < p.n ? 1u : 0u) << j;
+      r.dzr[j] = dz[(int64_t)min(b, p.n - 1) * 5184 + (row & 63) * 81 + band * 27 + q];
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int idx = tid + 256 * j;
       const int smp = idx / 640, rr = idx % 640;
       const int ch = rr / 40, q4 = rr % 40;
-      const int b = 2 * pair + smp;
-      r.im[j] = (b < p.n) ? *(const float4*)(in + (int64_t)b * 12800 + ch * 400 + band * 120 + q4 * 4) : make_float4(0, 0, 0, 0);
+      const int b = min(2 * pair + smp, p.n - 1);
+      r.im[j] = ld4(in + (int64_t)b * 12800 + ch * 400 + band * 120 + q4 * 4);
     }
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
       const int idx = tid + 256 * j;
-      if (idx < 3456) buf[idx] = r.dzr[j];
+      if (idx < 3456) buf[idx] = ((r.ok >> j) & 1u) ? r.dzr[j] : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) st4w(buf + B_OFF + (tid + 256 * j) * 4, r.im[j]);
+    for (int j = 0; j < 5; ++j) st4(buf + B_OFF + (tid + 256 * j) * 4, r.im[j]);
   }
-  __device__ void extra(const float* cur) {
+  __device__ __forceinline__ void extra(const float* cur) {
     if (g == 0 && threadIdx.x < 128) {
       const float* row = cur + threadIdx.x * 27;
       float s = 0.0f;
@@ -234,7 +241,7 @@ struct ConvWgrad2v2 {
       bacc += s;
     }
   }
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
     float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -270,7 +277,8 @@ struct ConvWgrad3v2 {
     int n, nsplit;
   };
   struct Regs {
-    float4 dzr[7], im[4];
+    f4 dzr[7], im[4];
+    unsigned ok;
   };
   int abase[1], bbase[3], kb_begin, kb_end;
   int e, g, split, l31, hi, wr, wc;
@@ -279,7 +287,7 @@ struct ConvWgrad3v2 {
   float bacc;
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return (s / 7) * 9 + (s % 7); }
-  __device__ void init(const Params& p, int tid, float*) {
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     const int lane = tid & 63, wave = tid >> 6;
     wr = wave >> 1;
     wc = wave & 1;
@@ -304,37 +312,39 @@ struct ConvWgrad3v2 {
       bbase[j] = B_OFF + hi * 1944 + (ch - ch0) * 81 + (t / 3) * 9 + (t % 3);
     }
   }
-  __device__ void fetch(const Params& p, int kb, Regs& r) {
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
+    r.ok = 0;  // unconditional, clamped loads; dz of a sample >= n is zeroed in commit()
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      const int idx = tid + 256 * j;
+      const int idx = min(tid + 256 * j, 1567);
       const int smp = idx / 784, q = idx % 784;
       const int b = 2 * kb + smp;
-      r.dzr[j] = (idx < 1568 && b < p.n) ? *(const float4*)(dz + (int64_t)b * FLAT + q * 4) : make_float4(0, 0, 0, 0);
+      r.ok |= (b < p.n ? 1u : 0u) << j;
+      r.dzr[j] = ld4(dz + (int64_t)min(b, p.n - 1) * FLAT + q * 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int idx = tid + 256 * j;
+      const int idx = min(tid + 256 * j, 971);
       const int smp = idx / 486, q = idx % 486;
-      const int b = 2 * kb + smp;
-      r.im[j] = (idx < 972 && b < p.n) ? *(const float4*)(in + (int64_t)b * 5184 + q * 4) : make_float4(0, 0, 0, 0);
+      const int b = min(2 * kb + smp, p.n - 1);
+      r.im[j] = ld4(in + (int64_t)b * 5184 + q * 4);
     }
   }
-  __device__ void commit(const Regs& r, float* buf) {
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int idx = tid + 256 * j;
-      if (idx < 1568) st4w(buf + idx * 4, r.dzr[j]);
+      if (idx < 1568) st4(buf + idx * 4, ((r.ok >> j) & 1u) ? r.dzr[j] : zero4());
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int idx = tid + 256 * j;
-      if (idx < 972) st4w(buf + B_OFF + idx * 4, r.im[j]);
+      if (idx < 972) st4(buf + B_OFF + idx * 4, r.im[j]);
     }
   }
-  __device__ void extra(const float* cur) {
+  __device__ __forceinline__ void extra(const float* cur) {
     if (g == 0 && threadIdx.x < 128) {
       const float* row = cur + threadIdx.x * 49;
       float s = 0.0f;
@@ -343,7 +353,7 @@ struct ConvWgrad3v2 {
       bacc += s;
     }
   }
-  __device__ void epilogue(const Params& p, f32x16 (&acc)[1][3], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[1][3], float* lds) {
     float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
