@@ -42,6 +42,13 @@ struct KMajorTile {
                                f4 (&r)[4]) {
     const int c4 = tid & 31, kk = tid >> 5;
     const int col = (col0 + c4 * 4) < ncols ? col0 + c4 * 4 : 0;
+    if (k0 + 32 <= nk) {  // fast path (all but the last k-block): scalar base + small offsets
+      const float* base = src + (int64_t)k0 * k_stride + col;
+      const int ks = (int)k_stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = ld4(base + (kk + 8 * j) * ks);
+      return 0xFu;
+    }
     unsigned ok = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

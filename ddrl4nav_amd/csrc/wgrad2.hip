@@ -50,6 +50,8 @@ struct ConvWgrad1v2 {
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int split, l31, hi, wc;
+  int64_t dzoff[3];         // k-block independent parts of this thread's source offsets
+  int imoff[6], ldsoff[3];
   float bacc;
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return 4 * s; }
@@ -65,6 +67,19 @@ struct ConvWgrad1v2 {
     kb_end = sp.pair_end * 20;
     bacc = 0.0f;
 #pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = min(tid + 256 * j, 639);
+      const int row = idx / 5, q4 = idx % 5;
+      dzoff[j] = ((row >> 5) & 1) * p.dz_es + (int64_t)(row >> 6) * 12800 + (row & 31) * 400 + q4 * 4;
+      ldsoff[j] = row * 21 + q4 * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = min(tid + 256 * j, 1343);
+      const int rr = idx % 672;
+      imoff[j] = (idx / 672) * 28224 + (rr / 168) * 7056 + (rr % 168) * 4;
+    }
+#pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 1344 + (i * 32 + l31) * 21;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -77,6 +92,19 @@ struct ConvWgrad1v2 {
     const int pair = kb / 20, oy = kb % 20;
     // All loads are unconditional from clamped addresses (a guarded load makes hipcc branch and
     // wait per load); a sample >= n contributes zero because its dz is zeroed in commit().
+    if (2 * pair + 1 < p.n) {  // fast path: scalar base + per-thread offsets from init()
+      const int64_t sb = (int64_t)pair * (2 * 12800) + oy * 20;
+      const uint8_t* fp = p.frames + (int64_t)pair * (2 * 28224) + oy * 336;
+      r.ok = 7u;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        r.dzr[j] = ld4(p.dz + sb + dzoff[j]);
+        r.actr[j] = ld4(p.act + sb + dzoff[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) r.im[j] = *(const unsigned*)(fp + imoff[j]);
+      return;
+    }
     r.ok = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -104,7 +132,7 @@ struct ConvWgrad1v2 {
     for (int j = 0; j < 3; ++j) {
       const int idx = tid + 256 * j;
       if (idx < 640) {
-        float* d = buf + (idx / 5) * 21 + (idx % 5) * 4;
+        float* d = buf + ldsoff[j];
         const f4 dzv = ((r.ok >> j) & 1u) ? r.dzr[j] : zero4();
         d[0] = leaky_g(r.actr[j].x, dzv.x);
         d[1] = leaky_g(r.actr[j].y, dzv.y);
@@ -173,6 +201,7 @@ struct ConvWgrad2v2 {
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int e, g, split, l31, hi, wc;
+  int dzoff[14], imoff[5];  // k-block independent part of this thread's source offsets
   const float* in;
   const float* dz;
   float bacc;
@@ -194,6 +223,18 @@ struct ConvWgrad2v2 {
     dz = p.dz + e * p.dz_es;
     bacc = 0.0f;
 #pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int idx = min(tid + 256 * j, 3455);
+      const int row = idx / 27;
+      dzoff[j] = (row >> 6) * 5184 + (row & 63) * 81 + idx % 27;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int idx = tid + 256 * j;
+      const int rr = idx % 640;
+      imoff[j] = (idx / 640) * 12800 + (rr / 40) * 400 + (rr % 40) * 4;
+    }
+#pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 1728 + (i * 32 + l31) * 27;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -204,7 +245,19 @@ struct ConvWgrad2v2 {
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
     const int pair = kb / 3, band = kb % 3;
-    r.ok = 0;  // unconditional, clamped loads; dz of a sample >= n is zeroed in commit()
+    // Unconditional loads (a guarded load makes hipcc branch and wait per load).  Fast path: both
+    // samples of the pair exist -> one scalar base + the per-thread offsets from init().
+    if (2 * pair + 1 < p.n) {
+      const float* dzp = dz + (int64_t)pair * (2 * 5184) + band * 27;
+      const float* inp = in + (int64_t)pair * (2 * 12800) + band * 120;
+      r.ok = 0x3FFFu;
+#pragma unroll
+      for (int j = 0; j < 14; ++j) r.dzr[j] = dzp[dzoff[j]];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) r.im[j] = ld4(inp + imoff[j]);
+      return;
+    }
+    r.ok = 0;  // last, odd pair: clamp the missing sample; its dz is zeroed in commit()
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
       const int idx = min(tid + 256 * j, 3455);
@@ -282,6 +335,7 @@ struct ConvWgrad3v2 {
   };
   int abase[1], bbase[3], kb_begin, kb_end;
   int e, g, split, l31, hi, wr, wc;
+  int imoff[4];
   const float* in;
   const float* dz;
   float bacc;
@@ -304,6 +358,11 @@ struct ConvWgrad3v2 {
     in = p.in + e * p.in_es + ch0 * 81;
     dz = p.dz + e * p.dz_es;
     bacc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = min(tid + 256 * j, 971);
+      imoff[j] = (idx / 486) * 5184 + (idx % 486) * 4;
+    }
     abase[0] = hi * 3136 + (wr * 32 + l31) * 49;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -314,7 +373,17 @@ struct ConvWgrad3v2 {
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
-    r.ok = 0;  // unconditional, clamped loads; dz of a sample >= n is zeroed in commit()
+    if (2 * kb + 1 < p.n) {  // fast path: both samples exist; the pair's dz3 is one contiguous run
+      const float* dzp = dz + (int64_t)kb * (2 * FLAT);
+      const float* inp = in + (int64_t)kb * (2 * 5184);
+      r.ok = 0x7Fu;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) r.dzr[j] = ld4(dzp + min(tid + 256 * j, 1567) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r.im[j] = ld4(inp + imoff[j]);
+      return;
+    }
+    r.ok = 0;  // last, odd pair: clamped loads; dz of the missing sample is zeroed in commit()
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int idx = min(tid + 256 * j, 1567);
