@@ -78,6 +78,23 @@ def cpu_baseline(seconds_budget=20.0):
             "host_cpus": cores}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per training launch of `kernel` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_pmc.sh -> profiles/*_pmc_traffic.json);
+    null when no profile of this build is committed.  bench.py itself never runs the profiler."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes"], "fetch_bytes": k["fetch_bytes"],
+                                       "write_bytes": k["write_bytes"], "mfma_busy_frac": k["mfma_busy_frac"],
+                                       "clock_ghz": k["clock_ghz"], "source": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def build_net(n_envs, horizon, iters):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
@@ -185,15 +202,12 @@ def main():
         kernels = {}
         for k, (ms, calls) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
             ent = {"ms_total": round(ms, 3), "calls": calls, "ms_avg": round(ms / max(calls, 1), 4)}
-            if k in MAC:
-                # training launches process B samples, acting launches N samples; both encoders
-                train_calls = steps * ITERS
-                act_calls = max(calls - train_calls, 0) if k.startswith("ConvFwd") else 0
-                if k == "FcFwd":
-                    train_calls = calls
-                flop = 2.0 * 2 * MAC[k] * (B * train_calls + N * act_calls)
-                ent["tflops"] = round(flop / (ms * 1e-3) / 1e12, 2)
-                ent["flop_per_launch_train"] = 2 * 2 * MAC[k] * B
+            base = k[:-4] if k.endswith(".act") else k
+            if base in MAC:
+                # training launches process B samples each, acting launches (".act", FcFwdSplit) N samples
+                per_launch = 2 * 2 * MAC[base] * (N if k.endswith(".act") else B)
+                ent["tflops"] = round(per_launch * calls / (ms * 1e-3) / 1e12, 2)
+                ent["flop_per_launch"] = per_launch
             kernels[k] = ent
         # dominant kernel = largest accumulated time among the GEMM-shaped kernels
         gemm = {k: v for k, v in kernels.items() if k in MAC}
@@ -202,11 +216,12 @@ def main():
             dom = max(gemm, key=lambda k: gemm[k]["ms_total"])
             d = gemm[dom]
             roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": pmc_traffic(dom),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
-                        "algorithmic_flop_per_sample_per_launch": 2 * 2 * MAC[dom],
-                        "note": "f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32; HIP events around each launch on the "
-                                "launch stream; acting-size launches of forward kernels are folded in by their own FLOPs"}
+                        "algorithmic_flop_per_launch": d["flop_per_launch"],
+                        "note": "dominant training kernel; f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32; HIP events "
+                                "around each launch on the launch stream; algorithmic FLOP = 2*2*MAC/sample (both encoders) x B"}
         upd_ms = phase["update_ms"] / steps
         total_flop = env_steps / world * (FLOP_ACT_PER_STEP + ITERS * FLOP_TRAIN_PER_SAMPLE)
         out = {

@@ -551,24 +551,24 @@ struct ConvDgrad2v2 {
 };
 
 // ================================================================================================
-void launch_conv_forward2(const EncCall& c, hipStream_t st) {
+void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
   const int n = c.n;
   {
     ConvFwd1v2::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b}, w.a1, MB * 12800, n};
-    ProfRange pr(c.prof, "ConvFwd1", st);
+    ProfRange pr(c.prof, acting ? "ConvFwd1.act" : "ConvFwd1", st);
     launch_engine2<ConvFwd1v2>(dim3((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1), p, st);
   }
   {
     ConvFwd2v2::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
-    ProfRange pr(c.prof, "ConvFwd2", st);
+    ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
     launch_engine2<ConvFwd2v2>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, 2), p, st);
   }
   {
     ConvFwd3v2::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
-    ProfRange pr(c.prof, "ConvFwd3", st);
+    ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
     launch_engine2<ConvFwd3v2>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, 2), p, st);
   }
 }

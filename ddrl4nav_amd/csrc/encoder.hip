@@ -6,7 +6,7 @@
 namespace ddrl {
 
 void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st) {
-  launch_conv_forward2(c, st);
+  launch_conv_forward2(c, acting, st);
   launch_fc_forward2(c, acting, st);
 }
 

@@ -44,7 +44,7 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st);
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st);
 
 // conv2.hip (v2 engine)
-void launch_conv_forward2(const EncCall& c, hipStream_t st);
+void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st);
 void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st);
 
