@@ -75,7 +75,7 @@ struct Workspace {
   int64_t total_bytes;
 };
 
-constexpr int HEAD_WG = 512;   // workgroups of the heads/loss kernel (fixed -> deterministic)
+constexpr int HEAD_WG = 2048;  // workgroups of the heads/loss kernel (fixed -> deterministic)
 constexpr int NORM_WG = 1024;  // workgroups of the grad-norm kernel
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

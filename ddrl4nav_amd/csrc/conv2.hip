@@ -416,20 +416,36 @@ struct ConvDgrad3v2 {
     }
   }
   __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+  // a2 values for the leaky-ReLU mask: loaded (unconditionally, clamped) before the last k-block
+  static constexpr int PRE_EPILOGUE = 1;
+  float actv[2][2][16];
+  __device__ __forceinline__ int64_t out_base(const Params& p, int j, bool& ok) const {
+    const int c = c0 + wc * 64 + j * 32 + l31;
+    ok = c < p.n * 81;
+    const int cc = ok ? c : c0;
+    return e * p.out_es + (int64_t)(cc / 81) * 5184 + cc % 81;
+  }
+  __device__ __forceinline__ void pre_epilogue(const Params& p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + l31;
-      if (c >= p.n * 81) continue;
-      const int b = c / 81, pix = c % 81;
-      const int64_t base = e * p.out_es + (int64_t)b * 5184 + pix;
+      bool ok;
+      const int64_t base = out_base(p, j, ok);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t idx = base + (i * 32 + acc_row(r, hi)) * 81;
-          p.out[idx] = leaky_g(p.act[idx], acc[i][j][r]);
-        }
+        for (int r = 0; r < 16; ++r) actv[i][j][r] = p.act[base + (i * 32 + acc_row(r, hi)) * 81];
+    }
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bool ok;
+      const int64_t base = out_base(p, j, ok);
+      if (!ok) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.out[base + (i * 32 + acc_row(r, hi)) * 81] = leaky_g(actv[i][j][r], acc[i][j][r]);
     }
   }
 };

@@ -75,6 +75,16 @@ struct OccOf<Op, decltype((void)Op::OCC)> {
   static constexpr int v = Op::OCC;
 };
 
+// Ops may define pre_epilogue(P): issued before the last k-block (see engine2_kernel).
+template <class Op, class = void>
+struct HasPreEpilogue {
+  static constexpr bool v = false;
+};
+template <class Op>
+struct HasPreEpilogue<Op, decltype((void)Op::PRE_EPILOGUE)> {
+  static constexpr bool v = true;
+};
+
 template <class Op>
 __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(typename Op::Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds2[];
@@ -101,6 +111,11 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
   int buf = 0;
   for (; kb < kbe; ++kb) {
     op.extra(lds2 + buf * Op::STAGE);
+    if constexpr (HasPreEpilogue<Op>::v) {
+      // global loads the epilogue needs (e.g. the activations for the leaky-ReLU mask) are issued
+      // before the last k-block, so their latency hides under its MFMAs instead of being exposed
+      if (kb == kbe - 1) op.pre_epilogue(P);
+    }
     compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
     if (kb + 1 < kbe) {
       op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);

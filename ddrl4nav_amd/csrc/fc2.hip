@@ -155,6 +155,7 @@ struct FcFwd2 : FcCommon {
 //  dz3[b][k] = leaky'(a3[b][k]) * sum_n dh[b][n] Wl[n][k]   rows = b, cols = k (3136), red = n (512)
 // ------------------------------------------------------------------------------------------------
 struct FcDgrad2 : FcCommon {
+  static constexpr int OCC = 2;  // the prefetched a3 values must not push the kernel to 1 wave/SIMD
   static constexpr int A_OFF = 0, B_OFF = RowMajorTile::FLOATS, STAGE = RowMajorTile::FLOATS + KMajorTile::FLOATS;
   struct Params {
     const float* dh;
@@ -195,6 +196,22 @@ struct FcDgrad2 : FcCommon {
     RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
     KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
   }
+  // a3 values for the leaky-ReLU mask: loaded (unconditionally, clamped) before the last k-block
+  static constexpr int PRE_EPILOGUE = 1;
+  float actv[2][2][16];
+  __device__ __forceinline__ void pre_epilogue(const Params& p) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = min(k0 + wc * 64 + j * 32 + l31, FLAT - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = min(b0 + wr * 64 + i * 32 + acc_row(r, hi), p.n - 1);
+          actv[i][j][r] = p.a3[e * p.a3_es + (int64_t)b * FLAT + k];
+        }
+    }
+  }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -205,10 +222,7 @@ struct FcDgrad2 : FcCommon {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-          if (b < p.n) {
-            const int64_t idx = e * p.a3_es + (int64_t)b * FLAT + k;
-            p.dz3[idx] = leaky_g(p.a3[idx], acc[i][j][r]);
-          }
+          if (b < p.n) p.dz3[e * p.a3_es + (int64_t)b * FLAT + k] = leaky_g(actv[i][j][r], acc[i][j][r]);
         }
     }
   }
