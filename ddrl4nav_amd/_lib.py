@@ -22,6 +22,7 @@ class Config(Structure):
         ("clip_grad", c_int32), ("clip_grad_norm", c_float), ("actor_lr", c_float), ("critic_lr", c_float),
         ("adam_beta1", c_float), ("adam_beta2", c_float), ("adam_eps", c_float), ("ppo_clip", c_float),
         ("dual_clip", c_float), ("v_loss_theta", c_float), ("ent_loss_theta", c_float),
+        ("learning_rate", c_float), ("smooth_l1_loss", c_int32),
     ]
 
 

@@ -90,6 +90,8 @@ int32_t ddrl_config_default(ddrl_config* c) {
   c->dual_clip = 3.0f;
   c->v_loss_theta = 1.0f;
   c->ent_loss_theta = 0.05f;
+  c->learning_rate = 2e-4f;
+  c->smooth_l1_loss = 0;
   return DDRL_OK;
 }
 
@@ -98,7 +100,7 @@ static int32_t validate(const ddrl_config* c) {
   if (c->max_batch < 1) return DDRL_ERR_INVALID_ARG;
   if (c->n_actions < 2 || c->n_actions > 8) return DDRL_ERR_UNSUPPORTED;  // heads kernels: A <= 8
   if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // int_frame_stack = 4
-  if (c->share_cnn_net != 0) return DDRL_ERR_UNSUPPORTED;                 // SHARE_CNN_NET=False only
+  if (c->share_cnn_net != 0 && c->share_cnn_net != 1) return DDRL_ERR_INVALID_ARG;
   // 32-bit element indexing inside one encoder's activation tensor
   if ((int64_t)c->max_batch * 32 * 400 >= (int64_t)1 << 31) return DDRL_ERR_UNSUPPORTED;
   return DDRL_OK;
@@ -107,7 +109,7 @@ static int32_t validate(const ddrl_config* c) {
 int32_t ddrl_param_count(const ddrl_config* c, int64_t* n_params, int64_t* n_actor) {
   int32_t s = validate(c);
   if (s != DDRL_OK) return s;
-  ParamLayout L = make_layout(c->n_actions, c->in_channels);
+  ParamLayout L = make_layout(c->n_actions, c->in_channels, c->share_cnn_net != 0);
   if (n_params) *n_params = L.n_params;
   if (n_actor) *n_actor = L.n_actor;
   return DDRL_OK;
@@ -133,13 +135,13 @@ int32_t ddrl_ctx_create(const ddrl_config* c, float* params, float* grads, float
   ddrl_ctx* ctx = new (std::nothrow) ddrl_ctx();
   if (!ctx) return DDRL_ERR_INVALID_ARG;
   ctx->cfg = *c;
-  ctx->L = make_layout(c->n_actions, c->in_channels);
+  ctx->L = make_layout(c->n_actions, c->in_channels, c->share_cnn_net != 0);
   const int64_t need = carve(ctx->ws, *c, workspace);
   if (need > workspace_bytes) {
     delete ctx;
     return DDRL_ERR_WORKSPACE;
   }
-  ctx->splits = choose_splits(c->max_batch);
+  ctx->splits = choose_splits(c->max_batch, ctx->L.NE);
   ctx->params = params;
   ctx->grads = grads;
   ctx->m = m;
@@ -223,7 +225,8 @@ int32_t ddrl_last_features(ddrl_ctx* ctx, int32_t n, float* h_actor, float* h_cr
   const size_t bytes = (size_t)n * FEAT * sizeof(float);
   if (h_actor) HIP_TRY(hipMemcpyAsync(h_actor, ctx->ws.h, bytes, hipMemcpyDeviceToDevice, st));
   if (h_critic)
-    HIP_TRY(hipMemcpyAsync(h_critic, ctx->ws.h + (int64_t)ctx->cfg.max_batch * FEAT, bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h_critic, ctx->ws.h + (ctx->L.NE == 2 ? (int64_t)ctx->cfg.max_batch * FEAT : 0), bytes,
+                           hipMemcpyDeviceToDevice, st));
   return DDRL_OK;
 }
 

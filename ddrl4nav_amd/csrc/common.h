@@ -23,16 +23,20 @@ struct EncLayout {  // offsets relative to the encoder's base
 };
 struct ParamLayout {
   int A, C;
+  int NE;  // encoders: 2 = actor.pre + critic.pre (SHARE_CNN_NET=False), 1 = one shared prenet
   EncLayout enc;
-  int64_t enc_base[2];  // [0]=actor.pre, [1]=critic.pre
+  int64_t enc_base[2];  // [0]=actor.pre, [1]=critic.pre  (both = prenet when shared)
   int64_t actor_w, actor_b, critic_w, critic_b;
   int64_t n_params, n_actor;
 };
 
-inline ParamLayout make_layout(int A, int C) {
+// named_parameters() order of the reference's PPO module (ppo.py:26-28): prenet (when shared,
+// runner/utils.py:136-143), then actor.* (its own pre first), then critic.*.
+inline ParamLayout make_layout(int A, int C, bool shared = false) {
   ParamLayout L;
   L.A = A;
   L.C = C;
+  L.NE = shared ? 1 : 2;
   int64_t o = 0;
   L.enc.c1w = o; o += (int64_t)C1_OC * C * 64;
   L.enc.c1b = o; o += C1_OC;
@@ -50,6 +54,12 @@ inline ParamLayout make_layout(int A, int C) {
   L.n_actor = p;
   L.critic_w = p; p += FEAT;
   L.critic_b = p; p += 1;
+  if (shared) {
+    L.enc_base[1] = L.enc_base[0];
+    L.n_params = p;
+    L.n_actor = p;  // one Adam group (ppo.py:39)
+    return L;
+  }
   L.enc_base[1] = p; p += L.enc.size;
   L.n_params = p;
   return L;
@@ -75,7 +85,7 @@ struct Workspace {
   int64_t total_bytes;
 };
 
-constexpr int HEAD_WG = 2048;  // workgroups of the heads/loss kernel (fixed -> deterministic)
+constexpr int HEAD_WG = 256;   // workgroups of the heads/loss kernel (fixed -> deterministic)
 constexpr int NORM_WG = 1024;  // workgroups of the grad-norm kernel
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -84,15 +94,16 @@ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 struct Splits {
   int c1, c2, c3, fc;
 };
-inline Splits choose_splits(int max_batch) {
+inline Splits choose_splits(int max_batch, int NE = 2) {
   // ~1024 workgroups per weight-gradient launch (2 resident per CU x 256 CUs x 2 rounds)
   const int pairs = (max_batch + 1) / 2;
   auto cap = [&](int want, int limit) { return want < limit ? (want < 1 ? 1 : want) : (limit < 1 ? 1 : limit); };
   Splits s;
   s.c1 = cap(1024, pairs);      // 1 column tile, encoders fused
-  s.c2 = cap(256, pairs);       // 2 column tiles x 2 encoders
-  s.c3 = cap(171, pairs);       // 3 column tiles x 2 encoders
-  s.fc = cap(5, (max_batch + 31) / 32);  // 25 x 4 tiles x 2 encoders
+  const int k = 2 / NE;         // one encoder: twice the splits keep the same number of workgroups
+  s.c2 = cap(256 * k, pairs);   // 2 column tiles x 2 encoders
+  s.c3 = cap(171 * k, pairs);   // 3 column tiles x 2 encoders
+  s.fc = cap(5 * k, (max_batch + 31) / 32);  // 25 x 4 tiles x 2 encoders
   return s;
 }
 
@@ -123,7 +134,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.dh = take(2 * MB * FEAT);
   w.dlogits = take(MB * A);
   w.dvalue = take(MB);
-  Splits s = choose_splits(c.max_batch);
+  Splits s = choose_splits(c.max_batch, c.share_cnn_net ? 1 : 2);
   // slabs hold weights followed by bias, like the arena
   int64_t p1 = (int64_t)s.c1 * 2 * (32 * C * 64 + 32);
   int64_t p2 = (int64_t)s.c2 * 2 * (64 * 512 + 64);

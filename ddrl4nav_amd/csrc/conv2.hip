@@ -217,14 +217,16 @@ struct ConvFwd3v2 {
 // LDS, de-interleaved by x mod 4 so that a stride-4 tap walk is bank-conflict free:
 //     pixel (row lr, x)  ->  lr*84 + (x&3)*21 + (x>>2)
 // ================================================================================================
+// NE = number of encoders whose conv1 shares one launch (rows = NE x 32 output channels)
+template <int NE>
 struct ConvFwd1v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 32;
-  static constexpr int W_FLOATS = 64 * 64, IMG_OFF = W_FLOATS, IMG_ROWS = 64, IMG_FLOATS = IMG_ROWS * 84;
+  static constexpr int THREADS = 256, TM = NE, TN = 2, KSTEPS = 32, ROWS = 32 * NE;
+  static constexpr int W_FLOATS = 64 * ROWS, IMG_OFF = W_FLOATS, IMG_ROWS = 64, IMG_FLOATS = IMG_ROWS * 84;
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
-  static constexpr int EXTRA = 64;  // bias of both encoders
+  static constexpr int EXTRA = 64;  // bias of the NE encoders
   struct Params {
     const uint8_t* frames;
-    const float* wp;  // [4][32][2][64]
+    const float* wp;  // [4][32][2][ROWS]
     const float* params;
     int64_t bias_off[2];
     float* out;  // a1 [e][n][32][400]
@@ -232,15 +234,15 @@ struct ConvFwd1v2 {
     int n;
   };
   struct Regs {
-    f4 w[4];
+    f4 w[2 * NE];
     unsigned im[6];
   };
-  int abase[2], bbase[2], kb_begin, kb_end;
+  int abase[NE], bbase[2], kb_begin, kb_end;
   int c0, l31, hi, wc;
   int b0, nd0, nd_total;     // dwords of part 0 / both parts
   int64_t src0, src1;        // byte offsets of the two row ranges inside channel 0
   int64_t imsrc[6];          // per-thread byte offset of its j-th staged dword (clamped when unused)
-  static constexpr int aoff(int s) { return 2 * s * 64; }
+  static constexpr int aoff(int s) { return 2 * s * ROWS; }
   static constexpr int boff(int s) { return (s / 4) * 84 + ((2 * (s % 4)) & 3) * 21 + ((2 * (s % 4)) >> 2); }
   __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
     const int lane = tid & 63;
@@ -266,14 +268,14 @@ struct ConvFwd1v2 {
     nd_total = nd0 + nrows1 * 21;
     src0 = (int64_t)b0 * 28224 + iy0_start * 84;
     src1 = (int64_t)b1 * 28224;
-    if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[tid >> 5] + (tid & 31)];
+    if (tid < ROWS) lds[2 * STAGE + tid] = p.params[p.bias_off[tid >> 5] + (tid & 31)];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int idx = tid + 256 * j;
       imsrc[j] = (idx >= nd_total) ? src0 : (idx < nd0 ? src0 + idx * 4 : src1 + (idx - nd0) * 4);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
+    for (int i = 0; i < NE; ++i) abase[i] = hi * ROWS + i * 32 + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int c = c0 + wc * 64 + j * 32 + l31;
@@ -287,7 +289,7 @@ struct ConvFwd1v2 {
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.w[j] = ld4(p.wp + kb * 4096 + (tid + 256 * j) * 4);
+    for (int j = 0; j < 2 * NE; ++j) r.w[j] = ld4(p.wp + kb * W_FLOATS + (tid + 256 * j) * 4);
     const uint8_t* ch = p.frames + kb * 7056;
 #pragma unroll
     for (int j = 0; j < 6; ++j) r.im[j] = *(const unsigned*)(ch + imsrc[j]);  // unconditional, clamped
@@ -295,7 +297,7 @@ struct ConvFwd1v2 {
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
+    for (int j = 0; j < 2 * NE; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int idx = tid + 256 * j;
@@ -311,14 +313,14 @@ struct ConvFwd1v2 {
     }
   }
   __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[NE][2], float* lds) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = c0 + wc * 64 + j * 32 + l31;
       if (c >= p.n * 400) continue;
       const int b = c / 400, pix = c % 400;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {  // i = encoder
+      for (int i = 0; i < NE; ++i) {  // i = encoder
         float* dst = p.out + i * p.out_es + (int64_t)b * 12800 + pix;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -573,19 +575,25 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const ParamLayout& L = *c.L;
   const int n = c.n;
   {
-    ConvFwd1v2::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b}, w.a1, MB * 12800, n};
     ProfRange pr(c.prof, acting ? "ConvFwd1.act" : "ConvFwd1", st);
-    launch_engine2<ConvFwd1v2>(dim3((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1), p, st);
+    const dim3 grid((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1);
+    if (L.NE == 2) {
+      ConvFwd1v2<2>::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b}, w.a1, MB * 12800, n};
+      launch_engine2<ConvFwd1v2<2>>(grid, p, st);
+    } else {
+      ConvFwd1v2<1>::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[0] + L.enc.c1b}, w.a1, MB * 12800, n};
+      launch_engine2<ConvFwd1v2<1>>(grid, p, st);
+    }
   }
   {
     ConvFwd2v2::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
-    launch_engine2<ConvFwd2v2>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, 2), p, st);
+    launch_engine2<ConvFwd2v2>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
   }
   {
     ConvFwd3v2::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
-    launch_engine2<ConvFwd3v2>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, 2), p, st);
+    launch_engine2<ConvFwd3v2>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
   }
 }
 
@@ -594,7 +602,7 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
   const int64_t MB = c.max_batch;
   ConvDgrad3v2::Params p{w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n};
   ProfRange pr(c.prof, "ConvDgrad3", st);
-  launch_engine2<ConvDgrad3v2>(dim3((unsigned)(((int64_t)c.n * 81 + 255) / 256), 1, 2), p, st);
+  launch_engine2<ConvDgrad3v2>(dim3((unsigned)(((int64_t)c.n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
 }
 
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
@@ -602,7 +610,7 @@ void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
   const int64_t MB = c.max_batch;
   ConvDgrad2v2::Params p{w.dz2, MB * 5184, w.wd2p, w.a1, w.dz1, MB * 12800, c.n};
   ProfRange pr(c.prof, "ConvDgrad2", st);
-  launch_engine2<ConvDgrad2v2>(dim3((unsigned)(((int64_t)c.n * 100 + 255) / 256), 1, 2), p, st);
+  launch_engine2<ConvDgrad2v2>(dim3((unsigned)(((int64_t)c.n * 100 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
 }
 
 }  // namespace ddrl

@@ -101,6 +101,7 @@ struct FcFwd2 : FcCommon {
     int n;
     int nsplit;   // > 1: write bias-free partial sums part[split][e][n][512] (acting path)
     float* part;
+    int ne;  // encoders (2, or 1 when the prenet is shared)
   };
   struct Regs {
     f4 a[4], b[4];
@@ -112,8 +113,8 @@ struct FcFwd2 : FcCommon {
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
-    e = blockIdx.z % 2;
-    split = blockIdx.z / 2;
+    e = blockIdx.z % p.ne;
+    split = blockIdx.z / p.ne;
     n0 = blockIdx.x * 128;
     b0 = blockIdx.y * 128;
     const int per = (FLAT / 32) / p.nsplit;
@@ -242,6 +243,7 @@ struct FcWgrad2 : FcCommon {
     int64_t a3_es;
     float* part;  // [nsplit][e][SLAB]
     int n, nsplit;
+    int ne;
   };
   struct Regs {
     f4 a[4], b[4];
@@ -255,8 +257,8 @@ struct FcWgrad2 : FcCommon {
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
-    e = blockIdx.z % 2;
-    split = blockIdx.z / 2;
+    e = blockIdx.z % p.ne;
+    split = blockIdx.z / p.ne;
     k0 = blockIdx.x * 128;
     n0 = blockIdx.y * 128;
     const int nkb = (p.n + 31) / 32;
@@ -317,9 +319,9 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   const int64_t MB = c.max_batch;
   const int nsplit = allow_split ? fc_forward_splits(c.n) : 1;  // 98 k-blocks = 14 x 7
   FcFwd2::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
-                   w.h, MB * FEAT, c.n, nsplit, w.wpart};
+                   w.h, MB * FEAT, c.n, nsplit, w.wpart, c.L->NE};
   ProfRange pr(c.prof, nsplit > 1 ? "FcFwdSplit" : "FcFwd", st);
-  launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, 2 * nsplit), p, st);
+  launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), p, st);
 }
 
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
@@ -328,18 +330,18 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
   const ParamLayout& L = *c.L;
   const int S = c.splits->fc;
   {
-    FcWgrad2::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S};
+    FcWgrad2::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S, L.NE};
     ProfRange pr(c.prof, "FcWgrad", st);
-    launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, 2 * S), p, st);
+    launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), p, st);
   }
   {
     ProfRange pr(c.prof, "reduce_partials", st);
-    launch_reduce_partials(w.wpart, S, FcWgrad2::SLAB, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
+    launch_reduce_partials(w.wpart, S, FcWgrad2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
   }
   {
     FcDgrad2::Params p{w.dh, MB * FEAT, w.wln, w.a3, w.dz3, MB * FLAT, c.n};
     ProfRange pr(c.prof, "FcDgrad", st);
-    launch_engine2<FcDgrad2>(dim3((FLAT + 127) / 128, (c.n + 127) / 128, 2), p, st);
+    launch_engine2<FcDgrad2>(dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), p, st);
   }
 }
 

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
   const int nw = (gridDim.x * blockDim.x) >> 6;
   HeadRegs R;
   load_head_weights(R, params, L, lane);
+  const int ec = L.NE - 1;  // encoder feeding the critic head (0 when the prenet is shared)
   for (int b = gw; b < n; b += nw) {
     float ha[8], hc[8];
     if (fc_nsplit > 0) {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
       for (int sp = 0; sp < fc_nsplit; ++sp) {
         float ta[8], tc[8];
         load8(fc_part + (((int64_t)sp * 2 + 0) * n + b) * FEAT + lane * 8, ta);
-        load8(fc_part + (((int64_t)sp * 2 + 1) * n + b) * FEAT + lane * 8, tc);
+        load8(fc_part + (((int64_t)sp * 2 + ec) * n + b) * FEAT + lane * 8, tc);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           ha[i] += ta[i];
@@ -139,10 +140,10 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
         hc[i] += params[L.enc_base[1] + L.enc.lb + lane * 8 + i];
       }
       store8(h + (int64_t)b * FEAT + lane * 8, ha);
-      store8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+      if (ec) store8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
     } else {
       load8(h + (int64_t)b * FEAT + lane * 8, ha);
-      load8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+      load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, hc);
     }
     float z[MAXA];
 #pragma unroll
@@ -214,10 +215,16 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
   double s_actor = 0.0, s_v = 0.0, s_ent = 0.0;
   const float lo = 1.0f - cfg.ppo_clip, hi = 1.0f + cfg.ppo_clip;
 
+  // shared prenet (ppo.py:110-117): one backward of total_loss = actor_loss + theta_v * v_loss
+  // - theta_e * entropy, so the value gradient carries theta_v, the entropy has a gradient, and
+  // both heads feed the one encoder.  Non-shared (ppo.py:118-129): actor_loss.backward() and
+  // v_loss.backward() only -- no theta_v, no entropy gradient.
+  const bool shared = (L.NE == 1);
+  const int ec = L.NE - 1;
   for (int b = gw; b < n; b += nw) {
     float ha[8], hc[8];
     load8(h + (int64_t)b * FEAT + lane * 8, ha);
-    load8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
+    load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, hc);
     float z[MAXA];
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
@@ -244,7 +251,15 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
     const float term = (adv > 0.0f) ? mn : fmaxf(mn, dual);
     s_actor += (double)term;
     const float err = rets[b] - v;
-    s_v += (double)err * (double)err;
+    float gv_unit;  // d(v_loss element)/d(v) before the 1/B
+    if (cfg.smooth_l1_loss) {  // F.smooth_l1_loss(ret, v), beta = 1 (ppo.py:54)
+      const float ae = fabsf(err);
+      s_v += (ae < 1.0f) ? 0.5 * (double)err * (double)err : (double)ae - 0.5;
+      gv_unit = (err < -1.0f) ? 1.0f : ((err > 1.0f) ? -1.0f : -err);
+    } else {  // mean((ret - v)^2) / 2 (ppo.py:57); the 1/2 is applied by heads_reduce
+      s_v += (double)err * (double)err;
+      gv_unit = -err;
+    }
     float ent = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXA; ++j)
@@ -268,14 +283,30 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
     const float g_ps = -g_qa * pa / (d.ps * d.ps);
     float gp[MAXA], dot = 0.0f;
 #pragma unroll
-    for (int j = 0; j < MAXA; ++j) {
-      gp[j] = ((j == a) ? g_qa / d.ps : 0.0f) + g_ps;
-      if (j < A) dot += gp[j] * d.p[j];
+    for (int j = 0; j < MAXA; ++j) gp[j] = ((j == a) ? g_qa / d.ps : 0.0f) + g_ps;
+    if (shared) {
+      // -theta_e * mean(H), H = -sum_j q_j * log(clamp(q_j)): dH/dq_j = -(lc_j + q_j * [in range] / clamp(q_j))
+      const float g_h = -cfg.ent_loss_theta * inv_b;
+      float gq[MAXA], gps_e = 0.0f;
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) {
+        const float qj = d.q[j];
+        const float qc = fminf(fmaxf(qj, CAT_EPS), 1.0f - CAT_EPS);
+        const float inr = (qj >= CAT_EPS && qj <= 1.0f - CAT_EPS) ? qj / qc : 0.0f;
+        gq[j] = (j < A) ? -g_h * (d.lc[j] + inr) : 0.0f;
+        gps_e -= gq[j] * d.p[j];
+      }
+      gps_e = gps_e / (d.ps * d.ps);
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) gp[j] += gq[j] / d.ps + gps_e;
     }
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j)
+      if (j < A) dot += gp[j] * d.p[j];
     float gz[MAXA];
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) gz[j] = (j < A) ? (gp[j] - dot) * d.p[j] : 0.0f;
-    const float gv = -err * inv_b;
+    const float gv = shared ? gv_unit * inv_b * cfg.v_loss_theta : gv_unit * inv_b;
 
     // ---- head layers backward ----
     float da[8], dc[8];
@@ -295,8 +326,14 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
       for (int i = 0; i < 8; ++i) gwa[j][i] = __builtin_fmaf(gz[j], ha[i], gwa[j][i]);
     }
     gbc += gv;
-    store8(dh + (int64_t)b * FEAT + lane * 8, da);
-    store8(dh + dh_es + (int64_t)b * FEAT + lane * 8, dc);
+    if (shared) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) da[i] += dc[i];
+      store8(dh + (int64_t)b * FEAT + lane * 8, da);
+    } else {
+      store8(dh + (int64_t)b * FEAT + lane * 8, da);
+      store8(dh + dh_es + (int64_t)b * FEAT + lane * 8, dc);
+    }
     if (lane < A) dlogits[(int64_t)b * A + lane] = pick(gz, lane);
     if (lane == 0) dvalue[b] = gv;
   }
@@ -352,7 +389,7 @@ __global__ __launch_bounds__(256) void heads_reduce_kernel(const float* __restri
     const int k = i - nloss0;
     double r;
     if (k == 0) r = -s * (double)inv_b;            // actor_loss = -mean(term)
-    else if (k == 1) r = s * (double)inv_b * 0.5;  // v_loss = mean(err^2)/2
+    else if (k == 1) r = s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5);  // v_loss = mean(err^2)/2
     else r = s * (double)inv_b;                    // entropy = mean(H)
     grads[L.n_params + k] = (float)r;
     return;

@@ -55,7 +55,7 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st);
 
 // optim.hip
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st);
-void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0,
+void launch_reduce_partials(const float* part, int nsplit, int64_t count, int ne, float* grads, int64_t off0,
                             int64_t off1, hipStream_t st);
 void launch_clip_adam(const ddrl_config& cfg, const ParamLayout& L, const Workspace& w, float* params,
                       float* grads, float* m, float* v, int64_t step, hipStream_t st);

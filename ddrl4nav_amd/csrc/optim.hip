@@ -39,9 +39,11 @@ __global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ 
 // k indices walk (channel pairs on the lane halves; tap pairs for conv1).
 __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ params, ParamLayout L, Workspace w) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  const int n1 = 4 * 32 * 2 * 64, n2 = 2 * 16 * 16 * 2 * 64, n3 = 2 * 16 * 18 * 2 * 64, n4 = n3, n5 = 2 * 8 * 16 * 2 * 128;
+  const int NE = L.NE, rows1 = 32 * NE;
+  const int n1 = 4 * 32 * 2 * rows1, n2 = NE * 16 * 16 * 2 * 64, n3 = NE * 16 * 18 * 2 * 64, n4 = n3, n5 = NE * 8 * 16 * 2 * 128;
   if (i < n1) {  // wp1[kb=ic][s][hi][e*32+oc] = W1_e[oc][ic][ky=s/4][kx=2*(s%4)+hi]
-    const int row = i & 63, hi = (i >> 6) & 1, s = (i >> 7) & 31, kb = i >> 12;
+    const int row = i % rows1, r = i / rows1;
+    const int hi = r & 1, s = (r >> 1) & 31, kb = r >> 6;
     const int e = row >> 5, oc = row & 31;
     w.wp1[i] = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + kb) * 8 + (s >> 2)) * 8 + 2 * (s & 3) + hi];
     return;
@@ -78,10 +80,10 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ pa
 
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
   {
-    const int total2 = 4 * 32 * 2 * 64 + 2 * 16 * 16 * 2 * 64 + 2 * 2 * 16 * 18 * 2 * 64 + 2 * 8 * 16 * 2 * 128;
+    const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);
   }
-  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, 2), dim3(256), 0, st, params, L, w.wlt, w.wln);
+  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, L.NE), dim3(256), 0, st, params, L, w.wlt, w.wln);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -96,9 +98,9 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)sp * 2 + e) * count + i];
   grads[(e ? off1 : off0) + i] = s;
 }
-void launch_reduce_partials(const float* part, int nsplit, int64_t count, float* grads, int64_t off0, int64_t off1,
-                            hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256), 2), dim3(256), 0, st, part, nsplit,
+void launch_reduce_partials(const float* part, int nsplit, int64_t count, int ne, float* grads, int64_t off0,
+                            int64_t off1, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256), ne), dim3(256), 0, st, part, nsplit,
                      count, grads, off0, off1);
 }
 
@@ -174,8 +176,12 @@ void launch_clip_adam(const ddrl_config& cfg, const ParamLayout& L, const Worksp
   AdamArgs a;
   const double bc1 = 1.0 - pow((double)cfg.adam_beta1, (double)step);
   const double bc2 = 1.0 - pow((double)cfg.adam_beta2, (double)step);
-  a.lr_step[0] = (float)((double)cfg.actor_lr / bc1);
-  a.lr_step[1] = (float)((double)cfg.critic_lr / bc1);
+  if (L.NE == 1) {  // shared prenet: self.optim = Adam(self.parameters(), LEARNING_RATE) (ppo.py:39,110-117)
+    a.lr_step[0] = a.lr_step[1] = (float)((double)cfg.learning_rate / bc1);
+  } else {
+    a.lr_step[0] = (float)((double)cfg.actor_lr / bc1);
+    a.lr_step[1] = (float)((double)cfg.critic_lr / bc1);
+  }
   a.bc2_sqrt = (float)sqrt(bc2);
   a.beta1 = cfg.adam_beta1;
   a.beta2 = cfg.adam_beta2;

@@ -31,9 +31,10 @@ struct WgradSplit {
 // conv1, both encoders fused: rows = (e, oc) = 64, cols = 256 taps (4 ch x 8 x 8),
 // k-block = (sample pair, output row oy): 20 k-steps (ox).
 // ================================================================================================
+template <int NE>
 struct ConvWgrad1v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 20;
-  static constexpr int A_FLOATS = 2 * 64 * 21, B_OFF = A_FLOATS, B_FLOATS = 2 * 4 * 672, STAGE = A_FLOATS + B_FLOATS;
+  static constexpr int THREADS = 256, TM = NE, TN = 2, KSTEPS = 20, ROWS = 32 * NE;  // rows = (e, oc)
+  static constexpr int A_FLOATS = 2 * ROWS * 21, NDZ = 2 * ROWS * 5, NDZ_J = (NDZ + 255) / 256, B_OFF = A_FLOATS, B_FLOATS = 2 * 4 * 672, STAGE = A_FLOATS + B_FLOATS;
   static constexpr int64_t SLAB = 32 * 256 + 32;
   struct Params {
     const uint8_t* frames;
@@ -44,14 +45,14 @@ struct ConvWgrad1v2 {
     int n, nsplit;
   };
   struct Regs {
-    f4 dzr[3], actr[3];
+    f4 dzr[NDZ_J], actr[NDZ_J];
     unsigned im[6];
     unsigned ok;  // bit j: dz element j belongs to a sample < n
   };
-  int abase[2], bbase[2], kb_begin, kb_end;
+  int abase[NE], bbase[2], kb_begin, kb_end;
   int split, l31, hi, wc;
-  int64_t dzoff[3];         // k-block independent parts of this thread's source offsets
-  int imoff[6], ldsoff[3];
+  int64_t dzoff[NDZ_J];         // k-block independent parts of this thread's source offsets
+  int imoff[6], ldsoff[NDZ_J];
   float bacc;
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return 4 * s; }
@@ -67,10 +68,10 @@ struct ConvWgrad1v2 {
     kb_end = sp.pair_end * 20;
     bacc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = min(tid + 256 * j, 639);
-      const int row = idx / 5, q4 = idx % 5;
-      dzoff[j] = ((row >> 5) & 1) * p.dz_es + (int64_t)(row >> 6) * 12800 + (row & 31) * 400 + q4 * 4;
+    for (int j = 0; j < NDZ_J; ++j) {
+      const int idx = min(tid + 256 * j, NDZ - 1);
+      const int row = idx / 5, q4 = idx % 5;  // row = (sample of the pair, e, oc)
+      dzoff[j] = ((row >> 5) % NE) * p.dz_es + (int64_t)(row / ROWS) * 12800 + (row & 31) * 400 + q4 * 4;
       ldsoff[j] = row * 21 + q4 * 4;
     }
 #pragma unroll
@@ -80,7 +81,7 @@ struct ConvWgrad1v2 {
       imoff[j] = (idx / 672) * 28224 + (rr / 168) * 7056 + (rr % 168) * 4;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = hi * 1344 + (i * 32 + l31) * 21;
+    for (int i = 0; i < NE; ++i) abase[i] = hi * (ROWS * 21) + (i * 32 + l31) * 21;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wc * 64 + j * 32 + l31;
@@ -97,7 +98,7 @@ struct ConvWgrad1v2 {
       const uint8_t* fp = p.frames + (int64_t)pair * (2 * 28224) + oy * 336;
       r.ok = 7u;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < NDZ_J; ++j) {
         r.dzr[j] = ld4(p.dz + sb + dzoff[j]);
         r.actr[j] = ld4(p.act + sb + dzoff[j]);
       }
@@ -107,10 +108,10 @@ struct ConvWgrad1v2 {
     }
     r.ok = 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = min(tid + 256 * j, 639);
+    for (int j = 0; j < NDZ_J; ++j) {
+      const int idx = min(tid + 256 * j, NDZ - 1);
       const int row = idx / 5, q4 = idx % 5;
-      const int smp = row >> 6, e = (row >> 5) & 1, oc = row & 31;
+      const int smp = row / ROWS, e = (row >> 5) % NE, oc = row & 31;
       const int b = 2 * pair + smp;
       r.ok |= (b < p.n ? 1u : 0u) << j;
       const int64_t off = e * p.dz_es + (int64_t)min(b, p.n - 1) * 12800 + oc * 400 + oy * 20 + q4 * 4;
@@ -129,9 +130,9 @@ struct ConvWgrad1v2 {
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NDZ_J; ++j) {
       const int idx = tid + 256 * j;
-      if (idx < 640) {
+      if (idx < NDZ) {
         float* d = buf + ldsoff[j];
         const f4 dzv = ((r.ok >> j) & 1u) ? r.dzr[j] : zero4();
         d[0] = leaky_g(r.actr[j].x, dzv.x);
@@ -150,7 +151,7 @@ struct ConvWgrad1v2 {
     }
   }
   __device__ __forceinline__ void extra(const float* cur) {
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < 2 * ROWS) {
       const float* row = cur + threadIdx.x * 21;
       float s = 0.0f;
 #pragma unroll
@@ -158,9 +159,9 @@ struct ConvWgrad1v2 {
       bacc += s;
     }
   }
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[NE][2], float* lds) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NE; ++i) {
       float* slab = p.part + ((int64_t)split * 2 + i) * SLAB;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -169,11 +170,11 @@ struct ConvWgrad1v2 {
         for (int r = 0; r < 16; ++r) slab[acc_row(r, hi) * 256 + col] = acc[i][j][r];
       }
     }
-    if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+    if (threadIdx.x < 2 * ROWS) lds[threadIdx.x] = bacc;
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < ROWS) {
       const int e = threadIdx.x >> 5, oc = threadIdx.x & 31;
-      p.part[((int64_t)split * 2 + e) * SLAB + 8192 + oc] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+      p.part[((int64_t)split * 2 + e) * SLAB + 8192 + oc] = lds[threadIdx.x] + lds[ROWS + threadIdx.x];
     }
   }
 };
@@ -447,10 +448,10 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
   {
     ConvWgrad3v2::Params p{w.a2, MB * 5184, w.dz3, MB * FLAT, w.wpart, c.n, S};
     ProfRange pr(c.prof, "ConvWgrad3", st);
-    launch_engine2<ConvWgrad3v2>(dim3(3, S, 2), p, st);
+    launch_engine2<ConvWgrad3v2>(dim3(3, S, L.NE), p, st);
   }
   ProfRange pr(c.prof, "reduce_partials", st);
-  launch_reduce_partials(w.wpart, S, ConvWgrad3v2::SLAB, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);
+  launch_reduce_partials(w.wpart, S, ConvWgrad3v2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);
 }
 
 void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
@@ -461,10 +462,10 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
   {
     ConvWgrad2v2::Params p{w.a1, MB * 12800, w.dz2, MB * 5184, w.wpart, c.n, S};
     ProfRange pr(c.prof, "ConvWgrad2", st);
-    launch_engine2<ConvWgrad2v2>(dim3(2, S, 2), p, st);
+    launch_engine2<ConvWgrad2v2>(dim3(2, S, L.NE), p, st);
   }
   ProfRange pr(c.prof, "reduce_partials", st);
-  launch_reduce_partials(w.wpart, S, ConvWgrad2v2::SLAB, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
+  launch_reduce_partials(w.wpart, S, ConvWgrad2v2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
 }
 
 void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
@@ -473,12 +474,17 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
   const ParamLayout& L = *c.L;
   const int S = c.splits->c1;
   {
-    ConvWgrad1v2::Params p{c.frames, w.dz1, w.a1, MB * 12800, w.wpart, c.n, S};
     ProfRange pr(c.prof, "ConvWgrad1", st);
-    launch_engine2<ConvWgrad1v2>(dim3(1, S, 1), p, st);
+    if (L.NE == 2) {
+      ConvWgrad1v2<2>::Params p{c.frames, w.dz1, w.a1, MB * 12800, w.wpart, c.n, S};
+      launch_engine2<ConvWgrad1v2<2>>(dim3(1, S, 1), p, st);
+    } else {
+      ConvWgrad1v2<1>::Params p{c.frames, w.dz1, w.a1, MB * 12800, w.wpart, c.n, S};
+      launch_engine2<ConvWgrad1v2<1>>(dim3(1, S, 1), p, st);
+    }
   }
   ProfRange pr(c.prof, "reduce_partials", st);
-  launch_reduce_partials(w.wpart, S, ConvWgrad1v2::SLAB, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
+  launch_reduce_partials(w.wpart, S, ConvWgrad1v2<2>::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
 }
 
 }  // namespace ddrl

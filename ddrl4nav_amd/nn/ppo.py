@@ -30,9 +30,9 @@ class PPO(Basenn):
     def __init__(self, actor, critic, prenet=None, rnd=None, config=None, config_nn=None, max_batch=None,
                  process_group=None):
         super().__init__(config, config_nn)
-        if prenet is not None or config_nn.SHARE_CNN_NET:
-            raise NotImplementedError("SHARE_CNN_NET=True (shared encoder) is not built yet; the default is False "
-                                      "(reference config_nn.py:57)")
+        if bool(config_nn.SHARE_CNN_NET) != (prenet is not None):
+            raise ValueError("SHARE_CNN_NET=True needs a shared prenet (and pre-less actor / critic); "
+                             "SHARE_CNN_NET=False needs prenet=None (reference runner/utils.py:122-143)")
         if rnd is not None:
             raise NotImplementedError("RND is disabled in the reference defaults (USE_RND=False) and out of scope")
         self.device = torch.device(config.DEVICE if str(config.DEVICE) != "cuda" else "cuda:%d" % torch.cuda.current_device())
@@ -51,16 +51,15 @@ class PPO(Basenn):
         self._calls = 0
         self._hp = None
         n_actions = actor.action_output_dim
-        in_ch = actor.pre.conv1.in_channels
+        in_ch = (prenet if prenet is not None else actor.pre).conv1.in_channels
         cap = int(max_batch if max_batch is not None else max(2 * config_nn.TRAINING_MIN_BATCH, 2048))
         self._build(cap, n_actions, in_ch)
 
     # ---- arena binding --------------------------------------------------------------------------
     def _hot_path_kwargs(self):
         c = self._cfg_nn
-        if c.SMOOTH_L1_LOSS:
-            raise NotImplementedError("SMOOTH_L1_LOSS=True is not built (reference default False)")
-        return dict(clip_grad=1 if c.CLIP_GRID else 0, clip_grad_norm=float(c.CLIP_GRID_NUM),
+        return dict(share_cnn_net=1 if c.SHARE_CNN_NET else 0, learning_rate=float(c.LEARNING_RATE),
+                    smooth_l1_loss=1 if c.SMOOTH_L1_LOSS else 0, clip_grad=1 if c.CLIP_GRID else 0, clip_grad_norm=float(c.CLIP_GRID_NUM),
                     actor_lr=float(c.ACTOR_LEARNING_RATE), critic_lr=float(c.CRITIC_LEARNING_RATE),
                     ppo_clip=float(c.PPO_CLIP), dual_clip=float(c.DUEL_PPO_CLIP), v_loss_theta=float(c.V_LOSS_THETA),
                     ent_loss_theta=float(c.ENTROPY_LOSS_THETA))

@@ -39,15 +39,21 @@ def ini_config(parse):
 
 
 def create_net(configs, max_batch=None, process_group=None) -> Basenn:
-    """atari / SHARE_CNN_NET=False branch of create_net (runner/utils.py:122-134,159-160)."""
+    """atari branches of create_net (runner/utils.py:122-143,159-160): two encoders
+    (SHARE_CNN_NET=False, the default) or one shared prenet."""
     config, config_nn, config_env = configs['config'], configs['config_nn'], configs['config_env']
     if config.TASK_TYPE != 'atari':
         raise NotImplementedError("only the atari task type is built (SURVEY.md section 8); got %s" % config.TASK_TYPE)
-    if config_nn.SHARE_CNN_NET:
-        raise NotImplementedError("SHARE_CNN_NET=True is not built yet")
     if config_nn.NETWORK_TYPE != "ppo":
         raise NotImplementedError("NETWORK_TYPE=%s is not built (GAIL: SURVEY.md section 8f row 4)" % config_nn.NETWORK_TYPE)
     frames = config_env['int_frame_stack']
+    if config_nn.SHARE_CNN_NET:
+        actor = config_nn.ACTOR_CLASS(action_output_dim=config_nn.ACTION_OUTPUT_DIM, device=config_nn.DEVICE,
+                                      last_input_dim=config_nn.AC_INPUT_DIM, soft_max_grid=config_nn.SOFT_MAX_GRID,
+                                      nn_dtype=config_nn.MODULE_TENSOR_DTYPE)
+        critic = Critic(device=config_nn.DEVICE)
+        prenet = AtariPreNet(frames, last_output_dim=config_nn.AC_INPUT_DIM, device=config_nn.DEVICE)
+        return PPO(actor, critic, prenet, None, config, config_nn, max_batch=max_batch, process_group=process_group)
     pre_actor = AtariPreNet(frames, last_output_dim=config_nn.AC_INPUT_DIM, device=config_nn.DEVICE)
     pre_critic = AtariPreNet(frames, last_output_dim=config_nn.AC_INPUT_DIM, device=config_nn.DEVICE)
     actor = config_nn.ACTOR_CLASS(action_output_dim=config_nn.ACTION_OUTPUT_DIM, device=config_nn.DEVICE,

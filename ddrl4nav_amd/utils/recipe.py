@@ -14,8 +14,9 @@ import numpy as np
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def param_specs(num_inputs=4, n_actions=6):
-    """[(name, shape, fan_in)] in the reference's ``named_parameters()`` order."""
+def param_specs(num_inputs=4, n_actions=6, shared=False):
+    """[(name, shape, fan_in)] in the reference's ``named_parameters()`` order; ``shared`` =
+    SHARE_CNN_NET=True (one ``prenet``, pre-less actor / critic, runner/utils.py:136-143)."""
     def enc(prefix):
         return [
             (prefix + "conv1.weight", (32, num_inputs, 8, 8), num_inputs * 64),
@@ -27,6 +28,11 @@ def param_specs(num_inputs=4, n_actions=6):
             (prefix + "linear.weight", (512, 3136), 3136),
             (prefix + "linear.bias", (512,), 3136),
         ]
+    if shared:
+        return enc("prenet.") + [("actor.actor_linear.weight", (n_actions, 512), 512),
+                                 ("actor.actor_linear.bias", (n_actions,), 512),
+                                 ("critic.critic_linear.weight", (1, 512), 512),
+                                 ("critic.critic_linear.bias", (1,), 512)]
     specs = enc("actor.pre.")
     specs += [("actor.actor_linear.weight", (n_actions, 512), 512),
               ("actor.actor_linear.bias", (n_actions,), 512)]
@@ -53,10 +59,10 @@ def hash_uniform(seed, stream, n):
     return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).astype(np.float32)
 
 
-def make_weights(seed=0, num_inputs=4, n_actions=6):
+def make_weights(seed=0, num_inputs=4, n_actions=6, shared=False):
     """dict name -> float32 ndarray, uniform in +-1/sqrt(fan_in)."""
     out = {}
-    for ti, (name, shape, fan_in) in enumerate(param_specs(num_inputs, n_actions)):
+    for ti, (name, shape, fan_in) in enumerate(param_specs(num_inputs, n_actions, shared)):
         n = int(np.prod(shape))
         u = hash_uniform(seed, ti, n)
         bound = np.float32(1.0 / np.sqrt(np.float64(fan_in)))
@@ -64,6 +70,9 @@ def make_weights(seed=0, num_inputs=4, n_actions=6):
     return out
 
 
-def flatten(weights, num_inputs=4, n_actions=6):
+def flatten(weights, num_inputs=4, n_actions=6, shared=None):
     """Concatenate into the flat fp32 arena (reference blob order)."""
-    return np.concatenate([weights[n].reshape(-1) for n, _, _ in param_specs(num_inputs, n_actions)]).astype(np.float32)
+    if shared is None:
+        shared = any(k.startswith("prenet.") for k in weights)
+    return np.concatenate([weights[n].reshape(-1)
+                           for n, _, _ in param_specs(num_inputs, n_actions, shared)]).astype(np.float32)

@@ -56,7 +56,9 @@ typedef struct ddrl_config {
   int32_t n_actions;      /* ACTION_OUTPUT_DIM, 6 for Pong                       */
   int32_t in_channels;    /* int_frame_stack, 4                                   */
   int32_t max_batch;      /* largest n / B any call will pass (sizes workspace)   */
-  int32_t share_cnn_net;  /* SHARE_CNN_NET; only 0 is implemented                 */
+  int32_t share_cnn_net;  /* SHARE_CNN_NET: 0 = actor and critic own an encoder each (default,
+                             ppo.py:118-129), 1 = one shared prenet, one Adam over every
+                             parameter on total_loss (ppo.py:110-117)                */
   int32_t clip_grad;      /* CLIP_GRID                                            */
   float clip_grad_norm;   /* CLIP_GRID_NUM = 0.5                                  */
   float actor_lr;         /* ACTOR_LEARNING_RATE = 5e-5                           */
@@ -68,6 +70,8 @@ typedef struct ddrl_config {
   float dual_clip;        /* DUEL_PPO_CLIP = 3                                    */
   float v_loss_theta;     /* V_LOSS_THETA = 1.0                                   */
   float ent_loss_theta;   /* ENTROPY_LOSS_THETA = 0.05                            */
+  float learning_rate;    /* LEARNING_RATE = 2e-4, the single Adam of the shared mode */
+  int32_t smooth_l1_loss; /* SMOOTH_L1_LOSS: 0 = mean((ret-v)^2)/2, 1 = F.smooth_l1_loss (ppo.py:53-57) */
 } ddrl_config;
 
 int32_t ddrl_abi_version(void);

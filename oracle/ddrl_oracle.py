@@ -14,7 +14,8 @@ Reference sites restated (all under /root/reference/USTC_lab):
   * nn/actor.py:73-101             CategoricalActor -> ``ActorHead`` / ``categorical_*``
   * nn/critic.py:8-21              Critic        -> ``CriticHead``
   * nn/ppo.py:72-75                PPO.forward   -> ``OraclePPO.forward``
-  * nn/ppo.py:77-146               PPO.learn     -> ``learn``
+  * nn/ppo.py:77-146               PPO.learn     -> ``learn`` (both the shared and the non-shared branch)
+  * runner/utils.py:136-143        SHARE_CNN_NET=True net -> ``OracleSharedPPO``
   * agent/agent.py:124-140         Agents._accumulate_rewards -> ``gae``
   * agent/statistics.py:118-123    Status.update_reward_status -> ``episode_returns``
   * env/gym_env/wrapper/warputils.py:300 + server/forward.py:102-104  u8/255.0 -> f32 -> ``u8_lut``
@@ -135,34 +136,66 @@ class OraclePPO(nn.Module):
                 torch.optim.Adam(self.critic.parameters(), CRITIC_LR))
 
 
-def ppo_losses(net, x, actions, old_logps, advs, rets):
+class OracleSharedPPO(nn.Module):
+    """SHARE_CNN_NET=True net of runner/utils.py:136-143: one ``prenet`` feeding a pre-less
+    CategoricalActor and Critic (ppo.py:72-75); one Adam over everything (ppo.py:39)."""
+
+    def __init__(self, n_actions=6, num_inputs=4):
+        super().__init__()
+        self.prenet = Encoder(num_inputs)
+        self.actor = nn.Module()
+        self.actor.actor_linear = nn.Linear(512, n_actions)
+        self.critic = nn.Module()
+        self.critic.critic_linear = nn.Linear(512, 1)
+        self.update_time = 0
+
+    load_weights = OraclePPO.load_weights
+
+    def forward(self, x):
+        h = self.prenet(x)
+        probs = F.softmax(self.actor.actor_linear(h), dim=-1)
+        p_hat, logits = categorical_logits(probs)
+        return probs, p_hat, logits, self.critic.critic_linear(h)
+
+    def make_optims(self):
+        return (torch.optim.Adam(self.parameters(), SHARED_LR),)
+
+
+def ppo_losses(net, x, actions, old_logps, advs, rets, smooth_l1=False):
     """Loss block of ppo.py:82-108.  Returns (total, actor_loss, v_loss, entropy) tensors."""
     _, p_hat, logits, v = net(x)
     log_p = categorical_log_prob(logits, actions)
     ratio = torch.exp(log_p - old_logps)
     m = torch.min(ratio * advs, torch.clamp(ratio, 1.0 - PPO_CLIP, 1.0 + PPO_CLIP) * advs)
     actor_loss = -torch.mean(torch.where(advs > 0, m, torch.max(m, DUEL_PPO_CLIP * advs)))
-    v_loss = torch.mean((rets - v.squeeze()) ** 2) / 2
+    if smooth_l1:  # SMOOTH_L1_LOSS (ppo.py:53-54): vlossf(data.values[0], values[0].squeeze())
+        v_loss = F.smooth_l1_loss(rets, v.squeeze())
+    else:
+        v_loss = torch.mean((rets - v.squeeze()) ** 2) / 2
     ent = torch.mean(categorical_entropy(p_hat, logits))
     total = actor_loss + v_loss * V_LOSS_THETA - ent * ENT_LOSS_THETA
     return total, actor_loss, v_loss, ent
 
 
-def learn(net, optims, x, actions, old_logps, advs, rets, iters=TRAINING_ITER_TIME, hook=None):
-    """Non-shared optimise block of ppo.py:118-129, as a generator like ppo.py:142."""
-    actor_optim, critic_optim = optims
+def learn(net, optims, x, actions, old_logps, advs, rets, iters=TRAINING_ITER_TIME, hook=None, smooth_l1=False):
+    """Optimise block of ppo.py:110-129 as a generator like ppo.py:142.  Two optimisers = the
+    default non-shared branch (actor_loss.backward(); v_loss.backward()); one optimiser = the
+    shared branch (total_loss.backward())."""
     for _ in range(iters):
         t0 = time.time()
-        total, actor_loss, v_loss, ent = ppo_losses(net, x, actions, old_logps, advs, rets)
-        actor_optim.zero_grad()
-        critic_optim.zero_grad()
-        actor_loss.backward()
-        v_loss.backward()
+        total, actor_loss, v_loss, ent = ppo_losses(net, x, actions, old_logps, advs, rets, smooth_l1)
+        for o in optims:
+            o.zero_grad()
+        if len(optims) == 1:
+            total.backward()
+        else:
+            actor_loss.backward()
+            v_loss.backward()
         gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP_GRAD_NUM)
         if hook is not None:
             hook(net, float(gnorm))
-        actor_optim.step()
-        critic_optim.step()
+        for o in optims:
+            o.step()
         net.update_time += 1
         yield ({"PpoTotalLoss": total.item(), "ActorLoss": actor_loss.item(), "VLoss": v_loss.item(),
                 "EntLoss": ent.item(), "PpoBackUpTime": time.time() - t0, "GradNorm": float(gnorm)},

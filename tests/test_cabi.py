@@ -48,11 +48,24 @@ def test_load_and_host_only_calls():
 
 def test_unsupported_configs_fail_loudly():
     lib = _lib.load()
-    cfg = _lib.default_config(max_batch=64, share_cnn_net=1)
     wb = ctypes.c_int64()
-    assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -2
+    for bad in (dict(n_actions=9), dict(in_channels=3)):
+        cfg = _lib.default_config(max_batch=64, **bad)
+        assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -2
+    cfg = _lib.default_config(max_batch=64, share_cnn_net=2)
+    assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -1
     with pytest.raises(_lib.DdrlError):
         _lib.check(-2)
+
+
+def test_shared_prenet_layout():
+    """SHARE_CNN_NET=True: prenet + two linear heads, one Adam group (reference ppo.py:39)."""
+    lib = _lib.load()
+    cfg = _lib.default_config(max_batch=64, share_cnn_net=1)
+    assert abs(cfg.learning_rate - 2e-4) < 1e-9 and cfg.smooth_l1_loss == 0
+    n, na = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(lib.ddrl_param_count(ctypes.byref(cfg), ctypes.byref(n), ctypes.byref(na)))
+    assert n.value == 1684128 + 6 * 512 + 6 + 512 + 1 and na.value == n.value
 
 
 def test_no_gpu_is_an_error_not_a_fallback():

@@ -350,3 +350,152 @@ def test_gradients_ragged_batches_vs_oracle(hp, onet, n):
         assert np.abs(got[name] - want).max() <= 1e-4 * scale + 1e-12, (name, n)
         g64, w64 = got[name].astype(np.float64).ravel(), want.astype(np.float64).ravel()
         assert g64 @ w64 / (np.linalg.norm(g64) * np.linalg.norm(w64) + 1e-300) > 1 - 1e-8, (name, n)
+
+
+# ---- non-default learner modes: SHARE_CNN_NET=True and SMOOTH_L1_LOSS=True ---------------------
+def _views(flat, shared):
+    out, off = {}, 0
+    for name, shape, _ in param_specs(shared=shared):
+        n = int(np.prod(shape))
+        out[name] = flat[off:off + n].reshape(shape)
+        off += n
+    return out
+
+
+def _sequence_check(h, ref, spread, frames, actions, old_logps, advs, rets, fixture, lr_of, shared, bad_frac=0.02):
+    envelope = np.maximum.accumulate(spread, axis=0)
+    for it in range(1, 11):
+        h.ppo_iter(frames, actions, old_logps, advs, rets)
+        h.clip_adam_step()
+        s = h.stats()
+        row = ref[it - 1]
+        got = np.array([s["PpoTotalLoss"], s["ActorLoss"], s["VLoss"], s["EntLoss"]])
+        tol = 10.0 * envelope[it - 1] + 1e-5 * np.abs(row) + 2e-6
+        assert np.all(np.abs(got - row) <= tol), (it, got, row, tol)
+        if it in (1, 10):
+            for name, arr in _views(h.params.cpu().numpy(), shared).items():
+                arr = arr.reshape(-1)
+                lr = lr_of(name)
+                want = fixture["it%d/stride/%s" % (it, name)]
+                gotp = arr[::max(1, arr.size // 257)][:257]
+                bad = np.abs(gotp - want) > 0.05 * lr * it + 1e-6 * np.abs(want)
+                assert bad.sum() <= max(1, bad_frac * bad.size), (name, it, bad.sum(), np.abs(gotp - want).max())
+                assert np.abs(gotp - want).max() <= 2.5 * lr * it
+
+
+@pytest.fixture(scope="module")
+def hp_shared():
+    from ddrl4nav_amd.engine import HotPath
+    h = HotPath(max_batch=512, share_cnn_net=1)
+    assert h.n_params == 1684128 + 6 * 512 + 6 + 513 and h.n_actor == h.n_params
+    h.set_params(flatten(make_weights(0, shared=True)))
+    yield h
+    h.close()
+
+
+def test_shared_prenet_forward_loss_gradients_f10(hp_shared, golden):
+    h = hp_shared
+    g3, g = golden("f3_loss"), golden("f10_shared")
+    frames = dev(g3["frames"])
+    probs, value, _, logp = h.forward(frames, act=dev(g["actions"]))
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(value.cpu().numpy(), g["value"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    ha, hc = h.last_features(64)
+    assert torch.equal(ha, hc)  # one encoder feeds both heads
+    np.testing.assert_allclose(ha.cpu().numpy()[:, :16], g["h"], rtol=1e-5, atol=2e-6)
+    h.ppo_iter(frames, dev(g["actions"]), dev(g["old_logps"]), dev(g["advs"]), dev(g["rets"]))
+    tail = h.grads[h.n_params:h.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail, g["loss4"][1:], rtol=1e-5, atol=1e-6)
+    # total_loss.backward(): value gradient scaled by V_LOSS_THETA, entropy term included
+    net = O.OracleSharedPPO()
+    net.load_weights(make_weights(0, shared=True))
+    t = lambda k: torch.from_numpy(g[k])
+    total, _, _, _ = O.ppo_losses(net, O.frames_to_f32(g3["frames"]), t("actions"), t("old_logps"), t("advs"), t("rets"))
+    total.backward()
+    got = _views(h.grads[:h.n_params].cpu().numpy(), True)
+    for name, p in net.named_parameters():
+        want = p.grad.numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got[name] - want).max() <= 2e-5 * scale, (name, np.abs(got[name] - want).max(), scale)
+        np.testing.assert_allclose(got[name].reshape(-1)[:64], g["ghead/" + name], rtol=0, atol=2e-5 * scale)
+    gn = float(torch.linalg.vector_norm(h.grads[:h.n_params].double()).item())
+    np.testing.assert_allclose(gn, g["gnorm"], rtol=1e-5)
+
+
+def test_shared_prenet_entropy_gradient_is_present(hp_shared, golden):
+    """Property: in the shared mode the entropy term has a gradient (ppo.py:108-112) -- changing
+    ENTROPY_LOSS_THETA must change the actor-head gradient; in the default mode it must not."""
+    from ddrl4nav_amd.engine import HotPath
+    g3, g = golden("f3_loss"), golden("f10_shared")
+    args = (dev(g3["frames"]), dev(g["actions"]), dev(g["old_logps"]), dev(g["advs"]), dev(g["rets"]))
+    outs = []
+    for shared in (1, 0):
+        for theta in (0.05, 0.5):
+            h = HotPath(max_batch=64, share_cnn_net=shared, ent_loss_theta=theta)
+            h.set_params(flatten(make_weights(0, shared=bool(shared))))
+            h.ppo_iter(*args)
+            outs.append(_views(h.grads[:h.n_params].cpu().numpy(), bool(shared))["actor.actor_linear.weight"].copy())
+            h.close()
+    assert np.abs(outs[0] - outs[1]).max() > 1e-4
+    assert np.array_equal(outs[2], outs[3])
+
+
+def test_shared_prenet_learn_sequence_f10(hp_shared, golden):
+    h = hp_shared
+    g3, g = golden("f3_loss"), golden("f10_shared")
+    h.set_params(flatten(make_weights(0, shared=True)))
+    h.reset_optimizer()
+    ref = g["losses"]
+    spread = np.maximum(np.abs(ref - g["losses_f64"]), np.abs(ref - g["losses_f32t8"]))
+    _sequence_check(h, ref, spread, dev(g3["frames"]), dev(g["actions"]), dev(g["old_logps"]), dev(g["advs"]),
+                    dev(g["rets"]), g, lambda name: float(g["learning_rate"]), True)
+
+
+@pytest.mark.parametrize("n", [1, 37, 300])
+def test_shared_prenet_ragged_gradients_vs_oracle(hp_shared, n):
+    rng = np.random.default_rng(900 + n)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    old = (np.full(n, -1.79) + rng.normal(0, 0.3, n)).astype(np.float32)
+    adv = rng.normal(size=n).astype(np.float32)
+    ret = rng.normal(size=n).astype(np.float32)
+    hp_shared.set_params(flatten(make_weights(0, shared=True)))
+    hp_shared.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    net = O.OracleSharedPPO()
+    net.load_weights(make_weights(0, shared=True))
+    t = torch.from_numpy
+    total, al, vl, ent = O.ppo_losses(net, O.frames_to_f32(frames), t(acts), t(old), t(adv), t(ret))
+    total.backward()
+    tail = hp_shared.grads[hp_shared.n_params:hp_shared.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail, [al.item(), vl.item(), ent.item()], rtol=2e-5, atol=2e-6)
+    got = _views(hp_shared.grads[:hp_shared.n_params].cpu().numpy(), True)
+    for name, p in net.named_parameters():
+        want = p.grad.numpy()
+        assert np.abs(got[name] - want).max() <= 1e-4 * np.abs(want).max() + 1e-12, (name, n)
+
+
+def test_smooth_l1_value_loss_f11(golden):
+    from ddrl4nav_amd.engine import HotPath
+    g3, g = golden("f3_loss"), golden("f11_smooth_l1")
+    h = HotPath(max_batch=64, smooth_l1_loss=1)
+    h.set_params(flatten(make_weights(0)))
+    args = (dev(g3["frames"]), dev(g3["actions"]), dev(g3["old_logps"]), dev(g3["advs"]), dev(g["rets"]))
+    h.ppo_iter(*args)
+    tail = h.grads[h.n_params:h.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail, g["loss4"][1:], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(h.debug_buffer(9, (), 64, 0).cpu().numpy(), g["dvalue"], rtol=1e-5, atol=1e-8)
+    got = _views(h.grads[:h.n_params].cpu().numpy(), False)
+    for name in got:
+        scale = max(np.abs(g["ghead/" + name]).max(), g["gl2/" + name] / np.sqrt(got[name].size))
+        np.testing.assert_allclose(got[name].reshape(-1)[:64], g["ghead/" + name], rtol=0, atol=5e-5 * scale)
+        np.testing.assert_allclose(np.sqrt((got[name].astype(np.float64) ** 2).sum()), g["gl2/" + name], rtol=1e-4)
+    h.reset_optimizer()
+    ref = g["losses"]
+    spread = np.abs(ref - g["losses_f64"])
+    lr_of = lambda name: 5e-5 if name.startswith("actor.") else 1e-3
+    # the smooth-L1 gradient is +-1/B for every |ret - v| > 1: many critic-side weight gradients sit
+    # at the fp32 noise floor, where Adam moves an element by O(lr) either way (same effect as in
+    # test_learn_sequence_golden_f4, more elements) -> larger allowance for the strided samples
+    _sequence_check(h, ref, spread, *args, g, lr_of, False, bad_frac=0.10)
+    h.close()

@@ -111,3 +111,51 @@ def test_inverse_cdf_sampler_contract():
     p = np.array([[0.1, 0.2, 0.3, 0.4], [0.25, 0.25, 0.25, 0.25]], np.float32)
     assert list(O.inverse_cdf_sample(p, np.array([0.05, 0.99], np.float32))) == [0, 3]
     assert list(O.inverse_cdf_sample(p, np.array([0.1, 0.5], np.float32))) == [1, 2]
+
+
+# ---- non-default learner modes (tests/golden/make_golden_shared.py) ------------------------------
+def _check_learn(gen, g):
+    it = 0
+    for it, (ld, ut, last) in enumerate(gen, 1):
+        got = [ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]]
+        np.testing.assert_allclose(got, g["losses"][it - 1], rtol=1e-6, atol=1e-7)
+    assert it == 10
+
+
+def test_f10_shared_prenet(golden):
+    g3, g = golden("f3_loss"), golden("f10_shared")
+    torch.set_num_threads(1)
+    w = make_weights(0, shared=True)
+    assert flatten(w).size == 1684128 + 6 * 512 + 6 + 513
+    net = O.OracleSharedPPO()
+    assert [k for k, _ in net.named_parameters()] == [n for n, _, _ in param_specs(shared=True)]
+    net.load_weights(w)
+    x = O.frames_to_f32(g3["frames"])
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        probs, _, logits, v = net(x)
+        assert np.array_equal(probs.numpy(), g["probs"]) and np.array_equal(v.numpy()[:, 0], g["value"])
+        assert np.array_equal(O.categorical_log_prob(logits, t("actions")).numpy(), g["logp"])
+    total, al, vl, ent = O.ppo_losses(net, x, t("actions"), t("old_logps"), t("advs"), t("rets"))
+    np.testing.assert_allclose([total.item(), al.item(), vl.item(), ent.item()], g["loss4"], rtol=1e-7, atol=0)
+    total.backward()
+    for k, p in net.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy().reshape(-1)[:64], g["ghead/" + k], rtol=1e-6, atol=1e-9)
+    net.zero_grad()
+    _check_learn(O.learn(net, net.make_optims(), x, t("actions"), t("old_logps"), t("advs"), t("rets")), g)
+    for k, p in net.named_parameters():
+        arr = p.detach().numpy().reshape(-1)
+        np.testing.assert_allclose(arr[::max(1, arr.size // 257)][:257], g["it10/stride/" + k], rtol=1e-6, atol=2e-8)
+
+
+def test_f11_smooth_l1(golden):
+    g3, g = golden("f3_loss"), golden("f11_smooth_l1")
+    torch.set_num_threads(1)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    x = O.frames_to_f32(g3["frames"])
+    t3 = lambda k: torch.from_numpy(g3[k])
+    rets = torch.from_numpy(g["rets"])
+    total, al, vl, ent = O.ppo_losses(net, x, t3("actions"), t3("old_logps"), t3("advs"), rets, smooth_l1=True)
+    np.testing.assert_allclose([total.item(), al.item(), vl.item(), ent.item()], g["loss4"], rtol=1e-7, atol=0)
+    _check_learn(O.learn(net, net.make_optims(), x, t3("actions"), t3("old_logps"), t3("advs"), rets, smooth_l1=True), g)

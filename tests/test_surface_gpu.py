@@ -246,3 +246,37 @@ def test_redis_message_to_device_pool_via_codec_and_ring(net):
     a, lp, v = eb.decode_data(replies[1])
     assert a.shape == (2,) and v.shape == (1, 2, 1)
     ring.close()
+
+
+def test_create_net_shared_prenet_branch(golden):
+    """SHARE_CNN_NET=True / SMOOTH_L1_LOSS=True through the reference's own surface
+    (runner/utils.py:136-143, ppo.py:110-117): names, forward, learn protocol."""
+    from ddrl4nav_amd.data import Experience
+    from ddrl4nav_amd.runner import create_net
+    cfgs = _configs()
+    cfgs["config_nn"].SHARE_CNN_NET = True
+    n = create_net(cfgs, max_batch=64)
+    names = [k for k, _ in n.named_parameters()]
+    assert names == [k for k, _, _ in param_specs(shared=True)] and list(n.state_dict().keys()) == names
+    assert n.prenet is not None and n.actor.pre is None and n.critic.pre is None and n.share_cnn_net
+    n.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0, shared=True).items()})
+    g3, g = golden("f3_loss"), golden("f10_shared")
+    (dist, logp), values = n([torch.from_numpy(g3["frames"])], torch.from_numpy(g["actions"]))
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(values[0].cpu().numpy()[:, 0], g["value"], rtol=1e-5, atol=1e-6)
+    exp = Experience(states=[g3["frames"]], advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"],
+                     values=g["rets"].reshape(1, -1))
+    exp.to_tensor(dtype=torch.float32, device="cuda")
+    ref = g["losses"]
+    env = np.maximum.accumulate(np.maximum(np.abs(ref - g["losses_f64"]), np.abs(ref - g["losses_f32t8"])), axis=0)
+    seen = 0
+    for loss_items, update_time, last in n.learn(exp):
+        seen += 1
+        got = np.array([loss_items[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
+        assert np.all(np.abs(got - ref[seen - 1]) <= 10.0 * env[seen - 1] + 1e-5 * np.abs(ref[seen - 1]) + 2e-6)
+    assert seen == 10
+    # mismatched prenet / SHARE_CNN_NET combinations are rejected instead of silently ignored
+    from ddrl4nav_amd.nn import PPO
+    cfgs2 = _configs()
+    with pytest.raises(ValueError):
+        PPO(n.actor, n.critic, n.prenet, None, cfgs2["config"], cfgs2["config_nn"], max_batch=8)

@@ -12,4 +12,4 @@ hp.profile(True)
 for _ in range(3): hp.ppo_iter(fr,a,old,adv,ret)
 torch.cuda.synchronize()
 p=hp.profile_read()
-print(sys.argv[1], " ".join("%s %.2f"%(k.replace("Conv",""), v[0]/3) for k,v in sorted(p.items()) if v[0]/3>1))
+print(sys.argv[1], " ".join("%s %.2f"%(k.replace("Conv",""), v[0]/3) for k,v in sorted(p.items()) if v[0]/3>0.3))
