@@ -98,7 +98,7 @@ int32_t ddrl_config_default(ddrl_config* c) {
 static int32_t validate(const ddrl_config* c) {
   if (!c) return DDRL_ERR_INVALID_ARG;
   if (c->max_batch < 1) return DDRL_ERR_INVALID_ARG;
-  if (c->n_actions < 2 || c->n_actions > 8) return DDRL_ERR_UNSUPPORTED;  // heads kernels: A <= 8
+  if (c->n_actions < 2 || c->n_actions > 18) return DDRL_ERR_UNSUPPORTED;  // heads kernels: A <= 18 (full Atari set)
   if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // int_frame_stack = 4
   if (c->share_cnn_net != 0 && c->share_cnn_net != 1) return DDRL_ERR_INVALID_ARG;
   // 32-bit element indexing inside one encoder's activation tensor

@@ -12,7 +12,10 @@
 
 namespace ddrl {
 
-constexpr int MAXA = 8;
+// Two instantiations of the head kernels: A <= 8 keeps the actor head weights and their
+// gradient accumulators in registers; 8 < A <= 18 (the full Atari action set) reads the weights
+// from LDS and leaves the actor-head weight gradient to head_wgrad_kernel.
+constexpr int MAXA_SMALL = 8, MAXA_LARGE = 18;
 constexpr float CAT_EPS = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -21,26 +24,52 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ void load8(const float* p, float* o);
+
+template <int MAXA, bool WLDS>
 struct HeadRegs {
-  float wa[MAXA][8];
+  float wa[WLDS ? 1 : MAXA][8];  // this lane's 8 columns of every actor row (register variant)
+  const float* wl;               // LDS copy [MAXA][512] (LDS variant)
   float wc[8];
   float ba[MAXA];
   float bc;
-};
-
-__device__ __forceinline__ void load_head_weights(HeadRegs& R, const float* params, const ParamLayout& L, int lane) {
-#pragma unroll
-  for (int j = 0; j < MAXA; ++j) {
-    if (j < L.A) {
-      const float4* src = (const float4*)(params + L.actor_w + (int64_t)j * FEAT + lane * 8);
-      const float4 x = src[0], y = src[1];
-      R.wa[j][0] = x.x; R.wa[j][1] = x.y; R.wa[j][2] = x.z; R.wa[j][3] = x.w;
-      R.wa[j][4] = y.x; R.wa[j][5] = y.y; R.wa[j][6] = y.z; R.wa[j][7] = y.w;
-      R.ba[j] = params[L.actor_b + j];
+  // this lane's 8 weights of actor row j
+  __device__ __forceinline__ void row(int j, int lane, float* o) const {
+    if constexpr (WLDS) {
+      load8(wl + j * FEAT + lane * 8, o);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) R.wa[j][i] = 0.0f;
-      R.ba[j] = 0.0f;
+      for (int i = 0; i < 8; ++i) o[i] = wa[j][i];
+    }
+  }
+};
+
+// `wl` = MAXA*512 floats of LDS for the WLDS variant (every thread of the block must call this)
+template <int MAXA, bool WLDS>
+__device__ __forceinline__ void load_head_weights(HeadRegs<MAXA, WLDS>& R, const float* params, const ParamLayout& L,
+                                                  int lane, float* wl) {
+  if constexpr (WLDS) {
+    for (int i = threadIdx.x; i < MAXA * FEAT; i += blockDim.x)
+      wl[i] = (i < L.A * FEAT) ? params[L.actor_w + i] : 0.0f;
+    R.wl = wl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) R.ba[j] = (j < L.A) ? params[L.actor_b + min(j, L.A - 1)] : 0.0f;
+  } else {
+    R.wl = nullptr;
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      if (j < L.A) {
+        const float4* src = (const float4*)(params + L.actor_w + (int64_t)j * FEAT + lane * 8);
+        const float4 x = src[0], y = src[1];
+        R.wa[j][0] = x.x; R.wa[j][1] = x.y; R.wa[j][2] = x.z; R.wa[j][3] = x.w;
+        R.wa[j][4] = y.x; R.wa[j][5] = y.y; R.wa[j][6] = y.z; R.wa[j][7] = y.w;
+        R.ba[j] = params[L.actor_b + j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) R.wa[j][i] = 0.0f;
+        R.ba[j] = 0.0f;
+      }
     }
   }
   // the flat arena is only 4-byte aligned at critic_w in general -> scalar loads
@@ -59,6 +88,7 @@ __device__ __forceinline__ void store8(float* p, const float* o) {
   ((float4*)p)[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+template <int MAXA>
 struct Dist {
   float p[MAXA];    // softmax output
   float q[MAXA];    // p / sum(p)                      (Categorical.probs)
@@ -66,7 +96,8 @@ struct Dist {
   float ps;
 };
 
-__device__ __forceinline__ void softmax_categorical(const float* z, int A, Dist& d) {
+template <int MAXA>
+__device__ __forceinline__ void softmax_categorical(const float* z, int A, Dist<MAXA>& d) {
   float m = z[0];
 #pragma unroll
   for (int j = 1; j < MAXA; ++j)
@@ -90,7 +121,8 @@ __device__ __forceinline__ void softmax_categorical(const float* z, int A, Dist&
   }
 }
 
-__device__ __forceinline__ float pick(const float* a, int idx) {
+template <int MAXA>
+__device__ __forceinline__ float pick(const float (&a)[MAXA], int idx) {
   float r = a[0];
 #pragma unroll
   for (int j = 1; j < MAXA; ++j) r = (idx == j) ? a[j] : r;
@@ -103,6 +135,7 @@ __device__ __forceinline__ float pick(const float* a, int idx) {
 // When fc_nsplit > 0 the encoder outputs arrive as split-K partial sums of the FC layer,
 // fc_part[s][e][n][512] without bias (small-batch acting path, fc2.hip); they are summed here in
 // split order, the linear bias is added and the finished h is written back to `h`.
+template <int MAXA, bool WLDS>
 __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, int64_t h_es,
                                                         const float* __restrict__ fc_part, int fc_nsplit,
                                                         const float* __restrict__ params, ParamLayout L, int n,
@@ -113,8 +146,9 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
   const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
-  HeadRegs R;
-  load_head_weights(R, params, L, lane);
+  __shared__ float wl[WLDS ? MAXA * FEAT : 1];
+  HeadRegs<MAXA, WLDS> R;
+  load_head_weights(R, params, L, lane, wl);
   const int ec = L.NE - 1;  // encoder feeding the critic head (0 when the prenet is shared)
   for (int b = gw; b < n; b += nw) {
     float ha[8], hc[8];
@@ -148,16 +182,17 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
     float z[MAXA];
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
-      float s = 0.0f;
+      float s = 0.0f, w[8];
+      R.row(j, lane, w);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], R.wa[j][i], s);
+      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], w[i], s);
       z[j] = wave_sum(s) + R.ba[j];
     }
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
     const float v = wave_sum(sv) + R.bc;
-    Dist d;
+    Dist<MAXA> d;
     softmax_categorical(z, L.A, d);
     int a;
     if (act_in != nullptr) {
@@ -191,6 +226,9 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
 // training: loss terms, d(loss)/d(logits, value), backward of both head layers
 // hpart layout per workgroup: [A*512 dWa][512 dwc][A dba][1 dbc][actor_sum, v_sum, ent_sum]
 // --------------------------------------------------------------------------------------------
+// WLDS (A > 8): the actor-head weight / bias gradient slots of hpart are written by
+// head_wgrad_kernel from dlogits instead (288 accumulator + weight registers do not fit a lane).
+template <int MAXA, bool WLDS>
 __global__ __launch_bounds__(256) void heads_loss_kernel(
     const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
     const float* __restrict__ actions, const float* __restrict__ old_logps, const float* __restrict__ advs,
@@ -201,11 +239,12 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
   const int gw = blockIdx.x * 4 + wave;
   const int nw = gridDim.x * 4;
   const int A = L.A;
-  HeadRegs R;
-  load_head_weights(R, params, L, lane);
-  float gwa[MAXA][8], gwc[8], gba[MAXA], gbc = 0.0f;
+  HeadRegs<MAXA, WLDS> R;
+  load_head_weights(R, params, L, lane, red);  // LDS weights alias the reduction buffer (used after the loop)
+  constexpr int GA = WLDS ? 1 : MAXA;
+  float gwa[GA][8], gwc[8], gba[GA], gbc = 0.0f;
 #pragma unroll
-  for (int j = 0; j < MAXA; ++j) {
+  for (int j = 0; j < GA; ++j) {
     gba[j] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) gwa[j][i] = 0.0f;
@@ -228,16 +267,17 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
     float z[MAXA];
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
-      float s = 0.0f;
+      float s = 0.0f, w[8];
+      R.row(j, lane, w);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], R.wa[j][i], s);
+      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], w[i], s);
       z[j] = wave_sum(s) + R.ba[j];
     }
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
     const float v = wave_sum(sv) + R.bc;
-    Dist d;
+    Dist<MAXA> d;
     softmax_categorical(z, A, d);
     const int a = (int)actions[b];
     const float adv = advs[b];
@@ -311,19 +351,26 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
     // ---- head layers backward ----
     float da[8], dc[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float s = 0.0f;
+    for (int i = 0; i < 8; ++i) da[i] = 0.0f;
 #pragma unroll
-      for (int j = 0; j < MAXA; ++j) s = __builtin_fmaf(gz[j], R.wa[j][i], s);
-      da[i] = s;
+    for (int j = 0; j < MAXA; ++j) {  // per element the same j-ordered fma chain as sum_j gz[j] * Wa[j][i]
+      float w[8];
+      R.row(j, lane, w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) da[i] = __builtin_fmaf(gz[j], w[i], da[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
       dc[i] = gv * R.wc[i];
       gwc[i] = __builtin_fmaf(gv, hc[i], gwc[i]);
     }
+    if constexpr (!WLDS) {
 #pragma unroll
-    for (int j = 0; j < MAXA; ++j) {
-      gba[j] += gz[j];
+      for (int j = 0; j < MAXA; ++j) {
+        gba[j] += gz[j];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) gwa[j][i] = __builtin_fmaf(gz[j], ha[i], gwa[j][i]);
+        for (int i = 0; i < 8; ++i) gwa[j][i] = __builtin_fmaf(gz[j], ha[i], gwa[j][i]);
+      }
     }
     gbc += gv;
     if (shared) {
@@ -340,24 +387,29 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
 
   // ---- workgroup reduction, waves accumulate in turn (fixed order) -> hpart[blockIdx.x] ----
   constexpr int SCAL = (MAXA + 1) * FEAT;
+  if constexpr (WLDS) __syncthreads();  // every wave is done with the LDS weights aliased by `red`
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
       const bool first = (w == 0);
+      if constexpr (!WLDS) {
 #pragma unroll
-      for (int j = 0; j < MAXA; ++j)
+        for (int j = 0; j < MAXA; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int idx = j * FEAT + lane * 8 + i;
-          red[idx] = first ? gwa[j][i] : red[idx] + gwa[j][i];
-        }
+          for (int i = 0; i < 8; ++i) {
+            const int idx = j * FEAT + lane * 8 + i;
+            red[idx] = first ? gwa[j][i] : red[idx] + gwa[j][i];
+          }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = MAXA * FEAT + lane * 8 + i;
         red[idx] = first ? gwc[i] : red[idx] + gwc[i];
       }
       if (lane == 0) {
+        if constexpr (!WLDS) {
 #pragma unroll
-        for (int j = 0; j < MAXA; ++j) red[SCAL + j] = first ? gba[j] : red[SCAL + j] + gba[j];
+          for (int j = 0; j < MAXA; ++j) red[SCAL + j] = first ? gba[j] : red[SCAL + j] + gba[j];
+        }
         red[SCAL + MAXA] = first ? gbc : red[SCAL + MAXA] + gbc;
         red[SCAL + MAXA + 1] = first ? (float)s_actor : red[SCAL + MAXA + 1] + (float)s_actor;
         red[SCAL + MAXA + 2] = first ? (float)s_v : red[SCAL + MAXA + 2] + (float)s_v;
@@ -367,11 +419,44 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
     __syncthreads();
   }
   float* out = hpart + (int64_t)blockIdx.x * hstride;
-  for (int i = threadIdx.x; i < A * FEAT; i += 256) out[i] = red[i];
+  if constexpr (!WLDS) {
+    for (int i = threadIdx.x; i < A * FEAT; i += 256) out[i] = red[i];
+    if (threadIdx.x < A) out[(A + 1) * FEAT + threadIdx.x] = red[SCAL + threadIdx.x];
+  }
   for (int i = threadIdx.x; i < FEAT; i += 256) out[A * FEAT + i] = red[MAXA * FEAT + i];
-  if (threadIdx.x < A) out[(A + 1) * FEAT + threadIdx.x] = red[SCAL + threadIdx.x];
   if (threadIdx.x == 0) out[(A + 1) * FEAT + A] = red[SCAL + MAXA];
   if (threadIdx.x < 3) out[(A + 1) * FEAT + A + 1 + threadIdx.x] = red[SCAL + MAXA + 1 + threadIdx.x];
+}
+
+// Actor-head weight / bias gradient for A > 8, from the dlogits heads_loss_kernel left behind:
+//   hpart[wg][j*512 + k] = sum_{b in the workgroup's samples} dlogits[b][j] * h_actor[b][k],  [A*512+512 + j] = sum dlogits[b][j]
+// (samples are dealt to workgroups round-robin; fixed order -> deterministic).
+template <int MAXA>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ h, const float* __restrict__ dlogits,
+                                                         int n, int A, float* __restrict__ hpart, int64_t hstride) {
+  float acc[MAXA][2], bsum[MAXA];
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) acc[j][0] = acc[j][1] = bsum[j] = 0.0f;
+  const int k = threadIdx.x;
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    const float h0 = h[(int64_t)b * FEAT + k], h1 = h[(int64_t)b * FEAT + 256 + k];
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) {
+      const float g = (j < A) ? dlogits[(int64_t)b * A + min(j, A - 1)] : 0.0f;
+      acc[j][0] = __builtin_fmaf(g, h0, acc[j][0]);
+      acc[j][1] = __builtin_fmaf(g, h1, acc[j][1]);
+      bsum[j] += g;
+    }
+  }
+  float* out = hpart + (int64_t)blockIdx.x * hstride;
+#pragma unroll
+  for (int j = 0; j < MAXA; ++j) {
+    if (j < A) {
+      out[j * FEAT + k] = acc[j][0];
+      out[j * FEAT + 256 + k] = acc[j][1];
+      if (threadIdx.x == 0) out[(A + 1) * FEAT + j] = bsum[j];
+    }
+  }
 }
 
 // grads[head params] = sum over workgroups (fixed order); grads[n_params+0..2] = loss shares
@@ -458,7 +543,8 @@ void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, ui
   int wgs = (c.n + 3) / 4;
   if (wgs > 1024) wgs = 1024;
   const int nsplit = fc_forward_splits(c.n);
-  hipLaunchKernelGGL(heads_act_kernel, dim3(wgs), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT,
+  auto kern = c.L->A <= MAXA_SMALL ? heads_act_kernel<MAXA_SMALL, false> : heads_act_kernel<MAXA_LARGE, true>;
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT,
                      nsplit > 1 ? c.ws->wpart : nullptr, nsplit > 1 ? nsplit : 0, c.params, *c.L, c.n,
                      act_in, seed, stream_id, probs, value, action_out, logp_out);
 }
@@ -466,9 +552,14 @@ void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, ui
 void launch_heads_loss(const HeadsCall& c, const float* actions, const float* old_logps, const float* advs,
                        const float* rets, float inv_b, float* grads, hipStream_t st) {
   const int64_t hs = hpart_stride(c.L->A);
-  hipLaunchKernelGGL(heads_loss_kernel, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT, c.params, *c.L,
+  const bool large = c.L->A > MAXA_SMALL;
+  auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : heads_loss_kernel<MAXA_SMALL, false>;
+  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.max_batch * FEAT, c.params, *c.L,
                      *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh, c.max_batch * FEAT, c.ws->dlogits,
                      c.ws->dvalue, c.ws->hpart, hs);
+  if (large)
+    hipLaunchKernelGGL(head_wgrad_kernel<MAXA_LARGE>, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.ws->dlogits, c.n,
+                       c.L->A, c.ws->hpart, hs);
   const int total = (c.L->A + 1) * FEAT + c.L->A + 1 + 3;
   hipLaunchKernelGGL(heads_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, c.ws->hpart, hs, HEAD_WG, *c.L,
                      *c.cfg, inv_b, grads);

@@ -5,6 +5,7 @@
                      (LEARNING_RATE) on total_loss (reference nn/ppo.py:39,110-117,
                      runner/utils.py:136-143)
   f11_smooth_l1.npz  SMOOTH_L1_LOSS=True on the default two-encoder net (ppo.py:53-54)
+  f12_actions18.npz  ACTION_OUTPUT_DIM=18 (the full Atari action set) on the default net
 
 Inputs are the frames of f3_loss.npz (stored once, there).  Runs only in the build container
 (needs /root/reference); nothing of the reference is copied, only its outputs are stored.
@@ -196,7 +197,63 @@ def main():
     net2.critic_optim = torch.optim.Adam(net2.critic.parameters(), cfg_nn2.CRITIC_LEARNING_RATE)
     out2["losses_f64"] = run_learn(net2, make_exp2(torch.float64), {}, False)
     np.savez(os.path.join(HERE, "f11_smooth_l1.npz"), **out2)
-    for f in ("f10_shared.npz", "f11_smooth_l1.npz"):
+    # ---------------- F12: 18 actions (full Atari action set), default two-encoder net --------
+    from USTC_lab.nn import AtariPreNet, CategoricalActor, Critic, PPO
+    from ddrl4nav_amd.utils.recipe import param_specs
+    cfg, cfg_nn3 = _cfg()
+    w18 = make_weights(seed=0, n_actions=18)
+    actor = CategoricalActor(action_output_dim=18, device="cpu", soft_max_grid=True, last_input_dim=512,
+                             pre=AtariPreNet(4, last_output_dim=512, device="cpu"), nn_dtype=torch.float32)
+    critic = Critic(device="cpu", last_input_dim=512, pre=AtariPreNet(4, last_output_dim=512, device="cpu"))
+    net3 = PPO(actor, critic, None, None, cfg, cfg_nn3).to("cpu")
+    assert [k for k, _ in net3.named_parameters()] == [n for n, _, _ in param_specs(n_actions=18)]
+    net3.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w18.items()}, strict=True)
+    rng = np.random.default_rng(12)
+    with torch.no_grad():
+        (dist, _), values = net3([xb])
+        torch.manual_seed(13)
+        act18 = dist.sample().to(torch.float32)
+        act18[:18] = torch.arange(18, dtype=torch.float32)  # every action index occurs
+        old18 = net3.actor.log_prob_from_distribution(dist, act18)
+        probs18, _ = net3.actor([xb], None, True)
+        ent18 = dist.entropy()
+    old18 = (old18 + torch.from_numpy(rng.normal(0, 0.25, B).astype(np.float32))).contiguous()
+    adv18 = torch.from_numpy(rng.normal(0, 1, B).astype(np.float32))
+    ret18 = (values[0][:, 0] + adv18).contiguous()
+    exp3 = Experience(states=[xb.numpy()], advs=adv18.numpy(), actions=act18.numpy(), old_logps=old18.numpy(),
+                      values=ret18.numpy().reshape(1, B))
+    exp3.to_tensor(dtype=torch.float32, device="cpu")
+    out3 = {"actions": act18.numpy(), "old_logps": old18.numpy(), "advs": adv18.numpy(), "rets": ret18.numpy(),
+            "probs": probs18.numpy(), "value": values[0].numpy()[:, 0], "entropy": ent18.numpy()}
+    with torch.no_grad():
+        (_, lp), _ = net3([xb], act18)
+    out3["logp"] = lp.numpy()
+    net3.zero_grad()
+    total, actor_loss, v_loss, ent, _ = loss_terms(net3, exp3)
+    actor_loss.backward()
+    v_loss.backward()
+    out3["loss4"] = np.array([total.item(), actor_loss.item(), v_loss.item(), ent.item()], np.float64)
+    grad_summary(net3, out3)
+    out3["grad_actor_linear_w"] = net3.actor.actor_linear.weight.grad.numpy().copy()
+    out3["grad_actor_linear_b"] = net3.actor.actor_linear.bias.grad.numpy().copy()
+    net3.zero_grad()
+    out3["losses"] = run_learn(net3, exp3, out3, False)
+    # the reference's own sensitivity to summation order (see make_golden.py, F4)
+    for tag, dtype, threads in (("f64", torch.float64, 1), ("f32t8", torch.float32, 8)):
+        torch.set_num_threads(threads)
+        net3.to(torch.float32)
+        net3.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w18.items()}, strict=True)
+        net3.to(dtype)
+        net3.update_time = 0
+        net3.actor_optim = torch.optim.Adam(net3.actor.parameters(), cfg_nn3.ACTOR_LEARNING_RATE)
+        net3.critic_optim = torch.optim.Adam(net3.critic.parameters(), cfg_nn3.CRITIC_LEARNING_RATE)
+        e = Experience(states=[xb.numpy()], advs=adv18.numpy(), actions=act18.numpy(), old_logps=old18.numpy(),
+                       values=ret18.numpy().reshape(1, B))
+        e.to_tensor(dtype=dtype, device="cpu")
+        out3["losses_" + tag] = run_learn(net3, e, {}, False)
+    torch.set_num_threads(1)
+    np.savez(os.path.join(HERE, "f12_actions18.npz"), **out3)
+    for f in ("f10_shared.npz", "f11_smooth_l1.npz", "f12_actions18.npz"):
         print("  %-20s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))
 
 

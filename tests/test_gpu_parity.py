@@ -499,3 +499,91 @@ def test_smooth_l1_value_loss_f11(golden):
     # test_learn_sequence_golden_f4, more elements) -> larger allowance for the strided samples
     _sequence_check(h, ref, spread, *args, g, lr_of, False, bad_frac=0.10)
     h.close()
+
+
+# ---- more than 8 actions: LDS-weight head kernels + head_wgrad (full Atari action set = 18) ----
+def _views_a(flat, n_actions):
+    out, off = {}, 0
+    for name, shape, _ in param_specs(n_actions=n_actions):
+        n = int(np.prod(shape))
+        out[name] = flat[off:off + n].reshape(shape)
+        off += n
+    return out
+
+
+def test_eighteen_actions_golden_f12(golden):
+    from ddrl4nav_amd.engine import HotPath
+    g3, g = golden("f3_loss"), golden("f12_actions18")
+    h = HotPath(max_batch=64, n_actions=18)
+    h.set_params(flatten(make_weights(0, n_actions=18), n_actions=18))
+    frames = dev(g3["frames"])
+    probs, value, _, logp = h.forward(frames, act=dev(g["actions"]))
+    assert probs.shape == (64, 18)
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(value.cpu().numpy(), g["value"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    _, _, ent = h.categorical_stats(probs)
+    np.testing.assert_allclose(ent.cpu().numpy(), g["entropy"], rtol=1e-5, atol=1e-6)
+    h.ppo_iter(frames, dev(g["actions"]), dev(g["old_logps"]), dev(g["advs"]), dev(g["rets"]))
+    tail = h.grads[h.n_params:h.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail, g["loss4"][1:], rtol=1e-5, atol=1e-6)
+    got = _views_a(h.grads[:h.n_params].cpu().numpy(), 18)
+    for key, name in (("grad_actor_linear_w", "actor.actor_linear.weight"), ("grad_actor_linear_b", "actor.actor_linear.bias")):
+        scale = np.abs(g[key]).max()
+        assert np.abs(got[name] - g[key]).max() <= 2e-5 * scale, name
+    for name in got:
+        np.testing.assert_allclose(np.sqrt((got[name].astype(np.float64) ** 2).sum()), g["gl2/" + name], rtol=2e-5)
+        scale = np.abs(got[name]).max()
+        np.testing.assert_allclose(got[name].reshape(-1)[:64], g["ghead/" + name], rtol=0, atol=2e-5 * scale)
+    # 10 Adam steps follow the reference's loss trajectory within 10x the reference's own spread
+    # under a changed summation order (float64 / 8-thread runs stored in the fixture)
+    h.reset_optimizer()
+    ref = g["losses"]
+    env = np.maximum.accumulate(np.maximum(np.abs(ref - g["losses_f64"]), np.abs(ref - g["losses_f32t8"])), axis=0)
+    for it in range(1, 11):
+        h.ppo_iter(frames, dev(g["actions"]), dev(g["old_logps"]), dev(g["advs"]), dev(g["rets"]))
+        h.clip_adam_step()
+        s = h.stats()
+        got4 = np.array([s["PpoTotalLoss"], s["ActorLoss"], s["VLoss"], s["EntLoss"]])
+        tol = 10.0 * env[it - 1] + 1e-5 * np.abs(ref[it - 1]) + 2e-6
+        assert np.all(np.abs(got4 - ref[it - 1]) <= tol), (it, got4, ref[it - 1], tol)
+    h.close()
+
+
+@pytest.mark.parametrize("A", [2, 9, 13, 18])
+def test_action_counts_vs_oracle(A):
+    from ddrl4nav_amd.engine import HotPath
+    n = 70
+    rng = np.random.default_rng(1200 + A)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, A, size=n).astype(np.float32)
+    old = (np.full(n, -np.log(A)) + rng.normal(0, 0.3, n)).astype(np.float32)
+    adv = rng.normal(size=n).astype(np.float32)
+    ret = rng.normal(size=n).astype(np.float32)
+    w = make_weights(3, n_actions=A)
+    h = HotPath(max_batch=n, n_actions=A)
+    h.set_params(flatten(w, n_actions=A))
+    net = O.OraclePPO(n_actions=A)
+    net.load_weights(w)
+    t = torch.from_numpy
+    probs, value, _, logp = h.forward(dev(frames), act=dev(acts))
+    with torch.no_grad():
+        oprobs, op_hat, ologits, ov = net(O.frames_to_f32(frames))
+    np.testing.assert_allclose(probs.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), O.categorical_log_prob(ologits, t(acts)).numpy(), rtol=1e-5, atol=1e-6)
+    # sampler contract: inverse CDF over p_hat with the shared counter-based uniforms
+    p2, _, action, lp2 = h.forward(dev(frames), act=None, seed=99, stream_id=5)
+    p_hat, logits, _ = h.categorical_stats(p2)
+    want = O.inverse_cdf_sample(p_hat.cpu().numpy(), hash_uniform(99, 5, n))
+    assert np.array_equal(action.cpu().numpy(), want.astype(np.float32))
+    h.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    _, al, vl, ent = O.ppo_losses(net, O.frames_to_f32(frames), t(acts), t(old), t(adv), t(ret))
+    al.backward()
+    vl.backward()
+    tail = h.grads[h.n_params:h.n_params + 3].cpu().numpy()
+    np.testing.assert_allclose(tail, [al.item(), vl.item(), ent.item()], rtol=2e-5, atol=2e-6)
+    got = _views_a(h.grads[:h.n_params].cpu().numpy(), A)
+    for name, p in net.named_parameters():
+        want_g = p.grad.numpy()
+        assert np.abs(got[name] - want_g).max() <= 5e-5 * np.abs(want_g).max() + 1e-12, (name, A)
+    h.close()

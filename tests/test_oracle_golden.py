@@ -159,3 +159,24 @@ def test_f11_smooth_l1(golden):
     total, al, vl, ent = O.ppo_losses(net, x, t3("actions"), t3("old_logps"), t3("advs"), rets, smooth_l1=True)
     np.testing.assert_allclose([total.item(), al.item(), vl.item(), ent.item()], g["loss4"], rtol=1e-7, atol=0)
     _check_learn(O.learn(net, net.make_optims(), x, t3("actions"), t3("old_logps"), t3("advs"), rets, smooth_l1=True), g)
+
+
+def test_f12_eighteen_actions(golden):
+    g3, g = golden("f3_loss"), golden("f12_actions18")
+    torch.set_num_threads(1)
+    net = O.OraclePPO(n_actions=18)
+    net.load_weights(make_weights(0, n_actions=18))
+    x = O.frames_to_f32(g3["frames"])
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        probs, p_hat, logits, v = net(x)
+    assert np.array_equal(probs.numpy(), g["probs"]) and np.array_equal(v.numpy()[:, 0], g["value"])
+    assert np.array_equal(O.categorical_log_prob(logits, t("actions")).numpy(), g["logp"])
+    assert np.array_equal(O.categorical_entropy(p_hat, logits).numpy(), g["entropy"])
+    total, al, vl, ent = O.ppo_losses(net, x, t("actions"), t("old_logps"), t("advs"), t("rets"))
+    np.testing.assert_allclose([total.item(), al.item(), vl.item(), ent.item()], g["loss4"], rtol=1e-7, atol=0)
+    al.backward()
+    vl.backward()
+    assert np.array_equal(net.actor.actor_linear.weight.grad.numpy(), g["grad_actor_linear_w"])
+    net.zero_grad()
+    _check_learn(O.learn(net, net.make_optims(), x, t("actions"), t("old_logps"), t("advs"), t("rets")), g)
