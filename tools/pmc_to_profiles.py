@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 --pmc pass CSVs written by tools/prof_pmc.sh into the two files kept under
+profiles/:
+
+  <tag>_pmc_per_kernel.csv   per-kernel averages of every counter + average duration (us)
+  <tag>_pmc_traffic.json     per-kernel HBM bytes per launch, MFMA-busy fraction, held clock;
+                             bench.py copies the dominant kernel's entry into roofline.traffic
+
+Usage: python tools/pmc_to_profiles.py gpurun_out/pmc profiles/r01_v4
+
+Counter conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are
+in KB (x1024 here) and come from separate passes; FETCH_SIZE counts 16-byte-per-lane streams at
+half their bytes on gfx950 (noted, not "corrected" per kernel because the kernels mix access
+widths); GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+SIMDS = 1024  # 256 CUs x 4
+
+
+def short(k):
+    m = re.search(r"engine2_kernel<ddrl::(\w+?)(?:v2|2)?(?:<(\d)>)?\s*>", k)
+    if m:
+        return m.group(1) + ("" if not m.group(2) or m.group(2) == "2" else ".ne" + m.group(2))
+    m = re.search(r"ddrl::(\w+?)(?:_kernel)?(?:<[^>]*>)?\(", k)
+    return m.group(1) if m else None
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+    tag = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc"
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    dur = defaultdict(lambda: [0.0, 0])
+    seen = set()
+    for f in sorted(glob.glob(os.path.join(src, "*counter_collection.csv"))):
+        for row in csv.DictReader(open(f)):
+            name = short(row["Kernel_Name"])
+            if name is None:
+                continue
+            # acting-size launches of the forward kernels (small grids) are kept apart from the
+            # training-size ones; every other kernel only runs in training (or is size-independent)
+            big = ("Fwd" not in name and name != "heads_act") or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000
+            key = name + ("" if big else ":acting")
+            c = agg[key][row["Counter_Name"]]
+            c[0] += float(row["Counter_Value"])
+            c[1] += 1
+            did = (f, row["Dispatch_Id"])
+            if did not in seen:
+                seen.add(did)
+                dur[key][0] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0
+                dur[key][1] += 1
+    counters = sorted({c for k in agg for c in agg[k]})
+    with open(tag + "_pmc_per_kernel.csv", "w") as out:
+        out.write("kernel,avg_us," + ",".join(counters) + "\n")
+        for k in sorted(agg):
+            vals = ["%.6g" % (agg[k][c][0] / max(1, agg[k][c][1])) if c in agg[k] else "" for c in counters]
+            out.write("%s,%.1f,%s\n" % (k, dur[k][0] / max(1, dur[k][1]), ",".join(vals)))
+    traffic = {"kernels": {}, "source": "tools/prof_pmc.sh -> tools/pmc_to_profiles.py; one PMC pass per counter group"}
+    for k in sorted(agg):
+        a = {c: agg[k][c][0] / max(1, agg[k][c][1]) for c in agg[k]}
+        if "FETCH_SIZE" not in a or "WRITE_SIZE" not in a:
+            continue
+        us = dur[k][0] / max(1, dur[k][1])
+        e = {"avg_us": round(us, 1), "fetch_bytes": a["FETCH_SIZE"] * 1024.0, "write_bytes": a["WRITE_SIZE"] * 1024.0,
+             "hbm_bytes": (a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024.0,
+             "fetch_note": "FETCH_SIZE as reported; 16-B-per-lane streams are counted at half their bytes on gfx950 "
+                           "(MI355X_MICROARCH.md)"}
+        if "GRBM_GUI_ACTIVE" in a and us > 0:
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0  # summed over 8 XCDs
+            e["clock_ghz"] = round(cyc / (us * 1000.0), 3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in a and cyc > 0:
+                # the counter ticks once per busy cycle per SIMD -> busy fraction = sum / (SIMDs x cycles)
+                e["mfma_busy_frac"] = round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 4)
+        traffic["kernels"][k] = e
+    with open(tag + "_pmc_traffic.json", "w") as out:
+        json.dump(traffic, out, indent=1, sort_keys=True)
+    print("wrote", tag + "_pmc_per_kernel.csv", tag + "_pmc_traffic.json", "(%d kernels)" % len(agg))
+
+
+if __name__ == "__main__":
+    main()
