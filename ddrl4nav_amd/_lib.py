@@ -36,6 +36,13 @@ class EbMsg(Structure):
                 ("payload_len", c_int64)]
 
 
+class ConvDesc(Structure):
+    """ddrl_conv_desc (include/ddrl.h)."""
+    _fields_ = [("n", c_int32), ("cin", c_int32), ("h", c_int32), ("w", c_int32), ("cout", c_int32), ("kh", c_int32),
+                ("kw", c_int32), ("stride", c_int32), ("pad_h", c_int32), ("pad_w", c_int32), ("in_sn", c_int64),
+                ("out_sn", c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/ddrl.h declares
 SIGNATURES = {
     "ddrl_abi_version": (c_int32, []),
@@ -83,6 +90,24 @@ SIGNATURES = {
     "ddrl_timer_elapsed_ms": (c_int32, [c_void_p, POINTER(c_float)]),
     "ddrl_profile_enable": (c_int32, [c_void_p, c_int32]),
     "ddrl_profile_read": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, POINTER(c_int32)]),
+    "ddrl_op_conv_out_shape": (c_int32, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
+    "ddrl_op_conv_pack_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
+    "ddrl_op_conv_pack": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_forward": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_conv_dgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_ws_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
+    "ddrl_op_conv_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_maxpool2_forward": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_maxpool2_relu_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_linear_pack_floats": (c_int32, [c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
+    "ddrl_op_linear_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_linear_forward": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
+                                         c_int32, c_int32, c_void_p]),
+    "ddrl_op_linear_dgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
+                                       c_int32, c_void_p]),
+    "ddrl_op_linear_ws_floats": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_int64)]),
+    "ddrl_op_linear_wgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                       c_int32, c_void_p]),
 }
 
 _lib = None

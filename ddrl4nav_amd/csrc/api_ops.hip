@@ -1,0 +1,160 @@
+// extern "C" operator-level entry points (include/ddrl.h, "ddrl_op_*"): generic convolution,
+// max-pool, dense layer, Gaussian / categorical heads on caller-owned buffers and a stand-alone
+// clip + Adam step.  The Python host composes the non-Atari encoders of the reference from them
+// (ddrl4nav_amd/nn/generic.py), mirroring USTC_lab/nn/nav_encoder.py and mlp_encoder.py.
+#include "kernels.h"
+#include "ops.h"
+
+using namespace ddrl;
+
+static int32_t op_check() { return hipGetLastError() == hipSuccess ? DDRL_OK : DDRL_ERR_HIP; }
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static bool fill_geom(const ddrl_conv_desc* d, ConvGeom& g) {
+  if (!d) return false;
+  g.n = d->n; g.cin = d->cin; g.h = d->h; g.w = d->w; g.cout = d->cout; g.kh = d->kh; g.kw = d->kw;
+  g.stride = d->stride; g.pad_h = d->pad_h; g.pad_w = d->pad_w;
+  if (!conv_geom_fill(g)) return false;
+  g.in_sn = d->in_sn > 0 ? d->in_sn : (int64_t)g.cin * g.h * g.w;
+  g.out_sn = d->out_sn > 0 ? d->out_sn : (int64_t)g.cout * g.oh * g.ow;
+  return true;
+}
+
+struct PackView {
+  int64_t off[5], total;
+};
+static PackView pack_view(const ConvGeom& g) {
+  int64_t sz[5];
+  conv_pack_sizes(g, sz);
+  PackView v;
+  int64_t o = 0;
+  for (int i = 0; i < 5; ++i) {
+    v.off[i] = o;
+    o += align_up(sz[i], 64);
+  }
+  v.total = o;
+  return v;
+}
+
+extern "C" {
+
+int32_t ddrl_op_conv_out_shape(const ddrl_conv_desc* d, int32_t* oh, int32_t* ow) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !oh || !ow) return DDRL_ERR_INVALID_ARG;
+  *oh = g.oh;
+  *ow = g.ow;
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_conv_pack_floats(const ddrl_conv_desc* d, int64_t* floats) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !floats) return DDRL_ERR_INVALID_ARG;
+  *floats = pack_view(g).total;
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed, void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !w || !packed || !aligned16(packed)) return DDRL_ERR_INVALID_ARG;
+  const PackView v = pack_view(g);
+  launch_conv_pack(g, w, packed + v.off[0], (int2*)(packed + v.off[1]), packed + v.off[2], (int2*)(packed + v.off[3]),
+                   (int*)(packed + v.off[4]), (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !floats) return DDRL_ERR_INVALID_ARG;
+  *floats = (int64_t)conv_wgrad_splits(g) * ((int64_t)g.cout * g.cin * g.kh * g.kw + g.cout);
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, int32_t act,
+                             float* out, void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
+  const PackView v = pack_view(g);
+  launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;
+  const PackView v = pack_view(g);
+  launch_conv_dgrad(g, dz, packed + v.off[2], (const int2*)(packed + v.off[3]), din, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float* dz, const float* packed, float* ws,
+                           float* dw, float* db, void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !in || !dz || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
+  if (g.oh * g.ow < 32) return DDRL_ERR_UNSUPPORTED;
+  const PackView v = pack_view(g);
+  launch_conv_wgrad(g, in, dz, (const int*)(packed + v.off[4]), ws, dw, db, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_maxpool2_forward(const float* in, int64_t planes, int32_t h, int32_t w, float* out, void* stream) {
+  if (!in || !out || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return DDRL_ERR_INVALID_ARG;
+  launch_maxpool2_fwd(in, planes, h, w, out, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_maxpool2_relu_backward(const float* a, const float* dpool, int64_t planes, int32_t h, int32_t w, float* dz,
+                                       void* stream) {
+  if (!a || !dpool || !dz || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return DDRL_ERR_INVALID_ARG;
+  launch_maxpool2_relu_bwd(a, dpool, planes, h, w, dz, (hipStream_t)stream);
+  return op_check();
+}
+
+// ---- dense layer --------------------------------------------------------------------------------
+static bool lin_ok(int32_t n, int32_t K, int32_t N) { return n >= 1 && K >= 1 && N >= 4 && (N & 3) == 0; }
+
+int32_t ddrl_op_linear_pack_floats(int32_t K, int32_t N, int64_t* wt_floats, int64_t* wn_floats) {
+  if (!lin_ok(1, K, N) || !wt_floats || !wn_floats) return DDRL_ERR_INVALID_ARG;
+  *wt_floats = (int64_t)((K + 31) / 32 * 32) * N;
+  *wn_floats = (int64_t)N * ((K + 3) / 4 * 4);
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, float* wn, void* stream) {
+  if (!lin_ok(1, K, N) || !w || !wt || !wn || !aligned16(wt) || !aligned16(wn)) return DDRL_ERR_INVALID_ARG;
+  launch_linear_pack(w, K, N, wt, wn, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act, float* out,
+                               int64_t ld_out, int32_t n, int32_t K, int32_t N, void* stream) {
+  if (!lin_ok(n, K, N) || !in || !wt || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
+  if ((ld_in & 3) || ld_in < (K + 3) / 4 * 4 || ld_out < N || !aligned16(in) || !aligned16(wt)) return DDRL_ERR_INVALID_ARG;
+  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, void* stream) {
+  if (!lin_ok(n, K, N) || !dout || !wn || !din) return DDRL_ERR_INVALID_ARG;
+  if ((ld_dout & 3) || ld_dout < N || ld_din < K || !aligned16(dout) || !aligned16(wn)) return DDRL_ERR_INVALID_ARG;
+  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats) {
+  if (!lin_ok(n, K, N) || !floats) return DDRL_ERR_INVALID_ARG;
+  *floats = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
+                             float* db, int32_t n, int32_t K, int32_t N, void* stream) {
+  if (!lin_ok(n, K, N) || !in || !dout || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
+  if ((ld_in & 3) || (ld_dout & 3) || ld_in < (K + 3) / 4 * 4 || ld_dout < N || !aligned16(in) || !aligned16(dout))
+    return DDRL_ERR_INVALID_ARG;
+  launch_linear_wgrad(in, ld_in, dout, ld_dout, ws, n, K, N, dw, db, (hipStream_t)stream);
+  return op_check();
+}
+
+}  // extern "C"

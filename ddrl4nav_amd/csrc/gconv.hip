@@ -1,0 +1,447 @@
+// Generic 2-D convolution (runtime geometry) as gather-type implicit GEMMs on the pipelined
+// f32-MFMA engine: forward (+bias, +ReLU), data gradient and weight/bias gradient, plus the
+// 2x2 max-pool pair.  These serve the encoders outside the Atari fast path -- NavPreNet /
+// NavPedPreNet / NavPreNet1D (reference USTC_lab/nn/nav_encoder.py:18-20,27-32,96-101,108-122; a
+// Conv1d is a Conv2d with H = KH = 1).  The Atari encoder keeps its direct-convolution kernels
+// (conv2.hip, wgrad2.hip), which are 2-3x faster than a gather formulation.
+//
+//   forward   rows = cout (64/tile), cols = (b, oy, ox) (256/tile), k = (ci, ky, kx)
+//   dgrad     rows = cin,            cols = (b, y, x),               k = (co, ky, kx)
+//   wgrad     rows = cout,           cols = taps (ci, ky, kx),       k = (b, oy, ox), split over k
+//
+// A thread of the forward / dgrad kernels owns ONE column for the whole k loop, so the
+// (b, y, x) decode happens once; the k -> (channel, ky, kx) decode is a table lookup (uniform).
+// All gathers are unconditional loads from clamped addresses, masked when committed to LDS.
+#include "engine2.h"
+#include "ops.h"
+
+namespace ddrl {
+
+namespace gconv {
+
+constexpr int LDA = 68, LDB = 260;  // k-major tiles A[32][64+4], B[32][256+4]
+constexpr int A_FLOATS = 32 * LDA, B_FLOATS = 32 * LDB;
+
+struct Common {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
+  static constexpr int A_OFF = 0, B_OFF = A_FLOATS, STAGE = A_FLOATS + B_FLOATS;
+  int abase[2], bbase[2], kb_begin, kb_end;
+  int l31, hi, wc;
+  static constexpr int aoff(int s) { return 2 * s * LDA; }
+  static constexpr int boff(int s) { return 2 * s * LDB; }
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void lanes(int tid) {
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + hi * LDA + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * LDB + wc * 64 + j * 32 + l31;
+  }
+};
+
+// ktab[k] = {offset of (channel, ky, kx) inside a sample of the gathered tensor, (ky << 16) | kx};
+// entries k >= K hold ky = 0x7fff (never in range -> zero)
+//
+// DGRAD = false: out[b][co][oy][ox] = act(bias[co] + sum W[co][ci][ky][kx] in[b][ci][oy*S+ky-ph][ox*S+kx-pw])
+// DGRAD = true : din[b][ci][y][x]   = sum W[co][ci][ky][kx] dz[b][co][(y+ph-ky)/S][(x+pw-kx)/S]
+template <bool DGRAD>
+struct Gather : Common {
+  struct Params {
+    ConvGeom g;
+    const float* src;   // gathered tensor (input for forward, dz for dgrad)
+    const float* wp;    // [row tile][kb][32][64]
+    const int2* ktab;   // [Kp32]
+    const float* bias;  // forward only
+    float* dst;
+    int K;    // reduction length (cin*kh*kw or cout*kh*kw)
+    int act;  // forward: 0 none, 1 relu
+  };
+  struct Regs {
+    f4 a[2];
+    float b[32];
+    unsigned ok;
+  };
+  int c0, r0;
+  int y0, x0;        // forward: oy*S-ph, ox*S-pw ; dgrad: y+ph, x+pw
+  int64_t colbase;   // sample base of this thread's column in src (+ spatial part for forward)
+  bool colok;
+  const float* wp;
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    const ConvGeom& g = p.g;
+    c0 = blockIdx.x * 256;
+    r0 = blockIdx.y * 64;
+    kb_begin = 0;
+    kb_end = (p.K + 31) / 32;
+    wp = p.wp + (int64_t)blockIdx.y * kb_end * 2048;
+    const int P = DGRAD ? g.h * g.w : g.oh * g.ow;
+    const int cw = DGRAD ? g.w : g.ow;
+    const int64_t col = (int64_t)c0 + tid;
+    colok = col < (int64_t)g.n * P;
+    const int64_t cc = colok ? col : 0;
+    const int b = (int)(cc / P), pix = (int)(cc % P);
+    const int y = pix / cw, x = pix % cw;
+    if (DGRAD) {
+      y0 = y + g.pad_h;
+      x0 = x + g.pad_w;
+      colbase = (int64_t)b * g.out_sn;  // dz has the forward OUTPUT's layout
+    } else {
+      y0 = y * g.stride - g.pad_h;
+      x0 = x * g.stride - g.pad_w;
+      colbase = (int64_t)b * g.in_sn + (int64_t)y0 * g.w + x0;
+    }
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+    const ConvGeom& g = p.g;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r.a[j] = ld4(wp + (int64_t)kb * 2048 + (tid + 256 * j) * 4);
+    r.ok = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int2 e = p.ktab[kb * 32 + j];  // uniform
+      const int ky = e.y >> 16, kx = e.y & 0xffff;
+      bool ok;
+      int64_t off;
+      if (DGRAD) {
+        const int ty = y0 - ky, tx = x0 - kx;
+        const int oy = ty >> g.lgs, ox = tx >> g.lgs;
+        ok = colok && ty >= 0 && tx >= 0 && ((ty | tx) & (g.stride - 1)) == 0 && oy < g.oh && ox < g.ow;
+        off = colbase + e.x + oy * g.ow + ox;
+      } else {
+        ok = colok && (unsigned)(y0 + ky) < (unsigned)g.h && (unsigned)(x0 + kx) < (unsigned)g.w;
+        off = colbase + e.x;
+      }
+      r.b[j] = p.src[ok ? off : 0];
+      r.ok |= (ok ? 1u : 0u) << j;
+    }
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j;  // f4 index inside [32][64]
+      st4(buf + A_OFF + (idx >> 4) * LDA + (idx & 15) * 4, r.a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) buf[B_OFF + j * LDB + tid] = ((r.ok >> j) & 1u) ? r.b[j] : 0.0f;
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+    const ConvGeom& g = p.g;
+    const int P = DGRAD ? g.h * g.w : g.oh * g.ow;
+    const int nrows = DGRAD ? g.cin : g.cout;
+    const int64_t dsn = DGRAD ? g.in_sn : g.out_sn;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = (int64_t)c0 + wc * 64 + j * 32 + l31;
+      if (col >= (int64_t)g.n * P) continue;
+      const int b = (int)(col / P), pix = (int)(col % P);
+      float* dst = p.dst + (int64_t)b * dsn + pix;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + i * 32 + acc_row(r, hi);
+          if (row < nrows) {
+            float v = acc[i][j][r];
+            if (!DGRAD) {
+              v += p.bias[row];
+              if (p.act == 1) v = fmaxf(v, 0.0f);
+            }
+            dst[(int64_t)row * P] = v;
+          }
+        }
+    }
+  }
+};
+
+// part[s][co][tap] = sum over the split's (b, oy, ox) of dz[b][co][oy][ox] * in[b][ci][oy*S+ky-ph][ox*S+kx-pw]
+// followed by the bias partial [cout].  Requires oh*ow >= 32.
+struct Wgrad : Common {
+  static constexpr int LDAW = 65;  // A tile written along k by consecutive lanes: odd stride
+  static constexpr int B_OFFW = 32 * LDAW, STAGE = B_OFFW + B_FLOATS;
+  struct Params {
+    ConvGeom g;
+    const float* in;
+    const float* dz;
+    const int* ptab;  // [oh*ow] = (oy << 16) | ox
+    float* part;      // [nsplit][cout*KT + cout]
+    int KT;           // taps = cin*kh*kw
+    int nsplit;
+  };
+  struct Regs {
+    float a[8], b[32];
+    unsigned oka, okb;
+  };
+  int r0, t0, split;
+  int tapoff, tky, tkx;  // this thread's tap (column)
+  bool tapok;
+  float bacc[8];
+  static constexpr int aoff(int s) { return 2 * s * LDAW; }
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
+    const ConvGeom& g = p.g;
+    const int lane = tid & 63;
+    wc = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = hi * LDAW + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFFW + hi * LDB + wc * 64 + j * 32 + l31;
+    t0 = blockIdx.x * 256;
+    r0 = blockIdx.y * 64;
+    split = blockIdx.z;
+    const int64_t ktot = (int64_t)g.n * g.oh * g.ow;
+    const int nkb = (int)((ktot + 31) / 32);
+    const int per = (nkb + p.nsplit - 1) / p.nsplit;
+    kb_begin = min(nkb, split * per);
+    kb_end = min(nkb, kb_begin + per);
+    const int tap = t0 + tid;
+    tapok = tap < p.KT;
+    const int tt = tapok ? tap : 0;
+    const int khw = g.kh * g.kw;
+    const int ci = tt / khw, rr = tt % khw;
+    tky = rr / g.kw - g.pad_h;
+    tkx = rr % g.kw - g.pad_w;
+    tapoff = ci * g.h * g.w + tky * g.w + tkx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bacc[j] = 0.0f;
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+    const ConvGeom& g = p.g;
+    const int P = g.oh * g.ow;
+    const int64_t k0 = (int64_t)kb * 32;
+    const int bu = (int)(k0 / P), remu = (int)(k0 % P);  // uniform
+    // ---- A: dz[b][row][pix], this thread: k = tid & 31, rows (tid >> 5) + 8 j ----
+    {
+      const int kk = tid & 31, rr = tid >> 5;
+      int pix = remu + kk, b = bu;
+      if (pix >= P) {
+        pix -= P;
+        b += 1;
+      }
+      const bool kok = b < g.n;
+      const int64_t base = (int64_t)(kok ? b : 0) * g.out_sn + pix;
+      r.oka = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = r0 + rr + 8 * j;
+        const bool ok = kok && row < g.cout;
+        r.a[j] = p.dz[ok ? base + (int64_t)row * P : 0];
+        r.oka |= (ok ? 1u : 0u) << j;
+      }
+    }
+    // ---- B: in[b][tap], k = j (uniform pixel), this thread's tap ----
+    r.okb = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      int pix = remu + j, b = bu;  // uniform
+      if (pix >= P) {
+        pix -= P;
+        b += 1;
+      }
+      const int e = p.ptab[pix < P ? pix : 0];
+      const int iy = (e >> 16) * g.stride, ix = (e & 0xffff) * g.stride;
+      const bool ok = tapok && b < g.n && (unsigned)(iy + tky) < (unsigned)g.h && (unsigned)(ix + tkx) < (unsigned)g.w;
+      const int64_t off = (int64_t)b * g.in_sn + iy * g.w + ix + tapoff;
+      r.b[j] = p.in[ok ? off : 0];
+      r.okb |= (ok ? 1u : 0u) << j;
+    }
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+    const int kk = tid & 31, rr = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = ((r.oka >> j) & 1u) ? r.a[j] : 0.0f;
+      buf[kk * LDAW + rr + 8 * j] = v;
+      bacc[j] += v;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) buf[B_OFFW + j * LDB + tid] = ((r.okb >> j) & 1u) ? r.b[j] : 0.0f;
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+    const ConvGeom& g = p.g;
+    float* slab = p.part + (int64_t)split * ((int64_t)g.cout * p.KT + g.cout);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tap = t0 + wc * 64 + j * 32 + l31;
+      if (tap >= p.KT) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + i * 32 + acc_row(r, hi);
+          if (row < g.cout) slab[(int64_t)row * p.KT + tap] = acc[i][j][r];
+        }
+    }
+    if (blockIdx.x == 0) {  // bias partial: sum this half-wave's 32 k lanes for its 8 rows
+      const int rr = threadIdx.x >> 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = bacc[j];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        const int row = r0 + rr + 8 * j;
+        if ((threadIdx.x & 31) == 0 && row < g.cout) slab[(int64_t)g.cout * p.KT + row] = s;
+      }
+    }
+  }
+};
+
+}  // namespace gconv
+
+// wp[row tile][kb][kk][64]: forward  A(row = co, k = (ci,ky,kx)) = W[co][ci][ky][kx]
+//                           dgrad    A(row = ci, k = (co,ky,kx)) = W[co][ci][ky][kx]
+// ktab: forward  {ci*H*W + ky*W + kx, ky<<16|kx};  dgrad {co*OH*OW, ky<<16|kx}
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, ConvGeom g, float* __restrict__ wpf,
+                                                        int2* __restrict__ ktf, float* __restrict__ wpd, int2* __restrict__ ktd) {
+  const int khw = g.kh * g.kw;
+  const int Kf = g.cin * khw, Kd = g.cout * khw;
+  const int kbf = (Kf + 31) / 32, kbd = (Kd + 31) / 32;
+  const int rtf = (g.cout + 63) / 64, rtd = (g.cin + 63) / 64;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (int64_t)rtf * kbf * 2048) {
+    const int row = (int)(i & 63), k = (int)((i >> 6) % (kbf * 32)), rt = (int)((i >> 6) / (kbf * 32));
+    const int co = rt * 64 + row;
+    wpf[i] = (co < g.cout && k < Kf) ? w[(int64_t)co * Kf + k] : 0.0f;
+  }
+  if (i < (int64_t)rtd * kbd * 2048) {
+    const int row = (int)(i & 63), k = (int)((i >> 6) % (kbd * 32)), rt = (int)((i >> 6) / (kbd * 32));
+    const int ci = rt * 64 + row;
+    const int co = k / khw, r = k % khw;
+    wpd[i] = (ci < g.cin && k < Kd) ? w[((int64_t)co * g.cin + ci) * khw + r] : 0.0f;
+  }
+  if (i < kbf * 32) {
+    const int k = (int)i, ci = k / khw, r = k % khw, ky = r / g.kw, kx = r % g.kw;
+    ktf[i] = k < Kf ? make_int2(ci * g.h * g.w + ky * g.w + kx, (ky << 16) | kx) : make_int2(0, 0x7fff << 16);
+  }
+  if (i < kbd * 32) {
+    const int k = (int)i, co = k / khw, r = k % khw, ky = r / g.kw, kx = r % g.kw;
+    ktd[i] = k < Kd ? make_int2(co * g.oh * g.ow, (ky << 16) | kx) : make_int2(0, 0x7fff << 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_ptab_kernel(int ow, int P, int* __restrict__ ptab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < P) ptab[i] = ((i / ow) << 16) | (i % ow);
+}
+
+// 2x2 / stride 2 max pool over [planes][H][W] (H, W even) -- F.max_pool2d(x, 2, stride=2)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, int64_t total, int H, int W,
+                                                           float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ow = W / 2, oh = H / 2;
+  const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+  const int64_t pl = i / ((int64_t)ow * oh);
+  const float* s = in + (pl * H + 2 * y) * W + 2 * x;
+  out[i] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[W], s[W + 1]));
+}
+
+// dz[plane][y][x] = (a[y][x] is the FIRST maximum of its window, row-major scan as in PyTorch) and
+// a[y][x] > 0 (ReLU') ? dpool[window] : 0          a = relu(conv) at full resolution
+__global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dpool,
+                                                                int64_t total, int H, int W, float* __restrict__ dz) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per pooled element
+  if (i >= total) return;
+  const int ow = W / 2, oh = H / 2;
+  const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+  const int64_t pl = i / ((int64_t)ow * oh);
+  const int64_t o = (pl * H + 2 * y) * W + 2 * x;
+  const float v0 = a[o], v1 = a[o + 1], v2 = a[o + W], v3 = a[o + W + 1];
+  int am = 0;
+  float m = v0;
+  if (v1 > m) { m = v1; am = 1; }
+  if (v2 > m) { m = v2; am = 2; }
+  if (v3 > m) { m = v3; am = 3; }
+  const float g = (m > 0.0f) ? dpool[i] : 0.0f;
+  dz[o] = am == 0 ? g : 0.0f;
+  dz[o + 1] = am == 1 ? g : 0.0f;
+  dz[o + W] = am == 2 ? g : 0.0f;
+  dz[o + W + 1] = am == 3 ? g : 0.0f;
+}
+
+// ---- host side --------------------------------------------------------------------------------
+
+static int ilog2(int s) { return s == 1 ? 0 : (s == 2 ? 1 : (s == 4 ? 2 : -1)); }
+
+bool conv_geom_fill(ConvGeom& g) {
+  g.lgs = ilog2(g.stride);
+  if (g.lgs < 0 || g.n < 1 || g.cin < 1 || g.cout < 1 || g.kh < 1 || g.kw < 1 || g.kh > 255 || g.kw > 255) return false;
+  g.oh = (g.h + 2 * g.pad_h - g.kh) / g.stride + 1;
+  g.ow = (g.w + 2 * g.pad_w - g.kw) / g.stride + 1;
+  if (g.oh < 1 || g.ow < 1 || g.oh > 32767 || g.ow > 32767) return false;
+  if ((int64_t)g.cin * g.h * g.w >= (int64_t)1 << 30 || (int64_t)g.cout * g.oh * g.ow >= (int64_t)1 << 30) return false;
+  return true;
+}
+
+// float counts of the packed buffers: wpf, ktf (int2 = 2 floats each), wpd, ktd, ptab
+void conv_pack_sizes(const ConvGeom& g, int64_t out[5]) {
+  const int khw = g.kh * g.kw;
+  const int kbf = (g.cin * khw + 31) / 32, kbd = (g.cout * khw + 31) / 32;
+  out[0] = (int64_t)((g.cout + 63) / 64) * kbf * 2048;
+  out[1] = (int64_t)kbf * 32 * 2;
+  out[2] = (int64_t)((g.cin + 63) / 64) * kbd * 2048;
+  out[3] = (int64_t)kbd * 32 * 2;
+  out[4] = (int64_t)g.oh * g.ow;
+}
+
+void launch_conv_pack(const ConvGeom& g, const float* w, float* wpf, int2* ktf, float* wpd, int2* ktd, int* ptab, hipStream_t st) {
+  int64_t sz[5];
+  conv_pack_sizes(g, sz);
+  const int64_t total = sz[0] > sz[2] ? sz[0] : sz[2];
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, g, wpf, ktf, wpd, ktd);
+  hipLaunchKernelGGL(conv_ptab_kernel, dim3((unsigned)((sz[4] + 255) / 256)), dim3(256), 0, st, g.ow, (int)sz[4], ptab);
+}
+
+void launch_conv_fwd(const ConvGeom& g, const float* in, const float* wpf, const int2* ktf, const float* bias, int act,
+                     float* out, hipStream_t st) {
+  gconv::Gather<false>::Params p{g, in, wpf, ktf, bias, out, g.cin * g.kh * g.kw, act};
+  const int64_t cols = (int64_t)g.n * g.oh * g.ow;
+  launch_engine2<gconv::Gather<false>>(dim3((unsigned)((cols + 255) / 256), (g.cout + 63) / 64, 1), p, st);
+}
+
+void launch_conv_dgrad(const ConvGeom& g, const float* dz, const float* wpd, const int2* ktd, float* din, hipStream_t st) {
+  gconv::Gather<true>::Params p{g, dz, wpd, ktd, nullptr, din, g.cout * g.kh * g.kw, 0};
+  const int64_t cols = (int64_t)g.n * g.h * g.w;
+  launch_engine2<gconv::Gather<true>>(dim3((unsigned)((cols + 255) / 256), (g.cin + 63) / 64, 1), p, st);
+}
+
+int conv_wgrad_splits(const ConvGeom& g) {
+  const int KT = g.cin * g.kh * g.kw;
+  const int tiles = ((KT + 255) / 256) * ((g.cout + 63) / 64);
+  int s = (768 + tiles - 1) / tiles;
+  const int64_t nkb = ((int64_t)g.n * g.oh * g.ow + 31) / 32;
+  const int64_t cap = (nkb + 3) / 4;  // at least 4 k-blocks per split
+  if (s > cap) s = (int)cap;
+  return s < 1 ? 1 : s;
+}
+
+void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, const int* ptab, float* part, float* dw, float* db,
+                       hipStream_t st) {
+  const int KT = g.cin * g.kh * g.kw;
+  const int S = conv_wgrad_splits(g);
+  gconv::Wgrad::Params p{g, in, dz, ptab, part, KT, S};
+  launch_engine2<gconv::Wgrad>(dim3((KT + 255) / 256, (g.cout + 63) / 64, S), p, st);
+  const int64_t slab = (int64_t)g.cout * KT + g.cout;
+  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
+  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
+}
+
+void launch_maxpool2_fwd(const float* in, int64_t planes, int H, int W, float* out, hipStream_t st) {
+  const int64_t total = planes * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, total, H, W, out);
+}
+
+void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes, int H, int W, float* dz, hipStream_t st) {
+  const int64_t total = planes * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dpool, total, H, W,
+                     dz);
+}
+
+}  // namespace ddrl

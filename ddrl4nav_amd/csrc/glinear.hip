@@ -1,0 +1,342 @@
+// Generic dense layer (nn.Linear) on the pipelined f32-MFMA engine: forward (+bias, +ReLU),
+// data gradient (+ReLU mask of the producing layer) and weight/bias gradient, with runtime
+// sizes and leading dimensions.  These serve the encoders outside the Atari fast path
+// (reference USTC_lab/nn/nav_encoder.py:21-24,103-106, USTC_lab/nn/mlp_encoder.py:18 and the
+// `mlp` helper USTC_lab/nn/utils.py:10-20); the 3136->512 Atari layer keeps its own kernels (fc2.hip).
+//
+// Layout contract (checked by the C ABI): every leading dimension is a multiple of 4 floats and
+// every base pointer 16-byte aligned, so that all staging loads are aligned f4 loads;
+//   wt  [Kp32][N]  = W^T, rows K..Kp32-1 zero   (forward B operand; Kp32 = K rounded up to 32)
+//   wn  [N][Kp4]   = W,   cols K..Kp4-1 zero    (data-gradient B operand; Kp4 = K rounded up to 4)
+// Tiles are 128 x 128 with a 32-deep k-block, as in fc2.hip.
+#include "engine2.h"
+#include "ops.h"
+
+namespace ddrl {
+
+namespace glin {
+
+// X[128 rows][32 k] of a K-contiguous matrix -> LDS [row][33]; row and column clamped (reads past
+// the logical K only ever meet zero weights)
+struct RowTile {
+  static constexpr int LD = 33, FLOATS = 128 * LD;
+  __device__ __forceinline__ static void fetch(const float* __restrict__ src, int64_t ld, int row0, int nrows, int k0, int kmax4,
+                                               int tid, f4 (&r)[4]) {
+    const int k4 = tid & 7, rr = tid >> 3;
+    const int kc = min(k0 + k4 * 4, kmax4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = min(row0 + rr + 32 * j, nrows - 1);
+      r[j] = ld4(src + (int64_t)row * ld + kc);
+    }
+  }
+  __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4]) {
+    const int k4 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* p = dst + (rr + 32 * j) * LD + k4 * 4;
+      p[0] = r[j].x; p[1] = r[j].y; p[2] = r[j].z; p[3] = r[j].w;
+    }
+  }
+};
+
+// X[32 k][128 cols] of a col-contiguous matrix -> LDS as is.  k (the reduction index) beyond nk is
+// masked to zero at commit; columns beyond ncols4 are clamped (they only feed discarded outputs).
+struct KTile {
+  static constexpr int LD = 128, FLOATS = 32 * LD;
+  __device__ __forceinline__ static unsigned fetch(const float* __restrict__ src, int64_t ld, int k0, int nk, int col0, int ncols4,
+                                                   int tid, f4 (&r)[4]) {
+    const int c4 = tid & 31, kk = tid >> 5;
+    const int col = (col0 + c4 * 4) < ncols4 ? col0 + c4 * 4 : 0;
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + kk + 8 * j;
+      ok |= (k < nk ? 1u : 0u) << j;
+      r[j] = ld4(src + (int64_t)min(k, nk - 1) * ld + col);
+    }
+    return ok;
+  }
+  __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4], unsigned ok) {
+    const int c4 = tid & 31, kk = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(dst + (kk + 8 * j) * LD + c4 * 4, ((ok >> j) & 1u) ? r[j] : zero4());
+  }
+};
+
+struct Common {
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
+  int abase[2], bbase[2];
+  int kb_begin, kb_end;
+  int wr, wc, l31, hi;
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void lanes(int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    wr = wave >> 1;
+    wc = wave & 1;
+  }
+};
+
+// out[b][n] = act( sum_k in[b][k] W[n][k] + bias[n] )      rows = b, cols = n, reduction = k
+struct Fwd : Common {
+  static constexpr int A_OFF = 0, B_OFF = RowTile::FLOATS, STAGE = RowTile::FLOATS + KTile::FLOATS;
+  struct Params {
+    const float* in;
+    int64_t ld_in;
+    const float* wt;  // [Kp32][N]
+    const float* bias;
+    float* out;
+    int64_t ld_out;
+    int n, K, N, act;  // act: 0 none, 1 relu
+  };
+  struct Regs {
+    f4 a[4], b[4];
+    unsigned ok;
+  };
+  int b0, n0;
+  static constexpr int aoff(int s) { return 2 * s; }
+  static constexpr int boff(int s) { return 2 * s * KTile::LD; }
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    n0 = blockIdx.x * 128;
+    b0 = blockIdx.y * 128;
+    kb_begin = 0;
+    kb_end = (p.K + 31) / 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowTile::LD + hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KTile::LD + wc * 64 + j * 32 + l31;
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    RowTile::fetch(p.in, p.ld_in, b0, p.n, kb * 32, (int)p.ld_in - 4, threadIdx.x, r.a);
+    r.ok = KTile::fetch(p.wt, p.N, kb * 32, (p.K + 31) / 32 * 32, n0, p.N, threadIdx.x, r.b);
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    RowTile::commit(buf + A_OFF, threadIdx.x, r.a);
+    KTile::commit(buf + B_OFF, threadIdx.x, r.b, r.ok);
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + l31;
+      if (n >= p.N) continue;
+      const float bias = p.bias[n];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+          float v = acc[i][j][r] + bias;
+          if (p.act == 1) v = fmaxf(v, 0.0f);
+          if (b < p.n) p.out[(int64_t)b * p.ld_out + n] = v;
+        }
+    }
+  }
+};
+
+// din[b][k] = mask(b,k) * sum_n dout[b][n] W[n][k]          rows = b, cols = k, reduction = n
+// mask: relu'(mask_src[b][k]) of the layer that produced this input (mask_src = its output), or 1
+struct Dgrad : Common {
+  static constexpr int A_OFF = 0, B_OFF = RowTile::FLOATS, STAGE = RowTile::FLOATS + KTile::FLOATS;
+  struct Params {
+    const float* dout;
+    int64_t ld_dout;
+    const float* wn;  // [N][Kp4]
+    const float* mask_src;  // may be null
+    int64_t ld_mask;
+    float* din;
+    int64_t ld_din;
+    int n, K, N, Kp4;
+  };
+  struct Regs {
+    f4 a[4], b[4];
+    unsigned ok;
+  };
+  int b0, k0;
+  static constexpr int aoff(int s) { return 2 * s; }
+  static constexpr int boff(int s) { return 2 * s * KTile::LD; }
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    k0 = blockIdx.x * 128;
+    b0 = blockIdx.y * 128;
+    kb_begin = 0;
+    kb_end = (p.N + 31) / 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowTile::LD + hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KTile::LD + wc * 64 + j * 32 + l31;
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    RowTile::fetch(p.dout, p.ld_dout, b0, p.n, kb * 32, (int)p.ld_dout - 4, threadIdx.x, r.a);
+    r.ok = KTile::fetch(p.wn, p.Kp4, kb * 32, p.N, k0, p.Kp4, threadIdx.x, r.b);
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    RowTile::commit(buf + A_OFF, threadIdx.x, r.a);
+    KTile::commit(buf + B_OFF, threadIdx.x, r.b, r.ok);
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wc * 64 + j * 32 + l31;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+          if (b < p.n) {
+            float v = acc[i][j][r];
+            if (p.mask_src != nullptr && !(p.mask_src[(int64_t)b * p.ld_mask + k] > 0.0f)) v = 0.0f;
+            p.din[(int64_t)b * p.ld_din + k] = v;
+          }
+        }
+    }
+  }
+};
+
+// part[s][n][k] = sum_{b in split s} dout[b][n] in[b][k] ; bias partial [N] appended per slab
+// rows = n, cols = k, reduction = b
+struct Wgrad : Common {
+  static constexpr int A_OFF = 0, B_OFF = KTile::FLOATS, STAGE = 2 * KTile::FLOATS;
+  struct Params {
+    const float* dout;
+    int64_t ld_dout;
+    const float* in;
+    int64_t ld_in;
+    float* part;  // [nsplit][N*K + N]
+    int n, K, N, nsplit;
+  };
+  struct Regs {
+    f4 a[4], b[4];
+    unsigned oka, okb;
+  };
+  int split, n0, k0;
+  f4 bsum;
+  static constexpr int aoff(int s) { return 2 * s * KTile::LD; }
+  static constexpr int boff(int s) { return 2 * s * KTile::LD; }
+  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
+    lanes(tid);
+    split = blockIdx.z;
+    k0 = blockIdx.x * 128;
+    n0 = blockIdx.y * 128;
+    const int nkb = (p.n + 31) / 32;
+    const int per = (nkb + p.nsplit - 1) / p.nsplit;
+    kb_begin = min(nkb, split * per);
+    kb_end = min(nkb, kb_begin + per);
+    bsum = zero4();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + hi * KTile::LD + wr * 64 + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KTile::LD + wc * 64 + j * 32 + l31;
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    r.oka = KTile::fetch(p.dout, p.ld_dout, kb * 32, p.n, n0, p.N, threadIdx.x, r.a);
+    r.okb = KTile::fetch(p.in, p.ld_in, kb * 32, p.n, k0, (int)p.ld_in, threadIdx.x, r.b);
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    KTile::commit(buf + A_OFF, threadIdx.x, r.a, r.oka);  // samples >= n contribute zero
+    KTile::commit(buf + B_OFF, threadIdx.x, r.b, r.okb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((r.oka >> j) & 1u) bsum += r.a[j];  // this thread always holds the same 4 columns of dout
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+    float* slab = p.part + (int64_t)split * ((int64_t)p.N * p.K + p.N);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wc * 64 + j * 32 + l31;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wr * 64 + i * 32 + acc_row(r, hi);
+          if (n < p.N) slab[(int64_t)n * p.K + k] = acc[i][j][r];
+        }
+    }
+    if (blockIdx.x == 0) {  // one column tile per (row tile, split) owns the bias partial
+      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
+      st4(lds + kk * 128 + c4 * 4, bsum);
+      __syncthreads();
+      if (threadIdx.x < 128 && n0 + threadIdx.x < p.N) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += lds[q * 128 + threadIdx.x];
+        slab[(int64_t)p.N * p.K + n0 + threadIdx.x] = s;
+      }
+    }
+  }
+};
+
+}  // namespace glin
+
+// wt[k][n] = W[n][k] (zero rows up to Kp32), wn[n][k] = W[n][k] (zero columns up to Kp4)
+__global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restrict__ w, int K, int N, int Kp32, int Kp4,
+                                                          float* __restrict__ wt, float* __restrict__ wn) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (int64_t)Kp32 * N) {
+    const int k = (int)(i / N), n = (int)(i % N);
+    wt[i] = k < K ? w[(int64_t)n * K + k] : 0.0f;
+  }
+  if (i < (int64_t)N * Kp4) {
+    const int n = (int)(i / Kp4), k = (int)(i % Kp4);
+    wn[i] = k < K ? w[(int64_t)n * K + k] : 0.0f;
+  }
+}
+
+// dst[i] = sum_s part[s * slab_stride + i]   (fixed order)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nsplit, int64_t slab_stride,
+                                                           int64_t count, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.0f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * slab_stride + i];
+  dst[i] = s;
+}
+
+void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, part, nsplit, slab_stride,
+                     count, dst);
+}
+
+void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st) {
+  const int Kp32 = (K + 31) / 32 * 32, Kp4 = (K + 3) / 4 * 4;
+  const int64_t total = (int64_t)N * (Kp32 > Kp4 ? Kp32 : Kp4);
+  hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N, Kp32, Kp4, wt, wn);
+}
+
+void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
+                       int K, int N, int act, hipStream_t st) {
+  glin::Fwd::Params p{in, ld_in, wt, bias, out, ld_out, n, K, N, act};
+  launch_engine2<glin::Fwd>(dim3((N + 127) / 128, (n + 127) / 128, 1), p, st);
+}
+
+void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
+                         float* din, int64_t ld_din, int n, int K, int N, hipStream_t st) {
+  glin::Dgrad::Params p{dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, (K + 3) / 4 * 4};
+  launch_engine2<glin::Dgrad>(dim3((K + 127) / 128, (n + 127) / 128, 1), p, st);
+}
+
+int linear_wgrad_splits(int n, int K, int N) {
+  // ~512 workgroups per launch, at least 2 k-blocks (64 samples) per split
+  const int tiles = ((K + 127) / 128) * ((N + 127) / 128);
+  int s = (512 + tiles - 1) / tiles;
+  const int cap = (n + 63) / 64;
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
+
+void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
+                         float* dw, float* db, hipStream_t st) {
+  const int S = linear_wgrad_splits(n, K, N);
+  glin::Wgrad::Params p{dout, ld_dout, in, ld_in, part, n, K, N, S};
+  launch_engine2<glin::Wgrad>(dim3((K + 127) / 128, (N + 127) / 128, S), p, st);
+  const int64_t slab = (int64_t)N * K + N;
+  launch_reduce_slabs(part, S, slab, (int64_t)N * K, dw, st);
+  launch_reduce_slabs(part + (int64_t)N * K, S, slab, N, db, st);
+}
+
+}  // namespace ddrl

@@ -1,0 +1,36 @@
+// Internal launcher interface of the generic operators (gconv.hip, glinear.hip, gheads.hip).
+#pragma once
+#include "common.h"
+
+namespace ddrl {
+
+struct ConvGeom {
+  int n, cin, h, w, cout, kh, kw, stride, lgs, pad_h, pad_w, oh, ow;
+  int64_t in_sn, out_sn;  // sample strides (floats) of the input / output tensors ([c][h][w] dense inside)
+};
+
+// gconv.hip
+bool conv_geom_fill(ConvGeom& g);  // derives lgs, oh, ow from the rest; false when unsupported
+void conv_pack_sizes(const ConvGeom& g, int64_t out[5]);
+void launch_conv_pack(const ConvGeom& g, const float* w, float* wpf, int2* ktf, float* wpd, int2* ktd, int* ptab, hipStream_t st);
+void launch_conv_fwd(const ConvGeom& g, const float* in, const float* wpf, const int2* ktf, const float* bias, int act,
+                     float* out, hipStream_t st);
+void launch_conv_dgrad(const ConvGeom& g, const float* dz, const float* wpd, const int2* ktd, float* din, hipStream_t st);
+int conv_wgrad_splits(const ConvGeom& g);
+void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, const int* ptab, float* part, float* dw, float* db,
+                       hipStream_t st);
+void launch_maxpool2_fwd(const float* in, int64_t planes, int H, int W, float* out, hipStream_t st);
+void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes, int H, int W, float* dz, hipStream_t st);
+
+// glinear.hip
+void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
+void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st);
+void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
+                       int K, int N, int act, hipStream_t st);
+void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
+                         float* din, int64_t ld_din, int n, int K, int N, hipStream_t st);
+int linear_wgrad_splits(int n, int K, int N);
+void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
+                         float* dw, float* db, hipStream_t st);
+
+}  // namespace ddrl

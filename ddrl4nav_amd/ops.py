@@ -1,0 +1,119 @@
+"""Thin ctypes wrappers of the operator-level C ABI (include/ddrl.h, ddrl_op_*): generic
+convolution, 2x2 max-pool and dense layers on torch-owned device buffers.  torch supplies memory
+and streams only; the arithmetic runs in csrc/gconv.hip and csrc/glinear.hip.  Used by
+ddrl4nav_amd.nn.generic to compose the reference's non-Atari encoders
+(USTC_lab/nn/nav_encoder.py, mlp_encoder.py)."""
+from ctypes import byref, c_int32, c_int64, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+
+def _p(t):
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def _st():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), "expected a contiguous fp32 device tensor"
+    return t
+
+
+class Conv:
+    """One Conv2d / Conv1d layer (torch weight layout [cout][cin][kh][kw]; Conv1d: h = kh = 1)."""
+
+    def __init__(self, cin, h, w, cout, kh, kw, stride=1, pad=(0, 0), max_n=1, device="cuda"):
+        self.lib = _lib.load()
+        self.cin, self.h, self.w, self.cout, self.kh, self.kw = cin, h, w, cout, kh, kw
+        self.stride, self.pad = stride, tuple(pad)
+        self.device = torch.device(device)
+        d = self.desc(max_n)
+        oh, ow, pf, wf = c_int32(), c_int32(), c_int64(), c_int64()
+        check(self.lib.ddrl_op_conv_out_shape(byref(d), byref(oh), byref(ow)))
+        check(self.lib.ddrl_op_conv_pack_floats(byref(d), byref(pf)))
+        check(self.lib.ddrl_op_conv_ws_floats(byref(d), byref(wf)))
+        self.oh, self.ow, self.max_n = oh.value, ow.value, max_n
+        self.packed = torch.zeros(pf.value, dtype=torch.float32, device=self.device)
+        self.ws = torch.empty(wf.value, dtype=torch.float32, device=self.device)
+
+    def desc(self, n, in_sn=0, out_sn=0):
+        return ConvDesc(n, self.cin, self.h, self.w, self.cout, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
+                        in_sn, out_sn)
+
+    def pack(self, weight):
+        check(self.lib.ddrl_op_conv_pack(byref(self.desc(1)), _p(_f32(weight)), _p(self.packed), _st()))
+
+    def forward(self, x, bias, relu, out=None, n=None):
+        n = x.shape[0] if n is None else n
+        if out is None:
+            out = torch.empty((n, self.cout, self.oh, self.ow), dtype=torch.float32, device=x.device)
+        check(self.lib.ddrl_op_conv_forward(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)),
+                                            1 if relu else 0, _p(out), _st()))
+        return out
+
+    def dgrad(self, dz, din=None, n=None):
+        n = dz.shape[0] if n is None else n
+        if din is None:
+            din = torch.empty((n, self.cin, self.h, self.w), dtype=torch.float32, device=dz.device)
+        check(self.lib.ddrl_op_conv_dgrad(byref(self.desc(n)), _p(_f32(dz)), _p(self.packed), _p(din), _st()))
+        return din
+
+    def wgrad(self, x, dz, dw, db, n=None):
+        n = x.shape[0] if n is None else n
+        assert n <= self.max_n, "batch larger than the split-K scratch was sized for"
+        check(self.lib.ddrl_op_conv_wgrad(byref(self.desc(n)), _p(_f32(x)), _p(_f32(dz)), _p(self.packed), _p(self.ws),
+                                          _p(dw), _p(db), _st()))
+
+
+def maxpool2(x, out=None):
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().ddrl_op_maxpool2_forward(_p(_f32(x)), n * c, h, w, _p(out), _st()))
+    return out
+
+
+def maxpool2_relu_backward(a, dpool, dz=None):
+    n, c, h, w = a.shape
+    if dz is None:
+        dz = torch.empty_like(a)
+    check(_lib.load().ddrl_op_maxpool2_relu_backward(_p(_f32(a)), _p(_f32(dpool)), n * c, h, w, _p(dz), _st()))
+    return dz
+
+
+class Linear:
+    """One nn.Linear(K, N) (+ReLU) layer; weight [N][K]."""
+
+    def __init__(self, K, N, max_n=1, device="cuda"):
+        self.lib = _lib.load()
+        self.K, self.N, self.max_n = K, N, max_n
+        self.device = torch.device(device)
+        a, b, wf = c_int64(), c_int64(), c_int64()
+        check(self.lib.ddrl_op_linear_pack_floats(K, N, byref(a), byref(b)))
+        check(self.lib.ddrl_op_linear_ws_floats(max_n, K, N, byref(wf)))
+        self.wt = torch.zeros(a.value, dtype=torch.float32, device=self.device)
+        self.wn = torch.zeros(b.value, dtype=torch.float32, device=self.device)
+        self.ws = torch.empty(wf.value, dtype=torch.float32, device=self.device)
+
+    def pack(self, weight):
+        check(self.lib.ddrl_op_linear_pack(_p(_f32(weight)), self.K, self.N, _p(self.wt), _p(self.wn), _st()))
+
+    def forward(self, x, ld_in, bias, relu, out, ld_out, n):
+        check(self.lib.ddrl_op_linear_forward(_p(x), ld_in, _p(self.wt), _p(_f32(bias)), 1 if relu else 0, _p(out), ld_out,
+                                              n, self.K, self.N, _st()))
+        return out
+
+    def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n):
+        check(self.lib.ddrl_op_linear_dgrad(_p(dout), ld_dout, _p(self.wn), _p(mask_src), ld_mask, _p(din), ld_din, n,
+                                            self.K, self.N, _st()))
+        return din
+
+    def wgrad(self, x, ld_in, dout, ld_dout, dw, db, n):
+        assert n <= self.max_n
+        check(self.lib.ddrl_op_linear_wgrad(_p(x), ld_in, _p(dout), ld_dout, _p(self.ws), _p(dw), _p(db), n, self.K,
+                                            self.N, _st()))

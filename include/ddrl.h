@@ -214,6 +214,65 @@ int32_t ddrl_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the st
 int32_t ddrl_profile_enable(ddrl_ctx* ctx, int32_t on);
 int32_t ddrl_profile_read(ddrl_ctx* ctx, char (*names)[48], float* ms, int32_t* calls, int32_t cap, int32_t* n);
 
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points for the encoders outside the Atari fast path.
+ *
+ * The reference builds its other networks from torch modules: NavPreNet / NavPedPreNet /
+ * NavPreNet1D (USTC_lab/nn/nav_encoder.py:12-128: Conv2d 3x3/5x5/7x7 + ReLU + max_pool2d(2),
+ * Conv1d, Linear(+ReLU), torch.cat) and MLPPreNet (USTC_lab/nn/mlp_encoder.py:12-29).  Each
+ * ddrl_op_* below replaces one of those torch operators (forward and the autograd backward it
+ * implies) on caller-owned device buffers; the Python host composes them exactly where the
+ * reference composes the torch modules (ddrl4nav_amd/nn/generic.py).  All tensors are fp32,
+ * NCHW-dense inside a sample; `*_sn` are sample strides in floats (0 = dense).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ddrl_conv_desc {
+  int32_t n;               /* samples                                                     */
+  int32_t cin, h, w;       /* input  [n][cin][h][w]   (Conv1d: h = 1)                     */
+  int32_t cout, kh, kw;    /* weight [cout][cin][kh][kw]  (torch layout)                  */
+  int32_t stride;          /* 1, 2 or 4, both directions                                  */
+  int32_t pad_h, pad_w;    /* zero padding                                                */
+  int64_t in_sn, out_sn;   /* sample strides of input / output, 0 = dense                 */
+} ddrl_conv_desc;
+
+int32_t ddrl_op_conv_out_shape(const ddrl_conv_desc* d, int32_t* oh, int32_t* ow);
+/* Derived weight layouts + index tables of one layer (rebuilt whenever the weights change). */
+int32_t ddrl_op_conv_pack_floats(const ddrl_conv_desc* d, int64_t* floats);
+int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed, void* stream);
+/* out = act(conv2d(in, w) + bias); act: 0 none, 1 ReLU        (torch.nn.Conv2d / Conv1d + F.relu) */
+int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias,
+                             int32_t act, float* out, void* stream);
+/* din = d(loss)/d(in) given dz = d(loss)/d(pre-activation output) */
+int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream);
+/* dw [cout][cin][kh][kw], db [cout] (overwritten); `ws` = split-K scratch of ddrl_op_conv_ws_floats.
+ * Requires oh*ow >= 32. */
+int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats);
+int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float* dz, const float* packed, float* ws,
+                           float* dw, float* db, void* stream);
+
+/* F.max_pool2d(x, 2, stride=2) over `planes` = n*c planes of h x w (both even), and its backward
+ * fused with the ReLU that precedes it in the reference (`a` = relu(conv) at full resolution):
+ * dz = dpool routed to the first maximum of each window (PyTorch scan order), zero where a <= 0. */
+int32_t ddrl_op_maxpool2_forward(const float* in, int64_t planes, int32_t h, int32_t w, float* out, void* stream);
+int32_t ddrl_op_maxpool2_relu_backward(const float* a, const float* dpool, int64_t planes, int32_t h, int32_t w,
+                                       float* dz, void* stream);
+
+/* nn.Linear(K, N) (+ReLU): out[b][:] = act(in[b][:K] W^T + bias).  Leading dimensions are
+ * multiples of 4 floats (>= K rounded up to 4), pointers 16-byte aligned, N a multiple of 4;
+ * padding columns [K, ld_in) must hold finite values (they meet zero weights).
+ * wt / wn = derived layouts written by ddrl_op_linear_pack (sizes from ddrl_op_linear_pack_floats). */
+int32_t ddrl_op_linear_pack_floats(int32_t K, int32_t N, int64_t* wt_floats, int64_t* wn_floats);
+int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, float* wn, void* stream);
+int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act,
+                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, void* stream);
+/* din[b][k] = [mask_src[b][k] > 0 or mask_src == NULL] * sum_n dout[b][n] W[n][k]; mask_src is the
+ * (ReLU) output of the layer that produced `in`. */
+int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, void* stream);
+int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats);
+/* dw [N][K] = dout^T in, db [N] = column sums of dout (overwritten) */
+int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
+                             float* db, int32_t n, int32_t K, int32_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,154 @@
+"""GPU tests of the operator-level C ABI (ddrl_op_*): every generic HIP operator against the
+plain PyTorch fp32 CPU operator it replaces (the operators of the reference's nav / MLP encoders,
+USTC_lab/nn/nav_encoder.py, mlp_encoder.py).  Tolerance: |d| <= 2e-5 * max|want| (+1e-6) --
+same products, different fp32 summation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, tol=2e-5):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    scale = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale + 1e-7, (err, scale)
+
+
+# (n, cin, h, w, cout, kh, kw, stride, pad) -- the nav encoder layers plus ragged shapes
+CONVS = [
+    (5, 3, 48, 48, 64, 7, 7, 1, (1, 1)),     # NavPreNet1D.conv1
+    (3, 64, 22, 22, 128, 5, 5, 1, (1, 1)),   # NavPreNet1D.conv2
+    (7, 128, 10, 10, 256, 3, 3, 1, (1, 1)),  # NavPreNet1D.conv3
+    (4, 1, 48, 48, 64, 3, 3, 1, (1, 1)),     # NavPreNet.conv1
+    (2, 64, 24, 24, 128, 3, 3, 1, (1, 1)),   # NavPreNet.conv2
+    (3, 128, 12, 12, 256, 3, 3, 1, (1, 1)),  # NavPreNet.conv3
+    (6, 1, 1, 960, 32, 1, 5, 2, (0, 0)),     # conv1d1
+    (6, 32, 1, 478, 32, 1, 3, 2, (0, 0)),    # conv1d2
+    (1, 5, 9, 11, 70, 3, 2, 1, (2, 0)),      # odd everything, one sample
+    (9, 4, 20, 20, 32, 4, 4, 2, (0, 0)),     # stride 2 square
+    (2, 3, 16, 16, 8, 8, 8, 4, (0, 0)),      # stride 4
+]
+
+
+@pytest.mark.parametrize("shape", CONVS)
+def test_conv_forward_backward_vs_torch(shape):
+    from ddrl4nav_amd.ops import Conv
+    n, cin, h, w, cout, kh, kw, s, pad = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / (cin * kh * kw) ** 0.5
+    b = torch.randn(cout, generator=g)
+    x.requires_grad_(True)
+    wt.requires_grad_(True)
+    b.requires_grad_(True)
+    z = F.conv2d(x, wt, b, stride=s, padding=pad)
+    out = F.relu(z)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    conv = Conv(cin, h, w, cout, kh, kw, stride=s, pad=pad, max_n=n)
+    assert (conv.oh, conv.ow) == tuple(z.shape[2:])
+    conv.pack(wt.detach().cuda())
+    xd, bd, dzd = x.detach().cuda(), b.detach().cuda(), dz.cuda()
+    close(conv.forward(xd, bd, relu=True), out)
+    close(conv.forward(xd, bd, relu=False), z)
+    close(conv.dgrad(dzd), x.grad)
+    if conv.oh * conv.ow >= 32:
+        dw = torch.full_like(wt.detach(), 7.0).cuda()
+        db = torch.full((cout,), 7.0).cuda()
+        conv.wgrad(xd, dzd, dw, db)
+        close(dw, wt.grad)
+        close(db, b.grad)
+
+
+def test_conv_strided_sample_layout():
+    """in_sn / out_sn: the layer reads and writes slices of wider per-sample records."""
+    from ddrl4nav_amd import _lib
+    from ddrl4nav_amd.ops import Conv, _p, _st
+    from ctypes import byref
+    n, cin, h, w, cout = 3, 2, 8, 8, 5
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin * h * w + 13, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    b = torch.randn(cout, generator=g)
+    conv = Conv(cin, h, w, cout, 3, 3, pad=(1, 1), max_n=n)
+    conv.pack(wt.cuda())
+    out = torch.zeros(n, cout * h * w + 6).cuda()
+    d = conv.desc(n, in_sn=x.shape[1], out_sn=out.shape[1])
+    xd, bd = x.cuda(), b.cuda()  # keep the device copies alive across the asynchronous launch
+    _lib.check(_lib.load().ddrl_op_conv_forward(byref(d), _p(xd), _p(conv.packed), _p(bd), 0, _p(out), _st()))
+    want = F.conv2d(x[:, :cin * h * w].reshape(n, cin, h, w), wt, b, padding=1)
+    close(out[:, :cout * h * w].reshape(n, cout, h, w), want)
+    assert float(out[:, cout * h * w:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("planes_hw", [((3, 5), 44, 44), ((2, 7), 20, 20), ((1, 1), 2, 2), ((4, 3), 10, 6)])
+def test_maxpool_relu_pair_vs_torch(planes_hw):
+    from ddrl4nav_amd.ops import maxpool2, maxpool2_relu_backward
+    (n, c), h, w = planes_hw
+    g = torch.Generator().manual_seed(h * 100 + w)
+    z = torch.randn(n, c, h, w, generator=g)
+    z[0, 0, :2, :2] = -1.0                      # a window that is entirely clipped by the ReLU
+    z[0, 0, 0, 0] = z[0, 0, 0, 1] = 0.75 if h > 2 else -1.0  # an exact tie inside a window
+    z.requires_grad_(True)
+    a = F.relu(z)
+    pooled = F.max_pool2d(a, 2, stride=2)
+    dpool = torch.randn(pooled.shape, generator=g)
+    pooled.backward(dpool)
+    ad = a.detach().cuda()
+    assert torch.equal(maxpool2(ad).cpu(), pooled.detach())
+    assert torch.equal(maxpool2_relu_backward(ad, dpool.cuda()).cpu(), z.grad)
+
+
+LINEARS = [(300, 7616, 256), (257, 6400, 512), (130, 773, 512), (64, 512, 512), (1, 512, 512), (33, 4, 128), (5, 37, 12)]
+
+
+@pytest.mark.parametrize("shape", LINEARS)
+def test_linear_forward_backward_vs_torch(shape):
+    from ddrl4nav_amd.ops import Linear
+    n, K, N = shape
+    g = torch.Generator().manual_seed(n + K + N)
+    ld_in = (K + 3) // 4 * 4 + 4  # padded leading dimension (as in the concat buffer)
+    xfull = torch.zeros(n, ld_in)
+    xfull[:, :K] = torch.relu(torch.randn(n, K, generator=g))
+    x = xfull[:, :K].clone().requires_grad_(True)
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    z = F.linear(x, wt, b)
+    dz = torch.randn(n, N, generator=g)
+    z.backward(dz)
+    lin = Linear(K, N, max_n=n)
+    lin.pack(wt.detach().cuda())
+    xd, bd, dzd = xfull.cuda(), b.detach().cuda(), dz.cuda()
+    out = torch.full((n, N + 8), 3.0).cuda()
+    lin.forward(xd, ld_in, bd, True, out, N + 8, n)
+    close(out[:, :N], F.relu(z))
+    assert float((out[:, N:] - 3.0).abs().max()) == 0.0
+    lin.forward(xd, ld_in, bd, False, out, N + 8, n)
+    close(out[:, :N], z)
+    din = torch.full((n, ld_in), 5.0).cuda()
+    lin.dgrad(dzd, N, None, 0, din, ld_in, n)
+    close(din[:, :K], x.grad)
+    # with the ReLU mask of the producing layer (its output = this layer's input)
+    lin.dgrad(dzd, N, xd, ld_in, din, ld_in, n)
+    close(din[:, :K], x.grad * (x.detach() > 0))
+    dw = torch.full((N, K), 9.0).cuda()
+    db = torch.full((N,), 9.0).cuda()
+    lin.wgrad(xd, ld_in, dzd, N, dw, db, n)
+    close(dw, wt.grad)
+    close(db, b.grad)
+
+
+def test_ops_reject_bad_arguments():
+    from ddrl4nav_amd import _lib
+    from ddrl4nav_amd.ops import Conv, Linear
+    with pytest.raises(_lib.DdrlError):
+        Conv(3, 8, 8, 4, 3, 3, stride=3)          # stride must be 1, 2 or 4
+    with pytest.raises(_lib.DdrlError):
+        Linear(16, 6)                              # N must be a multiple of 4
+    lin = Linear(16, 8, max_n=4)
+    x = torch.zeros(4, 16).cuda()
+    with pytest.raises(_lib.DdrlError):
+        lin.forward(x, 15, torch.zeros(8).cuda(), False, torch.zeros(4, 8).cuda(), 8, 4)  # ld not a multiple of 4
