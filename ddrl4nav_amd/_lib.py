@@ -43,6 +43,13 @@ class ConvDesc(Structure):
                 ("out_sn", c_int64)]
 
 
+class HeadsDesc(Structure):
+    """ddrl_heads_desc (include/ddrl.h)."""
+    _fields_ = [("continuous", c_int32), ("n_actions", c_int32), ("shared", c_int32), ("reserved", c_int32),
+                ("actor_w", c_int64), ("actor_b", c_int64), ("log_std", c_int64), ("critic_w", c_int64),
+                ("critic_b", c_int64), ("n_params", c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/ddrl.h declares
 SIGNATURES = {
     "ddrl_abi_version": (c_int32, []),
@@ -108,6 +115,16 @@ SIGNATURES = {
     "ddrl_op_linear_ws_floats": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_int64)]),
     "ddrl_op_linear_wgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_int32, c_void_p]),
+    "ddrl_op_heads_ws_floats": (c_int32, [POINTER(HeadsDesc), c_int32, POINTER(c_int64)]),
+    "ddrl_op_heads_act": (c_int32, [POINTER(HeadsDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_uint64, c_uint64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_heads_loss": (c_int32, [POINTER(HeadsDesc), POINTER(Config), c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_clip_adam_ws_bytes": (c_int32, [POINTER(c_int64)]),
+    "ddrl_op_clip_adam": (c_int32, [POINTER(Config), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
+                                    c_int64, c_void_p, c_void_p]),
+    "ddrl_op_relu_mask": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "ddrl_op_accumulate": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

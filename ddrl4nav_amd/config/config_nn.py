@@ -10,14 +10,14 @@ import torch
 
 class ConfigNN:
     def __init__(self, dict_config_env: dict):
-        from ddrl4nav_amd.nn import CategoricalActor
+        from ddrl4nav_amd.nn import CategoricalActor, GaussionActor
         if dict_config_env['discrete_action']:                      # config_nn.py:10-14
             self.ACTOR_CLASS = CategoricalActor
             self.ACTION_OUTPUT_DIM = len(dict_config_env['discrete_actions'])
             self.ACTIONS_DIM = 1
         else:                                                        # config_nn.py:15-17
-            raise NotImplementedError("GaussionActor (continuous actions) is outside the Pong hot path "
-                                      "(SURVEY.md section 8f row 3)")
+            self.ACTION_OUTPUT_DIM = self.ACTIONS_DIM = dict_config_env['act_dim']
+            self.ACTOR_CLASS = GaussionActor
 
     NETWORK_TYPE = "ppo"            # :19
     USE_RND = False                 # :21

@@ -157,4 +157,131 @@ int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, 
   return op_check();
 }
 
+// ---- heads + optimiser on caller-owned arenas --------------------------------------------------
+static bool heads_ok(const ddrl_heads_desc* d) {
+  if (!d || d->n_params < 1) return false;
+  if (d->continuous) return d->n_actions >= 1 && d->n_actions <= 8;
+  return d->n_actions >= 2 && d->n_actions <= 18;
+}
+static ParamLayout cat_layout(const ddrl_heads_desc* d) {
+  ParamLayout L = make_layout(d->n_actions, 4, d->shared != 0);  // encoder offsets are unused by the head kernels
+  L.actor_w = d->actor_w; L.actor_b = d->actor_b; L.critic_w = d->critic_w; L.critic_b = d->critic_b;
+  L.n_params = d->n_params;
+  return L;
+}
+static GaussLayout gauss_layout(const ddrl_heads_desc* d) {
+  GaussLayout L;
+  L.D = d->n_actions; L.shared = d->shared != 0;
+  L.actor_w = d->actor_w; L.actor_b = d->actor_b; L.log_std = d->log_std; L.critic_w = d->critic_w;
+  L.critic_b = d->critic_b; L.n_params = d->n_params;
+  return L;
+}
+struct HeadsWs {
+  float *dlogits, *dvalue, *hpart;
+  int64_t total;
+};
+static HeadsWs heads_ws(const ddrl_heads_desc* d, int64_t max_n, float* base) {
+  HeadsWs w;
+  int64_t o = 0;
+  auto take = [&](int64_t floats) { float* p = base ? base + o : nullptr; o += align_up(floats, 64); return p; };
+  w.dlogits = take(max_n * d->n_actions);
+  w.dvalue = take(max_n);
+  const int64_t hs = d->continuous ? gauss_hpart_stride(d->n_actions) : hpart_stride(d->n_actions);
+  w.hpart = take((int64_t)HEAD_WG * hs);
+  w.total = o;
+  return w;
+}
+
+int32_t ddrl_op_heads_ws_floats(const ddrl_heads_desc* d, int32_t max_n, int64_t* floats) {
+  if (!heads_ok(d) || max_n < 1 || !floats) return DDRL_ERR_INVALID_ARG;
+  *floats = heads_ws(d, max_n, nullptr).total;
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_heads_act(const ddrl_heads_desc* d, const float* params, const float* h_actor, const float* h_critic,
+                          int32_t n, const float* act_in, uint64_t seed, uint64_t stream_id, float* dist_out, float* value,
+                          float* action_out, float* logp_out, void* stream) {
+  if (!heads_ok(d) || !params || !h_actor || !h_critic || !value || n < 1) return DDRL_ERR_INVALID_ARG;
+  if (!aligned16(h_actor) || !aligned16(h_critic)) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->continuous) {
+    launch_gauss_act(gauss_layout(d), params, h_actor, h_critic, n, act_in, seed, stream_id, dist_out, value, action_out,
+                     logp_out, st);
+    return op_check();
+  }
+  ParamLayout L = cat_layout(d);
+  Workspace w{};
+  w.h = const_cast<float*>(h_actor);
+  ddrl_config cfg;
+  ddrl_config_default(&cfg);
+  HeadsCall hc{&w, &L, &cfg, params, n, n};
+  hc.h_es = d->shared ? 0 : (int64_t)(h_critic - h_actor);
+  hc.plain_features = true;
+  launch_heads_act(hc, act_in, seed, stream_id, dist_out, value, action_out, logp_out, st);
+  return op_check();
+}
+
+int32_t ddrl_op_heads_loss(const ddrl_heads_desc* d, const ddrl_config* cfg, const float* params, const float* h_actor,
+                           const float* h_critic, int32_t n, const float* actions, const float* old_logps, const float* advs,
+                           const float* rets, int64_t B_global, float* dh_actor, float* dh_critic, float* grads, float* ws,
+                           void* stream) {
+  if (!heads_ok(d) || !cfg || !params || !h_actor || !h_critic || !actions || !old_logps || !advs || !rets || !dh_actor ||
+      !grads || !ws || n < 1 || B_global < n)
+    return DDRL_ERR_INVALID_ARG;
+  if (!d->shared && !dh_critic) return DDRL_ERR_INVALID_ARG;
+  if (!aligned16(h_actor) || !aligned16(h_critic) || !aligned16(dh_actor) || !aligned16(ws)) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  HeadsWs hw = heads_ws(d, n, ws);
+  const float inv_b = (float)(1.0 / (double)B_global);
+  if (d->continuous) {
+    launch_gauss_loss(gauss_layout(d), *cfg, params, h_actor, d->shared ? h_actor : h_critic, n, actions, old_logps, advs,
+                      rets, inv_b, dh_actor, dh_critic, hw.dlogits, hw.dvalue, hw.hpart, grads, st);
+    return op_check();
+  }
+  ParamLayout L = cat_layout(d);
+  Workspace w{};
+  w.h = const_cast<float*>(h_actor);
+  w.dh = dh_actor;
+  w.dlogits = hw.dlogits;
+  w.dvalue = hw.dvalue;
+  w.hpart = hw.hpart;
+  HeadsCall hc{&w, &L, cfg, params, n, n};
+  hc.h_es = d->shared ? 0 : (int64_t)(h_critic - h_actor);
+  hc.dh_es = d->shared ? 0 : (int64_t)(dh_critic - dh_actor);
+  hc.plain_features = true;
+  launch_heads_loss(hc, actions, old_logps, advs, rets, inv_b, grads, st);
+  return op_check();
+}
+
+int32_t ddrl_op_clip_adam(const ddrl_config* cfg, float* params, float* grads, float* m, float* v, int64_t n_params,
+                          int64_t n_actor, int32_t shared, int64_t step, void* ws, void* stream) {
+  if (!cfg || !params || !grads || !m || !v || !ws || n_params < 1 || n_actor < 0 || n_actor > n_params || step < 1)
+    return DDRL_ERR_INVALID_ARG;
+  ParamLayout L = make_layout(2, 4, shared != 0);
+  L.n_params = n_params;
+  L.n_actor = shared ? n_params : n_actor;
+  Workspace w{};
+  w.npart = (double*)ws;
+  launch_clip_adam(*cfg, L, w, params, grads, m, v, step, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_clip_adam_ws_bytes(int64_t* bytes) {
+  if (!bytes) return DDRL_ERR_INVALID_ARG;
+  *bytes = (int64_t)NORM_WG * sizeof(double);
+  return DDRL_OK;
+}
+
+int32_t ddrl_op_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int32_t n, int32_t width, void* stream) {
+  if (!d || !act || n < 1 || width < 1 || ld_d < width || ld_act < width) return DDRL_ERR_INVALID_ARG;
+  launch_relu_mask(d, ld_d, act, ld_act, n, width, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_accumulate(float* dst, const float* src, int64_t count, void* stream) {
+  if (!dst || !src || count < 1) return DDRL_ERR_INVALID_ARG;
+  launch_accumulate(dst, src, count, (hipStream_t)stream);
+  return op_check();
+}
+
 }  // extern "C"

@@ -302,6 +302,29 @@ void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int
                      count, dst);
 }
 
+__global__ __launch_bounds__(256) void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] += src[i];
+}
+void launch_accumulate(float* dst, const float* src, int64_t count, hipStream_t st) {
+  int64_t wgs = (count + 255) / 256;
+  if (wgs > 4096) wgs = 4096;
+  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)wgs), dim3(256), 0, st, dst, src, count);
+}
+
+// d[b][k] = act[b][k] > 0 ? d[b][k] : 0   (ReLU backward where the encoder's last layer ends in a ReLU)
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d, int64_t ld_d, const float* __restrict__ act,
+                                                        int64_t ld_act, int64_t n, int width) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * width) return;
+  const int64_t b = i / width;
+  const int k = (int)(i % width);
+  if (!(act[b * ld_act + k] > 0.0f)) d[b * ld_d + k] = 0.0f;
+}
+void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n * width + 255) / 256)), dim3(256), 0, st, d, ld_d, act, ld_act, n,
+                     width);
+}
+
 void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st) {
   const int Kp32 = (K + 31) / 32 * 32, Kp4 = (K + 3) / 4 * 4;
   const int64_t total = (int64_t)N * (Kp32 > Kp4 ? Kp32 : Kp4);

@@ -71,6 +71,10 @@ struct HeadsCall {
   const float* params;
   int n;
   int64_t max_batch;
+  // generic callers (ddrl_op_heads_*): explicit actor->critic feature / gradient strides and no
+  // split-K FC partials to fold in; the Atari context leaves these at their defaults
+  int64_t h_es = -1, dh_es = -1;
+  bool plain_features = false;
 };
 void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id,
                       float* probs, float* value, float* action_out, float* logp_out, hipStream_t st);

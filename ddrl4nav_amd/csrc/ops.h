@@ -24,6 +24,8 @@ void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes
 
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
+void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);
+void launch_accumulate(float* dst, const float* src, int64_t count, hipStream_t st);
 void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st);
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
                        int K, int N, int act, hipStream_t st);
@@ -32,5 +34,20 @@ void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, co
 int linear_wgrad_splits(int n, int K, int N);
 void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
                          float* dw, float* db, hipStream_t st);
+
+// gheads.hip: Gaussian actor + critic heads; offsets into the caller's flat parameter arena
+struct GaussLayout {
+  int D;       // action dims (<= 8)
+  int shared;  // 1: total_loss is differentiated (shared prenet), both heads feed dh_actor
+  int64_t actor_w, actor_b, log_std, critic_w, critic_b, n_params;
+};
+int64_t gauss_hpart_stride(int D);
+void launch_gauss_act(const GaussLayout& L, const float* params, const float* h_actor, const float* h_critic, int n,
+                      const float* act_in, uint64_t seed, uint64_t stream_id, float* mu_out, float* value, float* action_out,
+                      float* logp_out, hipStream_t st);
+void launch_gauss_loss(const GaussLayout& L, const ddrl_config& cfg, const float* params, const float* h_actor,
+                       const float* h_critic, int n, const float* actions, const float* old_logps, const float* advs,
+                       const float* rets, float inv_b, float* dh_actor, float* dh_critic, float* dmu, float* dvalue,
+                       float* hpart, float* grads, hipStream_t st);
 
 }  // namespace ddrl

@@ -4,9 +4,11 @@ from ddrl4nav_amd.nn.critic import Critic
 from ddrl4nav_amd.nn.actor import Actor, CategoricalActor, GaussionActor
 from ddrl4nav_amd.nn.atari_encoder import AtariPreNet
 from ddrl4nav_amd.nn.distribution import HipCategorical
+from ddrl4nav_amd.nn.generic import GenericPPO, HipNormal, MLPPreNet, NavPedPreNet, NavPreNet, NavPreNet1D, mlp
 from ddrl4nav_amd.nn.ppo import PPO
 
 NETWORK_MAP = {"ppo": PPO}
 
-__all__ = ["PPO", "Basenn", "PreNet", "NETWORK_MAP", "CategoricalActor", "GaussionActor", "Critic", "AtariPreNet",
-           "Actor", "HipCategorical"]
+__all__ = ["PPO", "GenericPPO", "Basenn", "PreNet", "NETWORK_MAP", "CategoricalActor", "GaussionActor", "Critic",
+           "AtariPreNet", "MLPPreNet", "NavPreNet", "NavPedPreNet", "NavPreNet1D", "mlp", "Actor", "HipCategorical",
+           "HipNormal"]

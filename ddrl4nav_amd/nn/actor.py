@@ -32,5 +32,18 @@ class CategoricalActor(Actor):
 
 
 class GaussionActor(Actor):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("GaussionActor belongs to the nav-encoder configs (SURVEY.md section 8f row 3)")
+    """actor.py:43-70: mu = actor_linear(h), std = exp(log_std), Normal(mu, std); log-prob summed
+    over the action dims.  log_std is registered after ``pre`` is stored but, being a direct
+    Parameter of the module, comes FIRST in named_parameters() (as in the reference)."""
+
+    def __init__(self, action_output_dim=1, device='cpu', soft_max_grid=True, last_input_dim=512, pre=None, nn_dtype=None):
+        super().__init__(pre=pre, device=device)
+        import torch
+        self.action_output_dim = action_output_dim
+        self.actor_linear = nn.Linear(last_input_dim, action_output_dim)
+        self.log_std = nn.Parameter(-0.5 * torch.ones(action_output_dim, dtype=torch.float32))
+
+    def _log_prob_from_distribution(self, pi, act):
+        if hasattr(pi, "summed_log_prob"):
+            return pi.summed_log_prob(act)
+        return pi.log_prob(act).sum(axis=-1)

@@ -1,0 +1,583 @@
+"""Encoders and PPO for the reference's non-Atari nets, composed from the operator-level C ABI.
+
+The reference builds these from torch modules (USTC_lab/nn/nav_encoder.py:12-128,
+mlp_encoder.py:12-29, actor.py:43-70, critic.py:8-21, ppo.py:17-146) and lets autograd derive the
+backward.  Here every module keeps the reference's parameter names and shapes (so ``state_dict``
+and the Redis weight blob interchange), but its forward and backward are explicit sequences of
+ddrl_op_* launches (csrc/gconv.hip, glinear.hip, gheads.hip, heads.hip, optim.hip) on buffers it
+owns.  torch supplies memory, streams and input staging (dtype casts, channel concat) only.
+
+The Atari encoder does not go through this file: it has its own fused kernels (nn/ppo.py).
+"""
+import time
+from ctypes import byref, c_int64, c_void_p
+
+import torch
+from torch import nn
+
+from ddrl4nav_amd import _lib
+from ddrl4nav_amd._lib import STATS_FLOATS, HeadsDesc, check
+from ddrl4nav_amd.data import Experience
+from ddrl4nav_amd.nn.base import Basenn, PreNet
+from ddrl4nav_amd.ops import Conv, Linear, maxpool2, maxpool2_relu_backward, _p, _st
+
+FEAT = 512
+
+
+def _pad4(k):
+    return (k + 3) // 4 * 4
+
+
+def mlp(input_mlp):
+    """Parameter holder with the module tree of the reference's ``mlp`` helper
+    (USTC_lab/nn/utils.py:10-20): Linear at index 0, activation at index 1."""
+    layers = []
+    for in_dim, out_dim, af in input_mlp:
+        layers.append(nn.Linear(in_dim, out_dim, bias=True))
+        if af == "relu":
+            layers.append(nn.ReLU())
+        elif af == "sigmoid":
+            raise NotImplementedError("sigmoid activations are not used by any encoder of the reference")
+    return nn.Sequential(*layers)
+
+
+class _Dense:
+    """nn.Linear (+ReLU) bound to arena views: forward / backward through ddrl_op_linear_*."""
+
+    def __init__(self, module, relu, cap, device):
+        self.m, self.relu = module, relu
+        self.K, self.N = module.in_features, module.out_features
+        self.op = Linear(self.K, self.N, max_n=cap, device=device)
+
+    def pack(self):
+        self.op.pack(self.m.weight.data)
+
+    def forward(self, x, ld_in, out, ld_out, n):
+        return self.op.forward(x, ld_in, self.m.bias.data, self.relu, out, ld_out, n)
+
+    def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0):
+        """dout = gradient w.r.t. this layer's PRE-activation output (the consumer applied the ReLU mask)."""
+        self.op.wgrad(x, ld_in, dout, ld_dout, self.m.weight.grad_view, self.m.bias.grad_view, n)
+        if din is not None:
+            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n)
+
+
+class _ConvPool:
+    """Conv2d + ReLU + max_pool2d(2) (nav_encoder.py:27-31): keeps the full-resolution ReLU output
+    for the pool / ReLU backward."""
+
+    def __init__(self, module, h, w, cap, device, pool=True, relu=True):
+        self.m, self.pool, self.relu = module, pool, relu
+        kh, kw = module.kernel_size
+        pad = module.padding if isinstance(module.padding, tuple) else (module.padding, module.padding)
+        if len(pad) == 1:
+            pad = (0, pad[0])
+        self.op = Conv(module.in_channels, h, w, module.out_channels, kh, kw, stride=module.stride[0], pad=pad, max_n=cap,
+                       device=device)
+        oh, ow = self.op.oh, self.op.ow
+        f = dict(dtype=torch.float32, device=device)
+        self.a = torch.empty((cap, module.out_channels, oh, ow), **f)       # relu(conv)
+        self.dz = torch.empty((cap, module.out_channels, oh, ow), **f)      # d(loss)/d(pre-activation)
+        if pool:
+            self.p = torch.empty((cap, module.out_channels, oh // 2, ow // 2), **f)
+            self.dp = torch.empty_like(self.p)
+        self.out_shape = (module.out_channels, oh // 2, ow // 2) if pool else (module.out_channels, oh, ow)
+
+    def pack(self):
+        w = self.m.weight.data
+        self.op.pack(w if w.dim() == 4 else w.unsqueeze(2))
+
+    def forward(self, x, n):
+        self.op.forward(x, self.m.bias.data, self.relu, out=self.a, n=n)
+        if not self.pool:
+            return self.a
+        maxpool2(self.a[:n], out=self.p)
+        return self.p
+
+    def out_grad_buffer(self):
+        """Where the consumer writes d(loss)/d(output of this block)."""
+        return self.dp if self.pool else self.dz
+
+    def backward(self, x, n, din=None):
+        if self.pool:
+            maxpool2_relu_backward(self.a[:n], self.dp[:n], dz=self.dz)
+        self.op.wgrad(x, self.dz, self.m.weight.grad_view, self.m.bias.grad_view, n=n)
+        if din is not None:
+            self.op.dgrad(self.dz, din=din, n=n)
+
+
+class GenericPreNet(PreNet):
+    """Base of the operator-composed encoders: subclasses define the torch parameter tree in
+    __init__ (reference names) and implement build / forward_dev / backward_dev."""
+    n_inputs = 1
+
+    def forward(self, x):
+        raise RuntimeError("%s runs inside ddrl4nav_amd.nn.PPO (HIP operators); wrap it in a PPO net" % type(self).__name__)
+
+    def _f(self, cap, *shape):
+        return torch.empty((cap,) + shape, dtype=torch.float32, device=self._device)
+
+    def pack(self):
+        for b in self._blocks:
+            b.pack()
+
+
+class MLPPreNet(GenericPreNet):
+    """mlp_encoder.py:12-29: fc0 = Linear(input_dim, last_output_dim) + ReLU on state[0]."""
+
+    def __init__(self, input_dim=4, last_output_dim=128):
+        super().__init__()
+        self.fc0 = mlp([(input_dim, last_output_dim, "relu")])
+        self.input_dim, self.out_dim = input_dim, last_output_dim
+
+    def build(self, cap, device):
+        self._device = device
+        self.ld = _pad4(self.input_dim)
+        self.x = torch.zeros((cap, self.ld), dtype=torch.float32, device=device)
+        self.d0 = _Dense(self.fc0[0], True, cap, device)
+        self.h = self._f(cap, self.out_dim)
+        self._blocks = [self.d0]
+
+    def forward_dev(self, states, n):
+        self.x[:n, :self.input_dim].copy_(states[0].reshape(n, -1))
+        self.d0.forward(self.x, self.ld, self.h, self.out_dim, n)
+        return self.h
+
+    def backward_dev(self, dh, n):
+        # dh arrives w.r.t. the ReLU output of fc0 (the encoder's last layer): mask it first
+        check(_lib.load().ddrl_op_relu_mask(_p(dh), self.out_dim, _p(self.h), self.out_dim, n, self.out_dim, _st()))
+        self.d0.backward(self.x, self.ld, dh, self.out_dim, n)
+
+
+class _NavBase(GenericPreNet):
+    """conv stack + fc0 (+ReLU), cat with the vector state, fc1 (+ReLU), fc2 (nav_encoder.py:34-44)."""
+
+    def _build_tail(self, cap, device, flat_dim, vec_dim, extra=0):
+        self.vec_dim, self.extra = vec_dim, extra
+        self.cat_k = extra + 512 + vec_dim
+        self.ld_cat = _pad4(self.cat_k)
+        self.cat = torch.zeros((cap, self.ld_cat), dtype=torch.float32, device=device)
+        self.dcat = torch.zeros((cap, self.ld_cat), dtype=torch.float32, device=device)
+        self.d0 = _Dense(self.fc0[0], True, cap, device)
+        self.d1 = _Dense(self.fc1[0], True, cap, device)
+        self.d2 = _Dense(self.fc2, False, cap, device)
+        self.f1 = self._f(cap, 512)
+        self.df1 = self._f(cap, 512)
+        self.h = self._f(cap, 512)
+        self.flat_dim = flat_dim
+
+    def _tail_forward(self, flat, vec, n):
+        # torch.cat((x, state[1]), dim=1): fc0 writes its slice of the cat buffer directly
+        self.d0.forward(flat, self.flat_dim, self.cat[:, self.extra:], self.ld_cat, n)
+        self.cat[:n, self.extra + 512:self.cat_k].copy_(vec.reshape(n, -1))
+        self.d1.forward(self.cat, self.ld_cat, self.f1, 512, n)
+        self.d2.forward(self.f1, 512, self.h, 512, n)
+        return self.h
+
+    def _tail_backward(self, dh, flat, dflat, n):
+        self.d2.backward(self.f1, 512, dh, 512, n, din=self.df1, ld_din=512, mask_src=self.f1, ld_mask=512)
+        # the first extra+512 columns of cat are ReLU outputs: mask with the cat values themselves
+        self.d1.backward(self.cat, self.ld_cat, self.df1, 512, n, din=self.dcat, ld_din=self.ld_cat, mask_src=self.cat,
+                         ld_mask=self.ld_cat)
+        self.d0.backward(flat, self.flat_dim, self.dcat[:, self.extra:], self.ld_cat, n, din=dflat, ld_din=self.flat_dim)
+
+
+class NavPreNet(_NavBase):
+    """nav_encoder.py:12-44: state = [image [n,C,48,48], vector [n,9]]."""
+    n_inputs = 2
+    vec_dim = 9
+
+    def __init__(self, image_channel=1, last_output_dim=512):
+        super().__init__()
+        self.conv1 = nn.Conv2d(image_channel, 64, 3, stride=1, padding=(1, 1))
+        self.conv2 = nn.Conv2d(64, 128, 3, stride=1, padding=(1, 1))
+        self.conv3 = nn.Conv2d(128, 256, 3, stride=1, padding=(1, 1))
+        self.fc0 = mlp([(256 * 6 * 6, 512, "relu")])
+        self.fc1 = mlp([(512 + 9, 512, "relu")])
+        self.fc2 = nn.Linear(512, 512)
+        self.image_channel = image_channel
+
+    def build(self, cap, device):
+        self._device = device
+        self.c1 = _ConvPool(self.conv1, 48, 48, cap, device)
+        self.c2 = _ConvPool(self.conv2, 24, 24, cap, device)
+        self.c3 = _ConvPool(self.conv3, 12, 12, cap, device)
+        self._build_tail(cap, device, 256 * 6 * 6, 9)
+        self._blocks = [self.c1, self.c2, self.c3, self.d0, self.d1, self.d2]
+
+    def _image(self, states, n):
+        return states[0].reshape(n, self.image_channel, 48, 48).contiguous()
+
+    def forward_dev(self, states, n):
+        self.img = self._image(states, n)
+        p1 = self.c1.forward(self.img, n)
+        p2 = self.c2.forward(p1, n)
+        p3 = self.c3.forward(p2, n)
+        return self._tail_forward(p3, states[1], n)
+
+    def backward_dev(self, dh, n):
+        self._tail_backward(dh, self.c3.p, self.c3.dp, n)
+        self.c3.backward(self.c2.p, n, din=self.c2.dp)
+        self.c2.backward(self.c1.p, n, din=self.c1.dp)
+        self.c1.backward(self.img, n)
+
+
+class NavPedPreNet(NavPreNet):
+    """nav_encoder.py:47-83: the image is torch.cat([state[0], state[2]], axis=1)."""
+    n_inputs = 3
+
+    def __init__(self, image_channel=4, last_output_dim=512):
+        super().__init__(image_channel, last_output_dim)
+
+    def _image(self, states, n):
+        return torch.cat([states[0].reshape(n, -1, 48, 48), states[2].reshape(n, -1, 48, 48)], dim=1).contiguous()
+
+
+class NavPreNet1D(_NavBase):
+    """nav_encoder.py:86-128: state = [laser [n,1,960], vector [n,5], pedestrian image [n,3,48,48]];
+    two un-activated Conv1d layers + fc_1d on the laser scan, a 7x7 / 5x5 / 3x3 conv stack on the image."""
+    n_inputs = 3
+
+    def __init__(self, image_channel=1, last_output_dim=512):
+        super().__init__()
+        self.conv1 = nn.Conv2d(image_channel, 64, 7, stride=1, padding=(1, 1))
+        self.conv2 = nn.Conv2d(64, 128, 5, stride=1, padding=(1, 1))
+        self.conv3 = nn.Conv2d(128, 256, 3, stride=1, padding=(1, 1))
+        self.conv1d1 = nn.Conv1d(1, 32, 5, 2, "valid")
+        self.conv1d2 = nn.Conv1d(32, 32, 3, 2, "valid")
+        self.fc_1d = mlp([(7616, 256, "relu")])
+        self.fc0 = mlp([(6400, 512, "relu")])
+        self.fc1 = mlp([(256 + 512 + 5, 512, "relu")])
+        self.fc2 = nn.Linear(512, 512)
+        self.image_channel = image_channel
+
+    def build(self, cap, device):
+        self._device = device
+        self.c1 = _ConvPool(self.conv1, 48, 48, cap, device)    # -> 64 x 44 x 44 -> 22 x 22
+        self.c2 = _ConvPool(self.conv2, 22, 22, cap, device)    # -> 128 x 20 x 20 -> 10 x 10
+        self.c3 = _ConvPool(self.conv3, 10, 10, cap, device)    # -> 256 x 10 x 10 -> 5 x 5
+        self.l1 = _ConvPool(_as2d(self.conv1d1), 1, 960, cap, device, pool=False, relu=False)  # -> 32 x 478
+        self.l2 = _ConvPool(_as2d(self.conv1d2), 1, 478, cap, device, pool=False, relu=False)  # -> 32 x 238
+        self.l1.m, self.l2.m = self.conv1d1, self.conv1d2
+        self.d1d = _Dense(self.fc_1d[0], True, cap, device)
+        self._build_tail(cap, device, 6400, 5, extra=256)
+        self.dl2 = self._f(cap, 7616)
+        self._blocks = [self.c1, self.c2, self.c3, self.l1, self.l2, self.d1d, self.d0, self.d1, self.d2]
+
+    def forward_dev(self, states, n):
+        self.laser = states[0].reshape(n, 1, 1, 960).contiguous()
+        self.img = states[2].reshape(n, self.image_channel, 48, 48).contiguous()
+        a1 = self.l1.forward(self.laser, n)
+        a2 = self.l2.forward(a1, n)
+        self.d1d.forward(a2, 7616, self.cat, self.ld_cat, n)  # encoded laser -> cat[:, 0:256]
+        p1 = self.c1.forward(self.img, n)
+        p2 = self.c2.forward(p1, n)
+        p3 = self.c3.forward(p2, n)
+        return self._tail_forward(p3, states[1], n)
+
+    def backward_dev(self, dh, n):
+        self._tail_backward(dh, self.c3.p, self.c3.dp, n)
+        self.c3.backward(self.c2.p, n, din=self.c2.dp)
+        self.c2.backward(self.c1.p, n, din=self.c1.dp)
+        self.c1.backward(self.img, n)
+        # laser branch: dcat[:, 0:256] already carries the ReLU mask of fc_1d (applied by fc1's dgrad)
+        self.d1d.backward(self.l2.a, 7616, self.dcat, self.ld_cat, n, din=self.l2.dz, ld_din=7616)
+        self.l2.backward(self.l1.a, n, din=self.l1.dz)
+        self.l1.backward(self.laser, n)
+
+
+class _Conv1dAs2d:
+    """View of an nn.Conv1d with the attributes _ConvPool reads from a Conv2d (h = kh = 1)."""
+
+    def __init__(self, m):
+        self.in_channels, self.out_channels = m.in_channels, m.out_channels
+        self.kernel_size = (1, m.kernel_size[0])
+        self.stride = (m.stride[0], m.stride[0])
+        self.padding = (0, 0)  # "valid"
+        self.weight, self.bias = m.weight, m.bias
+
+
+def _as2d(m):
+    return _Conv1dAs2d(m)
+
+
+# ------------------------------------------------------------------------------------------------
+class HipNormal:
+    """What PPO.forward returns where the reference returns torch.distributions.Normal
+    (actor.py:62-66): .mean .stddev .sample() .log_prob(a) (per dim) .entropy()."""
+
+    def __init__(self, net, mu, log_std, action, logp, version):
+        self._net, self.mean, self._log_std = net, mu, log_std
+        self.stddev = torch.exp(log_std).expand_as(mu)
+        self._action, self._logp, self._version = action, logp, version
+
+    loc = property(lambda self: self.mean)
+    scale = property(lambda self: self.stddev)
+
+    def sample(self):
+        if self._action is None:
+            self._action, self._logp = self._net._resample(self._version)
+        return self._action
+
+    def summed_log_prob(self, value):
+        if value is self._action and self._logp is not None:
+            return self._logp
+        return self._net._eval_logp(value, self._version)
+
+    def log_prob(self, value):
+        # per-dimension Normal log-density (torch semantics); staging-level torch arithmetic on [n, D]
+        var = self.stddev ** 2
+        return -((value - self.mean) ** 2) / (2 * var) - self._log_std - 0.9189385332046727
+
+    def entropy(self):
+        return (0.5 + 0.9189385332046727 + self._log_std).expand_as(self.mean)
+
+
+class GenericPPO(Basenn):
+    """PPO over operator-composed encoders (any PreNet above) with a Categorical or Gaussian actor.
+    Same constructor and protocol as the reference's PPO (ppo.py:17-146); see nn/ppo.py for the
+    Atari fast path."""
+
+    def __init__(self, actor, critic, prenet=None, rnd=None, config=None, config_nn=None, max_batch=None,
+                 process_group=None):
+        super().__init__(config, config_nn)
+        if rnd is not None:
+            raise NotImplementedError("RND is disabled in the reference defaults (USE_RND=False) and out of scope")
+        if bool(config_nn.SHARE_CNN_NET) != (prenet is not None):
+            raise ValueError("SHARE_CNN_NET=True needs a shared prenet; SHARE_CNN_NET=False needs prenet=None")
+        if not torch.cuda.is_available():
+            raise _lib.DdrlError("ddrl4nav_amd needs a ROCm GPU; there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(config.DEVICE if str(config.DEVICE) != "cuda" else "cuda:%d" % torch.cuda.current_device())
+        self.prenet, self.actor, self.critic = prenet, actor, critic
+        self._critics = [self.critic]
+        self.rnd, self.gail_critic = rnd, False
+        self.share_cnn_net = bool(config_nn.SHARE_CNN_NET)
+        self.training_iter_time = config_nn.TRAINING_ITER_TIME
+        self.update_time = 0
+        self._cfg_nn, self._process_group = config_nn, process_group
+        self._seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        self._calls = 0
+        self.continuous = hasattr(actor, "log_std")
+        self.n_actions = actor.action_output_dim
+        self.cap = int(max_batch if max_batch is not None else 1024)
+        self._encs = [prenet] if self.share_cnn_net else [actor.pre, critic.pre]
+        for e in self._encs:
+            if not isinstance(e, GenericPreNet):
+                raise TypeError("GenericPPO needs operator-composed encoders (MLPPreNet, NavPreNet, ...), got %r" % type(e))
+        self._bind_arena()
+        for e in self._encs:
+            e.build(self.cap, self.device)
+        self._build_heads()
+        self._dirty = True
+        self._step = 0
+
+    # ---- flat arenas (reference named_parameters() order) ------------------------------------------
+    def _bind_arena(self):
+        params = list(self.named_parameters())
+        total = sum(p.numel() for _, p in params)
+        f = dict(dtype=torch.float32, device=self.device)
+        self.n_params = total
+        self.params = torch.zeros(total, **f)
+        self.grads = torch.zeros(total + STATS_FLOATS, **f)
+        self.gtmp = torch.zeros(total + STATS_FLOATS, **f)
+        self.adam_m = torch.zeros(total, **f)
+        self.adam_v = torch.zeros(total, **f)
+        self._offsets, off = {}, 0
+        with torch.no_grad():
+            for name, p in params:
+                n = p.numel()
+                view = self.params[off:off + n].view(p.shape)
+                view.copy_(p.detach().to(self.device, torch.float32))
+                p.data = view
+                p.requires_grad_(False)
+                p.grad_view = self.gtmp[off:off + n].view(p.shape)  # operators write gradients here
+                self._offsets[name] = off
+                off += n
+        # actor group = the leading run of actor.* parameters (ppo.py:40-42); everything when shared
+        self.n_actor = total if self.share_cnn_net else sum(p.numel() for k, p in params if k.startswith("actor."))
+        if not self.share_cnn_net:
+            assert all(k.startswith("actor.") for k, _ in params[:sum(1 for k, _ in params if k.startswith("actor."))])
+
+    def _build_heads(self):
+        o = self._offsets
+        d = HeadsDesc()
+        d.continuous = 1 if self.continuous else 0
+        d.n_actions, d.shared = self.n_actions, 1 if self.share_cnn_net else 0
+        d.actor_w, d.actor_b = o["actor.actor_linear.weight"], o["actor.actor_linear.bias"]
+        d.log_std = o.get("actor.log_std", 0)
+        d.critic_w, d.critic_b = o["critic.critic_linear.weight"], o["critic.critic_linear.bias"]
+        d.n_params = self.n_params
+        self._hd = d
+        wf, cb = c_int64(), c_int64()
+        check(self.lib.ddrl_op_heads_ws_floats(byref(d), self.cap, byref(wf)))
+        check(self.lib.ddrl_op_clip_adam_ws_bytes(byref(cb)))
+        f = dict(dtype=torch.float32, device=self.device)
+        self._heads_ws = torch.empty(wf.value, **f)
+        self._adam_ws = torch.empty(cb.value, dtype=torch.uint8, device=self.device)
+        self._dh = [torch.empty((self.cap, FEAT), **f) for _ in self._encs]
+        c = self._cfg_nn
+        self._cfg = _lib.default_config(
+            max_batch=self.cap, n_actions=max(2, min(self.n_actions, 18)), share_cnn_net=1 if self.share_cnn_net else 0,
+            learning_rate=float(c.LEARNING_RATE), smooth_l1_loss=1 if c.SMOOTH_L1_LOSS else 0,
+            clip_grad=1 if c.CLIP_GRID else 0, clip_grad_norm=float(c.CLIP_GRID_NUM), actor_lr=float(c.ACTOR_LEARNING_RATE),
+            critic_lr=float(c.CRITIC_LEARNING_RATE), ppo_clip=float(c.PPO_CLIP), dual_clip=float(c.DUEL_PPO_CLIP),
+            v_loss_theta=float(c.V_LOSS_THETA), ent_loss_theta=float(c.ENTROPY_LOSS_THETA))
+
+    def _ensure_packed(self):
+        if self._dirty:
+            for e in self._encs:
+                e.pack()
+            self._dirty = False
+
+    def params_changed(self):
+        self._dirty = True
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._dirty = True
+        return out
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self._step = 0
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def _stage(self, states, lo, hi):
+        return [torch.as_tensor(s)[lo:hi].to(self.device, torch.float32, non_blocking=True) for s in states]
+
+    def _features(self, st, n):
+        hs = [e.forward_dev(st, n) for e in self._encs]
+        return (hs[0], hs[0]) if self.share_cnn_net else (hs[0], hs[1])
+
+    def forward(self, states, act=None, play_mode=False):
+        states = states if isinstance(states, (list, tuple)) else [states]
+        n = int(torch.as_tensor(states[0]).shape[0])
+        self._ensure_packed()
+        self._calls += 1
+        A = self.n_actions
+        f = dict(dtype=torch.float32, device=self.device)
+        dist_out = torch.empty((n, A), **f)
+        value, logp = torch.empty(n, **f), torch.empty(n, **f)
+        a_in = None if act is None else torch.as_tensor(act, **f).contiguous()
+        action = a_in if a_in is not None else torch.empty((n, A) if self.continuous else (n,), **f)
+        for lo in range(0, n, self.cap):
+            hi = min(n, lo + self.cap)
+            ha, hc = self._features(self._stage(states, lo, hi), hi - lo)
+            check(self.lib.ddrl_op_heads_act(
+                byref(self._hd), _p(self.params), _p(ha), _p(hc), hi - lo, _p(None if a_in is None else a_in[lo:hi]),
+                self._seed, self._calls * 4096 + lo // self.cap, _p(dist_out[lo:hi]), _p(value[lo:hi]),
+                _p(None) if a_in is not None else _p(action[lo:hi]), _p(logp[lo:hi]), _st()))
+        self._last = (n, self._calls)
+        values = [value.view(n, 1)]
+        if play_mode:
+            return (dist_out, logp if act is not None else None), values
+        if self.continuous:
+            dist = HipNormal(self, dist_out, self.actor.log_std.data, action, logp, self._calls)
+        else:
+            from ddrl4nav_amd.nn.distribution import HipCategorical
+            dist = HipCategorical(_CatOps(self), dist_out, self._seed, self._calls, action, logp)
+        return (dist, logp if act is not None else None), values
+
+    def _eval_logp(self, value, version):
+        n, v = self._last
+        if v != version or n > self.cap:
+            raise RuntimeError("log_prob of new actions needs the features of the forward that made this distribution "
+                               "(call it before the next forward, batch <= max_batch)")
+        ha = self._encs[0].h
+        hc = ha if self.share_cnn_net else self._encs[1].h
+        f = dict(dtype=torch.float32, device=self.device)
+        logp, val = torch.empty(n, **f), torch.empty(n, **f)
+        a = torch.as_tensor(value, **f).contiguous()
+        check(self.lib.ddrl_op_heads_act(byref(self._hd), _p(self.params), _p(ha), _p(hc), n, _p(a), 0, 0, _p(None), _p(val),
+                                         _p(None), _p(logp), _st()))
+        return logp
+
+    def add_critic(self, critic):
+        raise NotImplementedError("extra critics (RND / GAIL) are out of scope on this path")
+
+    def get_rnd(self, states):
+        raise NotImplementedError("RND is out of scope on this path")
+
+    def states_normalization(self, states):
+        return states / 255
+
+    # ---- learn (ppo.py:77-146) -----------------------------------------------------------------------
+    def _iter_chunk(self, st, n, actions, old_logps, advs, rets, b_global):
+        """forward + loss + backward of one micro-batch; gradients land in self.gtmp (overwritten)."""
+        ha, hc = self._features(st, n)
+        dha = self._dh[0]
+        dhc = dha if self.share_cnn_net else self._dh[1]
+        check(self.lib.ddrl_op_heads_loss(byref(self._hd), byref(self._cfg), _p(self.params), _p(ha), _p(hc), n, _p(actions),
+                                          _p(old_logps), _p(advs), _p(rets), b_global, _p(dha), _p(dhc), _p(self.gtmp),
+                                          _p(self._heads_ws), _st()))
+        self._encs[0].backward_dev(dha, n)
+        if not self.share_cnn_net:
+            self._encs[1].backward_dev(dhc, n)
+
+    def learn(self, data: Experience):
+        states = data.states if isinstance(data.states, (list, tuple)) else [data.states]
+        B = int(torch.as_tensor(states[0]).shape[0])
+        f32 = lambda t: torch.as_tensor(t, dtype=torch.float32, device=self.device).contiguous()
+        actions, old_logps, advs = f32(data.actions), f32(data.old_logps), f32(data.advs)
+        rets = f32(data.values)[0].contiguous()
+        assert rets.shape == (B,)
+        world = 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self._process_group)
+        total = self.n_params + STATS_FLOATS
+        for _ in range(self.training_iter_time):
+            t0 = time.time()
+            self._ensure_packed()
+            for ci, lo in enumerate(range(0, B, self.cap)):
+                hi = min(B, lo + self.cap)
+                self._iter_chunk(self._stage(states, lo, hi), hi - lo, actions[lo:hi], old_logps[lo:hi], advs[lo:hi],
+                                 rets[lo:hi], B * world)
+                if ci == 0:
+                    self.grads.copy_(self.gtmp)
+                else:
+                    check(self.lib.ddrl_op_accumulate(_p(self.grads), _p(self.gtmp), total, _st()))
+            if world > 1:
+                from ddrl4nav_amd.dist import allreduce_flat
+                allreduce_flat(self.grads, self._process_group)
+            self._step += 1
+            check(self.lib.ddrl_op_clip_adam(byref(self._cfg), _p(self.params), _p(self.grads), _p(self.adam_m),
+                                             _p(self.adam_v), self.n_params, self.n_actor, 1 if self.share_cnn_net else 0,
+                                             self._step, _p(self._adam_ws), _st()))
+            self._dirty = True
+            self.update_time += 1
+            s = self.grads[self.n_params:self.n_params + 6].cpu().numpy()
+            yield ({"PpoTotalLoss": float(s[3]), "ActorLoss": float(s[0]), "VLoss": float(s[1]), "EntLoss": float(s[2]),
+                    "PpoBackUpTime": time.time() - t0}, self.update_time, True)
+
+    def stats(self):
+        s = self.grads[self.n_params:self.n_params + 6].cpu().numpy()
+        return {"ActorLoss": float(s[0]), "VLoss": float(s[1]), "EntLoss": float(s[2]), "PpoTotalLoss": float(s[3]),
+                "GradNorm": float(s[4]), "ClipCoef": float(s[5])}
+
+
+class _CatOps:
+    """categorical_stats / categorical_sample provider for HipCategorical (same C entry points as HotPath)."""
+
+    def __init__(self, net):
+        self.lib = net.lib
+
+    def categorical_stats(self, probs):
+        n, A = probs.shape
+        p_hat, logits = torch.empty_like(probs), torch.empty_like(probs)
+        ent = torch.empty(n, dtype=torch.float32, device=probs.device)
+        check(self.lib.ddrl_categorical_stats(_p(probs), n, A, _p(p_hat), _p(logits), _p(ent), _st()))
+        return p_hat, logits, ent
+
+    def categorical_sample(self, probs, seed, stream_id):
+        n, A = probs.shape
+        action = torch.empty(n, dtype=torch.float32, device=probs.device)
+        logp = torch.empty(n, dtype=torch.float32, device=probs.device)
+        check(self.lib.ddrl_categorical_sample(_p(probs), n, A, int(seed) & (2 ** 64 - 1), int(stream_id) & (2 ** 64 - 1),
+                                               _p(action), _p(logp), _st()))
+        return action, logp

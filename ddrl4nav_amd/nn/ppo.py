@@ -27,9 +27,21 @@ def _frames_u8(states, device):
 
 
 class PPO(Basenn):
+    def __new__(cls, actor, critic, prenet=None, *args, **kwargs):
+        """``PPO(...)`` over anything but the Atari encoder is the operator-composed GenericPPO
+        (nn/generic.py): same constructor, same protocol."""
+        from ddrl4nav_amd.nn.atari_encoder import AtariPreNet
+        enc = prenet if prenet is not None else getattr(actor, "pre", None)
+        if cls is PPO and not isinstance(enc, AtariPreNet):
+            from ddrl4nav_amd.nn.generic import GenericPPO
+            return GenericPPO(actor, critic, prenet, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, actor, critic, prenet=None, rnd=None, config=None, config_nn=None, max_batch=None,
                  process_group=None):
         super().__init__(config, config_nn)
+        if hasattr(actor, "log_std"):
+            raise NotImplementedError("the Atari fast path has a Categorical actor only (reference atari.yaml)")
         if bool(config_nn.SHARE_CNN_NET) != (prenet is not None):
             raise ValueError("SHARE_CNN_NET=True needs a shared prenet (and pre-less actor / critic); "
                              "SHARE_CNN_NET=False needs prenet=None (reference runner/utils.py:122-143)")

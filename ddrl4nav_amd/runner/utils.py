@@ -6,7 +6,7 @@ size is looked up from a small table (Pong: 6)."""
 import yaml
 
 from ddrl4nav_amd.config import BaseConfig, ConfigNN
-from ddrl4nav_amd.nn import AtariPreNet, Basenn, Critic, PPO
+from ddrl4nav_amd.nn import AtariPreNet, Basenn, Critic, MLPPreNet, NavPedPreNet, NavPreNet, NavPreNet1D, PPO
 
 _ATARI_ACTIONS = {"Pong": 6, "Breakout": 4, "SpaceInvaders": 6, "Seaquest": 18, "Qbert": 6, "BeamRider": 9,
                   "Enduro": 9, "MsPacman": 9, "Boxing": 18, "Freeway": 3}
@@ -42,10 +42,10 @@ def create_net(configs, max_batch=None, process_group=None) -> Basenn:
     """atari branches of create_net (runner/utils.py:122-143,159-160): two encoders
     (SHARE_CNN_NET=False, the default) or one shared prenet."""
     config, config_nn, config_env = configs['config'], configs['config_nn'], configs['config_env']
-    if config.TASK_TYPE != 'atari':
-        raise NotImplementedError("only the atari task type is built (SURVEY.md section 8); got %s" % config.TASK_TYPE)
     if config_nn.NETWORK_TYPE != "ppo":
         raise NotImplementedError("NETWORK_TYPE=%s is not built (GAIL: SURVEY.md section 8f row 4)" % config_nn.NETWORK_TYPE)
+    if config.TASK_TYPE != 'atari':
+        return _create_generic_net(config, config_nn, config_env, max_batch, process_group)
     frames = config_env['int_frame_stack']
     if config_nn.SHARE_CNN_NET:
         actor = config_nn.ACTOR_CLASS(action_output_dim=config_nn.ACTION_OUTPUT_DIM, device=config_nn.DEVICE,
@@ -61,3 +61,39 @@ def create_net(configs, max_batch=None, process_group=None) -> Basenn:
                                   pre=pre_actor, nn_dtype=config_nn.MODULE_TENSOR_DTYPE)
     critic = Critic(device=config_nn.DEVICE, last_input_dim=config_nn.AC_INPUT_DIM, pre=pre_critic)
     return PPO(actor, critic, None, None, config, config_nn, max_batch=max_batch, process_group=process_group)
+
+
+def _create_generic_net(config, config_nn, config_env, max_batch, process_group):
+    """mujoco / classical (MLPPreNet) and robot_nav / gazebo_env / real_env (nav encoders) branches of
+    create_net (runner/utils.py:61-121), on the operator-composed GenericPPO."""
+    dim = config_nn.AC_INPUT_DIM
+
+    def heads(pre_a, pre_c):
+        actor = config_nn.ACTOR_CLASS(action_output_dim=config_nn.ACTION_OUTPUT_DIM, device=config_nn.DEVICE,
+                                      soft_max_grid=config_nn.SOFT_MAX_GRID, last_input_dim=dim, pre=pre_a,
+                                      nn_dtype=config_nn.MODULE_TENSOR_DTYPE)
+        return actor, Critic(device=config_nn.DEVICE, last_input_dim=dim, pre=pre_c)
+
+    if config.TASK_TYPE in ("mujoco", "classical"):
+        make = lambda: MLPPreNet(config_env.get('input_dim', 4), dim)
+        if config_nn.SHARE_CNN_NET:
+            actor, critic = heads(None, None)
+            prenet = make()
+        else:
+            actor, critic = heads(make(), make())
+            prenet = None
+    elif config.TASK_TYPE in ("robot_nav", "gazebo_env", "real_env"):
+        if config_nn.SHARE_CNN_NET:
+            actor, critic = heads(None, None)
+            if config_env['ped_sim']['total'] > 0:   # pedestrian map as extra image channels (utils.py:98-102)
+                prenet = NavPedPreNet(image_channel=config_env["image_batch"] + 3, last_output_dim=dim)
+            else:
+                prenet = NavPreNet(image_channel=config_env["image_batch"], last_output_dim=dim)
+        else:                                         # utils.py:110-121
+            actor, critic = heads(NavPreNet1D(image_channel=3, last_output_dim=dim),
+                                  NavPreNet1D(image_channel=3, last_output_dim=dim))
+            prenet = None
+    else:
+        raise NotImplementedError("task type %s has no network in the reference either (runner/utils.py:144-145)"
+                                  % config.TASK_TYPE)
+    return PPO(actor, critic, prenet, None, config, config_nn, max_batch=max_batch, process_group=process_group)

@@ -76,3 +76,22 @@ def flatten(weights, num_inputs=4, n_actions=6, shared=None):
         shared = any(k.startswith("prenet.") for k in weights)
     return np.concatenate([weights[n].reshape(-1)
                            for n, _, _ in param_specs(num_inputs, n_actions, shared)]).astype(np.float32)
+
+
+def hash_weights(named_shapes, seed=0):
+    """Deterministic weights for ANY module tree: ``named_shapes`` = [(name, shape)] in
+    named_parameters() order.  Weights and biases: uniform in +-1/sqrt(fan_in) like torch's default
+    init (a bias takes the fan-in of the weight before it); ``log_std`` tensors: -0.5 + uniform +-0.2."""
+    out, fan_in = {}, 1
+    for ti, (name, shape) in enumerate(named_shapes):
+        shape = tuple(int(d) for d in shape)
+        n = int(np.prod(shape)) if shape else 1
+        u = hash_uniform(seed, 1000 + ti, n)
+        if name.endswith("log_std"):
+            out[name] = (np.float32(-0.5) + (u * np.float32(2.0) - np.float32(1.0)) * np.float32(0.2)).astype(np.float32).reshape(shape)
+            continue
+        if len(shape) > 1:
+            fan_in = int(np.prod(shape[1:]))
+        bound = np.float32(1.0 / np.sqrt(np.float64(fan_in)))
+        out[name] = ((u * np.float32(2.0) - np.float32(1.0)) * bound).astype(np.float32).reshape(shape)
+    return out

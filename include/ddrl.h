@@ -273,6 +273,44 @@ int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* float
 int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
                              float* db, int32_t n, int32_t K, int32_t N, void* stream);
 
+/* Actor / critic heads on 512-wide encoder features (AC_INPUT_DIM, config_nn.py:23) with the PPO
+ * loss block and its backward, for nets assembled from the operators above.  `continuous` selects
+ * GaussionActor (USTC_lab/nn/actor.py:43-70: mu = Linear(h), std = exp(log_std), Normal, log-prob
+ * summed over action dims) instead of CategoricalActor (actor.py:73-101).  Offsets are positions
+ * (in floats) of the head parameters inside the caller's flat parameter / gradient arenas. */
+typedef struct ddrl_heads_desc {
+  int32_t continuous;  /* 0 = CategoricalActor (A <= 18), 1 = GaussionActor (D <= 8)          */
+  int32_t n_actions;   /* ACTION_OUTPUT_DIM                                                   */
+  int32_t shared;      /* SHARE_CNN_NET: both heads read h_actor, total_loss is differentiated */
+  int32_t reserved;
+  int64_t actor_w, actor_b, log_std, critic_w, critic_b; /* log_std: Gaussian only             */
+  int64_t n_params;    /* grads[n_params .. +8) receive the loss statistics (see ddrl_ppo_iter) */
+} ddrl_heads_desc;
+
+int32_t ddrl_op_heads_ws_floats(const ddrl_heads_desc* d, int32_t max_n, int64_t* floats);
+/* h_actor / h_critic: [n][512].  dist_out: probs [n][A] (categorical) or mu [n][D] (Gaussian).
+ * act_in == NULL: sample (categorical: inverse CDF on the counter-based uniform stream, as
+ * ddrl_forward; Gaussian: mu + std * Box-Muller normal of the same stream); action_out is [n] or [n][D]. */
+int32_t ddrl_op_heads_act(const ddrl_heads_desc* d, const float* params, const float* h_actor, const float* h_critic,
+                          int32_t n, const float* act_in, uint64_t seed, uint64_t stream_id, float* dist_out, float* value,
+                          float* action_out, float* logp_out, void* stream);
+/* Loss terms of PPO.learn (ppo.py:82-108) for this shard scaled by 1/B_global, d(loss)/d(h) into
+ * dh_actor / dh_critic (shared: both into dh_actor), head parameter gradients and the loss
+ * statistics into `grads` (overwritten at the head offsets). */
+int32_t ddrl_op_heads_loss(const ddrl_heads_desc* d, const ddrl_config* cfg, const float* params, const float* h_actor,
+                           const float* h_critic, int32_t n, const float* actions, const float* old_logps, const float* advs,
+                           const float* rets, int64_t B_global, float* dh_actor, float* dh_critic, float* grads, float* ws,
+                           void* stream);
+/* clip_grad_norm_ + Adam (two lr groups split at n_actor, or one when shared) on flat arenas;
+ * `step` is the 1-based Adam step count; ws = ddrl_op_clip_adam_ws_bytes bytes. */
+int32_t ddrl_op_clip_adam_ws_bytes(int64_t* bytes);
+int32_t ddrl_op_clip_adam(const ddrl_config* cfg, float* params, float* grads, float* m, float* v, int64_t n_params,
+                          int64_t n_actor, int32_t shared, int64_t step, void* ws, void* stream);
+/* d[b][k] = 0 where act[b][k] <= 0: ReLU backward for an encoder whose OUTPUT is a ReLU (MLPPreNet) */
+int32_t ddrl_op_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int32_t n, int32_t width, void* stream);
+/* dst[i] += src[i]: gradient accumulation over micro-batches */
+int32_t ddrl_op_accumulate(float* dst, const float* src, int64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,47 @@ def test_f12_eighteen_actions(golden):
     assert np.array_equal(net.actor.actor_linear.weight.grad.numpy(), g["grad_actor_linear_w"])
     net.zero_grad()
     _check_learn(O.learn(net, net.make_optims(), x, t("actions"), t("old_logps"), t("advs"), t("rets")), g)
+
+
+# ---- non-Atari nets (tests/golden/make_golden_nav.py) ---------------------------------------------
+def _nav_case(name):
+    from oracle import ddrl_oracle_nav as N
+    return {"f13_nav1d_gauss": (lambda: N.NavPreNet1D(3), 2, True, False, 13),
+            "f14_navped_shared": (lambda: N.NavPedPreNet(4), 5, False, True, 14),
+            "f15_mlp_classical": (lambda: N.MLPPreNet(4, 512), 2, False, False, 15)}[name]
+
+
+@pytest.mark.parametrize("name", ["f13_nav1d_gauss", "f14_navped_shared", "f15_mlp_classical"])
+def test_nav_oracle_pinned_to_reference(golden, name):
+    from ddrl4nav_amd.utils.recipe import hash_weights
+    from oracle import ddrl_oracle_nav as N
+    g = golden(name)
+    make_pre, n_out, gaussian, shared, seed = _nav_case(name)
+    torch.set_num_threads(1)
+    net = N.OracleNet(make_pre, n_out, gaussian, shared)
+    names = [k for k, _ in net.named_parameters()]
+    assert names == list(g["names"])  # same module tree / parameter order as the reference
+    net.load_weights(hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed))
+    states = [torch.from_numpy(g["state%d" % i]) for i in range(len([k for k in g.files if k.startswith("state")]))]
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        dist_out, logp, ent_el, v = net(states, t("actions"))
+    assert np.array_equal(dist_out.numpy(), g["dist_out"]) and np.array_equal(v.numpy()[:, 0], g["value"])
+    assert np.array_equal(logp.numpy(), g["logp"]) and np.array_equal(ent_el.numpy(), g["entropy"])
+    total, al, vl, ent = N.losses(net, states, t("actions"), t("old_logps"), t("advs"), t("rets"))
+    np.testing.assert_allclose([total.item(), al.item(), vl.item(), ent.item()], g["loss4"], rtol=1e-7, atol=0)
+    if shared:
+        total.backward()
+    else:
+        al.backward()
+        vl.backward()
+    for k, p in net.named_parameters():
+        flat = p.grad.numpy().reshape(-1)
+        np.testing.assert_allclose(flat[::max(1, flat.size // 129)][:129], g["gstride/" + k], rtol=1e-6, atol=1e-10)
+    net.zero_grad()
+    it = 0
+    for it, (ld, ut, last) in enumerate(N.learn(net, net.make_optims(), states, t("actions"), t("old_logps"), t("advs"),
+                                                t("rets")), 1):
+        got = [ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]]
+        np.testing.assert_allclose(got, g["losses"][it - 1], rtol=2e-6, atol=2e-7)
+    assert it == 10

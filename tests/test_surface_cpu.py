@@ -21,8 +21,9 @@ def test_config_nn_contract_matches_reference():
         assert getattr(cfg, k) == v, k
     from ddrl4nav_amd.nn import CategoricalActor
     assert cfg.ACTOR_CLASS is CategoricalActor
-    with pytest.raises(NotImplementedError):
-        ConfigNN({"discrete_action": False, "act_dim": 2})
+    from ddrl4nav_amd.nn import GaussionActor
+    cont = ConfigNN({"discrete_action": False, "act_dim": 2})   # config_nn.py:15-17
+    assert cont.ACTOR_CLASS is GaussionActor and cont.ACTION_OUTPUT_DIM == 2 and cont.ACTIONS_DIM == 2
 
 
 def test_base_config_and_game_type():
