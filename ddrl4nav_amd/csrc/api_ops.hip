@@ -127,10 +127,10 @@ int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, flo
 }
 
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act, float* out,
-                               int64_t ld_out, int32_t n, int32_t K, int32_t N, void* stream) {
+                               int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, void* stream) {
   if (!lin_ok(n, K, N) || !in || !wt || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   if ((ld_in & 3) || ld_in < (K + 3) / 4 * 4 || ld_out < N || !aligned16(in) || !aligned16(wt)) return DDRL_ERR_INVALID_ARG;
-  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, (hipStream_t)stream);
+  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, ws, (hipStream_t)stream);
   return op_check();
 }
 
@@ -144,7 +144,9 @@ int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn
 
 int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats) {
   if (!lin_ok(n, K, N) || !floats) return DDRL_ERR_INVALID_ARG;
-  *floats = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);
+  const int64_t wg = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);
+  const int64_t fw = (int64_t)linear_fwd_splits(n, K, N) * n * N;  // split-K partials of the forward
+  *floats = wg > fw ? wg : fw;
   return DDRL_OK;
 }
 

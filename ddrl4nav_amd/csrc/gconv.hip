@@ -19,11 +19,14 @@ namespace ddrl {
 
 namespace gconv {
 
-constexpr int LDA = 68, LDB = 260;  // k-major tiles A[32][64+4], B[32][256+4]
-constexpr int A_FLOATS = 32 * LDA, B_FLOATS = 32 * LDB;
+// k-block depth: 16 keeps two stages at 42 KB of LDS, i.e. 2-3 workgroups per CU (32 would be
+// 83 KB -> one workgroup, one wave per SIMD, nothing to hide the gather latency behind)
+constexpr int KBLK = 16;
+constexpr int LDA = 68, LDB = 260;  // k-major tiles A[KBLK][64+4], B[KBLK][256+4]
+constexpr int A_FLOATS = KBLK * LDA, B_FLOATS = KBLK * LDB;
 
 struct Common {
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
+  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = KBLK / 2;
   static constexpr int A_OFF = 0, B_OFF = A_FLOATS, STAGE = A_FLOATS + B_FLOATS;
   int abase[2], bbase[2], kb_begin, kb_end;
   int l31, hi, wc;
@@ -60,8 +63,8 @@ struct Gather : Common {
     int act;  // forward: 0 none, 1 relu
   };
   struct Regs {
-    f4 a[2];
-    float b[32];
+    f4 a;
+    float b[KBLK];
     unsigned ok;
   };
   int c0, r0;
@@ -75,8 +78,8 @@ struct Gather : Common {
     c0 = blockIdx.x * 256;
     r0 = blockIdx.y * 64;
     kb_begin = 0;
-    kb_end = (p.K + 31) / 32;
-    wp = p.wp + (int64_t)blockIdx.y * kb_end * 2048;
+    kb_end = (p.K + KBLK - 1) / KBLK;
+    wp = p.wp + (int64_t)blockIdx.y * kb_end * (KBLK * 64);
     const int P = DGRAD ? g.h * g.w : g.oh * g.ow;
     const int cw = DGRAD ? g.w : g.ow;
     const int64_t col = (int64_t)c0 + tid;
@@ -97,12 +100,11 @@ struct Gather : Common {
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
     const ConvGeom& g = p.g;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) r.a[j] = ld4(wp + (int64_t)kb * 2048 + (tid + 256 * j) * 4);
+    r.a = ld4(wp + (int64_t)kb * (KBLK * 64) + tid * 4);
     r.ok = 0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int2 e = p.ktab[kb * 32 + j];  // uniform
+    for (int j = 0; j < KBLK; ++j) {
+      const int2 e = p.ktab[kb * KBLK + j];  // uniform
       const int ky = e.y >> 16, kx = e.y & 0xffff;
       bool ok;
       int64_t off;
@@ -121,13 +123,9 @@ struct Gather : Common {
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
+    st4(buf + A_OFF + (tid >> 4) * LDA + (tid & 15) * 4, r.a);  // f4 index tid inside [KBLK][64]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = tid + 256 * j;  // f4 index inside [32][64]
-      st4(buf + A_OFF + (idx >> 4) * LDA + (idx & 15) * 4, r.a[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) buf[B_OFF + j * LDB + tid] = ((r.ok >> j) & 1u) ? r.b[j] : 0.0f;
+    for (int j = 0; j < KBLK; ++j) buf[B_OFF + j * LDB + tid] = ((r.ok >> j) & 1u) ? r.b[j] : 0.0f;
   }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
     const ConvGeom& g = p.g;
@@ -159,10 +157,10 @@ struct Gather : Common {
 };
 
 // part[s][co][tap] = sum over the split's (b, oy, ox) of dz[b][co][oy][ox] * in[b][ci][oy*S+ky-ph][ox*S+kx-pw]
-// followed by the bias partial [cout].  Requires oh*ow >= 32.
+// followed by the bias partial [cout].  Requires oh*ow >= KBLK.
 struct Wgrad : Common {
   static constexpr int LDAW = 65;  // A tile written along k by consecutive lanes: odd stride
-  static constexpr int B_OFFW = 32 * LDAW, STAGE = B_OFFW + B_FLOATS;
+  static constexpr int B_OFFW = KBLK * LDAW, STAGE = B_OFFW + B_FLOATS;
   struct Params {
     ConvGeom g;
     const float* in;
@@ -173,13 +171,13 @@ struct Wgrad : Common {
     int nsplit;
   };
   struct Regs {
-    float a[8], b[32];
+    float a[4], b[KBLK];
     unsigned oka, okb;
   };
   int r0, t0, split;
   int tapoff, tky, tkx;  // this thread's tap (column)
   bool tapok;
-  float bacc[8];
+  float bacc[4];
   static constexpr int aoff(int s) { return 2 * s * LDAW; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     const ConvGeom& g = p.g;
@@ -195,7 +193,7 @@ struct Wgrad : Common {
     r0 = blockIdx.y * 64;
     split = blockIdx.z;
     const int64_t ktot = (int64_t)g.n * g.oh * g.ow;
-    const int nkb = (int)((ktot + 31) / 32);
+    const int nkb = (int)((ktot + KBLK - 1) / KBLK);
     const int per = (nkb + p.nsplit - 1) / p.nsplit;
     kb_begin = min(nkb, split * per);
     kb_end = min(nkb, kb_begin + per);
@@ -208,17 +206,17 @@ struct Wgrad : Common {
     tkx = rr % g.kw - g.pad_w;
     tapoff = ci * g.h * g.w + tky * g.w + tkx;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bacc[j] = 0.0f;
+    for (int j = 0; j < 4; ++j) bacc[j] = 0.0f;
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     const int tid = threadIdx.x;
     const ConvGeom& g = p.g;
     const int P = g.oh * g.ow;
-    const int64_t k0 = (int64_t)kb * 32;
+    const int64_t k0 = (int64_t)kb * KBLK;
     const int bu = (int)(k0 / P), remu = (int)(k0 % P);  // uniform
-    // ---- A: dz[b][row][pix], this thread: k = tid & 31, rows (tid >> 5) + 8 j ----
+    // ---- A: dz[b][row][pix], this thread: k = tid & 15, rows (tid >> 4) + 16 j ----
     {
-      const int kk = tid & 31, rr = tid >> 5;
+      const int kk = tid & (KBLK - 1), rr = tid >> 4;
       int pix = remu + kk, b = bu;
       if (pix >= P) {
         pix -= P;
@@ -228,8 +226,8 @@ struct Wgrad : Common {
       const int64_t base = (int64_t)(kok ? b : 0) * g.out_sn + pix;
       r.oka = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int row = r0 + rr + 8 * j;
+      for (int j = 0; j < 4; ++j) {
+        const int row = r0 + rr + 16 * j;
         const bool ok = kok && row < g.cout;
         r.a[j] = p.dz[ok ? base + (int64_t)row * P : 0];
         r.oka |= (ok ? 1u : 0u) << j;
@@ -238,7 +236,7 @@ struct Wgrad : Common {
     // ---- B: in[b][tap], k = j (uniform pixel), this thread's tap ----
     r.okb = 0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < KBLK; ++j) {
       int pix = remu + j, b = bu;  // uniform
       if (pix >= P) {
         pix -= P;
@@ -254,15 +252,15 @@ struct Wgrad : Common {
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
-    const int kk = tid & 31, rr = tid >> 5;
+    const int kk = tid & (KBLK - 1), rr = tid >> 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const float v = ((r.oka >> j) & 1u) ? r.a[j] : 0.0f;
-      buf[kk * LDAW + rr + 8 * j] = v;
+      buf[kk * LDAW + rr + 16 * j] = v;
       bacc[j] += v;
     }
 #pragma unroll
-    for (int j = 0; j < 32; ++j) buf[B_OFFW + j * LDB + tid] = ((r.okb >> j) & 1u) ? r.b[j] : 0.0f;
+    for (int j = 0; j < KBLK; ++j) buf[B_OFFW + j * LDB + tid] = ((r.okb >> j) & 1u) ? r.b[j] : 0.0f;
   }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
     const ConvGeom& g = p.g;
@@ -279,15 +277,15 @@ struct Wgrad : Common {
           if (row < g.cout) slab[(int64_t)row * p.KT + tap] = acc[i][j][r];
         }
     }
-    if (blockIdx.x == 0) {  // bias partial: sum this half-wave's 32 k lanes for its 8 rows
-      const int rr = threadIdx.x >> 5;
+    if (blockIdx.x == 0) {  // bias partial: sum the 16 k lanes that share this thread's 4 rows
+      const int rr = threadIdx.x >> 4;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 4; ++j) {
         float s = bacc[j];
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        const int row = r0 + rr + 8 * j;
-        if ((threadIdx.x & 31) == 0 && row < g.cout) slab[(int64_t)g.cout * p.KT + row] = s;
+        for (int off = KBLK / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        const int row = r0 + rr + 16 * j;
+        if ((threadIdx.x & (KBLK - 1)) == 0 && row < g.cout) slab[(int64_t)g.cout * p.KT + row] = s;
       }
     }
   }
@@ -295,32 +293,33 @@ struct Wgrad : Common {
 
 }  // namespace gconv
 
-// wp[row tile][kb][kk][64]: forward  A(row = co, k = (ci,ky,kx)) = W[co][ci][ky][kx]
+// wp[row tile][kb][kk < KBLK][64]: forward  A(row = co, k = (ci,ky,kx)) = W[co][ci][ky][kx]
 //                           dgrad    A(row = ci, k = (co,ky,kx)) = W[co][ci][ky][kx]
 // ktab: forward  {ci*H*W + ky*W + kx, ky<<16|kx};  dgrad {co*OH*OW, ky<<16|kx}
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, ConvGeom g, float* __restrict__ wpf,
                                                         int2* __restrict__ ktf, float* __restrict__ wpd, int2* __restrict__ ktd) {
   const int khw = g.kh * g.kw;
   const int Kf = g.cin * khw, Kd = g.cout * khw;
-  const int kbf = (Kf + 31) / 32, kbd = (Kd + 31) / 32;
+  constexpr int KB = gconv::KBLK;
+  const int kbf = (Kf + KB - 1) / KB, kbd = (Kd + KB - 1) / KB;
   const int rtf = (g.cout + 63) / 64, rtd = (g.cin + 63) / 64;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < (int64_t)rtf * kbf * 2048) {
-    const int row = (int)(i & 63), k = (int)((i >> 6) % (kbf * 32)), rt = (int)((i >> 6) / (kbf * 32));
+  if (i < (int64_t)rtf * kbf * (KB * 64)) {
+    const int row = (int)(i & 63), k = (int)((i >> 6) % (kbf * KB)), rt = (int)((i >> 6) / (kbf * KB));
     const int co = rt * 64 + row;
     wpf[i] = (co < g.cout && k < Kf) ? w[(int64_t)co * Kf + k] : 0.0f;
   }
-  if (i < (int64_t)rtd * kbd * 2048) {
-    const int row = (int)(i & 63), k = (int)((i >> 6) % (kbd * 32)), rt = (int)((i >> 6) / (kbd * 32));
+  if (i < (int64_t)rtd * kbd * (KB * 64)) {
+    const int row = (int)(i & 63), k = (int)((i >> 6) % (kbd * KB)), rt = (int)((i >> 6) / (kbd * KB));
     const int ci = rt * 64 + row;
     const int co = k / khw, r = k % khw;
     wpd[i] = (ci < g.cin && k < Kd) ? w[((int64_t)co * g.cin + ci) * khw + r] : 0.0f;
   }
-  if (i < kbf * 32) {
+  if (i < kbf * KB) {
     const int k = (int)i, ci = k / khw, r = k % khw, ky = r / g.kw, kx = r % g.kw;
     ktf[i] = k < Kf ? make_int2(ci * g.h * g.w + ky * g.w + kx, (ky << 16) | kx) : make_int2(0, 0x7fff << 16);
   }
-  if (i < kbd * 32) {
+  if (i < kbd * KB) {
     const int k = (int)i, co = k / khw, r = k % khw, ky = r / g.kw, kx = r % g.kw;
     ktd[i] = k < Kd ? make_int2(co * g.oh * g.ow, (ky << 16) | kx) : make_int2(0, 0x7fff << 16);
   }
@@ -383,11 +382,12 @@ bool conv_geom_fill(ConvGeom& g) {
 // float counts of the packed buffers: wpf, ktf (int2 = 2 floats each), wpd, ktd, ptab
 void conv_pack_sizes(const ConvGeom& g, int64_t out[5]) {
   const int khw = g.kh * g.kw;
-  const int kbf = (g.cin * khw + 31) / 32, kbd = (g.cout * khw + 31) / 32;
-  out[0] = (int64_t)((g.cout + 63) / 64) * kbf * 2048;
-  out[1] = (int64_t)kbf * 32 * 2;
-  out[2] = (int64_t)((g.cin + 63) / 64) * kbd * 2048;
-  out[3] = (int64_t)kbd * 32 * 2;
+  constexpr int KB = gconv::KBLK;
+  const int kbf = (g.cin * khw + KB - 1) / KB, kbd = (g.cout * khw + KB - 1) / KB;
+  out[0] = (int64_t)((g.cout + 63) / 64) * kbf * (KB * 64);
+  out[1] = (int64_t)kbf * KB * 2;
+  out[2] = (int64_t)((g.cin + 63) / 64) * kbd * (KB * 64);
+  out[3] = (int64_t)kbd * KB * 2;
   out[4] = (int64_t)g.oh * g.ow;
 }
 
@@ -416,8 +416,8 @@ int conv_wgrad_splits(const ConvGeom& g) {
   const int KT = g.cin * g.kh * g.kw;
   const int tiles = ((KT + 255) / 256) * ((g.cout + 63) / 64);
   int s = (768 + tiles - 1) / tiles;
-  const int64_t nkb = ((int64_t)g.n * g.oh * g.ow + 31) / 32;
-  const int64_t cap = (nkb + 3) / 4;  // at least 4 k-blocks per split
+  const int64_t nkb = ((int64_t)g.n * g.oh * g.ow + gconv::KBLK - 1) / gconv::KBLK;
+  const int64_t cap = (nkb + 7) / 8;  // at least 8 k-blocks per split
   if (s > cap) s = (int)cap;
   return s < 1 ? 1 : s;
 }

@@ -90,20 +90,25 @@ struct Fwd : Common {
     float* out;
     int64_t ld_out;
     int n, K, N, act;  // act: 0 none, 1 relu
+    int nsplit;        // > 1: split-K, bias-free partial sums part[split][b][N] (small n x N: fills the GPU)
+    float* part;
   };
   struct Regs {
     f4 a[4], b[4];
     unsigned ok;
   };
-  int b0, n0;
+  int b0, n0, split;
   static constexpr int aoff(int s) { return 2 * s; }
   static constexpr int boff(int s) { return 2 * s * KTile::LD; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
     n0 = blockIdx.x * 128;
     b0 = blockIdx.y * 128;
-    kb_begin = 0;
-    kb_end = (p.K + 31) / 32;
+    split = blockIdx.z;
+    const int nkb = (p.K + 31) / 32;
+    const int per = (nkb + p.nsplit - 1) / p.nsplit;
+    kb_begin = min(nkb, split * per);
+    kb_end = min(nkb, kb_begin + per);
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowTile::LD + hi;
 #pragma unroll
@@ -122,6 +127,17 @@ struct Fwd : Common {
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wc * 64 + j * 32 + l31;
       if (n >= p.N) continue;
+      if (p.nsplit > 1) {
+        float* dst = p.part + (int64_t)split * p.n * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+            if (b < p.n) dst[(int64_t)b * p.N + n] = acc[i][j][r];
+          }
+        continue;
+      }
       const float bias = p.bias[n];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -331,10 +347,37 @@ void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipS
   hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N, Kp32, Kp4, wt, wn);
 }
 
+// out[b][n] = act(bias[n] + sum_s part[s][b][n])   (fixed order)
+__global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restrict__ part, int nsplit, int64_t n, int N,
+                                                            const float* __restrict__ bias, int act, float* __restrict__ out,
+                                                            int64_t ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * N) return;
+  const int64_t b = i / N;
+  const int c = (int)(i % N);
+  float s = 0.0f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * n * N + i];
+  s += bias[c];
+  if (act == 1) s = fmaxf(s, 0.0f);
+  out[b * ld_out + c] = s;
+}
+
+int linear_fwd_splits(int n, int K, int N) {
+  const int tiles = ((N + 127) / 128) * ((n + 127) / 128);
+  int s = (512 + tiles - 1) / tiles;
+  const int cap = ((K + 31) / 32) / 8;  // at least 8 k-blocks per split
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
+
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
-                       int K, int N, int act, hipStream_t st) {
-  glin::Fwd::Params p{in, ld_in, wt, bias, out, ld_out, n, K, N, act};
-  launch_engine2<glin::Fwd>(dim3((N + 127) / 128, (n + 127) / 128, 1), p, st);
+                       int K, int N, int act, float* part, hipStream_t st) {
+  const int S = part ? linear_fwd_splits(n, K, N) : 1;
+  glin::Fwd::Params p{in, ld_in, wt, bias, out, ld_out, n, K, N, act, S, part};
+  launch_engine2<glin::Fwd>(dim3((N + 127) / 128, (n + 127) / 128, S), p, st);
+  if (S > 1)
+    hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)(((int64_t)n * N + 255) / 256)), dim3(256), 0, st, part, S,
+                       (int64_t)n, N, bias, act, out, ld_out);
 }
 
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,

@@ -27,8 +27,9 @@ void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int
 void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);
 void launch_accumulate(float* dst, const float* src, int64_t count, hipStream_t st);
 void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st);
+int linear_fwd_splits(int n, int K, int N);
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
-                       int K, int N, int act, hipStream_t st);
+                       int K, int N, int act, float* part, hipStream_t st);
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
                          float* din, int64_t ld_din, int n, int K, int N, hipStream_t st);
 int linear_wgrad_splits(int n, int K, int N);

@@ -104,8 +104,9 @@ class Linear:
         check(self.lib.ddrl_op_linear_pack(_p(_f32(weight)), self.K, self.N, _p(self.wt), _p(self.wn), _st()))
 
     def forward(self, x, ld_in, bias, relu, out, ld_out, n):
+        assert n <= self.max_n
         check(self.lib.ddrl_op_linear_forward(_p(x), ld_in, _p(self.wt), _p(_f32(bias)), 1 if relu else 0, _p(out), ld_out,
-                                              n, self.K, self.N, _st()))
+                                              n, self.K, self.N, _p(self.ws), _st()))
         return out
 
     def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n):

@@ -262,8 +262,10 @@ int32_t ddrl_op_maxpool2_relu_backward(const float* a, const float* dpool, int64
  * wt / wn = derived layouts written by ddrl_op_linear_pack (sizes from ddrl_op_linear_pack_floats). */
 int32_t ddrl_op_linear_pack_floats(int32_t K, int32_t N, int64_t* wt_floats, int64_t* wn_floats);
 int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, float* wn, void* stream);
+/* ws: scratch of ddrl_op_linear_ws_floats(n, K, N) floats (lets small n x N problems split K over
+ * workgroups), or NULL for a single pass. */
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act,
-                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, void* stream);
+                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, void* stream);
 /* din[b][k] = [mask_src[b][k] > 0 or mask_src == NULL] * sum_n dout[b][n] W[n][k]; mask_src is the
  * (ReLU) output of the layer that produced `in`. */
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,

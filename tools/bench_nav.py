@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Measurement of the operator-composed robot_nav net (BASELINE config 4 shape: NavPreNet1D x2 +
+GaussionActor(2) + Critic): PPO iterations on synthetic inputs, per-operator HIP-event times and
+algorithmic TFLOP/s.  Not the headline bench (bench.py is); prints one JSON line.
+
+Usage: python tools/bench_nav.py [B] [micro_batch] [iters]"""
+import json
+import sys
+import time
+import types
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from ddrl4nav_amd import ops  # noqa: E402
+from ddrl4nav_amd.config import BaseConfig, ConfigNN  # noqa: E402
+from ddrl4nav_amd.data import Experience  # noqa: E402
+from ddrl4nav_amd.runner import create_net  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+CAP = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+
+events = []
+
+
+def timed(name, flop_fn, fn):
+    def wrap(self, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(self, *a, **k)
+        e1.record()
+        events.append((name(self), flop_fn(self, *a, **k), e0, e1))
+        return out
+    return wrap
+
+
+def conv_name(kind):
+    return lambda c: "conv%dx%d_%d->%d_%s" % (c.kh, c.kw, c.cin, c.cout, kind)
+
+
+def conv_flop(c, *a, n=None, **k):
+    n = n if n is not None else a[0].shape[0]
+    return 2.0 * n * c.oh * c.ow * c.cout * c.cin * c.kh * c.kw
+
+
+def lin_name(kind):
+    return lambda l: "linear_%d->%d_%s" % (l.K, l.N, kind)
+
+
+def lin_flop(l, *a, **k):
+    return 2.0 * a[-1] * l.K * l.N
+
+
+ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
+ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
+ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
+ops.Linear.forward = timed(lin_name("fwd"), lin_flop, ops.Linear.forward)
+ops.Linear.dgrad = timed(lin_name("dgrad"), lin_flop, ops.Linear.dgrad)
+ops.Linear.wgrad = timed(lin_name("wgrad"), lin_flop, ops.Linear.wgrad)
+
+env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "discrete_action": False, "act_dim": 2,
+       "image_batch": 1, "ped_sim": {"total": 3}}
+cfg = BaseConfig(types.SimpleNamespace(task="bench", ip="127.0.0.1"), env)
+cfg.TASK_TYPE = "robot_nav"
+cfg_nn = ConfigNN(env)
+cfg_nn.TRAINING_ITER_TIME = ITERS
+net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=CAP)
+g = torch.Generator(device="cuda")
+g.manual_seed(4)
+states = [torch.rand((B, 1, 960), device="cuda", generator=g), torch.randn((B, 5), device="cuda", generator=g),
+          (torch.rand((B, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
+(dist, _), values = net([s[:CAP] for s in states])
+exp = Experience(states=states, advs=torch.randn(B, device="cuda", generator=g),
+                 actions=torch.randn((B, 2), device="cuda", generator=g), old_logps=torch.full((B,), -2.0, device="cuda"),
+                 values=torch.randn((1, B), device="cuda", generator=g))
+for _ in net.learn(exp):  # warm-up (also sizes every lazily created buffer)
+    pass
+events.clear()
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in net.learn(exp):
+    pass
+torch.cuda.synchronize()
+wall = (time.time() - t0) / ITERS
+agg = defaultdict(lambda: [0.0, 0.0, 0])
+for name, flop, e0, e1 in events:
+    a = agg[name]
+    a[0] += e0.elapsed_time(e1)
+    a[1] += flop
+    a[2] += 1
+rows = {k: {"ms_per_iter": round(v[0] / ITERS, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "calls_per_iter": v[2] // ITERS}
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+tot_ms = sum(v[0] for v in agg.values()) / ITERS
+tot_flop = sum(v[1] for v in agg.values()) / ITERS
+print(json.dumps({"workload": "robot_nav: NavPreNet1D x2 + GaussionActor(2), PPO iteration", "B": B, "micro_batch": CAP,
+                  "ms_per_ppo_iter_wall": round(wall * 1e3, 2), "gemm_ops_ms_per_iter": round(tot_ms, 2),
+                  "algorithmic_tflops_over_gemm_ops": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
+                  "samples_per_s": round(B / wall, 1), "ops": rows}))
