@@ -133,3 +133,41 @@ def test_gloo_world2_gradient_allreduce_equals_full_batch():
     got = outs[0][2]
     assert np.abs(got[:-3] - full).max() <= 2e-6 * np.abs(full).max()
     np.testing.assert_allclose(got[-3:], [al.item(), vl.item(), ent.item()], rtol=1e-5, atol=1e-7)
+
+
+def test_generic_net_parameter_trees_match_reference(golden):
+    """Module trees of the operator-composed nets (no GPU needed to build the parameter holders):
+    names and order equal the reference's named_parameters() (fixtures f13-f15 store them)."""
+    from ddrl4nav_amd.nn import (CategoricalActor, Critic, GaussionActor, MLPPreNet, NavPedPreNet, NavPreNet, NavPreNet1D)
+    from torch import nn
+
+    class Tree(nn.Module):  # PPO's registration order (ppo.py:26-28): prenet, actor, critic
+        def __init__(self, prenet, actor, critic):
+            super().__init__()
+            self.prenet, self.actor, self.critic = prenet, actor, critic
+
+    t13 = Tree(None, GaussionActor(action_output_dim=2, pre=NavPreNet1D(3)), Critic(pre=NavPreNet1D(3)))
+    assert [k for k, _ in t13.named_parameters()] == list(golden("f13_nav1d_gauss")["names"])
+    t14 = Tree(NavPedPreNet(4), CategoricalActor(action_output_dim=5), Critic())
+    assert [k for k, _ in t14.named_parameters()] == list(golden("f14_navped_shared")["names"])
+    t15 = Tree(None, CategoricalActor(action_output_dim=2, pre=MLPPreNet(4, 512)), Critic(pre=MLPPreNet(4, 512)))
+    assert [k for k, _ in t15.named_parameters()] == list(golden("f15_mlp_classical")["names"])
+    n = NavPreNet(2)
+    assert n.fc0[0].in_features == 256 * 6 * 6 and n.fc1[0].in_features == 521 and n.conv1.in_channels == 2
+
+
+def test_create_net_rejects_unknown_task_and_needs_gpu():
+    import torch
+    from ddrl4nav_amd import _lib
+    from ddrl4nav_amd.config import BaseConfig, ConfigNN
+    from ddrl4nav_amd.runner import create_net
+    env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "discrete_action": True,
+           "discrete_actions": [0, 1], "input_dim": 4}
+    cfg = BaseConfig(types.SimpleNamespace(task="t", ip="127.0.0.1"), env)
+    cfg.TASK_TYPE = "no_such_task"
+    with pytest.raises(NotImplementedError):
+        create_net({"config": cfg, "config_nn": ConfigNN(env), "config_env": env})
+    if not torch.cuda.is_available():
+        cfg.TASK_TYPE = "classical"
+        with pytest.raises(_lib.DdrlError):   # no CPU fallback for the generic nets either
+            create_net({"config": cfg, "config_nn": ConfigNN(env), "config_env": env})
