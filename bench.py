@@ -34,6 +34,14 @@ MAC = {"ConvFwd1": 32 * 400 * 256, "ConvFwd2": 64 * 81 * 512, "ConvFwd3": 64 * 4
 FLOP_ACT_PER_STEP = 37_379_072          # per env-step, both encoders + heads
 FLOP_TRAIN_PER_SAMPLE = 99_030_016      # per sample per PPO iteration
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense f32-input MFMA = fp32 vector peak
+PEAK_HBM_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# algorithmic HBM bytes per launch of the HBM-bound kernels, f(N envs, B samples, P params)
+HBM_BYTES = {
+    "heads_loss": lambda N, B, P: B * (2 * 2 * 512 * 4 + 72),       # read h, write dh (both heads) + loss operands
+    "heads_act": lambda N, B, P: N * (2 * 512 * 4 + 36),            # read h of both encoders, write probs/value/action/logp
+    "clip_adam": lambda N, B, P: P * 32,                            # norm read + p,g,m,v read + p,m,v write
+    "pack_weights": lambda N, B, P: P * 4 * 3,                      # read params, write two derived layouts (approx.)
+}
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -208,6 +216,12 @@ def main():
                 per_launch = 2 * 2 * MAC[base] * (N if k.endswith(".act") else B)
                 ent["tflops"] = round(per_launch * calls / (ms * 1e-3) / 1e12, 2)
                 ent["flop_per_launch"] = per_launch
+            elif k in HBM_BYTES:
+                # HBM-bound kernels: algorithmic bytes per launch / launch time
+                per_launch = HBM_BYTES[k](N, B, hp.n_params)
+                ent["gbps"] = round(per_launch * calls / (ms * 1e-3) / 1e9, 1)
+                ent["bytes_per_launch"] = per_launch
+                ent["frac_of_hbm_peak"] = round(ent["gbps"] / PEAK_HBM_GBPS, 4)
             kernels[k] = ent
         # dominant kernel = largest accumulated time among the GEMM-shaped kernels
         gemm = {k: v for k, v in kernels.items() if k in MAC}

@@ -175,8 +175,10 @@ struct Wgrad : Common {
     unsigned oka, okb;
   };
   int r0, t0, split;
-  int tapoff, tky, tkx;  // this thread's tap (column)
-  bool tapok;
+  // Staging roles: this thread owns pixel k = tid & 15 of every k-block (so the 16 lanes of a
+  // group read 16 CONSECUTIVE pixels: coalesced) and the 16 taps (tid >> 4) + 16 j of the tile.
+  int tapoff[KBLK];   // ci*H*W + (ky-ph)*W + (kx-pw) of tap j
+  int tapyx[KBLK];    // ((ky-ph) << 16) | ((kx-pw) & 0xffff); ky = 0x4000 marks a tap >= KT
   float bacc[4];
   static constexpr int aoff(int s) { return 2 * s * LDAW; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
@@ -197,14 +199,17 @@ struct Wgrad : Common {
     const int per = (nkb + p.nsplit - 1) / p.nsplit;
     kb_begin = min(nkb, split * per);
     kb_end = min(nkb, kb_begin + per);
-    const int tap = t0 + tid;
-    tapok = tap < p.KT;
-    const int tt = tapok ? tap : 0;
     const int khw = g.kh * g.kw;
-    const int ci = tt / khw, rr = tt % khw;
-    tky = rr / g.kw - g.pad_h;
-    tkx = rr % g.kw - g.pad_w;
-    tapoff = ci * g.h * g.w + tky * g.w + tkx;
+#pragma unroll
+    for (int j = 0; j < KBLK; ++j) {
+      const int tap = t0 + (tid >> 4) + 16 * j;
+      const bool ok = tap < p.KT;
+      const int tt = ok ? tap : 0;
+      const int ci = tt / khw, rr = tt % khw;
+      const int ty = rr / g.kw - g.pad_h, tx = rr % g.kw - g.pad_w;
+      tapoff[j] = ci * g.h * g.w + ty * g.w + tx;
+      tapyx[j] = ok ? ((ty << 16) | (tx & 0xffff)) : (0x4000 << 16);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) bacc[j] = 0.0f;
   }
@@ -214,16 +219,17 @@ struct Wgrad : Common {
     const int P = g.oh * g.ow;
     const int64_t k0 = (int64_t)kb * KBLK;
     const int bu = (int)(k0 / P), remu = (int)(k0 % P);  // uniform
-    // ---- A: dz[b][row][pix], this thread: k = tid & 15, rows (tid >> 4) + 16 j ----
+    const int kk = tid & (KBLK - 1), rr = tid >> 4;
+    int pix = remu + kk, b = bu;  // this thread's k = (sample, output pixel)
+    if (pix >= P) {
+      pix -= P;
+      b += 1;
+    }
+    const bool kok = b < g.n;
+    const int bc = kok ? b : 0;
+    // ---- A: dz[b][row][pix], rows (tid >> 4) + 16 j ----
     {
-      const int kk = tid & (KBLK - 1), rr = tid >> 4;
-      int pix = remu + kk, b = bu;
-      if (pix >= P) {
-        pix -= P;
-        b += 1;
-      }
-      const bool kok = b < g.n;
-      const int64_t base = (int64_t)(kok ? b : 0) * g.out_sn + pix;
+      const int64_t base = (int64_t)bc * g.out_sn + pix;
       r.oka = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -233,21 +239,19 @@ struct Wgrad : Common {
         r.oka |= (ok ? 1u : 0u) << j;
       }
     }
-    // ---- B: in[b][tap], k = j (uniform pixel), this thread's tap ----
-    r.okb = 0;
-#pragma unroll
-    for (int j = 0; j < KBLK; ++j) {
-      int pix = remu + j, b = bu;  // uniform
-      if (pix >= P) {
-        pix -= P;
-        b += 1;
-      }
-      const int e = p.ptab[pix < P ? pix : 0];
+    // ---- B: in[b][ci][oy*S+ky-ph][ox*S+kx-pw] for this pixel and the thread's 16 taps ----
+    {
+      const int e = p.ptab[pix];
       const int iy = (e >> 16) * g.stride, ix = (e & 0xffff) * g.stride;
-      const bool ok = tapok && b < g.n && (unsigned)(iy + tky) < (unsigned)g.h && (unsigned)(ix + tkx) < (unsigned)g.w;
-      const int64_t off = (int64_t)b * g.in_sn + iy * g.w + ix + tapoff;
-      r.b[j] = p.in[ok ? off : 0];
-      r.okb |= (ok ? 1u : 0u) << j;
+      const int64_t base = (int64_t)bc * g.in_sn + iy * g.w + ix;
+      r.okb = 0;
+#pragma unroll
+      for (int j = 0; j < KBLK; ++j) {
+        const int ty = tapyx[j] >> 16, tx = (int)(short)(tapyx[j] & 0xffff);
+        const bool ok = kok && (unsigned)(iy + ty) < (unsigned)g.h && (unsigned)(ix + tx) < (unsigned)g.w;
+        r.b[j] = p.in[ok ? base + tapoff[j] : 0];
+        r.okb |= (ok ? 1u : 0u) << j;
+      }
     }
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
@@ -259,8 +263,9 @@ struct Wgrad : Common {
       buf[kk * LDAW + rr + 16 * j] = v;
       bacc[j] += v;
     }
+    // B[k][tap]: lanes differ in k (stride LDB = 260 -> bank 4k) and in tap (+1 per 16-lane group): no conflicts
 #pragma unroll
-    for (int j = 0; j < KBLK; ++j) buf[B_OFFW + j * LDB + tid] = ((r.okb >> j) & 1u) ? r.b[j] : 0.0f;
+    for (int j = 0; j < KBLK; ++j) buf[B_OFFW + kk * LDB + rr + 16 * j] = ((r.okb >> j) & 1u) ? r.b[j] : 0.0f;
   }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
     const ConvGeom& g = p.g;
