@@ -152,3 +152,28 @@ def test_ops_reject_bad_arguments():
     x = torch.zeros(4, 16).cuda()
     with pytest.raises(_lib.DdrlError):
         lin.forward(x, 15, torch.zeros(8).cuda(), False, torch.zeros(4, 8).cuda(), 8, 4)  # ld not a multiple of 4
+
+
+@pytest.mark.parametrize("shape", [(512, 3, 48, 48, 64, 7, 7, 1, (1, 1)), (512, 64, 22, 22, 128, 5, 5, 1, (1, 1)),
+                                   (512, 128, 10, 10, 256, 3, 3, 1, (1, 1)), (512, 32, 1, 478, 32, 1, 3, 2, (0, 0))])
+def test_conv_full_batch_size_vs_torch_gpu(shape):
+    """BASELINE config 4 batch (512 envs): the nav layers at n = 512 against torch's own GPU
+    convolution (MIOpen) -- a second, independent implementation at a size the CPU oracle would
+    take minutes for.  Both sides are fp32 with different summation orders."""
+    from ddrl4nav_amd.ops import Conv
+    n, cin, h, w, cout, kh, kw, s, pad = shape
+    g = torch.Generator(device="cuda").manual_seed(n + cin)
+    x = torch.randn(n, cin, h, w, device="cuda", generator=g).requires_grad_(True)
+    wt = (torch.randn(cout, cin, kh, kw, device="cuda", generator=g) / (cin * kh * kw) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, device="cuda", generator=g).requires_grad_(True)
+    z = F.conv2d(x, wt, b, stride=s, padding=pad)
+    dz = torch.randn(z.shape, device="cuda", generator=g)
+    z.backward(dz)
+    conv = Conv(cin, h, w, cout, kh, kw, stride=s, pad=pad, max_n=n)
+    conv.pack(wt.detach())
+    close(conv.forward(x.detach(), b.detach(), relu=False), z, tol=5e-5)
+    close(conv.dgrad(dz), x.grad, tol=5e-5)
+    dw, db = torch.empty_like(wt.detach()), torch.empty_like(b.detach())
+    conv.wgrad(x.detach(), dz, dw, db)
+    close(dw, wt.grad, tol=2e-4)   # sums over 512 x oh x ow signed terms
+    close(db, b.grad, tol=2e-4)
