@@ -79,11 +79,53 @@ def cpu_baseline(seconds_budget=20.0):
         iters += 1
     t_iter = (time.perf_counter() - t0) / iters / B  # s per sample per iteration
     per_env_step = t_fwd + 10 * t_iter
-    return {"value": round(1.0 / per_env_step, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle (torch-CPU fp32 restatement of PPO.forward/learn): forward n=256 x%d, "
-                      "PPO iteration B=1024 x%d; per env-step = 1 forward + 10 iterations" % (reps, iters),
-            "forward_samples_per_s": round(1.0 / t_fwd, 1), "ppo_iter_ms_B1024": round(t_iter * B * 1e3, 2),
-            "host_cpus": cores}
+    out = {"value": round(1.0 / per_env_step, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": "oracle (torch-CPU fp32 restatement of PPO.forward/learn): forward n=256 x%d, "
+                     "PPO iteration B=1024 x%d; per env-step = 1 forward + 10 iterations" % (reps, iters),
+           "forward_samples_per_s": round(1.0 / t_fwd, 1), "ppo_iter_ms_B1024": round(t_iter * B * 1e3, 2),
+           "host_cpus": cores}
+    try:
+        out["same_gpu_torch"] = torch_rocm_baseline(net, x, acts, old, adv, ret)
+    except Exception as e:  # the comparison leg must never take the bench line down
+        out["same_gpu_torch"] = {"error": repr(e)[:200]}
+    return out
+
+
+def torch_rocm_baseline(net, x, acts, old, adv, ret):
+    """The same oracle modules executed by PyTorch-ROCm on this GPU (MIOpen / rocBLAS, fp32, TF32
+    off): what the reference's own torch code would do on an MI355X.  Reported next to the CPU
+    figure for orientation only; bounded to a few seconds."""
+    from oracle import ddrl_oracle as O
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = torch.device("cuda:0")
+    net = net.to(dev)
+    Bg = 8192
+    reps = Bg // x.shape[0]
+    xg = x.to(dev).repeat(reps, 1, 1, 1)
+    a, o, ad, r = (t.to(dev).repeat(reps) for t in (acts, old, adv, ret))
+    with torch.no_grad():
+        for _ in range(3):
+            net(xg[:256])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            net(xg[:256])
+        torch.cuda.synchronize()
+        t_fwd = (time.perf_counter() - t0) / 20 / 256
+    gen = O.learn(net, net.make_optims(), xg, a, o, ad, r, iters=100)
+    for _ in range(2):
+        next(gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        next(gen)
+    torch.cuda.synchronize()
+    t_iter = (time.perf_counter() - t0) / 4 / Bg
+    return {"value": round(1.0 / (t_fwd + 10 * t_iter), 1), "unit": "env-steps/s", "ppo_iter_ms_B8192": round(t_iter * Bg * 1e3, 2),
+            "forward_samples_per_s_n256": round(1.0 / t_fwd, 1),
+            "sample": "oracle modules on cuda:0 through PyTorch-ROCm (fp32, TF32 off): forward n=256 x20, PPO iteration "
+                      "B=8192 x4 (4 .item() syncs per iteration as in the reference)"}
 
 
 def pmc_traffic(kernel):
