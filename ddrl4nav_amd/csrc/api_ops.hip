@@ -21,15 +21,21 @@ static bool fill_geom(const ddrl_conv_desc* d, ConvGeom& g) {
   return true;
 }
 
+// the direct kernels stage whole planes with 16-byte loads: strides and bases must allow that
+static bool direct_ok(const ConvGeom& g, const void* in_side, const void* out_side) {
+  return (g.in_sn & 3) == 0 && (g.out_sn & 3) == 0 && aligned16(in_side) && aligned16(out_side);
+}
+
 struct PackView {
-  int64_t off[5], total;
+  int64_t off[7], total;
 };
 static PackView pack_view(const ConvGeom& g) {
-  int64_t sz[5];
+  int64_t sz[7];
   conv_pack_sizes(g, sz);
+  conv_direct_pack_sizes(g, sz + 5);  // specialised direct-convolution layouts (dconv.hip), 0 when absent
   PackView v;
   int64_t o = 0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 7; ++i) {
     v.off[i] = o;
     o += align_up(sz[i], 64);
   }
@@ -60,6 +66,7 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
   const PackView v = pack_view(g);
   launch_conv_pack(g, w, packed + v.off[0], (int2*)(packed + v.off[1]), packed + v.off[2], (int2*)(packed + v.off[3]),
                    (int*)(packed + v.off[4]), (hipStream_t)stream);
+  if (conv_has_direct(g)) launch_conv_direct_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
   return op_check();
 }
 
@@ -75,7 +82,10 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
+  if (conv_has_direct(g) && direct_ok(g, in, out))
+    launch_conv_direct_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
+  else
+    launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
   return op_check();
 }
 
@@ -83,7 +93,10 @@ int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float
   ConvGeom g;
   if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  launch_conv_dgrad(g, dz, packed + v.off[2], (const int2*)(packed + v.off[3]), din, (hipStream_t)stream);
+  if (conv_has_direct(g) && direct_ok(g, din, dz))
+    launch_conv_direct_dgrad(g, dz, packed + v.off[6], din, (hipStream_t)stream);
+  else
+    launch_conv_dgrad(g, dz, packed + v.off[2], (const int2*)(packed + v.off[3]), din, (hipStream_t)stream);
   return op_check();
 }
 

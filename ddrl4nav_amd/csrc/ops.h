@@ -22,6 +22,14 @@ void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, cons
 void launch_maxpool2_fwd(const float* in, int64_t planes, int H, int W, float* out, hipStream_t st);
 void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes, int H, int W, float* dz, hipStream_t st);
 
+// dconv.hip: compile-time-geometry direct convolutions for the heavy nav layers
+bool conv_has_direct(const ConvGeom& g);
+void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]);
+void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st);
+void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
+                            hipStream_t st);
+void launch_conv_direct_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* din, hipStream_t st);
+
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
 void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);
