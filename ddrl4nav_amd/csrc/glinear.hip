@@ -312,10 +312,35 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   dst[i] = s;
 }
 
+// Many slabs, few elements (thin weight gradients: hundreds of splits of a few hundred values): 16
+// lane groups walk the slabs in parallel (group g takes slabs g, g+16, ...), then one lane adds the
+// 16 partial sums in group order -- still a fixed order, so still deterministic.
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ part, int nsplit, int64_t slab_stride,
+                                                                int64_t count, float* __restrict__ dst) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  float s = 0.0f;
+  if (i < count)
+    for (int sp = g; sp < nsplit; sp += 16) s += part[(int64_t)sp * slab_stride + i];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < count) {
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][e];
+    dst[i] = t;
+  }
+}
+
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, part, nsplit, slab_stride,
-                     count, dst);
+  if (nsplit >= 64 && count < 65536)
+    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, st, part, nsplit,
+                       slab_stride, count, dst);
+  else
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, part, nsplit,
+                       slab_stride, count, dst);
 }
 
 __global__ __launch_bounds__(256) void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {

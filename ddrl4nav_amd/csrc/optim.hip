@@ -98,10 +98,34 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)sp * 2 + e) * count + i];
   grads[(e ? off1 : off0) + i] = s;
 }
+// Many slabs of few elements (conv1: 1,024 slabs x 8,224 values): 16 lane groups walk the slabs in
+// parallel (group g takes slabs g, g+16, ...), one lane then adds the 16 partial sums in group order.
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part, int nsplit, int64_t count,
+                                                                   float* __restrict__ grads, int64_t off0, int64_t off1) {
+  __shared__ float red[16][17];
+  const int e = blockIdx.y;
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + el;
+  float s = 0.0f;
+  if (i < count)
+    for (int sp = g; sp < nsplit; sp += 16) s += part[((int64_t)sp * 2 + e) * count + i];
+  red[g][el] = s;
+  __syncthreads();
+  if (g == 0 && i < count) {
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][el];
+    grads[(e ? off1 : off0) + i] = t;
+  }
+}
 void launch_reduce_partials(const float* part, int nsplit, int64_t count, int ne, float* grads, int64_t off0,
                             int64_t off1, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256), ne), dim3(256), 0, st, part, nsplit,
-                     count, grads, off0, off1);
+  if (nsplit >= 64 && count < 65536)
+    hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((count + 15) / 16), ne), dim3(256), 0, st, part, nsplit,
+                       count, grads, off0, off1);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256), ne), dim3(256), 0, st, part, nsplit,
+                       count, grads, off0, off1);
 }
 
 // --------------------------------------------------------------------------------------------
