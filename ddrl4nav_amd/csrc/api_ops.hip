@@ -73,7 +73,9 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
 int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
   ConvGeom g;
   if (!fill_geom(d, g) || !floats) return DDRL_ERR_INVALID_ARG;
-  *floats = (int64_t)conv_wgrad_splits(g) * ((int64_t)g.cout * g.cin * g.kh * g.kw + g.cout);
+  int splits = conv_wgrad_splits(g);
+  if (conv_direct_wgrad_splits(g) > splits) splits = conv_direct_wgrad_splits(g);
+  *floats = (int64_t)splits * ((int64_t)g.cout * g.cin * g.kh * g.kw + g.cout);
   return DDRL_OK;
 }
 
@@ -106,7 +108,10 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
   if (!fill_geom(d, g) || !in || !dz || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if (g.oh * g.ow < 32) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  launch_conv_wgrad(g, in, dz, (const int*)(packed + v.off[4]), ws, dw, db, (hipStream_t)stream);
+  if (conv_has_direct(g) && direct_ok(g, in, dz) && (g.in_sn & 1) == 0)
+    launch_conv_direct_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
+  else
+    launch_conv_wgrad(g, in, dz, (const int*)(packed + v.off[4]), ws, dw, db, (hipStream_t)stream);
   return op_check();
 }
 

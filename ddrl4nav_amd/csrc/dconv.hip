@@ -162,6 +162,151 @@ __global__ __launch_bounds__(256) void direct_pack_kernel(const float* __restric
   wp[i] = flip ? w[((int64_t)ch * cin + rr) * kk + (kk - 1 - tap)] : w[((int64_t)rr * cin + ch) * kk + tap];
 }
 
+// Weight gradient of the same layers:
+//   part[split][co][ci][ky][kx] = sum over the split's sample pairs and all output pixels of
+//                                 dz[b][co][oy][ox] * in[b][ci][oy + ky - PAD][ox + kx - PAD]
+// rows = co (64 per workgroup: 2 wave rows x 32), cols = taps of CT input channels (4 x 32 per wave
+// column), k-block = (sample pair, band of R output rows); the two k indices of an MFMA are the SAME
+// pixel of the pair's two samples.  dz of the band and the R + KS - 1 input rows it touches are
+// staged raw (16- / 8-byte coalesced loads); image rows outside the input are written as zeros and
+// the PAD columns of the LDS planes stay zero, so every operand is again lane_base + immediate.
+template <int CIN, int COUT, int KS, int HIN, int PAD, int R, int CT>
+struct DirectWgrad {
+  static constexpr int THREADS = 256, TM = 1, TN = 4;
+  static constexpr int KK = KS * KS, KT = CIN * KK;
+  static constexpr int OH = HIN + 2 * PAD - KS + 1, P = OH * OH, RAW = HIN * HIN, LP = HIN + 2 * PAD;
+  static_assert(OH % R == 0 && (R * OH) % 4 == 0 && HIN % 2 == 0, "band geometry");
+  static constexpr int NB = OH / R, KSTEPS = R * OH, BR = R + KS - 1;
+  static constexpr int ASTR = KSTEPS + 1;  // odd row stride: lanes (= rows) hit distinct banks
+  static constexpr int A_FLOATS = 2 * 64 * ASTR, B_OFF = (A_FLOATS + 3) / 4 * 4;
+  static constexpr int BPL = BR * LP, B_FLOATS = 2 * CT * BPL, STAGE = B_OFF + (B_FLOATS + 3) / 4 * 4;
+  static constexpr int CTILES = (CIN + CT - 1) / CT, COLS = CT * KK;
+  static_assert(COLS <= 256, "column tile");
+  static constexpr int K4 = KSTEPS / 4, NA4 = 2 * 64 * K4, NAJ = (NA4 + 255) / 256;
+  static constexpr int H2 = HIN / 2, NB2 = 2 * CT * BR * H2, NBJ = (NB2 + 255) / 256;
+  struct Params {
+    const float* in;
+    int64_t in_sn;
+    const float* dz;
+    int64_t out_sn;
+    float* part;  // [nsplit][COUT*KT + COUT]
+    int n, nsplit;
+  };
+  struct Regs {
+    f4 a[NAJ];
+    float2 b[NBJ];
+    unsigned oka, okb;
+  };
+  int abase[1], bbase[4], kb_begin, kb_end;
+  int ct, split, r0, ch0, l31, hi, wr, wc;
+  float bacc;
+  static constexpr int aoff(int s) { return s; }
+  static constexpr int boff(int s) { return (s / OH) * LP + (s % OH); }
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
+    const int lane = tid & 63, wave = tid >> 6;
+    wr = wave >> 1;
+    wc = wave & 1;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    ct = blockIdx.x;
+    split = blockIdx.y;
+    r0 = blockIdx.z * 64;
+    ch0 = ct * CT;
+    const int npairs = (p.n + 1) >> 1;
+    const int per = (npairs + p.nsplit - 1) / p.nsplit;
+    const int pb = min(npairs, split * per), pe = min(npairs, pb + per);
+    kb_begin = pb * NB;
+    kb_end = pe * NB;
+    bacc = 0.0f;
+    for (int i = tid; i < B_FLOATS; i += 256) {  // PAD columns (and nothing else) rely on this
+      lds[B_OFF + i] = 0.0f;
+      lds[STAGE + B_OFF + i] = 0.0f;
+    }
+    __syncthreads();
+    abase[0] = hi * (64 * ASTR) + (wr * 32 + l31) * ASTR;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = min(wc * 128 + j * 32 + l31, COLS - 1);
+      const int ch = col / KK, t = col % KK;
+      bbase[j] = B_OFF + hi * (CT * BPL) + ch * BPL + (t / KS) * LP + (t % KS);
+    }
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+    const int pair = kb / NB, band = kb % NB;
+    r.oka = 0;
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) {
+      const int idx = min(tid + 256 * j, NA4 - 1);
+      const int smp = idx / (64 * K4), row = (idx / K4) % 64, q = idx % K4;
+      const int b = 2 * pair + smp;
+      r.oka |= (b < p.n ? 1u : 0u) << j;
+      r.a[j] = ld4(p.dz + (int64_t)min(b, p.n - 1) * p.out_sn + (int64_t)(r0 + row) * P + band * KSTEPS + q * 4);
+    }
+    r.okb = 0;
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int idx = min(tid + 256 * j, NB2 - 1);
+      const int x2 = idx % H2, rr = (idx / H2) % BR, ch = (idx / (H2 * BR)) % CT, smp = idx / (H2 * BR * CT);
+      const int iy = band * R - PAD + rr;
+      const bool ok = iy >= 0 && iy < HIN && ch0 + ch < CIN;
+      const int b = min(2 * pair + smp, p.n - 1);
+      const int64_t off = (int64_t)b * p.in_sn + (int64_t)min(ch0 + ch, CIN - 1) * RAW + min(max(iy, 0), HIN - 1) * HIN + x2 * 2;
+      r.b[j] = *(const float2*)(p.in + off);
+      r.okb |= (ok ? 1u : 0u) << j;
+    }
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NA4) {
+        const int smp = idx / (64 * K4), row = (idx / K4) % 64, q = idx % K4;
+        const f4 v = ((r.oka >> j) & 1u) ? r.a[j] : zero4();  // a missing sample contributes zero
+        float* d = buf + smp * (64 * ASTR) + row * ASTR + q * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NB2) {
+        const int x2 = idx % H2, rr = (idx / H2) % BR, ch = (idx / (H2 * BR)) % CT, smp = idx / (H2 * BR * CT);
+        const bool ok = (r.okb >> j) & 1u;
+        float* d = buf + B_OFF + smp * (CT * BPL) + ch * BPL + rr * LP + PAD + x2 * 2;
+        d[0] = ok ? r.b[j].x : 0.0f;
+        d[1] = ok ? r.b[j].y : 0.0f;
+      }
+    }
+  }
+  __device__ __forceinline__ void extra(const float* cur) {  // bias gradient: row sums of the staged dz
+    if (ct == 0 && threadIdx.x < 128) {
+      const float* row = cur + threadIdx.x * ASTR;
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < KSTEPS; ++q) s += row[q];
+      bacc += s;
+    }
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[1][4], float* lds) {
+    float* slab = p.part + (int64_t)split * ((int64_t)COUT * KT + COUT);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wc * 128 + j * 32 + l31;
+      if (col >= COLS || ch0 + col / KK >= CIN) continue;
+      const int tap = ct * COLS + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(int64_t)(r0 + wr * 32 + acc_row(r, hi)) * KT + tap] = acc[0][j][r];
+    }
+    if (ct == 0) {
+      if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+      __syncthreads();
+      if (threadIdx.x < 64) slab[(int64_t)COUT * KT + r0 + threadIdx.x] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+    }
+  }
+};
+
 }  // namespace dconv
 
 // ---- dispatch table ------------------------------------------------------------------------------
@@ -171,6 +316,8 @@ using Nav1dC2F = dconv::Direct<64, 128, 5, 22, 1, 2>;
 using Nav1dC2D = dconv::Direct<128, 64, 5, 20, 3, 2>;
 using Nav1dC3F = dconv::Direct<128, 256, 3, 10, 1, 4>;
 using Nav1dC3D = dconv::Direct<256, 128, 3, 10, 1, 4>;
+using Nav1dC2W = dconv::DirectWgrad<64, 128, 5, 22, 1, 2, 10>;   // bands of 2 output rows, 10 channels x 25 taps per tile
+using Nav1dC3W = dconv::DirectWgrad<128, 256, 3, 10, 1, 2, 28>;  // bands of 2 output rows, 28 channels x 9 taps per tile
 
 static int direct_id(const ConvGeom& g) {
   if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w) return -1;
@@ -196,6 +343,33 @@ void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, floa
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(dconv::direct_pack_kernel, dim3(blocks), dim3(256), 0, st, w, g.cin, g.cout, kk, cpb, 0, wpf);
   hipLaunchKernelGGL(dconv::direct_pack_kernel, dim3(blocks), dim3(256), 0, st, w, g.cin, g.cout, kk, cpb, 1, wpd);
+}
+
+int conv_direct_wgrad_splits(const ConvGeom& g) {
+  const int id = direct_id(g);
+  if (id < 0) return 0;
+  const int tiles = (id == 0 ? Nav1dC2W::CTILES : Nav1dC3W::CTILES) * (g.cout / 64);
+  int s = (1024 + tiles - 1) / tiles;
+  const int cap = ((g.n + 1) / 2 + 1) / 2;  // at least 2 sample pairs per split
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
+
+template <class Op>
+static void run_direct_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, int S, hipStream_t st) {
+  typename Op::Params p{in, g.in_sn, dz, g.out_sn, part, g.n, S};
+  launch_engine2<Op>(dim3(Op::CTILES, S, g.cout / 64), p, st);
+}
+
+void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db,
+                              hipStream_t st) {
+  const int S = conv_direct_wgrad_splits(g);
+  if (direct_id(g) == 0) run_direct_wgrad<Nav1dC2W>(g, in, dz, part, S, st);
+  else run_direct_wgrad<Nav1dC3W>(g, in, dz, part, S, st);
+  const int KT = g.cin * g.kh * g.kw;
+  const int64_t slab = (int64_t)g.cout * KT + g.cout;
+  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
+  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
 }
 
 template <class Op>

@@ -29,6 +29,9 @@ void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, floa
 void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
                             hipStream_t st);
 void launch_conv_direct_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* din, hipStream_t st);
+int conv_direct_wgrad_splits(const ConvGeom& g);  // 0 when there is no specialisation
+void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db,
+                              hipStream_t st);
 
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
