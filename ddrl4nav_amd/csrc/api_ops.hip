@@ -108,7 +108,7 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
   if (!fill_geom(d, g) || !in || !dz || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if (g.oh * g.ow < 32) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  if (conv_has_direct(g) && direct_ok(g, in, dz) && (g.in_sn & 1) == 0)
+  if (conv_has_direct_wgrad(g) && direct_ok(g, in, dz))
     launch_conv_direct_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
   else
     launch_conv_wgrad(g, in, dz, (const int*)(packed + v.off[4]), ws, dw, db, (hipStream_t)stream);

@@ -318,26 +318,29 @@ using Nav1dC3F = dconv::Direct<128, 256, 3, 10, 1, 4>;
 using Nav1dC3D = dconv::Direct<256, 128, 3, 10, 1, 4>;
 using Nav1dC2W = dconv::DirectWgrad<64, 128, 5, 22, 1, 2, 10>;   // bands of 2 output rows, 10 channels x 25 taps per tile
 using Nav1dC3W = dconv::DirectWgrad<128, 256, 3, 10, 1, 2, 28>;  // bands of 2 output rows, 28 channels x 9 taps per tile
+using Nav1dC1W = dconv::DirectWgrad<3, 64, 7, 48, 1, 1, 3>;      // conv1 (3 -> 64, 7x7, 48 -> 44): one row per band, 147 taps
 
 static int direct_id(const ConvGeom& g) {
   if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w) return -1;
   if (g.cin == 64 && g.cout == 128 && g.kh == 5 && g.h == 22 && g.pad_h == 1) return 0;
   if (g.cin == 128 && g.cout == 256 && g.kh == 3 && g.h == 10 && g.pad_h == 1) return 1;
+  if (g.cin == 3 && g.cout == 64 && g.kh == 7 && g.h == 48 && g.pad_h == 1) return 2;  // weight gradient only
   return -1;
 }
 
-bool conv_has_direct(const ConvGeom& g) { return direct_id(g) >= 0; }
+bool conv_has_direct(const ConvGeom& g) { return direct_id(g) == 0 || direct_id(g) == 1; }
+bool conv_has_direct_wgrad(const ConvGeom& g) { return direct_id(g) >= 0; }
 
 // floats of the two extra packed regions (forward, data gradient); 0 when there is no specialisation
 void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]) {
   out[0] = out[1] = 0;
-  if (direct_id(g) < 0) return;
+  if (!conv_has_direct(g)) return;
   out[0] = out[1] = (int64_t)g.cout * g.cin * g.kh * g.kw;  // same element count, different order
 }
 
 void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st) {
   const int id = direct_id(g);
-  if (id < 0) return;
+  if (!conv_has_direct(g)) return;
   const int kk = g.kh * g.kw, cpb = id == 0 ? 2 : 4;
   const int64_t total = (int64_t)g.cout * g.cin * kk;
   const unsigned blocks = (unsigned)((total + 255) / 256);
@@ -348,9 +351,9 @@ void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, floa
 int conv_direct_wgrad_splits(const ConvGeom& g) {
   const int id = direct_id(g);
   if (id < 0) return 0;
-  const int tiles = (id == 0 ? Nav1dC2W::CTILES : Nav1dC3W::CTILES) * (g.cout / 64);
+  const int tiles = (id == 0 ? Nav1dC2W::CTILES : id == 1 ? Nav1dC3W::CTILES : Nav1dC1W::CTILES) * (g.cout / 64);
   int s = (1024 + tiles - 1) / tiles;
-  const int cap = ((g.n + 1) / 2 + 1) / 2;  // at least 2 sample pairs per split
+  const int cap = id == 2 ? (g.n + 1) / 2 : ((g.n + 1) / 2 + 1) / 2;  // >= 1 (conv1: 44 bands each) or 2 sample pairs per split
   if (s > cap) s = cap;
   return s < 1 ? 1 : s;
 }
@@ -365,7 +368,8 @@ void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* d
                               hipStream_t st) {
   const int S = conv_direct_wgrad_splits(g);
   if (direct_id(g) == 0) run_direct_wgrad<Nav1dC2W>(g, in, dz, part, S, st);
-  else run_direct_wgrad<Nav1dC3W>(g, in, dz, part, S, st);
+  else if (direct_id(g) == 1) run_direct_wgrad<Nav1dC3W>(g, in, dz, part, S, st);
+  else run_direct_wgrad<Nav1dC1W>(g, in, dz, part, S, st);
   const int KT = g.cin * g.kh * g.kw;
   const int64_t slab = (int64_t)g.cout * KT + g.cout;
   launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
