@@ -310,26 +310,40 @@ struct DirectWgrad {
 }  // namespace dconv
 
 // ---- dispatch table ------------------------------------------------------------------------------
-// NavPreNet1D.conv2 (64 -> 128, 5x5, 22 -> 20, pad 1) and conv3 (128 -> 256, 3x3, 10 -> 10, pad 1),
-// each with its data gradient (channels swapped, PAD' = KS-1-PAD, input = the forward's output size)
-using Nav1dC2F = dconv::Direct<64, 128, 5, 22, 1, 2>;
-using Nav1dC2D = dconv::Direct<128, 64, 5, 20, 3, 2>;
-using Nav1dC3F = dconv::Direct<128, 256, 3, 10, 1, 4>;
-using Nav1dC3D = dconv::Direct<256, 128, 3, 10, 1, 4>;
-using Nav1dC2W = dconv::DirectWgrad<64, 128, 5, 22, 1, 2, 10>;   // bands of 2 output rows, 10 channels x 25 taps per tile
-using Nav1dC3W = dconv::DirectWgrad<128, 256, 3, 10, 1, 2, 28>;  // bands of 2 output rows, 28 channels x 9 taps per tile
-using Nav1dC1W = dconv::DirectWgrad<3, 64, 7, 48, 1, 1, 3>;      // conv1 (3 -> 64, 7x7, 48 -> 44): one row per band, 147 taps
+// NavPreNet1D (nav_encoder.py:96-98): conv1 3->64 7x7 @48 (weight gradient only: 3 input channels do
+// not pair up for the forward's channel-pair MFMA), conv2 64->128 5x5 @22, conv3 128->256 3x3 @10.
+// NavPreNet / NavPedPreNet (nav_encoder.py:18-20): conv2 64->128 3x3 @24, conv3 128->256 3x3 @12
+// (their conv1 planes, 50x50 padded, do not fit the whole-plane staging: gather kernels).
+// A data gradient is the forward template with channels swapped, HIN' = OH and PAD' = KS-1-PAD.
+using N1dC2F = dconv::Direct<64, 128, 5, 22, 1, 2>;
+using N1dC2D = dconv::Direct<128, 64, 5, 20, 3, 2>;
+using N1dC3F = dconv::Direct<128, 256, 3, 10, 1, 4>;
+using N1dC3D = dconv::Direct<256, 128, 3, 10, 1, 4>;
+using NavC2F = dconv::Direct<64, 128, 3, 24, 1, 4>;
+using NavC2D = dconv::Direct<128, 64, 3, 24, 1, 4>;
+using NavC3F = dconv::Direct<128, 256, 3, 12, 1, 4>;
+using NavC3D = dconv::Direct<256, 128, 3, 12, 1, 4>;
+using N1dC1W = dconv::DirectWgrad<3, 64, 7, 48, 1, 1, 3>;      // one output row per band, 147 taps
+using N1dC2W = dconv::DirectWgrad<64, 128, 5, 22, 1, 2, 10>;   // bands of 2 rows, 10 channels x 25 taps per tile
+using N1dC3W = dconv::DirectWgrad<128, 256, 3, 10, 1, 2, 28>;  // bands of 2 rows, 28 channels x 9 taps per tile
+using NavC2W = dconv::DirectWgrad<64, 128, 3, 24, 1, 1, 28>;
+using NavC3W = dconv::DirectWgrad<128, 256, 3, 12, 1, 2, 28>;
 
-static int direct_id(const ConvGeom& g) {
-  if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w) return -1;
-  if (g.cin == 64 && g.cout == 128 && g.kh == 5 && g.h == 22 && g.pad_h == 1) return 0;
-  if (g.cin == 128 && g.cout == 256 && g.kh == 3 && g.h == 10 && g.pad_h == 1) return 1;
-  if (g.cin == 3 && g.cout == 64 && g.kh == 7 && g.h == 48 && g.pad_h == 1) return 2;  // weight gradient only
-  return -1;
+enum DirectId { kNone = -1, kN1dC2, kN1dC3, kN1dC1, kNavC2, kNavC3 };
+
+static DirectId direct_id(const ConvGeom& g) {
+  if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w || g.pad_h != 1) return kNone;
+  const auto is = [&](int cin, int cout, int ks, int h) { return g.cin == cin && g.cout == cout && g.kh == ks && g.h == h; };
+  if (is(64, 128, 5, 22)) return kN1dC2;
+  if (is(128, 256, 3, 10)) return kN1dC3;
+  if (is(3, 64, 7, 48)) return kN1dC1;
+  if (is(64, 128, 3, 24)) return kNavC2;
+  if (is(128, 256, 3, 12)) return kNavC3;
+  return kNone;
 }
 
-bool conv_has_direct(const ConvGeom& g) { return direct_id(g) == 0 || direct_id(g) == 1; }
-bool conv_has_direct_wgrad(const ConvGeom& g) { return direct_id(g) >= 0; }
+bool conv_has_direct(const ConvGeom& g) { return direct_id(g) != kNone && direct_id(g) != kN1dC1; }
+bool conv_has_direct_wgrad(const ConvGeom& g) { return direct_id(g) != kNone; }
 
 // floats of the two extra packed regions (forward, data gradient); 0 when there is no specialisation
 void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]) {
@@ -339,21 +353,61 @@ void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]) {
 }
 
 void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st) {
-  const int id = direct_id(g);
   if (!conv_has_direct(g)) return;
-  const int kk = g.kh * g.kw, cpb = id == 0 ? 2 : 4;
+  const int kk = g.kh * g.kw, cpb = direct_id(g) == kN1dC2 ? 2 : 4;  // = the CPB of the instantiations above
   const int64_t total = (int64_t)g.cout * g.cin * kk;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(dconv::direct_pack_kernel, dim3(blocks), dim3(256), 0, st, w, g.cin, g.cout, kk, cpb, 0, wpf);
   hipLaunchKernelGGL(dconv::direct_pack_kernel, dim3(blocks), dim3(256), 0, st, w, g.cin, g.cout, kk, cpb, 1, wpd);
 }
 
+template <class Op>
+static void run_direct(const float* in, int64_t in_sn, const float* wp, const float* bias, int act, float* out,
+                       int64_t out_sn, int n, int rows, hipStream_t st) {
+  typename Op::Params p{in, in_sn, wp, bias, out, out_sn, n, act};
+  launch_engine2<Op>(dim3((unsigned)(((int64_t)n * Op::P + 255) / 256), rows / 64, 1), p, st);
+}
+
+void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
+                            hipStream_t st) {
+  switch (direct_id(g)) {
+    case kN1dC2: run_direct<N1dC2F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st); break;
+    case kN1dC3: run_direct<N1dC3F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st); break;
+    case kNavC2: run_direct<NavC2F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st); break;
+    case kNavC3: run_direct<NavC3F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st); break;
+    default: break;
+  }
+}
+
+void launch_conv_direct_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* din, hipStream_t st) {
+  switch (direct_id(g)) {
+    case kN1dC2: run_direct<N1dC2D>(dz, g.out_sn, wpd, nullptr, 0, din, g.in_sn, g.n, g.cin, st); break;
+    case kN1dC3: run_direct<N1dC3D>(dz, g.out_sn, wpd, nullptr, 0, din, g.in_sn, g.n, g.cin, st); break;
+    case kNavC2: run_direct<NavC2D>(dz, g.out_sn, wpd, nullptr, 0, din, g.in_sn, g.n, g.cin, st); break;
+    case kNavC3: run_direct<NavC3D>(dz, g.out_sn, wpd, nullptr, 0, din, g.in_sn, g.n, g.cin, st); break;
+    default: break;
+  }
+}
+
+static int direct_ctiles(DirectId id) {
+  switch (id) {
+    case kN1dC1: return N1dC1W::CTILES;
+    case kN1dC2: return N1dC2W::CTILES;
+    case kN1dC3: return N1dC3W::CTILES;
+    case kNavC2: return NavC2W::CTILES;
+    case kNavC3: return NavC3W::CTILES;
+    default: return 0;
+  }
+}
+
 int conv_direct_wgrad_splits(const ConvGeom& g) {
-  const int id = direct_id(g);
-  if (id < 0) return 0;
-  const int tiles = (id == 0 ? Nav1dC2W::CTILES : id == 1 ? Nav1dC3W::CTILES : Nav1dC1W::CTILES) * (g.cout / 64);
+  const DirectId id = direct_id(g);
+  if (id == kNone) return 0;
+  const int tiles = direct_ctiles(id) * (g.cout / 64);
   int s = (1024 + tiles - 1) / tiles;
-  const int cap = id == 2 ? (g.n + 1) / 2 : ((g.n + 1) / 2 + 1) / 2;  // >= 1 (conv1: 44 bands each) or 2 sample pairs per split
+  // a sample pair is 10 (conv2/3) to 44 (conv1) k-blocks: at least 2 pairs per split, 1 for the long ones
+  const int pairs = (g.n + 1) / 2;
+  const int cap = (id == kN1dC1 || id == kNavC2) ? pairs : (pairs + 1) / 2;
   if (s > cap) s = cap;
   return s < 1 ? 1 : s;
 }
@@ -367,31 +421,18 @@ static void run_direct_wgrad(const ConvGeom& g, const float* in, const float* dz
 void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db,
                               hipStream_t st) {
   const int S = conv_direct_wgrad_splits(g);
-  if (direct_id(g) == 0) run_direct_wgrad<Nav1dC2W>(g, in, dz, part, S, st);
-  else if (direct_id(g) == 1) run_direct_wgrad<Nav1dC3W>(g, in, dz, part, S, st);
-  else run_direct_wgrad<Nav1dC1W>(g, in, dz, part, S, st);
+  switch (direct_id(g)) {
+    case kN1dC1: run_direct_wgrad<N1dC1W>(g, in, dz, part, S, st); break;
+    case kN1dC2: run_direct_wgrad<N1dC2W>(g, in, dz, part, S, st); break;
+    case kN1dC3: run_direct_wgrad<N1dC3W>(g, in, dz, part, S, st); break;
+    case kNavC2: run_direct_wgrad<NavC2W>(g, in, dz, part, S, st); break;
+    case kNavC3: run_direct_wgrad<NavC3W>(g, in, dz, part, S, st); break;
+    default: return;
+  }
   const int KT = g.cin * g.kh * g.kw;
   const int64_t slab = (int64_t)g.cout * KT + g.cout;
   launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
   launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
-}
-
-template <class Op>
-static void run_direct(const float* in, int64_t in_sn, const float* wp, const float* bias, int act, float* out,
-                       int64_t out_sn, int n, int rows, hipStream_t st) {
-  typename Op::Params p{in, in_sn, wp, bias, out, out_sn, n, act};
-  launch_engine2<Op>(dim3((unsigned)(((int64_t)n * Op::P + 255) / 256), rows / 64, 1), p, st);
-}
-
-void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
-                            hipStream_t st) {
-  if (direct_id(g) == 0) run_direct<Nav1dC2F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st);
-  else run_direct<Nav1dC3F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st);
-}
-
-void launch_conv_direct_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* din, hipStream_t st) {
-  if (direct_id(g) == 0) run_direct<Nav1dC2D>(dz, g.out_sn, wpd, nullptr, 0, din, g.in_sn, g.n, g.cin, st);
-  else run_direct<Nav1dC3D>(dz, g.out_sn, wpd, nullptr, 0, din, g.in_sn, g.n, g.cin, st);
 }
 
 }  // namespace ddrl
