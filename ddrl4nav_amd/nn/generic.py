@@ -531,12 +531,14 @@ class GenericPPO(Basenn):
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(self._process_group)
         total = self.n_params + STATS_FLOATS
+        # the batch is read by every one of the TRAINING_ITER_TIME iterations: stage it on the device once
+        dstates = [torch.as_tensor(s).to(self.device, torch.float32, non_blocking=True) for s in states]
         for _ in range(self.training_iter_time):
             t0 = time.time()
             self._ensure_packed()
             for ci, lo in enumerate(range(0, B, self.cap)):
                 hi = min(B, lo + self.cap)
-                self._iter_chunk(self._stage(states, lo, hi), hi - lo, actions[lo:hi], old_logps[lo:hi], advs[lo:hi],
+                self._iter_chunk([s[lo:hi] for s in dstates], hi - lo, actions[lo:hi], old_logps[lo:hi], advs[lo:hi],
                                  rets[lo:hi], B * world)
                 if ci == 0:
                     self.grads.copy_(self.gtmp)

@@ -75,3 +75,35 @@ def test_no_gpu_is_an_error_not_a_fallback():
     from ddrl4nav_amd.engine import HotPath
     with pytest.raises(_lib.DdrlError):
         HotPath(max_batch=8)
+
+
+def test_operator_abi_host_side_queries():
+    """Shape / size queries of the operator-level ABI run on the host (no GPU needed)."""
+    from ctypes import byref, c_int32, c_int64
+    lib = _lib.load()
+    d = _lib.ConvDesc(4, 3, 48, 48, 64, 7, 7, 1, 1, 1, 0, 0)          # NavPreNet1D.conv1 (nav_encoder.py:96)
+    oh, ow, f = c_int32(), c_int32(), c_int64()
+    _lib.check(lib.ddrl_op_conv_out_shape(byref(d), byref(oh), byref(ow)))
+    assert (oh.value, ow.value) == (44, 44)
+    d1 = _lib.ConvDesc(4, 1, 1, 960, 32, 1, 5, 2, 0, 0, 0, 0)          # conv1d1 as a 1 x 960 image
+    _lib.check(lib.ddrl_op_conv_out_shape(byref(d1), byref(oh), byref(ow)))
+    assert (oh.value, ow.value) == (1, 478)
+    _lib.check(lib.ddrl_op_conv_pack_floats(byref(d), byref(f)))
+    assert f.value >= 64 * 3 * 49
+    _lib.check(lib.ddrl_op_conv_ws_floats(byref(d), byref(f)))
+    assert f.value >= 64 * 3 * 49 + 64
+    bad = _lib.ConvDesc(4, 3, 48, 48, 64, 7, 7, 3, 1, 1, 0, 0)         # stride 3 is not supported
+    assert lib.ddrl_op_conv_out_shape(byref(bad), byref(oh), byref(ow)) == -1
+    a, b = c_int64(), c_int64()
+    _lib.check(lib.ddrl_op_linear_pack_floats(773, 512, byref(a), byref(b)))
+    assert a.value == 800 * 512 and b.value == 512 * 776
+    assert lib.ddrl_op_linear_pack_floats(16, 6, byref(a), byref(b)) == -1  # N must be a multiple of 4
+    _lib.check(lib.ddrl_op_linear_ws_floats(1024, 7616, 256, byref(f)))
+    assert f.value >= 7616 * 256 + 256
+    h = _lib.HeadsDesc(1, 2, 0, 0, 100, 1124, 0, 1126, 1638, 1639)
+    _lib.check(lib.ddrl_op_heads_ws_floats(byref(h), 256, byref(f)))
+    assert f.value > 256 * 3
+    h.n_actions = 9                                                      # Gaussian heads: at most 8 action dims
+    assert lib.ddrl_op_heads_ws_floats(byref(h), 256, byref(f)) == -1
+    _lib.check(lib.ddrl_op_clip_adam_ws_bytes(byref(f)))
+    assert f.value == 1024 * 8
