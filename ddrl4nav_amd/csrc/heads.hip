@@ -228,16 +228,17 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
 // --------------------------------------------------------------------------------------------
 // WLDS (A > 8): the actor-head weight / bias gradient slots of hpart are written by
 // head_wgrad_kernel from dlogits instead (288 accumulator + weight registers do not fit a lane).
+constexpr int LOSS_WAVES = 8;  // waves per workgroup of heads_loss: two per SIMD keep the h / dh streams in flight
 template <int MAXA, bool WLDS>
-__global__ __launch_bounds__(256) void heads_loss_kernel(
+__global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
     const float* __restrict__ actions, const float* __restrict__ old_logps, const float* __restrict__ advs,
     const float* __restrict__ rets, float inv_b, float* __restrict__ dh, int64_t dh_es, float* __restrict__ dlogits,
     float* __restrict__ dvalue, float* __restrict__ hpart, int64_t hstride) {
   __shared__ float red[(MAXA + 1) * FEAT + 2 * MAXA + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw = blockIdx.x * 4 + wave;
-  const int nw = gridDim.x * 4;
+  const int gw = blockIdx.x * LOSS_WAVES + wave;
+  const int nw = gridDim.x * LOSS_WAVES;
   const int A = L.A;
   HeadRegs<MAXA, WLDS> R;
   load_head_weights(R, params, L, lane, red);  // LDS weights alias the reduction buffer (used after the loop)
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
   // ---- workgroup reduction, waves accumulate in turn (fixed order) -> hpart[blockIdx.x] ----
   constexpr int SCAL = (MAXA + 1) * FEAT;
   if constexpr (WLDS) __syncthreads();  // every wave is done with the LDS weights aliased by `red`
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < LOSS_WAVES; ++w) {
     if (wave == w) {
       const bool first = (w == 0);
       if constexpr (!WLDS) {
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(
   }
   float* out = hpart + (int64_t)blockIdx.x * hstride;
   if constexpr (!WLDS) {
-    for (int i = threadIdx.x; i < A * FEAT; i += 256) out[i] = red[i];
+    for (int i = threadIdx.x; i < A * FEAT; i += LOSS_WAVES * 64) out[i] = red[i];
     if (threadIdx.x < A) out[(A + 1) * FEAT + threadIdx.x] = red[SCAL + threadIdx.x];
   }
-  for (int i = threadIdx.x; i < FEAT; i += 256) out[A * FEAT + i] = red[MAXA * FEAT + i];
+  for (int i = threadIdx.x; i < FEAT; i += LOSS_WAVES * 64) out[A * FEAT + i] = red[MAXA * FEAT + i];
   if (threadIdx.x == 0) out[(A + 1) * FEAT + A] = red[SCAL + MAXA];
   if (threadIdx.x < 3) out[(A + 1) * FEAT + A + 1 + threadIdx.x] = red[SCAL + MAXA + 1 + threadIdx.x];
 }
@@ -554,7 +555,7 @@ void launch_heads_loss(const HeadsCall& c, const float* actions, const float* ol
   const int64_t hs = hpart_stride(c.L->A);
   const bool large = c.L->A > MAXA_SMALL;
   auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : heads_loss_kernel<MAXA_SMALL, false>;
-  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.h_es >= 0 ? c.h_es : c.max_batch * FEAT, c.params,
+  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(LOSS_WAVES * 64), 0, st, c.ws->h, c.h_es >= 0 ? c.h_es : c.max_batch * FEAT, c.params,
                      *c.L, *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh,
                      c.dh_es >= 0 ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs);
   if (large)
