@@ -13,7 +13,8 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ddrl4nav_amd import ops  # noqa: E402
 from ddrl4nav_amd.config import BaseConfig, ConfigNN  # noqa: E402
 from ddrl4nav_amd.data import Experience  # noqa: E402
