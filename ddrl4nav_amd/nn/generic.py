@@ -370,6 +370,9 @@ class GenericPPO(Basenn):
         self._bind_arena()
         for e in self._encs:
             e.build(self.cap, self.device)
+            if e.h.shape[1] != FEAT:
+                raise NotImplementedError("the head kernels take %d-wide features (AC_INPUT_DIM, config_nn.py:23); "
+                                          "this encoder emits %d" % (FEAT, e.h.shape[1]))
         self._build_heads()
         self._dirty = True
         self._step = 0
