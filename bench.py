@@ -273,7 +273,8 @@ def main():
             d = gemm[dom]
             roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": pmc_traffic(dom),
+                        "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch"),  # HBM bytes per launch (PMC)
+                        "traffic_detail": pmc_traffic(dom),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
                         "algorithmic_flop_per_launch": d["flop_per_launch"],
                         "note": "dominant training kernel; f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32; HIP events "
