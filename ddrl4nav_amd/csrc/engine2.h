@@ -49,6 +49,9 @@ __device__ __forceinline__ float u8_unit(unsigned b) {
 template <class Op>
 __device__ __forceinline__ void compute_block(const Op& op, const float* __restrict__ cur,
                                               f32x16 (&acc)[Op::TM][Op::TN]) {
+#ifdef DDRL_SETPRIO
+  __builtin_amdgcn_s_setprio(DDRL_SETPRIO);
+#endif
 #pragma unroll
   for (int s = 0; s < Op::KSTEPS; ++s) {
     float a[Op::TM], b[Op::TN];
@@ -62,6 +65,9 @@ __device__ __forceinline__ void compute_block(const Op& op, const float* __restr
       for (int j = 0; j < Op::TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
+#ifdef DDRL_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // Ops may declare `static constexpr int OCC` = waves per SIMD the register allocator must leave
