@@ -52,6 +52,40 @@ __device__ __forceinline__ void compute_block(const Op& op, const float* __restr
 #ifdef DDRL_SETPRIO
   __builtin_amdgcn_s_setprio(DDRL_SETPRIO);
 #endif
+#ifndef DDRL_NO_LDS_PREFETCH
+  // operands of k-step s+1 are read from LDS before the MFMAs of k-step s are issued (measured:
+  // -0.75 ms per PPO iteration over the un-pinned schedule, profiles/README.md)
+  float a[Op::TM], b[Op::TN];
+#pragma unroll
+  for (int i = 0; i < Op::TM; ++i) a[i] = cur[op.abase[i] + Op::aoff(0)];
+#pragma unroll
+  for (int j = 0; j < Op::TN; ++j) b[j] = cur[op.bbase[j] + Op::boff(0)];
+#pragma unroll
+  for (int s = 0; s < Op::KSTEPS; ++s) {
+    float an[Op::TM], bn[Op::TN];
+    if (s + 1 < Op::KSTEPS) {
+#pragma unroll
+      for (int i = 0; i < Op::TM; ++i) an[i] = cur[op.abase[i] + Op::aoff(s + 1 < Op::KSTEPS ? s + 1 : s)];
+#pragma unroll
+      for (int j = 0; j < Op::TN; ++j) bn[j] = cur[op.bbase[j] + Op::boff(s + 1 < Op::KSTEPS ? s + 1 : s)];
+    }
+#pragma unroll
+    for (int i = 0; i < Op::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Op::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (s + 1 < Op::KSTEPS) {
+#pragma unroll
+      for (int i = 0; i < Op::TM; ++i) a[i] = an[i];
+#pragma unroll
+      for (int j = 0; j < Op::TN; ++j) b[j] = bn[j];
+    }
+    // pin the order the machine scheduler would otherwise undo: the LDS reads of the NEXT k-step, then
+    // this k-step's MFMAs (0x100 = DS read, 0x008 = MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, Op::TM + Op::TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, Op::TM * Op::TN, 0);
+  }
+#else
 #pragma unroll
   for (int s = 0; s < Op::KSTEPS; ++s) {
     float a[Op::TM], b[Op::TN];
@@ -65,6 +99,7 @@ __device__ __forceinline__ void compute_block(const Op& op, const float* __restr
       for (int j = 0; j < Op::TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
+#endif
 #ifdef DDRL_SETPRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
@@ -79,6 +114,18 @@ struct OccOf {
 template <class Op>
 struct OccOf<Op, decltype((void)Op::OCC)> {
   static constexpr int v = Op::OCC;
+};
+
+// Ops may declare `static constexpr int COMMIT_FIRST = 1`: commit + fetch run before the MFMA block
+// of each iteration instead of after it (measured per op: helps the conv weight gradients, whose
+// commits carry the ReLU masks / u8 conversions; hurts the forward and data-gradient kernels).
+template <class Op, class = void>
+struct CommitFirstOf {
+  static constexpr bool v = false;
+};
+template <class Op>
+struct CommitFirstOf<Op, decltype((void)Op::COMMIT_FIRST)> {
+  static constexpr bool v = Op::COMMIT_FIRST != 0;
 };
 
 // Ops may define pre_epilogue(P): issued before the last k-block (see engine2_kernel).
@@ -122,10 +169,20 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
       // before the last k-block, so their latency hides under its MFMAs instead of being exposed
       if (kb == kbe - 1) op.pre_epilogue(P);
     }
-    compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
-    if (kb + 1 < kbe) {
-      op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
-      if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+    if constexpr (CommitFirstOf<Op>::v) {
+      // ops with a VALU-heavy commit (masks, u8 conversion): write the NEXT stage and issue the
+      // following fetch before this block's MFMAs, so the scheduler can run them under the MFMAs
+      if (kb + 1 < kbe) {
+        op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
+        if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+      }
+      compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
+    } else {
+      compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
+      if (kb + 1 < kbe) {
+        op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
+        if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+      }
     }
     __syncthreads();
     buf ^= 1;

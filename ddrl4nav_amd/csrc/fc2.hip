@@ -234,6 +234,7 @@ struct FcDgrad2 : FcCommon {
 //  rows = n (512), cols = k (3136), reduction = b
 // ------------------------------------------------------------------------------------------------
 struct FcWgrad2 : FcCommon {
+  static constexpr int COMMIT_FIRST = 1;  // 3.84 -> 3.80 ms
   static constexpr int A_OFF = 0, B_OFF = KMajorTile::FLOATS, STAGE = 2 * KMajorTile::FLOATS;
   static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena
   struct Params {
