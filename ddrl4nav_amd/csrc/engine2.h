@@ -46,6 +46,17 @@ __device__ __forceinline__ float u8_unit(unsigned b) {
   return __builtin_fmaf(e, r, q);
 }
 
+// Ops may declare `static constexpr int IGLP = 1`: use __builtin_amdgcn_iglp_opt(0) instead of the
+// pinned read-ahead order (measured per op: better for the three dense-layer kernels only).
+template <class Op, class = void>
+struct IglpOf {
+  static constexpr bool v = false;
+};
+template <class Op>
+struct IglpOf<Op, decltype((void)Op::IGLP)> {
+  static constexpr bool v = Op::IGLP != 0;
+};
+
 template <class Op>
 __device__ __forceinline__ void compute_block(const Op& op, const float* __restrict__ cur,
                                               f32x16 (&acc)[Op::TM][Op::TN]) {
@@ -82,8 +93,12 @@ __device__ __forceinline__ void compute_block(const Op& op, const float* __restr
     }
     // pin the order the machine scheduler would otherwise undo: the LDS reads of the NEXT k-step, then
     // this k-step's MFMAs (0x100 = DS read, 0x008 = MFMA)
-    __builtin_amdgcn_sched_group_barrier(0x100, Op::TM + Op::TN, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, Op::TM * Op::TN, 0);
+    if constexpr (IglpOf<Op>::v) {
+      if (s == 0) __builtin_amdgcn_iglp_opt(0);  // LLVM's built-in MFMA / DS interleave for small GEMMs
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, Op::TM + Op::TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, Op::TM * Op::TN, 0);
+    }
   }
 #else
 #pragma unroll

@@ -65,6 +65,7 @@ struct KTile {
 };
 
 struct Common {
+  static constexpr int IGLP = 1;  // as fc2.hip
   static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
   int abase[2], bbase[2];
   int kb_begin, kb_end;
