@@ -54,7 +54,11 @@ struct IglpOf {
 };
 template <class Op>
 struct IglpOf<Op, decltype((void)Op::IGLP)> {
+#ifdef DDRL_NO_IGLP  // A/B switch for tools/ablate_iter.py
+  static constexpr bool v = false;
+#else
   static constexpr bool v = Op::IGLP != 0;
+#endif
 };
 
 template <class Op>
@@ -140,7 +144,11 @@ struct CommitFirstOf {
 };
 template <class Op>
 struct CommitFirstOf<Op, decltype((void)Op::COMMIT_FIRST)> {
+#ifdef DDRL_NO_COMMIT_FIRST  // A/B switch for tools/ablate_iter.py
+  static constexpr bool v = false;
+#else
   static constexpr bool v = Op::COMMIT_FIRST != 0;
+#endif
 };
 
 // Ops may define pre_epilogue(P): issued before the last k-block (see engine2_kernel).
