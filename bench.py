@@ -145,7 +145,73 @@ def pmc_traffic(kernel):
         return None
 
 
-def build_net(n_envs, horizon, iters):
+def async_actor_leg(net, config_nn, N, T, ITERS, dev, steps=3):
+    """Asynchronous actor / learner on ONE GPU, as the reference deploys them by default (SYNC = False,
+    base_config.py:37: Forward servers keep acting while Backward trains and pick the new weights up
+    when the update tag moves, forward.py:121-126): the rollout of step i runs on a second HIP stream,
+    from a replica of the weights published after update i-2, while update i-1 runs on the main
+    stream.  Same work per step as the sequential headline (one 256 x 256 rollout + GAE + 10 PPO
+    iterations); reported next to it, never instead of it."""
+    from ddrl4nav_amd.agent import DeviceRollout
+    actor, _ = build_net(N, T, ITERS, max_batch=N)
+    ahp, hp = actor.hot_path, net.hot_path
+    ros = [DeviceRollout(actor, N, horizon=T, gamma=config_nn.EXTRINSIC_DISCOUNT, landa=config_nn.LANDA, seed=7 + i)
+           for i in range(2)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    for ro in ros:
+        ro.frames.copy_(torch.randint(0, 256, ro.frames.shape, dtype=torch.uint8, device=dev, generator=g))
+        u = torch.rand((T, N), device=dev, generator=g)
+        ro.rewards.copy_(torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)))
+        ro.dones.copy_((torch.rand((T, N), device=dev, generator=g) < (1.0 / 800)).to(torch.uint8))
+    snapshot = hp.params.clone()
+    # acting launches are small and latency-bound: a high-priority stream lets their workgroups slot in
+    # between the learner's long-running ones
+    s_act, cur = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.current_stream()
+    ev_published, ev_taken = torch.cuda.Event(), torch.cuda.Event()
+    ev_acted = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_published.record(cur)
+    ev_taken.record(cur)
+
+    def enqueue_rollout(i):
+        ro = ros[i % 2]
+        with torch.cuda.stream(s_act):
+            s_act.wait_event(ev_published)
+            ahp.params.copy_(snapshot)
+            ev_taken.record(s_act)
+            ahp.params_changed()
+            for t in range(T):
+                ro.act(t)
+            ro.bootstrap()
+            ro.finish()
+            ev_acted[i % 2].record(s_act)
+
+    def learn_on(i):
+        cur.wait_event(ev_acted[i % 2])
+        for _ in net.learn(ros[i % 2].batch()):
+            pass
+        cur.wait_event(ev_taken)       # the actor has copied the previous publication
+        snapshot.copy_(hp.params)      # publish (the reference: nn2redis after the last iteration, backward.py:196-199)
+        ev_published.record(cur)
+
+    enqueue_rollout(0)
+    enqueue_rollout(1)
+    learn_on(0)                        # warm-up step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1, steps + 1):
+        enqueue_rollout(i + 1)
+        learn_on(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    actor.hot_path.close()
+    return {"value": round(steps * N * T / elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "steps": steps,
+            "note": "rollout i+1 (second stream, weights published after update i-1) overlaps update i on one GPU: the "
+                    "reference's default asynchronous deployment (SYNC=False); same work per step as `value`"}
+
+
+def build_net(n_envs, horizon, iters, max_batch=None):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
     env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": n_envs, "int_frame_stack": 4,
@@ -155,7 +221,8 @@ def build_net(n_envs, horizon, iters):
     config_nn.TRAINING_ITER_TIME = iters
     config = BaseConfig(parse, env)
     config.TIME_MAX = horizon
-    return create_net({"config": config, "config_nn": config_nn, "config_env": env}, max_batch=n_envs * horizon), config_nn
+    return create_net({"config": config, "config_nn": config_nn, "config_env": env},
+                      max_batch=max_batch if max_batch is not None else n_envs * horizon), config_nn
 
 
 def main():
@@ -167,6 +234,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=256, help="TIME_MAX")
     ap.add_argument("--iters", type=int, default=10, help="TRAINING_ITER_TIME")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-async", action="store_true", help="skip the asynchronous actor/learner leg")
     args = ap.parse_args()
 
     from ddrl4nav_amd.dist import broadcast_params, init_from_env
@@ -297,6 +365,12 @@ def main():
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
         }
+        if world == 1 and not args.no_async:
+            hp.profile(False)
+            try:
+                out["async_actor_learner"] = async_actor_leg(net, config_nn, N, T, ITERS, dev)
+            except Exception as e:  # an extra, never allowed to take the headline line down
+                out["async_actor_learner"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
