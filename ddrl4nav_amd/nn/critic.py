@@ -1,14 +1,30 @@
-"""Critic head (mirror of USTC_lab/nn/critic.py:6-21); note critic_linear is registered before
-pre, which fixes the parameter order of the flat arena."""
+"""Value head: parameter holder for the state-value estimator V(s).
+
+Interface parity with the reference's critic (USTC_lab/nn/critic.py:6-21): constructor keywords
+``device``, ``last_input_dim``, ``pre`` and the attribute names ``critic_linear`` / ``pre`` -- the
+latter fix the ``state_dict`` keys (``critic.critic_linear.weight`` ...) and, because the linear
+layer is registered BEFORE the optional private encoder, the position of both inside the flat
+parameter arena (csrc/common.h: make_layout).
+
+There is no arithmetic here.  The dot product with the 512-wide features, the squared-error /
+smooth-L1 loss and their backward run in the head kernels (csrc/heads.hip, csrc/gheads.hip) of the
+PPO object that owns this module.
+"""
 from torch import nn
+
+__all__ = ["Critic"]
+
+_FEATURES = 512  # AC_INPUT_DIM
 
 
 class Critic(nn.Module):
-    def __init__(self, device='cpu', last_input_dim=512, pre=None):
-        super().__init__()
+    def __init__(self, device="cpu", last_input_dim=_FEATURES, pre=None):
+        nn.Module.__init__(self)
+        # registration order matters: head first, encoder second (see module docstring)
+        self.add_module("critic_linear", nn.Linear(int(last_input_dim), 1))
+        self.add_module("pre", pre) if pre is not None else setattr(self, "pre", None)
         self.device = device
-        self.critic_linear = nn.Linear(last_input_dim, 1)
-        self.pre = pre
 
-    def forward(self, x):
-        raise RuntimeError("the critic runs inside ddrl4nav_amd.nn.PPO (HIP kernels)")
+    def forward(self, features):
+        raise RuntimeError("Critic is evaluated inside ddrl4nav_amd.nn.PPO / GenericPPO by the HIP head kernels; "
+                           "it cannot be called on its own")
