@@ -181,3 +181,42 @@ def test_generic_ppo_dispatch_and_blob_roundtrip(golden):
     g = golden("f15_mlp_classical")
     (_, lp), _ = net2(_states(g), torch.from_numpy(g["actions"]))
     np.testing.assert_allclose(lp.cpu().numpy(), g["logp"], rtol=2e-5, atol=2e-6)
+
+
+def test_nav_config4_batch_properties():
+    """BASELINE config 4 scale (512 envs): size-independent properties of the robot_nav net at
+    B = 2,048 -- (a) the micro-batched gradient (4 x 512) equals the one-shot gradient, (b) duplicating
+    the batch leaves mean losses and the mean gradient unchanged, (c) forward is independent of the
+    position of a sample in the batch."""
+    from ddrl4nav_amd.data import Experience
+    B = 2048
+    g = torch.Generator(device="cuda").manual_seed(404)
+    half = B // 2
+    lz = torch.rand((half, 1, 960), device="cuda", generator=g)
+    vec = torch.randn((half, 5), device="cuda", generator=g)
+    ped = (torch.rand((half, 3, 48, 48), device="cuda", generator=g) < 0.15).float()
+    dup = lambda t: torch.cat([t, t]).contiguous()
+    states = [dup(lz), dup(vec), dup(ped)]
+    acts = dup(torch.randn((half, 2), device="cuda", generator=g))
+    old = dup(torch.full((half,), -2.0, device="cuda") + 0.2 * torch.randn(half, device="cuda", generator=g))
+    adv = dup(torch.randn(half, device="cuda", generator=g))
+    ret = dup(torch.randn(half, device="cuda", generator=g))
+    grads, losses = [], []
+    for cap, sl in ((2048, slice(0, B)), (512, slice(0, B)), (1024, slice(0, half))):
+        net, _ = _make("f13_nav1d_gauss", max_batch=cap)
+        net.training_iter_time = 1
+        exp = Experience(states=[s[sl] for s in states], advs=adv[sl], actions=acts[sl], old_logps=old[sl],
+                         values=ret[sl].reshape(1, -1))
+        losses.append([l for l, _, _ in net.learn(exp)][0])
+        grads.append(net.grads[:net.n_params].clone())
+        if cap == 2048:
+            (d1, _), v1 = net([s[:300] for s in states], acts[:300])
+            (d2, _), v2 = net([s[half:half + 300] for s in states], acts[half:half + 300])
+            assert torch.equal(v1[0], v2[0]) and torch.equal(d1.mean, d2.mean)       # (c)
+    # clip_adam scales .grad in place by the clip coefficient: compare directions and the logged losses
+    unit = [x / x.norm() for x in grads]
+    assert (unit[0] - unit[1]).abs().max().item() <= 2e-4 * unit[0].abs().max().item()   # (a)
+    assert (unit[0] - unit[2]).abs().max().item() <= 2e-4 * unit[0].abs().max().item()   # (b)
+    for k in ("ActorLoss", "VLoss", "EntLoss"):
+        assert abs(losses[0][k] - losses[1][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
+        assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
