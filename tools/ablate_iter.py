@@ -1,5 +1,7 @@
-import torch, sys
-sys.path.insert(0, ".")
+"""Per-kernel HIP-event times of three PPO iterations at the bench shape (B = 65,536): the A/B driver of the
+kernel experiments recorded in profiles/README.md.  Usage: python tools/ablate_iter.py <tag>"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ddrl4nav_amd.engine import HotPath
 from ddrl4nav_amd.utils.recipe import flatten, make_weights
 B=65536
