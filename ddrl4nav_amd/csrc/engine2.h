@@ -1,15 +1,20 @@
-// Pipelined f32-MFMA tile engine (v2).
+// Pipelined f32-MFMA tile engine shared by every GEMM-shaped kernel of the library.
 //
 //   C[row][col] = sum_k A(row,k) * B(k,col),  rows -> MFMA A operand -> accumulator registers,
 //   cols -> MFMA B operand -> lanes (stores are coalesced along cols).
 //
-// Differences from the v1 engine in igemm.hip:
+// Design points (the first build of this library gathered im2col tiles element by element and
+// ran at a third of this engine's rate, profiles/README.md):
 //   * operands are read from LDS as  lds[lane_base + compile-time immediate]  (one ds_read_b32
 //     with an offset field per operand, zero address VALU inside the k loop);
 //   * LDS is double buffered and the next k-block is prefetched global -> registers while the
 //     current one feeds the matrix pipe (one barrier per k-block);
 //   * ops stage RAW tensors (input planes, weight slabs) with wide coalesced loads instead of
-//     gathering an im2col tile element by element.
+//     gathering an im2col tile element by element (the generic gather ops of gconv.hip are the
+//     exception, for layers without a specialised kernel);
+//   * the order of LDS reads and MFMAs inside a k-block is pinned (compute_block), and ops choose
+//     by trait whether commit/fetch run before or after the MFMA block (COMMIT_FIRST, IGLP, OCC,
+//     EXTRA, PRE_EPILOGUE below).
 //
 // An Op provides:
 //   constants  THREADS, TM, TN, KSTEPS, STAGE (floats per LDS buffer)

@@ -1,6 +1,6 @@
 // Actor / critic heads, Categorical bookkeeping, PPO dual-clip loss and its gradient, fused with
 // the backward of the two head layers.  One wavefront per sample: the 512-wide dot products
-// are 8 elements per lane + a wave64 xor-shuffle butterfly; the A (<= 8) logits then live
+// are 8 elements per lane + a wave64 xor-shuffle butterfly; the A (<= 18) logits then live
 // redundantly in every lane so softmax / loss / gradient need no further communication.
 //
 // Reference arithmetic replaced:

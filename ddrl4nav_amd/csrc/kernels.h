@@ -32,7 +32,7 @@ struct EncCall {
   int64_t max_batch;
 };
 
-// igemm.hip
+// encoder.hip
 void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st);
 void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
 
