@@ -3,7 +3,8 @@
 GaussionActor(2) + Critic): PPO iterations on synthetic inputs, per-operator HIP-event times and
 algorithmic TFLOP/s.  Not the headline bench (bench.py is); prints one JSON line.
 
-Usage: python tools/bench_nav.py [B] [micro_batch] [iters]"""
+Usage: python tools/bench_nav.py [B] [micro_batch] [iters] [T]
+(T given: also one whole actor-learner loop at 512 envs x T steps, BASELINE config 4 shape)"""
 import json
 import sys
 import time
@@ -96,7 +97,48 @@ rows = {k: {"ms_per_iter": round(v[0] / ITERS, 3), "tflops": round(v[1] / (v[0] 
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
 tot_ms = sum(v[0] for v in agg.values()) / ITERS
 tot_flop = sum(v[1] for v in agg.values()) / ITERS
+# ---- whole loop at the BASELINE config-4 shape: 512 envs, T steps of acting + bootstrap + GAE + one PPO update ----
+loop = None
+if len(sys.argv) > 4:
+    from ddrl4nav_amd.agent.agent import gae_device
+    N, T = 512, int(sys.argv[4])
+    pool = [torch.rand((T + 1, N, 1, 960), device="cuda", generator=g), torch.randn((T + 1, N, 5), device="cuda", generator=g),
+            (torch.rand((T + 1, N, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
+    values = torch.zeros((T + 1, N), device="cuda")
+    actions = torch.zeros((T, N, 2), device="cuda")
+    logps = torch.zeros((T, N), device="cuda")
+    u = torch.rand((T, N), device="cuda", generator=g)
+    rewards = torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)).contiguous()
+    dones = (torch.rand((T, N), device="cuda", generator=g) < 1.0 / 800).to(torch.uint8)
+
+    def one_loop():
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for t in range(T + 1):
+            (dist, _), v = net([p[t] for p in pool])
+            values[t].copy_(v[0][:, 0])
+            if t < T:
+                a = dist.sample()
+                actions[t].copy_(a)
+                logps[t].copy_(net.actor.log_prob_from_distribution(dist, a))
+        adv, ret = gae_device(values, rewards, dones, 0.99, 0.95)
+        e1.record()
+        exp = Experience(states=[p[:T].reshape((T * N,) + tuple(p.shape[2:])) for p in pool], advs=adv.view(-1),
+                         actions=actions.view(T * N, 2), old_logps=logps.view(-1), values=ret.view(1, -1))
+        for _ in net.learn(exp):
+            pass
+        e2.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1), e1.elapsed_time(e2)
+
+    one_loop()
+    events.clear()
+    act_ms, upd_ms = one_loop()
+    loop = {"envs": N, "horizon": T, "ppo_iters": ITERS, "acting_plus_gae_ms": round(act_ms, 1), "update_ms": round(upd_ms, 1),
+            "env_steps_per_s": round(N * T / ((act_ms + upd_ms) * 1e-3), 1),
+            "acting_env_steps_per_s": round(N * (T + 1) / (act_ms * 1e-3), 1)}
 print(json.dumps({"workload": "robot_nav: NavPreNet1D x2 + GaussionActor(2), PPO iteration", "B": B, "micro_batch": CAP,
+                  "whole_loop": loop,
                   "ms_per_ppo_iter_wall": round(wall * 1e3, 2), "gemm_ops_ms_per_iter": round(tot_ms, 2),
                   "algorithmic_tflops_over_gemm_ops": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
                   "samples_per_s": round(B / wall, 1), "ops": rows}))
