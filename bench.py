@@ -84,11 +84,36 @@ def cpu_baseline(seconds_budget=20.0):
                      "PPO iteration B=1024 x%d; per env-step = 1 forward + 10 iterations" % (reps, iters),
            "forward_samples_per_s": round(1.0 / t_fwd, 1), "ppo_iter_ms_B1024": round(t_iter * B * 1e3, 2),
            "host_cpus": cores}
-    try:
-        out["same_gpu_torch"] = torch_rocm_baseline(net, x, acts, old, adv, ret)
-    except Exception as e:  # the comparison leg must never take the bench line down
-        out["same_gpu_torch"] = {"error": repr(e)[:200]}
+    out["same_gpu_torch"] = torch_rocm_baseline_child()
     return out
+
+
+def torch_rocm_baseline_child(timeout_s=240):
+    """Run torch_rocm_baseline in a child process: MIOpen / rocBLAS are third-party code paths this
+    library never uses, and a fault in them must not be able to take the bench line down."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-leg"], capture_output=True, text=True,
+                           timeout=timeout_s)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": "rc=%d %s" % (r.returncode, r.stderr.strip()[-160:])}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
+def torch_leg_main():
+    from ddrl4nav_amd.utils.recipe import make_weights
+    from oracle import ddrl_oracle as O
+    rng = np.random.default_rng(1234)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    B = 1024
+    x = O.frames_to_f32(rng.integers(0, 256, size=(B, 4, 84, 84), dtype=np.uint8))
+    acts = torch.from_numpy(rng.integers(0, 6, size=B).astype(np.float32))
+    old = torch.full((B,), -1.79, dtype=torch.float32)
+    adv = torch.from_numpy(rng.normal(size=B).astype(np.float32))
+    ret = torch.from_numpy(rng.normal(size=B).astype(np.float32))
+    print(json.dumps(torch_rocm_baseline(net, x, acts, old, adv, ret)))
 
 
 def torch_rocm_baseline(net, x, acts, old, adv, ret):
@@ -226,6 +251,8 @@ def build_net(n_envs, horizon, iters, max_batch=None):
 
 
 def main():
+    if "--torch-leg" in sys.argv:  # child process of cpu_baseline(): the same-GPU PyTorch-ROCm comparison
+        return torch_leg_main()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
