@@ -280,3 +280,22 @@ def test_create_net_shared_prenet_branch(golden):
     cfgs2 = _configs()
     with pytest.raises(ValueError):
         PPO(n.actor, n.critic, n.prenet, None, cfgs2["config"], cfgs2["config_nn"], max_batch=8)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """tests/c/abi_smoke.c: a C program (no Python, no torch) drives forward / GAE / PPO iteration /
+    Adam through include/ddrl.h."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or "cc"
+    lib_dir = os.path.join(root, "ddrl4nav_amd", "csrc")
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run([cc, "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "c", "abi_smoke.c"),
+                    "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include", "-L", lib_dir, "-L", "/opt/rocm/lib",
+                    "-lddrl_hip", "-lamdhip64", "-lm", "-o", exe], check=True, timeout=300)
+    env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "C ABI OK" in out.stdout
