@@ -10,6 +10,7 @@
 //   PPO.learn loss block + autograd                            USTC_lab/nn/ppo.py:82-129
 #include "kernels.h"
 #include "ops.h"
+#include "ppo_math.h"
 
 namespace ddrl {
 
@@ -127,7 +128,6 @@ __global__ __launch_bounds__(256) void gauss_loss_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) gwc[i] = 0.0f;
   double s_actor = 0.0, s_v = 0.0, s_ent = 0.0;
-  const float lo = 1.0f - cfg.ppo_clip, hi = 1.0f + cfg.ppo_clip;
   float ent_b = 0.0f;  // sum_d entropy_d / D : identical for every sample
 #pragma unroll
   for (int d = 0; d < MAXD; ++d)
@@ -153,34 +153,12 @@ __global__ __launch_bounds__(256) void gauss_loss_kernel(
       if (d < D) logp += -(diff[d] * diff[d]) / (2.0f * R.var[d]) - R.log_scale[d] - LOG_SQRT_2PI;
     }
     const float adv = advs[b];
-    const float ratio = expf(logp - old_logps[b]);
-    const float surr1 = ratio * adv;
-    const float rc = fminf(fmaxf(ratio, lo), hi);
-    const float surr2 = rc * adv;
-    const float mn = fminf(surr1, surr2);
-    const float dual = cfg.dual_clip * adv;
-    const float term = (adv > 0.0f) ? mn : fmaxf(mn, dual);
-    s_actor += (double)term;
+    const SurrogateTerm sg = ppo_surrogate(logp, old_logps[b], adv, cfg, inv_b);
+    s_actor += (double)sg.term;
     const float err = rets[b] - v;
-    float gv_unit;
-    if (cfg.smooth_l1_loss) {
-      const float ae = fabsf(err);
-      s_v += (ae < 1.0f) ? 0.5 * (double)err * (double)err : (double)ae - 0.5;
-      gv_unit = (err < -1.0f) ? 1.0f : ((err > 1.0f) ? -1.0f : -err);
-    } else {
-      s_v += (double)err * (double)err;
-      gv_unit = -err;
-    }
+    const float gv_unit = value_loss_element(err, cfg, s_v);
     s_ent += (double)ent_b;
-    // backward through the surrogate (torch min/max tie rule: split evenly), as heads.hip
-    const float g_term = -inv_b;
-    float g_mn;
-    if (adv > 0.0f) g_mn = g_term;
-    else g_mn = (mn > dual) ? g_term : ((mn == dual) ? 0.5f * g_term : 0.0f);
-    const float g_s1 = (surr1 < surr2) ? g_mn : ((surr1 == surr2) ? 0.5f * g_mn : 0.0f);
-    const float g_s2 = (surr2 < surr1) ? g_mn : ((surr1 == surr2) ? 0.5f * g_mn : 0.0f);
-    const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
-    const float g_logp = (g_s1 * adv + g_s2 * adv * inrange) * ratio;
+    const float g_logp = sg.g_logp;
     const float gv = shared ? gv_unit * inv_b * cfg.v_loss_theta : gv_unit * inv_b;
     float dmu[MAXD];
 #pragma unroll

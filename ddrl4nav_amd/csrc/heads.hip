@@ -9,6 +9,7 @@
 //   ForwardThread.run sampling + log_prob      USTC_lab/server/forward.py:132-138
 //   PPO.learn loss block + autograd            USTC_lab/nn/ppo.py:82-108,122-123
 #include "kernels.h"
+#include "ppo_math.h"
 
 namespace ddrl {
 
@@ -253,7 +254,6 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) gwc[i] = 0.0f;
   double s_actor = 0.0, s_v = 0.0, s_ent = 0.0;
-  const float lo = 1.0f - cfg.ppo_clip, hi = 1.0f + cfg.ppo_clip;
 
   // shared prenet (ppo.py:110-117): one backward of total_loss = actor_loss + theta_v * v_loss
   // - theta_e * entropy, so the value gradient carries theta_v, the entropy has a gradient, and
@@ -283,40 +283,17 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     const int a = (int)actions[b];
     const float adv = advs[b];
     const float logp = pick(d.lc, a);
-    const float ratio = expf(logp - old_logps[b]);
-    const float surr1 = ratio * adv;
-    const float rc = fminf(fmaxf(ratio, lo), hi);
-    const float surr2 = rc * adv;
-    const float mn = fminf(surr1, surr2);
-    const float dual = cfg.dual_clip * adv;
-    const float term = (adv > 0.0f) ? mn : fmaxf(mn, dual);
-    s_actor += (double)term;
+    const SurrogateTerm sg = ppo_surrogate(logp, old_logps[b], adv, cfg, inv_b);
+    s_actor += (double)sg.term;
     const float err = rets[b] - v;
-    float gv_unit;  // d(v_loss element)/d(v) before the 1/B
-    if (cfg.smooth_l1_loss) {  // F.smooth_l1_loss(ret, v), beta = 1 (ppo.py:54)
-      const float ae = fabsf(err);
-      s_v += (ae < 1.0f) ? 0.5 * (double)err * (double)err : (double)ae - 0.5;
-      gv_unit = (err < -1.0f) ? 1.0f : ((err > 1.0f) ? -1.0f : -err);
-    } else {  // mean((ret - v)^2) / 2 (ppo.py:57); the 1/2 is applied by heads_reduce
-      s_v += (double)err * (double)err;
-      gv_unit = -err;
-    }
+    const float gv_unit = value_loss_element(err, cfg, s_v);  // d(v_loss element)/d(v) before the 1/B
     float ent = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXA; ++j)
       if (j < A) ent += d.lc[j] * d.q[j];
     s_ent += (double)(-ent);
 
-    // ---- backward through the surrogate (torch min/max tie rule: split evenly) ----
-    const float g_term = -inv_b;
-    float g_mn;
-    if (adv > 0.0f) g_mn = g_term;
-    else g_mn = (mn > dual) ? g_term : ((mn == dual) ? 0.5f * g_term : 0.0f);
-    const float g_s1 = (surr1 < surr2) ? g_mn : ((surr1 == surr2) ? 0.5f * g_mn : 0.0f);
-    const float g_s2 = (surr2 < surr1) ? g_mn : ((surr1 == surr2) ? 0.5f * g_mn : 0.0f);
-    const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
-    const float g_ratio = g_s1 * adv + g_s2 * adv * inrange;
-    const float g_logp = g_ratio * ratio;
+    const float g_logp = sg.g_logp;
     // ---- log(clamp(q_a)) , q = p / sum(p) , softmax ----
     const float qa = pick(d.q, a), pa = pick(d.p, a);
     const float qa_c = fminf(fmaxf(qa, CAT_EPS), 1.0f - CAT_EPS);
