@@ -17,20 +17,6 @@ namespace ddrl {
 constexpr int MAXD = 8;
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;  // math.log(math.sqrt(2 * math.pi))
 
-__device__ __forceinline__ float gwave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ void gload8(const float* p, float* o) {
-  const float4 x = ((const float4*)p)[0], y = ((const float4*)p)[1];
-  o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
-  o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
-}
-__device__ __forceinline__ void gstore8(float* p, const float* o) {
-  ((float4*)p)[0] = make_float4(o[0], o[1], o[2], o[3]);
-  ((float4*)p)[1] = make_float4(o[4], o[5], o[6], o[7]);
-}
 
 struct GHeadRegs {
   float wa[MAXD][8], wc[8], ba[MAXD], std[MAXD], var[MAXD], log_scale[MAXD], bc;
@@ -72,19 +58,19 @@ __global__ __launch_bounds__(256) void gauss_act_kernel(const float* __restrict_
   gload_weights(R, params, L, lane);
   for (int b = gw; b < n; b += nw) {
     float ha[8], hc[8];
-    gload8(h_actor + (int64_t)b * FEAT + lane * 8, ha);
-    gload8(h_critic + (int64_t)b * FEAT + lane * 8, hc);
+    load8(h_actor + (int64_t)b * FEAT + lane * 8, ha);
+    load8(h_critic + (int64_t)b * FEAT + lane * 8, hc);
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
-    const float v = gwave_sum(sv) + R.bc;
+    const float v = wave_sum(sv) + R.bc;
     float logp = 0.0f;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], R.wa[d][i], s);
-      const float mu = gwave_sum(s) + R.ba[d];
+      const float mu = wave_sum(s) + R.ba[d];
       if (d < L.D) {
         float a;
         if (act_in != nullptr) a = act_in[(int64_t)b * L.D + d];
@@ -136,19 +122,19 @@ __global__ __launch_bounds__(256) void gauss_loss_kernel(
 
   for (int b = gw; b < n; b += nw) {
     float ha[8], hc[8];
-    gload8(h_actor + (int64_t)b * FEAT + lane * 8, ha);
-    gload8(h_critic + (int64_t)b * FEAT + lane * 8, hc);
+    load8(h_actor + (int64_t)b * FEAT + lane * 8, ha);
+    load8(h_critic + (int64_t)b * FEAT + lane * 8, hc);
     float sv = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
-    const float v = gwave_sum(sv) + R.bc;
+    const float v = wave_sum(sv) + R.bc;
     float diff[MAXD], logp = 0.0f;
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) {
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], R.wa[d][i], s);
-      const float mu = gwave_sum(s) + R.ba[d];
+      const float mu = wave_sum(s) + R.ba[d];
       diff[d] = (d < D) ? actions[(int64_t)b * D + min(d, D - 1)] - mu : 0.0f;
       if (d < D) logp += -(diff[d] * diff[d]) / (2.0f * R.var[d]) - R.log_scale[d] - LOG_SQRT_2PI;
     }
@@ -188,10 +174,10 @@ __global__ __launch_bounds__(256) void gauss_loss_kernel(
     if (shared) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) da[i] += dc[i];
-      gstore8(dh_actor + (int64_t)b * FEAT + lane * 8, da);
+      store8(dh_actor + (int64_t)b * FEAT + lane * 8, da);
     } else {
-      gstore8(dh_actor + (int64_t)b * FEAT + lane * 8, da);
-      gstore8(dh_critic + (int64_t)b * FEAT + lane * 8, dc);
+      store8(dh_actor + (int64_t)b * FEAT + lane * 8, da);
+      store8(dh_critic + (int64_t)b * FEAT + lane * 8, dc);
     }
     if (lane < D) {
       float x = dmu[0];

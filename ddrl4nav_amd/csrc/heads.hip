@@ -19,13 +19,6 @@ namespace ddrl {
 constexpr int MAXA_SMALL = 8, MAXA_LARGE = 18;
 constexpr float CAT_EPS = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-__device__ __forceinline__ void load8(const float* p, float* o);
 
 template <int MAXA, bool WLDS>
 struct HeadRegs {
@@ -79,15 +72,6 @@ __device__ __forceinline__ void load_head_weights(HeadRegs<MAXA, WLDS>& R, const
   R.bc = params[L.critic_b];
 }
 
-__device__ __forceinline__ void load8(const float* p, float* o) {
-  const float4 x = ((const float4*)p)[0], y = ((const float4*)p)[1];
-  o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
-  o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
-}
-__device__ __forceinline__ void store8(float* p, const float* o) {
-  ((float4*)p)[0] = make_float4(o[0], o[1], o[2], o[3]);
-  ((float4*)p)[1] = make_float4(o[4], o[5], o[6], o[7]);
-}
 
 template <int MAXA>
 struct Dist {

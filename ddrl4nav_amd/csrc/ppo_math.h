@@ -1,4 +1,4 @@
-// Per-sample arithmetic of the PPO loss block shared by the categorical (heads.hip) and Gaussian
+// Wave-level helpers and the per-sample arithmetic of the PPO loss block shared by the categorical (heads.hip) and Gaussian
 // (gheads.hip) head kernels.  Reference: USTC_lab/nn/ppo.py:82-108 and the autograd backward of
 // torch.min / torch.max / torch.clamp / torch.where (ties split evenly, clamp passes gradient on
 // the closed interval).
@@ -6,6 +6,22 @@
 #include "common.h"
 
 namespace ddrl {
+
+// ---- one wavefront per sample: 512 features = 8 per lane -----------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {  // wave64 xor-shuffle butterfly, result in every lane
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ void load8(const float* p, float* o) {
+  const float4 x = ((const float4*)p)[0], y = ((const float4*)p)[1];
+  o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
+  o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
+}
+__device__ __forceinline__ void store8(float* p, const float* o) {
+  ((float4*)p)[0] = make_float4(o[0], o[1], o[2], o[3]);
+  ((float4*)p)[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
 
 struct SurrogateTerm {
   float term;    // where(adv > 0, m, max(m, dual_clip * adv)),  m = min(ratio * adv, clamp(ratio) * adv)
