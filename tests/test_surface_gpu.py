@@ -299,3 +299,37 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "C ABI OK" in out.stdout
+
+
+def test_pinned_ring_producer_consumer_threads():
+    """Producer and consumer on different threads, more messages than slots: order is preserved, no
+    slot is overwritten before its copy finished, back-pressure blocks instead of dropping."""
+    import threading
+    from ddrl4nav_amd.data import PinnedRing
+    slot, n_msgs = 256 * 1024, 64
+    ring = PinnedRing(slot, n_slots=4)
+    dst = torch.zeros((n_msgs, slot), dtype=torch.uint8, device="cuda")
+    errors = []
+
+    def producer():
+        try:
+            for i in range(n_msgs):
+                buf = ring.acquire(timeout_ms=5000)
+                buf[:] = (i * 7 + np.arange(slot) % 251) % 256   # content depends on the message index
+                ring.commit()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=producer)
+    t.start()
+    stream = torch.cuda.Stream()
+    for i in range(n_msgs):
+        ring.pop_to(dst[i], stream=stream, timeout_ms=5000)
+    t.join(timeout=30)
+    stream.synchronize()
+    assert not errors and not t.is_alive() and ring.pending() == 0
+    got = dst.cpu().numpy()
+    base = np.arange(slot) % 251
+    for i in range(n_msgs):
+        assert np.array_equal(got[i], ((i * 7 + base) % 256).astype(np.uint8)), i
+    ring.close()
