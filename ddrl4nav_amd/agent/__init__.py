@@ -1,4 +1,4 @@
 from ddrl4nav_amd.agent.agent import Agents, gae_device
-from ddrl4nav_amd.agent.rollout import DeviceRollout
+from ddrl4nav_amd.agent.rollout import DeviceRollout, StateRollout
 
-__all__ = ["Agents", "gae_device", "DeviceRollout"]
+__all__ = ["Agents", "gae_device", "DeviceRollout", "StateRollout"]

@@ -75,3 +75,68 @@ class DeviceRollout:
         B = self.N * self.T
         return Experience(states=[self.frames[:self.T].view(B, self.C, 84, 84)], advs=self.adv.view(B),
                           actions=self.actions.view(B), old_logps=self.logps.view(B), values=self.ret.view(1, B))
+
+
+class StateRollout:
+    """DeviceRollout for the operator-composed nets (nn/generic.py): the observation is a LIST of
+    float tensors per env (e.g. robot_nav: laser [1,960], vector [5], pedestrian image [3,48,48]) and
+    the action may be continuous.  Same pool layout idea ([time][env] major, everything on the GPU),
+    same life cycle: put_states(t, ...) -> act(t) -> record(t, ...) ... bootstrap() -> finish() -> batch()."""
+
+    def __init__(self, net, n_envs, state_shapes, horizon=256, gamma=0.99, landa=0.95, device=None):
+        self.net = net
+        self.N, self.T = int(n_envs), int(horizon)
+        self.gamma, self.landa = gamma, landa
+        dev = torch.device(device if device is not None else net.device)
+        self.device = dev
+        N, T = self.N, self.T
+        f = dict(dtype=torch.float32, device=dev)
+        self.states = [torch.empty((T + 1, N) + tuple(int(d) for d in shape), **f) for shape in state_shapes]
+        self.values = torch.zeros((T + 1, N), **f)
+        self.rewards = torch.zeros((T, N), **f)
+        self.dones = torch.zeros((T, N), dtype=torch.uint8, device=dev)
+        act_shape = (T, N, net.n_actions) if getattr(net, "continuous", False) else (T, N)
+        self.actions = torch.zeros(act_shape, **f)
+        self.logps = torch.zeros((T, N), **f)
+        self.adv = torch.empty((T, N), **f)
+        self.ret = torch.empty((T, N), **f)
+        self.copy_stream = torch.cuda.Stream(device=dev)
+
+    def put_states(self, t, states):
+        """Device or pinned-host tensors, one per observation component -> pool slot t."""
+        for pool, s in zip(self.states, states):
+            pool[t].copy_(torch.as_tensor(s).reshape(pool[t].shape), non_blocking=True)
+
+    def put_state_from_ring(self, t, index, ring):
+        """Component `index` of slot t from a pinned ring (raw fp32 bytes), on the copy stream."""
+        ring.pop_to(self.states[index][t], stream=self.copy_stream)
+        torch.cuda.current_stream().wait_stream(self.copy_stream)
+
+    def act(self, t):
+        (dist, _), values = self.net([p[t] for p in self.states])
+        a = dist.sample()
+        self.values[t].copy_(values[0][:, 0])
+        self.actions[t].copy_(a)
+        self.logps[t].copy_(self.net.actor.log_prob_from_distribution(dist, a))
+        return self.actions[t]
+
+    def bootstrap(self):
+        (_, _), values = self.net([p[self.T] for p in self.states], play_mode=True)
+        self.values[self.T].copy_(values[0][:, 0])
+
+    def record(self, t, rewards, dones):
+        self.rewards[t].copy_(rewards, non_blocking=True)
+        self.dones[t].copy_(dones, non_blocking=True)
+
+    def finish(self):
+        gae_device(self.values, self.rewards, self.dones, self.gamma, self.landa, adv=self.adv, ret=self.ret)
+
+    def carry_over(self):
+        for p in self.states:
+            p[0].copy_(p[self.T])
+
+    def batch(self):
+        B = self.N * self.T
+        return Experience(states=[p[:self.T].reshape((B,) + tuple(p.shape[2:])) for p in self.states],
+                          advs=self.adv.view(B), actions=self.actions.view((B,) + tuple(self.actions.shape[2:])),
+                          old_logps=self.logps.view(B), values=self.ret.view(1, B))

@@ -220,3 +220,37 @@ def test_nav_config4_batch_properties():
     for k in ("ActorLoss", "VLoss", "EntLoss"):
         assert abs(losses[0][k] - losses[1][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
         assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
+
+
+def test_state_rollout_loop_matches_manual_sequence(golden):
+    """StateRollout (device-resident pool for list-of-tensor observations): acting, bootstrap, GAE and the
+    learner batch equal the same steps done by hand; one learn() on its batch runs."""
+    from ddrl4nav_amd.agent import StateRollout
+    from oracle import ddrl_oracle as O
+    net, _ = _make("f13_nav1d_gauss", max_batch=64)
+    N, T = 6, 5
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ro = StateRollout(net, N, [(1, 960), (5,), (3, 48, 48)], horizon=T)
+    for t in range(T + 1):
+        ro.put_states(t, [torch.rand((N, 1, 960), device="cuda", generator=g), torch.randn((N, 5), device="cuda", generator=g),
+                          (torch.rand((N, 3, 48, 48), device="cuda", generator=g) < 0.2).float()])
+    rew = torch.randn((T, N), device="cuda", generator=g)
+    done = (torch.rand((T, N), device="cuda", generator=g) < 0.2).to(torch.uint8)
+    for t in range(T):
+        a = ro.act(t)
+        assert a.shape == (N, 2)
+        ro.record(t, rew[t], done[t])
+    ro.bootstrap()
+    ro.finish()
+    # values / logps equal a fresh evaluation of the stored actions; GAE equals the oracle scan
+    for t in range(T):
+        (_, lp), v = net([p[t] for p in ro.states], ro.actions[t])
+        assert torch.allclose(lp, ro.logps[t], rtol=1e-5, atol=1e-5) and torch.equal(v[0][:, 0], ro.values[t])
+    adv, ret = O.gae(ro.values.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy())
+    assert np.array_equal(ro.adv.cpu().numpy(), adv) and np.array_equal(ro.ret.cpu().numpy(), ret)
+    exp = ro.batch()
+    assert exp.states[2].shape == (N * T, 3, 48, 48) and exp.actions.shape == (N * T, 2) and exp.values.shape == (1, N * T)
+    losses = [l for l, _, _ in net.learn(exp)]
+    assert len(losses) == 10 and all(np.isfinite(l["PpoTotalLoss"]) for l in losses)
+    ro.carry_over()
+    assert torch.equal(ro.states[0][0], ro.states[0][T])

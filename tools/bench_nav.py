@@ -100,32 +100,25 @@ tot_flop = sum(v[1] for v in agg.values()) / ITERS
 # ---- whole loop at the BASELINE config-4 shape: 512 envs, T steps of acting + bootstrap + GAE + one PPO update ----
 loop = None
 if len(sys.argv) > 4:
-    from ddrl4nav_amd.agent.agent import gae_device
+    from ddrl4nav_amd.agent import StateRollout
     N, T = 512, int(sys.argv[4])
-    pool = [torch.rand((T + 1, N, 1, 960), device="cuda", generator=g), torch.randn((T + 1, N, 5), device="cuda", generator=g),
-            (torch.rand((T + 1, N, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
-    values = torch.zeros((T + 1, N), device="cuda")
-    actions = torch.zeros((T, N, 2), device="cuda")
-    logps = torch.zeros((T, N), device="cuda")
+    ro = StateRollout(net, N, [(1, 960), (5,), (3, 48, 48)], horizon=T)
+    ro.states[0].copy_(torch.rand(ro.states[0].shape, device="cuda", generator=g))
+    ro.states[1].copy_(torch.randn(ro.states[1].shape, device="cuda", generator=g))
+    ro.states[2].copy_((torch.rand(ro.states[2].shape, device="cuda", generator=g) < 0.15).float())
     u = torch.rand((T, N), device="cuda", generator=g)
-    rewards = torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)).contiguous()
-    dones = (torch.rand((T, N), device="cuda", generator=g) < 1.0 / 800).to(torch.uint8)
+    ro.rewards.copy_(torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)))
+    ro.dones.copy_((torch.rand((T, N), device="cuda", generator=g) < 1.0 / 800).to(torch.uint8))
 
     def one_loop():
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        for t in range(T + 1):
-            (dist, _), v = net([p[t] for p in pool])
-            values[t].copy_(v[0][:, 0])
-            if t < T:
-                a = dist.sample()
-                actions[t].copy_(a)
-                logps[t].copy_(net.actor.log_prob_from_distribution(dist, a))
-        adv, ret = gae_device(values, rewards, dones, 0.99, 0.95)
+        for t in range(T):
+            ro.act(t)
+        ro.bootstrap()
+        ro.finish()
         e1.record()
-        exp = Experience(states=[p[:T].reshape((T * N,) + tuple(p.shape[2:])) for p in pool], advs=adv.view(-1),
-                         actions=actions.view(T * N, 2), old_logps=logps.view(-1), values=ret.view(1, -1))
-        for _ in net.learn(exp):
+        for _ in net.learn(ro.batch()):
             pass
         e2.record()
         torch.cuda.synchronize()
