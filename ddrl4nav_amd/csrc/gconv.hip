@@ -417,7 +417,11 @@ void launch_conv_dgrad(const ConvGeom& g, const float* dz, const float* wpd, con
   launch_engine2<gconv::Gather<true>>(dim3((unsigned)((cols + 255) / 256), (g.cin + 63) / 64, 1), p, st);
 }
 
+bool conv_is_thin(const ConvGeom& g);
+int conv_thin_wgs(const ConvGeom& g);
+
 int conv_wgrad_splits(const ConvGeom& g) {
+  if (conv_is_thin(g)) return conv_thin_wgs(g);  // one slab per workgroup of thin_wgrad_kernel
   const int KT = g.cin * g.kh * g.kw;
   const int tiles = ((KT + 255) / 256) * ((g.cout + 63) / 64);
   int s = (768 + tiles - 1) / tiles;
@@ -427,8 +431,86 @@ int conv_wgrad_splits(const ConvGeom& g) {
   return s < 1 ? 1 : s;
 }
 
+// "Thin" weight gradient: a Conv1d with a handful of taps and few output channels (NavPreNet1D.conv1d1:
+// 1 -> 32 channels, 5 taps) is a reduction over (b, x), not a GEMM -- 160 sums fed by 60 KB of dz per
+// sample.  Lanes run along x, so the dz rows and the input taps are read coalesced; every thread keeps
+// all cout x KT partial sums in registers over the samples its workgroup owns; one shuffle + LDS
+// reduction at the end, then the usual slab reduction.
+constexpr int THIN_MAX_TAPS = 6, THIN_COUT = 32, THIN_WGS = 512;
+template <int KT>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(ConvGeom g, const float* __restrict__ in, const float* __restrict__ dz,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4][THIN_COUT * (KT + 1)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[THIN_COUT][KT], bias[THIN_COUT];
+#pragma unroll
+  for (int c = 0; c < THIN_COUT; ++c) {
+    bias[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[c][k] = 0.0f;
+  }
+  for (int b = blockIdx.x; b < g.n; b += gridDim.x) {
+    const float* dzb = dz + (int64_t)b * g.out_sn;
+    const float* inb = in + (int64_t)b * g.in_sn;
+    for (int x = threadIdx.x; x < g.ow; x += 256) {
+      float v[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const int ci = k / g.kw, ix = x * g.stride + (k % g.kw) - g.pad_w;
+        v[k] = inb[ci * g.w + min(max(ix, 0), g.w - 1)];
+        if (ix < 0 || ix >= g.w) v[k] = 0.0f;
+      }
+#pragma unroll
+      for (int c = 0; c < THIN_COUT; ++c) {
+        const float d = (c < g.cout) ? dzb[min(c, g.cout - 1) * g.ow + x] : 0.0f;
+        bias[c] += d;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[c][k] = __builtin_fmaf(d, v[k], acc[c][k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < THIN_COUT; ++c) {
+#pragma unroll
+    for (int k = 0; k <= KT; ++k) {
+      float s = (k < KT) ? acc[c][k < KT ? k : 0] : bias[c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (lane == 0) red[wave][c * (KT + 1) + k] = s;
+    }
+  }
+  __syncthreads();
+  float* slab = part + (int64_t)blockIdx.x * ((int64_t)g.cout * KT + g.cout);
+  for (int i = threadIdx.x; i < g.cout * (KT + 1); i += 256) {
+    const int c = i / (KT + 1), k = i % (KT + 1);
+    const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (k == KT) slab[(int64_t)g.cout * KT + c] = s;
+    else slab[c * KT + k] = s;
+  }
+}
+
+bool conv_is_thin(const ConvGeom& g) {
+  return g.kh == 1 && g.h == 1 && g.oh == 1 && g.cin * g.kw <= THIN_MAX_TAPS && g.cout <= THIN_COUT && g.pad_h == 0;
+}
+int conv_thin_wgs(const ConvGeom& g) { return g.n < THIN_WGS ? g.n : THIN_WGS; }
+
 void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, const int* ptab, float* part, float* dw, float* db,
                        hipStream_t st) {
+  if (conv_is_thin(g)) {
+    const int KT = g.cin * g.kw, W = conv_thin_wgs(g);
+    switch (KT) {
+      case 1: hipLaunchKernelGGL(thin_wgrad_kernel<1>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
+      case 2: hipLaunchKernelGGL(thin_wgrad_kernel<2>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
+      case 3: hipLaunchKernelGGL(thin_wgrad_kernel<3>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
+      case 4: hipLaunchKernelGGL(thin_wgrad_kernel<4>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
+      case 5: hipLaunchKernelGGL(thin_wgrad_kernel<5>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
+      default: hipLaunchKernelGGL(thin_wgrad_kernel<6>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
+    }
+    const int64_t slab = (int64_t)g.cout * KT + g.cout;
+    launch_reduce_slabs(part, W, slab, (int64_t)g.cout * KT, dw, st);
+    launch_reduce_slabs(part + (int64_t)g.cout * KT, W, slab, g.cout, db, st);
+    return;
+  }
   const int KT = g.cin * g.kh * g.kw;
   const int S = conv_wgrad_splits(g);
   gconv::Wgrad::Params p{g, in, dz, ptab, part, KT, S};
