@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void direct_pack_kernel(const float* __restric
 // pixel of the pair's two samples.  dz of the band and the R + KS - 1 input rows it touches are
 // staged raw (16- / 8-byte coalesced loads); image rows outside the input are written as zeros and
 // the PAD columns of the LDS planes stay zero, so every operand is again lane_base + immediate.
-template <int CIN, int COUT, int KS, int HIN, int PAD, int R, int CT>
+template <int CIN, int COUT, int KS, int HIN, int PAD, int R, int CT, int TNV = 4>
 struct DirectWgrad {
-  static constexpr int THREADS = 256, TM = 1, TN = 4;
+  static constexpr int THREADS = 256, TM = 1, TN = TNV;  // column tile = 2 wave columns x TN x 32 taps
   static constexpr int KK = KS * KS, KT = CIN * KK;
   static constexpr int OH = HIN + 2 * PAD - KS + 1, P = OH * OH, RAW = HIN * HIN, LP = HIN + 2 * PAD;
   static_assert(OH % R == 0 && (R * OH) % 4 == 0 && HIN % 2 == 0, "band geometry");
@@ -181,7 +181,7 @@ struct DirectWgrad {
   static constexpr int A_FLOATS = 2 * 64 * ASTR, B_OFF = (A_FLOATS + 3) / 4 * 4;
   static constexpr int BPL = BR * LP, B_FLOATS = 2 * CT * BPL, STAGE = B_OFF + (B_FLOATS + 3) / 4 * 4;
   static constexpr int CTILES = (CIN + CT - 1) / CT, COLS = CT * KK;
-  static_assert(COLS <= 256, "column tile");
+  static_assert(COLS <= 2 * TN * 32, "column tile");
   static constexpr int K4 = KSTEPS / 4, NA4 = 2 * 64 * K4, NAJ = (NA4 + 255) / 256;
   static constexpr int H2 = HIN / 2, NB2 = 2 * CT * BR * H2, NBJ = (NB2 + 255) / 256;
   struct Params {
@@ -197,7 +197,7 @@ struct DirectWgrad {
     float2 b[NBJ];
     unsigned oka, okb;
   };
-  int abase[1], bbase[4], kb_begin, kb_end;
+  int abase[1], bbase[TN], kb_begin, kb_end;
   int ct, split, r0, ch0, l31, hi, wr, wc;
   float bacc;
   static constexpr int aoff(int s) { return s; }
@@ -225,8 +225,8 @@ struct DirectWgrad {
     __syncthreads();
     abase[0] = hi * (64 * ASTR) + (wr * 32 + l31) * ASTR;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = min(wc * 128 + j * 32 + l31, COLS - 1);
+    for (int j = 0; j < TN; ++j) {
+      const int col = min(wc * (TN * 32) + j * 32 + l31, COLS - 1);
       const int ch = col / KK, t = col % KK;
       bbase[j] = B_OFF + hi * (CT * BPL) + ch * BPL + (t / KS) * LP + (t % KS);
     }
@@ -289,11 +289,11 @@ struct DirectWgrad {
       bacc += s;
     }
   }
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[1][4], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[1][TN], float* lds) {
     float* slab = p.part + (int64_t)split * ((int64_t)COUT * KT + COUT);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = wc * 128 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      const int col = wc * (TN * 32) + j * 32 + l31;
       if (col >= COLS || ch0 + col / KK >= CIN) continue;
       const int tap = ct * COLS + col;
 #pragma unroll
@@ -323,7 +323,7 @@ using NavC2F = dconv::Direct<64, 128, 3, 24, 1, 4>;
 using NavC2D = dconv::Direct<128, 64, 3, 24, 1, 4>;
 using NavC3F = dconv::Direct<128, 256, 3, 12, 1, 4>;
 using NavC3D = dconv::Direct<256, 128, 3, 12, 1, 4>;
-using N1dC1W = dconv::DirectWgrad<3, 64, 7, 48, 1, 1, 3>;      // one output row per band, 147 taps
+using N1dC1W = dconv::DirectWgrad<3, 64, 7, 48, 1, 1, 3, 3>;   // one output row per band, 147 taps in a 192-wide tile
 using N1dC2W = dconv::DirectWgrad<64, 128, 5, 22, 1, 2, 10>;   // bands of 2 rows, 10 channels x 25 taps per tile
 using N1dC3W = dconv::DirectWgrad<128, 256, 3, 10, 1, 2, 28>;  // bands of 2 rows, 28 channels x 9 taps per tile
 using NavC2W = dconv::DirectWgrad<64, 128, 3, 24, 1, 1, 28>;
