@@ -66,7 +66,8 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
   const PackView v = pack_view(g);
   launch_conv_pack(g, w, packed + v.off[0], (int2*)(packed + v.off[1]), packed + v.off[2], (int2*)(packed + v.off[3]),
                    (int*)(packed + v.off[4]), (hipStream_t)stream);
-  if (conv_has_direct(g)) launch_conv_direct_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
+  if (conv_has_direct(g) || conv_has_band_fwd(g))
+    launch_conv_direct_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
   return op_check();
 }
 
@@ -84,7 +85,7 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  if (conv_has_direct(g) && direct_ok(g, in, out))
+  if ((conv_has_direct(g) || conv_has_band_fwd(g)) && direct_ok(g, in, out))
     launch_conv_direct_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
   else
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);

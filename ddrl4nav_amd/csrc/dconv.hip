@@ -162,6 +162,121 @@ __global__ __launch_bounds__(256) void direct_pack_kernel(const float* __restric
   wp[i] = flip ? w[((int64_t)ch * cin + rr) * kk + (kk - 1 - tap)] : w[((int64_t)rr * cin + ch) * kk + tap];
 }
 
+// Forward for layers with few input channels (NavPreNet1D.conv1: 3 -> 64, 7x7, 48 -> 44), where the
+// channel-pair MFMA k of `Direct` does not apply: the two k indices of an MFMA are the taps (kx, kx+1)
+// of one kernel row (KS is padded to an even width with a zero weight), one k-block per input channel.
+// Column tile = a band of R output rows of ONE sample; only the R + KS - 1 input rows the band
+// touches are staged (8-byte loads), rows outside the image as zeros.
+template <int CIN, int COUT, int KS, int HIN, int PAD, int R, int TNV>
+struct DirectBandFwd {
+  static constexpr int THREADS = 256, TM = 1, TN = TNV;
+  static constexpr int KXP = (KS + 1) / 2, KSTEPS = KS * KXP;  // k-steps per input channel
+  static constexpr int OH = HIN + 2 * PAD - KS + 1, P = OH * OH, RAW = HIN * HIN, LP = HIN + 2 * PAD + 1;
+  static_assert(OH % R == 0 && HIN % 2 == 0 && COUT == 64, "band geometry");
+  static constexpr int NB = OH / R, COLS = R * OH, BR = R + KS - 1;
+  static_assert(COLS <= 2 * TN * 32, "column tile");
+  static constexpr int W_FLOATS = KSTEPS * 2 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = (BR * LP + 3) / 4 * 4;
+  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
+  static constexpr int NW4 = W_FLOATS / 4, NWJ = (NW4 + 255) / 256;
+  static constexpr int H2 = HIN / 2, NI2 = BR * H2, NIJ = (NI2 + 255) / 256;
+  struct Params {
+    const float* in;
+    int64_t in_sn;
+    const float* wp;  // [CIN][KSTEPS][2][64]
+    const float* bias;
+    float* out;
+    int64_t out_sn;
+    int n, act;
+  };
+  struct Regs {
+    f4 w[NWJ];
+    float2 im[NIJ];
+  };
+  int abase[1], bbase[TN], kb_begin, kb_end;
+  int b, band, l31, hi, wr, wc;
+  static constexpr int aoff(int s) { return 2 * s * 64; }
+  static constexpr int boff(int s) { return (s / KXP) * LP + 2 * (s % KXP); }
+  __device__ __forceinline__ void extra(const float*) {}
+  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
+    const int lane = tid & 63, wave = tid >> 6;
+    wr = wave >> 1;
+    wc = wave & 1;
+    l31 = lane & 31;
+    hi = lane >> 5;
+    band = blockIdx.x;
+    b = blockIdx.y;
+    kb_begin = 0;
+    kb_end = CIN;
+    for (int i = tid; i < IMG_FLOATS; i += 256) {  // PAD columns stay zero
+      lds[IMG_OFF + i] = 0.0f;
+      lds[STAGE + IMG_OFF + i] = 0.0f;
+    }
+    __syncthreads();
+    abase[0] = hi * 64 + wr * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = min(wc * (TN * 32) + j * 32 + l31, COLS - 1);
+      bbase[j] = IMG_OFF + (c / OH) * LP + (c % OH) + hi;
+    }
+  }
+  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) r.w[j] = ld4(p.wp + kb * W_FLOATS + min(tid + 256 * j, NW4 - 1) * 4);
+#pragma unroll
+    for (int j = 0; j < NIJ; ++j) {
+      const int idx = min(tid + 256 * j, NI2 - 1);
+      const int iy = band * R - PAD + idx / H2;
+      r.im[j] = *(const float2*)(p.in + (int64_t)b * p.in_sn + kb * RAW + min(max(iy, 0), HIN - 1) * HIN + (idx % H2) * 2);
+    }
+  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NW4) st4(buf + idx * 4, r.w[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NIJ; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NI2) {
+        const int rr = idx / H2, x2 = idx % H2;
+        const int iy = band * R - PAD + rr;
+        const bool ok = iy >= 0 && iy < HIN;
+        float* d = buf + IMG_OFF + rr * LP + PAD + x2 * 2;
+        d[0] = ok ? r.im[j].x : 0.0f;
+        d[1] = ok ? r.im[j].y : 0.0f;
+      }
+    }
+  }
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[1][TN], float*) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = wc * (TN * 32) + j * 32 + l31;
+      if (c >= COLS) continue;
+      float* dst = p.out + (int64_t)b * p.out_sn + band * COLS + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 32 + acc_row(r, hi);
+        float v = acc[0][j][r] + p.bias[row];
+        if (p.act == 1) v = fmaxf(v, 0.0f);
+        dst[(int64_t)row * P] = v;
+      }
+    }
+  }
+};
+
+// wp[ci][s = ky*KXP + kxp][hi][co] = W[co][ci][ky][2*kxp + hi]  (zero where 2*kxp + hi == KS)
+__global__ __launch_bounds__(256) void band_pack_kernel(const float* __restrict__ w, int cin, int ks, float* __restrict__ wp) {
+  const int kxp = (ks + 1) / 2, ksteps = ks * kxp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cin * ksteps * 128) return;
+  const int co = i & 63, hi = (i >> 6) & 1, s = (i >> 7) % ksteps, ci = (i >> 7) / ksteps;
+  const int ky = s / kxp, kx = 2 * (s % kxp) + hi;
+  wp[i] = kx < ks ? w[((co * cin + ci) * ks + ky) * ks + kx] : 0.0f;
+}
+
 // Weight gradient of the same layers:
 //   part[split][co][ci][ky][kx] = sum over the split's sample pairs and all output pixels of
 //                                 dz[b][co][oy][ox] * in[b][ci][oy + ky - PAD][ox + kx - PAD]
@@ -324,6 +439,7 @@ using NavC2D = dconv::Direct<128, 64, 3, 24, 1, 4>;
 using NavC3F = dconv::Direct<128, 256, 3, 12, 1, 4>;
 using NavC3D = dconv::Direct<256, 128, 3, 12, 1, 4>;
 using N1dC1W = dconv::DirectWgrad<3, 64, 7, 48, 1, 1, 3, 3>;   // one output row per band, 147 taps in a 192-wide tile
+using N1dC1F = dconv::DirectBandFwd<3, 64, 7, 48, 1, 4, 3>;     // bands of 4 output rows (176 pixels) in a 192-wide tile
 using N1dC2W = dconv::DirectWgrad<64, 128, 5, 22, 1, 2, 10>;   // bands of 2 rows, 10 channels x 25 taps per tile
 using N1dC3W = dconv::DirectWgrad<128, 256, 3, 10, 1, 2, 28>;  // bands of 2 rows, 28 channels x 9 taps per tile
 using NavC2W = dconv::DirectWgrad<64, 128, 3, 24, 1, 1, 28>;
@@ -343,16 +459,26 @@ static DirectId direct_id(const ConvGeom& g) {
 }
 
 bool conv_has_direct(const ConvGeom& g) { return direct_id(g) != kNone && direct_id(g) != kN1dC1; }
+bool conv_has_band_fwd(const ConvGeom& g) { return direct_id(g) == kN1dC1; }
 bool conv_has_direct_wgrad(const ConvGeom& g) { return direct_id(g) != kNone; }
 
 // floats of the two extra packed regions (forward, data gradient); 0 when there is no specialisation
 void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]) {
   out[0] = out[1] = 0;
+  if (conv_has_band_fwd(g)) {  // forward only: [CIN][KSTEPS][2][64]
+    out[0] = (int64_t)g.cin * N1dC1F::W_FLOATS;
+    return;
+  }
   if (!conv_has_direct(g)) return;
   out[0] = out[1] = (int64_t)g.cout * g.cin * g.kh * g.kw;  // same element count, different order
 }
 
 void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st) {
+  if (conv_has_band_fwd(g)) {
+    const int total = g.cin * N1dC1F::W_FLOATS;
+    hipLaunchKernelGGL(dconv::band_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, g.cin, g.kh, wpf);
+    return;
+  }
   if (!conv_has_direct(g)) return;
   const int kk = g.kh * g.kw, cpb = direct_id(g) == kN1dC2 ? 2 : 4;  // = the CPB of the instantiations above
   const int64_t total = (int64_t)g.cout * g.cin * kk;
@@ -370,6 +496,11 @@ static void run_direct(const float* in, int64_t in_sn, const float* wp, const fl
 
 void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
                             hipStream_t st) {
+  if (conv_has_band_fwd(g)) {
+    N1dC1F::Params p{in, g.in_sn, wpf, bias, out, g.out_sn, g.n, act};
+    launch_engine2<N1dC1F>(dim3(N1dC1F::NB, g.n, 1), p, st);
+    return;
+  }
   switch (direct_id(g)) {
     case kN1dC2: run_direct<N1dC2F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st); break;
     case kN1dC3: run_direct<N1dC3F>(in, g.in_sn, wpf, bias, act, out, g.out_sn, g.n, g.cout, st); break;

@@ -25,6 +25,7 @@ void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes
 // dconv.hip: compile-time-geometry direct convolutions for the heavy nav layers
 bool conv_has_direct(const ConvGeom& g);        // forward + data gradient
 bool conv_has_direct_wgrad(const ConvGeom& g);  // weight gradient
+bool conv_has_band_fwd(const ConvGeom& g);      // forward only (few input channels)
 void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]);
 void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st);
 void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
