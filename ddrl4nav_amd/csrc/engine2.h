@@ -38,6 +38,25 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ f4 ld4(const float* p) { return *(const f4*)p; }
 __device__ __forceinline__ void st4(float* p, f4 v) { *(f4*)p = v; }
 __device__ __forceinline__ f4 zero4() { return (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
+// Load through the  scalar base + 32-bit lane offset  addressing form (global_load v, v_off, s[base]): the
+// k-block dependent part of the address is a wave-uniform pointer, the lane part a loop-invariant byte offset
+// kept in ONE register, so no address arithmetic runs on the vector ALU inside the k loop.  That matters
+// because VALU instructions do not overlap f32 MFMAs on a SIMD (tools/mfma_peak.hip: ~3.5 cycles of
+// matrix-pipe time lost per VALU instruction).  The empty asm keeps the zero-extension next to the load;
+// hoisted out of the loop it would turn back into a 64-bit vector add per load.  pin_offsets() "redefines" the
+// loop-carried offset registers in place (no copy) and must run once per fetch, BEFORE any branch that
+// selects between load paths (a redefinition inside one arm costs a register copy per offset at the join).
+template <int N>
+__device__ __forceinline__ void pin_offsets(uint32_t (&off)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(off[j]));
+}
+__device__ __forceinline__ f4 ld4_so(const void* uniform_base, uint32_t lane_bytes) {
+  return *(const f4*)((const char*)uniform_base + lane_bytes);
+}
+__device__ __forceinline__ unsigned ld1u_so(const void* uniform_base, uint32_t lane_bytes) {
+  return *(const unsigned*)((const char*)uniform_base + lane_bytes);
+}
 
 __device__ __forceinline__ float leaky_f(float v) { return v > 0.0f ? v : v * LEAKY; }
 __device__ __forceinline__ float leaky_g(float act, float g) { return act > 0.0f ? g : g * LEAKY; }
@@ -197,25 +216,48 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
       // before the last k-block, so their latency hides under its MFMAs instead of being exposed
       if (kb == kbe - 1) op.pre_epilogue(P);
     }
+    // DDRL_ABL_* are timing-only knock-outs for tools/ablate_engine.sh (results are WRONG with any of
+    // them set): they show what each phase of the loop costs on top of the bare LDS->MFMA stream.
     if constexpr (CommitFirstOf<Op>::v) {
       // ops with a VALU-heavy commit (masks, u8 conversion): write the NEXT stage and issue the
       // following fetch before this block's MFMAs, so the scheduler can run them under the MFMAs
       if (kb + 1 < kbe) {
+#ifndef DDRL_ABL_NOCOMMIT
         op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
+#endif
+#ifndef DDRL_ABL_NOFETCH
         if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+#endif
       }
       compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
     } else {
       compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
       if (kb + 1 < kbe) {
+#ifndef DDRL_ABL_NOCOMMIT
         op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
+#endif
+#ifndef DDRL_ABL_NOFETCH
         if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+#endif
       }
     }
+#ifndef DDRL_ABL_NOBARRIER
     __syncthreads();
+#endif
     buf ^= 1;
   }
+#ifndef DDRL_ABL_NOEPILOGUE
   op.epilogue(P, acc, lds2);
+#else
+  float sink = 0.0f;
+#pragma unroll
+  for (int i = 0; i < Op::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Op::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+  if (sink == 123.456f) lds2[0] = sink;  // keeps the accumulators live without an epilogue
+#endif
 }
 
 // Ops may declare `static constexpr int EXTRA` = floats of LDS behind the two stage buffers that

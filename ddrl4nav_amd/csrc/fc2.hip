@@ -11,16 +11,17 @@ namespace ddrl {
 struct RowMajorTile {
   static constexpr int LD = 33;
   static constexpr int FLOATS = 128 * LD;
-  __device__ __forceinline__ static void fetch(const float* __restrict__ src, int64_t row_stride, int row0, int nrows, int kcol0, int tid,
-                               f4 (&r)[4]) {
+  // Lane byte offsets of the 4 loads relative to  src + row0 * row_stride + kcol0  (loop invariant).
+  // Loads are unconditional from a clamped row: rows >= nrows only feed output rows that the epilogue
+  // discards (a guarded load would make hipcc branch and wait per load).
+  __device__ __forceinline__ static void lane_offsets(int row_stride, int row0, int nrows, int tid, uint32_t (&off)[4]) {
     const int k4 = tid & 7, rr = tid >> 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // unconditional load from a clamped row: rows >= nrows only feed output rows that the
-      // epilogue discards (a guarded load would make hipcc branch and wait per load)
-      const int row = min(row0 + rr + 32 * j, nrows - 1);
-      r[j] = ld4(src + (int64_t)row * row_stride + kcol0 + k4 * 4);
-    }
+    for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((min(row0 + rr + 32 * j, nrows - 1) - row0) * row_stride + k4 * 4) * 4);
+  }
+  __device__ __forceinline__ static void fetch(const float* __restrict__ uniform_base, const uint32_t (&off)[4], f4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = ld4_so(uniform_base, off[j]);
   }
   __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4]) {
     const int k4 = tid & 7, rr = tid >> 3;
@@ -38,17 +39,22 @@ struct KMajorTile {
   // Unconditional loads from clamped (k, col); returns a 4-bit mask of the j whose k is in range.
   // Out-of-range columns only feed discarded output columns; out-of-range k (the reduction index)
   // must contribute zero, which commit_masked() enforces for ONE of the two operands.
-  __device__ __forceinline__ static unsigned fetch(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
-                               f4 (&r)[4]) {
+  // Lane byte offsets of the 4 loads of a FULL k-block relative to  src + k0 * k_stride  (loop invariant).
+  __device__ __forceinline__ static void lane_offsets(int k_stride, int col0, int ncols, int tid, uint32_t (&off)[4]) {
     const int c4 = tid & 31, kk = tid >> 5;
     const int col = (col0 + c4 * 4) < ncols ? col0 + c4 * 4 : 0;
-    if (k0 + 32 <= nk) {  // fast path (all but the last k-block): scalar base + small offsets
-      const float* base = src + (int64_t)k0 * k_stride + col;
-      const int ks = (int)k_stride;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = ld4(base + (kk + 8 * j) * ks);
-      return 0xFu;
-    }
+    for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((kk + 8 * j) * k_stride + col) * 4);
+  }
+  __device__ __forceinline__ static void fetch_full(const float* __restrict__ uniform_base, const uint32_t (&off)[4], f4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = ld4_so(uniform_base, off[j]);
+  }
+  // k-block that crosses nk (the last one of a ragged reduction): clamped rows + mask
+  __device__ __forceinline__ static unsigned fetch_tail(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
+                                                        f4 (&r)[4]) {
+    const int c4 = tid & 31, kk = tid >> 5;
+    const int col = (col0 + c4 * 4) < ncols ? col0 + c4 * 4 : 0;
     unsigned ok = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -108,8 +114,9 @@ struct FcFwd2 : FcCommon {
     f4 a[4], b[4];
   };
   int e, split, b0, n0;
-  const float* a3;
+  const float* a3;   // + b0 rows
   const float* wlt;
+  uint32_t offa[4], offb[4];
   static constexpr int aoff(int s) { return 2 * s; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
@@ -121,16 +128,20 @@ struct FcFwd2 : FcCommon {
     const int per = (FLAT / 32) / p.nsplit;
     kb_begin = split * per;
     kb_end = kb_begin + per;
-    a3 = p.a3 + e * p.a3_es;
+    a3 = p.a3 + e * p.a3_es + (int64_t)b0 * FLAT;
     wlt = p.wlt + (int64_t)e * FLAT * FEAT;
+    RowMajorTile::lane_offsets(FLAT, b0, p.n, tid, offa);
+    KMajorTile::lane_offsets(FEAT, n0, FEAT, tid, offb);
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowMajorTile::LD + hi;
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    RowMajorTile::fetch(a3, FLAT, b0, p.n, kb * 32, threadIdx.x, r.a);
-    KMajorTile::fetch(wlt, FEAT, kb * 32, FLAT, n0, FEAT, threadIdx.x, r.b);
+    pin_offsets(offa);
+    pin_offsets(offb);
+    RowMajorTile::fetch(a3 + kb * 32, offa, r.a);
+    KMajorTile::fetch_full(wlt + (int64_t)kb * 32 * FEAT, offb, r.b);  // FLAT = 98 x 32: every k-block is full
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
@@ -172,8 +183,9 @@ struct FcDgrad2 : FcCommon {
     f4 a[4], b[4];
   };
   int e, b0, k0;
-  const float* dh;
+  const float* dh;   // + b0 rows
   const float* wln;
+  uint32_t offa[4], offb[4];
   static constexpr int aoff(int s) { return 2 * s; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
@@ -183,16 +195,20 @@ struct FcDgrad2 : FcCommon {
     b0 = blockIdx.y * 128;
     kb_begin = 0;
     kb_end = FEAT / 32;
-    dh = p.dh + e * p.dh_es;
+    dh = p.dh + e * p.dh_es + (int64_t)b0 * FEAT;
     wln = p.wln + (int64_t)e * FLAT * FEAT;
+    RowMajorTile::lane_offsets(FEAT, b0, p.n, tid, offa);
+    KMajorTile::lane_offsets(FLAT, k0, FLAT, tid, offb);
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowMajorTile::LD + hi;
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    RowMajorTile::fetch(dh, FEAT, b0, p.n, kb * 32, threadIdx.x, r.a);
-    KMajorTile::fetch(wln, FLAT, kb * 32, FEAT, k0, FLAT, threadIdx.x, r.b);
+    pin_offsets(offa);
+    pin_offsets(offb);
+    RowMajorTile::fetch(dh + kb * 32, offa, r.a);
+    KMajorTile::fetch_full(wln + (int64_t)kb * 32 * FLAT, offb, r.b);  // FEAT = 16 x 32: every k-block is full
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
@@ -250,10 +266,12 @@ struct FcWgrad2 : FcCommon {
   struct Regs {
     f4 a[4], b[4];
     unsigned ok;
+    bool full;  // wave-uniform: the k-block lies inside the batch, no masks needed
   };
   int e, split, n0, k0;
   const float* dh;
   const float* a3;
+  uint32_t offa[4], offb[4];
   f4 bsum;
   static constexpr int aoff(int s) { return 2 * s * KMajorTile::LD; }
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
@@ -270,22 +288,42 @@ struct FcWgrad2 : FcCommon {
     dh = p.dh + e * p.dh_es;
     a3 = p.a3 + e * p.a3_es;
     bsum = zero4();
+    KMajorTile::lane_offsets(FEAT, n0, FEAT, tid, offa);
+    KMajorTile::lane_offsets(FLAT, k0, FLAT, tid, offb);
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = A_OFF + hi * KMajorTile::LD + wr * 64 + i * 32 + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    r.ok = KMajorTile::fetch(dh, FEAT, kb * 32, p.n, n0, FEAT, threadIdx.x, r.a);
-    KMajorTile::fetch(a3, FLAT, kb * 32, p.n, k0, FLAT, threadIdx.x, r.b);
+    r.full = kb * 32 + 32 <= p.n;
+    pin_offsets(offa);
+    pin_offsets(offb);
+    if (r.full) {
+      KMajorTile::fetch_full(dh + (int64_t)kb * 32 * FEAT, offa, r.a);
+      KMajorTile::fetch_full(a3 + (int64_t)kb * 32 * FLAT, offb, r.b);
+      r.ok = 0xFu;
+    } else {
+      r.ok = KMajorTile::fetch_tail(dh, FEAT, kb * 32, p.n, n0, FEAT, threadIdx.x, r.a);
+      KMajorTile::fetch_tail(a3, FLAT, kb * 32, p.n, k0, FLAT, threadIdx.x, r.b);
+    }
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    KMajorTile::commit_masked(buf + A_OFF, threadIdx.x, r.a, r.ok);  // samples >= n contribute zero
     KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
-    // bias gradient rides along: this thread always holds the same 4 columns of dh
+    // bias gradient rides along in the workgroups of column tile 0 (the epilogue's owner of the bias
+    // partial): this thread always holds the same 4 columns of dh
+    const bool bias_owner = blockIdx.x == 0;
+    if (r.full) {
+      KMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
+      if (bias_owner) bsum += (r.a[0] + r.a[1]) + (r.a[2] + r.a[3]);
+    } else {
+      KMajorTile::commit_masked(buf + A_OFF, threadIdx.x, r.a, r.ok);  // samples >= n contribute zero
+      if (bias_owner) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if ((r.ok >> j) & 1u) bsum += r.a[j];
+        for (int j = 0; j < 4; ++j)
+          if ((r.ok >> j) & 1u) bsum += r.a[j];
+      }
+    }
   }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
     float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;

@@ -2,6 +2,8 @@
 kernel experiments recorded in profiles/README.md.  Usage: python tools/ablate_iter.py <tag>"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ddrl4nav_amd import _lib
+if os.environ.get("DDRL_ABL_LIB"): _lib.LIB_PATH = os.environ["DDRL_ABL_LIB"]  # knock-out builds of tools/ablate_engine.sh
 from ddrl4nav_amd.engine import HotPath
 from ddrl4nav_amd.utils.recipe import flatten, make_weights
 B=65536
