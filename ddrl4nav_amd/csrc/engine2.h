@@ -35,6 +35,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // lowers to llvm.memcpy, and an alloca touched only by memcpys is never promoted to registers
 // (the prefetch buffers then live in scratch and every load is waited for immediately).
 using f4 = __attribute__((ext_vector_type(4))) float;
+using f2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f4 ld4(const float* p) { return *(const f4*)p; }
 __device__ __forceinline__ void st4(float* p, f4 v) { *(f4*)p = v; }
 __device__ __forceinline__ f4 zero4() { return (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
@@ -46,6 +47,10 @@ __device__ __forceinline__ f4 zero4() { return (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
 // hoisted out of the loop it would turn back into a 64-bit vector add per load.  pin_offsets() "redefines" the
 // loop-carried offset registers in place (no copy) and must run once per fetch, BEFORE any branch that
 // selects between load paths (a redefinition inside one arm costs a register copy per offset at the join).
+// First and last statement of a rarely taken arm (ragged tails): an un-speculatable marker, so that the
+// compiler keeps the arm behind its wave-uniform branch instead of hoisting / sinking its instructions
+// into the common path (which costs per-lane selects or register copies there).
+__device__ __forceinline__ void rare_path() { asm volatile("; rare path"); }
 template <int N>
 __device__ __forceinline__ void pin_offsets(uint32_t (&off)[N]) {
 #pragma unroll
@@ -185,6 +190,51 @@ struct HasPreEpilogue<Op, decltype((void)Op::PRE_EPILOGUE)> {
   static constexpr bool v = true;
 };
 
+// One k-block of the pipeline with the LDS buffer index as a compile-time constant: every LDS address of
+// the block is then  lane register + immediate  (no per-iteration buffer arithmetic on the vector ALU).
+// BUF = -1: the buffer index is the run-time argument `rbuf` (the tail of the k loop, which also hosts the
+// pre-epilogue hook, is compiled once this way).
+template <class Op, int BUF>
+__device__ __forceinline__ void engine2_step(Op& op, const typename Op::Params& P, int kb, int kbe, typename Op::Regs& regs,
+                                             f32x16 (&acc)[Op::TM][Op::TN], float* lds2, int rbuf = 0) {
+  float* cur = lds2 + (BUF < 0 ? rbuf : BUF) * Op::STAGE;
+  float* nxt = lds2 + (BUF < 0 ? rbuf ^ 1 : BUF ^ 1) * Op::STAGE;
+  op.extra(cur);
+  if constexpr (HasPreEpilogue<Op>::v && BUF < 0) {
+    // global loads the epilogue needs (e.g. the activations for the leaky-ReLU mask) are issued
+    // before the last k-block, so their latency hides under its MFMAs instead of being exposed
+    if (kb == kbe - 1) op.pre_epilogue(P);
+  }
+  // DDRL_ABL_* are timing-only knock-outs for tools/ablate_engine.sh (results are WRONG with any of
+  // them set): they show what each phase of the loop costs on top of the bare LDS->MFMA stream.
+  if constexpr (CommitFirstOf<Op>::v) {
+    // ops with a VALU-heavy commit (masks, u8 conversion): write the NEXT stage and issue the
+    // following fetch before this block's MFMAs, so the scheduler can run them under the MFMAs
+    if (kb + 1 < kbe) {
+#ifndef DDRL_ABL_NOCOMMIT
+      op.commit(regs, nxt);
+#endif
+#ifndef DDRL_ABL_NOFETCH
+      if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+#endif
+    }
+    compute_block<Op>(op, cur, acc);
+  } else {
+    compute_block<Op>(op, cur, acc);
+    if (kb + 1 < kbe) {
+#ifndef DDRL_ABL_NOCOMMIT
+      op.commit(regs, nxt);
+#endif
+#ifndef DDRL_ABL_NOFETCH
+      if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
+#endif
+    }
+  }
+#ifndef DDRL_ABL_NOBARRIER
+  __syncthreads();
+#endif
+}
+
 template <class Op>
 __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(typename Op::Params P) {
   extern __shared__ __attribute__((aligned(16))) float lds2[];
@@ -208,44 +258,14 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
     if (kb + 1 < kbe) op.fetch(P, kb + 1, regs);
   }
   __syncthreads();
-  int buf = 0;
-  for (; kb < kbe; ++kb) {
-    op.extra(lds2 + buf * Op::STAGE);
-    if constexpr (HasPreEpilogue<Op>::v) {
-      // global loads the epilogue needs (e.g. the activations for the leaky-ReLU mask) are issued
-      // before the last k-block, so their latency hides under its MFMAs instead of being exposed
-      if (kb == kbe - 1) op.pre_epilogue(P);
-    }
-    // DDRL_ABL_* are timing-only knock-outs for tools/ablate_engine.sh (results are WRONG with any of
-    // them set): they show what each phase of the loop costs on top of the bare LDS->MFMA stream.
-    if constexpr (CommitFirstOf<Op>::v) {
-      // ops with a VALU-heavy commit (masks, u8 conversion): write the NEXT stage and issue the
-      // following fetch before this block's MFMAs, so the scheduler can run them under the MFMAs
-      if (kb + 1 < kbe) {
-#ifndef DDRL_ABL_NOCOMMIT
-        op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
-#endif
-#ifndef DDRL_ABL_NOFETCH
-        if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
-#endif
-      }
-      compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
-    } else {
-      compute_block<Op>(op, lds2 + buf * Op::STAGE, acc);
-      if (kb + 1 < kbe) {
-#ifndef DDRL_ABL_NOCOMMIT
-        op.commit(regs, lds2 + (buf ^ 1) * Op::STAGE);
-#endif
-#ifndef DDRL_ABL_NOFETCH
-        if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
-#endif
-      }
-    }
-#ifndef DDRL_ABL_NOBARRIER
-    __syncthreads();
-#endif
-    buf ^= 1;
+  // The loop is unrolled by the two LDS buffers (engine2_step) and leaves the last one or two k-blocks to a
+  // tail with a run-time buffer index (an exit in the middle of the unrolled loop would cost a copy of every
+  // accumulator register per iteration; the tail also keeps the pre-epilogue registers out of the loop).
+  for (; kb + 2 < kbe; kb += 2) {
+    engine2_step<Op, 0>(op, P, kb, kbe, regs, acc, lds2);
+    engine2_step<Op, 1>(op, P, kb + 1, kbe, regs, acc, lds2);
   }
+  for (int rbuf = 0; kb < kbe; ++kb, rbuf ^= 1) engine2_step<Op, -1>(op, P, kb, kbe, regs, acc, lds2, rbuf);
 #ifndef DDRL_ABL_NOEPILOGUE
   op.epilogue(P, acc, lds2);
 #else

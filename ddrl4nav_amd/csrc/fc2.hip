@@ -6,10 +6,11 @@
 namespace ddrl {
 
 // Loader helpers --------------------------------------------------------------------------------
-// "row-major odd": tile X[128 rows][32 k] of a K-contiguous matrix, stored in LDS as [row][33]
-// so that lanes (= rows) hit 32 different banks.  4 f4 per thread.
+// "row-major": tile X[128 rows][32 k] of a K-contiguous matrix, stored in LDS as [row][34] so that
+// 32 lanes (= rows) hit 32 different banks (34 l mod 64 is distinct over l < 32) and the committed quads
+// are 8-byte aligned (two ds_write_b64 with immediate offsets).  4 f4 per thread.
 struct RowMajorTile {
-  static constexpr int LD = 33;
+  static constexpr int LD = 34;
   static constexpr int FLOATS = 128 * LD;
   // Lane byte offsets of the 4 loads relative to  src + row0 * row_stride + kcol0  (loop invariant).
   // Loads are unconditional from a clamped row: rows >= nrows only feed output rows that the epilogue
@@ -27,8 +28,9 @@ struct RowMajorTile {
     const int k4 = tid & 7, rr = tid >> 3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float* p = dst + (rr + 32 * j) * LD + k4 * 4;
-      p[0] = r[j].x; p[1] = r[j].y; p[2] = r[j].z; p[3] = r[j].w;
+      f2* p = (f2*)(dst + (rr + 32 * j) * LD + k4 * 4);
+      p[0] = (f2){r[j].x, r[j].y};
+      p[1] = (f2){r[j].z, r[j].w};
     }
   }
 };

@@ -6,8 +6,8 @@
 //   straight out of the staged RAW input planes), reduction = (sample, pixel).
 // The two k indices of one 32x32x2 MFMA are the SAME pixel of two consecutive samples, so the
 // lane halves differ by a constant (one staged sample) and every operand address is again
-// lane_base + compile-time immediate.  The bias gradient (sum of dz) rides along: half of the
-// threads add up their dz row from LDS once per k-block.  Slabs are laid out like the arena
+// lane_base + compile-time immediate.  The bias gradient (sum of dz) rides along: conv1 adds up the dz
+// quads it stages in registers, conv2/conv3 add up their dz rows from LDS once per k-block.  Slabs are laid out like the arena
 // (weights then bias) so that one reduce_partials launch finishes both.
 //
 // Reference: autograd weight/bias gradients of conv1..conv3 (atari_encoder.py:16-18 through
@@ -35,7 +35,11 @@ template <int NE>
 struct ConvWgrad1v2 {
   static constexpr int COMMIT_FIRST = 1;  // 7.68 -> 7.38 ms
   static constexpr int THREADS = 256, TM = NE, TN = 2, KSTEPS = 20, ROWS = 32 * NE;  // rows = (e, oc)
-  static constexpr int A_FLOATS = 2 * ROWS * 21, NDZ = 2 * ROWS * 5, NDZ_J = (NDZ + 255) / 256, B_OFF = A_FLOATS, B_FLOATS = 2 * 4 * 672, STAGE = A_FLOATS + B_FLOATS;
+  // dz staging: the threads are split by encoder (TPE each) so that the encoder's base pointer is
+  // wave-uniform; an encoder's k-block is 2 samples x 32 oc x 5 quads of one output row.
+  static constexpr int TPE = 256 / NE, QPE = 2 * 32 * 5, NDZ_J = (QPE + TPE - 1) / TPE;
+  static constexpr int LDA = 22;  // dz row stride: even (8-byte aligned quad halves), 22 l mod 64 distinct over 32 lanes
+  static constexpr int A_FLOATS = 2 * ROWS * LDA, B_OFF = A_FLOATS, B_FLOATS = 2 * 4 * 672, STAGE = A_FLOATS + B_FLOATS;
   static constexpr int64_t SLAB = 32 * 256 + 32;
   struct Params {
     const uint8_t* frames;
@@ -48,13 +52,15 @@ struct ConvWgrad1v2 {
   struct Regs {
     f4 dzr[NDZ_J], actr[NDZ_J];
     unsigned im[6];
-    unsigned ok;  // bit j: dz element j belongs to a sample < n
+    bool full;  // wave-uniform: both samples of the pair exist
   };
   int abase[NE], bbase[2], kb_begin, kb_end;
-  int split, l31, hi, wc;
-  int64_t dzoff[NDZ_J];         // k-block independent parts of this thread's source offsets
-  int imoff[6], ldsoff[NDZ_J];
-  float bacc;
+  int split, l31, hi, wc, ew;
+  // k-block independent lane parts (bytes) of this thread's source addresses, see ld4_so()
+  uint32_t dzoff[NDZ_J], imoff[6];
+  int ldsoff[NDZ_J];
+  unsigned dz_s1, dz_ok, im_s1;  // bit j: slot j belongs to the pair's second sample / exists
+  float bacc[NDZ_J];             // bias gradient: running sums of this thread's dz quads
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return 4 * s; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
@@ -67,22 +73,28 @@ struct ConvWgrad1v2 {
     sp.set(p.n, p.nsplit, split);
     kb_begin = sp.pair_begin * 20;
     kb_end = sp.pair_end * 20;
-    bacc = 0.0f;
+    ew = __builtin_amdgcn_readfirstlane(tid / TPE);
+    const int te = tid % TPE;
+    dz_s1 = dz_ok = im_s1 = 0;
 #pragma unroll
     for (int j = 0; j < NDZ_J; ++j) {
-      const int idx = min(tid + 256 * j, NDZ - 1);
-      const int row = idx / 5, q4 = idx % 5;  // row = (sample of the pair, e, oc)
-      dzoff[j] = ((row >> 5) % NE) * p.dz_es + (int64_t)(row / ROWS) * 12800 + (row & 31) * 400 + q4 * 4;
-      ldsoff[j] = row * 21 + q4 * 4;
+      const int idx = te + TPE * j, c = min(idx, QPE - 1);
+      const int row = c / 5, q4 = c % 5, smp = row >> 5, oc = row & 31;
+      dzoff[j] = (uint32_t)((smp * 12800 + oc * 400 + q4 * 4) * 4);
+      ldsoff[j] = (smp * ROWS + ew * 32 + oc) * LDA + q4 * 4;
+      dz_s1 |= (unsigned)smp << j;
+      dz_ok |= (idx < QPE ? 1u : 0u) << j;
+      bacc[j] = 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int idx = min(tid + 256 * j, 1343);
-      const int rr = idx % 672;
-      imoff[j] = (idx / 672) * 28224 + (rr / 168) * 7056 + (rr % 168) * 4;
+      const int smp = idx / 672, rr = idx % 672;
+      imoff[j] = (uint32_t)(smp * 28224 + (rr / 168) * 7056 + (rr % 168) * 4);
+      im_s1 |= (unsigned)smp << j;
     }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) abase[i] = hi * (ROWS * 21) + (i * 32 + l31) * 21;
+    for (int i = 0; i < NE; ++i) abase[i] = hi * (ROWS * LDA) + (i * 32 + l31) * LDA;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wc * 64 + j * 32 + l31;
@@ -90,56 +102,53 @@ struct ConvWgrad1v2 {
     }
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
     const int pair = kb / 20, oy = kb % 20;
-    // All loads are unconditional from clamped addresses (a guarded load makes hipcc branch and
-    // wait per load); a sample >= n contributes zero because its dz is zeroed in commit().
-    if (2 * pair + 1 < p.n) {  // fast path: scalar base + per-thread offsets from init()
-      const int64_t sb = (int64_t)pair * (2 * 12800) + oy * 20;
-      const uint8_t* fp = p.frames + (int64_t)pair * (2 * 28224) + oy * 336;
-      r.ok = 7u;
+    r.full = 2 * pair + 1 < p.n;
+    pin_offsets(dzoff);
+    pin_offsets(imoff);
+    // All loads are unconditional (a guarded load makes hipcc branch and wait per load).
+    const int64_t sb = ew * p.dz_es + (int64_t)pair * (2 * 12800) + oy * 20;
+    const float* dzb = p.dz + sb;
+    const float* acb = p.act + sb;
+    const uint8_t* fp = p.frames + (int64_t)pair * (2 * 28224) + oy * 336;
+    if (r.full) {
 #pragma unroll
       for (int j = 0; j < NDZ_J; ++j) {
-        r.dzr[j] = ld4(p.dz + sb + dzoff[j]);
-        r.actr[j] = ld4(p.act + sb + dzoff[j]);
+        r.dzr[j] = ld4_so(dzb, dzoff[j]);
+        r.actr[j] = ld4_so(acb, dzoff[j]);
       }
 #pragma unroll
-      for (int j = 0; j < 6; ++j) r.im[j] = *(const unsigned*)(fp + imoff[j]);
-      return;
-    }
-    r.ok = 0;
+      for (int j = 0; j < 6; ++j) r.im[j] = ld1u_so(fp, imoff[j]);
+    } else {
+      // last, half-filled pair of an odd batch: the second sample does not exist -> its slots read
+      // the first sample instead and commit() zeroes their dz
+      rare_path();
 #pragma unroll
-    for (int j = 0; j < NDZ_J; ++j) {
-      const int idx = min(tid + 256 * j, NDZ - 1);
-      const int row = idx / 5, q4 = idx % 5;
-      const int smp = row / ROWS, e = (row >> 5) % NE, oc = row & 31;
-      const int b = 2 * pair + smp;
-      r.ok |= (b < p.n ? 1u : 0u) << j;
-      const int64_t off = e * p.dz_es + (int64_t)min(b, p.n - 1) * 12800 + oc * 400 + oy * 20 + q4 * 4;
-      r.dzr[j] = ld4(p.dz + off);
-      r.actr[j] = ld4(p.act + off);
-    }
+      for (int j = 0; j < NDZ_J; ++j) {
+        const uint32_t o = dzoff[j] - ((dz_s1 >> j) & 1u) * (12800u * 4u);
+        r.dzr[j] = ld4_so(dzb, o);
+        r.actr[j] = ld4_so(acb, o);
+      }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int idx = min(tid + 256 * j, 1343);
-      const int smp = idx / 672, rr = idx % 672;
-      const int ch = rr / 168, d = rr % 168;
-      const int b = min(2 * pair + smp, p.n - 1);
-      r.im[j] = *(const unsigned*)(p.frames + (int64_t)b * 28224 + ch * 7056 + oy * 336 + d * 4);
+      for (int j = 0; j < 6; ++j) r.im[j] = ld1u_so(fp, imoff[j] - ((im_s1 >> j) & 1u) * 28224u);
+      rare_path();
     }
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NDZ_J; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < NDZ) {
-        float* d = buf + ldsoff[j];
-        const f4 dzv = ((r.ok >> j) & 1u) ? r.dzr[j] : zero4();
-        d[0] = leaky_g(r.actr[j].x, dzv.x);
-        d[1] = leaky_g(r.actr[j].y, dzv.y);
-        d[2] = leaky_g(r.actr[j].z, dzv.z);
-        d[3] = leaky_g(r.actr[j].w, dzv.w);
+      if (j + 1 < NDZ_J || ((dz_ok >> j) & 1u)) {
+        f4 g = (f4){leaky_g(r.actr[j].x, r.dzr[j].x), leaky_g(r.actr[j].y, r.dzr[j].y), leaky_g(r.actr[j].z, r.dzr[j].z),
+                    leaky_g(r.actr[j].w, r.dzr[j].w)};
+        if (!r.full) {
+          rare_path();
+          if ((dz_s1 >> j) & 1u) g = zero4();
+        }
+        f2* d = (f2*)(buf + ldsoff[j]);  // 8-byte aligned: two ds_write_b64 with immediate offsets
+        d[0] = (f2){g.x, g.y};
+        d[1] = (f2){g.z, g.w};
+        bacc[j] += (g.x + g.y) + (g.z + g.w);  // the bias gradient rides along
       }
     }
 #pragma unroll
@@ -151,15 +160,7 @@ struct ConvWgrad1v2 {
       }
     }
   }
-  __device__ __forceinline__ void extra(const float* cur) {
-    if (threadIdx.x < 2 * ROWS) {
-      const float* row = cur + threadIdx.x * 21;
-      float s = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 20; ++q) s += row[q];
-      bacc += s;
-    }
-  }
+  __device__ __forceinline__ void extra(const float*) {}
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[NE][2], float* lds) {
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -171,11 +172,20 @@ struct ConvWgrad1v2 {
         for (int r = 0; r < 16; ++r) slab[acc_row(r, hi) * 256 + col] = acc[i][j][r];
       }
     }
-    if (threadIdx.x < 2 * ROWS) lds[threadIdx.x] = bacc;
+    // bias partial of (e, oc) = its 2 samples x 5 quad sums
+    const int te = threadIdx.x % TPE;
+#pragma unroll
+    for (int j = 0; j < NDZ_J; ++j)
+      if ((dz_ok >> j) & 1u) lds[ew * QPE + te + TPE * j] = bacc[j];
     __syncthreads();
     if (threadIdx.x < ROWS) {
       const int e = threadIdx.x >> 5, oc = threadIdx.x & 31;
-      p.part[((int64_t)split * 2 + e) * SLAB + 8192 + oc] = lds[threadIdx.x] + lds[ROWS + threadIdx.x];
+      float s = 0.0f;
+#pragma unroll
+      for (int smp = 0; smp < 2; ++smp)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s += lds[e * QPE + (smp * 32 + oc) * 5 + q];
+      p.part[((int64_t)split * 2 + e) * SLAB + 8192 + oc] = s;
     }
   }
 };
