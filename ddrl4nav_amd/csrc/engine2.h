@@ -59,6 +59,9 @@ __device__ __forceinline__ void pin_offsets(uint32_t (&off)[N]) {
 __device__ __forceinline__ f4 ld4_so(const void* uniform_base, uint32_t lane_bytes) {
   return *(const f4*)((const char*)uniform_base + lane_bytes);
 }
+__device__ __forceinline__ float ld1f_so(const void* uniform_base, uint32_t lane_bytes) {
+  return *(const float*)((const char*)uniform_base + lane_bytes);
+}
 __device__ __forceinline__ unsigned ld1u_so(const void* uniform_base, uint32_t lane_bytes) {
   return *(const unsigned*)((const char*)uniform_base + lane_bytes);
 }
@@ -91,27 +94,55 @@ struct IglpOf<Op, decltype((void)Op::IGLP)> {
 };
 
 template <class Op>
-__device__ __forceinline__ void compute_block(const Op& op, const float* __restrict__ cur,
+__device__ __forceinline__ void compute_block(const Op& op, const float* __restrict__ cur, const float* lds_base,
                                               f32x16 (&acc)[Op::TM][Op::TN]) {
 #ifdef DDRL_SETPRIO
   __builtin_amdgcn_s_setprio(DDRL_SETPRIO);
 #endif
 #ifndef DDRL_NO_LDS_PREFETCH
+  // Operand pointers of this k-block.  When the two stage buffers together exceed the 64 KB reach of the
+  // DS immediate offset, the (compile-time) offset of the second buffer is folded into the lane registers
+  // here, once per k-block, and hidden from the compiler; otherwise it would re-base the address with a
+  // vector add in front of every far read.
+  const float* pa[Op::TM];
+  const float* pb[Op::TN];
+  if constexpr (2 * Op::STAGE * sizeof(float) > 65536) {
+    // (the pinned quantity is the byte offset from the start of LDS, not a pointer: an opaque pointer
+    // would lose its LDS address space and turn the reads into flat loads)
+    const unsigned cur_bytes = (unsigned)((const char*)cur - (const char*)lds_base);
+#pragma unroll
+    for (int i = 0; i < Op::TM; ++i) {
+      unsigned o = cur_bytes + 4u * (unsigned)op.abase[i];
+      asm volatile("" : "+v"(o));
+      pa[i] = (const float*)((const char*)lds_base + o);
+    }
+#pragma unroll
+    for (int j = 0; j < Op::TN; ++j) {
+      unsigned o = cur_bytes + 4u * (unsigned)op.bbase[j];
+      asm volatile("" : "+v"(o));
+      pb[j] = (const float*)((const char*)lds_base + o);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < Op::TM; ++i) pa[i] = cur + op.abase[i];
+#pragma unroll
+    for (int j = 0; j < Op::TN; ++j) pb[j] = cur + op.bbase[j];
+  }
   // operands of k-step s+1 are read from LDS before the MFMAs of k-step s are issued (measured:
   // -0.75 ms per PPO iteration over the un-pinned schedule, profiles/README.md)
   float a[Op::TM], b[Op::TN];
 #pragma unroll
-  for (int i = 0; i < Op::TM; ++i) a[i] = cur[op.abase[i] + Op::aoff(0)];
+  for (int i = 0; i < Op::TM; ++i) a[i] = pa[i][Op::aoff(0)];
 #pragma unroll
-  for (int j = 0; j < Op::TN; ++j) b[j] = cur[op.bbase[j] + Op::boff(0)];
+  for (int j = 0; j < Op::TN; ++j) b[j] = pb[j][Op::boff(0)];
 #pragma unroll
   for (int s = 0; s < Op::KSTEPS; ++s) {
     float an[Op::TM], bn[Op::TN];
     if (s + 1 < Op::KSTEPS) {
 #pragma unroll
-      for (int i = 0; i < Op::TM; ++i) an[i] = cur[op.abase[i] + Op::aoff(s + 1 < Op::KSTEPS ? s + 1 : s)];
+      for (int i = 0; i < Op::TM; ++i) an[i] = pa[i][Op::aoff(s + 1 < Op::KSTEPS ? s + 1 : s)];
 #pragma unroll
-      for (int j = 0; j < Op::TN; ++j) bn[j] = cur[op.bbase[j] + Op::boff(s + 1 < Op::KSTEPS ? s + 1 : s)];
+      for (int j = 0; j < Op::TN; ++j) bn[j] = pb[j][Op::boff(s + 1 < Op::KSTEPS ? s + 1 : s)];
     }
 #pragma unroll
     for (int i = 0; i < Op::TM; ++i)
@@ -218,9 +249,9 @@ __device__ __forceinline__ void engine2_step(Op& op, const typename Op::Params& 
       if (kb + 2 < kbe) op.fetch(P, kb + 2, regs);
 #endif
     }
-    compute_block<Op>(op, cur, acc);
+    compute_block<Op>(op, cur, lds2, acc);
   } else {
-    compute_block<Op>(op, cur, acc);
+    compute_block<Op>(op, cur, lds2, acc);
     if (kb + 1 < kbe) {
 #ifndef DDRL_ABL_NOCOMMIT
       op.commit(regs, nxt);

@@ -198,6 +198,9 @@ struct ConvWgrad2v2 {
   static constexpr int COMMIT_FIRST = 1;  // 5.73 -> 5.64 ms
   static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 27;
   static constexpr int A_FLOATS = 2 * 64 * 27, B_OFF = A_FLOATS, B_FLOATS = 2 * 16 * 160, STAGE = A_FLOATS + B_FLOATS;
+  // dz staging: the k-block's 128 rows (sample, oc) x 27 floats are copied element by element (the rows are
+  // only 4-byte aligned in global memory; 16-byte loads at that alignment measured slower than dword loads)
+  static constexpr int NDZ = 128 * 27, NDZ_J = (NDZ + 255) / 256;
   static constexpr int64_t SLAB = 64 * 512 + 64;
   struct Params {
     const float* in;  // a1
@@ -208,16 +211,18 @@ struct ConvWgrad2v2 {
     int n, nsplit;
   };
   struct Regs {
-    float dzr[14];
+    float dzr[NDZ_J];
     f4 im[5];
-    unsigned ok;
+    bool full;  // wave-uniform: both samples of the pair exist
   };
   int abase[2], bbase[2], kb_begin, kb_end;
   int e, g, split, l31, hi, wc;
-  int dzoff[14], imoff[5];  // k-block independent part of this thread's source offsets
+  // k-block independent lane parts (bytes) of this thread's source addresses, see ld4_so()
+  uint32_t dzoff[NDZ_J], imoff[5];
+  unsigned dz_s1, dz_ok, im_s1;  // bit j: slot j belongs to the pair's second sample / exists
+  float bacc[NDZ_J];             // bias gradient: running sums of the dz elements this thread stages
   const float* in;
   const float* dz;
-  float bacc;
   static constexpr int aoff(int s) { return s; }
   static constexpr int boff(int s) { return (s / 9) * 40 + (s % 9) * 2; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
@@ -234,18 +239,22 @@ struct ConvWgrad2v2 {
     kb_end = sp.pair_end * 3;
     in = p.in + e * p.in_es + g * 16 * 400;
     dz = p.dz + e * p.dz_es;
-    bacc = 0.0f;
+    dz_s1 = dz_ok = im_s1 = 0;
 #pragma unroll
-    for (int j = 0; j < 14; ++j) {
-      const int idx = min(tid + 256 * j, 3455);
-      const int row = idx / 27;
-      dzoff[j] = (row >> 6) * 5184 + (row & 63) * 81 + idx % 27;
+    for (int j = 0; j < NDZ_J; ++j) {
+      const int idx = tid + 256 * j, c = min(idx, NDZ - 1);
+      const int row = c / 27;
+      dzoff[j] = (uint32_t)(((row >> 6) * 5184 + (row & 63) * 81 + c % 27) * 4);
+      dz_s1 |= (unsigned)(row >> 6) << j;
+      dz_ok |= (idx < NDZ ? 1u : 0u) << j;
+      bacc[j] = 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int idx = tid + 256 * j;
       const int rr = idx % 640;
-      imoff[j] = (idx / 640) * 12800 + (rr / 40) * 400 + (rr % 40) * 4;
+      imoff[j] = (uint32_t)(((idx / 640) * 12800 + (rr / 40) * 400 + (rr % 40) * 4) * 4);
+      im_s1 |= (unsigned)(idx / 640) << j;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 1728 + (i * 32 + l31) * 27;
@@ -256,57 +265,53 @@ struct ConvWgrad2v2 {
     }
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
     const int pair = kb / 3, band = kb % 3;
-    // Unconditional loads (a guarded load makes hipcc branch and wait per load).  Fast path: both
-    // samples of the pair exist -> one scalar base + the per-thread offsets from init().
-    if (2 * pair + 1 < p.n) {
-      const float* dzp = dz + (int64_t)pair * (2 * 5184) + band * 27;
-      const float* inp = in + (int64_t)pair * (2 * 12800) + band * 120;
-      r.ok = 0x3FFFu;
+    r.full = 2 * pair + 1 < p.n;
+    pin_offsets(dzoff);
+    pin_offsets(imoff);
+    // Unconditional loads (a guarded load makes hipcc branch and wait per load).
+    const float* dzp = dz + (int64_t)pair * (2 * 5184) + band * 27;
+    const float* inp = in + (int64_t)pair * (2 * 12800) + band * 120;
+    if (r.full) {
 #pragma unroll
-      for (int j = 0; j < 14; ++j) r.dzr[j] = dzp[dzoff[j]];
+      for (int j = 0; j < NDZ_J; ++j) r.dzr[j] = ld1f_so(dzp, dzoff[j]);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) r.im[j] = ld4(inp + imoff[j]);
-      return;
-    }
-    r.ok = 0;  // last, odd pair: clamp the missing sample; its dz is zeroed in commit()
+      for (int j = 0; j < 5; ++j) r.im[j] = ld4_so(inp, imoff[j]);
+    } else {
+      // last, half-filled pair of an odd batch: the second sample does not exist -> its slots read
+      // the first sample instead and commit() zeroes their dz
+      rare_path();
 #pragma unroll
-    for (int j = 0; j < 14; ++j) {
-      const int idx = min(tid + 256 * j, 3455);
-      const int row = idx / 27, q = idx % 27;
-      const int b = 2 * pair + (row >> 6);
-      r.ok |= (b < p.n ? 1u : 0u) << j;
-      r.dzr[j] = dz[(int64_t)min(b, p.n - 1) * 5184 + (row & 63) * 81 + band * 27 + q];
-    }
+      for (int j = 0; j < NDZ_J; ++j) r.dzr[j] = ld1f_so(dzp, dzoff[j] - ((dz_s1 >> j) & 1u) * (5184u * 4u));
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int idx = tid + 256 * j;
-      const int smp = idx / 640, rr = idx % 640;
-      const int ch = rr / 40, q4 = rr % 40;
-      const int b = min(2 * pair + smp, p.n - 1);
-      r.im[j] = ld4(in + (int64_t)b * 12800 + ch * 400 + band * 120 + q4 * 4);
+      for (int j = 0; j < 5; ++j) r.im[j] = ld4_so(inp, imoff[j] - ((im_s1 >> j) & 1u) * (12800u * 4u));
+      rare_path();
     }
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
+    if (r.full) {
 #pragma unroll
-    for (int j = 0; j < 14; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 3456) buf[idx] = ((r.ok >> j) & 1u) ? r.dzr[j] : 0.0f;
+      for (int j = 0; j < NDZ_J; ++j)
+        if (j + 1 < NDZ_J || ((dz_ok >> j) & 1u)) {
+          buf[tid + 256 * j] = r.dzr[j];
+          if (g == 0) bacc[j] += r.dzr[j];  // the bias gradient rides along
+        }
+    } else {
+      rare_path();
+#pragma unroll
+      for (int j = 0; j < NDZ_J; ++j)
+        if (j + 1 < NDZ_J || ((dz_ok >> j) & 1u)) {
+          const float v = ((dz_s1 >> j) & 1u) ? 0.0f : r.dzr[j];
+          buf[tid + 256 * j] = v;
+          if (g == 0) bacc[j] += v;
+        }
+      rare_path();
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) st4(buf + B_OFF + (tid + 256 * j) * 4, r.im[j]);
   }
-  __device__ __forceinline__ void extra(const float* cur) {
-    if (g == 0 && threadIdx.x < 128) {
-      const float* row = cur + threadIdx.x * 27;
-      float s = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 27; ++q) s += row[q];
-      bacc += s;
-    }
-  }
+  __device__ __forceinline__ void extra(const float*) {}
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
     float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
 #pragma unroll
@@ -317,10 +322,19 @@ struct ConvWgrad2v2 {
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[(i * 32 + acc_row(r, hi)) * 512 + col] = acc[i][j][r];
     }
-    if (g == 0) {
-      if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+    if (g == 0) {  // bias partial of oc = the sums of its 2 x 27 staged elements
+#pragma unroll
+      for (int j = 0; j < NDZ_J; ++j)
+        if ((dz_ok >> j) & 1u) lds[threadIdx.x + 256 * j] = bacc[j];
       __syncthreads();
-      if (threadIdx.x < 64) slab[32768 + threadIdx.x] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+      if (threadIdx.x < 64) {
+        float s = 0.0f;
+#pragma unroll
+        for (int smp = 0; smp < 2; ++smp)
+#pragma unroll
+          for (int q = 0; q < 27; ++q) s += lds[(smp * 64 + threadIdx.x) * 27 + q];
+        slab[32768 + threadIdx.x] = s;
+      }
     }
   }
 };
@@ -345,11 +359,13 @@ struct ConvWgrad3v2 {
   };
   struct Regs {
     f4 dzr[7], im[4];
-    unsigned ok;
+    bool full;  // wave-uniform: both samples of the pair exist
   };
   int abase[1], bbase[3], kb_begin, kb_end;
   int e, g, split, l31, hi, wr, wc;
-  int imoff[4];
+  // k-block independent lane parts (bytes) of this thread's source addresses, see ld4_so()
+  uint32_t dzoff[7], imoff[4];
+  unsigned dz_s1, im_s1;  // bit j: slot j belongs to the pair's second sample
   const float* in;
   const float* dz;
   float bacc;
@@ -372,10 +388,18 @@ struct ConvWgrad3v2 {
     in = p.in + e * p.in_es + ch0 * 81;
     dz = p.dz + e * p.dz_es;
     bacc = 0.0f;
+    dz_s1 = im_s1 = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int idx = min(tid + 256 * j, 1567);
+      dzoff[j] = (uint32_t)(idx * 16);
+      dz_s1 |= (unsigned)(idx / 784) << j;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int idx = min(tid + 256 * j, 971);
-      imoff[j] = (idx / 486) * 5184 + (idx % 486) * 4;
+      imoff[j] = (uint32_t)(((idx / 486) * 5184 + (idx % 486) * 4) * 4);
+      im_s1 |= (unsigned)(idx / 486) << j;
     }
     abase[0] = hi * 3136 + (wr * 32 + l31) * 49;
 #pragma unroll
@@ -386,40 +410,43 @@ struct ConvWgrad3v2 {
     }
   }
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
-    if (2 * kb + 1 < p.n) {  // fast path: both samples exist; the pair's dz3 is one contiguous run
-      const float* dzp = dz + (int64_t)kb * (2 * FLAT);
-      const float* inp = in + (int64_t)kb * (2 * 5184);
-      r.ok = 0x7Fu;
+    r.full = 2 * kb + 1 < p.n;
+    pin_offsets(dzoff);
+    pin_offsets(imoff);
+    const float* dzp = dz + (int64_t)kb * (2 * FLAT);  // the pair's dz3 is one contiguous run
+    const float* inp = in + (int64_t)kb * (2 * 5184);
+    if (r.full) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) r.dzr[j] = ld4(dzp + min(tid + 256 * j, 1567) * 4);
+      for (int j = 0; j < 7; ++j) r.dzr[j] = ld4_so(dzp, dzoff[j]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r.im[j] = ld4(inp + imoff[j]);
-      return;
-    }
-    r.ok = 0;  // last, odd pair: clamped loads; dz of the missing sample is zeroed in commit()
+      for (int j = 0; j < 4; ++j) r.im[j] = ld4_so(inp, imoff[j]);
+    } else {
+      // last, half-filled pair of an odd batch: the second sample does not exist -> its slots read
+      // the first sample instead and commit() zeroes their dz
+      rare_path();
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int idx = min(tid + 256 * j, 1567);
-      const int smp = idx / 784, q = idx % 784;
-      const int b = 2 * kb + smp;
-      r.ok |= (b < p.n ? 1u : 0u) << j;
-      r.dzr[j] = ld4(dz + (int64_t)min(b, p.n - 1) * FLAT + q * 4);
-    }
+      for (int j = 0; j < 7; ++j) r.dzr[j] = ld4_so(dzp, dzoff[j] - ((dz_s1 >> j) & 1u) * (uint32_t)(FLAT * 4));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = min(tid + 256 * j, 971);
-      const int smp = idx / 486, q = idx % 486;
-      const int b = min(2 * kb + smp, p.n - 1);
-      r.im[j] = ld4(in + (int64_t)b * 5184 + q * 4);
+      for (int j = 0; j < 4; ++j) r.im[j] = ld4_so(inp, imoff[j] - ((im_s1 >> j) & 1u) * (5184u * 4u));
+      rare_path();
     }
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
+    if (r.full) {
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 1568) st4(buf + idx * 4, ((r.ok >> j) & 1u) ? r.dzr[j] : zero4());
+      for (int j = 0; j < 7; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < 1568) st4(buf + idx * 4, r.dzr[j]);
+      }
+    } else {
+      rare_path();
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < 1568) st4(buf + idx * 4, ((dz_s1 >> j) & 1u) ? zero4() : r.dzr[j]);
+      }
+      rare_path();
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -428,11 +455,14 @@ struct ConvWgrad3v2 {
     }
   }
   __device__ __forceinline__ void extra(const float* cur) {
-    if (g == 0 && threadIdx.x < 128) {
-      const float* row = cur + threadIdx.x * 49;
+    // bias gradient: every thread of the column-tile-0 workgroups adds up half a dz row (25 / 24 values) per
+    // k-block, so that the LDS reads are spread over all four waves
+    if (g == 0) {
+      const float* row = cur + (threadIdx.x >> 1) * 49 + (threadIdx.x & 1) * 25;
       float s = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 49; ++q) s += row[q];
+      for (int q = 0; q < 24; ++q) s += row[q];
+      if (!(threadIdx.x & 1)) s += row[24];
       bacc += s;
     }
   }
@@ -445,9 +475,12 @@ struct ConvWgrad3v2 {
       for (int r = 0; r < 16; ++r) slab[(wr * 32 + acc_row(r, hi)) * 576 + col] = acc[0][j][r];
     }
     if (g == 0) {
-      if (threadIdx.x < 128) lds[threadIdx.x] = bacc;
+      lds[threadIdx.x] = bacc;  // [sample of the pair][oc][half row]
       __syncthreads();
-      if (threadIdx.x < 64) slab[36864 + threadIdx.x] = lds[threadIdx.x] + lds[64 + threadIdx.x];
+      if (threadIdx.x < 64) {
+        const float* q = lds + 2 * threadIdx.x;
+        slab[36864 + threadIdx.x] = (q[0] + q[1]) + (q[128] + q[129]);
+      }
     }
   }
 };
