@@ -271,6 +271,9 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
   extern __shared__ __attribute__((aligned(16))) float lds2[];
   Op op;
   const int tid = threadIdx.x;
+#ifdef DDRL_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(DDRL_EDGE_PRIO);
+#endif
   op.init(P, tid, lds2);
   typename Op::Regs regs;
   f32x16 acc[Op::TM][Op::TN];
@@ -289,6 +292,9 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
     if (kb + 1 < kbe) op.fetch(P, kb + 1, regs);
   }
   __syncthreads();
+#ifdef DDRL_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // The loop is unrolled by the two LDS buffers (engine2_step) and leaves the last one or two k-blocks to a
   // tail with a run-time buffer index (an exit in the middle of the unrolled loop would cost a copy of every
   // accumulator register per iteration; the tail also keeps the pre-epilogue registers out of the loop).
@@ -297,6 +303,9 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
     engine2_step<Op, 1>(op, P, kb + 1, kbe, regs, acc, lds2);
   }
   for (int rbuf = 0; kb < kbe; ++kb, rbuf ^= 1) engine2_step<Op, -1>(op, P, kb, kbe, regs, acc, lds2, rbuf);
+#ifdef DDRL_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(DDRL_EDGE_PRIO);
+#endif
 #ifndef DDRL_ABL_NOEPILOGUE
   op.epilogue(P, acc, lds2);
 #else

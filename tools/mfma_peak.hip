@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+typedef __attribute__((ext_vector_type(4))) float f4v;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0, float b0) {
@@ -124,6 +125,83 @@ __global__ __launch_bounds__(256) void mfma_valu_loop(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// mode 4: mode 2 plus NLD independent 1 KB global loads per 32 MFMAs and wave (streaming, never waited for
+// inside the loop, scalar-base addressing so that no VALU work is added): does HBM traffic by itself slow the
+// matrix pipe (power / clock, shared paths)?
+template <int NLD>
+__global__ __launch_bounds__(256) void mfma_stream_loop(float* out, const char* src, unsigned long long src_bytes, int iters) {
+  __shared__ float lds[8192];
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = ((float)((i * 2654435761u) >> 8) / 16777216.0f - 0.5f) * 0.05f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int abase = (lane >> 5) * 64 + (lane & 31), bbase = 4096 + (lane >> 5) * 260 + wave * 64 + (lane & 31);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const unsigned voff = lane * 16;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * 4;
+  const unsigned long long wid = (unsigned long long)blockIdx.x * 4 + (unsigned)__builtin_amdgcn_readfirstlane(wave);
+  unsigned long long pos = wid * 1024;  // wave-uniform (blockIdx / wave id only)
+  // "+v": the destination stays allocated to the asm statements for the whole loop -- the loads complete
+  // asynchronously, so their register must never be handed to anything else
+  f4v sink = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+      const unsigned long long ab = (unsigned long long)(src + pos);
+      const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(ab >> 32));
+      const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ab);  // (unsigned: no sign extension below)
+      const unsigned long long sb = ((unsigned long long)hi32 << 32) | (unsigned long long)lo32;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(sink) : "v"(voff), "s"(sb) : "memory");
+      pos += nwaves * 1024;
+      if (pos + 1024 > src_bytes) pos = wid * 1024;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = lds[abase + i * 32 + 2 * s * 128];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = lds[bbase + j * 32 + 2 * s * 4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (NLD > 0) s += sink[0] * 0.0f;
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NLD>
+static void run_stream(float* out, const char* src, unsigned long long src_bytes, int wgs, int iters, double flop, hipEvent_t e0, hipEvent_t e1) {
+  float best = 1e9f;
+  for (int w = 0; w < 6; ++w) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(mfma_stream_loop<NLD>, dim3(wgs), dim3(256), 0, 0, out, src, src_bytes, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (w >= 2 && ms < best) best = ms;
+  }
+  const double bytes = (double)wgs * 4 * iters * NLD * 1024.0;
+  printf("%d x 1 KB global load per 32 MFMAs: %8.2f ms  %7.1f TFLOP/s   %6.2f TB/s streamed\n", NLD, best, flop / (best * 1e-3) / 1e12,
+         bytes / (best * 1e-3) / 1e12);
+}
+
 template <int NV>
 static void run_valu(float* out, int wgs, int iters, double flop, hipEvent_t e0, hipEvent_t e1) {
   float best = 1e9f;
@@ -171,6 +249,18 @@ int main() {
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     if (w < 3 || w % 10 == 9) printf("%3d   %8.2f   %7.1f\n", w, ms, flop_per_launch / (ms * 1e-3) / 1e12);
+  }
+  {
+    const unsigned long long src_bytes = 4ull << 30;
+    char* src = nullptr;
+    if (hipMalloc((void**)&src, src_bytes) == hipSuccess) {
+      hipMemset(src, 0, src_bytes);
+      run_stream<0>(out, src, src_bytes, wgs, iters, flop_per_launch, e0, e1);
+      run_stream<1>(out, src, src_bytes, wgs, iters, flop_per_launch, e0, e1);
+      run_stream<2>(out, src, src_bytes, wgs, iters, flop_per_launch, e0, e1);
+      run_stream<4>(out, src, src_bytes, wgs, iters, flop_per_launch, e0, e1);
+      hipFree(src);
+    }
   }
   run_valu<0>(out, wgs, iters, flop_per_launch, e0, e1);
   run_valu<4>(out, wgs, iters, flop_per_launch, e0, e1);
