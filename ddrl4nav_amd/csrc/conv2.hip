@@ -104,13 +104,15 @@ struct ConvFwd2v2 {
       const int c = c0 + wc * 64 + j * 32 + l31;
       if (c >= p.n * 81) continue;
       const int b = c / 81, pix = c % 81;
-      float* dst = p.out + e * p.out_es + (int64_t)b * 5184 + pix;
+      // stores: wave-uniform base per output channel + one 32-bit lane offset (no address VALU per store)
+      float* base = p.out + e * p.out_es;
+      const uint32_t lane = (uint32_t)((b * 5184 + pix + hi * (4 * 81)) * 4);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int oc = i * 32 + acc_row(r, hi);
-          dst[oc * 81] = leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]);
+          st1_so(base + (i * 32 + acc_row(r, 0)) * 81, lane, leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]));
         }
     }
   }
@@ -198,13 +200,14 @@ struct ConvFwd3v2 {
       const int c = c0 + wc * 64 + j * 32 + l31;
       if (c >= p.n * 49) continue;
       const int b = c / 49, pix = c % 49;
-      float* dst = p.out + e * p.out_es + (int64_t)b * FLAT + pix;
+      float* base = p.out + e * p.out_es;
+      const uint32_t lane = (uint32_t)((b * FLAT + pix + hi * (4 * 49)) * 4);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int oc = i * 32 + acc_row(r, hi);
-          dst[oc * 49] = leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]);
+          st1_so(base + (i * 32 + acc_row(r, 0)) * 49, lane, leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]));
         }
     }
   }
@@ -319,13 +322,14 @@ struct ConvFwd1v2 {
       const int c = c0 + wc * 64 + j * 32 + l31;
       if (c >= p.n * 400) continue;
       const int b = c / 400, pix = c % 400;
+      const uint32_t lane = (uint32_t)((b * 12800 + pix + hi * (4 * 400)) * 4);  // < 2^32: ddrl_ctx_create checks max_batch
 #pragma unroll
       for (int i = 0; i < NE; ++i) {  // i = encoder
-        float* dst = p.out + i * p.out_es + (int64_t)b * 12800 + pix;
+        float* base = p.out + i * p.out_es;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int oc = acc_row(r, hi);
-          dst[oc * 400] = leaky_f(acc[i][j][r] + lds[2 * STAGE + i * 32 + oc]);
+          st1_so(base + acc_row(r, 0) * 400, lane, leaky_f(acc[i][j][r] + lds[2 * STAGE + i * 32 + oc]));
         }
       }
     }

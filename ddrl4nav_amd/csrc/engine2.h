@@ -59,6 +59,9 @@ __device__ __forceinline__ void pin_offsets(uint32_t (&off)[N]) {
 __device__ __forceinline__ f4 ld4_so(const void* uniform_base, uint32_t lane_bytes) {
   return *(const f4*)((const char*)uniform_base + lane_bytes);
 }
+__device__ __forceinline__ void st1_so(void* uniform_base, uint32_t lane_bytes, float v) {
+  *(float*)((char*)uniform_base + lane_bytes) = v;
+}
 __device__ __forceinline__ float ld1f_so(const void* uniform_base, uint32_t lane_bytes) {
   return *(const float*)((const char*)uniform_base + lane_bytes);
 }
@@ -66,16 +69,19 @@ __device__ __forceinline__ unsigned ld1u_so(const void* uniform_base, uint32_t l
   return *(const unsigned*)((const char*)uniform_base + lane_bytes);
 }
 
-__device__ __forceinline__ float leaky_f(float v) { return v > 0.0f ? v : v * LEAKY; }
+// leaky_relu(v) = max(v, LEAKY * v) for a slope below one: one multiply + one max (bit-identical to the
+// compare/select form, signed zeros included)
+__device__ __forceinline__ float leaky_f(float v) { return __builtin_fmaxf(v, v * LEAKY); }
 __device__ __forceinline__ float leaky_g(float act, float g) { return act > 0.0f ? g : g * LEAKY; }
 
-// float32(u8/255.0) for the four bytes of a dword (same arithmetic as ddrl_u8_table)
+// float32(u8/255.0), correctly rounded, in three vector instructions (convert, multiply, fma): 1/255 is
+// split into float32 hi + lo parts and x*hi + fl(x*lo) is rounded once.  Exhaustively equal to the
+// correctly rounded quotient for x = 0..255 (tests/test_gpu_parity.py checks ddrl_u8_table, which runs this
+// function, bit for bit against numpy).
 __device__ __forceinline__ float u8_unit(unsigned b) {
   const float x = (float)b;
-  const float r = 1.0f / 255.0f;
-  const float q = x * r;
-  const float e = __builtin_fmaf(-255.0f, q, x);
-  return __builtin_fmaf(e, r, q);
+  const float r_hi = 0x1.010102p-8f, r_lo = -0x1.fdfdfep-33f;
+  return __builtin_fmaf(x, r_hi, x * r_lo);
 }
 
 // Ops may declare `static constexpr int IGLP = 1`: use __builtin_amdgcn_iglp_opt(0) instead of the

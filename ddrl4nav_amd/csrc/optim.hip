@@ -3,7 +3,7 @@
 // Reference arithmetic replaced:
 //   clip_grad_norm_ + two torch.optim.Adam steps   USTC_lab/nn/ppo.py:40-42,125-129
 //   Agents._accumulate_rewards                     USTC_lab/agent/agent.py:124-140
-#include "kernels.h"
+#include "engine2.h"
 
 namespace ddrl {
 
@@ -251,14 +251,8 @@ void launch_gae(const float* values, const float* rewards, const uint8_t* dones,
                      ret);
 }
 
-// float32(u8/255.0) table via the same arithmetic the conv1 loader uses
-__global__ void fill_lut_kernel(float* lut) {
-  const float x = (float)threadIdx.x;
-  const float r = 1.0f / 255.0f;
-  const float q = x * r;
-  const float e = __builtin_fmaf(-255.0f, q, x);
-  lut[threadIdx.x] = __builtin_fmaf(e, r, q);
-}
+// float32(u8/255.0) table via the function the conv1 loaders use (engine2.h)
+__global__ void fill_lut_kernel(float* lut) { lut[threadIdx.x] = u8_unit(threadIdx.x); }
 void launch_fill_lut(float* lut, hipStream_t st) { hipLaunchKernelGGL(fill_lut_kernel, dim3(1), dim3(256), 0, st, lut); }
 
 }  // namespace ddrl
