@@ -47,6 +47,30 @@ __device__ __forceinline__ f4 zero4() { return (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
 // hoisted out of the loop it would turn back into a 64-bit vector add per load.  pin_offsets() "redefines" the
 // loop-carried offset registers in place (no copy) and must run once per fetch, BEFORE any branch that
 // selects between load paths (a redefinition inside one arm costs a register copy per offset at the join).
+// LDS-direct staging: one global_load_lds_dwordx4 moves 16 bytes per lane from global memory straight into
+// LDS (no staging registers, no ds_write): the 64 lanes of a wave fill the 1 KB that starts at `lds_wave_base`
+// (wave-uniform) in lane order.  Completion is tracked by vmcnt; the engine waits for it before the barrier
+// that publishes the stage (engine2_step).
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+__device__ __forceinline__ void ld16_to_lds(const void* uniform_base, uint32_t lane_bytes, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gvoid_t*)((const char*)uniform_base + lane_bytes), (lvoid_t*)lds_wave_base, 16, 0, 0);
+}
+// Contiguous tile copy, LDS-direct: quad (tid + 256 j) of the tile comes from uniform_base + off[j]; the 64
+// quads a wave moves per j land 1 KB contiguous at tile + (64 wave + 256 j) quads.  Quads >= nquads are
+// skipped (the lanes are masked off).
+// wave index inside the workgroup as a scalar (the LDS base of an LDS-direct load must be wave-uniform)
+__device__ __forceinline__ int wave_u() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+template <int NJ>
+__device__ __forceinline__ void direct_copy(const void* uniform_base, const uint32_t (&off)[NJ], float* tile, int wave, int tid, int nquads) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (256 * (j + 1) <= nquads || tid + 256 * j < nquads) ld16_to_lds(uniform_base, off[j], tile + (64 * wave + 256 * j) * 4);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 // First and last statement of a rarely taken arm (ragged tails): an un-speculatable marker, so that the
 // compiler keeps the arm behind its wave-uniform branch instead of hoisting / sinking its instructions
 // into the common path (which costs per-lane selects or register copies there).
@@ -217,6 +241,29 @@ struct CommitFirstOf<Op, decltype((void)Op::COMMIT_FIRST)> {
 #endif
 };
 
+// Ops may stage (part of) a k-block with LDS-direct loads: `static constexpr int DIRECT_PENDING` = number of
+// register-prefetch global loads fetch() issues (they are issued AFTER the direct loads of an iteration
+// and may stay in flight across the barrier), and direct(P, kb, stage) issues the direct loads of k-block kb.
+template <class Op, class = void>
+struct HasDirect {
+  static constexpr bool v = false;
+};
+template <class Op>
+struct HasDirect<Op, decltype((void)Op::DIRECT_PENDING)> {
+  static constexpr bool v = true;
+};
+template <class Op>
+__device__ __forceinline__ void wait_direct(bool fetch_in_flight) {
+  if constexpr (HasDirect<Op>::v) {
+    if constexpr (Op::DIRECT_PENDING == 0) {
+      wait_vmcnt<0>();
+    } else {
+      if (fetch_in_flight) wait_vmcnt<Op::DIRECT_PENDING>();
+      else wait_vmcnt<0>();
+    }
+  }
+}
+
 // Ops may define pre_epilogue(P): issued before the last k-block (see engine2_kernel).
 template <class Op, class = void>
 struct HasPreEpilogue {
@@ -236,6 +283,11 @@ __device__ __forceinline__ void engine2_step(Op& op, const typename Op::Params& 
                                              f32x16 (&acc)[Op::TM][Op::TN], float* lds2, int rbuf = 0) {
   float* cur = lds2 + (BUF < 0 ? rbuf : BUF) * Op::STAGE;
   float* nxt = lds2 + (BUF < 0 ? rbuf ^ 1 : BUF ^ 1) * Op::STAGE;
+  if constexpr (HasDirect<Op>::v) {
+    // LDS-direct part of the next stage: in flight under this block's MFMAs (the other buffer was released by
+    // the barrier that ended the previous block)
+    if (kb + 1 < kbe) op.direct(P, kb + 1, nxt);
+  }
   op.extra(cur);
   if constexpr (HasPreEpilogue<Op>::v && BUF < 0) {
     // global loads the epilogue needs (e.g. the activations for the leaky-ReLU mask) are issued
@@ -267,6 +319,10 @@ __device__ __forceinline__ void engine2_step(Op& op, const typename Op::Params& 
 #endif
     }
   }
+  wait_direct<Op>(kb + 2 < kbe);
+  if constexpr (HasDirect<Op>::v) {
+    if (kb + 1 < kbe) op.direct_done(P, kb + 1, nxt);  // e.g. zero-fill of a ragged last k-block
+  }
 #ifndef DDRL_ABL_NOBARRIER
   __syncthreads();
 #endif
@@ -293,9 +349,12 @@ __global__ __launch_bounds__(Op::THREADS, OccOf<Op>::v) void engine2_kernel(type
   int kb = op.kb_begin;
   const int kbe = op.kb_end;
   if (kb < kbe) {
+    if constexpr (HasDirect<Op>::v) op.direct(P, kb, lds2);
     op.fetch(P, kb, regs);
     op.commit(regs, lds2);
     if (kb + 1 < kbe) op.fetch(P, kb + 1, regs);
+    wait_direct<Op>(kb + 1 < kbe);
+    if constexpr (HasDirect<Op>::v) op.direct_done(P, kb, lds2);
   }
   __syncthreads();
 #ifdef DDRL_EDGE_PRIO

@@ -52,6 +52,11 @@ struct KMajorTile {
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = ld4_so(uniform_base, off[j]);
   }
+  // the same 4 quads straight into LDS (a wave's 64 quads of one j are 1 KB contiguous: rows 2 * wave + 8 j, +1)
+  __device__ __forceinline__ static void direct_full(const float* __restrict__ uniform_base, const uint32_t (&off)[4], float* tile, int wave) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld16_to_lds(uniform_base, off[j], tile + (2 * wave + 8 * j) * LD);
+  }
   // k-block that crosses nk (the last one of a ragged reduction): clamped rows + mask
   __device__ __forceinline__ static unsigned fetch_tail(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
                                                         f4 (&r)[4]) {
@@ -112,10 +117,11 @@ struct FcFwd2 : FcCommon {
     float* part;
     int ne;  // encoders (2, or 1 when the prenet is shared)
   };
+  static constexpr int DIRECT_PENDING = 4;  // the weight tile is staged LDS-direct, the 4 activation loads by register
   struct Regs {
-    f4 a[4], b[4];
+    f4 a[4];
   };
-  int e, split, b0, n0;
+  int e, split, b0, n0, wave;
   const float* a3;   // + b0 rows
   const float* wlt;
   uint32_t offa[4], offb[4];
@@ -132,6 +138,7 @@ struct FcFwd2 : FcCommon {
     kb_end = kb_begin + per;
     a3 = p.a3 + e * p.a3_es + (int64_t)b0 * FLAT;
     wlt = p.wlt + (int64_t)e * FLAT * FEAT;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     RowMajorTile::lane_offsets(FLAT, b0, p.n, tid, offa);
     KMajorTile::lane_offsets(FEAT, n0, FEAT, tid, offb);
 #pragma unroll
@@ -139,16 +146,16 @@ struct FcFwd2 : FcCommon {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
+  __device__ __forceinline__ void direct(const Params&, int kb, float* stage) {
+    pin_offsets(offb);
+    KMajorTile::direct_full(wlt + (int64_t)kb * 32 * FEAT, offb, stage + B_OFF, wave);  // FLAT = 98 x 32: every k-block is full
+  }
+  __device__ __forceinline__ void direct_done(const Params&, int, float*) {}
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     pin_offsets(offa);
-    pin_offsets(offb);
     RowMajorTile::fetch(a3 + kb * 32, offa, r.a);
-    KMajorTile::fetch_full(wlt + (int64_t)kb * 32 * FEAT, offb, r.b);  // FLAT = 98 x 32: every k-block is full
   }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
-    KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
-  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) { RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a); }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -181,10 +188,11 @@ struct FcDgrad2 : FcCommon {
     int64_t a3_es;
     int n;
   };
+  static constexpr int DIRECT_PENDING = 4;  // the weight tile is staged LDS-direct, the 4 dh loads by register
   struct Regs {
-    f4 a[4], b[4];
+    f4 a[4];
   };
-  int e, b0, k0;
+  int e, b0, k0, wave;
   const float* dh;   // + b0 rows
   const float* wln;
   uint32_t offa[4], offb[4];
@@ -199,6 +207,7 @@ struct FcDgrad2 : FcCommon {
     kb_end = FEAT / 32;
     dh = p.dh + e * p.dh_es + (int64_t)b0 * FEAT;
     wln = p.wln + (int64_t)e * FLAT * FEAT;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     RowMajorTile::lane_offsets(FEAT, b0, p.n, tid, offa);
     KMajorTile::lane_offsets(FLAT, k0, FLAT, tid, offb);
 #pragma unroll
@@ -206,16 +215,16 @@ struct FcDgrad2 : FcCommon {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
+  __device__ __forceinline__ void direct(const Params&, int kb, float* stage) {
+    pin_offsets(offb);
+    KMajorTile::direct_full(wln + (int64_t)kb * 32 * FLAT, offb, stage + B_OFF, wave);  // FEAT = 16 x 32: every k-block is full
+  }
+  __device__ __forceinline__ void direct_done(const Params&, int, float*) {}
   __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
     pin_offsets(offa);
-    pin_offsets(offb);
     RowMajorTile::fetch(dh + kb * 32, offa, r.a);
-    KMajorTile::fetch_full(wln + (int64_t)kb * 32 * FLAT, offb, r.b);  // FEAT = 16 x 32: every k-block is full
   }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
-    KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
-  }
+  __device__ __forceinline__ void commit(const Regs& r, float* buf) { RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a); }
   // a3 values for the leaky-ReLU mask: loaded (unconditionally, clamped) before the last k-block
   static constexpr int PRE_EPILOGUE = 1;
   float actv[2][2][16];
@@ -253,7 +262,9 @@ struct FcDgrad2 : FcCommon {
 //  rows = n (512), cols = k (3136), reduction = b
 // ------------------------------------------------------------------------------------------------
 struct FcWgrad2 : FcCommon {
-  static constexpr int COMMIT_FIRST = 1;  // 3.84 -> 3.80 ms
+  // Both operand tiles are plain [32 k][128 col] copies of global memory: they are staged with LDS-direct
+  // loads (no staging registers, no commit), which also leaves room for a third wave per SIMD.
+  static constexpr int DIRECT_PENDING = 0;
   static constexpr int A_OFF = 0, B_OFF = KMajorTile::FLOATS, STAGE = 2 * KMajorTile::FLOATS;
   static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena
   struct Params {
@@ -265,12 +276,8 @@ struct FcWgrad2 : FcCommon {
     int n, nsplit;
     int ne;
   };
-  struct Regs {
-    f4 a[4], b[4];
-    unsigned ok;
-    bool full;  // wave-uniform: the k-block lies inside the batch, no masks needed
-  };
-  int e, split, n0, k0;
+  struct Regs {};
+  int e, split, n0, k0, wave;
   const float* dh;
   const float* a3;
   uint32_t offa[4], offb[4];
@@ -279,6 +286,7 @@ struct FcWgrad2 : FcCommon {
   static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
   __device__ __forceinline__ void init(const Params& p, int tid, float*) {
     lanes(tid);
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     e = blockIdx.z % p.ne;
     split = blockIdx.z / p.ne;
     k0 = blockIdx.x * 128;
@@ -297,34 +305,49 @@ struct FcWgrad2 : FcCommon {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
   }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    r.full = kb * 32 + 32 <= p.n;
+  // thread -> (row kk + 8 j, 4 columns at c4 * 4): a wave covers rows 2 * wave + 8 j (+1), 1 KB contiguous in LDS
+  __device__ __forceinline__ void direct(const Params& p, int kb, float* stage) {
+    const int kbase = kb * 32;
     pin_offsets(offa);
     pin_offsets(offb);
-    if (r.full) {
-      KMajorTile::fetch_full(dh + (int64_t)kb * 32 * FEAT, offa, r.a);
-      KMajorTile::fetch_full(a3 + (int64_t)kb * 32 * FLAT, offb, r.b);
-      r.ok = 0xFu;
+    if (kbase + 32 <= p.n) {
+      const float* da = dh + (int64_t)kbase * FEAT;
+      const float* db = a3 + (int64_t)kbase * FLAT;
+      KMajorTile::direct_full(da, offa, stage + A_OFF, wave);
+      KMajorTile::direct_full(db, offb, stage + B_OFF, wave);
     } else {
-      r.ok = KMajorTile::fetch_tail(dh, FEAT, kb * 32, p.n, n0, FEAT, threadIdx.x, r.a);
-      KMajorTile::fetch_tail(a3, FLAT, kb * 32, p.n, k0, FLAT, threadIdx.x, r.b);
+      // ragged last k-block: rows >= n are read from row n - 1 instead (direct_done() zeroes them in dh's tile)
+      rare_path();
+      const int kk = threadIdx.x >> 5;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t row = min(kbase + kk + 8 * j, p.n - 1);
+        const uint32_t ca = offa[j] - (uint32_t)((kk + 8 * j) * FEAT * 4), cb = offb[j] - (uint32_t)((kk + 8 * j) * FLAT * 4);
+        ld16_to_lds(dh + row * FEAT, ca, stage + A_OFF + (2 * wave + 8 * j) * KMajorTile::LD);
+        ld16_to_lds(a3 + row * FLAT, cb, stage + B_OFF + (2 * wave + 8 * j) * KMajorTile::LD);
+      }
+      rare_path();
     }
   }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    KMajorTile::commit(buf + B_OFF, threadIdx.x, r.b);
-    // bias gradient rides along in the workgroups of column tile 0 (the epilogue's owner of the bias
-    // partial): this thread always holds the same 4 columns of dh
-    const bool bias_owner = blockIdx.x == 0;
-    if (r.full) {
-      KMajorTile::commit(buf + A_OFF, threadIdx.x, r.a);
-      if (bias_owner) bsum += (r.a[0] + r.a[1]) + (r.a[2] + r.a[3]);
-    } else {
-      KMajorTile::commit_masked(buf + A_OFF, threadIdx.x, r.a, r.ok);  // samples >= n contribute zero
-      if (bias_owner) {
+  __device__ __forceinline__ void direct_done(const Params& p, int kb, float* stage) {
+    if (kb * 32 + 32 > p.n) {  // samples >= n contribute zero: each thread clears what it loaded itself
+      rare_path();
+      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((r.ok >> j) & 1u) bsum += r.a[j];
-      }
+      for (int j = 0; j < 4; ++j)
+        if (kb * 32 + kk + 8 * j >= p.n) st4(stage + A_OFF + (kk + 8 * j) * KMajorTile::LD + c4 * 4, zero4());
+      rare_path();
+    }
+  }
+  __device__ __forceinline__ void fetch(const Params&, int, Regs&) {}
+  __device__ __forceinline__ void commit(const Regs&, float*) {}
+  __device__ __forceinline__ void extra(const float* cur) {
+    // bias gradient in the workgroups of column tile 0 (the epilogue's owner of the bias partial): every
+    // thread adds up its 4 columns of the 4 dh rows it staged
+    if (blockIdx.x == 0) {
+      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
+      const float* q = cur + A_OFF + kk * KMajorTile::LD + c4 * 4;
+      bsum += (ld4(q) + ld4(q + 8 * KMajorTile::LD)) + (ld4(q + 16 * KMajorTile::LD) + ld4(q + 24 * KMajorTile::LD));
     }
   }
   __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {

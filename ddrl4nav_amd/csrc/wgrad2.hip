@@ -357,10 +357,9 @@ struct ConvWgrad3v2 {
     float* part;
     int n, nsplit;
   };
-  struct Regs {
-    f4 dzr[7], im[4];
-    bool full;  // wave-uniform: both samples of the pair exist
-  };
+  // both tiles are plain copies of global memory: staged LDS-direct (no staging registers, no commit)
+  static constexpr int DIRECT_PENDING = 0;
+  struct Regs {};
   int abase[1], bbase[3], kb_begin, kb_end;
   int e, g, split, l31, hi, wr, wc;
   // k-block independent lane parts (bytes) of this thread's source addresses, see ld4_so()
@@ -409,51 +408,42 @@ struct ConvWgrad3v2 {
       bbase[j] = B_OFF + hi * 1944 + (ch - ch0) * 81 + (t / 3) * 9 + (t % 3);
     }
   }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    r.full = 2 * kb + 1 < p.n;
+  __device__ __forceinline__ void direct(const Params& p, int kb, float* stage) {
     pin_offsets(dzoff);
     pin_offsets(imoff);
     const float* dzp = dz + (int64_t)kb * (2 * FLAT);  // the pair's dz3 is one contiguous run
     const float* inp = in + (int64_t)kb * (2 * 5184);
-    if (r.full) {
-#pragma unroll
-      for (int j = 0; j < 7; ++j) r.dzr[j] = ld4_so(dzp, dzoff[j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r.im[j] = ld4_so(inp, imoff[j]);
+    const int wave = wave_u(), tid = threadIdx.x;
+    if (2 * kb + 1 < p.n) {
+      direct_copy(dzp, dzoff, stage, wave, tid, 1568);
+      direct_copy(inp, imoff, stage + B_OFF, wave, tid, 972);
     } else {
-      // last, half-filled pair of an odd batch: the second sample does not exist -> its slots read
-      // the first sample instead and commit() zeroes their dz
+      // last, half-filled pair of an odd batch: the second sample does not exist -> its quads read the
+      // first sample instead and direct_done() zeroes them in the dz tile
       rare_path();
+      uint32_t dzo[7], imo[4];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) r.dzr[j] = ld4_so(dzp, dzoff[j] - ((dz_s1 >> j) & 1u) * (uint32_t)(FLAT * 4));
+      for (int q = 0; q < 7; ++q) dzo[q] = dzoff[q] - ((dz_s1 >> q) & 1u) * (uint32_t)(FLAT * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r.im[j] = ld4_so(inp, imoff[j] - ((im_s1 >> j) & 1u) * (5184u * 4u));
+      for (int q = 0; q < 4; ++q) imo[q] = imoff[q] - ((im_s1 >> q) & 1u) * (5184u * 4u);
+      direct_copy(dzp, dzo, stage, wave, tid, 1568);
+      direct_copy(inp, imo, stage + B_OFF, wave, tid, 972);
       rare_path();
     }
   }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    const int tid = threadIdx.x;
-    if (r.full) {
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int idx = tid + 256 * j;
-        if (idx < 1568) st4(buf + idx * 4, r.dzr[j]);
-      }
-    } else {
+  __device__ __forceinline__ void direct_done(const Params& p, int kb, float* stage) {
+    if (2 * kb + 1 >= p.n) {  // each thread clears the second-sample quads it loaded itself
       rare_path();
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int idx = tid + 256 * j;
-        if (idx < 1568) st4(buf + idx * 4, ((dz_s1 >> j) & 1u) ? zero4() : r.dzr[j]);
+      for (int q = 0; q < 7; ++q) {
+        const int idx = threadIdx.x + 256 * q;
+        if (idx < 1568 && ((dz_s1 >> q) & 1u)) st4(stage + idx * 4, zero4());
       }
       rare_path();
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 972) st4(buf + B_OFF + idx * 4, r.im[j]);
     }
   }
+  __device__ __forceinline__ void fetch(const Params&, int, Regs&) {}
+  __device__ __forceinline__ void commit(const Regs&, float*) {}
   __device__ __forceinline__ void extra(const float* cur) {
     // bias gradient: every thread of the column-tile-0 workgroups adds up half a dz row (25 / 24 values) per
     // k-block, so that the LDS reads are spread over all four waves
