@@ -321,6 +321,38 @@ def test_clip_coefficient_and_norm(hp, onet, golden):
     np.testing.assert_allclose(s["ClipCoef"], min(1.0, 0.5 / (gn + 1e-6)), rtol=1e-6)
 
 
+@pytest.mark.parametrize("n", [1, 33, 37])
+def test_gradients_batch_fills_an_odd_capacity(onet, n):
+    """n == max_batch, odd: the weight-gradient kernels pair samples and the dense-layer gradient reduces
+    over 32-sample k-blocks, so their last pair / k-block is ragged exactly at the END of every workspace
+    tensor and of the caller's frame buffer -- the tail paths must neither read past them nor let the
+    missing samples contribute."""
+    from ddrl4nav_amd.engine import HotPath
+    h = HotPath(max_batch=n)
+    try:
+        h.set_params(flatten(make_weights(0)))
+        rng = np.random.default_rng(4100 + n)
+        frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+        acts = rng.integers(0, 6, size=n).astype(np.float32)
+        old = (np.full(n, -1.79) + rng.normal(0, 0.3, n)).astype(np.float32)
+        adv = rng.normal(size=n).astype(np.float32)
+        ret = rng.normal(size=n).astype(np.float32)
+        h.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+        onet.load_weights(make_weights(0))
+        onet.zero_grad()
+        t = torch.from_numpy
+        _, al, vl, ent = O.ppo_losses(onet, O.frames_to_f32(frames), t(acts), t(old), t(adv), t(ret))
+        al.backward()
+        vl.backward()
+        got = _grad_views(h)
+        for name, p in onet.named_parameters():
+            want = p.grad.numpy()
+            assert np.isfinite(got[name]).all(), name
+            assert np.abs(got[name] - want).max() <= 1e-4 * np.abs(want).max() + 1e-12, (name, n)
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("n", [1, 37, 200, 511])
 def test_gradients_ragged_batches_vs_oracle(hp, onet, n):
     """Odd sample counts exercise the zero-padded half of a sample pair in the weight-gradient
