@@ -102,7 +102,7 @@ static int32_t validate(const ddrl_config* c) {
   if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // int_frame_stack = 4
   if (c->share_cnn_net != 0 && c->share_cnn_net != 1) return DDRL_ERR_INVALID_ARG;
   // 32-bit element indexing inside one encoder's activation tensor
-  // the kernels address a1 / da1 with 32-bit BYTE offsets from wave-uniform bases (max_batch <= 83,885)
+  // the kernels address a1 / da1 with 32-bit BYTE offsets from wave-uniform bases (max_batch <= 83,886)
   if ((int64_t)c->max_batch * 32 * 400 * 4 >= (int64_t)1 << 32) return DDRL_ERR_UNSUPPORTED;
   return DDRL_OK;
 }

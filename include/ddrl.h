@@ -55,7 +55,9 @@ typedef struct ddrl_ring ddrl_ring;
 typedef struct ddrl_config {
   int32_t n_actions;      /* ACTION_OUTPUT_DIM, 6 for Pong                       */
   int32_t in_channels;    /* int_frame_stack, 4                                   */
-  int32_t max_batch;      /* largest n / B any call will pass (sizes workspace)   */
+  int32_t max_batch;      /* largest n / B any call will pass (sizes workspace);
+                             1 .. 83,886 (32-bit byte offsets into the conv1 activations);
+                             larger global batches: shard, or pass B_global to ddrl_ppo_iter */
   int32_t share_cnn_net;  /* SHARE_CNN_NET: 0 = actor and critic own an encoder each (default,
                              ppo.py:118-129), 1 = one shared prenet, one Adam over every
                              parameter on total_loss (ppo.py:110-117)                */

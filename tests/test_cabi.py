@@ -54,6 +54,11 @@ def test_unsupported_configs_fail_loudly():
         assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -2
     cfg = _lib.default_config(max_batch=64, share_cnn_net=2)
     assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -1
+    # the kernels address the conv1 activations with 32-bit byte offsets: 83,886 samples is the last size
+    cfg = _lib.default_config(max_batch=83886)
+    assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == 0
+    cfg = _lib.default_config(max_batch=83887)
+    assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -2
     with pytest.raises(_lib.DdrlError):
         _lib.check(-2)
 
