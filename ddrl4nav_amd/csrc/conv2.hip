@@ -22,9 +22,12 @@ namespace ddrl {
 // conv2 forward: a1 [e][n][32][20][20] -> a2 [e][n][64][9][9], k4 s2.   rows = oc (64),
 // cols = b*81+pix (256 per workgroup, <= 5 samples), k-block = 2 input channels x 16 taps.
 // ================================================================================================
+// TNV = 32-column groups per wave: 2 (256-column tiles) for training batches, 1 (128-column tiles, twice
+// the workgroups) when a small acting batch would otherwise leave most CUs without work.
+template <int TNV>
 struct ConvFwd2v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
-  static constexpr int NS = 5, W_FLOATS = 32 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 2 * 400;
+  static constexpr int THREADS = 256, TM = 2, TN = TNV, KSTEPS = 16, CW = 128 * TNV;
+  static constexpr int NS = (CW - 1) / 81 + 2, NIMJ = (NS * 200 + 255) / 256, W_FLOATS = 32 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 2 * 400;
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
   static constexpr int EXTRA = 64;  // bias vector, read by the epilogue from LDS
   struct Params {
@@ -38,11 +41,11 @@ struct ConvFwd2v2 {
     int n;
   };
   struct Regs {
-    f4 w[2], im[4];
+    f4 w[2], im[NIMJ];
   };
-  int abase[2], bbase[2], kb_begin, kb_end;
+  int abase[2], bbase[TN], kb_begin, kb_end;
   int e, c0, b_first, l31, hi, wc;
-  int imoff[4];  // per-thread source offsets of the staged planes (k-block independent part)
+  int imoff[NIMJ];  // per-thread source offsets of the staged planes (k-block independent part)
   const float* in;
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
@@ -53,7 +56,7 @@ struct ConvFwd2v2 {
     l31 = lane & 31;
     hi = lane >> 5;
     e = blockIdx.z;
-    c0 = blockIdx.x * 256;
+    c0 = blockIdx.x * CW;
     b_first = c0 / 81;
     kb_begin = 0;
     kb_end = 16;
@@ -64,7 +67,7 @@ struct ConvFwd2v2 {
     // out-of-range threads / samples read clamped, valid addresses; what they stage is either
     // not stored (idx guard in commit) or only feeds output columns that are discarded.
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NIMJ; ++j) {
       const int idx = tid + 256 * j;
       const bool has = idx < NS * 200;
       const int b = min(b_first + (has ? idx / 200 : 0), p.n - 1);
@@ -73,8 +76,8 @@ struct ConvFwd2v2 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int c = c0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      int c = c0 + wc * (32 * TN) + j * 32 + l31;
       if (c >= p.n * 81) c = c0;
       const int b = c / 81, pix = c % 81;
       bbase[j] = IMG_OFF + (b - b_first) * 800 + (pix / 9) * 40 + (pix % 9) * 2 + hi * 400;
@@ -85,23 +88,23 @@ struct ConvFwd2v2 {
 #pragma unroll
     for (int j = 0; j < 2; ++j) r.w[j] = ld4(wp + kb * 2048 + (tid + 256 * j) * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.im[j] = ld4(in + imoff[j] + kb * 800);
+    for (int j = 0; j < NIMJ; ++j) r.im[j] = ld4(in + imoff[j] + kb * 800);
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 2; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NIMJ; ++j) {
       const int idx = tid + 256 * j;
       if (idx < NS * 200) st4(buf + IMG_OFF + idx * 4, r.im[j]);
     }
   }
   __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][TN], float* lds) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      const int c = c0 + wc * (32 * TN) + j * 32 + l31;
       if (c >= p.n * 81) continue;
       const int b = c / 81, pix = c % 81;
       // stores: wave-uniform base per output channel + one 32-bit lane offset (no address VALU per store)
@@ -122,9 +125,11 @@ struct ConvFwd2v2 {
 // conv3 forward: a2 [e][n][64][9][9] -> a3 [e][n][64][7][7], k3 s1.   rows = oc (64),
 // cols = b*49+pix (<= 7 samples), k-block = 4 input channels x 9 taps (pairs = channels).
 // ================================================================================================
+template <int TNV>  // see ConvFwd2v2
 struct ConvFwd3v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 18;
-  static constexpr int NS = 7, W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = 2272;  // 7*4*81 = 2268
+  static constexpr int THREADS = 256, TM = 2, TN = TNV, KSTEPS = 18, CW = 128 * TNV;
+  static constexpr int NS = (CW - 1) / 49 + 2, NIMJ = (NS * 81 + 255) / 256;
+  static constexpr int W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = (NS * 4 * 81 + 3) / 4 * 4;
   static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
   static constexpr int EXTRA = 64;  // bias vector
   struct Params {
@@ -138,11 +143,11 @@ struct ConvFwd3v2 {
     int n;
   };
   struct Regs {
-    f4 w[3], im[3];
+    f4 w[3], im[NIMJ];
   };
-  int abase[2], bbase[2], kb_begin, kb_end;
+  int abase[2], bbase[TN], kb_begin, kb_end;
   int e, c0, b_first, l31, hi, wc;
-  int imoff[3];
+  int imoff[NIMJ];
   const float* in;
   const float* wp;
   static constexpr int aoff(int s) { return 2 * s * 64; }
@@ -153,7 +158,7 @@ struct ConvFwd3v2 {
     l31 = lane & 31;
     hi = lane >> 5;
     e = blockIdx.z;
-    c0 = blockIdx.x * 256;
+    c0 = blockIdx.x * CW;
     b_first = c0 / 49;
     kb_begin = 0;
     kb_end = 16;
@@ -161,7 +166,7 @@ struct ConvFwd3v2 {
     wp = p.wp + (int64_t)e * 16 * 2304;
     if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {  // unconditional, clamped loads (see ConvFwd2v2::init)
+    for (int j = 0; j < NIMJ; ++j) {  // unconditional, clamped loads (see ConvFwd2v2::init)
       const int idx = tid + 256 * j;
       const bool has = idx < NS * 81;
       const int b = min(b_first + (has ? idx / 81 : 0), p.n - 1);
@@ -170,8 +175,8 @@ struct ConvFwd3v2 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int c = c0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      int c = c0 + wc * (32 * TN) + j * 32 + l31;
       if (c >= p.n * 49) c = c0;
       const int b = c / 49, pix = c % 49;
       bbase[j] = IMG_OFF + (b - b_first) * 324 + (pix / 7) * 9 + (pix % 7) + hi * 81;
@@ -182,7 +187,7 @@ struct ConvFwd3v2 {
 #pragma unroll
     for (int j = 0; j < 3; ++j) r.w[j] = ld4(wp + kb * 2304 + min(tid + 256 * j, 575) * 4);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) r.im[j] = ld4(in + imoff[j] + kb * 324);
+    for (int j = 0; j < NIMJ; ++j) r.im[j] = ld4(in + imoff[j] + kb * 324);
   }
   __device__ __forceinline__ void commit(const Regs& r, float* buf) {
     const int tid = threadIdx.x;
@@ -190,14 +195,18 @@ struct ConvFwd3v2 {
     for (int j = 0; j < 3; ++j) {
       const int idx = tid + 256 * j;
       if (idx < 576) st4(buf + idx * 4, r.w[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NIMJ; ++j) {
+      const int idx = tid + 256 * j;
       if (idx < NS * 81) st4(buf + IMG_OFF + idx * 4, r.im[j]);
     }
   }
   __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
+  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][TN], float* lds) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      const int c = c0 + wc * (32 * TN) + j * 32 + l31;
       if (c >= p.n * 49) continue;
       const int b = c / 49, pix = c % 49;
       float* base = p.out + e * p.out_es;
@@ -589,15 +598,27 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
       launch_engine2<ConvFwd1v2<1>>(grid, p, st);
     }
   }
+  // 128-column tiles when 256-column tiles would give fewer than ~1.5 workgroups per CU (small acting batches)
+  const auto narrow = [&](int pix) { return (((int64_t)n * pix + 255) / 256) * L.NE < 384; };
   {
-    ConvFwd2v2::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
+    ConvFwd2v2<2>::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
-    launch_engine2<ConvFwd2v2>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
+    if (narrow(81)) {
+      ConvFwd2v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
+      launch_engine2<ConvFwd2v2<1>>(dim3((unsigned)(((int64_t)n * 81 + 127) / 128), 1, (unsigned)c.L->NE), q, st);
+    } else {
+      launch_engine2<ConvFwd2v2<2>>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
+    }
   }
   {
-    ConvFwd3v2::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
+    ConvFwd3v2<2>::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
-    launch_engine2<ConvFwd3v2>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
+    if (narrow(49)) {
+      ConvFwd3v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
+      launch_engine2<ConvFwd3v2<1>>(dim3((unsigned)(((int64_t)n * 49 + 127) / 128), 1, (unsigned)c.L->NE), q, st);
+    } else {
+      launch_engine2<ConvFwd3v2<2>>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
+    }
   }
 }
 
