@@ -7,7 +7,7 @@
 # on the GPU box times them.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function -Wno-unused-value -Wno-unused-result -Xclang -target-feature -Xclang -load-store-opt"  # = the Makefile's flags
 variant() {  # name, extra flags
   D=/tmp/ddrl_abl_$1
   rm -rf $D && mkdir -p $D/ddrl4nav_amd/csrc $D/include
