@@ -321,7 +321,10 @@ def main():
     torch.cuda.synchronize()
     hp.profile(False)
     hp.profile_read()
-    hp.profile(True)  # reset accumulators: per-kernel times cover the timed region only
+    # Reset the accumulators: per-kernel times cover the timed region only.  The training kernels (ms each) are
+    # timed live; the acting launches (10-40 us each, 1,285 per rollout) are NOT -- event records around them cost
+    # about as much as they do (measured: 44.5 -> 34.6 ms per rollout without) -- they get their own pass below.
+    hp.profile(True, acting=False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -339,6 +342,15 @@ def main():
         elapsed = float(tmax.item())
     stats = hp.stats()
     prof = hp.profile_read()
+    # per-kernel times of the acting launches: a separate, untimed pass of 64 forwards with events around them
+    hp.profile(False)
+    hp.profile(True, acting=True)
+    for t in range(min(T, 64)):
+        ro.act(t)
+    torch.cuda.synchronize()
+    hp.profile(False)
+    for k, v in hp.profile_read().items():
+        prof.setdefault(k, v)
 
     if rank == 0:
         steps = args.steps
@@ -391,6 +403,8 @@ def main():
             "whole_step_frac_of_f32_peak": round(total_flop / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
+            "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
+                             "(*.act, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
         }
         if world == 1 and not args.no_async:
             hp.profile(False)

@@ -27,6 +27,7 @@ struct ddrl_ctx : public ddrl::Profiler {
   bool dirty;
   int last_n;
   bool profile;
+  bool profile_acting;  // ddrl_profile_enable(on = 1): also time the (small, latency-bound) ddrl_forward launches
   std::vector<ProfEntry> prof_pending;
   std::vector<std::string> prof_names;
   std::vector<double> prof_ms;
@@ -151,6 +152,7 @@ int32_t ddrl_ctx_create(const ddrl_config* c, float* params, float* grads, float
   ctx->dirty = true;
   ctx->last_n = 0;
   ctx->profile = false;
+  ctx->profile_acting = false;
   *out = ctx;
   return DDRL_OK;
 }
@@ -195,11 +197,14 @@ int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const floa
   if (n < 1 || n > ctx->cfg.max_batch) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
-  EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  // HIP events around launches of tens of microseconds cost about as much as the launches (an event
+  // record drains the queue): the acting path is only timed when asked for explicitly (on = 1)
+  Profiler* prof = ctx->profile && ctx->profile_acting ? ctx : nullptr;
+  EncCall ec{prof, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
   launch_encoder_forward(ec, true, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, n, ctx->cfg.max_batch};
   {
-    ProfRange ps(ctx->profile ? ctx : nullptr, "heads_act", st);
+    ProfRange ps(prof, "heads_act", st);
     launch_heads_act(hc, act_in, seed, stream_id, probs, value, action_out, logp_out, st);
   }
   ctx->last_n = n;
@@ -470,6 +475,7 @@ int32_t ddrl_profile_enable(ddrl_ctx* ctx, int32_t on) {
     ctx->prof_calls.clear();
   }
   ctx->profile = on != 0;
+  ctx->profile_acting = on == 1;
   return DDRL_OK;
 }
 

@@ -177,8 +177,10 @@ class HotPath:
         check(self.lib.ddrl_u8_table(_ptr(out), _stream()))
         return out
 
-    def profile(self, on=True):
-        check(self.lib.ddrl_profile_enable(self.ctx, 1 if on else 0))
+    def profile(self, on=True, acting=True):
+        """Per-kernel HIP-event timing; acting=False leaves the ddrl_forward launches untimed (the event
+        records around those short launches slow them by about a quarter)."""
+        check(self.lib.ddrl_profile_enable(self.ctx, (1 if acting else 2) if on else 0))
 
     def profile_read(self):
         cap = 64

@@ -211,8 +211,10 @@ int32_t ddrl_timer_start(void* timer, void* stream);
 int32_t ddrl_timer_stop(void* timer, void* stream);
 int32_t ddrl_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
 
-/* Enable per-kernel HIP-event timing inside ddrl_ppo_iter/ddrl_forward (diagnostic; off by
- * default).  names/ms arrays are filled up to `cap` entries; returns the count in *n. */
+/* Enable per-kernel HIP-event timing (diagnostic; off by default): on = 1 inside ddrl_ppo_iter,
+ * ddrl_clip_adam_step and ddrl_forward; on = 2 not inside ddrl_forward, whose launches last tens of
+ * microseconds and would be slowed by about a quarter by the event records around them; on = 0 off.
+ * names/ms arrays are filled up to `cap` entries; returns the count in *n. */
 int32_t ddrl_profile_enable(ddrl_ctx* ctx, int32_t on);
 int32_t ddrl_profile_read(ddrl_ctx* ctx, char (*names)[48], float* ms, int32_t* calls, int32_t cap, int32_t* n);
 
