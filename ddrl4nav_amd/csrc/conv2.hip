@@ -632,7 +632,8 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
 // ds_add_f32 per accumulator element, no two lanes on the same address within a tap, taps separated by
 // barriers -- the summation order is fixed.  The dz3 block (5 x 3,136 floats, contiguous in global memory)
 // is staged once, LDS-direct; the 32 x 64 weight slice of a tap is double buffered.  8 waves: wave w owns
-// columns 32 w .. 32 w + 31.  Executed / algorithmic FLOP = 256 / 245.
+// columns 32 w .. 32 w + 31.  Executed / algorithmic FLOP = 256 / 245.  Workgroups are persistent (one per CU) and
+// stream the next tile's dz3 block in under the last epilogue of the current one.
 // ================================================================================================
 struct Dgrad3S {
   static constexpr int THREADS = 512, NS = 5, RI = 32, NCOL = NS * 49;
@@ -645,36 +646,16 @@ struct Dgrad3S {
 __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(const float* __restrict__ dz3, int64_t dz_es,
                                                                                const float* __restrict__ wd3p,
                                                                                const float* __restrict__ a2, float* __restrict__ dz2,
-                                                                               int64_t out_es, int n) {
+                                                                               int64_t out_es, int n, int nb, int ntiles) {
   using K = Dgrad3S;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = wave_u();
-  const int e = blockIdx.z, b0 = blockIdx.x * K::NS;
-  const int nvalid = min(K::NS, n - b0);
-  const float* dz = dz3 + e * dz_es + (int64_t)b0 * FLAT;
-  // 1. the dz3 block of the workgroup's samples, LDS-direct (quad q -> LDS quad q); it serves both halves of
-  //    the input channels
-#pragma unroll
-  for (int j = 0; j < (K::DQ + 511) / 512; ++j) {
-    const int q = tid + 512 * j;
-    if (q < K::DQ) {
-      // a sample beyond the batch (last workgroup) reads the last valid one instead: its columns are never stored
-      const int sq = q / 784, over = sq - (nvalid - 1);
-      const int src = over > 0 ? q - over * 784 : q;
-      ld16_to_lds(dz, (uint32_t)(src * 16), lds + (64 * wave + 512 * j) * 4);
-    }
-  }
-  // 2. zero the dz2 image
-  for (int i = tid; i < K::O_FLOATS / 4; i += 512) st4(lds + K::O_OFF + i * 4, zero4());
-  // 3. weight slice of (half 0, tap 0): thread -> (oc pair s_, lane half h_, 4 input channels);
-  //    wd3p[e][kb][s][hi][ic] with oc = 4 kb + 2 (s / 9) + hi, tap = s % 9 (optim.hip)
+  // thread -> (oc pair s_, lane half h_, 4 input channels) of a weight slice;
+  // wd3p[e][kb][s][hi][ic] with oc = 4 kb + 2 (s / 9) + hi, tap = s % 9 (optim.hip)
   const int s_ = tid >> 4, h_ = (tid >> 3) & 1, icq = tid & 7;
-  const float* wbase = wd3p + (int64_t)e * (16 * 18 * 128) + ((s_ >> 1) * 18 + (s_ & 1) * 9) * 128 + h_ * 64 + icq * 4;
+  const int woff = ((s_ >> 1) * 18 + (s_ & 1) * 9) * 128 + h_ * 64 + icq * 4;
   const int wdst = K::A_OFF + (s_ * 2 + h_) * K::RI + icq * 4;
-  st4(lds + wdst, ld4(wbase));
-  wait_vmcnt<0>();
-  __syncthreads();
   // lane constants: column = dz3 pixel (sample cs, position cp)
   const int col = wave * 32 + l31;
   const bool cval = col < K::NCOL;
@@ -684,55 +665,95 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
   const float* Ap = lds + K::A_OFF + hi * K::RI + l31;                    // + 64 per oc pair (+ buffer)
   float* Op = lds + K::O_OFF + cs * 81 + (cp / 7) * 9 + cp % 7 + 4 * hi * K::OS;  // + acc_row(r, 0) * OS + tap offset
   constexpr int NEJ = (K::O_FLOATS + 511) / 512;
-  const float* a2w = a2 + e * out_es + (int64_t)b0 * 5184;
-  float* dz2w = dz2 + e * out_es + (int64_t)b0 * 5184;
+
+  // the dz3 block of a tile's samples, LDS-direct (quad q -> LDS quad q); it serves both halves of the channels
+  auto stage_dz3 = [&](int tile) {
+    const int e = tile / nb, b0 = (tile % nb) * K::NS;
+    const int nvalid = min(K::NS, n - b0);
+    const float* dz = dz3 + e * dz_es + (int64_t)b0 * FLAT;
 #pragma unroll
-  for (int ih = 0; ih < 2; ++ih) {  // the two halves of the 64 input channels
-    // the a2 values the leaky-ReLU mask of this half's epilogue needs are loaded now, so that they arrive under
-    // the MFMAs (element i = tid + 512 j of the [ic][s][81] image; offsets relative to the first sample)
-    float actv[NEJ];
-    int eoff[NEJ];  // < 0: nothing to store
-#pragma unroll
-    for (int j = 0; j < NEJ; ++j) {
-      const int i = tid + 512 * j;
-      const int ic = i / K::OS, r = i % K::OS, sm = r / 81, px = r % 81;
-      const bool ok = i < K::O_FLOATS && sm < nvalid;
-      eoff[j] = ok ? sm * 5184 + (ih * K::RI + ic) * 81 + px : -1;
-      actv[j] = a2w[ok ? eoff[j] : 0];
+    for (int j = 0; j < (K::DQ + 511) / 512; ++j) {
+      const int q = tid + 512 * j;
+      if (q < K::DQ) {
+        // a sample beyond the batch (last tile) reads the last valid one instead: its columns are never stored
+        const int sq = q / 784, over = sq - (nvalid - 1);
+        const int src = over > 0 ? q - over * 784 : q;
+        ld16_to_lds(dz, (uint32_t)(src * 16), lds + (64 * wave + 512 * j) * 4);
+      }
     }
+  };
+
+  // persistent workgroups (one per CU: the 131 KB of LDS allow no second one), tiles = (encoder, 5 samples)
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  stage_dz3(tile);
+  for (int i = tid; i < K::O_FLOATS / 4; i += 512) st4(lds + K::O_OFF + i * 4, zero4());
+  st4(lds + wdst, ld4(wd3p + (int64_t)(tile / nb) * (16 * 18 * 128) + woff));  // weight slice of (half 0, tap 0)
+  wait_vmcnt<0>();
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int e = tile / nb, b0 = (tile % nb) * K::NS;
+    const int nvalid = min(K::NS, n - b0);
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < ntiles;
+    const float* wbase = wd3p + (int64_t)e * (16 * 18 * 128) + woff;
+    const float* a2w = a2 + e * out_es + (int64_t)b0 * 5184;
+    float* dz2w = dz2 + e * out_es + (int64_t)b0 * 5184;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int step = ih * 9 + t;  // the weight slices alternate between the two buffers over all 18 steps
-      f4 wnext;
-      if (step + 1 < 18) wnext = ld4(wbase + (t + 1 < 9 ? ih * K::RI + (t + 1) * 128 : K::RI));
-      f32x16 acc0, acc1;
+    for (int ih = 0; ih < 2; ++ih) {  // the two halves of the 64 input channels
+      // the a2 values the leaky-ReLU mask of this half's epilogue needs are loaded now, so that they arrive under
+      // the MFMAs (element i = tid + 512 j of the [ic][s][81] image; offsets relative to the first sample)
+      float actv[NEJ];
+      int eoff[NEJ];  // < 0: nothing to store
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-      const float* A = Ap + (step & 1) * K::A_FLOATS;
-#pragma unroll
-      for (int sp = 0; sp < 32; sp += 2) {  // two accumulators: consecutive MFMAs are independent
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sp * 64], Bp[sp * 98], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(sp + 1) * 64], Bp[(sp + 1) * 98], acc1, 0, 0, 0);
+      for (int j = 0; j < NEJ; ++j) {
+        const int i = tid + 512 * j;
+        const int ic = i / K::OS, r = i % K::OS, sm = r / 81, px = r % 81;
+        const bool ok = i < K::O_FLOATS && sm < nvalid;
+        eoff[j] = ok ? sm * 5184 + (ih * K::RI + ic) * 81 + px : -1;
+        actv[j] = a2w[ok ? eoff[j] : 0];
       }
-      if (cval) {
-        // one lane per address within a tap: plain read-add-write (ds_add_f32 measured ~3 cycles per LANE here)
-        float* o = Op + (t / 3) * 9 + t % 3;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[acc_row(r, 0) * K::OS] += acc0[r] + acc1[r];
+      for (int t = 0; t < 9; ++t) {
+        const int step = ih * 9 + t;  // the weight slices alternate between the two buffers over all 18 steps
+        f4 wnext = zero4();
+        if (step + 1 < 18) {
+          wnext = ld4(wbase + (t + 1 < 9 ? ih * K::RI + (t + 1) * 128 : K::RI));
+        } else if (has_next) {  // (half 0, tap 0) of the next tile
+          wnext = ld4(wd3p + (int64_t)(next / nb) * (16 * 18 * 128) + woff);
+        }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+        const float* A = Ap + (step & 1) * K::A_FLOATS;
+#pragma unroll
+        for (int sp = 0; sp < 32; sp += 2) {  // two accumulators: consecutive MFMAs are independent
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sp * 64], Bp[sp * 98], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(sp + 1) * 64], Bp[(sp + 1) * 98], acc1, 0, 0, 0);
+        }
+        if (cval) {
+          // one lane per address within a tap: plain read-add-write (ds_add_f32 measured ~3 cycles per LANE here)
+          float* o = Op + (t / 3) * 9 + t % 3;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[acc_row(r, 0) * K::OS] += acc0[r] + acc1[r];
+        }
+        st4(lds + wdst + ((step + 1) & 1) * K::A_FLOATS, wnext);  // (step 17 without a next tile: zeros, never read)
+        __syncthreads();
       }
-      if (step + 1 < 18) st4(lds + wdst + ((step + 1) & 1) * K::A_FLOATS, wnext);
+      // the dz3 block is free after the last tap: the next tile's streams in under this epilogue
+      if (ih == 1 && has_next) stage_dz3(next);
+      // dz2 = leaky'(a2) * image, coalesced along the 81 pixels of a (sample, channel) plane; the image is
+      // cleared for the next half / tile by the thread that read it
+#pragma unroll
+      for (int j = 0; j < NEJ; ++j) {
+        const int i = min(tid + 512 * j, K::O_FLOATS - 1);
+        const float v = lds[K::O_OFF + i];
+        if (eoff[j] >= 0) dz2w[eoff[j]] = leaky_g(actv[j], v);
+        if (tid + 512 * j < K::O_FLOATS) lds[K::O_OFF + i] = 0.0f;
+      }
+      if (ih == 1) wait_vmcnt<0>();  // the next tile's dz3 block (and this tile's stores)
       __syncthreads();
     }
-    // dz2 = leaky'(a2) * image, coalesced along the 81 pixels of a (sample, channel) plane; the image is cleared
-    // for the second half by the thread that read it
-#pragma unroll
-    for (int j = 0; j < NEJ; ++j) {
-      const int i = min(tid + 512 * j, K::O_FLOATS - 1);
-      const float v = lds[K::O_OFF + i];
-      if (eoff[j] >= 0) dz2w[eoff[j]] = leaky_g(actv[j], v);
-      if (ih == 0 && tid + 512 * j < K::O_FLOATS) lds[K::O_OFF + i] = 0.0f;
-    }
-    if (ih == 0) __syncthreads();
   }
 }
 
@@ -750,8 +771,17 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_dgrad3_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_dgrad3_scatter_kernel, dim3((unsigned)((c.n + Dgrad3S::NS - 1) / Dgrad3S::NS), 1, (unsigned)c.L->NE),
-                     dim3(Dgrad3S::THREADS), bytes, st, w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount
+               : 256;
+  }
+  const int nb = (c.n + Dgrad3S::NS - 1) / Dgrad3S::NS, ntiles = nb * c.L->NE;
+  hipLaunchKernelGGL(conv_dgrad3_scatter_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(Dgrad3S::THREADS), bytes, st,
+                     w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n, nb, ntiles);
 #endif
 }
 
