@@ -71,6 +71,9 @@ struct Workspace {
   float* wlt;  // [2][3136][512]    FC fwd B operand
   // v2 packed weights: [k-block][k-step][lane half][row], see conv2.hip / wgrad2.hip
   float *wp1, *wp2, *wp3, *wd3p, *wd2p;
+  // conv1 weights split into three bf16 planes (W = W1 + W2 + W3 to 24 bits), conv2.hip conv_fwd1_bf16x3_kernel:
+  // [channel 4][ky pair 4][plane 3][lane half 2][row 32 NE][kx 8] bf16
+  unsigned short* wp1b;
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
@@ -120,6 +123,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wlt = take(2 * (int64_t)FLAT * FEAT);
   w.wln = take(2 * (int64_t)FLAT * FEAT);
   w.wp1 = take(4 * 32 * 2 * 64);
+  w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wp2 = take(2 * 16 * 16 * 2 * 64);
   w.wp3 = take(2 * 16 * 18 * 2 * 64);
   w.wd3p = take(2 * 16 * 18 * 2 * 64);

@@ -582,6 +582,167 @@ struct ConvDgrad2v2 {
 };
 
 // ================================================================================================
+// conv1 forward on the bf16 matrix rate, fp32-accurate.  The input pixels are integers 0..255 and therefore EXACT
+// in bf16; the weights are split into three bf16 planes whose sum reproduces them to 24 bits (optim.hip).  Every
+// product plane x pixel is exact in fp32, the MFMA accumulates in fp32, and the 1/255 of the reference's frame
+// normalisation is applied once to the sum:  z = (sum_k (W1 + W2 + W3)[k] x[k]) / 255 + b.  Three
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each).
+//   rows = (e, oc), cols = b*400 + pix (256 per workgroup), k-block = one input channel = 4 k-groups of 16:
+//   k = (ky = 2 g + h, kx = j): lane half h picks the image row, the 8 elements of a fragment are 8 consecutive
+//   pixels of that row (stride-4 convolution: x = 4 ox + kx), i.e. one 16-byte LDS read per operand.
+// The image is kept as bf16 rows (pitch 176 B) in natural pixel order.
+// ================================================================================================
+using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf4 = __attribute__((ext_vector_type(4))) __bf16;
+
+template <int NE>
+struct Fwd1B {
+  static constexpr int ROWS = 32 * NE, A_BYTES = 4 * 3 * 2 * ROWS * 16, PITCH = 176, IMG_BYTES = 64 * PITCH;
+  static constexpr int STAGE_BYTES = A_BYTES + IMG_BYTES, AQ = A_BYTES / 16, NAJ = AQ / 256;  // weight quads per thread
+  static constexpr size_t LDS_BYTES = 2 * STAGE_BYTES + ROWS * 4;
+};
+
+template <int NE>
+__global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
+                                                               const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
+                                                               float* __restrict__ out, int64_t out_es, int n) {
+  using K = Fwd1B<NE>;
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  // tile geometry: 256 output pixels of at most two samples and the input rows they need (as ConvFwd1v2)
+  const int c0 = blockIdx.x * 256, ctot = n * 400, clast = min(c0 + 255, ctot - 1);
+  const int b0 = c0 / 400, b1 = clast / 400, oyf0 = (c0 % 400) / 20, iy0_start = 4 * oyf0;
+  int nrows0, nrows1 = 0;
+  if (b1 == b0) {
+    nrows0 = 4 * ((clast % 400) / 20 - oyf0) + 8;
+  } else {
+    nrows0 = 84 - iy0_start;
+    nrows1 = 4 * ((clast % 400) / 20) + 8;
+  }
+  const int nd0 = nrows0 * 21, nd_total = nd0 + nrows1 * 21;
+  const int64_t src0 = (int64_t)b0 * 28224 + iy0_start * 84, src1 = (int64_t)b1 * 28224;
+  float* bias = (float*)(ldsb + 2 * K::STAGE_BYTES);
+  if (tid < K::ROWS) bias[tid] = params[(tid >> 5 ? bias_off1 : bias_off0) + (tid & 31)];
+  int64_t imsrc[6];
+  int imdst[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int idx = tid + 256 * j;
+    imsrc[j] = (idx >= nd_total) ? src0 : (idx < nd0 ? src0 + idx * 4 : src1 + (idx - nd0) * 4);
+    imdst[j] = K::A_BYTES + (idx / 21) * K::PITCH + (idx % 21) * 8;  // 4 pixels -> 4 bf16
+  }
+  int abase[NE], bbase[2];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) abase[i] = (hi * K::ROWS + i * 32 + l31) * 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int c = c0 + wc * 64 + j * 32 + l31;
+    if (c >= ctot) c = c0;
+    const int b = c / 400, pix = c % 400, oy = pix / 20, ox = pix % 20;
+    const int lr = (b == b0) ? (4 * oy - iy0_start) : (nrows0 + 4 * oy);
+    bbase[j] = K::A_BYTES + (lr + hi) * K::PITCH + ox * 8;
+  }
+  f4 wreg[K::NAJ];
+  unsigned imreg[6];
+  auto fetch = [&](int ch) {
+    const char* wsrc = (const char*)wp1b + (size_t)ch * K::A_BYTES;
+#pragma unroll
+    for (int j = 0; j < K::NAJ; ++j) wreg[j] = *(const f4*)(wsrc + (tid + 256 * j) * 16);
+    const uint8_t* chp = frames + ch * 7056;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) imreg[j] = *(const unsigned*)(chp + imsrc[j]);  // unconditional, clamped
+  };
+  auto commit = [&](char* st) {
+#pragma unroll
+    for (int j = 0; j < K::NAJ; ++j) *(f4*)(st + (tid + 256 * j) * 16) = wreg[j];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (tid + 256 * j < nd_total) {
+        const unsigned v = imreg[j];
+        // float(byte) has at most 8 significant bits: its upper 16 bits ARE the bf16 value
+        const unsigned f0 = __float_as_uint((float)(v & 255u)), f1 = __float_as_uint((float)((v >> 8) & 255u));
+        const unsigned f2 = __float_as_uint((float)((v >> 16) & 255u)), f3 = __float_as_uint((float)(v >> 24));
+        uint2 pk;
+        pk.x = (f0 >> 16) | (f1 & 0xFFFF0000u);
+        pk.y = (f2 >> 16) | (f3 & 0xFFFF0000u);
+        *(uint2*)(st + imdst[j]) = pk;
+      }
+    }
+  };
+  f32x16 acc[NE][2];
+#pragma unroll
+  for (int i = 0; i < NE; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  fetch(0);
+  commit(ldsb);
+  fetch(1);
+  __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    const char* cur = ldsb + (ch & 1) * K::STAGE_BYTES;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf8 b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {  // 8-byte aligned: two 8-byte reads
+        const bf4 lo = *(const bf4*)(cur + bbase[j] + g * (2 * K::PITCH));
+        const bf4 hi4 = *(const bf4*)(cur + bbase[j] + g * (2 * K::PITCH) + 8);
+        b[j] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int p = 2; p >= 0; --p) {  // smallest plane first
+        bf8 a[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) a[i] = *(const bf8*)(cur + abase[i] + ((g * 3 + p) * 2) * K::ROWS * 16);
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < 4) {
+      commit(ldsb + ((ch + 1) & 1) * K::STAGE_BYTES);
+      if (ch + 2 < 4) fetch(ch + 2);
+    }
+    __syncthreads();
+  }
+  const float r255 = 1.0f / 255.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + wc * 64 + j * 32 + l31;
+    if (c >= ctot) continue;
+    const int b = c / 400, pix = c % 400;
+    const uint32_t lanep = (uint32_t)((b * 12800 + pix + hi * (4 * 400)) * 4);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {  // i = encoder
+      float* base = out + i * out_es;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = acc_row(r, hi);
+        st1_so(base + acc_row(r, 0) * 400, lanep, leaky_f(acc[i][j][r] * r255 + bias[i * 32 + oc]));
+      }
+    }
+  }
+}
+
+template <int NE>
+static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
+  const Workspace& w = *c.ws;
+  const ParamLayout& L = *c.L;
+  using K = Fwd1B<NE>;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd1_bf16x3_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL(conv_fwd1_bf16x3_kernel<NE>, dim3((unsigned)(((int64_t)c.n * 400 + 255) / 256)), dim3(256), K::LDS_BYTES, st, c.frames,
+                     w.wp1b, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n);
+}
+
+// ================================================================================================
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -590,6 +751,14 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   {
     ProfRange pr(c.prof, acting ? "ConvFwd1.act" : "ConvFwd1", st);
     const dim3 grid((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1);
+#ifndef DDRL_FWD1_F32  // default: the bf16x3 kernel; -DDDRL_FWD1_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+    if (L.NE == 2) {
+      launch_fwd1_bf16x3<2>(c, st);
+    } else {
+      launch_fwd1_bf16x3<1>(c, st);
+    }
+    (void)grid;
+#else
     if (L.NE == 2) {
       ConvFwd1v2<2>::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b}, w.a1, MB * 12800, n};
       launch_engine2<ConvFwd1v2<2>>(grid, p, st);
@@ -597,6 +766,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
       ConvFwd1v2<1>::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[0] + L.enc.c1b}, w.a1, MB * 12800, n};
       launch_engine2<ConvFwd1v2<1>>(grid, p, st);
     }
+#endif
   }
   // 128-column tiles when 256-column tiles would give fewer than ~1.5 workgroups per CU (small acting batches)
   const auto narrow = [&](int pix) { return (((int64_t)n * pix + 255) / 256) * L.NE < 384; };

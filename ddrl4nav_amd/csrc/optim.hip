@@ -78,7 +78,33 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ pa
   }
 }
 
+// conv1 weights as three bf16 planes: p0 = bf16(w), p1 = bf16(w - p0), p2 = bf16(w - p0 - p1) (round to nearest
+// even; the two subtractions are exact in fp32), so p0 + p1 + p2 reproduces w to 24 bits.  Layout: common.h wp1b.
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+  const int rows = 32 * L.NE;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4 * 4 * 2 * rows * 8) return;
+  const int j = idx & 7, row = (idx >> 3) % rows, r = (idx >> 3) / rows;
+  const int h = r & 1, g = (r >> 1) & 3, c = r >> 3;
+  const int e = row >> 5, oc = row & 31, ky = 2 * g + h;
+  const float w = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + c) * 8 + ky) * 8 + j];
+  const unsigned short p0 = bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
+  const unsigned short p1 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = bf16_rne(r2);
+  const int base = (c * 4 + g) * 3;
+  dst[(((base + 0) * 2 + h) * rows + row) * 8 + j] = p0;
+  dst[(((base + 1) * 2 + h) * rows + row) * 8 + j] = p1;
+  dst[(((base + 2) * 2 + h) * rows + row) * 8 + j] = p2;
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b);
   {
     const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);

@@ -52,8 +52,26 @@ def frames_to_f32(frames_u8):
     return torch.from_numpy(u8_lut()[np.asarray(frames_u8)])
 
 
+class _LeakyForced(torch.autograd.Function):
+    """leaky_relu whose BACKWARD slope follows a given decision tensor instead of sign(z) (tests only: lets a
+    gradient comparison be made under identical ReLU decisions when a pre-activation sits within fp32 noise of 0)."""
+
+    @staticmethod
+    def forward(ctx, z, positive):
+        ctx.save_for_backward(positive)
+        return F.leaky_relu(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        (positive,) = ctx.saved_tensors
+        return g * torch.where(positive, torch.ones_like(g), torch.full_like(g, 0.01)), None
+
+
 class Encoder(nn.Module):
-    """AtariPreNet (atari_encoder.py:12-32): 3 x conv + leaky_relu(0.01), flatten, linear."""
+    """AtariPreNet (atari_encoder.py:12-32): 3 x conv + leaky_relu(0.01), flatten, linear.
+
+    Test hooks (not part of the reference): ``last_z`` keeps the three pre-activations of the latest forward;
+    ``forced`` = [pos1, pos2, pos3] (bool tensors) makes the backward use those decisions (_LeakyForced)."""
 
     def __init__(self, num_inputs=4):
         super().__init__()
@@ -61,11 +79,18 @@ class Encoder(nn.Module):
         self.conv2 = nn.Conv2d(32, 64, 4, stride=2)
         self.conv3 = nn.Conv2d(64, 64, 3, stride=1)
         self.linear = nn.Linear(3136, 512)
+        self.forced = None
+        self.last_z = None
+
+    def _act(self, z, k):
+        self.last_z.append(z.detach())
+        return F.leaky_relu(z) if self.forced is None else _LeakyForced.apply(z, self.forced[k])
 
     def forward(self, x):
-        x = F.leaky_relu(self.conv1(x))
-        x = F.leaky_relu(self.conv2(x))
-        x = F.leaky_relu(self.conv3(x))
+        self.last_z = []
+        x = self._act(self.conv1(x), 0)
+        x = self._act(self.conv2(x), 1)
+        x = self._act(self.conv3(x), 2)
         return self.linear(x.view(x.size(0), -1))
 
 
