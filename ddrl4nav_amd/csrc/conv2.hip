@@ -642,23 +642,26 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
     const int lr = (b == b0) ? (4 * oy - iy0_start) : (nrows0 + 4 * oy);
     bbase[j] = K::A_BYTES + (lr + hi) * K::PITCH + ox * 8;
   }
-  f4 wreg[K::NAJ];
-  unsigned imreg[6];
-  auto fetch = [&](int ch) {
-    const char* wsrc = (const char*)wp1b + (size_t)ch * K::A_BYTES;
+  // the frame bytes of all four channels are requested at once (24 dwords per thread): with 48 short MFMAs per
+  // k-block a one-block prefetch distance does not cover an HBM round trip
+  unsigned imreg[4][6];
 #pragma unroll
-    for (int j = 0; j < K::NAJ; ++j) wreg[j] = *(const f4*)(wsrc + (tid + 256 * j) * 16);
-    const uint8_t* chp = frames + ch * 7056;
+  for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) imreg[j] = *(const unsigned*)(chp + imsrc[j]);  // unconditional, clamped
+    for (int j = 0; j < 6; ++j) imreg[ch][j] = *(const unsigned*)(frames + ch * 7056 + imsrc[j]);  // unconditional, clamped
+  // the weight planes of a channel are a plain copy of global memory: LDS-direct, one k-block ahead (L2-resident)
+  const int wave = wave_u();
+  uint32_t woff[K::NAJ];
+#pragma unroll
+  for (int j = 0; j < K::NAJ; ++j) woff[j] = (uint32_t)((tid + 256 * j) * 16);
+  auto stage_w = [&](int ch, char* st) {
+    direct_copy((const char*)wp1b + (size_t)ch * K::A_BYTES, woff, (float*)st, wave, tid, K::AQ);
   };
-  auto commit = [&](char* st) {
-#pragma unroll
-    for (int j = 0; j < K::NAJ; ++j) *(f4*)(st + (tid + 256 * j) * 16) = wreg[j];
+  auto commit_img = [&](char* st, int ch) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       if (tid + 256 * j < nd_total) {
-        const unsigned v = imreg[j];
+        const unsigned v = imreg[ch][j];
         // float(byte) has at most 8 significant bits: its upper 16 bits ARE the bf16 value
         const unsigned f0 = __float_as_uint((float)(v & 255u)), f1 = __float_as_uint((float)((v >> 8) & 255u));
         const unsigned f2 = __float_as_uint((float)((v >> 16) & 255u)), f3 = __float_as_uint((float)(v >> 24));
@@ -676,13 +679,15 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  fetch(0);
-  commit(ldsb);
-  fetch(1);
+  stage_w(0, ldsb);
+  commit_img(ldsb, 0);
+  wait_vmcnt<0>();
   __syncthreads();
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch) {
     const char* cur = ldsb + (ch & 1) * K::STAGE_BYTES;
+    char* nxt = ldsb + ((ch + 1) & 1) * K::STAGE_BYTES;
+    if (ch + 1 < 4) stage_w(ch + 1, nxt);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bf8 b[2];
@@ -704,8 +709,8 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
       }
     }
     if (ch + 1 < 4) {
-      commit(ldsb + ((ch + 1) & 1) * K::STAGE_BYTES);
-      if (ch + 2 < 4) fetch(ch + 2);
+      commit_img(nxt, ch + 1);
+      wait_vmcnt<0>();
     }
     __syncthreads();
   }
