@@ -504,6 +504,253 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
   launch_reduce_partials(w.wpart, S, ConvWgrad2v2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
 }
 
+// ================================================================================================
+// conv1 weight gradient on the bf16 matrix pipe, fp32-accurate (the counterpart of conv_fwd1_bf16x3_kernel).
+//   dW1[(e,oc)][tap] = (1/255) sum_{b,oy,ox} dz1[b][(e,oc)][oy][ox] * pixel[b][ch][4 oy + ky][4 ox + kx]
+// The pixels (0..255) are exact in bf16; dz1 = leaky'(a1) * da1 is split into three bf16 planes while it is
+// staged (p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1): exact to 24 bits), the products are exact in
+// fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_bf16; 1/255 is applied to the accumulators.
+//   rows = (e, oc), cols = 256 taps (wave w: taps 64 w ..), k-block = (sample pair, output row oy) as in
+//   ConvWgrad1v2; its 2 x 20 output pixels form 6 fragments of 8 consecutive ox (ox 0-7, 8-15, 16-19 + 4 zeros
+//   per sample) = 3 MFMAs of K = 16 (lane half h takes fragment 2 m + h).
+// LDS: dz planes [sample][fragment][plane][row][8 bf16]; the image rows de-interleaved by x mod 4 as bf16
+//   [sample][ch][8 rows][q = x mod 4][24], so that the 8 pixels 4 (ox0 + j) + kx of a fragment are contiguous in
+//   plane kx mod 4 from index ox0 + kx / 4; the one-element shift of kx >= 4 is done with v_alignbit on 5 dwords.
+// ================================================================================================
+using bf8w = __attribute__((ext_vector_type(8))) __bf16;
+using bf2w = __attribute__((ext_vector_type(2))) __bf16;
+using f2w = __attribute__((ext_vector_type(2))) float;
+using u4w = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int NE>
+struct Wgrad1B {
+  static constexpr int ROWS = 32 * NE, PLANE = ROWS * 16, A_BYTES = 2 * 3 * 3 * PLANE, B_OFF = A_BYTES;
+  static constexpr int B_BYTES = 2 * 4 * 8 * 192 + 64, STAGE = A_BYTES + B_BYTES;
+  static constexpr int TPE = 256 / NE, QPE = 2 * 32 * 5, NDZ_J = (QPE + TPE - 1) / TPE;
+  static constexpr int64_t SLAB = 32 * 256 + 32;
+  static constexpr size_t LDS_BYTES = 2 * STAGE;
+};
+
+// two fp32 -> one dword of two bf16 (round to nearest even), and back
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const bf2w v = __builtin_convertvector((f2w){a, b}, bf2w);
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf_hi(unsigned pk) { return __uint_as_float(pk & 0xFFFF0000u); }
+
+template <int NE>
+__global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ dz,
+                                                                 const float* __restrict__ act, int64_t dz_es, float* __restrict__ part,
+                                                                 int n, int nsplit) {
+  using K = Wgrad1B<NE>;
+  extern __shared__ __attribute__((aligned(16))) char ldsw[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int split = blockIdx.y;
+  WgradSplit sp;
+  sp.set(n, nsplit, split);
+  const int kb_begin = sp.pair_begin * 20, kb_end = sp.pair_end * 20;
+  // zero both stages once: the pad half of fragment 2 and the plane pads are never written again
+  for (int i = tid; i < (int)(K::LDS_BYTES / 16); i += 256) *(f4*)(ldsw + i * 16) = zero4();
+  // ---- dz staging map (as ConvWgrad1v2: threads split by encoder so that the encoder's base is wave-uniform)
+  const int ew = __builtin_amdgcn_readfirstlane(tid / K::TPE), te = tid % K::TPE;
+  uint32_t dzoff[K::NDZ_J];
+  int adst[K::NDZ_J];
+  unsigned dz_s1 = 0, dz_ok = 0;
+  float bacc[K::NDZ_J];
+#pragma unroll
+  for (int j = 0; j < K::NDZ_J; ++j) {
+    const int idx = te + K::TPE * j, c = min(idx, K::QPE - 1);
+    const int row5 = c / 5, q4 = c % 5, smp = row5 >> 5, oc = row5 & 31, f = q4 >> 1, half = q4 & 1;
+    dzoff[j] = (uint32_t)((smp * 12800 + oc * 400 + q4 * 4) * 4);
+    adst[j] = ((smp * 3 + f) * 3 * K::ROWS + ew * 32 + oc) * 16 + half * 8;
+    dz_s1 |= (unsigned)smp << j;
+    dz_ok |= (idx < K::QPE ? 1u : 0u) << j;
+    bacc[j] = 0.0f;
+  }
+  // ---- image staging map: unit u = (row R = (sample, ch, r), g): g < 5 = pixels 16 g .. 16 g + 15, g = 5 = 80 .. 83
+  uint32_t imoff[2];
+  int bdst[2];
+  unsigned im_s1 = 0, im_ok = 0, im_tail = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = tid + 256 * k, uc = min(u, 383);
+    const int R = uc / 6, g = uc % 6, smp = R >> 5, ch = (R >> 3) & 3, r = R & 7;
+    imoff[k] = (uint32_t)(smp * 28224 + ch * 7056 + r * 84 + (g < 5 ? g * 16 : 68));  // g = 5: bytes 68..83, the last dword counts
+    bdst[k] = K::B_OFF + R * 192 + (g < 5 ? g * 8 : 40);
+    im_s1 |= (unsigned)smp << k;
+    im_ok |= (u < 384 ? 1u : 0u) << k;
+    im_tail |= (g == 5 ? 1u : 0u) << k;
+  }
+  // ---- operand lane bases: MFMA m of a k-block, lane half hi -> fragment fi = 2 m + hi = (sample fi / 3, frag fi % 3)
+  int aa[NE][3], bb[2][3], shamt[2];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int fi = 2 * m + hi, fs = fi / 3, ff = fi % 3;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) aa[i][m] = ((fs * 3 + ff) * 3 * K::ROWS + i * 32 + l31) * 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = wc * 64 + j * 32 + l31, ch = c >> 6, ky = (c >> 3) & 7, kx = c & 7;
+      bb[j][m] = K::B_OFF + ((fs * 4 + ch) * 8 + ky) * 192 + (kx & 3) * 48 + ff * 16;
+      shamt[j] = (kx >> 2) * 16;
+    }
+  }
+  f4 dzr[K::NDZ_J], actr[K::NDZ_J];
+  u4w imr[2];
+  bool full = true;
+  auto fetch = [&](int kb) {
+    const int pair = kb / 20, oy = kb % 20;
+    full = 2 * pair + 1 < n;
+    const int64_t sb = ew * dz_es + (int64_t)pair * (2 * 12800) + oy * 20;
+    const char* dzb = (const char*)(dz + sb);
+    const char* acb = (const char*)(act + sb);
+    const char* fp = (const char*)frames + (int64_t)pair * (2 * 28224) + oy * 336;
+    // odd batch tail: the second sample does not exist -> its slots read the first sample, commit() zeroes its dz
+#pragma unroll
+    for (int j = 0; j < K::NDZ_J; ++j) {
+      const uint32_t o = full ? dzoff[j] : dzoff[j] - ((dz_s1 >> j) & 1u) * (12800u * 4u);
+      dzr[j] = *(const f4*)(dzb + o);
+      actr[j] = *(const f4*)(acb + o);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t o = full ? imoff[k] : imoff[k] - ((im_s1 >> k) & 1u) * 28224u;
+      const unsigned* q = (const unsigned*)(fp + o);  // 4-byte aligned
+      imr[k] = (u4w){q[0], q[1], q[2], q[3]};
+    }
+  };
+  auto commit = [&](char* st) {
+#pragma unroll
+    for (int j = 0; j < K::NDZ_J; ++j) {
+      if (j + 1 < K::NDZ_J || ((dz_ok >> j) & 1u)) {
+        f4 g = (f4){leaky_g(actr[j].x, dzr[j].x), leaky_g(actr[j].y, dzr[j].y), leaky_g(actr[j].z, dzr[j].z),
+                    leaky_g(actr[j].w, dzr[j].w)};
+        if (!full && ((dz_s1 >> j) & 1u)) g = zero4();
+        bacc[j] += (g.x + g.y) + (g.z + g.w);  // the bias gradient rides along (fp32)
+        // three bf16 planes; the subtractions are exact in fp32
+        const unsigned p0a = pk_bf16(g.x, g.y), p0b = pk_bf16(g.z, g.w);
+        const float r1x = g.x - bf_lo(p0a), r1y = g.y - bf_hi(p0a), r1z = g.z - bf_lo(p0b), r1w = g.w - bf_hi(p0b);
+        const unsigned p1a = pk_bf16(r1x, r1y), p1b = pk_bf16(r1z, r1w);
+        const float r2x = r1x - bf_lo(p1a), r2y = r1y - bf_hi(p1a), r2z = r1z - bf_lo(p1b), r2w = r1w - bf_hi(p1b);
+        const unsigned p2a = pk_bf16(r2x, r2y), p2b = pk_bf16(r2z, r2w);
+        char* d = st + adst[j];
+        *(uint2*)(d) = make_uint2(p0a, p0b);
+        *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
+        *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if ((im_ok >> k) & 1u) {
+        char* d = st + bdst[k];
+        if (!((im_tail >> k) & 1u)) {
+          // 16 pixels x0 .. x0+15: plane q gets pixels x0+q, +4, +8, +12 = byte q of the four dwords, as bf16
+          // (float(byte) has <= 8 significant bits: its upper half IS the bf16)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned f0 = __float_as_uint((float)((imr[k][0] >> (8 * q)) & 255u));
+            const unsigned f1 = __float_as_uint((float)((imr[k][1] >> (8 * q)) & 255u));
+            const unsigned f2 = __float_as_uint((float)((imr[k][2] >> (8 * q)) & 255u));
+            const unsigned f3 = __float_as_uint((float)((imr[k][3] >> (8 * q)) & 255u));
+            *(uint2*)(d + q * 48) = make_uint2((f0 >> 16) | (f1 & 0xFFFF0000u), (f2 >> 16) | (f3 & 0xFFFF0000u));
+          }
+        } else {
+          const unsigned v = imr[k][3];  // pixels 80..83 -> element 20 of each plane
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(unsigned short*)(d + q * 48) = (unsigned short)(__float_as_uint((float)((v >> (8 * q)) & 255u)) >> 16);
+        }
+      }
+    }
+  };
+  f32x16 acc[NE][2];
+#pragma unroll
+  for (int i = 0; i < NE; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  __syncthreads();  // zero fill complete
+  int kb = kb_begin;
+  if (kb < kb_end) {
+    fetch(kb);
+    commit(ldsw);
+    if (kb + 1 < kb_end) fetch(kb + 1);
+  }
+  __syncthreads();
+  for (int buf = 0; kb < kb_end; ++kb, buf ^= 1) {
+    const char* cur = ldsw + buf * K::STAGE;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      bf8w b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* q = cur + bb[j][m];
+        const uint2 w01 = *(const uint2*)q, w23 = *(const uint2*)(q + 8);
+        const unsigned w4 = *(const unsigned*)(q + 16);
+        const u4w o = (u4w){__builtin_amdgcn_alignbit(w01.y, w01.x, shamt[j]), __builtin_amdgcn_alignbit(w23.x, w01.y, shamt[j]),
+                            __builtin_amdgcn_alignbit(w23.y, w23.x, shamt[j]), __builtin_amdgcn_alignbit(w4, w23.y, shamt[j])};
+        b[j] = __builtin_bit_cast(bf8w, o);
+      }
+#pragma unroll
+      for (int p = 2; p >= 0; --p) {  // smallest plane first
+        bf8w a[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) a[i] = *(const bf8w*)(cur + aa[i][m] + p * K::PLANE);
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kb + 1 < kb_end) {
+      commit(ldsw + (buf ^ 1) * K::STAGE);
+      if (kb + 2 < kb_end) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+  // slabs: weights (scaled by the 1/255 of the frame normalisation), then the bias partial
+  const float r255 = 1.0f / 255.0f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    float* slab = part + ((int64_t)split * 2 + i) * K::SLAB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wc * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[acc_row(r, hi) * 256 + col] = acc[i][j][r] * r255;
+    }
+  }
+  float* red = (float*)ldsw;
+#pragma unroll
+  for (int j = 0; j < K::NDZ_J; ++j)
+    if ((dz_ok >> j) & 1u) red[ew * K::QPE + te + K::TPE * j] = bacc[j];
+  __syncthreads();
+  if (tid < K::ROWS) {
+    const int e = tid >> 5, oc = tid & 31;
+    float sum = 0.0f;
+#pragma unroll
+    for (int smp = 0; smp < 2; ++smp)
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sum += red[e * K::QPE + (smp * 32 + oc) * 5 + q];
+    part[((int64_t)split * 2 + e) * K::SLAB + 8192 + oc] = sum;
+  }
+}
+
+template <int NE>
+static void launch_wgrad1_bf16x3(const EncCall& c, int S, hipStream_t st) {
+  using K = Wgrad1B<NE>;
+  const Workspace& w = *c.ws;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad1_bf16x3_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad1_bf16x3_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.a1, c.max_batch * 12800,
+                     w.wpart, c.n, S);
+}
+
 void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -511,6 +758,14 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
   const int S = c.splits->c1;
   {
     ProfRange pr(c.prof, "ConvWgrad1", st);
+#ifndef DDRL_WGRAD1_F32  // default: the bf16x3 kernel; -DDDRL_WGRAD1_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+    if (L.NE == 2) {
+      launch_wgrad1_bf16x3<2>(c, S, st);
+    } else {
+      launch_wgrad1_bf16x3<1>(c, S, st);
+    }
+    (void)MB;
+#else
     if (L.NE == 2) {
       ConvWgrad1v2<2>::Params p{c.frames, w.dz1, w.a1, MB * 12800, w.wpart, c.n, S};
       launch_engine2<ConvWgrad1v2<2>>(dim3(1, S, 1), p, st);
@@ -518,6 +773,7 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
       ConvWgrad1v2<1>::Params p{c.frames, w.dz1, w.a1, MB * 12800, w.wpart, c.n, S};
       launch_engine2<ConvWgrad1v2<1>>(dim3(1, S, 1), p, st);
     }
+#endif
   }
   ProfRange pr(c.prof, "reduce_partials", st);
   launch_reduce_partials(w.wpart, S, ConvWgrad1v2<2>::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
