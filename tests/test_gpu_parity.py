@@ -321,6 +321,56 @@ def test_clip_coefficient_and_norm(hp, onet, golden):
     np.testing.assert_allclose(s["ClipCoef"], min(1.0, 0.5 / (gn + 1e-6)), rtol=1e-6)
 
 
+def test_conv1_forward_is_at_least_fp32_accurate(hp):
+    """The conv1 forward runs on the bf16 matrix pipe (exact-bf16 pixels x three bf16 planes of the fp32 weights,
+    fp32 accumulation).  That is not a precision trade: against a float64 evaluation of the reference arithmetic its
+    error must not exceed that of torch's own fp32 convolution (measured: about half of it)."""
+    n = 96
+    rng = np.random.default_rng(31)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    w = make_weights(0)
+    hp.set_params(flatten(w))
+    probs = torch.empty((n, 6), device="cuda")
+    val, act, lp = (torch.empty(n, device="cuda") for _ in range(3))
+    hp.forward(dev(frames), seed=1, stream_id=0, probs=probs, value=val, action=act, logp=lp)
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        a1 = hp.debug_buffer(0, (32, 20, 20), n, enc).cpu().numpy().astype(np.float64)
+        W, b = torch.from_numpy(w[pre + ".conv1.weight"]), torch.from_numpy(w[pre + ".conv1.bias"])
+        x64 = torch.from_numpy(frames.astype(np.float64) / 255.0)
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x64, W.double(), b.double(), stride=4), 0.01).numpy()
+        x32 = O.frames_to_f32(frames)
+        t32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x32, W, b, stride=4), 0.01).numpy().astype(np.float64)
+        err_kernel, err_torch32 = np.abs(a1 - ref).max(), np.abs(t32 - ref).max()
+        assert err_kernel <= 1.25 * err_torch32 + 1e-9, (pre, err_kernel, err_torch32)
+        assert np.abs(a1 - ref).mean() <= 1.25 * np.abs(t32 - ref).mean() + 1e-12, pre
+
+
+def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp):
+    """Same statement for the conv1 weight gradient (dz1 split into three bf16 planes x exact-bf16 pixels): given
+    the kernel's own dz1 and the frames, its dW1 must be as close to the float64 sum as an fp32 evaluation is."""
+    n = 64
+    rng = np.random.default_rng(32)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    old = np.full(n, -1.79, dtype=np.float32)
+    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    hp.set_params(flatten(make_weights(0)))
+    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    got = _grad_views(hp)
+    x64 = torch.from_numpy(frames.astype(np.float64) / 255.0)
+    cols64 = torch.nn.functional.unfold(x64, kernel_size=8, stride=4)          # [n, 256, 400]
+    cols32 = torch.nn.functional.unfold(O.frames_to_f32(frames), kernel_size=8, stride=4)
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        a1 = hp.debug_buffer(0, (32, 20, 20), n, enc).cpu()
+        da1 = hp.debug_buffer(4, (32, 20, 20), n, enc).cpu()
+        dz = torch.where(a1 > 0, da1, da1 * np.float32(0.01)).reshape(n, 32, 400)   # the kernel's fp32 mask arithmetic
+        ref = torch.einsum("bop,btp->ot", dz.double(), cols64).numpy().reshape(32, 4, 8, 8)
+        f32 = torch.einsum("bop,btp->ot", dz, cols32).numpy().astype(np.float64).reshape(32, 4, 8, 8)
+        k = got[pre + ".conv1.weight"].astype(np.float64)
+        err_kernel, err_f32 = np.abs(k - ref).max(), np.abs(f32 - ref).max()
+        assert err_kernel <= 1.5 * err_f32 + 1e-12, (pre, err_kernel, err_f32)
+
+
 def _adopt_kernel_decisions(h, net, n, x):
     """Leaky-ReLU decision boundaries.  A pre-activation within fp32 noise of zero can come out on either side
     depending on the summation order (the conv1 forward is a bf16x3 kernel whose output is CLOSER to float64 than
