@@ -379,6 +379,130 @@ struct FcWgrad2 : FcCommon {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Dense-layer forward on the bf16 matrix pipe, fp32-accurate ("bf16x6"): both operands are split into three bf16
+// planes (x = x0 + x1 + x2 to 24 bits; the weights once per optimiser step in optim.hip, the activations while they
+// are staged) and the six plane products whose magnitude reaches 2^-18 of the largest are accumulated in fp32:
+// a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 (the dropped ones are below 2^-26).  192 matrix-pipe cycles per 16 k instead of
+// the 512 of eight f32 MFMAs.  128 x 128 tile, k-block 32 = 2 MFMA k-groups; LDS holds ONE stage
+// ([plane][row][32 k] bf16, row pitch 80 B so that 16 lanes' 16-byte fragments hit distinct banks): the next
+// k-block waits in registers and is committed between two barriers while the CU's other workgroup computes.
+// ------------------------------------------------------------------------------------------------
+using bf8f = __attribute__((ext_vector_type(8))) __bf16;
+using bf2f = __attribute__((ext_vector_type(2))) __bf16;
+using f2f = __attribute__((ext_vector_type(2))) float;
+
+struct FcFwdB {
+  static constexpr int PITCH = 80, PLANE = 128 * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
+};
+__device__ __forceinline__ unsigned pkbf(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2f){a, b}, bf2f));
+}
+
+__global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
+                                                            const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
+                                                            float* __restrict__ h, int64_t h_es, int n) {
+  using K = FcFwdB;
+  extern __shared__ __attribute__((aligned(16))) char ldsf[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int e = blockIdx.z, n0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+  // staging maps: activations = 4 quads of 4 k per thread (row rr + 32 j, k4), weights = 2 x 3 fragments of 8 k
+  const int k4 = tid & 7, rr = tid >> 3;
+  const float* asrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asrc[j] = a3 + e * a3_es + (int64_t)min(b0 + rr + 32 * j, n - 1) * FLAT + k4 * 4;
+  const int k8 = tid & 3, cc = tid >> 2;
+  const unsigned short* wsrc = wlb + (int64_t)e * 3 * FLAT * FEAT + (int64_t)(n0 + cc) * FLAT + k8 * 8;
+  int aA[2], bB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = (wr * 64 + i * 32 + l31) * K::PITCH + hi * 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (wc * 64 + j * 32 + l31) * K::PITCH + hi * 16;
+  f4 ar[4], wrg[2][3];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ar[j] = ld4(asrc[j] + kb * 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wrg[j][p] = *(const f4*)(wsrc + (int64_t)p * FLAT * FEAT + (int64_t)j * 64 * FLAT + kb * 32);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f4 v = ar[j];
+      const unsigned p0a = pkbf(v.x, v.y), p0b = pkbf(v.z, v.w);
+      const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
+      const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
+      const unsigned p1a = pkbf(r1x, r1y), p1b = pkbf(r1z, r1w);
+      const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
+      const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
+      const unsigned p2a = pkbf(r2x, r2y), p2b = pkbf(r2z, r2w);
+      char* d = ldsf + (rr + 32 * j) * K::PITCH + k4 * 8;
+      *(uint2*)(d) = make_uint2(p0a, p0b);
+      *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
+      *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(f4*)(ldsf + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + k8 * 16) = wrg[j][p];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = FLAT / 32;
+  fetch(0);
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      bf8f a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8f*)(ldsf + aA[i] + p * K::PLANE + kg * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8f*)(ldsf + bB[j] + p * K::PLANE + kg * 32);
+      }
+      // smallest products first
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nn = n0 + wc * 64 + j * 32 + l31;
+    const float bias = params[(e ? bias_off1 : bias_off0) + nn];
+    float* dst = h + e * h_es;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+        if (b < n) dst[(int64_t)b * FEAT + nn] = acc[i][j][r] + bias;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -386,6 +510,18 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   FcFwd2::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
                    w.h, MB * FEAT, c.n, nsplit, w.wpart, c.L->NE};
   ProfRange pr(c.prof, nsplit > 1 ? "FcFwdSplit" : "FcFwd", st);
+#ifndef DDRL_FC_F32  // default: the bf16x6 kernel for full launches; -DDDRL_FC_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+  if (nsplit == 1) {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)fc_fwd_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
+      configured = true;
+    }
+    hipLaunchKernelGGL(fc_fwd_bf16x6_kernel, dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE), dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT,
+                       w.wlb, c.params, c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n);
+    return;
+  }
+#endif
   launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), p, st);
 }
 

@@ -103,7 +103,25 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
   dst[(((base + 2) * 2 + h) * rows + row) * 8 + j] = p2;
 }
 
+// dense-layer weights as three bf16 planes (see pack_conv1_bf16_kernel): wlb[e][plane][n][k]
+__global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+  const int e = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)FLAT * FEAT) return;
+  const float w = params[L.enc_base[e] + L.enc.lw + i];
+  const unsigned short p0 = bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
+  const unsigned short p1 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = bf16_rne(r2);
+  unsigned short* d = dst + (int64_t)e * 3 * FLAT * FEAT + i;
+  d[0] = p0;
+  d[(int64_t)FLAT * FEAT] = p1;
+  d[2 * (int64_t)FLAT * FEAT] = p2;
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb);
   hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b);
   {
     const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);
