@@ -403,9 +403,10 @@ def main():
             "whole_step_frac_of_f32_peak": round(total_flop / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
-            "dtype_note": "fp32 accumulation everywhere; all GEMM kernels use the f32-input MFMA except conv1's forward and weight "
-                          "gradient, which multiply exact-bf16 pixels (0..255) with three bf16 planes of the other fp32 operand on the "
-                          "bf16 MFMA (forward error against float64 below that of an fp32 chain); their 'tflops' is fp32-equivalent work",
+            "dtype_note": "fp32 accumulation everywhere; the GEMM kernels use the f32-input MFMA except conv1's forward and weight "
+                          "gradient (exact-bf16 pixels 0..255 x three bf16 planes of the other fp32 operand) and the dense layer's "
+                          "forward (three bf16 planes of both operands, six products), which run on the bf16 MFMA with errors against "
+                          "float64 no larger than an fp32 chain's; their 'tflops' is fp32-equivalent work",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
                              "(*.act, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
         }
