@@ -371,6 +371,31 @@ def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp):
         assert err_kernel <= 1.5 * err_f32 + 1e-12, (pre, err_kernel, err_f32)
 
 
+def test_dense_forward_is_at_least_fp32_accurate(hp):
+    """The dense layer's forward in a training launch splits BOTH operands into three bf16 planes and sums six plane
+    products in fp32 (fc_bf16x6_kernel).  Given the kernel's own a3, the error of h against the float64 product must
+    stay within 16 rounding units (2^-24) of sum_k |a_k w_k| (measured: about 4) -- far below the n * eps bound of a sequential fp32
+    chain over K = 3,136 (torch's blocked CPU matmul, whose error is reported alongside, is closer still)."""
+    n = 200
+    rng = np.random.default_rng(33)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    old = np.full(n, -1.79, dtype=np.float32)
+    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    w = make_weights(0)
+    hp.set_params(flatten(w))
+    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        a3 = hp.debug_buffer(2, (3136,), n, enc).cpu()
+        h = hp.debug_buffer(3, (512,), n, enc).cpu().numpy().astype(np.float64)
+        W, b = torch.from_numpy(w[pre + ".linear.weight"]), torch.from_numpy(w[pre + ".linear.bias"])
+        ref = (a3.double() @ W.double().T + b.double()).numpy()
+        f32 = (a3 @ W.T + b).numpy().astype(np.float64)
+        err_kernel, err_f32 = np.abs(h - ref).max(), np.abs(f32 - ref).max()
+        mass = float((a3.double().abs() @ W.double().abs().T).max())  # largest sum_k |a_k w_k|
+        assert err_kernel <= 16 * 2.0 ** -24 * mass, (pre, err_kernel, err_f32, mass)  # measured: ~4 units
+
+
 def _adopt_kernel_decisions(h, net, n, x):
     """Leaky-ReLU decision boundaries.  A pre-activation within fp32 noise of zero can come out on either side
     depending on the summation order (the conv1 forward is a bf16x3 kernel whose output is CLOSER to float64 than
