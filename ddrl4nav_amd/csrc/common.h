@@ -74,6 +74,8 @@ struct Workspace {
   // conv1 weights split into three bf16 planes (W = W1 + W2 + W3 to 24 bits), conv2.hip conv_fwd1_bf16x3_kernel:
   // [channel 4][ky pair 4][plane 3][lane half 2][row 32 NE][kx 8] bf16
   unsigned short* wp1b;
+  // conv2 weights as three bf16 planes [e][in channel 32][plane 3][oc 64][tap 16] (conv2.hip conv_fwd2_bf16x6_kernel)
+  unsigned short* wp2b;
   // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_bf16x6_kernel)
   unsigned short* wlb;
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
@@ -127,6 +129,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp1 = take(4 * 32 * 2 * 64);
   w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
+  w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
   w.wp2 = take(2 * 16 * 16 * 2 * 64);
   w.wp3 = take(2 * 16 * 18 * 2 * 64);
   w.wd3p = take(2 * 16 * 18 * 2 * 64);

@@ -748,6 +748,167 @@ static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
 }
 
 // ================================================================================================
+// conv2 forward on the bf16 matrix pipe, fp32-accurate ("bf16x6", see fc2.hip fc_fwd_bf16x6_kernel): the weights come
+// as three bf16 planes from optim.hip (wp2b), the a1 values are split into three planes while they are staged, and the
+// six plane products that reach 2^-18 of the largest are accumulated in fp32.  One MFMA k-group (16) = the 4 x 4 taps
+// of ONE input channel: lane (pixel, h) holds taps (ky = 2h, kx = 0..3) and (ky = 2h + 1, kx = 0..3) = two runs of four
+// consecutive bf16 in the staged image (4-byte aligned 8-byte LDS reads), so the im2col stays implicit.
+// Tile = 64 output channels x 3 whole samples (243 columns in 8 column tiles of 32), k-block = 4 input channels;
+// LDS holds ONE stage (image planes [plane][sample][channel][400] bf16 + weight planes [channel][plane][oc][16]):
+// the next k-block waits in registers and is split / committed between two barriers while the CU's other
+// workgroups compute.
+// ================================================================================================
+struct Fwd2B {
+  static constexpr int SPT = 3;                                   // samples per tile
+  static constexpr int IMG_PLANE = SPT * 4 * 400 * 2;             // 9,600 B
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 4 * 3 * 64 * 32;  // 28,800 + 24,576
+  static constexpr int BIAS_OFF = W_OFF + W_BYTES;
+  static constexpr int NIU = SPT * 4 * 100, NIJ = (NIU + 255) / 256;      // image units of 4 pixels, per thread
+  static constexpr int NWJ = W_BYTES / 16 / 256;                          // weight quads per thread (6)
+  static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
+};
+struct __attribute__((packed, aligned(4))) lds_u2 {
+  unsigned x, y;
+};
+using u4v = __attribute__((ext_vector_type(4))) unsigned;
+using bf2v = __attribute__((ext_vector_type(2))) __bf16;
+using f2v = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ unsigned pkbf2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){a, b}, bf2v));
+}
+
+__global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
+                                                               const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
+                                                               float* __restrict__ out, int64_t out_es, int n) {
+  using K = Fwd2B;
+  extern __shared__ __attribute__((aligned(16))) char ldsc2[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
+  if (tid < 64) ((float*)(ldsc2 + K::BIAS_OFF))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
+  // ---- staging maps.  image unit u = tid + 256 j: sample u / 400, channel (u % 400) / 100, pixel quad u % 100;
+  // its LDS byte offset inside a plane is simply 8 u.  Missing samples of the last tile read the last sample.
+  const float* isrc[K::NIJ];
+#pragma unroll
+  for (int j = 0; j < K::NIJ; ++j) {
+    const int u = min(tid + 256 * j, K::NIU - 1);
+    const int s = u / 400, rem = u % 400;
+    isrc[j] = a1 + e * a1_es + (int64_t)min(b0 + s, n - 1) * 12800 + rem * 4;  // + kb * 1600
+  }
+  const unsigned short* wsrc = wp2b + (int64_t)e * (32 * 3 * 64 * 16) + tid * 8;  // + kb * 12288 + j * 2048
+  // ---- operand bases
+  int aA[2], bB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int c = wc * 64 + j * 32 + l31;
+    if (c >= K::SPT * 81) c = 0;
+    const int s = c / 81, pix = c % 81, oy = pix / 9, ox = pix % 9;
+    bB[j] = (s * 1600 + (2 * oy + 2 * hi) * 20 + 2 * ox) * 2;
+  }
+  f4 ir[K::NIJ], wr[K::NWJ];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j) ir[j] = ld4(isrc[j] + kb * 1600);
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * 12288 + j * 2048);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j) {
+      if (j + 1 < K::NIJ || tid + 256 * j < K::NIU) {
+        const f4 v = ir[j];
+        const unsigned p0a = pkbf2(v.x, v.y), p0b = pkbf2(v.z, v.w);
+        const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
+        const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
+        const unsigned p1a = pkbf2(r1x, r1y), p1b = pkbf2(r1z, r1w);
+        const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
+        const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
+        const unsigned p2a = pkbf2(r2x, r2y), p2b = pkbf2(r2z, r2w);
+        char* d = ldsc2 + (tid + 256 * j) * 8;
+        *(uint2*)(d) = make_uint2(p0a, p0b);
+        *(uint2*)(d + K::IMG_PLANE) = make_uint2(p1a, p1b);
+        *(uint2*)(d + 2 * K::IMG_PLANE) = make_uint2(p2a, p2b);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j) *(f4*)(ldsc2 + K::W_OFF + (tid + 256 * j) * 16) = wr[j];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = 8;
+  fetch(0);
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      bf8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8*)(ldsc2 + aA[i] + (kg * 3 + p) * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* q = ldsc2 + bB[j] + p * K::IMG_PLANE + kg * 800;
+          const lds_u2 lo = *(const lds_u2*)q, up = *(const lds_u2*)(q + 40);
+          b[p][j] = __builtin_bit_cast(bf8, (u4v){lo.x, lo.y, up.x, up.y});
+        }
+      }
+      // smallest products first
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+  const float* bias = (const float*)(ldsc2 + K::BIAS_OFF);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = wc * 64 + j * 32 + l31;
+    const int s = c / 81, pix = c % 81;
+    if (c >= K::SPT * 81 || b0 + s >= n) continue;
+    float* base = out + e * out_es + (int64_t)b0 * 5184;
+    const uint32_t lb = (uint32_t)((s * 5184 + pix + hi * (4 * 81)) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = i * 32 + acc_row(r, hi);
+        st1_so(base + (i * 32 + acc_row(r, 0)) * 81, lb, leaky_f(acc[i][j][r] + bias[oc]));
+      }
+  }
+}
+static void launch_fwd2_bf16x6(const EncCall& c, hipStream_t st) {
+  using K = Fwd2B;
+  const Workspace& w = *c.ws;
+  const ParamLayout& L = *c.L;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd2_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL(conv_fwd2_bf16x6_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a1,
+                     c.max_batch * 12800, w.wp2b, c.params, L.enc_base[0] + L.enc.c2b, L.enc_base[L.NE - 1] + L.enc.c2b, w.a2, c.max_batch * 5184,
+                     c.n);
+}
+
+// ================================================================================================
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -778,6 +939,11 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   {
     ConvFwd2v2<2>::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
+#ifndef DDRL_FWD2_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+    if (!acting) {
+      launch_fwd2_bf16x6(c, st);
+    } else
+#endif
     if (narrow(81)) {
       ConvFwd2v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
       launch_engine2<ConvFwd2v2<1>>(dim3((unsigned)(((int64_t)n * 81 + 127) / 128), 1, (unsigned)c.L->NE), q, st);

@@ -120,7 +120,26 @@ __global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restri
   d[2 * (int64_t)FLAT * FEAT] = p2;
 }
 
+// conv2 weights as three bf16 planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
+__global__ __launch_bounds__(256) void pack_conv2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+  const int e = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (oc, ch, tap) in parameter order
+  if (i >= 64 * 32 * 16) return;
+  const int tap = i & 15, ch = (i >> 4) & 31, oc = i >> 9;
+  const float w = params[L.enc_base[e] + L.enc.c2w + i];
+  const unsigned short p0 = bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
+  const unsigned short p1 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = bf16_rne(r2);
+  unsigned short* d = dst + (((int64_t)(e * 32 + ch) * 3) * 64 + oc) * 16 + tap;
+  d[0] = p0;
+  d[64 * 16] = p1;
+  d[2 * 64 * 16] = p2;
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b);
   hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb);
   hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b);
   {
