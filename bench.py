@@ -158,7 +158,10 @@ def pmc_traffic(kernel):
     (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_pmc.sh -> profiles/*_pmc_traffic.json);
     null when no profile of this build is committed.  bench.py itself never runs the profiler."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    import re
+    # newest profile = highest (round, version) in the file name r<round>_v<version>_... ("v9" sorts after "v15" as text)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
         return None
     try:

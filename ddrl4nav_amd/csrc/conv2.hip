@@ -754,14 +754,25 @@ static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
 // of ONE input channel: lane (pixel, h) holds taps (ky = 2h, kx = 0..3) and (ky = 2h + 1, kx = 0..3) = two runs of four
 // consecutive bf16 in the staged image (4-byte aligned 8-byte LDS reads), so the im2col stays implicit.
 // Tile = 64 output channels x 3 whole samples (243 columns in 8 column tiles of 32), k-block = 4 input channels;
-// LDS holds ONE stage (image planes [plane][sample][channel][400] bf16 + weight planes [channel][plane][oc][16]):
+// LDS holds ONE stage (image planes [plane][sample][channel][20 rows of pitch 26] bf16 + weight planes [channel][plane][oc][16]):
 // the next k-block waits in registers and is split / committed between two barriers while the CU's other
 // workgroups compute.
 // ================================================================================================
+// Build knobs (A/B and timing-only knock-outs, see profiles/README.md v16): DDRL_F2B_ROW = image row pitch in bytes (40 = dense,
+// 52 = bank-conflict free), DDRL_F2B_KO = 1 drops the residual-plane arithmetic, 2 the global loads inside the k loop
+// (both give WRONG results, only their kernel times mean something).
+#ifndef DDRL_F2B_ROW
+#define DDRL_F2B_ROW 52
+#endif
+#ifndef DDRL_F2B_KO
+#define DDRL_F2B_KO 0
+#endif
 struct Fwd2B {
   static constexpr int SPT = 3;                                   // samples per tile
-  static constexpr int IMG_PLANE = SPT * 4 * 400 * 2;             // 9,600 B
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 4 * 3 * 64 * 32;  // 28,800 + 24,576
+  // image row pitch 26 bf16 (13 words): the 5 input-row pairs a 32-pixel column tile reads in one instruction start
+  // 26 words apart = banks {0, 26, 52, 14, 40} + c, ten words each, disjoint (pitch 20: 2-way conflicts, 46 % of LDS cycles)
+  static constexpr int ROW = DDRL_F2B_ROW, CH = 20 * ROW, IMG_PLANE = SPT * 4 * CH;  // 12,480 B
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 4 * 3 * 64 * 32;  // 37,440 + 24,576
   static constexpr int BIAS_OFF = W_OFF + W_BYTES;
   static constexpr int NIU = SPT * 4 * 100, NIJ = (NIU + 255) / 256;      // image units of 4 pixels, per thread
   static constexpr int NWJ = W_BYTES / 16 / 256;                          // weight quads per thread (6)
@@ -785,14 +796,16 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
   if (tid < 64) ((float*)(ldsc2 + K::BIAS_OFF))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
-  // ---- staging maps.  image unit u = tid + 256 j: sample u / 400, channel (u % 400) / 100, pixel quad u % 100;
-  // its LDS byte offset inside a plane is simply 8 u.  Missing samples of the last tile read the last sample.
+  // ---- staging maps.  image unit u = tid + 256 j: sample u / 400, channel (u % 400) / 100, pixel quad u % 100
+  // (row q / 5, quad q % 5).  Missing samples of the last tile read the last sample.
   const float* isrc[K::NIJ];
+  int idst[K::NIJ];
 #pragma unroll
   for (int j = 0; j < K::NIJ; ++j) {
     const int u = min(tid + 256 * j, K::NIU - 1);
-    const int s = u / 400, rem = u % 400;
+    const int s = u / 400, rem = u % 400, q = rem % 100;
     isrc[j] = a1 + e * a1_es + (int64_t)min(b0 + s, n - 1) * 12800 + rem * 4;  // + kb * 1600
+    idst[j] = (s * 4 + rem / 100) * K::CH + (q / 5) * K::ROW + (q % 5) * 8;
   }
   const unsigned short* wsrc = wp2b + (int64_t)e * (32 * 3 * 64 * 16) + tid * 8;  // + kb * 12288 + j * 2048
   // ---- operand bases
@@ -804,7 +817,7 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
     int c = wc * 64 + j * 32 + l31;
     if (c >= K::SPT * 81) c = 0;
     const int s = c / 81, pix = c % 81, oy = pix / 9, ox = pix % 9;
-    bB[j] = (s * 1600 + (2 * oy + 2 * hi) * 20 + 2 * ox) * 2;
+    bB[j] = s * 4 * K::CH + (2 * oy + 2 * hi) * K::ROW + 4 * ox;
   }
   f4 ir[K::NIJ], wr[K::NWJ];
   auto fetch = [&](int kb) {
@@ -821,14 +834,19 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
         const unsigned p0a = pkbf2(v.x, v.y), p0b = pkbf2(v.z, v.w);
         const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
         const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
+#if DDRL_F2B_KO == 1  // knock-out (timing only): no residual planes
+        const unsigned p1a = p0a, p1b = p0b, p2a = p0a, p2b = p0b;
+        (void)r1x; (void)r1y; (void)r1z; (void)r1w;
+#else
         const unsigned p1a = pkbf2(r1x, r1y), p1b = pkbf2(r1z, r1w);
         const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
         const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
         const unsigned p2a = pkbf2(r2x, r2y), p2b = pkbf2(r2z, r2w);
-        char* d = ldsc2 + (tid + 256 * j) * 8;
-        *(uint2*)(d) = make_uint2(p0a, p0b);
-        *(uint2*)(d + K::IMG_PLANE) = make_uint2(p1a, p1b);
-        *(uint2*)(d + 2 * K::IMG_PLANE) = make_uint2(p2a, p2b);
+#endif
+        char* d = ldsc2 + idst[j];  // 4-byte aligned (odd rows start at 4 mod 8)
+        *(lds_u2*)(d) = lds_u2{p0a, p0b};
+        *(lds_u2*)(d + K::IMG_PLANE) = lds_u2{p1a, p1b};
+        *(lds_u2*)(d + 2 * K::IMG_PLANE) = lds_u2{p2a, p2b};
       }
     }
 #pragma unroll
@@ -856,8 +874,8 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
         for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8*)(ldsc2 + aA[i] + (kg * 3 + p) * 2048);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const char* q = ldsc2 + bB[j] + p * K::IMG_PLANE + kg * 800;
-          const lds_u2 lo = *(const lds_u2*)q, up = *(const lds_u2*)(q + 40);
+          const char* q = ldsc2 + bB[j] + p * K::IMG_PLANE + kg * K::CH;
+          const lds_u2 lo = *(const lds_u2*)q, up = *(const lds_u2*)(q + K::ROW);
           b[p][j] = __builtin_bit_cast(bf8, (u4v){lo.x, lo.y, up.x, up.y});
         }
       }
@@ -873,7 +891,9 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
       commit();
+#if DDRL_F2B_KO != 2  // knock-out 2 (timing only): no global loads inside the loop
       if (kb + 2 < NKB) fetch(kb + 2);
+#endif
     }
     __syncthreads();
   }
