@@ -76,6 +76,8 @@ struct Workspace {
   unsigned short* wp1b;
   // conv2 weights as three bf16 planes [e][in channel 32][plane 3][oc 64][tap 16] (conv2.hip conv_fwd2_bf16x6_kernel)
   unsigned short* wp2b;
+  // conv3 weights as three bf16 planes [e][k-block 8][tap pair 5][plane 3][oc 64][tap parity 2][channel 8] (conv_fwd3_bf16x6_kernel)
+  unsigned short* wp3b;
   // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_bf16x6_kernel)
   unsigned short* wlb;
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
@@ -130,6 +132,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
+  w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wp2 = take(2 * 16 * 16 * 2 * 64);
   w.wp3 = take(2 * 16 * 18 * 2 * 64);
   w.wd3p = take(2 * 16 * 18 * 2 * 64);

@@ -929,6 +929,162 @@ static void launch_fwd2_bf16x6(const EncCall& c, hipStream_t st) {
 }
 
 // ================================================================================================
+// conv3 forward as bf16x6 (see conv_fwd2_bf16x6_kernel).  Nine taps per input channel do not fill an MFMA k-group, so the
+// k index runs over CHANNELS: the a2 block is staged channel-innermost ([plane][sample][pixel][8 channels] bf16, one
+// 16-byte fragment per pixel) and one k-group = (two taps) x (8 channels): lane half h reads tap 2 kg + h.  Nine taps =
+// 4.5 pairs: the tenth "tap" re-reads tap 8 against zero weights (10 % of the MFMAs).  Tile = 64 output channels x 5
+// whole samples (245 columns in 8 column tiles), k-block = 8 input channels = 5 k-groups; one LDS stage, the next
+// k-block waits in registers.  Weights: wp3b[e][k-block 8][k-group 5][plane 3][oc 64][h 2][8 channels] (optim.hip).
+// ================================================================================================
+struct Fwd3B {
+  static constexpr int SPT = 5, NPX = SPT * 81;                   // staged pixels per k-block
+  static constexpr int IMG_PLANE = NPX * 16;                      // 6,480 B
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 19,440 + 30,720
+  static constexpr int BIAS_OFF = W_OFF + W_BYTES;
+  static constexpr int NIJ = (NPX + 255) / 256;                   // pixel units per thread (2)
+  static constexpr int NWJ = (W_BYTES / 16 + 255) / 256;          // weight quads per thread (8, the last one partial)
+  static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
+};
+
+__global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
+                                                               const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
+                                                               float* __restrict__ out, int64_t out_es, int n) {
+  using K = Fwd3B;
+  extern __shared__ __attribute__((aligned(16))) char ldsc3[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
+  if (tid < 64) ((float*)(ldsc3 + K::BIAS_OFF))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
+  // ---- staging maps.  pixel unit u = tid + 256 j: sample u / 81, pixel u % 81; it loads the 8 channels of the k-block
+  // (stride 81 floats) and writes one 16-byte fragment per plane.  Missing samples of the last tile read the last one.
+  const float* isrc[K::NIJ];
+#pragma unroll
+  for (int j = 0; j < K::NIJ; ++j) {
+    const int u = min(tid + 256 * j, K::NPX - 1);
+    const int s = u / 81, px = u % 81;
+    isrc[j] = a2 + e * a2_es + (int64_t)min(b0 + s, n - 1) * 5184 + px;  // + (8 kb + c) * 81
+  }
+  const unsigned short* wsrc = wp3b + (int64_t)e * (8 * 5 * 3 * 64 * 16) + tid * 8;  // + kb * 15360 + j * 2048
+  // ---- operand bases
+  int aA[2], bB[2], tapoff[5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int c = wc * 64 + j * 32 + l31;
+    if (c >= K::SPT * 49) c = 0;
+    const int s = c / 49, pix = c % 49;
+    bB[j] = (s * 81 + (pix / 7) * 9 + pix % 7) * 16;
+  }
+#pragma unroll
+  for (int kg = 0; kg < 5; ++kg) {
+    const int tap = min(2 * kg + hi, 8);
+    tapoff[kg] = ((tap / 3) * 9 + tap % 3) * 16;
+  }
+  float ir[K::NIJ][8];
+  f4 wr[K::NWJ];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 81];
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j)
+      if (j + 1 < K::NWJ || tid + 256 * j < K::W_BYTES / 16) wr[j] = *(const f4*)(wsrc + kb * 15360 + j * 2048);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j) {
+      if (j + 1 < K::NIJ || tid + 256 * j < K::NPX) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = ir[j][2 * c], y = ir[j][2 * c + 1];
+          p0[c] = pkbf2(x, y);
+          const float r1x = x - __uint_as_float(p0[c] << 16), r1y = y - __uint_as_float(p0[c] & 0xFFFF0000u);
+          p1[c] = pkbf2(r1x, r1y);
+          const float r2x = r1x - __uint_as_float(p1[c] << 16), r2y = r1y - __uint_as_float(p1[c] & 0xFFFF0000u);
+          p2[c] = pkbf2(r2x, r2y);
+        }
+        char* d = ldsc3 + (tid + 256 * j) * 16;
+        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
+        *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
+        *(u4v*)(d + 2 * K::IMG_PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j)
+      if (j + 1 < K::NWJ || tid + 256 * j < K::W_BYTES / 16) *(f4*)(ldsc3 + K::W_OFF + (tid + 256 * j) * 16) = wr[j];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = 8;
+  fetch(0);
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 5; ++kg) {
+      bf8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8*)(ldsc3 + aA[i] + (kg * 3 + p) * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8*)(ldsc3 + bB[j] + tapoff[kg] + p * K::IMG_PLANE);
+      }
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+  const float* bias = (const float*)(ldsc3 + K::BIAS_OFF);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = wc * 64 + j * 32 + l31;
+    const int s = c / 49, pix = c % 49;
+    if (c >= K::SPT * 49 || b0 + s >= n) continue;
+    float* base = out + e * out_es + (int64_t)b0 * FLAT;
+    const uint32_t lb = (uint32_t)((s * FLAT + pix + hi * (4 * 49)) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = i * 32 + acc_row(r, hi);
+        st1_so(base + (i * 32 + acc_row(r, 0)) * 49, lb, leaky_f(acc[i][j][r] + bias[oc]));
+      }
+  }
+}
+static void launch_fwd3_bf16x6(const EncCall& c, hipStream_t st) {
+  using K = Fwd3B;
+  const Workspace& w = *c.ws;
+  const ParamLayout& L = *c.L;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd3_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL(conv_fwd3_bf16x6_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a2,
+                     c.max_batch * 5184, w.wp3b, c.params, L.enc_base[0] + L.enc.c3b, L.enc_base[L.NE - 1] + L.enc.c3b, w.a3, c.max_batch * FLAT,
+                     c.n);
+}
+
+// ================================================================================================
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -974,6 +1130,11 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   {
     ConvFwd3v2<2>::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
+#ifndef DDRL_FWD3_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD3_F32 keeps the fp32-MFMA kernel
+    if (!acting) {
+      launch_fwd3_bf16x6(c, st);
+    } else
+#endif
     if (narrow(49)) {
       ConvFwd3v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
       launch_engine2<ConvFwd3v2<1>>(dim3((unsigned)(((int64_t)n * 49 + 127) / 128), 1, (unsigned)c.L->NE), q, st);

@@ -423,6 +423,30 @@ def test_conv2_forward_is_at_least_fp32_accurate(hp):
         print(pre, "conv2 fwd err", err_kernel, "torch f32", err_f32, "units of mass", err_kernel / (2.0 ** -24 * mass))
 
 
+def test_conv3_forward_is_at_least_fp32_accurate(hp):
+    """Same statement for conv3's training-launch forward (conv_fwd3_bf16x6_kernel: a2 staged channel-innermost, one
+    MFMA k-group = two taps x eight channels, the tenth tap padded with zero weights)."""
+    n = 101  # 21 tiles of 5 samples, the last one holds a single sample
+    rng = np.random.default_rng(35)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    old = np.full(n, -1.79, dtype=np.float32)
+    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    w = make_weights(0)
+    hp.set_params(flatten(w))
+    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        a2 = hp.debug_buffer(1, (64, 9, 9), n, enc).cpu()
+        a3 = hp.debug_buffer(2, (64, 7, 7), n, enc).cpu().numpy().astype(np.float64)
+        W, b = torch.from_numpy(w[pre + ".conv3.weight"]), torch.from_numpy(w[pre + ".conv3.bias"])
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(a2.double(), W.double(), b.double()), 0.01).numpy()
+        f32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(a2, W, b), 0.01).numpy().astype(np.float64)
+        err_kernel, err_f32 = np.abs(a3 - ref).max(), np.abs(f32 - ref).max()
+        mass = float(torch.nn.functional.conv2d(a2.double().abs(), W.double().abs()).max())
+        assert err_kernel <= 16 * 2.0 ** -24 * mass, (pre, err_kernel, err_f32, mass)
+        assert np.abs(a3 - ref).mean() <= 1.5 * np.abs(f32 - ref).mean() + 1e-12, (pre, np.abs(a3 - ref).mean(), np.abs(f32 - ref).mean())
+
+
 def _adopt_kernel_decisions(h, net, n, x):
     """Leaky-ReLU decision boundaries.  A pre-activation within fp32 noise of zero can come out on either side
     depending on the summation order (the conv1 forward is a bf16x3 kernel whose output is CLOSER to float64 than
