@@ -407,8 +407,8 @@ def main():
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
             "dtype_note": "fp32 accumulation everywhere; the GEMM kernels use the f32-input MFMA except conv1's forward and weight "
-                          "gradient (exact-bf16 pixels 0..255 x three bf16 planes of the other fp32 operand) and the dense layer's "
-                          "forward (three bf16 planes of both operands, six products), which run on the bf16 MFMA with errors against "
+                          "gradient (exact-bf16 pixels 0..255 x three bf16 planes of the other fp32 operand) and the training-launch "
+                          "forwards of conv2, conv3 and the dense layer (three bf16 planes of both operands, six products), which run on the bf16 MFMA with errors against "
                           "float64 no larger than an fp32 chain's; their 'tflops' is fp32-equivalent work",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
                              "(*.act, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
