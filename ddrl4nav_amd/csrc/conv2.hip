@@ -1307,11 +1307,168 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 #endif
 }
 
+// ================================================================================================
+// conv2 data gradient as bf16x6 (see conv_fwd2_bf16x6_kernel / conv_fwd3_bf16x6_kernel):
+//   da1[b][ic][2p+a][2q+c] = sum_{oc,u,v} dz2[b][oc][p-u][q-v] W2[oc][ic][2u+a][2v+c]
+// A workgroup owns one row parity a, both column parities c (rows = (c, ic) = 64) and 5 whole samples
+// (cols = (sample, p, q) = 500, wave w = columns 128 w .. 128 w + 127, 2 x 4 fragment tiles per wave).  dz2 is staged
+// channel-innermost into zero-bordered 11 x 11 images ([plane][sample][pixel][8 oc] bf16, 16 B per pixel): one MFMA
+// k-group = (u; v = lane half) x 8 oc, a k-block = 8 oc = 2 k-groups, 8 k-blocks.  One LDS stage; the border stays
+// zero because only interior pixels are ever written.  Weights: wd2b[e][a][k-block 8][u 2][plane 3][row 64][v 2][oc 8].
+// The output is the raw d(loss)/d(a1) as in ConvDgrad2v2 (the leaky mask is applied by its only consumer).
+// (A first version with 5-wave workgroups of 3 samples kept only ONE workgroup resident per CU -- SQ_WAVE_CYCLES -- and
+// ran at 6.7 ms.)
+// ================================================================================================
+struct Dgrad2B {
+  static constexpr int SPT = 5, THREADS = 256, TN = 4;
+  static constexpr int IMG_PLANE = SPT * 121 * 16;                // 9,680 B
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 2 * 3 * 64 * 32;  // 29,040 + 12,288
+  static constexpr int NIU = SPT * 81, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 405 -> 2 per thread
+  static constexpr int NWQ = W_BYTES / 16, NWJ = NWQ / THREADS;              // 768 weight quads -> 3 per thread
+  static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad2_bf16x6_kernel(const float* __restrict__ dz2, int64_t dz_es, const unsigned short* __restrict__ wd2b,
+                                                                 float* __restrict__ out, int64_t out_es, int n) {
+  using K = Dgrad2B;
+  extern __shared__ __attribute__((aligned(16))) char ldsd2[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  // The two row parities of one tile write interleaved rows of the same cache lines: workgroup ids are dealt round-robin
+  // to the 8 XCDs, so ids g and g + 8 are consecutive on ONE XCD -- they get the same tile, a = 0 and a = 1, run at the same
+  // time and their half-line stores merge in that XCD's L2 (with a in blockIdx.z they ran a whole launch apart: +7 %).
+  const int e = blockIdx.y, a = (blockIdx.x >> 3) & 1, tile = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+  const int b0 = tile * K::SPT;
+  if (b0 >= n) return;  // padding of the tile count to a multiple of 8 (whole workgroup, before any barrier)
+  for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd2 + i * 16) = zero4();  // images incl. their zero borders
+  // ---- staging maps.  unit u = tid + 256 j: sample u / 81, pixel u % 81 -> 8 loads of stride 81 (the k-block's 8 oc)
+  const float* isrc[K::NIJ];
+  int idst[K::NIJ];
+#pragma unroll
+  for (int j = 0; j < K::NIJ; ++j) {
+    const int u = min(tid + K::THREADS * j, K::NIU - 1);
+    const int s = u / 81, px = u % 81;
+    isrc[j] = dz2 + e * dz_es + (int64_t)min(b0 + s, n - 1) * 5184 + px;  // + (8 kb + c) * 81
+    idst[j] = (s * 121 + (px / 9 + 1) * 11 + px % 9 + 1) * 16;
+  }
+  const unsigned short* wsrc = wd2b + (int64_t)(e * 2 + a) * (8 * 2 * 3 * 64 * 16) + tid * 8;  // + kb * 6144 + j * 2048
+  // ---- operand bases
+  int aA[2], bB[K::TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
+#pragma unroll
+  for (int j = 0; j < K::TN; ++j) {
+    int c = wc * (32 * K::TN) + j * 32 + l31;
+    if (c >= K::SPT * 100) c = 0;
+    const int s = c / 100, pq = c % 100;
+    bB[j] = (s * 121 + (pq / 10 + 1) * 11 + (pq % 10 + 1) - hi) * 16;  // pixel (p, q - v) of the padded image, v = lane half
+  }
+  float ir[K::NIJ][8];
+  f4 wr[K::NWJ];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 81];
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * 6144 + j * 2048);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j) {
+      if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = ir[j][2 * c], y = ir[j][2 * c + 1];
+          p0[c] = pkbf2(x, y);
+          const float r1x = x - __uint_as_float(p0[c] << 16), r1y = y - __uint_as_float(p0[c] & 0xFFFF0000u);
+          p1[c] = pkbf2(r1x, r1y);
+          const float r2x = r1x - __uint_as_float(p1[c] << 16), r2y = r1y - __uint_as_float(p1[c] & 0xFFFF0000u);
+          p2[c] = pkbf2(r2x, r2y);
+        }
+        char* d = ldsd2 + idst[j];
+        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
+        *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
+        *(u4v*)(d + 2 * K::IMG_PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j) *(f4*)(ldsd2 + K::W_OFF + (tid + K::THREADS * j) * 16) = wr[j];
+  };
+  f32x16 acc[2][K::TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < K::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = 8;
+  fetch(0);
+  __syncthreads();  // zero fill complete
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {  // kg = u
+      bf8 af[3][2], bfr[3][K::TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[p][i] = *(const bf8*)(ldsd2 + aA[i] + (kg * 3 + p) * 2048);
+#pragma unroll
+        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const bf8*)(ldsd2 + bB[j] + p * K::IMG_PLANE - kg * (11 * 16));
+      }
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < K::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bfr[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+  // rows i = column parity c: the two classes of one (p, q) are horizontally adjacent pixels -> one 8-byte store
+#pragma unroll
+  for (int j = 0; j < K::TN; ++j) {
+    const int c = wc * (32 * K::TN) + j * 32 + l31;
+    const int s = c / 100, pq = c % 100;
+    if (c >= K::SPT * 100 || b0 + s >= n) continue;
+    float* base = out + e * out_es + (int64_t)(b0 + s) * 12800 + (2 * (pq / 10) + a) * 20 + 2 * (pq % 10);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *(float2*)(base + acc_row(r, hi) * 400) = make_float2(acc[0][j][r], acc[1][j][r]);
+  }
+}
+static void launch_dgrad2_bf16x6(const EncCall& c, hipStream_t st) {
+  using K = Dgrad2B;
+  const Workspace& w = *c.ws;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)conv_dgrad2_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  const unsigned tiles8 = (unsigned)(((c.n + K::SPT - 1) / K::SPT + 7) / 8 * 8);
+  hipLaunchKernelGGL(conv_dgrad2_bf16x6_kernel, dim3(tiles8 * 2, (unsigned)c.L->NE, 1), dim3(K::THREADS),
+                     K::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.dz1, c.max_batch * 12800, c.n);
+}
+
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   ConvDgrad2v2::Params p{w.dz2, MB * 5184, w.wd2p, w.a1, w.dz1, MB * 12800, c.n};
   ProfRange pr(c.prof, "ConvDgrad2", st);
+#ifndef DDRL_DGRAD2_F32  // default: the bf16x6 kernel; -DDDRL_DGRAD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+  launch_dgrad2_bf16x6(c, st);
+  (void)p;
+  return;
+#endif
   launch_engine2<ConvDgrad2v2>(dim3((unsigned)(((int64_t)c.n * 100 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
 }
 

@@ -157,7 +157,28 @@ __global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __res
   d[2 * 64 * 16] = p2;
 }
 
+// conv2 weights for the bf16x6 data gradient: wd2b[e][a][kb 8][u 2][plane][row = c * 32 + ic][v][o]
+//   = W2[oc = 8 kb + o][ic][2 u + a][2 v + c]
+__global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+  const int e = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (a, kb, u, row, v, o)
+  if (i >= 2 * 8 * 2 * 64 * 16) return;
+  const int o = i & 7, v = (i >> 3) & 1, row = (i >> 4) & 63, u = (i >> 10) & 1, kb = (i >> 11) & 7, a = i >> 14;
+  const int c = row >> 5, ic = row & 31, oc = 8 * kb + o;
+  const float w = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + (2 * u + a) * 4 + 2 * v + c];
+  const unsigned short p0 = bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
+  const unsigned short p1 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = bf16_rne(r2);
+  unsigned short* d = dst + (((((int64_t)(e * 2 + a) * 8 + kb) * 2 + u) * 3) * 64 + row) * 16 + v * 8 + o;
+  d[0] = p0;
+  d[64 * 16] = p1;
+  d[2 * 64 * 16] = p2;
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b);
   hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b);
   hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb);
