@@ -80,6 +80,8 @@ struct Workspace {
   unsigned short* wp3b;
   // conv2 weights for the data gradient as three bf16 planes [e][row parity 2][k-block 8][u 2][plane 3][(c, ic) 64][v 2][oc 8]
   unsigned short* wd2b;
+  // conv3 weights for the data gradient as three bf16 planes [e][k-block 8][tap pair 5][plane 3][ic 64][tap parity 2][oc 8]
+  unsigned short* wd3b;
   // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_bf16x6_kernel)
   unsigned short* wlb;
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
@@ -136,6 +138,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);
+  w.wd3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wp2 = take(2 * 16 * 16 * 2 * 64);
   w.wp3 = take(2 * 16 * 18 * 2 * 64);
   w.wd3p = take(2 * 16 * 18 * 2 * 64);

@@ -1279,11 +1279,177 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
   }
 }
 
+// ================================================================================================
+// conv3 data gradient as bf16x6, gather form (see conv_fwd3_bf16x6_kernel, whose mirror image it is):
+//   dz2[b][ic][y][x] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][y-ky][x-kx] W3[oc][ic][ky][kx]
+// dz3 is staged channel-innermost into zero-bordered 11 x 11 images (data at +2, +2; [plane][sample][pixel][8 oc] bf16),
+// one MFMA k-group = (two taps) x 8 oc, the tenth tap padded with zero weights; tile = 64 ic x 6 whole samples (486
+// columns, wave w = columns 128 w .., 2 x 4 fragment tiles), k-block = 8 oc = 5 k-groups, 8 k-blocks, one LDS stage.
+// It walks all 81 x 9 tap products of which 49 x 9 are non-zero (the scatter form, conv_dgrad3_scatter_kernel, does
+// not) and still wins: 192 instead of 512 matrix-pipe cycles per 16 k.
+// Weights: wd3b[e][k-block 8][tap pair 5][plane 3][ic 64][tap parity 2][oc 8] (optim.hip).
+// ================================================================================================
+struct Dgrad3B {
+  static constexpr int SPT = 6, THREADS = 256, TN = 4;
+  static constexpr int IMG_PLANE = SPT * 121 * 16;                // 11,616 B
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 34,848 + 30,720
+  static constexpr int NIU = SPT * 49, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 294 -> 2 per thread
+  static constexpr int NWQ = W_BYTES / 16, NWJ = (NWQ + THREADS - 1) / THREADS;  // 1,920 weight quads -> 8 per thread (last partial)
+  static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad3_bf16x6_kernel(
+    const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3b, const float* __restrict__ a2, float* __restrict__ out,
+    int64_t out_es, int n) {
+  using K = Dgrad3B;
+  extern __shared__ __attribute__((aligned(16))) char ldsd3[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
+  for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd3 + i * 16) = zero4();  // images incl. their zero borders
+  // ---- staging maps.  unit u = tid + 256 j: sample u / 49, pixel u % 49 -> 8 loads of stride 49 (the k-block's 8 oc)
+  const float* isrc[K::NIJ];
+  int idst[K::NIJ];
+#pragma unroll
+  for (int j = 0; j < K::NIJ; ++j) {
+    const int u = min(tid + K::THREADS * j, K::NIU - 1);
+    const int s = u / 49, px = u % 49;
+    isrc[j] = dz3 + e * dz_es + (int64_t)min(b0 + s, n - 1) * FLAT + px;  // + (8 kb + c) * 49
+    idst[j] = (s * 121 + (px / 7 + 2) * 11 + px % 7 + 2) * 16;
+  }
+  const unsigned short* wsrc = wd3b + (int64_t)e * (8 * 5 * 3 * 64 * 16) + tid * 8;  // + kb * 15360 + j * 2048
+  // ---- operand bases
+  int aA[2], bB[K::TN], tapoff[5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
+#pragma unroll
+  for (int j = 0; j < K::TN; ++j) {
+    int c = wc * (32 * K::TN) + j * 32 + l31;
+    if (c >= K::SPT * 81) c = 0;
+    const int s = c / 81, pix = c % 81;
+    bB[j] = (s * 121 + (pix / 9 + 2) * 11 + pix % 9 + 2) * 16;
+  }
+#pragma unroll
+  for (int kg = 0; kg < 5; ++kg) {
+    const int tap = min(2 * kg + hi, 8);
+    tapoff[kg] = ((tap / 3) * 11 + tap % 3) * 16;  // subtracted: source pixel (y - ky, x - kx)
+  }
+  float ir[K::NIJ][8];
+  f4 wr[K::NWJ];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 49];
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j)
+      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * 15360 + j * 2048);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < K::NIJ; ++j) {
+      if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = ir[j][2 * c], y = ir[j][2 * c + 1];
+          p0[c] = pkbf2(x, y);
+          const float r1x = x - __uint_as_float(p0[c] << 16), r1y = y - __uint_as_float(p0[c] & 0xFFFF0000u);
+          p1[c] = pkbf2(r1x, r1y);
+          const float r2x = r1x - __uint_as_float(p1[c] << 16), r2y = r1y - __uint_as_float(p1[c] & 0xFFFF0000u);
+          p2[c] = pkbf2(r2x, r2y);
+        }
+        char* d = ldsd3 + idst[j];
+        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
+        *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
+        *(u4v*)(d + 2 * K::IMG_PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j)
+      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) *(f4*)(ldsd3 + K::W_OFF + (tid + K::THREADS * j) * 16) = wr[j];
+  };
+  f32x16 acc[2][K::TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < K::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = 8;
+  fetch(0);
+  __syncthreads();  // zero fill complete
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 5; ++kg) {
+      bf8 af[3][2], bfr[3][K::TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[p][i] = *(const bf8*)(ldsd3 + aA[i] + (kg * 3 + p) * 2048);
+#pragma unroll
+        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const bf8*)(ldsd3 + bB[j] - tapoff[kg] + p * K::IMG_PLANE);
+      }
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < K::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bfr[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+  // dz2 = leaky'(a2) * sum; a2 is read here, one column tile (32 values per lane) at a time
+#pragma unroll
+  for (int j = 0; j < K::TN; ++j) {
+    const int c = wc * (32 * K::TN) + j * 32 + l31;
+    const int s = c / 81, pix = c % 81;
+    if (c >= K::SPT * 81 || b0 + s >= n) continue;
+    const int64_t off = (int64_t)(b0 + s) * 5184 + pix + hi * (4 * 81);
+    const float* ap = a2 + e * out_es + off;
+    float* op = out + e * out_es + off;
+    float av[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) av[i][r] = ap[(i * 32 + acc_row(r, 0)) * 81];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[(i * 32 + acc_row(r, 0)) * 81] = leaky_g(av[i][r], acc[i][j][r]);
+  }
+}
+static void launch_dgrad3_bf16x6(const EncCall& c, hipStream_t st) {
+  using K = Dgrad3B;
+  const Workspace& w = *c.ws;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)conv_dgrad3_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL(conv_dgrad3_bf16x6_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)c.L->NE), dim3(K::THREADS), K::LDS_BYTES, st,
+                     w.dz3, c.max_batch * FLAT, w.wd3b, w.a2, w.dz2, c.max_batch * 5184, c.n);
+}
+
 void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   ProfRange pr(c.prof, "ConvDgrad3", st);
-#ifdef DDRL_DGRAD3_GATHER  // the gather form (A/B switch)
+#if !defined(DDRL_DGRAD3_GATHER) && !defined(DDRL_DGRAD3_SCATTER)  // default: the bf16x6 gather kernel
+  launch_dgrad3_bf16x6(c, st);
+  (void)MB;
+  return;
+#endif
+#ifdef DDRL_DGRAD3_GATHER  // the fp32-MFMA gather form (A/B switch); -DDDRL_DGRAD3_SCATTER: the fp32-MFMA scatter form
   ConvDgrad3v2::Params p{w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n};
   launch_engine2<ConvDgrad3v2>(dim3((unsigned)(((int64_t)c.n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
 #else

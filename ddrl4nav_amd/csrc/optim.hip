@@ -177,7 +177,27 @@ __global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __re
   d[2 * 64 * 16] = p2;
 }
 
+// conv3 weights for the bf16x6 data gradient: wd3b[e][kb][tap pair][plane][ic][tap parity][o] = W3[oc = 8 kb + o][ic][tap]
+__global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+  const int e = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, kg, ic, h, o)
+  if (i >= 8 * 5 * 64 * 16) return;
+  const int o = i & 7, h = (i >> 3) & 1, ic = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
+  const int tap = 2 * kg + h;
+  const float w = tap < 9 ? params[L.enc_base[e] + L.enc.c3w + ((8 * kb + o) * 64 + ic) * 9 + tap] : 0.0f;
+  const unsigned short p0 = bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
+  const unsigned short p1 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+  const unsigned short p2 = bf16_rne(r2);
+  unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * 3) * 64 + ic) * 16 + h * 8 + o;
+  d[0] = p0;
+  d[64 * 16] = p1;
+  d[2 * 64 * 16] = p2;
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b);
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b);
   hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b);
