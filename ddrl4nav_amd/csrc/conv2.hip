@@ -936,8 +936,12 @@ static void launch_fwd2_bf16x6(const EncCall& c, hipStream_t st) {
 // whole samples (245 columns in 8 column tiles), k-block = 8 input channels = 5 k-groups; one LDS stage, the next
 // k-block waits in registers.  Weights: wp3b[e][k-block 8][k-group 5][plane 3][oc 64][h 2][8 channels] (optim.hip).
 // ================================================================================================
+#ifndef DDRL_F3B_TN
+#define DDRL_F3B_TN 2
+#endif
 struct Fwd3B {
-  static constexpr int SPT = 5, NPX = SPT * 81;                   // staged pixels per k-block
+  // column tiles per wave (2 x 4 fragment tiles = 10 samples per tile measured 3.00 vs 2.70 ms: not a general win); whole samples per tile
+  static constexpr int TN = DDRL_F3B_TN, SPT = (128 * TN) / 49, NPX = SPT * 81;
   static constexpr int IMG_PLANE = NPX * 16;                      // 6,480 B
   static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 19,440 + 30,720
   static constexpr int BIAS_OFF = W_OFF + W_BYTES;
@@ -946,7 +950,7 @@ struct Fwd3B {
   static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
 };
 
-__global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_fwd3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
                                                                const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
                                                                float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd3B;
@@ -965,12 +969,12 @@ __global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __re
   }
   const unsigned short* wsrc = wp3b + (int64_t)e * (8 * 5 * 3 * 64 * 16) + tid * 8;  // + kb * 15360 + j * 2048
   // ---- operand bases
-  int aA[2], bB[2], tapoff[5];
+  int aA[2], bB[K::TN], tapoff[5];
 #pragma unroll
   for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int c = wc * 64 + j * 32 + l31;
+  for (int j = 0; j < K::TN; ++j) {
+    int c = wc * (32 * K::TN) + j * 32 + l31;
     if (c >= K::SPT * 49) c = 0;
     const int s = c / 49, pix = c % 49;
     bB[j] = (s * 81 + (pix / 7) * 9 + pix % 7) * 16;
@@ -1015,11 +1019,11 @@ __global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __re
     for (int j = 0; j < K::NWJ; ++j)
       if (j + 1 < K::NWJ || tid + 256 * j < K::W_BYTES / 16) *(f4*)(ldsc3 + K::W_OFF + (tid + 256 * j) * 16) = wr[j];
   };
-  f32x16 acc[2][2];
+  f32x16 acc[2][K::TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < K::TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   constexpr int NKB = 8;
@@ -1030,13 +1034,13 @@ __global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __re
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < 5; ++kg) {
-      bf8 a[3][2], b[3][2];
+      bf8 a[3][2], b[3][K::TN];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8*)(ldsc3 + aA[i] + (kg * 3 + p) * 2048);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8*)(ldsc3 + bB[j] + tapoff[kg] + p * K::IMG_PLANE);
+        for (int j = 0; j < K::TN; ++j) b[p][j] = *(const bf8*)(ldsc3 + bB[j] + tapoff[kg] + p * K::IMG_PLANE);
       }
       constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
 #pragma unroll
@@ -1044,7 +1048,7 @@ __global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < K::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -1055,8 +1059,8 @@ __global__ __launch_bounds__(256) void conv_fwd3_bf16x6_kernel(const float* __re
   }
   const float* bias = (const float*)(ldsc3 + K::BIAS_OFF);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = wc * 64 + j * 32 + l31;
+  for (int j = 0; j < K::TN; ++j) {
+    const int c = wc * (32 * K::TN) + j * 32 + l31;
     const int s = c / 49, pix = c % 49;
     if (c >= K::SPT * 49 || b0 + s >= n) continue;
     float* base = out + e * out_es + (int64_t)b0 * FLAT;
@@ -1283,17 +1287,21 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
 // conv3 data gradient as bf16x6, gather form (see conv_fwd3_bf16x6_kernel, whose mirror image it is):
 //   dz2[b][ic][y][x] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][y-ky][x-kx] W3[oc][ic][ky][kx]
 // dz3 is staged channel-innermost into zero-bordered 11 x 11 images (data at +2, +2; [plane][sample][pixel][8 oc] bf16),
-// one MFMA k-group = (two taps) x 8 oc, the tenth tap padded with zero weights; tile = 64 ic x 6 whole samples (486
-// columns, wave w = columns 128 w .., 2 x 4 fragment tiles), k-block = 8 oc = 5 k-groups, 8 k-blocks, one LDS stage.
+// one MFMA k-group = (two taps) x 8 oc, the tenth tap padded with zero weights; tile = 64 ic x 3 whole samples (243
+// columns, wave w = columns 64 w .., 2 x 2 fragment tiles), k-block = 8 oc = 5 k-groups, 8 k-blocks, one LDS stage.
+// (Requesting the a2 values of the mask before the last k-block instead of in the epilogue: no gain, 4.37 vs 4.33 ms.)
 // It walks all 81 x 9 tap products of which 49 x 9 are non-zero (the scatter form, conv_dgrad3_scatter_kernel, does
 // not) and still wins: 192 instead of 512 matrix-pipe cycles per 16 k.
 // Weights: wd3b[e][k-block 8][tap pair 5][plane 3][ic 64][tap parity 2][oc 8] (optim.hip).
 // ================================================================================================
+#ifndef DDRL_D3B_TN
+#define DDRL_D3B_TN 2  // 2 x 2 fragment tiles, 3 samples per tile: 4.19 vs 4.27 ms for 2 x 4 / 6 samples
+#endif
 struct Dgrad3B {
-  static constexpr int SPT = 6, THREADS = 256, TN = 4;
-  static constexpr int IMG_PLANE = SPT * 121 * 16;                // 11,616 B
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 34,848 + 30,720
-  static constexpr int NIU = SPT * 49, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 294 -> 2 per thread
+  static constexpr int THREADS = 256, TN = DDRL_D3B_TN, SPT = (128 * TN) / 81;  // column tiles per wave, whole samples per tile
+  static constexpr int IMG_PLANE = SPT * 121 * 16;                // 5,808 B
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 17,424 + 30,720
+  static constexpr int NIU = SPT * 49, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 147 -> 1 per thread
   static constexpr int NWQ = W_BYTES / 16, NWJ = (NWQ + THREADS - 1) / THREADS;  // 1,920 weight quads -> 8 per thread (last partial)
   static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
 };
