@@ -84,6 +84,8 @@ struct Workspace {
   unsigned short* wd3b;
   // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_bf16x6_kernel)
   unsigned short* wlb;
+  // the same planes transposed, [e][plane 3][3136][512] (fc2.hip fc_dgrad_bf16x6_kernel)
+  unsigned short* wdlb;
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
@@ -135,6 +137,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp1 = take(4 * 32 * 2 * 64);
   w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
+  w.wdlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);

@@ -525,6 +525,122 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), p, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense-layer data gradient as bf16x6 (same structure as fc_fwd_bf16x6_kernel with the roles K = 512 features,
+// N = 3,136 conv3 outputs):  dz3[b][k] = leaky'(a3[b][k]) * sum_n dh[b][n] Wl[n][k].
+// dh is split into three bf16 planes while it is staged, the weights come pre-split and transposed from optim.hip
+// (wdlb[e][plane][k 3136][n 512]); 128 x 128 tile, k-block 32 = 2 MFMA k-groups, one LDS stage.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fc_dgrad_bf16x6_kernel(const float* __restrict__ dh, int64_t dh_es, const unsigned short* __restrict__ wdlb,
+                                                              const float* __restrict__ a3, float* __restrict__ dz3, int64_t a3_es, int n) {
+  using K = FcFwdB;
+  extern __shared__ __attribute__((aligned(16))) char ldsg[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int e = blockIdx.z, k0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+  // staging maps: dh = 4 quads of 4 n per thread (row rr + 32 j, n4), weights = 2 x 3 fragments of 8 n (column cc + 64 j)
+  const int n4 = tid & 7, rr = tid >> 3;
+  const float* asrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asrc[j] = dh + e * dh_es + (int64_t)min(b0 + rr + 32 * j, n - 1) * FEAT + n4 * 4;
+  const int n8 = tid & 3, cc = tid >> 2;
+  const unsigned short* wsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wsrc[j] = wdlb + (int64_t)e * 3 * FLAT * FEAT + (int64_t)min(k0 + cc + 64 * j, FLAT - 1) * FEAT + n8 * 8;
+  int aA[2], bB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = (wr * 64 + i * 32 + l31) * K::PITCH + hi * 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (wc * 64 + j * 32 + l31) * K::PITCH + hi * 16;
+  f4 ar[4], wrg[2][3];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ar[j] = ld4(asrc[j] + kb * 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wrg[j][p] = *(const f4*)(wsrc[j] + (int64_t)p * FLAT * FEAT + kb * 32);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f4 v = ar[j];
+      const unsigned p0a = pkbf(v.x, v.y), p0b = pkbf(v.z, v.w);
+      const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
+      const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
+      const unsigned p1a = pkbf(r1x, r1y), p1b = pkbf(r1z, r1w);
+      const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
+      const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
+      const unsigned p2a = pkbf(r2x, r2y), p2b = pkbf(r2z, r2w);
+      char* d = ldsg + (rr + 32 * j) * K::PITCH + n4 * 8;
+      *(uint2*)(d) = make_uint2(p0a, p0b);
+      *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
+      *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *(f4*)(ldsg + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + n8 * 16) = wrg[j][p];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = FEAT / 32;
+  fetch(0);
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      bf8f a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8f*)(ldsg + aA[i] + p * K::PLANE + kg * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8f*)(ldsg + bB[j] + p * K::PLANE + kg * 32);
+      }
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = k0 + wc * 64 + j * 32 + l31;
+    if (k >= FLAT) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float av[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int b = min(b0 + wr * 64 + i * 32 + acc_row(r, hi), n - 1);
+        av[r] = a3[e * a3_es + (int64_t)b * FLAT + k];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
+        if (b < n) dz3[e * a3_es + (int64_t)b * FLAT + k] = leaky_g(av[r], acc[i][j][r]);
+      }
+    }
+  }
+}
+
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -542,6 +658,17 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
   {
     FcDgrad2::Params p{w.dh, MB * FEAT, w.wln, w.a3, w.dz3, MB * FLAT, c.n};
     ProfRange pr(c.prof, "FcDgrad", st);
+#ifndef DDRL_FCDGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCDGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)fc_dgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
+      configured = true;
+    }
+    hipLaunchKernelGGL(fc_dgrad_bf16x6_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcFwdB::LDS_BYTES, st, w.dh, MB * FEAT,
+                       w.wdlb, w.a3, w.dz3, MB * FLAT, c.n);
+    (void)p;
+    return;
+#endif
     launch_engine2<FcDgrad2>(dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), p, st);
   }
 }

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
 }
 
 // dense-layer weights as three bf16 planes (see pack_conv1_bf16_kernel): wlb[e][plane][n][k]
-__global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
+                                                           unsigned short* __restrict__ dst_t) {
   const int e = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)FLAT * FEAT) return;
@@ -118,6 +119,12 @@ __global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restri
   d[0] = p0;
   d[(int64_t)FLAT * FEAT] = p1;
   d[2 * (int64_t)FLAT * FEAT] = p2;
+  // transposed copy [plane][k][n] for the data gradient
+  const int nn = (int)(i / FLAT), kk = (int)(i % FLAT);
+  unsigned short* t = dst_t + (int64_t)e * 3 * FLAT * FEAT + (int64_t)kk * FEAT + nn;
+  t[0] = p0;
+  t[(int64_t)FLAT * FEAT] = p1;
+  t[2 * (int64_t)FLAT * FEAT] = p2;
 }
 
 // conv2 weights as three bf16 planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
@@ -201,7 +208,7 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b);
   hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b);
-  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb);
+  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb);
   hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b);
   {
     const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);

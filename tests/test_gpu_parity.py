@@ -560,7 +560,11 @@ def _views(flat, shared):
     return out
 
 
-def _sequence_check(h, ref, spread, frames, actions, old_logps, advs, rets, fixture, lr_of, shared, bad_frac=0.02):
+def _sequence_check(h, ref, spread, frames, actions, old_logps, advs, rets, fixture, lr_of, shared, bad_frac=0.02, self_drift=None):
+    """self_drift: optional fixture with pbad/it<k>/<name> = the fraction of a tensor's strided sample by which the
+    REFERENCE differs from itself (same criterion) when only its batch order changes; twice that fraction is allowed
+    where it exceeds bad_frac (a batch permutation re-rounds only the batch reductions, a different kernel re-rounds
+    every sum, so it moves more of the elements whose gradient sits at the fp32 noise floor)."""
     envelope = np.maximum.accumulate(spread, axis=0)
     for it in range(1, 11):
         h.ppo_iter(frames, actions, old_logps, advs, rets)
@@ -577,7 +581,10 @@ def _sequence_check(h, ref, spread, frames, actions, old_logps, advs, rets, fixt
                 want = fixture["it%d/stride/%s" % (it, name)]
                 gotp = arr[::max(1, arr.size // 257)][:257]
                 bad = np.abs(gotp - want) > 0.05 * lr * it + 1e-6 * np.abs(want)
-                assert bad.sum() <= max(1, bad_frac * bad.size), (name, it, bad.sum(), np.abs(gotp - want).max())
+                allowed = bad_frac
+                if self_drift is not None and "pbad/it%d/%s" % (it, name) in self_drift.files:
+                    allowed = max(allowed, 2.0 * float(self_drift["pbad/it%d/%s" % (it, name)]))
+                assert bad.sum() <= max(1, allowed * bad.size), (name, it, bad.sum(), np.abs(gotp - want).max())
                 assert np.abs(gotp - want).max() <= 2.5 * lr * it
 
 
@@ -695,12 +702,13 @@ def test_smooth_l1_value_loss_f11(golden):
     # what "the same computation" means for this sequence: the reference itself in float64, and the reference in
     # fp32 with the batch in three other orders (same mathematics -- full-batch means --, other summation order;
     # tests/golden/make_golden_reorder.py).  The permuted runs drift 3.5 x further by iteration 10 than the f64 one.
-    spread = np.maximum(np.abs(ref - g["losses_f64"]), np.abs(golden("f11b_smooth_l1_reorder")["losses_perm"] - ref[None]).max(axis=0))
+    gb = golden("f11b_smooth_l1_reorder")
+    spread = np.maximum(np.abs(ref - g["losses_f64"]), np.abs(gb["losses_perm"] - ref[None]).max(axis=0))
     lr_of = lambda name: 5e-5 if name.startswith("actor.") else 1e-3
     # the smooth-L1 gradient is +-1/B for every |ret - v| > 1: many critic-side weight gradients sit
     # at the fp32 noise floor, where Adam moves an element by O(lr) either way (same effect as in
     # test_learn_sequence_golden_f4, more elements) -> larger allowance for the strided samples
-    _sequence_check(h, ref, spread, *args, g, lr_of, False, bad_frac=0.10)
+    _sequence_check(h, ref, spread, *args, g, lr_of, False, bad_frac=0.10, self_drift=gb)
     h.close()
 
 
