@@ -408,7 +408,7 @@ def main():
             "roofline": roofline, "kernels": kernels,
             "dtype_note": "fp32 accumulation everywhere; the GEMM kernels use the f32-input MFMA except conv1's forward and weight "
                           "gradient (exact-bf16 pixels 0..255 x three bf16 planes of the other fp32 operand) and the training-launch "
-                          "forwards of conv2, conv3 and the dense layer plus the data gradients of conv2 and conv3 (three bf16 planes of "
+                          "forwards and the data gradients of conv2, conv3 and the dense layer (three bf16 planes of "
                           "both operands, six products), which run on the bf16 MFMA with errors against "
                           "float64 no larger than an fp32 chain's; their 'tflops' is fp32-equivalent work",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
