@@ -524,11 +524,13 @@ using u4w = __attribute__((ext_vector_type(4))) unsigned;
 
 template <int NE>
 struct Wgrad1B {
-  static constexpr int ROWS = 32 * NE, PLANE = ROWS * 16, A_BYTES = 2 * 3 * 3 * PLANE, B_OFF = A_BYTES;
-  static constexpr int B_BYTES = 2 * 4 * 8 * 192 + 64, STAGE = A_BYTES + B_BYTES;
+  static constexpr int ROWS = 32 * NE, PLANE = ROWS * 16, A_BYTES = 2 * 3 * 3 * PLANE;
+  // image: a ring of 16 rows (4 groups of 4) per (sample, channel), NOT part of the double-buffered stage: consecutive
+  // k-blocks (output rows) share 4 of their 8 input rows, so only the 4 new ones are loaded, converted and written per block
+  static constexpr int IMG_OFF = 2 * A_BYTES, IMG_BYTES = 2 * 4 * 16 * 192 + 64, STAGE = A_BYTES;
   static constexpr int TPE = 256 / NE, QPE = 2 * 32 * 5, NDZ_J = (QPE + TPE - 1) / TPE;
   static constexpr int64_t SLAB = 32 * 256 + 32;
-  static constexpr size_t LDS_BYTES = 2 * STAGE;
+  static constexpr size_t LDS_BYTES = 2 * A_BYTES + IMG_BYTES;
 };
 
 // two fp32 -> one dword of two bf16 (round to nearest even), and back
@@ -568,22 +570,27 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
     dz_ok |= (idx < K::QPE ? 1u : 0u) << j;
     bacc[j] = 0.0f;
   }
-  // ---- image staging map: unit u = (row R = (sample, ch, r), g): g < 5 = pixels 16 g .. 16 g + 15, g = 5 = 80 .. 83
+  // ---- image staging map: a k-block stages NG new row groups (1; 2 for the first block of a sample pair).
+  // unit u = (R = (group gsel, sample, ch, r), g): g < 5 = pixels 16 g .. 16 g + 15, g = 5 = 80 .. 83; 192 units per group,
+  // i.e. the second group = the k = 1 units of threads 0 .. 127, a lone group = the k = 0 units of waves 0 .. 2
   uint32_t imoff[2];
   int bdst[2];
-  unsigned im_s1 = 0, im_ok = 0, im_tail = 0;
+  unsigned im_s1 = 0, im_g1 = 0, im_ok1 = 0, im_ok2 = 0, im_tail = 0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int u = tid + 256 * k, uc = min(u, 383);
-    const int R = uc / 6, g = uc % 6, smp = R >> 5, ch = (R >> 3) & 3, r = R & 7;
-    imoff[k] = (uint32_t)(smp * 28224 + ch * 7056 + r * 84 + (g < 5 ? g * 16 : 68));  // g = 5: bytes 68..83, the last dword counts
-    bdst[k] = K::B_OFF + R * 192 + (g < 5 ? g * 8 : 40);
+    const int R = uc / 6, g = uc % 6, gsel = R >> 5, smp = (R >> 4) & 1, ch = (R >> 2) & 3, r = R & 3;
+    imoff[k] = (uint32_t)(smp * 28224 + ch * 7056 + (4 * gsel + r) * 84 + (g < 5 ? g * 16 : 68));  // g = 5: bytes 68..83, last dword
+    bdst[k] = K::IMG_OFF + ((smp * 4 + ch) * 16 + r) * 192 + (g < 5 ? g * 8 : 40);              // + ring group * 4 * 192
     im_s1 |= (unsigned)smp << k;
-    im_ok |= (u < 384 ? 1u : 0u) << k;
+    im_g1 |= (unsigned)gsel << k;
+    im_ok1 |= (u < 192 ? 1u : 0u) << k;
+    im_ok2 |= (u < 384 ? 1u : 0u) << k;
     im_tail |= (g == 5 ? 1u : 0u) << k;
   }
+  const bool lone_group_wave = __builtin_amdgcn_readfirstlane(tid) < 192;  // waves 0 .. 2
   // ---- operand lane bases: MFMA m of a k-block, lane half hi -> fragment fi = 2 m + hi = (sample fi / 3, frag fi % 3)
-  int aa[NE][3], bb[2][3], shamt[2];
+  int aa[NE][3], bb[2][3], shamt[2], kyhi[2], kylo[2];
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     const int fi = 2 * m + hi, fs = fi / 3, ff = fi % 3;
@@ -592,20 +599,26 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = wc * 64 + j * 32 + l31, ch = c >> 6, ky = (c >> 3) & 7, kx = c & 7;
-      bb[j][m] = K::B_OFF + ((fs * 4 + ch) * 8 + ky) * 192 + (kx & 3) * 48 + ff * 16;
+      bb[j][m] = K::IMG_OFF + ((fs * 4 + ch) * 16) * 192 + (kx & 3) * 48 + ff * 16;  // + ring row of ky (per block)
       shamt[j] = (kx >> 2) * 16;
+      kyhi[j] = ky >> 2;
+      kylo[j] = ky & 3;
     }
   }
   f4 dzr[K::NDZ_J], actr[K::NDZ_J];
-  u4w imr[2];
-  bool full = true;
+  u4w imr[2] = {(u4w){0u, 0u, 0u, 0u}, (u4w){0u, 0u, 0u, 0u}};
+  bool full = true, imfirst = true;
+  int imam = 0;  // ring group (mod 4) of the first group this fetch stages
   auto fetch = [&](int kb) {
     const int pair = kb / 20, oy = kb % 20;
     full = 2 * pair + 1 < n;
+    imfirst = kb == kb_begin || oy == 0;        // first block of a pair: both of its row groups are new
+    const int gfirst = imfirst ? 0 : 1;
+    imam = (21 * pair + oy + gfirst) & 3;
     const int64_t sb = ew * dz_es + (int64_t)pair * (2 * 12800) + oy * 20;
     const char* dzb = (const char*)(dz + sb);
     const char* acb = (const char*)(act + sb);
-    const char* fp = (const char*)frames + (int64_t)pair * (2 * 28224) + oy * 336;
+    const char* fp = (const char*)frames + (int64_t)pair * (2 * 28224) + (oy + gfirst) * 336;
     // odd batch tail: the second sample does not exist -> its slots read the first sample, commit() zeroes its dz
 #pragma unroll
     for (int j = 0; j < K::NDZ_J; ++j) {
@@ -615,6 +628,8 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
+      // wave-uniform skips: a lone group has no k = 1 units and none in wave 3 (their loads were the cost, not the conversion)
+      if (!imfirst && (k == 1 || !lone_group_wave)) continue;
       const uint32_t o = full ? imoff[k] : imoff[k] - ((im_s1 >> k) & 1u) * 28224u;
       const unsigned* q = (const unsigned*)(fp + o);  // 4-byte aligned
       imr[k] = (u4w){q[0], q[1], q[2], q[3]};
@@ -640,10 +655,11 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
         *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
       }
     }
+    const unsigned im_ok = imfirst ? im_ok2 : im_ok1;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if ((im_ok >> k) & 1u) {
-        char* d = st + bdst[k];
+        char* d = ldsw + bdst[k] + ((imam + (int)((im_g1 >> k) & 1u)) & 3) * (4 * 192);
         if (!((im_tail >> k) & 1u)) {
           // 16 pixels x0 .. x0+15: plane q gets pixels x0+q, +4, +8, +12 = byte q of the four dwords, as bf16
           // (float(byte) has <= 8 significant bits: its upper half IS the bf16)
@@ -681,12 +697,16 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
   __syncthreads();
   for (int buf = 0; kb < kb_end; ++kb, buf ^= 1) {
     const char* cur = ldsw + buf * K::STAGE;
+    const int am = (21 * (kb / 20) + kb % 20) & 3;  // ring group of this block's first 4 input rows
+    int rowoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rowoff[j] = ((((am + kyhi[j]) & 3) << 2) | kylo[j]) * 192;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       bf8w b[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const char* q = cur + bb[j][m];
+        const char* q = ldsw + bb[j][m] + rowoff[j];
         const uint2 w01 = *(const uint2*)q, w23 = *(const uint2*)(q + 8);
         const unsigned w4 = *(const unsigned*)(q + 16);
         const u4w o = (u4w){__builtin_amdgcn_alignbit(w01.y, w01.x, shamt[j]), __builtin_amdgcn_alignbit(w23.x, w01.y, shamt[j]),
