@@ -782,11 +782,6 @@ struct __attribute__((packed, aligned(4))) lds_u2 {
   unsigned x, y;
 };
 using u4v = __attribute__((ext_vector_type(4))) unsigned;
-using bf2v = __attribute__((ext_vector_type(2))) __bf16;
-using f2v = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ unsigned pkbf2(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2v){a, b}, bf2v));
-}
 
 __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
                                                                const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
@@ -831,17 +826,12 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + 256 * j < K::NIU) {
         const f4 v = ir[j];
-        const unsigned p0a = pkbf2(v.x, v.y), p0b = pkbf2(v.z, v.w);
-        const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
-        const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
 #if DDRL_F2B_KO == 1  // knock-out (timing only): no residual planes
-        const unsigned p1a = p0a, p1b = p0b, p2a = p0a, p2b = p0b;
-        (void)r1x; (void)r1y; (void)r1z; (void)r1w;
+        const unsigned p0a = pack_bf16x2(v.x, v.y), p0b = pack_bf16x2(v.z, v.w), p1a = p0a, p1b = p0b, p2a = p0a, p2b = p0b;
 #else
-        const unsigned p1a = pkbf2(r1x, r1y), p1b = pkbf2(r1z, r1w);
-        const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
-        const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
-        const unsigned p2a = pkbf2(r2x, r2y), p2b = pkbf2(r2z, r2w);
+        unsigned p0a, p0b, p1a, p1b, p2a, p2b;
+        split_bf16x3(v.x, v.y, p0a, p1a, p2a);
+        split_bf16x3(v.z, v.w, p0b, p1b, p2b);
 #endif
         char* d = ldsc2 + idst[j];  // 4-byte aligned (odd rows start at 4 mod 8)
         *(lds_u2*)(d) = lds_u2{p0a, p0b};
@@ -880,7 +870,7 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
         }
       }
       // smallest products first
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+      DDRL_BF16X6_PRODUCTS;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -1001,14 +991,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (j + 1 < K::NIJ || tid + 256 * j < K::NPX) {
         unsigned p0[4], p1[4], p2[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float x = ir[j][2 * c], y = ir[j][2 * c + 1];
-          p0[c] = pkbf2(x, y);
-          const float r1x = x - __uint_as_float(p0[c] << 16), r1y = y - __uint_as_float(p0[c] & 0xFFFF0000u);
-          p1[c] = pkbf2(r1x, r1y);
-          const float r2x = r1x - __uint_as_float(p1[c] << 16), r2y = r1y - __uint_as_float(p1[c] & 0xFFFF0000u);
-          p2[c] = pkbf2(r2x, r2y);
-        }
+        for (int c = 0; c < 4; ++c) split_bf16x3(ir[j][2 * c], ir[j][2 * c + 1], p0[c], p1[c], p2[c]);
         char* d = ldsc3 + (tid + 256 * j) * 16;
         *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
         *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
@@ -1042,7 +1025,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < K::TN; ++j) b[p][j] = *(const bf8*)(ldsc3 + bB[j] + tapoff[kg] + p * K::IMG_PLANE);
       }
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+      DDRL_BF16X6_PRODUCTS;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -1358,14 +1341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
         unsigned p0[4], p1[4], p2[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float x = ir[j][2 * c], y = ir[j][2 * c + 1];
-          p0[c] = pkbf2(x, y);
-          const float r1x = x - __uint_as_float(p0[c] << 16), r1y = y - __uint_as_float(p0[c] & 0xFFFF0000u);
-          p1[c] = pkbf2(r1x, r1y);
-          const float r2x = r1x - __uint_as_float(p1[c] << 16), r2y = r1y - __uint_as_float(p1[c] & 0xFFFF0000u);
-          p2[c] = pkbf2(r2x, r2y);
-        }
+        for (int c = 0; c < 4; ++c) split_bf16x3(ir[j][2 * c], ir[j][2 * c + 1], p0[c], p1[c], p2[c]);
         char* d = ldsd3 + idst[j];
         *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
         *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
@@ -1400,7 +1376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const bf8*)(ldsd3 + bB[j] - tapoff[kg] + p * K::IMG_PLANE);
       }
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+      DDRL_BF16X6_PRODUCTS;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -1552,14 +1528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
         unsigned p0[4], p1[4], p2[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float x = ir[j][2 * c], y = ir[j][2 * c + 1];
-          p0[c] = pkbf2(x, y);
-          const float r1x = x - __uint_as_float(p0[c] << 16), r1y = y - __uint_as_float(p0[c] & 0xFFFF0000u);
-          p1[c] = pkbf2(r1x, r1y);
-          const float r2x = r1x - __uint_as_float(p1[c] << 16), r2y = r1y - __uint_as_float(p1[c] & 0xFFFF0000u);
-          p2[c] = pkbf2(r2x, r2y);
-        }
+        for (int c = 0; c < 4; ++c) split_bf16x3(ir[j][2 * c], ir[j][2 * c + 1], p0[c], p1[c], p2[c]);
         char* d = ldsd2 + idst[j];
         *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
         *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
@@ -1593,7 +1562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const bf8*)(ldsd2 + bB[j] + p * K::IMG_PLANE - kg * (11 * 16));
       }
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+      DDRL_BF16X6_PRODUCTS;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll

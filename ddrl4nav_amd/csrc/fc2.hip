@@ -388,15 +388,10 @@ struct FcWgrad2 : FcCommon {
 // k-block waits in registers and is committed between two barriers while the CU's other workgroup computes.
 // ------------------------------------------------------------------------------------------------
 using bf8f = __attribute__((ext_vector_type(8))) __bf16;
-using bf2f = __attribute__((ext_vector_type(2))) __bf16;
-using f2f = __attribute__((ext_vector_type(2))) float;
 
 struct FcFwdB {
   static constexpr int PITCH = 80, PLANE = 128 * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
 };
-__device__ __forceinline__ unsigned pkbf(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2f){a, b}, bf2f));
-}
 
 __global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
                                                             const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
@@ -431,13 +426,9 @@ __global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f4 v = ar[j];
-      const unsigned p0a = pkbf(v.x, v.y), p0b = pkbf(v.z, v.w);
-      const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
-      const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
-      const unsigned p1a = pkbf(r1x, r1y), p1b = pkbf(r1z, r1w);
-      const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
-      const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
-      const unsigned p2a = pkbf(r2x, r2y), p2b = pkbf(r2z, r2w);
+      unsigned p0a, p0b, p1a, p1b, p2a, p2b;
+      split_bf16x3(v.x, v.y, p0a, p1a, p2a);
+      split_bf16x3(v.z, v.w, p0b, p1b, p2b);
       char* d = ldsf + (rr + 32 * j) * K::PITCH + k4 * 8;
       *(uint2*)(d) = make_uint2(p0a, p0b);
       *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
@@ -471,8 +462,7 @@ __global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8f*)(ldsf + bB[j] + p * K::PLANE + kg * 32);
       }
-      // smallest products first
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+      DDRL_BF16X6_PRODUCTS;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -565,13 +555,9 @@ __global__ __launch_bounds__(256) void fc_dgrad_bf16x6_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f4 v = ar[j];
-      const unsigned p0a = pkbf(v.x, v.y), p0b = pkbf(v.z, v.w);
-      const float r1x = v.x - __uint_as_float(p0a << 16), r1y = v.y - __uint_as_float(p0a & 0xFFFF0000u);
-      const float r1z = v.z - __uint_as_float(p0b << 16), r1w = v.w - __uint_as_float(p0b & 0xFFFF0000u);
-      const unsigned p1a = pkbf(r1x, r1y), p1b = pkbf(r1z, r1w);
-      const float r2x = r1x - __uint_as_float(p1a << 16), r2y = r1y - __uint_as_float(p1a & 0xFFFF0000u);
-      const float r2z = r1z - __uint_as_float(p1b << 16), r2w = r1w - __uint_as_float(p1b & 0xFFFF0000u);
-      const unsigned p2a = pkbf(r2x, r2y), p2b = pkbf(r2z, r2w);
+      unsigned p0a, p0b, p1a, p1b, p2a, p2b;
+      split_bf16x3(v.x, v.y, p0a, p1a, p2a);
+      split_bf16x3(v.z, v.w, p0b, p1b, p2b);
       char* d = ldsg + (rr + 32 * j) * K::PITCH + n4 * 8;
       *(uint2*)(d) = make_uint2(p0a, p0b);
       *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
@@ -605,7 +591,7 @@ __global__ __launch_bounds__(256) void fc_dgrad_bf16x6_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8f*)(ldsg + bB[j] + p * K::PLANE + kg * 32);
       }
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // smallest products first
+      DDRL_BF16X6_PRODUCTS;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
