@@ -84,6 +84,14 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {
   const unsigned u = __float_as_uint(f);
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
+// w = p0 + p1 + p2 to 24 bits (the two subtractions are exact in fp32)
+__device__ __forceinline__ void bf16_planes(float w, unsigned short& p0, unsigned short& p1, unsigned short& p2) {
+  p0 = bf16_rne(w);
+  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
+  p1 = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
+  p2 = bf16_rne(r2);
+}
 __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
   const int rows = 32 * L.NE;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -92,11 +100,8 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
   const int h = r & 1, g = (r >> 1) & 3, c = r >> 3;
   const int e = row >> 5, oc = row & 31, ky = 2 * g + h;
   const float w = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + c) * 8 + ky) * 8 + j];
-  const unsigned short p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  const unsigned short p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  const unsigned short p2 = bf16_rne(r2);
+  unsigned short p0, p1, p2;
+  bf16_planes(w, p0, p1, p2);
   const int base = (c * 4 + g) * 3;
   dst[(((base + 0) * 2 + h) * rows + row) * 8 + j] = p0;
   dst[(((base + 1) * 2 + h) * rows + row) * 8 + j] = p1;
@@ -110,11 +115,8 @@ __global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restri
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)FLAT * FEAT) return;
   const float w = params[L.enc_base[e] + L.enc.lw + i];
-  const unsigned short p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  const unsigned short p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  const unsigned short p2 = bf16_rne(r2);
+  unsigned short p0, p1, p2;
+  bf16_planes(w, p0, p1, p2);
   unsigned short* d = dst + (int64_t)e * 3 * FLAT * FEAT + i;
   d[0] = p0;
   d[(int64_t)FLAT * FEAT] = p1;
@@ -134,11 +136,8 @@ __global__ __launch_bounds__(256) void pack_conv2_bf16_kernel(const float* __res
   if (i >= 64 * 32 * 16) return;
   const int tap = i & 15, ch = (i >> 4) & 31, oc = i >> 9;
   const float w = params[L.enc_base[e] + L.enc.c2w + i];
-  const unsigned short p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  const unsigned short p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  const unsigned short p2 = bf16_rne(r2);
+  unsigned short p0, p1, p2;
+  bf16_planes(w, p0, p1, p2);
   unsigned short* d = dst + (((int64_t)(e * 32 + ch) * 3) * 64 + oc) * 16 + tap;
   d[0] = p0;
   d[64 * 16] = p1;
@@ -153,11 +152,8 @@ __global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __res
   const int c = i & 7, h = (i >> 3) & 1, oc = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
   const int tap = 2 * kg + h;
   const float w = tap < 9 ? params[L.enc_base[e] + L.enc.c3w + (oc * 64 + kb * 8 + c) * 9 + tap] : 0.0f;
-  const unsigned short p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  const unsigned short p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  const unsigned short p2 = bf16_rne(r2);
+  unsigned short p0, p1, p2;
+  bf16_planes(w, p0, p1, p2);
   unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * 3) * 64 + oc) * 16 + h * 8 + c;
   d[0] = p0;
   d[64 * 16] = p1;
@@ -173,11 +169,8 @@ __global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __re
   const int o = i & 7, v = (i >> 3) & 1, row = (i >> 4) & 63, u = (i >> 10) & 1, kb = (i >> 11) & 7, a = i >> 14;
   const int c = row >> 5, ic = row & 31, oc = 8 * kb + o;
   const float w = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + (2 * u + a) * 4 + 2 * v + c];
-  const unsigned short p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  const unsigned short p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  const unsigned short p2 = bf16_rne(r2);
+  unsigned short p0, p1, p2;
+  bf16_planes(w, p0, p1, p2);
   unsigned short* d = dst + (((((int64_t)(e * 2 + a) * 8 + kb) * 2 + u) * 3) * 64 + row) * 16 + v * 8 + o;
   d[0] = p0;
   d[64 * 16] = p1;
@@ -192,11 +185,8 @@ __global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __re
   const int o = i & 7, h = (i >> 3) & 1, ic = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
   const int tap = 2 * kg + h;
   const float w = tap < 9 ? params[L.enc_base[e] + L.enc.c3w + ((8 * kb + o) * 64 + ic) * 9 + tap] : 0.0f;
-  const unsigned short p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  const unsigned short p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  const unsigned short p2 = bf16_rne(r2);
+  unsigned short p0, p1, p2;
+  bf16_planes(w, p0, p1, p2);
   unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * 3) * 64 + ic) * 16 + h * 8 + o;
   d[0] = p0;
   d[64 * 16] = p1;
