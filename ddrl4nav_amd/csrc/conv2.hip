@@ -753,7 +753,7 @@ static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
 // six plane products that reach 2^-18 of the largest are accumulated in fp32.  One MFMA k-group (16) = the 4 x 4 taps
 // of ONE input channel: lane (pixel, h) holds taps (ky = 2h, kx = 0..3) and (ky = 2h + 1, kx = 0..3) = two runs of four
 // consecutive bf16 in the staged image (4-byte aligned 8-byte LDS reads), so the im2col stays implicit.
-// Tile = 64 output channels x 3 whole samples (243 columns in 8 column tiles of 32), k-block = 4 input channels;
+// Tile = 64 output channels x 3 whole samples (243 columns in 8 column tiles of 32), k-block = 2 input channels (DDRL_F2B_KC);
 // LDS holds ONE stage (image planes [plane][sample][channel][20 rows of pitch 26] bf16 + weight planes [channel][plane][oc][16]):
 // the next k-block waits in registers and is split / committed between two barriers while the CU's other
 // workgroups compute.
@@ -767,14 +767,20 @@ static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
 #ifndef DDRL_F2B_KO
 #define DDRL_F2B_KO 0
 #endif
+#ifndef DDRL_F2B_KC
+#define DDRL_F2B_KC 2  // input channels per k-block: 2 -> 146 VGPRs and 31 KB of LDS, three workgroups per CU (3.66 vs 3.83 ms at 4 / two)
+#endif
+#ifndef DDRL_F2B_WPE
+#define DDRL_F2B_WPE 3  // waves per SIMD the register budget is cut for
+#endif
 struct Fwd2B {
-  static constexpr int SPT = 3;                                   // samples per tile
+  static constexpr int SPT = 3, KC = DDRL_F2B_KC;                 // samples per tile, input channels per k-block
   // image row pitch 26 bf16 (13 words): the 5 input-row pairs a 32-pixel column tile reads in one instruction start
   // 26 words apart = banks {0, 26, 52, 14, 40} + c, ten words each, disjoint (pitch 20: 2-way conflicts, 46 % of LDS cycles)
-  static constexpr int ROW = DDRL_F2B_ROW, CH = 20 * ROW, IMG_PLANE = SPT * 4 * CH;  // 12,480 B
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 4 * 3 * 64 * 32;  // 37,440 + 24,576
+  static constexpr int ROW = DDRL_F2B_ROW, CH = 20 * ROW, IMG_PLANE = SPT * KC * CH;  // 12,480 B at KC = 4
+  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = KC * 3 * 64 * 32;  // 37,440 + 24,576 at KC = 4
   static constexpr int BIAS_OFF = W_OFF + W_BYTES;
-  static constexpr int NIU = SPT * 4 * 100, NIJ = (NIU + 255) / 256;      // image units of 4 pixels, per thread
+  static constexpr int NIU = SPT * KC * 100, NIJ = (NIU + 255) / 256;      // image units of 4 pixels, per thread
   static constexpr int NWJ = W_BYTES / 16 / 256;                          // weight quads per thread (6)
   static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
 };
@@ -783,7 +789,7 @@ struct __attribute__((packed, aligned(4))) lds_u2 {
 };
 using u4v = __attribute__((ext_vector_type(4))) unsigned;
 
-__global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WPE, DDRL_F2B_WPE))) void conv_fwd2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
                                                                const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
                                                                float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd2B;
@@ -798,9 +804,9 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
 #pragma unroll
   for (int j = 0; j < K::NIJ; ++j) {
     const int u = min(tid + 256 * j, K::NIU - 1);
-    const int s = u / 400, rem = u % 400, q = rem % 100;
+    const int s = u / (100 * K::KC), rem = u % (100 * K::KC), q = rem % 100;
     isrc[j] = a1 + e * a1_es + (int64_t)min(b0 + s, n - 1) * 12800 + rem * 4;  // + kb * 1600
-    idst[j] = (s * 4 + rem / 100) * K::CH + (q / 5) * K::ROW + (q % 5) * 8;
+    idst[j] = (s * K::KC + rem / 100) * K::CH + (q / 5) * K::ROW + (q % 5) * 8;
   }
   const unsigned short* wsrc = wp2b + (int64_t)e * (32 * 3 * 64 * 16) + tid * 8;  // + kb * 12288 + j * 2048
   // ---- operand bases
@@ -812,14 +818,14 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
     int c = wc * 64 + j * 32 + l31;
     if (c >= K::SPT * 81) c = 0;
     const int s = c / 81, pix = c % 81, oy = pix / 9, ox = pix % 9;
-    bB[j] = s * 4 * K::CH + (2 * oy + 2 * hi) * K::ROW + 4 * ox;
+    bB[j] = s * K::KC * K::CH + (2 * oy + 2 * hi) * K::ROW + 4 * ox;
   }
   f4 ir[K::NIJ], wr[K::NWJ];
   auto fetch = [&](int kb) {
 #pragma unroll
-    for (int j = 0; j < K::NIJ; ++j) ir[j] = ld4(isrc[j] + kb * 1600);
+    for (int j = 0; j < K::NIJ; ++j) ir[j] = ld4(isrc[j] + kb * (400 * K::KC));
 #pragma unroll
-    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * 12288 + j * 2048);
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * (K::KC * 3072) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -849,14 +855,14 @@ __global__ __launch_bounds__(256) void conv_fwd2_bf16x6_kernel(const float* __re
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  constexpr int NKB = 8;
+  constexpr int NKB = 32 / K::KC;
   fetch(0);
   commit();
   fetch(1);
   __syncthreads();
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
+    for (int kg = 0; kg < K::KC; ++kg) {
       bf8 a[3][2], b[3][2];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -929,6 +935,9 @@ static void launch_fwd2_bf16x6(const EncCall& c, hipStream_t st) {
 #ifndef DDRL_F3B_TN
 #define DDRL_F3B_TN 2
 #endif
+#ifndef DDRL_F3B_WPE
+#define DDRL_F3B_WPE 3  // waves per SIMD the register budget is cut for: 162 VGPRs, three 50 KB workgroups per CU (2.57 vs 2.69 ms at 2)
+#endif
 struct Fwd3B {
   // column tiles per wave (2 x 4 fragment tiles = 10 samples per tile measured 3.00 vs 2.70 ms: not a general win); whole samples per tile
   static constexpr int TN = DDRL_F3B_TN, SPT = (128 * TN) / 49, NPX = SPT * 81;
@@ -940,7 +949,7 @@ struct Fwd3B {
   static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_fwd3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WPE, DDRL_F3B_WPE))) void conv_fwd3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
                                                                const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
                                                                float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd3B;
