@@ -521,52 +521,63 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
 // dh is split into three bf16 planes while it is staged, the weights come pre-split and transposed from optim.hip
 // (wdlb[e][plane][k 3136][n 512]); 128 x 128 tile, k-block 32 = 2 MFMA k-groups, one LDS stage.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fc_dgrad_bf16x6_kernel(const float* __restrict__ dh, int64_t dh_es, const unsigned short* __restrict__ wdlb,
+#ifndef DDRL_FCD_KBK
+#define DDRL_FCD_KBK 32
+#endif
+#ifndef DDRL_FCD_WPE
+#define DDRL_FCD_WPE 2
+#endif
+struct FcDgradB {  // k-block KBK = 32 or 16 features; row pitch = data + 16 B so that 16 lanes' fragments hit distinct banks
+  static constexpr int KBK = DDRL_FCD_KBK, WPE = DDRL_FCD_WPE, PITCH = 2 * KBK + 16, PLANE = 128 * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
+  static constexpr int NAQ = KBK / 4, ARJ = 128 * NAQ / 256, AROWS = 256 / NAQ;  // dh: quads of 4 features per row, per thread, rows per round
+  static constexpr int NWF = KBK / 8, WJ = 128 * NWF / 256, WCOLS = 256 / NWF;   // weights: fragments of 8 features per column
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::WPE, FcDgradB::WPE))) void fc_dgrad_bf16x6_kernel(const float* __restrict__ dh, int64_t dh_es, const unsigned short* __restrict__ wdlb,
                                                               const float* __restrict__ a3, float* __restrict__ dz3, int64_t a3_es, int n) {
-  using K = FcFwdB;
+  using K = FcDgradB;
   extern __shared__ __attribute__((aligned(16))) char ldsg[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
   const int e = blockIdx.z, k0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
   // staging maps: dh = 4 quads of 4 n per thread (row rr + 32 j, n4), weights = 2 x 3 fragments of 8 n (column cc + 64 j)
-  const int n4 = tid & 7, rr = tid >> 3;
-  const float* asrc[4];
+  const int n4 = tid % K::NAQ, rr = tid / K::NAQ;
+  const float* asrc[K::ARJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) asrc[j] = dh + e * dh_es + (int64_t)min(b0 + rr + 32 * j, n - 1) * FEAT + n4 * 4;
-  const int n8 = tid & 3, cc = tid >> 2;
-  const unsigned short* wsrc[2];
+  for (int j = 0; j < K::ARJ; ++j) asrc[j] = dh + e * dh_es + (int64_t)min(b0 + rr + K::AROWS * j, n - 1) * FEAT + n4 * 4;
+  const int n8 = tid % K::NWF, cc = tid / K::NWF;
+  const unsigned short* wsrc[K::WJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) wsrc[j] = wdlb + (int64_t)e * 3 * FLAT * FEAT + (int64_t)min(k0 + cc + 64 * j, FLAT - 1) * FEAT + n8 * 8;
+  for (int j = 0; j < K::WJ; ++j) wsrc[j] = wdlb + (int64_t)e * 3 * FLAT * FEAT + (int64_t)min(k0 + cc + K::WCOLS * j, FLAT - 1) * FEAT + n8 * 8;
   int aA[2], bB[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) aA[i] = (wr * 64 + i * 32 + l31) * K::PITCH + hi * 16;
 #pragma unroll
   for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (wc * 64 + j * 32 + l31) * K::PITCH + hi * 16;
-  f4 ar[4], wrg[2][3];
+  f4 ar[K::ARJ], wrg[K::WJ][3];
   auto fetch = [&](int kb) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ar[j] = ld4(asrc[j] + kb * 32);
+    for (int j = 0; j < K::ARJ; ++j) ar[j] = ld4(asrc[j] + kb * K::KBK);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < K::WJ; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wrg[j][p] = *(const f4*)(wsrc[j] + (int64_t)p * FLAT * FEAT + kb * 32);
+      for (int p = 0; p < 3; ++p) wrg[j][p] = *(const f4*)(wsrc[j] + (int64_t)p * FLAT * FEAT + kb * K::KBK);
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < K::ARJ; ++j) {
       const f4 v = ar[j];
       unsigned p0a, p0b, p1a, p1b, p2a, p2b;
       split_bf16x3(v.x, v.y, p0a, p1a, p2a);
       split_bf16x3(v.z, v.w, p0b, p1b, p2b);
-      char* d = ldsg + (rr + 32 * j) * K::PITCH + n4 * 8;
+      char* d = ldsg + (rr + K::AROWS * j) * K::PITCH + n4 * 8;
       *(uint2*)(d) = make_uint2(p0a, p0b);
       *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
       *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < K::WJ; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(f4*)(ldsg + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + n8 * 16) = wrg[j][p];
+      for (int p = 0; p < 3; ++p) *(f4*)(ldsg + K::B_OFF + p * K::PLANE + (cc + K::WCOLS * j) * K::PITCH + n8 * 16) = wrg[j][p];
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -575,14 +586,14 @@ __global__ __launch_bounds__(256) void fc_dgrad_bf16x6_kernel(const float* __res
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  constexpr int NKB = FEAT / 32;
+  constexpr int NKB = FEAT / K::KBK;
   fetch(0);
   commit();
   fetch(1);
   __syncthreads();
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
+    for (int kg = 0; kg < K::KBK / 16; ++kg) {
       bf8f a[3][2], b[3][2];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -647,10 +658,10 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
 #ifndef DDRL_FCDGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCDGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)fc_dgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)fc_dgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcDgradB::LDS_BYTES);
       configured = true;
     }
-    hipLaunchKernelGGL(fc_dgrad_bf16x6_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcFwdB::LDS_BYTES, st, w.dh, MB * FEAT,
+    hipLaunchKernelGGL(fc_dgrad_bf16x6_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcDgradB::LDS_BYTES, st, w.dh, MB * FEAT,
                        w.wdlb, w.a3, w.dz3, MB * FLAT, c.n);
     (void)p;
     return;
