@@ -638,21 +638,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
   }
 }
 
-void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st) {
+void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int part) {  // part: 0 = both, 1 = data gradient only, 2 = weight gradient only
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
   const int S = c.splits->fc;
-  {
+  if (part != 1) {
     FcWgrad2::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S, L.NE};
     ProfRange pr(c.prof, "FcWgrad", st);
     launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), p, st);
   }
-  {
+  if (part != 1) {
     ProfRange pr(c.prof, "reduce_partials", st);
     launch_reduce_partials(w.wpart, S, FcWgrad2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
   }
-  {
+  if (part != 2) {
     FcDgrad2::Params p{w.dh, MB * FEAT, w.wln, w.a3, w.dz3, MB * FLAT, c.n};
     ProfRange pr(c.prof, "FcDgrad", st);
 #ifndef DDRL_FCDGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCDGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)

@@ -41,7 +41,7 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
 // path, where heads_act sums the partials).  7 k-blocks of 32 per split.
 inline int fc_forward_splits(int n) { return n <= 1024 ? 14 : 1; }
 void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st);
-void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st);
+void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int part = 0);
 
 // conv2.hip (v2 engine)
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st);
