@@ -1081,6 +1081,11 @@ static void launch_fwd3_bf16x6(const EncCall& c, hipStream_t st) {
 }
 
 // ================================================================================================
+#ifndef DDRL_ACT_BF16X6_MIN
+// acting launches of at least this many envs use the bf16x6 conv2 / conv3 kernels too (us per ddrl_forward, fp32-MFMA
+// narrow-tile kernels vs bf16x6: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7, 2048: 606.2 / 480.9)
+#define DDRL_ACT_BF16X6_MIN 192
+#endif
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -1112,7 +1117,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     ConvFwd2v2<2>::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
 #ifndef DDRL_FWD2_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-    if (!acting) {
+    if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
       launch_fwd2_bf16x6(c, st);
     } else
 #endif
@@ -1127,7 +1132,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     ConvFwd3v2<2>::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
 #ifndef DDRL_FWD3_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD3_F32 keeps the fp32-MFMA kernel
-    if (!acting) {
+    if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
       launch_fwd3_bf16x6(c, st);
     } else
 #endif
