@@ -178,7 +178,8 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   return off;
 }
 
-// counter-based uniform in [0,1): identical to ddrl4nav_amd/utils/recipe.py:hash_uniform
+// counter-based uniform in [0,1) of the samplers: identical to ddrl4nav_amd/utils/recipe.py:sample_uniform.
+// All 64 bits of the stream id take part (callers put rollout / draw counters in the high bits).
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   uint64_t z = x;
@@ -187,7 +188,7 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
   return z ^ (z >> 31);
 }
 __host__ __device__ inline float hash_uniform(uint64_t seed, uint64_t stream, uint64_t idx) {
-  uint64_t base = splitmix64(seed ^ (stream << 40));
+  uint64_t base = splitmix64(splitmix64(seed) ^ stream);
   uint64_t z = splitmix64(base + idx);
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }

@@ -96,19 +96,20 @@ int32_t ddrl_eb_scan(const uint8_t* buf, int64_t len, ddrl_eb_array* out, int32_
   int64_t i = 0;
   int32_t k = 0;
   while (i < len) {
-    if (i + 10 > len) return DDRL_ERR_INVALID_ARG;
+    if (len - i < 10) return DDRL_ERR_INVALID_ARG;
     const int32_t dtype = (int16_t)be16(buf + i);
     const int isz = item_size(dtype);
     if (!isz) return DDRL_ERR_UNSUPPORTED;  // "Match data type error" -> ValueError in the reference
     const int64_t count = be32(buf + i + 2);
     const int32_t ndim = (int32_t)be32(buf + i + 6);
-    if (ndim < 0 || ndim > 8 || i + 10 + 4 * (int64_t)ndim > len) return DDRL_ERR_INVALID_ARG;
+    if (ndim < 0 || ndim > 8 || 10 + 4 * (int64_t)ndim > len - i) return DDRL_ERR_INVALID_ARG;
     int64_t prod = 1;
     ddrl_eb_array a;
     std::memset(&a, 0, sizeof(a));
     for (int d = 0; d < ndim; ++d) {
       a.dims[d] = be32(buf + i + 10 + 4 * d);
       prod *= a.dims[d];
+      if (prod > 0xFFFFFFFFll) return DDRL_ERR_INVALID_ARG;  // count is a uint32 on the wire; also keeps prod from wrapping
     }
     if (prod != count) return DDRL_ERR_INVALID_ARG;
     a.dtype = dtype;
@@ -116,7 +117,7 @@ int32_t ddrl_eb_scan(const uint8_t* buf, int64_t len, ddrl_eb_array* out, int32_
     a.count = count;
     a.data_offset = i + 10 + 4 * ndim;
     a.nbytes = count * isz;
-    if (a.data_offset + a.nbytes > len) return DDRL_ERR_INVALID_ARG;
+    if (a.nbytes > len - a.data_offset) return DDRL_ERR_INVALID_ARG;
     if (k < cap) out[k] = a;
     ++k;
     i = a.data_offset + a.nbytes;
@@ -142,13 +143,14 @@ int32_t ddrl_eb_scan_forward_states(const uint8_t* buf, int64_t len, ddrl_eb_msg
   int64_t i = 0;
   int32_t k = 0;
   while (i < len) {
-    if (i + 20 > len) return DDRL_ERR_INVALID_ARG;
+    if (len - i < 20) return DDRL_ERR_INVALID_ARG;
     ddrl_eb_msg m;
     m.payload_len = (int64_t)be64(buf + i);
     for (int q = 0; q < 4; ++q) m.ip[q] = be16(buf + i + 8 + 2 * q);
     m.process_env_id = be32(buf + i + 16);
     m.payload_offset = i + 20;
-    if (m.payload_len < 0 || m.payload_offset + m.payload_len > len) return DDRL_ERR_INVALID_ARG;
+    // the length is an untrusted u64: compare without adding, so nothing wraps
+    if (m.payload_len < 0 || m.payload_len > len - m.payload_offset) return DDRL_ERR_INVALID_ARG;
     if (k < cap) out[k] = m;
     ++k;
     i = m.payload_offset + m.payload_len;
@@ -163,13 +165,13 @@ int32_t ddrl_eb_scan_forward_states(const uint8_t* buf, int64_t len, ddrl_eb_msg
 // mapped back with round(x*255) (exact: |x*255 - k| < 2^-20).
 int32_t ddrl_eb_frames_to_u8(const uint8_t* buf, int64_t len, int32_t state_index, uint8_t* dst, int64_t dst_cap,
                              int64_t* n_samples, int64_t* sample_elems) {
-  if (!buf || !dst || !n_samples || !sample_elems || state_index < 0) return DDRL_ERR_INVALID_ARG;
+  if (!buf || !dst || !n_samples || !sample_elems || state_index < 0 || len < 0 || dst_cap < 0) return DDRL_ERR_INVALID_ARG;
   int64_t i = 0, written = 0, total = 0, per = -1;
   while (i < len) {
-    if (i + 20 > len) return DDRL_ERR_INVALID_ARG;
+    if (len - i < 20) return DDRL_ERR_INVALID_ARG;
     const int64_t plen = (int64_t)be64(buf + i);
     const int64_t poff = i + 20;
-    if (plen < 0 || poff + plen > len) return DDRL_ERR_INVALID_ARG;
+    if (plen < 0 || plen > len - poff) return DDRL_ERR_INVALID_ARG;
     ddrl_eb_array arr[16];
     int32_t na = 0;
     int32_t s = ddrl_eb_scan(buf + poff, plen, arr, 16, &na);
@@ -180,7 +182,7 @@ int32_t ddrl_eb_frames_to_u8(const uint8_t* buf, int64_t len, int32_t state_inde
     const int64_t elems = a.dims[0] ? a.count / a.dims[0] : 0;
     if (per < 0) per = elems;
     if (elems != per) return DDRL_ERR_INVALID_ARG;
-    if (written + a.count > dst_cap) return DDRL_ERR_WORKSPACE;
+    if (a.count > dst_cap - written) return DDRL_ERR_WORKSPACE;
     const uint8_t* src = buf + poff + a.data_offset;
     uint8_t* d = dst + written;
     switch (a.dtype) {
@@ -222,9 +224,9 @@ int32_t ddrl_eb_scan_backward(const uint8_t* buf, int64_t len, int64_t* states_o
                               int64_t* other_len, int64_t* tail_off) {
   if (!buf || !states_off || !states_len || !other_off || !other_len || !tail_off || len < 16) return DDRL_ERR_INVALID_ARG;
   const int64_t sl = (int64_t)be64(buf);
-  if (sl < 0 || 8 + sl + 8 > len) return DDRL_ERR_INVALID_ARG;
+  if (sl < 0 || sl > len - 16) return DDRL_ERR_INVALID_ARG;
   const int64_t ol = (int64_t)be64(buf + 8 + sl);
-  if (ol < 0 || 16 + sl + ol > len) return DDRL_ERR_INVALID_ARG;
+  if (ol < 0 || ol > len - 16 - sl) return DDRL_ERR_INVALID_ARG;
   *states_off = 8;
   *states_len = sl;
   *other_off = 16 + sl;

@@ -90,6 +90,12 @@ class Basenn(torch.nn.Module):
             if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
                 torch.nn.init.orthogonal_(m.weight, np.sqrt(2))
                 m.bias.data.zero_()
+        self.params_changed()
+
+    def params_changed(self):
+        """Parameters are views into the flat arena; the kernels read packed copies of it.  Anything
+        that writes parameters in place (init_weight, ``p.data.copy_()``) must call this afterwards
+        (load_state_dict and the optimiser step do it themselves).  PPO / GenericPPO override it."""
 
     def states_normalization(self, states):
         pass

@@ -31,12 +31,13 @@ class HipCategorical:
 
     def sample(self):
         """First call returns the draw fused into the forward kernel; later calls draw again from
-        the same counter-based stream family (stream id offset by the draw index)."""
+        the same counter-based stream family (draw index in bits 48.. of the stream id; all 64 bits
+        of the id are mixed into the generator, csrc/common.h:hash_uniform)."""
         if self._draws == 0 and self._action is not None:
             self._draws += 1
             return self._action
         self._draws += 1
-        a, lp = self._hp.categorical_sample(self._p, self._seed, self._stream + (self._draws << 32))
+        a, lp = self._hp.categorical_sample(self._p, self._seed, self._stream ^ (self._draws << 48))
         self._action, self._logp = a, lp
         return a
 

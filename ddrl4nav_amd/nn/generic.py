@@ -310,13 +310,19 @@ class HipNormal:
         self._net, self.mean, self._log_std = net, mu, log_std
         self.stddev = torch.exp(log_std).expand_as(mu)
         self._action, self._logp, self._version = action, logp, version
+        self._draws = 0
 
     loc = property(lambda self: self.mean)
     scale = property(lambda self: self.stddev)
 
     def sample(self):
-        if self._action is None:
-            self._action, self._logp = self._net._resample(self._version)
+        """First call: the draw fused into the forward; later calls draw again on the retained
+        features with a fresh stream id (draw index in bits 48.. of the id)."""
+        if self._draws == 0 and self._action is not None:
+            self._draws = 1
+            return self._action
+        self._draws += 1
+        self._action, self._logp = self._net._resample(self._version, self._draws)
         return self._action
 
     def summed_log_prob(self, value):
@@ -502,6 +508,20 @@ class GenericPPO(Basenn):
                                          _p(None), _p(logp), _st()))
         return logp
 
+    def _resample(self, version, draw):
+        """A fresh Gaussian draw (and its summed log-prob) on the features of forward `version`."""
+        n, v = self._last
+        if v != version or n > self.cap:
+            raise RuntimeError("sample() after another forward (or on a batch > max_batch) has no features to draw from")
+        ha = self._encs[0].h
+        hc = ha if self.share_cnn_net else self._encs[1].h
+        f = dict(dtype=torch.float32, device=self.device)
+        mu, val, logp = torch.empty((n, self.n_actions), **f), torch.empty(n, **f), torch.empty(n, **f)
+        action = torch.empty((n, self.n_actions), **f)
+        check(self.lib.ddrl_op_heads_act(byref(self._hd), _p(self.params), _p(ha), _p(hc), n, _p(None), self._seed,
+                                         (version * 4096) ^ (int(draw) << 48), _p(mu), _p(val), _p(action), _p(logp), _st()))
+        return action, logp
+
     def add_critic(self, critic):
         raise NotImplementedError("extra critics (RND / GAIL) are out of scope on this path")
 
@@ -531,10 +551,10 @@ class GenericPPO(Basenn):
         actions, old_logps, advs = f32(data.actions), f32(data.old_logps), f32(data.advs)
         rets = f32(data.values)[0].contiguous()
         assert rets.shape == (B,)
-        world = 1
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self._process_group)
+        from ddrl4nav_amd.dist import global_batch
+        world = dist.get_world_size(self._process_group) if dist.is_available() and dist.is_initialized() else 1
+        b_global = global_batch(B, self._process_group)  # shards may be uneven
         total = self.n_params + STATS_FLOATS
         # the batch is read by every one of the TRAINING_ITER_TIME iterations: stage it on the device once
         dstates = [torch.as_tensor(s).to(self.device, torch.float32, non_blocking=True) for s in states]
@@ -544,7 +564,7 @@ class GenericPPO(Basenn):
             for ci, lo in enumerate(range(0, B, self.cap)):
                 hi = min(B, lo + self.cap)
                 self._iter_chunk([s[lo:hi] for s in dstates], hi - lo, actions[lo:hi], old_logps[lo:hi], advs[lo:hi],
-                                 rets[lo:hi], B * world)
+                                 rets[lo:hi], b_global)
                 if ci == 0:
                     self.grads.copy_(self.gtmp)
                 else:

@@ -114,6 +114,11 @@ class PPO(Basenn):
         self._hp.params_changed()
         return out
 
+    def params_changed(self):
+        """Rebuild the packed weight layouts after an in-place write to the parameter views."""
+        if self._hp is not None:
+            self._hp.params_changed()
+
     def to(self, *args, **kwargs):  # the arena already lives on the GPU; keep `.to(DEVICE)` callers happy
         return self
 
@@ -152,13 +157,12 @@ class PPO(Basenn):
         actions, old_logps, advs = f32(data.actions), f32(data.old_logps), f32(data.advs)
         rets = f32(data.values)[0].contiguous()
         assert rets.shape == (B,)
-        world = 1
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self._process_group)
+        # data-parallel: every rank scales by 1 / (sum of the ranks' batch sizes) -- shards may be uneven
+        from ddrl4nav_amd.dist import global_batch
+        b_global = global_batch(B, self._process_group)
         for _ in range(self.training_iter_time):
             t0 = time.time()
-            self._hp.ppo_iter(frames, actions, old_logps, advs, rets, b_global=B * world)
+            self._hp.ppo_iter(frames, actions, old_logps, advs, rets, b_global=b_global)
             self._hp.allreduce_grads()
             self._hp.clip_adam_step()
             self.update_time += 1

@@ -51,10 +51,23 @@ def _splitmix64(x):
 
 
 def hash_uniform(seed, stream, n):
-    """n float32 values in [0,1) (24-bit mantissa) from (seed, stream, index)."""
+    """n float32 values in [0,1) (24-bit mantissa) from (seed, stream, index): the WEIGHT recipe the
+    golden fixtures were generated with (stream = tensor index, far below 2^24 -- only the low 24
+    bits of `stream` take part, so this is not the samplers' generator; see sample_uniform)."""
     with np.errstate(over="ignore"):
         idx = np.arange(n, dtype=np.uint64)
         base = _splitmix64(np.uint64(seed) ^ (np.uint64(stream) << np.uint64(40)))
+        z = _splitmix64(base + idx)
+    return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).astype(np.float32)
+
+
+def sample_uniform(seed, stream, n):
+    """The samplers' counter stream (csrc/common.h:hash_uniform): n float32 values in [0,1) from
+    (seed, stream, index) with ALL 64 bits of `stream` mixed in, so that streams which differ only
+    in high bits (rollout counter, draw index) are independent."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        base = _splitmix64(_splitmix64(np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)) ^ np.uint64(int(stream) & 0xFFFFFFFFFFFFFFFF))
         z = _splitmix64(base + idx)
     return ((z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))).astype(np.float32)
 

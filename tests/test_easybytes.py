@@ -115,3 +115,50 @@ def test_codec_fuzz_roundtrip_and_truncation():
             assert len(short) < len(arrs) and all(np.array_equal(x, y) for x, y in zip(short, arrs))
 
     check()
+
+
+_MALFORMED = r"""
+import struct, sys
+import numpy as np
+from ddrl4nav_amd.data import EasyBytes
+from ddrl4nav_amd._lib import DdrlError
+s = EasyBytes()
+bad = 0
+def expect_loud(fn, *a):
+    global bad
+    try:
+        fn(*a)
+    except (DdrlError, KeyError, ValueError):
+        bad += 1
+big = [0x7FFFFFFFFFFFFFF0, 0x7FFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFF0, 0x8000000000000000, 21]
+out = np.zeros(64, np.uint8)
+for L in big:
+    hdr = struct.pack(">Q4HI", L, 127, 0, 0, 1, 7)
+    expect_loud(s.decode_forward_states, hdr)
+    expect_loud(s.frames_to_u8, hdr, out)
+    expect_loud(s.decode_backward_data, struct.pack(">QQ", L, 0))
+    expect_loud(s.decode_backward_data, struct.pack(">QQ", 0, L))
+# array record whose dims multiply past 2^64 (wraps to the stated count without the guard)
+rec = struct.pack(">hII", 1, 0, 8) + struct.pack(">8I", *([0x10000] * 8))
+expect_loud(s.decode_data, rec)
+rec = struct.pack(">hII", 4, 0xFFFFFFFF, 1) + struct.pack(">I", 0xFFFFFFFF)
+expect_loud(s.decode_data, rec)
+# a benign header still decodes
+ok = s.encode_forward_states(1, [np.zeros((1, 4), np.float32)])
+ids, st = s.decode_forward_states(ok)
+assert ids == ["127.0.0.1_1"] and st[0].shape == (1, 4)
+print("LOUD", bad)
+"""
+
+
+def test_malformed_lengths_fail_loudly_instead_of_reading_out_of_bounds():
+    """Lengths on the wire are untrusted big-endian u64 / u32 values: near-INT64_MAX lengths and
+    overflowing dim products must come back as an error status, not as a wild read (run in a child
+    process so that a regression shows up as a failed test and not as a dead pytest)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _MALFORMED], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    assert "LOUD 22" in r.stdout, r.stdout

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from ddrl4nav_amd.utils.recipe import hash_uniform, hash_weights
+from ddrl4nav_amd.utils.recipe import hash_weights, sample_uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -154,7 +154,7 @@ def test_gaussian_sampler_contract(golden):
     a = dist.sample()
     n, D = a.shape
     seed, stream = net._seed, net._calls * 4096
-    u = hash_uniform(seed, stream, 2 * n * D)
+    u = sample_uniform(seed, stream, 2 * n * D)
     z = N.box_muller(u[0::2], u[1::2]).reshape(n, D)
     mu, std = dist.mean.cpu().numpy(), np.exp(w["actor.log_std"])
     np.testing.assert_allclose(a.cpu().numpy(), mu + std * z, rtol=1e-5, atol=1e-5)

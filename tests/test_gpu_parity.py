@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from ddrl4nav_amd.utils.recipe import flatten, hash_uniform, make_weights, param_specs
+from ddrl4nav_amd.utils.recipe import flatten, make_weights, param_specs, sample_uniform
 from oracle import ddrl_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -109,7 +109,7 @@ def test_sampler_inverse_cdf_contract(hp):
     frames = dev(rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8))
     probs, value, action, logp = hp.forward(frames, act=None, seed=1234, stream_id=77)
     p_hat, logits, _ = hp.categorical_stats(probs)
-    u = hash_uniform(1234, 77, n)
+    u = sample_uniform(1234, 77, n)
     want = O.inverse_cdf_sample(p_hat.cpu().numpy(), u)
     got = action.cpu().numpy()
     assert np.array_equal(got, want.astype(np.float32))
@@ -785,7 +785,7 @@ def test_action_counts_vs_oracle(A):
     # sampler contract: inverse CDF over p_hat with the shared counter-based uniforms
     p2, _, action, lp2 = h.forward(dev(frames), act=None, seed=99, stream_id=5)
     p_hat, logits, _ = h.categorical_stats(p2)
-    want = O.inverse_cdf_sample(p_hat.cpu().numpy(), hash_uniform(99, 5, n))
+    want = O.inverse_cdf_sample(p_hat.cpu().numpy(), sample_uniform(99, 5, n))
     assert np.array_equal(action.cpu().numpy(), want.astype(np.float32))
     h.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
     _, al, vl, ent = O.ppo_losses(net, O.frames_to_f32(frames), t(acts), t(old), t(adv), t(ret))

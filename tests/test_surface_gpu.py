@@ -333,3 +333,55 @@ def test_pinned_ring_producer_consumer_threads():
     for i in range(n_msgs):
         assert np.array_equal(got[i], ((i * 7 + base) % 256).astype(np.uint8)), i
     ring.close()
+
+
+def test_sampler_streams_use_all_64_bits_and_successive_draws_differ(net):
+    """Stream ids carry the forward counter / draw index in their HIGH bits: ids that differ only
+    above bit 24 (or 32, or 48) must give independent draws, a second dist.sample() is a new draw,
+    and the draws follow utils.recipe.sample_uniform (the documented counter stream)."""
+    from ddrl4nav_amd.utils.recipe import sample_uniform
+    hp = net.hot_path
+    n = 128
+    probs = torch.full((n, 6), 1.0 / 6, device="cuda")
+    base, _ = hp.categorical_sample(probs, 7, 3)
+    for shift in (24, 32, 40, 48, 63):
+        other, _ = hp.categorical_sample(probs, 7, 3 + (1 << shift))
+        assert not torch.equal(base, other), shift
+        u = sample_uniform(7, 3 + (1 << shift), n)
+        want = np.minimum((u.astype(np.float64) * 6).astype(np.int64), 5)
+        # inverse CDF over six equal bins (a draw within 1e-6 of a bin edge may land on either side)
+        got = other.cpu().numpy()
+        edge = np.abs(u.astype(np.float64) * 6 - np.round(u.astype(np.float64) * 6)) < 1e-5
+        assert np.array_equal(got[~edge], want[~edge].astype(np.float32)), shift
+    again, _ = hp.categorical_sample(probs, 7, 3)
+    assert torch.equal(base, again)  # same (seed, stream) -> same draw
+    rng = np.random.default_rng(5)
+    frames = torch.from_numpy(rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8))
+    (dist, _), _ = net([frames])
+    a1 = dist.sample().clone()
+    a2 = dist.sample().clone()
+    a3 = dist.sample().clone()
+    assert not torch.equal(a1, a2) and not torch.equal(a2, a3) and not torch.equal(a1, a3)
+    lp = net.actor.log_prob_from_distribution(dist, a3)
+    want = dist.logits.gather(-1, a3.long().unsqueeze(-1)).squeeze(-1)
+    np.testing.assert_allclose(lp.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_init_weight_refreshes_packed_weights(net):
+    """Basenn.init_weight writes the parameter views in place; the kernels must see the new weights."""
+    w0 = {k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()}
+    rng = np.random.default_rng(6)
+    frames = torch.from_numpy(rng.integers(0, 256, size=(16, 4, 84, 84), dtype=np.uint8))
+    (p0, _), v0 = net([frames], play_mode=True)
+    p0, v0 = p0.clone(), v0[0].clone()
+    torch.manual_seed(3)
+    net.init_weight()
+    (p1, _), v1 = net([frames], play_mode=True)
+    assert not torch.allclose(p0, p1) and not torch.allclose(v0, v1[0])
+    onet = O.OraclePPO()
+    onet.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        oprobs, _, _, ov = onet(O.frames_to_f32(frames.numpy()))
+    np.testing.assert_allclose(p1.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v1[0].cpu().numpy(), ov.numpy(), rtol=1e-5, atol=2e-6)
+    net.load_state_dict(w0)
