@@ -329,6 +329,7 @@ def main():
     # about as much as they do (measured: 44.5 -> 34.6 ms per rollout without) -- they get their own pass below.
     hp.profile(True, acting=False)
     if world > 1:
+        hp.time_allreduce(True)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -344,6 +345,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     stats = hp.stats()
+    ar_ms = hp.allreduce_ms() if world > 1 else []
+    hp.time_allreduce(False)
     prof = hp.profile_read()
     # per-kernel times of the acting launches: a separate, untimed pass of 64 forwards with events around them
     hp.profile(False)
@@ -404,6 +407,13 @@ def main():
             "acting_env_steps_per_s_per_gpu": round(N * (T + 1) / (phase["act_ms"] / steps * 1e-3), 1),
             "whole_step_tflops_per_gpu": round(total_flop / elapsed / 1e12, 2),
             "whole_step_frac_of_f32_peak": round(total_flop / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            # section 8e: one SUM all-reduce of the 13,487,420-byte gradient arena (+ loss tail) per PPO iteration, bracketed by
+            # events on the compute stream of rank 0 (includes waiting for the slowest rank to arrive)
+            "allreduce": None if world == 1 else {
+                "bytes": int(hp.grads.numel() * 4), "calls": len(ar_ms), "ms_avg": round(float(np.mean(ar_ms)), 4),
+                "ms_p50": round(float(np.median(ar_ms)), 4), "ms_max": round(float(np.max(ar_ms)), 4),
+                "ms_per_update": round(float(np.sum(ar_ms)) / steps, 3), "backend": dist.get_backend(),
+                "algbw_gbps": round(hp.grads.numel() * 4 / (float(np.median(ar_ms)) * 1e-3) / 1e9, 2)},
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
             "dtype_note": "fp32 accumulation everywhere; the GEMM kernels use the f32-input MFMA except conv1's forward and weight "

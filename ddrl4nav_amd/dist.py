@@ -54,12 +54,23 @@ def global_batch(local_batch, group=None):
 def allreduce_flat(flat, group=None):
     """In-place SUM all-reduce of the flat gradient arena (13,487,388 B + 32 B tail per call)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            # several ranks sharing one GPU (single-GPU test boxes, DDRL_DIST_BACKEND=gloo): reduce on the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 
 def broadcast_params(flat, src=0, group=None):
     """Make the replicas bit-identical at start-up (weights come from rank 0)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(flat, src=src, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src, group=group)
     return flat

@@ -49,6 +49,7 @@ class HotPath:
         self.process_group = process_group
         self.n_actions = int(n_actions)
         self.max_batch = int(max_batch)
+        self._ar_events = None  # (start, stop) event pairs around the gradient all-reduce while time_allreduce(True)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -151,7 +152,26 @@ class HotPath:
         """One RCCL all-reduce (sum) of the flat gradient arena + loss tail per PPO iteration
         (SURVEY.md section 8e); gradients were pre-scaled by 1/B_global."""
         from .dist import allreduce_flat
+        if self._ar_events is None:
+            allreduce_flat(self.grads, self.process_group)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         allreduce_flat(self.grads, self.process_group)
+        e1.record()
+        self._ar_events.append((e0, e1))
+
+    def time_allreduce(self, on=True):
+        """Bracket every gradient all-reduce with events on the compute stream (what the learner waits for)."""
+        self._ar_events = [] if on else None
+
+    def allreduce_ms(self):
+        """Durations (ms) of the all-reduces since time_allreduce(True); synchronises."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in (self._ar_events or [])]
+        if self._ar_events is not None:
+            self._ar_events = []
+        return out
 
     def clip_adam_step(self):
         check(self.lib.ddrl_clip_adam_step(self.ctx, _stream()))

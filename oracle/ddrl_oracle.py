@@ -125,7 +125,8 @@ EPS = float(torch.finfo(torch.float32).eps)
 def categorical_logits(probs):
     """torch.distributions.Categorical(probs=p): p_hat = p / sum(p); logits = log(clamp(p_hat, eps, 1-eps))."""
     p_hat = probs / probs.sum(-1, keepdim=True)
-    return p_hat, torch.log(torch.clamp(p_hat, EPS, 1.0 - EPS))
+    eps = torch.finfo(probs.dtype).eps  # torch.distributions.utils.clamp_probs: eps of the probs' dtype
+    return p_hat, torch.log(torch.clamp(p_hat, eps, 1.0 - eps))
 
 
 def categorical_log_prob(logits, act):

@@ -224,3 +224,22 @@ def test_nav_oracle_pinned_to_reference(golden, name):
         got = [ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]]
         np.testing.assert_allclose(got, g["losses"][it - 1], rtol=2e-6, atol=2e-7)
     assert it == 10
+
+
+@pytest.mark.parametrize("mode", ["default", "shared", "smooth"])
+def test_oracle_float64_trajectory_pinned_to_reference_float64(mode):
+    """The GPU sequence tests measure every parameter against the oracle's FLOAT64 trajectory
+    (tests/parity_util.py); that trajectory is pinned here against the reference's own float64 run
+    (tests/golden/make_golden_spread.py): losses and per-tensor checksums after iterations 1 and 10."""
+    import parity_util as P
+    sp = P._load(P.MODES[mode][0])
+    tr = P.f64_trajectory(mode)
+    np.testing.assert_allclose(tr["losses"], sp["losses_f64"], rtol=1e-11, atol=1e-13)
+    for it in (1, 10):
+        for name, a in tr["params"][it].items():
+            k = "it%d/%s" % (it, name)
+            np.testing.assert_allclose(np.sqrt((a ** 2).sum()), sp["f64_l2/" + k], rtol=1e-12)
+            np.testing.assert_allclose(a.ravel()[:8], sp["f64_head/" + k], rtol=0, atol=1e-13)
+            np.testing.assert_allclose(a.sum(), sp["f64_sum/" + k], rtol=0, atol=1e-11 * np.sqrt(a.size))
+            # the stored reference spread is a positive number every bound divides by
+            assert sp["ref_l2/" + k] > 0 and sp["ref_max/" + k] > 0

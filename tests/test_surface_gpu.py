@@ -80,18 +80,22 @@ def test_learn_generator_protocol_golden_f4(net, golden):
     exp = Experience(states=[g3["frames"]], advs=g3["advs"], actions=g3["actions"], old_logps=g3["old_logps"],
                      values=g3["rets"].reshape(1, -1))
     exp.to_tensor(dtype=torch.float32, device="cuda")
+    import parity_util as P
     ref = g4["losses"]
-    spread = np.maximum(np.abs(ref - g4["losses_f64"]), np.abs(ref - g4["losses_f32t8"]))
-    env = np.maximum.accumulate(spread, axis=0)
-    seen = 0
-    for loss_items, update_time, last in net.learn(exp):
-        seen += 1
-        assert update_time == seen and last is True
+    env = P.loss_envelope(ref, g4["losses_f64"], g4["losses_f32t8"])
+    gen = net.learn(exp)
+    seen = [0]
+
+    def step():
+        loss_items, update_time, last = next(gen)
+        seen[0] += 1
+        assert update_time == seen[0] and last is True
         assert set(loss_items) == {"PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss", "PpoBackUpTime"}
-        got = np.array([loss_items[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
-        tol = 10.0 * env[seen - 1] + 1e-5 * np.abs(ref[seen - 1]) + 2e-6
-        assert np.all(np.abs(got - ref[seen - 1]) <= tol), (seen, got, ref[seen - 1])
-    assert seen == 10 and net.update_time == 10
+        return [loss_items[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")]
+
+    # same bounds as tests/test_gpu_parity.py::test_learn_sequence_golden_f4, through the drop-in surface
+    P.check_sequence("learn_f4", "default", step, lambda: net.hot_path.params.cpu().numpy(), ref, env)
+    assert next(gen, None) is None and seen[0] == 10 and net.update_time == 10
 
 
 def test_redis_blob_and_checkpoint_roundtrip(net, tmp_path):
