@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""tests/golden/margins.json from a recorded GPU run.
+
+`DDRL_RECORD_MARGINS=1 python -m pytest tests -m gpu` (on the MI355X box) writes every envelope-type ratio it
+measured to gpurun_out/margins_measured.json; this script turns them into the committed limits:
+limit = measured x 1.5, rounded up to two significant digits.  Entries keep the measured value and the box run
+they came from, so the headroom of every bound is on record ("make the parity bounds falsifiable").
+
+usage: python tools/update_margins.py [--source gpurun_out/margins_measured.json] [--note "r02 v23, MI355X"]
+"""
+import argparse
+import json
+import math
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def round_up(x, digits=2):
+    if x <= 0:
+        return 0.0
+    e = math.floor(math.log10(x)) - (digits - 1)
+    return round(math.ceil(x / 10 ** e) * 10 ** e, max(0, -e))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--source", default=os.path.join(ROOT, "gpurun_out", "margins_measured.json"))
+    ap.add_argument("--note", default="")
+    ap.add_argument("--headroom", type=float, default=1.5)
+    args = ap.parse_args()
+    measured = json.load(open(args.source))
+    path = os.path.join(ROOT, "tests", "golden", "margins.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for test, d in measured.items():
+        slot = out.setdefault(test, {})
+        for key, v in d.items():
+            prev = slot.get(key, {}).get("measured", 0.0)
+            m = max(prev, v)  # several boxes / runs: keep the largest ratio seen
+            # a ratio that is ~0 on one box (e.g. losses inside the single-step tolerance) still gets a usable limit
+            slot[key] = {"measured": round(m, 4), "limit": max(round_up(m * args.headroom), 0.5), "note": args.note or slot.get(key, {}).get("note", "")}
+    out["_doc"] = ("ratio = deviation of the HIP path / the reference's own deviation (tests/parity_util.py); "
+                   "limit = largest measured ratio x %.1f, rounded up; regenerate with tools/update_margins.py" % args.headroom)
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
