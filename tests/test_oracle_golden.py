@@ -243,3 +243,81 @@ def test_oracle_float64_trajectory_pinned_to_reference_float64(mode):
             np.testing.assert_allclose(a.sum(), sp["f64_sum/" + k], rtol=0, atol=1e-11 * np.sqrt(a.size))
             # the stored reference spread is a positive number every bound divides by
             assert sp["ref_l2/" + k] > 0 and sp["ref_max/" + k] > 0
+
+
+def _gail_case(name, golden):
+    from oracle import ddrl_oracle_gail as G
+    from oracle import ddrl_oracle_nav as N
+    g = golden(name)
+    hidden = int(g["d_mlp_hidden"])
+    if name == "f16_gail_classical":
+        net = G.OracleGAIL(lambda: N.MLPPreNet(4, 512), 2, False, [(513, hidden, "relu"), (hidden, 1, None)])
+        states_np, seed = g["states"], 16
+    else:
+        net = G.OracleGAIL(lambda: G.AtariPre(4), 6, False, [(513, hidden, "relu"), (hidden, 1, None)])
+        states_np, seed = O.u8_lut()[golden("f3_loss")["frames"]], 17
+    return g, net, states_np, seed
+
+
+@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])
+def test_gail_oracle_pinned_to_reference(golden, name):
+    """Discriminator forward / WGAN step / StepLR and the PPO update with the extra GAIL critic, against the
+    reference's own GAIL.learn (tests/golden/make_golden_gail.py)."""
+    from ddrl4nav_amd.utils.recipe import hash_weights
+    from oracle import ddrl_oracle_gail as G
+    g, net, states_np, seed = _gail_case(name, golden)
+    torch.set_num_threads(1)
+    assert [k for k, _ in net.named_parameters()] == list(g["names"])
+    w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
+    net.load_weights(w)
+    t = lambda k: torch.from_numpy(g[k])
+    states = [torch.from_numpy(states_np)]
+    ex_states = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy())]
+    with torch.no_grad():
+        probs, logp, _, values = net(states, t("actions"))
+        dr = net.d_reward(states, t("actions"))
+    assert np.array_equal(probs.numpy(), g["probs"]) and np.array_equal(logp.numpy(), g["logp"])
+    assert np.array_equal(values[0].numpy()[:, 0], g["value0"]) and np.array_equal(values[1].numpy()[:, 0], g["value1"])
+    assert np.array_equal(dr.numpy()[:, 0], g["d_reward"])
+    optims = net.make_optims()
+    rows = list(G.learn(net, optims, states, t("actions"), t("old_logps"), t("advs"), t("rets"), ex_states, t("expert_actions")))
+    assert [last for _, _, last in rows] == [False] + [True] * 10 and [ut for _, ut, _ in rows] == [1] + list(range(1, 11))
+    np.testing.assert_allclose(rows[0][0]["Gail[D]Loss"], g["d_loss"][0], rtol=1e-6, atol=1e-9)
+    got = np.array([[r[0][k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")] for r in rows[1:]])
+    np.testing.assert_allclose(got, g["losses"], rtol=2e-6, atol=2e-7)
+    assert optims[1].param_groups[0]["lr"] == float(g["d_lr_after"])
+    for k, p in net.named_parameters():
+        a = p.detach().numpy().reshape(-1)
+        np.testing.assert_allclose(a[::max(1, a.size // 129)][:129], g["it10/stride/" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+        if k.startswith("gail_critic."):
+            assert np.array_equal(p.detach().numpy(), w[k])   # in no optimiser: never trained (ppo.py:39,61-62)
+
+
+def test_gail_discriminator_steplr_boundary(golden):
+    """260 discriminator-only steps: the loss trajectory and the learning rate across the StepLR(250, 0.95) boundary."""
+    from ddrl4nav_amd.utils.recipe import hash_weights
+    from oracle import ddrl_oracle_gail as G
+    g, net, states_np, seed = _gail_case("f16_gail_classical", golden)
+    torch.set_num_threads(1)
+    net.load_weights(hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed))
+    t = lambda k: torch.from_numpy(g[k])
+    states = [torch.from_numpy(states_np)]
+    ex_states = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy())]
+    _, d_optim, d_sched = net.make_optims()
+    rows, lrs = [], []
+    for _ in range(260):
+        item, _, _ = G.d_step(net, d_optim, d_sched, states, t("actions"), ex_states, t("expert_actions"))
+        rows.append(item["Gail[D]Loss"])
+        lrs.append(d_optim.param_groups[0]["lr"])
+    assert lrs == list(g["d_only_lr"]) and lrs[248] == 5e-5 and abs(lrs[249] - 4.75e-5) < 1e-18
+    np.testing.assert_allclose(rows, g["d_only_loss"], rtol=1e-5, atol=1e-8)
+    for k, p in net.discriminator.named_parameters():
+        a = p.detach().numpy().reshape(-1)
+        np.testing.assert_allclose(a[::max(1, a.size // 129)][:129], g["Dend/stride/discriminator." + k], rtol=1e-4, atol=1e-7)
+
+
+def test_gae_two_value_rows_bit_exact(golden):
+    from oracle import ddrl_oracle_gail as G
+    g = golden("f18_gae_two_rows")
+    adv, ret = G.gae_rows(g["values"], g["rewards"], g["dones"], g["discounts"], float(g["landa"]))
+    assert np.array_equal(adv, g["adv"]) and np.array_equal(ret, g["ret"])
