@@ -125,6 +125,18 @@ SIGNATURES = {
                                     c_int64, c_void_p, c_void_p]),
     "ddrl_op_relu_mask": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "ddrl_op_accumulate": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddrl_encoder_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "ddrl_encoder_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "ddrl_encoder_buffers": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
+    "ddrl_op_value_head_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_value_head_ws_floats": (c_int32, [POINTER(c_int64)]),
+    "ddrl_op_value_head_loss": (c_int32, [POINTER(Config), c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                          c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_wgan_terms": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_float, c_void_p, c_int64, c_int32, c_void_p,
+                                     c_int32, c_void_p]),
+    "ddrl_op_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_clip_rmsprop": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
+                                       c_void_p]),
 }
 
 _lib = None

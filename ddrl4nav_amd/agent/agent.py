@@ -46,10 +46,21 @@ class Agents:
         self.all_num = self.agent_num_per_env * self.batch_num_per_env
         self.model_dtype = config_nn.MODULE_NUMPY_DTYPE
         self.discounts_tmp, self.landa = [config_nn.EXTRINSIC_DISCOUNT], config_nn.LANDA
-        self.discounts = np.array(self.discounts_tmp, dtype=self.model_dtype).reshape([len(self.discounts_tmp), 1])
         self.T = getattr(config, "TIME_MAX", 256)
         self.value_dim_num = self.reward_dim_num = 1
-        self.network_type = 'ppo'
+        # The reference hard-codes network_type = 'ppo' here (agent.py:95), which switches its own GAIL branch off; this
+        # mirror follows the config so that NETWORK_TYPE = "gail" gets the second value / reward row (agent.py:97-101).
+        self.network_type = getattr(config_nn, "NETWORK_TYPE", "ppo")
+        if self.network_type == 'gail':
+            self.reward_dim_num += 1
+            if config_nn.GAN_VALUE_TRICK:
+                self.value_dim_num += 1
+                self.discounts_tmp.append(config_nn.GAN_DISCOUNT)
+        self.discounts = np.array(self.discounts_tmp, dtype=self.model_dtype).reshape([len(self.discounts_tmp), 1])
+        self.dones = np.zeros([self.value_dim_num, self.all_num], dtype=np.uint8)   # row 0 = episode dones; other rows stay 0
+        self.gail_d_reward_coff = lambda x: config_nn.D_REWARD_COFF
+        self.ppo_reward_coff = lambda x: config_nn.EXTRINSIC_REWARD_COFF
+        self.episode = 0
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
 
     def _accumulate_rewards(self, experiences: List[Experience], rewards_step: np.ndarray) -> List[Experience]:
@@ -77,6 +88,9 @@ class Agents:
         return experiences[:-1]
 
     def adv_reshape(self, adv):
+        """agent.py:188-199 (defined there, called nowhere: _accumulate_rewards keeps row 0 as the advantage)."""
         if self.reward_dim_num == 1:
             return adv[0] * 1.0
-        raise NotImplementedError("multi-reward advantage mixing (GAIL / RND) is out of scope")
+        if self.reward_dim_num == 2 and self.network_type == 'gail':
+            return self.ppo_reward_coff(self.episode) * adv[0] + self.gail_d_reward_coff(self.episode) * adv[-1]
+        raise NotImplementedError("RND reward mixing is out of scope (USE_RND=False in the reference defaults)")

@@ -27,11 +27,20 @@ class BaseConfig:
         assert len(self.MACHINE_IP.split(".")) == 4
         self.TASK_NAME = getattr(parse, "task", "ddrl") + "-" + self.MACHINE_IP
         self.TEST = config_env.get('test', False)
+        # The reference's Discriminator reads config.ACTIONS_DIM and config.GAN_D_MLP_LIST (nn/GAIL.py:23,47); neither is
+        # defined by its config classes.  ACTIONS_DIM follows ConfigNN (config_nn.py:14,16); the score network defaults to
+        # one hidden layer on cat(512 features, action).
+        if config_env.get('discrete_action', True):
+            self.ACTIONS_DIM = 1
+        else:
+            self.ACTIONS_DIM = int(config_env.get('act_dim', 1))
+        self.GAN_D_MLP_LIST = [(512 + self.ACTIONS_DIM, 256, "relu"), (256, 1, None)]
 
     SYNC = False                 # :37
     PLAY_MODE = False
     DEMONSTRATE_MODE = False
     MIMIC_START = False
+    MIMIC_START_LOAD_PATH = "./mimic/"   # base_config.py:49 points into a developer's home directory
     LOAD_CHECKPOINT = False
     LOAD_CHECKPOINT_PATH = ""
     LOAD_EPISODE = 0

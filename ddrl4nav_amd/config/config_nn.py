@@ -46,11 +46,17 @@ class ConfigNN:
     MODULE_NUMPY_DTYPE = numpy.float32
     MODULE_BITS = 32
     # GAIL / RND switches the agent constructor reads (config_nn.py:92-126); both are off on this path
-    GAN_VALUE_TRICK = True
-    GAN_DISCOUNT = 0.99
+    GAN_VALUE_TRICK = True          # :90
+    GAN_DISCOUNT = 0.99             # :91
+    GAN_D_LEARNING_RATE = 5e-5      # :93
+    GAN_D_EPOCH = 1                 # :95
+    GAN_D_BATCH_SIZE = 128          # :97
+    WGAN_CLIP_GRAD_NUM = 0.01       # :99
     D_REWARD_DECAY = 1 / 10000
     D_REWARD_COFF = 1
     RND_VALUE_TRICK = False
     RND_DISCOUNT = 0.99
     RND_REWARD_COFF = 1
-    MODEL_TO_REDIS_FREQUENCY = TRAINING_ITER_TIME   # :131
+    # :131 `GAN_D_EPOCH if NETWORK_TYPE == "gail" else TRAINING_ITER_TIME`, evaluated when the class body runs (i.e. with the
+    # class default NETWORK_TYPE = "ppo"); runner.ini_config re-evaluates it for instances whose NETWORK_TYPE was changed
+    MODEL_TO_REDIS_FREQUENCY = TRAINING_ITER_TIME

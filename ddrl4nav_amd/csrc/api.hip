@@ -130,7 +130,7 @@ int32_t ddrl_ctx_create(const ddrl_config* c, float* params, float* grads, float
                         int64_t workspace_bytes, ddrl_ctx** out) {
   int32_t s = validate(c);
   if (s != DDRL_OK) return s;
-  if (!params || !grads || !m || !v || !workspace || !out) return DDRL_ERR_INVALID_ARG;
+  if (!params || !grads || !workspace || !out) return DDRL_ERR_INVALID_ARG;  // m / v: NULL for encoder-only contexts
   if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) return DDRL_ERR_INVALID_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DDRL_ERR_NO_DEVICE;
@@ -262,8 +262,33 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   return check_launch();
 }
 
+int32_t ddrl_encoder_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream) {
+  if (!ctx || !frames || n < 1 || n > ctx->cfg.max_batch || ctx->L.NE != 1) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  ensure_packed(ctx, st);
+  EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  launch_encoder_forward(ec, false, st);  // complete features (no split-K partials left for a head kernel to sum)
+  ctx->last_n = n;
+  return check_launch();
+}
+
+int32_t ddrl_encoder_backward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream) {
+  if (!ctx || !frames || n < 1 || n > ctx->cfg.max_batch || ctx->L.NE != 1) return DDRL_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  launch_encoder_backward(ec, ctx->grads, st);
+  return check_launch();
+}
+
+int32_t ddrl_encoder_buffers(ddrl_ctx* ctx, float** h, float** dh) {
+  if (!ctx || !h || !dh) return DDRL_ERR_INVALID_ARG;
+  *h = ctx->ws.h;
+  *dh = ctx->ws.dh;
+  return DDRL_OK;
+}
+
 int32_t ddrl_clip_adam_step(ddrl_ctx* ctx, void* stream) {
-  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  if (!ctx || !ctx->m || !ctx->v) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ctx->step += 1;
   {

@@ -62,6 +62,42 @@ class _Dense:
             self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n)
 
 
+class _PaddedDense(_Dense):
+    """nn.Linear whose out_features is not a multiple of 4 (the discriminator's 1-wide score layer, GAIL.py:26):
+    the operator runs on a zero-padded copy [Np][K] of the weights; forward writes [n][Np] (columns >= N are the
+    padded zeros + zero bias), the weight gradient is computed at the padded width and its first N rows are copied
+    to the parameter's gradient view."""
+
+    def __init__(self, module, relu, cap, device):
+        self.m, self.relu = module, relu
+        self.K, self.N_real = module.in_features, module.out_features
+        self.N = _pad4(self.N_real)
+        self.op = Linear(self.K, self.N, max_n=cap, device=device)
+        f = dict(dtype=torch.float32, device=device)
+        self.wpad, self.bpad = torch.zeros((self.N, self.K), **f), torch.zeros(self.N, **f)
+        self.dwpad, self.dbpad = torch.zeros((self.N, self.K), **f), torch.zeros(self.N, **f)
+
+    def pack(self):
+        self.wpad[:self.N_real].copy_(self.m.weight.data)
+        self.bpad[:self.N_real].copy_(self.m.bias.data)
+        self.op.pack(self.wpad)
+
+    def forward(self, x, ld_in, out, ld_out, n):
+        return self.op.forward(x, ld_in, self.bpad, self.relu, out, ld_out, n)
+
+    def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0):
+        self.op.wgrad(x, ld_in, dout, ld_dout, self.dwpad, self.dbpad, n)
+        self.m.weight.grad_view.copy_(self.dwpad[:self.N_real])
+        # bias gradient = column sums of dout, correctly rounded (see csrc/gail.hip:colsum_kernel)
+        check(_lib.load().ddrl_op_colsum(_p(dout), ld_dout, n, self.N_real, _p(self.m.bias.grad_view), _st()))
+        if din is not None:
+            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n)
+
+
+def dense_layer(module, relu, cap, device):
+    return (_Dense if module.out_features % 4 == 0 else _PaddedDense)(module, relu, cap, device)
+
+
 class _ConvPool:
     """Conv2d + ReLU + max_pool2d(2) (nav_encoder.py:27-31): keeps the full-resolution ReLU output
     for the pool / ReLU backward."""
@@ -371,8 +407,11 @@ class GenericPPO(Basenn):
         self.cap = int(max_batch if max_batch is not None else 4096)
         self._encs = [prenet] if self.share_cnn_net else [actor.pre, critic.pre]
         for e in self._encs:
-            if not isinstance(e, GenericPreNet):
-                raise TypeError("GenericPPO needs operator-composed encoders (MLPPreNet, NavPreNet, ...), got %r" % type(e))
+            if not all(hasattr(e, k) for k in ("build", "forward_dev", "backward_dev", "pack")):
+                raise TypeError("GenericPPO needs operator-composed encoders (MLPPreNet, NavPreNet, AtariPreNet, ...), "
+                                "got %r" % type(e))
+        self._raw_u8 = bool(getattr(self._encs[0], "raw_u8", False))  # AtariPreNet: uint8 frames go to the kernels as they are
+        self._extra = []   # [(critic module, value-loss scratch)]: PPO.add_critic (ppo.py:61-62)
         self._bind_arena()
         for e in self._encs:
             e.build(self.cap, self.device)
@@ -426,7 +465,8 @@ class GenericPPO(Basenn):
         f = dict(dtype=torch.float32, device=self.device)
         self._heads_ws = torch.empty(wf.value, **f)
         self._adam_ws = torch.empty(cb.value, dtype=torch.uint8, device=self.device)
-        self._dh = [torch.empty((self.cap, FEAT), **f) for _ in self._encs]
+        # an encoder that owns its d(loss)/d(h) buffer (AtariPreNet: inside its kernel workspace) gets the gradient written there
+        self._dh = [e._dh if getattr(e, "_dh", None) is not None else torch.empty((self.cap, FEAT), **f) for e in self._encs]
         c = self._cfg_nn
         self._cfg = _lib.default_config(
             max_batch=self.cap, n_actions=max(2, min(self.n_actions, 18)), share_cnn_net=1 if self.share_cnn_net else 0,
@@ -459,6 +499,8 @@ class GenericPPO(Basenn):
 
     # ---- forward -----------------------------------------------------------------------------------
     def _stage(self, states, lo, hi):
+        if self._raw_u8:
+            return [torch.as_tensor(s)[lo:hi] for s in states]
         return [torch.as_tensor(s)[lo:hi].to(self.device, torch.float32, non_blocking=True) for s in states]
 
     def _features(self, st, n):
@@ -476,15 +518,19 @@ class GenericPPO(Basenn):
         value, logp = torch.empty(n, **f), torch.empty(n, **f)
         a_in = None if act is None else torch.as_tensor(act, **f).contiguous()
         action = a_in if a_in is not None else torch.empty((n, A) if self.continuous else (n,), **f)
+        extra_values = [torch.empty(n, **f) for _ in self._extra]
         for lo in range(0, n, self.cap):
             hi = min(n, lo + self.cap)
             ha, hc = self._features(self._stage(states, lo, hi), hi - lo)
+            for (crit, _), xv in zip(self._extra, extra_values):   # [critic(states) for critic in self._critics] (ppo.py:75)
+                check(self.lib.ddrl_op_value_head_forward(_p(crit.critic_linear.weight.data), _p(crit.critic_linear.bias.data),
+                                                          _p(hc), FEAT, hi - lo, _p(xv[lo:hi]), _st()))
             check(self.lib.ddrl_op_heads_act(
                 byref(self._hd), _p(self.params), _p(ha), _p(hc), hi - lo, _p(None if a_in is None else a_in[lo:hi]),
                 self._seed, self._calls * 4096 + lo // self.cap, _p(dist_out[lo:hi]), _p(value[lo:hi]),
                 _p(None) if a_in is not None else _p(action[lo:hi]), _p(logp[lo:hi]), _st()))
         self._last = (n, self._calls)
-        values = [value.view(n, 1)]
+        values = [value.view(n, 1)] + [x.view(n, 1) for x in extra_values]
         if play_mode:
             return (dist_out, logp if act is not None else None), values
         if self.continuous:
@@ -523,7 +569,22 @@ class GenericPPO(Basenn):
         return action, logp
 
     def add_critic(self, critic):
-        raise NotImplementedError("extra critics (RND / GAIL) are out of scope on this path")
+        """PPO.add_critic (ppo.py:61-62): one more value head on the features the critic reads.  As in the reference the
+        head is appended to a plain list: it is NOT a parameter of this module, so neither the grad-norm clip nor the
+        Adam of this net sees it (ppo.py:39 builds the optimiser before GAIL.__init__ calls add_critic, GAIL.py:116-117)
+        -- it is never trained, but its value loss is part of VLoss / PpoTotalLoss and, with a shared prenet, its gradient
+        flows into the encoder."""
+        if not self.share_cnn_net or getattr(critic, "pre", None) is not None:
+            raise NotImplementedError("an extra critic with its own encoder (SHARE_CNN_NET=False: deepcopy(critic) carries a "
+                                      "third encoder, runner/utils.py:162) is not built; GAIL itself needs the shared prenet "
+                                      "(D_prenet = deepcopy(prenet) if prenet else None, utils.py:164)")
+        critic.to(self.device)
+        for p in critic.parameters():
+            p.requires_grad_(False)
+        wf = c_int64()
+        check(self.lib.ddrl_op_value_head_ws_floats(byref(wf)))
+        self._critics.append(critic)
+        self._extra.append((critic, torch.empty(wf.value, dtype=torch.float32, device=self.device)))
 
     def get_rnd(self, states):
         raise NotImplementedError("RND is out of scope on this path")
@@ -532,7 +593,7 @@ class GenericPPO(Basenn):
         return states / 255
 
     # ---- learn (ppo.py:77-146) -----------------------------------------------------------------------
-    def _iter_chunk(self, st, n, actions, old_logps, advs, rets, b_global):
+    def _iter_chunk(self, st, n, actions, old_logps, advs, rets, b_global, extra_rets=()):
         """forward + loss + backward of one micro-batch; gradients land in self.gtmp (overwritten)."""
         ha, hc = self._features(st, n)
         dha = self._dh[0]
@@ -540,6 +601,12 @@ class GenericPPO(Basenn):
         check(self.lib.ddrl_op_heads_loss(byref(self._hd), byref(self._cfg), _p(self.params), _p(ha), _p(hc), n, _p(actions),
                                           _p(old_logps), _p(advs), _p(rets), b_global, _p(dha), _p(dhc), _p(self.gtmp),
                                           _p(self._heads_ws), _st()))
+        # v_loss = ppov_loss + rndv_loss + gailv_loss (ppo.py:95-107): each extra head adds its loss share to the VLoss
+        # slot of the statistics tail and its d(loss)/d(h) to the shared encoder's gradient
+        for (crit, ws), xr in zip(self._extra, extra_rets):
+            check(self.lib.ddrl_op_value_head_loss(byref(self._cfg), 1, _p(crit.critic_linear.weight.data),
+                                                   _p(crit.critic_linear.bias.data), _p(hc), FEAT, n, _p(xr), b_global, _p(dha),
+                                                   FEAT, _p(None), _p(None), _p(self.gtmp[self.n_params + 1:]), _p(ws), _st()))
         self._encs[0].backward_dev(dha, n)
         if not self.share_cnn_net:
             self._encs[1].backward_dev(dhc, n)
@@ -549,22 +616,30 @@ class GenericPPO(Basenn):
         B = int(torch.as_tensor(states[0]).shape[0])
         f32 = lambda t: torch.as_tensor(t, dtype=torch.float32, device=self.device).contiguous()
         actions, old_logps, advs = f32(data.actions), f32(data.old_logps), f32(data.advs)
-        rets = f32(data.values)[0].contiguous()
+        vals = f32(data.values)
+        rets = vals[0].contiguous()
         assert rets.shape == (B,)
+        # ppo.py:97-104: the GAIL critic's targets are the LAST row of data.values (with RND unbuilt there is one extra head)
+        assert len(self._extra) <= 1 and (not self._extra or vals.shape[0] >= 2), "data.values needs one row per critic"
+        extra_rets = [vals[-1].contiguous()] if self._extra else []
         import torch.distributed as dist
         from ddrl4nav_amd.dist import global_batch
         world = dist.get_world_size(self._process_group) if dist.is_available() and dist.is_initialized() else 1
         b_global = global_batch(B, self._process_group)  # shards may be uneven
         total = self.n_params + STATS_FLOATS
         # the batch is read by every one of the TRAINING_ITER_TIME iterations: stage it on the device once
-        dstates = [torch.as_tensor(s).to(self.device, torch.float32, non_blocking=True) for s in states]
+        if self._raw_u8:
+            from ddrl4nav_amd.nn.atari_encoder import frames_u8
+            dstates = [frames_u8(states, self.device)]
+        else:
+            dstates = [torch.as_tensor(s).to(self.device, torch.float32, non_blocking=True) for s in states]
         for _ in range(self.training_iter_time):
             t0 = time.time()
             self._ensure_packed()
             for ci, lo in enumerate(range(0, B, self.cap)):
                 hi = min(B, lo + self.cap)
                 self._iter_chunk([s[lo:hi] for s in dstates], hi - lo, actions[lo:hi], old_logps[lo:hi], advs[lo:hi],
-                                 rets[lo:hi], b_global)
+                                 rets[lo:hi], b_global, [x[lo:hi] for x in extra_rets])
                 if ci == 0:
                     self.grads.copy_(self.gtmp)
                 else:

@@ -16,14 +16,7 @@ from ddrl4nav_amd.nn.base import Basenn
 from ddrl4nav_amd.nn.distribution import HipCategorical
 
 
-def _frames_u8(states, device):
-    """states[0] as a contiguous uint8 device tensor.  Float inputs are the reference's
-    float32(uint8/255.0) frames (forward.py:102-104); x*255 rounds back to the byte exactly."""
-    x = states[0] if isinstance(states, (list, tuple)) else states
-    x = torch.as_tensor(x)
-    if x.dtype != torch.uint8:
-        x = torch.round(x.to(torch.float32) * 255.0).clamp_(0, 255).to(torch.uint8)
-    return x.to(device, non_blocking=True).contiguous()
+from ddrl4nav_amd.nn.atari_encoder import frames_u8 as _frames_u8  # noqa: E402
 
 
 class PPO(Basenn):

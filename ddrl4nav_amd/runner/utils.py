@@ -6,7 +6,10 @@ size is looked up from a small table (Pong: 6)."""
 import yaml
 
 from ddrl4nav_amd.config import BaseConfig, ConfigNN
-from ddrl4nav_amd.nn import AtariPreNet, Basenn, Critic, MLPPreNet, NavPedPreNet, NavPreNet, NavPreNet1D, PPO
+import copy
+
+from ddrl4nav_amd.nn import (AtariPreNet, Basenn, Critic, Discriminator, GAIL, GenericPPO, MLPPreNet, NavPedPreNet, NavPreNet,
+                             NavPreNet1D, PPO)
 
 _ATARI_ACTIONS = {"Pong": 6, "Breakout": 4, "SpaceInvaders": 6, "Seaquest": 18, "Qbert": 6, "BeamRider": 9,
                   "Enduro": 9, "MsPacman": 9, "Boxing": 18, "Freeway": 3}
@@ -33,17 +36,22 @@ def read_yaml(parse) -> dict:
 def ini_config(parse):
     dict_config_env = read_yaml(parse)
     config_nn = ConfigNN(dict_config_env)
+    if config_nn.NETWORK_TYPE == "gail":            # config_nn.py:131
+        config_nn.MODEL_TO_REDIS_FREQUENCY = config_nn.GAN_D_EPOCH
     config = BaseConfig(parse, dict_config_env)
     config.TEST = dict_config_env.get('test', False)
     return config, config_nn, dict_config_env
 
 
-def create_net(configs, max_batch=None, process_group=None) -> Basenn:
-    """atari branches of create_net (runner/utils.py:122-143,159-160): two encoders
-    (SHARE_CNN_NET=False, the default) or one shared prenet."""
+def create_net(configs, max_batch=None, process_group=None, expert_data=None) -> Basenn:
+    """create_net (runner/utils.py:59-170): the atari branches (two encoders -- SHARE_CNN_NET=False, the default -- or one
+    shared prenet), the generic branches, and NETWORK_TYPE "ppo" or "gail"."""
     config, config_nn, config_env = configs['config'], configs['config_nn'], configs['config_env']
+    if config_nn.NETWORK_TYPE == "gail":
+        return _create_gail_net(config, config_nn, config_env, max_batch, process_group, expert_data)
     if config_nn.NETWORK_TYPE != "ppo":
-        raise NotImplementedError("NETWORK_TYPE=%s is not built (GAIL: SURVEY.md section 8f row 4)" % config_nn.NETWORK_TYPE)
+        raise NotImplementedError("NETWORK_TYPE=%s does not exist in the reference either (nn/__init__.py:19-22)"
+                                  % config_nn.NETWORK_TYPE)
     if config.TASK_TYPE != 'atari':
         return _create_generic_net(config, config_nn, config_env, max_batch, process_group)
     frames = config_env['int_frame_stack']
@@ -61,6 +69,36 @@ def create_net(configs, max_batch=None, process_group=None) -> Basenn:
                                   pre=pre_actor, nn_dtype=config_nn.MODULE_TENSOR_DTYPE)
     critic = Critic(device=config_nn.DEVICE, last_input_dim=config_nn.AC_INPUT_DIM, pre=pre_critic)
     return PPO(actor, critic, None, None, config, config_nn, max_batch=max_batch, process_group=process_group)
+
+
+def _create_gail_net(config, config_nn, config_env, max_batch, process_group, expert_data):
+    """The gail branch (runner/utils.py:161-168): gail_critic = deepcopy(critic), generator = PPO(actor, critic, prenet),
+    D_net = Discriminator(pre=deepcopy(prenet)), GAIL(generator, D_net, gail_critic).  The reference's version only works
+    with a shared prenet (D_prenet is None otherwise and GAIL.py:68 fails); so does this one, loudly."""
+    if not config_nn.SHARE_CNN_NET:
+        raise NotImplementedError("NETWORK_TYPE='gail' needs SHARE_CNN_NET=True: the reference builds the discriminator's "
+                                  "encoder as deepcopy(prenet) (runner/utils.py:164)")
+    dim = config_nn.AC_INPUT_DIM
+    actor = config_nn.ACTOR_CLASS(action_output_dim=config_nn.ACTION_OUTPUT_DIM, device=config_nn.DEVICE, last_input_dim=dim,
+                                  soft_max_grid=config_nn.SOFT_MAX_GRID, nn_dtype=config_nn.MODULE_TENSOR_DTYPE)
+    critic = Critic(device=config_nn.DEVICE, last_input_dim=dim)
+    if config.TASK_TYPE == 'atari':
+        prenet = AtariPreNet(config_env['int_frame_stack'], last_output_dim=dim, device=config_nn.DEVICE)
+    elif config.TASK_TYPE in ("mujoco", "classical"):
+        prenet = MLPPreNet(config_env.get('input_dim', 4), dim)
+    elif config.TASK_TYPE in ("robot_nav", "gazebo_env", "real_env"):
+        if config_env['ped_sim']['total'] > 0:
+            prenet = NavPedPreNet(image_channel=config_env["image_batch"] + 3, last_output_dim=dim)
+        else:
+            prenet = NavPreNet(image_channel=config_env["image_batch"], last_output_dim=dim)
+    else:
+        raise NotImplementedError("task type %s has no network in the reference either" % config.TASK_TYPE)
+    gail_critic = copy.deepcopy(critic)
+    d_prenet = copy.deepcopy(prenet)
+    # the generator is the operator-composed PPO for every encoder (the fused Atari iteration has no slot for a second value head)
+    ppo_net = GenericPPO(actor, critic, prenet, None, config, config_nn, max_batch=max_batch, process_group=process_group)
+    d_net = Discriminator(pre=d_prenet, config=config, config_nn=config_nn, max_batch=max_batch, expert_data=expert_data)
+    return GAIL(generator=ppo_net, discriminator=d_net, gail_critic=gail_critic)
 
 
 def _create_generic_net(config, config_nn, config_env, max_batch, process_group):

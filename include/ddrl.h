@@ -317,6 +317,46 @@ int32_t ddrl_op_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_a
 /* dst[i] += src[i]: gradient accumulation over micro-batches */
 int32_t ddrl_op_accumulate(float* dst, const float* src, int64_t count, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GAIL (USTC_lab/nn/GAIL.py, nn/ppo.py:61-62,97-107).
+ * ------------------------------------------------------------------------------------------ */
+/* The Atari encoder on its own, for callers that compose it with other operators (the GAIL discriminator's
+ * `pre`, GAIL.py:27,65-66, and a generator whose heads carry an extra critic): AtariPreNet.forward
+ * (atari_encoder.py:25-32) into the context's feature buffer and its backward from the context's dh buffer into
+ * the context's grad arena (encoder slots only; the head slots are not touched).  The context is created with
+ * share_cnn_net = 1; `params` / `grads` point at the encoder's first parameter (prenet.conv1.weight) inside
+ * the caller's arenas; adam_m / adam_v may be NULL for such a context (ddrl_clip_adam_step then fails).
+ * ddrl_encoder_buffers returns the device addresses of h [max_batch][512] and dh [max_batch][512]. */
+int32_t ddrl_encoder_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream);
+int32_t ddrl_encoder_backward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream);
+int32_t ddrl_encoder_buffers(ddrl_ctx* ctx, float** h, float** dh);
+
+/* One more value head next to the critic (PPO.add_critic, ppo.py:61-62): value[b] = w . h[b] + bias on 512-wide
+ * features (Critic.forward, critic.py:14-21).  w [512] / b [1] may sit anywhere in an fp32 arena. */
+int32_t ddrl_op_value_head_forward(const float* w, const float* b, const float* h, int64_t ld_h, int32_t n, float* value,
+                                   void* stream);
+/* Its loss term vlossf(rets, value) (ppo.py:101-103) scaled by 1/B_global: the loss share is ADDED to vloss_accum[0]
+ * (= &grads[n_params + 1], so that VLoss / PpoTotalLoss include it, ppo.py:107-108), d(loss)/d(h) is ADDED to dh
+ * (run after ddrl_op_heads_loss; `shared` != 0: the gradient carries v_loss_theta, as total_loss.backward() does),
+ * dw [512] / db [1] receive the head's own gradient (either may be NULL: the reference never steps this head, see
+ * nn/gail.py).  ws: ddrl_op_value_head_ws_floats floats. */
+int32_t ddrl_op_value_head_ws_floats(int64_t* floats);
+int32_t ddrl_op_value_head_loss(const ddrl_config* cfg, int32_t shared, const float* w, const float* b, const float* h,
+                                int64_t ld_h, int32_t n, const float* rets, int64_t B_global, float* dh, int64_t ld_dh, float* dw,
+                                float* db, float* vloss_accum, float* ws, void* stream);
+/* One term of the discriminator loss (GAIL.py:78-80): loss[0] (+)= sign * sum(score[0:n, 0]) / n_total, and the
+ * gradient it seeds: dscore[i][0] = sign / n_total, dscore[i][1..width) = 0 (score / dscore rows are `ld` / `ld_d`
+ * floats apart; `width` = padded output width of the last dense layer). */
+int32_t ddrl_op_wgan_terms(const float* score, int64_t ld, int32_t n, int64_t n_total, float sign, float* dscore, int64_t ld_d,
+                           int32_t width, float* loss, int32_t accumulate, void* stream);
+/* out[c] = sum over the n rows of x[:, c] for c < width, accumulated in double and rounded once (bias gradient of a
+ * narrow dense layer, e.g. the discriminator's 1-wide score layer). */
+int32_t ddrl_op_colsum(const float* x, int64_t ld, int32_t n, int32_t width, float* out, void* stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.RMSprop(lr, alpha, eps).step() (GAIL.py:28,83-84)
+ * on flat arenas; grads[n_params + 4] <- grad norm, grads[n_params + 5] <- clip coefficient.  ws: as ddrl_op_clip_adam. */
+int32_t ddrl_op_clip_rmsprop(float* params, float* grads, float* square_avg, int64_t n_params, float lr, float alpha, float eps,
+                             float max_norm, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,167 @@
+"""GPU tests of the GAIL path (BASELINE config 5) against golden vectors produced by the
+reference's own GAIL / Discriminator / PPO objects (tests/golden/make_golden_gail.py: F16 classical, F17 Atari, F18 GAE)
+and the pinned oracle (oracle/ddrl_oracle_gail.py).  Everything goes through the drop-in surface:
+create_net(NETWORK_TYPE="gail") -> GAIL.forward / GAIL.learn -> the HIP operators behind include/ddrl.h."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from ddrl4nav_amd.utils.recipe import hash_weights
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["f16_gail_classical", "f17_gail_atari"]
+
+
+def _net(name, golden, max_batch=256):
+    from ddrl4nav_amd.config import BaseConfig, ConfigNN
+    from ddrl4nav_amd.runner import create_net
+    g = golden(name)
+    if name == "f16_gail_classical":
+        env = {"env_type": "gym", "env_name": "CartPole-v1", "env_num": 8, "discrete_action": True, "discrete_actions": [0, 1],
+               "input_dim": 4}
+        states = g["states"]
+        seed = 16
+    else:
+        env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "int_frame_stack": 4, "discrete_action": True,
+               "discrete_actions": list(range(6))}
+        states = golden("f3_loss")["frames"]      # uint8; the reference fixture saw float32(u8 / 255.0)
+        seed = 17
+    cfg = BaseConfig(types.SimpleNamespace(task="gail", ip="127.0.0.1"), env)
+    cfg_nn = ConfigNN(env)
+    cfg_nn.NETWORK_TYPE, cfg_nn.SHARE_CNN_NET = "gail", True
+    hidden = int(g["d_mlp_hidden"])
+    cfg.GAN_D_MLP_LIST = [(512 + cfg.ACTIONS_DIM, hidden, "relu"), (hidden, 1, None)]
+    ex_states = states[g["expert_index"]][::-1].copy()
+    expert = [(ex_states[None], g["expert_actions"])]       # the reference-shaped batch: states [1, n, ...]
+    net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=max_batch, expert_data=expert)
+    assert [k for k, _ in net.named_parameters()] == list(g["names"])   # reference module tree / blob order
+    w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
+    res = net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("actor.") for k in res.missing_keys)   # alias of generator.actor
+    return g, net, states, w
+
+
+def _params(net):
+    return {k: p.detach().cpu().numpy().copy() for k, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gail_forward_two_critics_and_discriminator_reward(golden, name):
+    g, net, states, _ = _net(name, golden)
+    B = len(g["actions"])
+    acts = torch.from_numpy(g["actions"])
+    (dist, logp), values = net([states], acts)
+    assert len(values) == 2 and values[0].shape == (B, 1) and values[1].shape == (B, 1)
+    np.testing.assert_allclose(values[0].cpu().numpy()[:, 0], g["value0"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(values[1].cpu().numpy()[:, 0], g["value1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=2e-5, atol=2e-6)
+    (probs, _), _ = net([states], None, True)
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=2e-5, atol=2e-6)
+    # forward.py:159-165: D_rewards = net((batch_states, actions.reshape(n, action_dim)))[:, 0]
+    d = net(([states], acts.reshape(B, 1)))
+    assert d.shape == (B, 1)
+    np.testing.assert_allclose(d.cpu().numpy()[:, 0], g["d_reward"], rtol=2e-5, atol=2e-6)
+    # micro-batched evaluation gives the same scores
+    net.discriminator.cap, cap = 48, net.discriminator.cap
+    d2 = net(([states], acts.reshape(B, 1)))
+    net.discriminator.cap = cap
+    assert torch.equal(d, d2)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gail_learn_matches_reference(golden, name):
+    """GAIL.learn = one discriminator step (last=False) then ten PPO iterations with the GAIL critic (last=True):
+    protocol, losses, and every parameter tensor relative to the reference's own fp32 spread around its float64 run."""
+    import parity_util as P
+    from ddrl4nav_amd.data import Experience
+    g, net, states, w = _net(name, golden)
+    exp = Experience(states=[states], advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
+    tag = "gail_" + name[:3]
+    env = P.loss_envelope(g["losses"], g["losses_f64"], g["losses_f32t8"], g["losses_perm"])
+    rows, seen_d = [], 0
+    for loss_item, update_time, last in net.learn(exp):
+        if not last:
+            seen_d += 1
+            assert set(loss_item) == {"Gail[D]BackUpTime", "Gail[D]Loss"} and update_time == seen_d
+            excess = abs(loss_item["Gail[D]Loss"] - g["d_loss"][0]) - (2e-5 * abs(g["d_loss"][0]) + 2e-7)
+            P.MARGINS.check(tag, "d_loss", max(0.0, excess / max(float(g["d_loss_spread"]), 1e-9)))
+            worst = P.gail_param_deviation(name, "D1", _params(net))
+            for k, (v, pname) in worst.items():
+                P.MARGINS.check(tag, "D1_param_" + k, v, "(%s)" % pname)
+            continue
+        rows.append([loss_item[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
+        it = len(rows)
+        assert update_time == it
+        row = g["losses"][it - 1]
+        excess = np.abs(np.asarray(rows[-1]) - row) - (1e-5 * np.abs(row) + 2e-6)
+        P.MARGINS.check(tag, "loss_env", max(0.0, float(np.max(excess / np.maximum(env[it - 1], 1e-12)))), "(iteration %d)" % it)
+        if it in (1, 10):
+            worst = P.gail_param_deviation(name, "it%d" % it, _params(net))
+            for k, (v, pname) in worst.items():
+                P.MARGINS.check(tag, "param_%s_it%d" % (k, it), v, "(%s)" % pname)
+    assert seen_d == 1 and len(rows) == 10
+    got = _params(net)
+    for k in got:   # in no optimiser (ppo.py:39,61-62): the GAIL critic has not moved
+        if k.startswith("gail_critic."):
+            assert np.array_equal(got[k], w[k])
+    assert net.discriminator.lr == float(g["d_lr_after"])
+
+
+def test_discriminator_260_steps_cross_the_steplr_boundary(golden):
+    """RMSprop + grad-norm clip + StepLR(250, 0.95): loss trajectory, learning rate and final parameters of a
+    discriminator-only run (reference: f16 `d_only_*`)."""
+    import parity_util as P
+    from ddrl4nav_amd.data import Experience
+    g, net, states, _ = _net("f16_gail_classical", golden)
+    exp = Experience(states=[states], advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
+    D = net.discriminator
+    ref, ref64 = g["d_only_loss"], g["d_only_loss_f64"]
+    env = np.maximum.accumulate(np.abs(ref - ref64)) + 1e-9
+    worst = 0.0
+    for step in range(1, 261):
+        items = list(D.learn(exp))
+        assert len(items) == 1 and items[0][1] == step and items[0][2] is True
+        assert D.lr == float(g["d_only_lr"][step - 1])
+        excess = abs(items[0][0]["Gail[D]Loss"] - ref[step - 1]) - (2e-5 * abs(ref[step - 1]) + 2e-7)
+        worst = max(worst, excess / env[step - 1])
+    P.MARGINS.check("gail_d_only", "loss_env", max(0.0, worst))
+    assert D.lr == 5e-5 * 0.95
+    w0 = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], 16)
+    for k, p in D.named_parameters():
+        a = p.detach().cpu().numpy().reshape(-1)
+        want = g["Dend/stride/discriminator." + k]
+        got = a[::max(1, a.size // 129)][:129]
+        start = w0["discriminator." + k].reshape(-1)[::max(1, a.size // 129)][:129]
+        moved = np.abs(want - start).max()     # 260 RMSprop steps: ~1e-2
+        if moved < 1e-5:
+            # the score layer's bias: its gradient is sum(1/n) - sum(1/m) = 0; the reference's sums cancel exactly and so
+            # must ours (ddrl_op_colsum), otherwise RMSprop turns the residue into a random walk of ~lr per step
+            assert np.abs(got - want).max() <= 1e-6, (k, np.abs(got - want).max())
+            continue
+        # RMSprop normalises by sqrt(E[g^2]): like Adam it amplifies summation-order noise on elements whose gradient is
+        # tiny; the limit (margins.json) is a fraction of the distance the tensor travelled in 260 steps
+        P.MARGINS.check("gail_d_only", "param_end", float(np.abs(got - want).max() / moved), "(%s)" % k)
+
+
+def test_agents_two_row_gae_bit_exact(golden):
+    """Agents._accumulate_rewards with the GAIL value row (agent.py:97-101,124-140) == the reference, bit for bit."""
+    from ddrl4nav_amd.agent import Agents
+    from ddrl4nav_amd.config import BaseConfig, ConfigNN
+    from ddrl4nav_amd.data import Experience
+    g = golden("f18_gae_two_rows")
+    env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 6, "discrete_action": True,
+           "discrete_actions": list(range(6)), "agent_num_per_env": 1, "batch_num_per_env": 6}
+    cfg_nn = ConfigNN(env)
+    cfg_nn.NETWORK_TYPE = "gail"
+    cfg_nn.GAN_DISCOUNT = float(g["discounts"][1])
+    ag = Agents(config=BaseConfig(types.SimpleNamespace(task="t", ip="127.0.0.1"), env), config_nn=cfg_nn, config_env=env)
+    assert ag.value_dim_num == 2 and ag.reward_dim_num == 2 and ag.discounts.shape == (2, 1)
+    T = g["values"].shape[0] - 1
+    exps = [Experience(states=None, values=g["values"][t].copy(), dones=g["dones"][t].copy()) for t in range(T + 1)]
+    out = ag._accumulate_rewards(exps, g["rewards"])
+    assert len(out) == T
+    assert np.array_equal(np.stack([e.advs for e in out]), g["adv"])
+    assert np.array_equal(np.stack([e.values for e in out]), g["ret"])

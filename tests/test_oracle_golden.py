@@ -321,3 +321,17 @@ def test_gae_two_value_rows_bit_exact(golden):
     g = golden("f18_gae_two_rows")
     adv, ret = G.gae_rows(g["values"], g["rewards"], g["dones"], g["discounts"], float(g["landa"]))
     assert np.array_equal(adv, g["adv"]) and np.array_equal(ret, g["ret"])
+
+
+@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])
+def test_gail_oracle_float64_trajectory_pinned(name):
+    """The float64 trajectory the GPU GAIL tests measure against == the reference's own float64 GAIL.learn."""
+    import parity_util as P
+    g = P._load(name)
+    tr = P.gail_f64_trajectory(name)
+    np.testing.assert_allclose(tr["losses"], g["losses_f64"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(tr["d_loss"], g["d_loss_f64"], rtol=1e-10, atol=1e-14)
+    for tag in ("D1", "it1", "it10"):
+        for k, a in tr["params"][tag].items():
+            np.testing.assert_allclose(np.sqrt((a ** 2).sum()), g["f64_l2/%s/%s" % (tag, k)], rtol=1e-12)
+            np.testing.assert_allclose(a.ravel()[:8], g["f64_head/%s/%s" % (tag, k)], rtol=0, atol=1e-13)
