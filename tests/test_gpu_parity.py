@@ -17,6 +17,7 @@ import torch
 
 from ddrl4nav_amd.utils.recipe import flatten, make_weights, param_specs, sample_uniform
 from oracle import ddrl_oracle as O
+import parity_util as P
 
 pytestmark = pytest.mark.gpu
 
@@ -354,7 +355,7 @@ def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp):
 def test_dense_forward_is_at_least_fp32_accurate(hp):
     """The dense layer's forward in a training launch splits BOTH operands into three bf16 planes and sums six plane
     products in fp32 (fc_bf16x6_kernel).  Given the kernel's own a3, the error of h against the float64 product must
-    stay within 16 rounding units (2^-24) of sum_k |a_k w_k| (measured: about 4) -- far below the n * eps bound of a sequential fp32
+    stay within a few rounding units (2^-24) of sum_k |a_k w_k| (limit: tests/golden/margins.json = measured x 1.5) -- far below the n * eps bound of a sequential fp32
     chain over K = 3,136 (torch's blocked CPU matmul, whose error is reported alongside, is closer still)."""
     n = 200
     rng = np.random.default_rng(33)
@@ -373,13 +374,13 @@ def test_dense_forward_is_at_least_fp32_accurate(hp):
         f32 = (a3 @ W.T + b).numpy().astype(np.float64)
         err_kernel, err_f32 = np.abs(h - ref).max(), np.abs(f32 - ref).max()
         mass = float((a3.double().abs() @ W.double().abs().T).max())  # largest sum_k |a_k w_k|
-        assert err_kernel <= 16 * 2.0 ** -24 * mass, (pre, err_kernel, err_f32, mass)  # measured: ~4 units
+        P.MARGINS.check("accuracy", "dense_fwd_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
 
 
 def test_conv2_forward_is_at_least_fp32_accurate(hp):
     """conv2's forward in a training launch is a bf16x6 kernel too (conv_fwd2_bf16x6_kernel: weights pre-split, a1 split
     while staged, one MFMA k-group = the 16 taps of one input channel).  Given the kernel's own a1, a2 must be as close
-    to the float64 convolution as torch's fp32 convolution is, and within 16 rounding units of sum |a w|."""
+    to the float64 convolution as torch's fp32 convolution is, and within a few rounding units of sum |a w| (margins.json)."""
     n = 100  # 34 tiles of 3 samples, the last one holds a single sample
     rng = np.random.default_rng(34)
     frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
@@ -398,7 +399,7 @@ def test_conv2_forward_is_at_least_fp32_accurate(hp):
         f32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(a1, W, b, stride=2), 0.01).numpy().astype(np.float64)
         err_kernel, err_f32 = np.abs(a2 - ref).max(), np.abs(f32 - ref).max()
         mass = float(torch.nn.functional.conv2d(a1.double().abs(), W.double().abs(), stride=2).max())
-        assert err_kernel <= 16 * 2.0 ** -24 * mass, (pre, err_kernel, err_f32, mass)
+        P.MARGINS.check("accuracy", "conv2_fwd_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
         assert np.abs(a2 - ref).mean() <= 1.5 * np.abs(f32 - ref).mean() + 1e-12, (pre, np.abs(a2 - ref).mean(), np.abs(f32 - ref).mean())
         print(pre, "conv2 fwd err", err_kernel, "torch f32", err_f32, "units of mass", err_kernel / (2.0 ** -24 * mass))
 
@@ -423,8 +424,84 @@ def test_conv3_forward_is_at_least_fp32_accurate(hp):
         f32 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(a2, W, b), 0.01).numpy().astype(np.float64)
         err_kernel, err_f32 = np.abs(a3 - ref).max(), np.abs(f32 - ref).max()
         mass = float(torch.nn.functional.conv2d(a2.double().abs(), W.double().abs()).max())
-        assert err_kernel <= 16 * 2.0 ** -24 * mass, (pre, err_kernel, err_f32, mass)
+        P.MARGINS.check("accuracy", "conv3_fwd_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
         assert np.abs(a3 - ref).mean() <= 1.5 * np.abs(f32 - ref).mean() + 1e-12, (pre, np.abs(a3 - ref).mean(), np.abs(f32 - ref).mean())
+
+
+def _bwd_setup(hp, n, seed):
+    rng = np.random.default_rng(seed)
+    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    acts = rng.integers(0, 6, size=n).astype(np.float32)
+    old = np.full(n, -1.79, dtype=np.float32)
+    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    w = make_weights(0)
+    hp.set_params(flatten(w))
+    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    return w
+
+
+def _leaky_mask(a, g):
+    """the kernels' decision: slope 1 where the stored activation is positive, 0.01 elsewhere"""
+    return torch.where(a > 0, g, g * 0.01)
+
+
+def test_dense_data_gradient_is_at_least_fp32_accurate(hp):
+    """fc_dgrad_bf16x6_kernel (dh and the transposed weight planes split into three bf16 planes each, six plane products,
+    leaky mask in the epilogue): given the kernel's own dh and a3, dz3 against the float64 product, in rounding units of
+    sum_k |dh_k w_k| and beside torch's fp32 matmul."""
+    n = 200
+    w = _bwd_setup(hp, n, 41)
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        dh = hp.debug_buffer(7, (512,), n, enc).cpu()
+        a3 = hp.debug_buffer(2, (3136,), n, enc).cpu()
+        dz3 = hp.debug_buffer(6, (3136,), n, enc).cpu().numpy().astype(np.float64)
+        W = torch.from_numpy(w[pre + ".linear.weight"])
+        ref = _leaky_mask(a3.double(), dh.double() @ W.double()).numpy()
+        f32 = _leaky_mask(a3, dh @ W).numpy().astype(np.float64)
+        err_kernel, err_f32 = np.abs(dz3 - ref).max(), np.abs(f32 - ref).max()
+        mass = float((dh.double().abs() @ W.double().abs()).max())
+        P.MARGINS.check("accuracy", "dense_dgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
+        # mean error beside torch's fp32 operator (a bf16x6 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
+        P.MARGINS.check("accuracy", "dense_dgrad_mean_vs_torch_fp32", np.abs(dz3 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
+
+
+def test_conv3_data_gradient_is_at_least_fp32_accurate(hp):
+    """conv_dgrad3_bf16x6_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
+    against float64."""
+    n = 101
+    w = _bwd_setup(hp, n, 42)
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        dz3 = hp.debug_buffer(6, (64, 7, 7), n, enc).cpu()
+        a2 = hp.debug_buffer(1, (64, 9, 9), n, enc).cpu()
+        dz2 = hp.debug_buffer(5, (64, 9, 9), n, enc).cpu().numpy().astype(np.float64)
+        W = torch.from_numpy(w[pre + ".conv3.weight"])
+        ct = torch.nn.functional.conv_transpose2d
+        ref = _leaky_mask(a2.double(), ct(dz3.double(), W.double())).numpy()
+        f32 = _leaky_mask(a2, ct(dz3, W)).numpy().astype(np.float64)
+        err_kernel, err_f32 = np.abs(dz2 - ref).max(), np.abs(f32 - ref).max()
+        mass = float(ct(dz3.double().abs(), W.double().abs()).max())
+        P.MARGINS.check("accuracy", "conv3_dgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
+        # mean error beside torch's fp32 operator (a bf16x6 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
+        P.MARGINS.check("accuracy", "conv3_dgrad_mean_vs_torch_fp32", np.abs(dz2 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
+
+
+def test_conv2_data_gradient_is_at_least_fp32_accurate(hp):
+    """conv_dgrad2_bf16x6_kernel: given the kernel's own dz2, the RAW gradient w.r.t. a1 (conv1's leaky mask is applied
+    later, by the conv1 weight gradient) = conv_transpose(dz2, W2, stride 2) against float64."""
+    n = 100
+    w = _bwd_setup(hp, n, 43)
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        dz2 = hp.debug_buffer(5, (64, 9, 9), n, enc).cpu()
+        da1 = hp.debug_buffer(4, (32, 20, 20), n, enc).cpu().numpy().astype(np.float64)
+        W = torch.from_numpy(w[pre + ".conv2.weight"])
+        ct = torch.nn.functional.conv_transpose2d
+        ref = ct(dz2.double(), W.double(), stride=2).numpy()
+        f32 = ct(dz2, W, stride=2).numpy().astype(np.float64)
+        err_kernel, err_f32 = np.abs(da1 - ref).max(), np.abs(f32 - ref).max()
+        mass = float(ct(dz2.double().abs(), W.double().abs(), stride=2).max())
+        P.MARGINS.check("accuracy", "conv2_dgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
+        # mean error beside torch's fp32 operator (a bf16x6 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
+        P.MARGINS.check("accuracy", "conv2_dgrad_mean_vs_torch_fp32", np.abs(da1 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
 def _adopt_kernel_decisions(h, net, n, x):

@@ -335,3 +335,15 @@ def test_gail_oracle_float64_trajectory_pinned(name):
         for k, a in tr["params"][tag].items():
             np.testing.assert_allclose(np.sqrt((a ** 2).sum()), g["f64_l2/%s/%s" % (tag, k)], rtol=1e-12)
             np.testing.assert_allclose(a.ravel()[:8], g["f64_head/%s/%s" % (tag, k)], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["f13_nav1d_gauss", "f14_navped_shared", "f15_mlp_classical"])
+def test_nav_oracle_float64_trajectory_pinned(name):
+    import parity_util as P
+    sp = P._load(name[:3] + "b_spread")
+    tr = P.nav_f64_trajectory(name)
+    np.testing.assert_allclose(tr["losses"], sp["losses_f64"], rtol=1e-10, atol=1e-12)
+    for it in (1, 10):
+        for k, a in tr["params"][it].items():
+            np.testing.assert_allclose(np.sqrt((a ** 2).sum()), sp["f64_l2/it%d/%s" % (it, k)], rtol=1e-11)
+            np.testing.assert_allclose(a.ravel()[:8], sp["f64_head/it%d/%s" % (it, k)], rtol=0, atol=1e-12)
