@@ -44,46 +44,97 @@ HBM_BYTES = {
 }
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Reference-equivalent CPU path (the oracle: torch-CPU restatement pinned to the reference
-    by tests/golden) timed on this host: forward at n=256 and PPO iterations at B=1024."""
+def _host_cpu():
+    """(model string, logical CPUs, physical cores) of this host from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, logical, (len(cores) or logical)
+
+
+def _timed(fn, warm, reps, budget_s):
+    """median / p95 (ms) of fn() over up to `reps` repetitions, at least 2, stopping early when `budget_s` is spent."""
+    for _ in range(warm):
+        fn()
+    ts, t_start = [], time.perf_counter()
+    while len(ts) < reps and (len(ts) < 2 or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return {"median_ms": round(float(np.median(ts)), 4), "p95_ms": round(float(np.percentile(ts, 95)), 4), "reps": len(ts)}
+
+
+def cpu_baseline():
+    """Reference-equivalent CPU path (the oracle: torch-CPU restatement pinned to the reference by tests/golden) timed on
+    this host as BASELINE.md section 3 lays out: PPO iterations at B = 1024 and 2048, forward at n = 4 and 256, GAE at
+    N = 8 and 256 (T = 256), with k = all physical cores and k = 1, median + p95 of >= 10 repetitions where the bounded
+    sample allows (every figure states its repetition count; about a minute of CPU work in total)."""
     from ddrl4nav_amd.utils.recipe import make_weights
     from oracle import ddrl_oracle as O
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    model, logical, physical = _host_cpu()
     rng = np.random.default_rng(1234)
-    net = O.OraclePPO()
-    net.load_weights(make_weights(0))
-    nf, B = 256, 1024
-    x = O.frames_to_f32(rng.integers(0, 256, size=(B, 4, 84, 84), dtype=np.uint8))
-    with torch.no_grad():
-        net(x[:nf])
-        t0 = time.perf_counter()
-        reps = 0
-        while reps < 3 or (time.perf_counter() - t0 < seconds_budget * 0.2 and reps < 20):
-            net(x[:nf])
-            reps += 1
-        t_fwd = (time.perf_counter() - t0) / reps / nf  # s per env-step
-    acts = torch.from_numpy(rng.integers(0, 6, size=B).astype(np.float32))
-    old = torch.full((B,), -1.79, dtype=torch.float32)
-    adv = torch.from_numpy(rng.normal(size=B).astype(np.float32))
-    ret = torch.from_numpy(rng.normal(size=B).astype(np.float32))
-    opt = net.make_optims()
-    gen = O.learn(net, opt, x, acts, old, adv, ret, iters=100)
-    next(gen)  # warm-up iteration
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < 2 or (time.perf_counter() - t0 < seconds_budget * 0.8 and iters < 40):
-        next(gen)
-        iters += 1
-    t_iter = (time.perf_counter() - t0) / iters / B  # s per sample per iteration
-    per_env_step = t_fwd + 10 * t_iter
-    out = {"value": round(1.0 / per_env_step, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
-           "sample": "oracle (torch-CPU fp32 restatement of PPO.forward/learn): forward n=256 x%d, "
-                     "PPO iteration B=1024 x%d; per env-step = 1 forward + 10 iterations" % (reps, iters),
-           "forward_samples_per_s": round(1.0 / t_fwd, 1), "ppo_iter_ms_B1024": round(t_iter * B * 1e3, 2),
-           "host_cpus": cores}
+    Bmax = 2048
+    x = O.frames_to_f32(rng.integers(0, 256, size=(Bmax, 4, 84, 84), dtype=np.uint8))
+    acts = torch.from_numpy(rng.integers(0, 6, size=Bmax).astype(np.float32))
+    old = torch.full((Bmax,), -1.79, dtype=torch.float32)
+    adv = torch.from_numpy(rng.normal(size=Bmax).astype(np.float32))
+    ret = torch.from_numpy(rng.normal(size=Bmax).astype(np.float32))
+    T = 256
+    gae_in = {}
+    for N in (8, 256):
+        u = rng.random((T, N))
+        gae_in[N] = (rng.normal(size=(T + 1, N)).astype(np.float32),
+                     np.where(u < 0.01, -1.0, np.where(u > 0.99, 1.0, 0.0)).astype(np.float32),
+                     (rng.random((T, N)) < 1.0 / 800).astype(np.uint8))
+
+    def leg(threads, full):
+        torch.set_num_threads(threads)
+        net = O.OraclePPO()
+        net.load_weights(make_weights(0))
+        out = {"threads": threads}
+        with torch.no_grad():
+            for n, reps in ((4, 20), (256, 10 if full else 3)):
+                r = _timed(lambda: net(x[:n]), 2 if full else 1, reps, 6.0)
+                r["samples_per_s"] = round(n / (r["median_ms"] * 1e-3), 1)
+                out["forward_n%d" % n] = r
+        for B, reps in ((1024, 10 if full else 2), (2048, 5 if full else 0)):
+            if reps == 0:
+                continue
+            gen = O.learn(net, net.make_optims(), x[:B], acts[:B], old[:B], adv[:B], ret[:B], iters=10 ** 6)
+            r = _timed(lambda: next(gen), 1, reps, 12.0 if full else 16.0)
+            r["update_ms_10_iters"] = round(10 * r["median_ms"], 2)
+            r["env_steps_per_s_equiv"] = round(B / (10 * r["median_ms"] * 1e-3), 1)   # B / update time (BASELINE.md section 3)
+            out["ppo_iter_B%d" % B] = r
+        if full:
+            for N in (8, 256):
+                out["gae_T256_N%d" % N] = _timed(lambda: O.gae(*gae_in[N]), 1, 10, 4.0)
+        return out
+
+    k_all = physical                 # BASELINE.md section 3: k = all physical host cores (and k = 1 for a per-core figure)
+    full, one = leg(k_all, True), leg(1, False)
+    t_fwd = full["forward_n256"]["median_ms"] * 1e-3 / 256
+    t_iter = full["ppo_iter_B1024"]["median_ms"] * 1e-3 / 1024
+    out = {"value": round(1.0 / (t_fwd + 10 * t_iter), 2), "unit": "env-steps/s", "cores": k_all, "kind": "port",
+           "sample": "oracle (torch-CPU fp32 restatement of PPO.forward / learn / GAE, pinned to the reference by tests/golden) on "
+                     "synthetic inputs (rng 1234): value = 1 / (forward n=256 per sample + 10 x PPO iteration B=1024 per sample) at "
+                     "%d threads; every figure below is a median over `reps` repetitions" % k_all,
+           "cpu_model": model, "host_logical_cpus": logical, "host_physical_cores": physical,
+           "torch_threads_used": k_all, "k_all": full, "k_1": one}
+    torch.set_num_threads(k_all)
     out["same_gpu_torch"] = torch_rocm_baseline_child()
     return out
 
@@ -239,6 +290,75 @@ def async_actor_leg(net, config_nn, N, T, ITERS, dev, steps=3):
                     "reference's default asynchronous deployment (SYNC=False); same work per step as `value`"}
 
 
+def ingest_leg(net, ro, N, T, steps=2, host_memcpy=False):
+    """SURVEY.md section 8d(i) with the H2D on the clock: the frames of every acting step arrive through the pinned-host
+    ring (ddrl_ring_*: a producer thread commits one [N,4,84,84] uint8 slot per step, the consumer issues hipMemcpyAsync
+    on a copy stream into the device pool, the forward waits for that copy and overlaps the next one).  By default the
+    producer commits slots that already hold frames -- env workers write into the pinned slots themselves --;
+    host_memcpy=True adds a host-side copy of the 7.2 MB per step into the slot.  Same step otherwise."""
+    import threading
+    from ddrl4nav_amd.data import PinnedRing
+    slot = N * 4 * 84 * 84
+    ring = PinnedRing(slot, n_slots=16)
+    rng = np.random.default_rng(4321)
+    pool = [rng.integers(0, 256, size=slot, dtype=np.uint8) for _ in range(4)] if host_memcpy else None
+    for _ in range(16):              # every slot holds frames before the clock starts
+        buf = ring.acquire(timeout_ms=10000)
+        buf[:] = rng.integers(0, 256, size=slot, dtype=np.uint8)
+        ring.commit()
+    scratch = torch.empty(slot, dtype=torch.uint8, device=ro.frames.device)
+    for _ in range(16):
+        ring.pop_to(scratch)
+    torch.cuda.synchronize()
+    total = (steps + 1) * (T + 1)
+    err = []
+
+    def producer():
+        try:
+            for i in range(total):
+                buf = ring.acquire(timeout_ms=60000)
+                if pool is not None:
+                    buf[:] = pool[i % 4]
+                ring.commit()
+        except Exception as e:  # surfaced by the consumer's timeout
+            err.append(e)
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    act_ms = []
+
+    def step():
+        ev0.record()
+        for t in range(T + 1):
+            ro.put_frames_from_ring(t, ring)
+            if t < T:
+                ro.act(t)
+        ro.bootstrap()
+        ev1.record()
+        ro.finish()
+        for _ in net.learn(ro.batch()):
+            pass
+        torch.cuda.synchronize()
+        act_ms.append(ev0.elapsed_time(ev1))
+
+    step()                           # warm-up
+    act_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    th.join(10)
+    ring.close()
+    a = float(np.mean(act_ms))
+    return {"value": round(steps * N * T / elapsed, 1), "unit": "env-steps/s", "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "steps": steps, "acting_ms_per_rollout": round(a, 2), "h2d_bytes_per_rollout": slot * (T + 1),
+            "h2d_gbps_over_acting_phase": round(slot * (T + 1) / (a * 1e-3) / 1e9, 2), "host_memcpy_into_slot": bool(host_memcpy),
+            "producer_error": repr(err[0])[:120] if err else None,
+            "note": "frames of every acting step cross PCIe through the pinned ring inside the timed region; `value` (the headline) "
+                    "has them resident in HBM as the metric defines"}
+
+
 def build_net(n_envs, horizon, iters, max_batch=None):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
@@ -265,6 +385,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10, help="TRAINING_ITER_TIME")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-async", action="store_true", help="skip the asynchronous actor/learner leg")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the leg that feeds the frames through the pinned-host ring")
+    ap.add_argument("--ingest-memcpy", action="store_true", help="ingest leg: the producer also copies 7.2 MB per step into the slot")
     args = ap.parse_args()
 
     from ddrl4nav_amd.dist import broadcast_params, init_from_env
@@ -430,6 +552,13 @@ def main():
                 out["async_actor_learner"] = async_actor_leg(net, config_nn, N, T, ITERS, dev)
             except Exception as e:  # an extra, never allowed to take the headline line down
                 out["async_actor_learner"] = {"error": repr(e)[:200]}
+        if world == 1 and not args.no_ingest:
+            hp.profile(False)
+            try:
+                out["with_ingest"] = ingest_leg(net, ro, N, T, host_memcpy=args.ingest_memcpy)
+                out["value_with_ingest"] = out["with_ingest"]["value"]
+            except Exception as e:
+                out["with_ingest"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
