@@ -125,6 +125,13 @@ SIGNATURES = {
                                     c_int64, c_void_p, c_void_p]),
     "ddrl_op_relu_mask": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "ddrl_op_accumulate": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddrl_comm_unique_id": (c_int32, [c_void_p]),
+    "ddrl_comm_create": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_void_p)]),
+    "ddrl_comm_destroy": (c_int32, [c_void_p]),
+    "ddrl_allreduce_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddrl_broadcast_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "ddrl_grad_allreduce": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "ddrl_params_broadcast": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "ddrl_encoder_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "ddrl_encoder_backward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "ddrl_encoder_buffers": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),

@@ -262,6 +262,18 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   return check_launch();
 }
 
+int32_t ddrl_grad_allreduce(ddrl_ctx* ctx, ddrl_comm* comm, void* stream) {
+  if (!ctx || !comm) return DDRL_ERR_INVALID_ARG;
+  return ddrl_allreduce_f32(comm, ctx->grads, ctx->L.n_params + DDRL_STATS_FLOATS, stream);
+}
+
+int32_t ddrl_params_broadcast(ddrl_ctx* ctx, ddrl_comm* comm, int32_t root, void* stream) {
+  if (!ctx || !comm) return DDRL_ERR_INVALID_ARG;
+  int32_t s = ddrl_broadcast_f32(comm, ctx->params, ctx->L.n_params, root, stream);
+  ctx->dirty = true;
+  return s;
+}
+
 int32_t ddrl_encoder_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream) {
   if (!ctx || !frames || n < 1 || n > ctx->cfg.max_batch || ctx->L.NE != 1) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;

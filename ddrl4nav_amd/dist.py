@@ -74,3 +74,51 @@ def broadcast_params(flat, src=0, group=None):
         else:
             dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+class RcclComm:
+    """The C-ABI communicator (include/ddrl.h: ddrl_comm_*): RCCL without torch.distributed on the data path.  A
+    non-Python host exchanges the 128-byte id out of band; here rank 0's id travels through the already initialised
+    torch.distributed group (any backend) or is passed in.  `DDRL_ALLREDUCE=rccl` makes HotPath.allreduce_grads use it."""
+
+    def __init__(self, rank=0, world=1, unique_id=None, group=None):
+        from ctypes import byref, c_void_p, create_string_buffer
+        from . import _lib
+        self.lib, self.rank, self.world = _lib.load(), int(rank), int(world)
+        if unique_id is None:
+            buf = create_string_buffer(128)
+            if self.rank == 0:
+                _lib.check(self.lib.ddrl_comm_unique_id(buf))
+            ids = [bytes(buf.raw)]
+            if self.world > 1:
+                dist.broadcast_object_list(ids, src=0, group=group)
+            unique_id = ids[0]
+        assert len(unique_id) == 128
+        self.h = c_void_p()
+        _lib.check(self.lib.ddrl_comm_create(create_string_buffer(unique_id, 128), self.rank, self.world, byref(self.h)))
+
+    def allreduce(self, flat):
+        from ctypes import c_void_p
+        from . import _lib
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        _lib.check(self.lib.ddrl_allreduce_f32(self.h, c_void_p(flat.data_ptr()), flat.numel(),
+                                               c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return flat
+
+    def broadcast(self, flat, root=0):
+        from ctypes import c_void_p
+        from . import _lib
+        _lib.check(self.lib.ddrl_broadcast_f32(self.h, c_void_p(flat.data_ptr()), flat.numel(), int(root),
+                                               c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return flat
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ddrl_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -50,6 +50,13 @@ class HotPath:
         self.n_actions = int(n_actions)
         self.max_batch = int(max_batch)
         self._ar_events = None  # (start, stop) event pairs around the gradient all-reduce while time_allreduce(True)
+        self.comm = None        # dist.RcclComm: the C-ABI all-reduce (ddrl_grad_allreduce) instead of torch.distributed
+        import os
+        import torch.distributed as tdist
+        if os.environ.get("DDRL_ALLREDUCE") == "rccl" and tdist.is_available() and tdist.is_initialized() \
+                and tdist.get_world_size(process_group) > 1:
+            from .dist import RcclComm
+            self.comm = RcclComm(tdist.get_rank(process_group), tdist.get_world_size(process_group), group=process_group)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -152,12 +159,19 @@ class HotPath:
         """One RCCL all-reduce (sum) of the flat gradient arena + loss tail per PPO iteration
         (SURVEY.md section 8e); gradients were pre-scaled by 1/B_global."""
         from .dist import allreduce_flat
+
+        def run():
+            if self.comm is not None:
+                check(self.lib.ddrl_grad_allreduce(self.ctx, self.comm.h, _stream()))
+            else:
+                allreduce_flat(self.grads, self.process_group)
+
         if self._ar_events is None:
-            allreduce_flat(self.grads, self.process_group)
+            run()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        allreduce_flat(self.grads, self.process_group)
+        run()
         e1.record()
         self._ar_events.append((e0, e1))
 

@@ -50,6 +50,7 @@ extern "C" {
 
 typedef struct ddrl_ctx ddrl_ctx;
 typedef struct ddrl_ring ddrl_ring;
+typedef struct ddrl_comm ddrl_comm;
 
 /* Hyper-parameters: the ConfigNN contract (USTC_lab/config/config_nn.py:19-57). */
 typedef struct ddrl_config {
@@ -150,6 +151,25 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
  * Run after the (optional) all-reduce of the grad arena.  grads[n_params + 4] <- global grad
  * norm, grads[n_params + 5] <- clip coefficient, grads[n_params + 3] <- total loss. */
 int32_t ddrl_clip_adam_step(ddrl_ctx* ctx, void* stream);
+
+/* ---- multi-GPU: one process per GPU, env shards, full parameter / Adam replica per rank.
+ * The reference has no such path (USTC_lab/server/backward.py:167 "TODO support mutil GPU CARD").  A communicator wraps
+ * an RCCL communicator (librccl is resolved with dlopen at first use; DDRL_ERR_UNSUPPORTED when it is absent):
+ * rank 0 calls ddrl_comm_unique_id and hands the 128 bytes to the other ranks by any out-of-band means (a file, a TCP
+ * socket, MPI, torchrun's store), then every rank calls ddrl_comm_create.
+ *   ddrl_params_broadcast : make the replicas bit-identical at start-up (weights of `root`)
+ *   ddrl_grad_allreduce   : SUM all-reduce of the flat gradient arena + DDRL_STATS_FLOATS loss tail (13,487,420 B for the
+ *                           default net), between ddrl_ppo_iter (which scaled everything by 1/B_global) and
+ *                           ddrl_clip_adam_step: every rank then holds the full-batch mean gradient and loss shares, the clip
+ *                           sees the global norm (ppo.py:126) and the replicas stay in step.
+ * All calls are asynchronous on `stream`. */
+int32_t ddrl_comm_unique_id(uint8_t* out128);
+int32_t ddrl_comm_create(const uint8_t* id128, int32_t rank, int32_t world, ddrl_comm** out);
+int32_t ddrl_comm_destroy(ddrl_comm* comm);
+int32_t ddrl_allreduce_f32(ddrl_comm* comm, float* buf, int64_t count, void* stream);
+int32_t ddrl_broadcast_f32(ddrl_comm* comm, float* buf, int64_t count, int32_t root, void* stream);
+int32_t ddrl_grad_allreduce(ddrl_ctx* ctx, ddrl_comm* comm, void* stream);
+int32_t ddrl_params_broadcast(ddrl_ctx* ctx, ddrl_comm* comm, int32_t root, void* stream);
 
 /* float32(uint8/255.0) for all 256 byte values, computed with the conv1 loader's arithmetic
  * (reference: warputils.py:300 divides in float64, forward.py:102-104 casts to float32). */

@@ -80,8 +80,21 @@ int main(void) {
     CHECK(ddrl_forward(ctx, frames + t * fstep, N, NULL, 7, (uint64_t)t, probs, values + t * N, actions + t * N,
                        logps + t * N, NULL));
   CHECK(ddrl_gae(values, rewards, dones, T, N, 0.99f, 0.95f, adv, ret, NULL));
+  /* the multi-GPU step of INTEGRATION.md section 2 with a communicator of ONE rank (a one-GPU box cannot hold two RCCL
+   * ranks): unique id -> communicator -> parameter broadcast -> gradient all-reduce between ppo_iter and clip_adam */
+  uint8_t id[128];
+  ddrl_comm* comm = NULL;
+  int32_t cs = ddrl_comm_unique_id(id);
+  if (cs == DDRL_OK) {
+    CHECK(ddrl_comm_create(id, 0, 1, &comm));
+    CHECK(ddrl_params_broadcast(ctx, comm, 0, NULL));
+  } else if (cs != DDRL_ERR_UNSUPPORTED) { /* UNSUPPORTED = no librccl on this host */
+    fprintf(stderr, "ddrl_comm_unique_id -> %s\n", ddrl_status_string(cs));
+    return 5;
+  }
   for (int it = 0; it < 2; ++it) {
     CHECK(ddrl_ppo_iter(ctx, frames, actions, logps, adv, ret, B, B, NULL));
+    if (comm) CHECK(ddrl_grad_allreduce(ctx, comm, NULL));
     CHECK(ddrl_clip_adam_step(ctx, NULL));
   }
   HIP(hipDeviceSynchronize());
@@ -92,11 +105,13 @@ int main(void) {
   for (int j = 0; j < 6; ++j) psum += hprobs[j];
   int64_t step = 0;
   CHECK(ddrl_get_step(ctx, &step));
+  if (comm) CHECK(ddrl_comm_destroy(comm));
   CHECK(ddrl_ctx_destroy(ctx));
   if (!(fabsf(psum - 1.0f) < 1e-5f) || !isfinite(stats[0]) || !isfinite(stats[1]) || !(stats[2] > 0.f) || step != 2) {
     fprintf(stderr, "unexpected results: psum %g losses %g %g %g step %lld\n", psum, stats[0], stats[1], stats[2], (long long)step);
     return 4;
   }
+  printf("rccl communicator: %s\n", comm ? "used (1 rank)" : "librccl not found, skipped");
   printf("C ABI OK: actor_loss %.6f v_loss %.6f entropy %.6f grad_norm %.6f\n", stats[0], stats[1], stats[2], stats[4]);
   return 0;
 }

@@ -389,3 +389,34 @@ def test_init_weight_refreshes_packed_weights(net):
     np.testing.assert_allclose(p1.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(v1[0].cpu().numpy(), ov.numpy(), rtol=1e-5, atol=2e-6)
     net.load_state_dict(w0)
+
+
+def test_rccl_communicator_through_the_c_abi(net):
+    """ddrl_comm_* / ddrl_grad_allreduce / ddrl_params_broadcast with a communicator of one rank (a one-GPU box cannot hold
+    two RCCL ranks; the N > 1 arithmetic is covered by tests/test_dist_gpu.py over gloo): SUM over one rank is the identity,
+    bit for bit, and the learner step runs with the collective between ppo_iter and clip_adam."""
+    from ctypes import c_void_p
+    from ddrl4nav_amd._lib import check
+    from ddrl4nav_amd.dist import RcclComm
+    hp = net.hot_path
+    comm = RcclComm(0, 1)
+    x = torch.randn(100003, device="cuda")
+    want = x.clone()
+    comm.allreduce(x)
+    comm.broadcast(x, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    rng = np.random.default_rng(9)
+    n = 32
+    frames = torch.from_numpy(rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)).cuda()
+    f = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
+    args = (frames, f(rng.integers(0, 6, size=n)), f(np.full(n, -1.79)), f(rng.normal(size=n)), f(rng.normal(size=n)))
+    hp.ppo_iter(*args)
+    before = hp.grads.clone()
+    s = c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(hp.lib.ddrl_grad_allreduce(hp.ctx, comm.h, s))
+    check(hp.lib.ddrl_params_broadcast(hp.ctx, comm.h, 0, s))
+    torch.cuda.synchronize()
+    assert torch.equal(hp.grads, before)
+    comm.close()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
