@@ -126,15 +126,34 @@ def cpu_baseline():
 
     k_all = physical                 # k = all physical host cores (and k = 1 for a per-core figure)
     full, one = leg(k_all, True), leg(1, False)
-    t_fwd = full["forward_n256"]["median_ms"] * 1e-3 / 256
-    t_iter = full["ppo_iter_B1024"]["median_ms"] * 1e-3 / 1024
-    out = {"value": round(1.0 / (t_fwd + 10 * t_iter), 2), "unit": "env-steps/s", "cores": k_all, "kind": "port",
+
+    def per_env_step(d):
+        return d["forward_n256"]["median_ms"] * 1e-3 / 256 + 10 * d["ppo_iter_B1024"]["median_ms"] * 1e-3 / 1024
+
+    # torch's CPU convolutions do not scale to a whole 128-core host at these batch sizes (measured: 128 threads are slower
+    # than one): a short sweep finds the thread count at which the reference-equivalent code is FASTEST, and `value` uses it
+    sweep = {}
+    for k in sorted({k for k in (8, 16, 32, 64) if k < k_all}):
+        torch.set_num_threads(k)
+        net = O.OraclePPO()
+        net.load_weights(make_weights(0))
+        with torch.no_grad():
+            f = _timed(lambda: net(x[:256]), 1, 3, 2.0)
+        gen = O.learn(net, net.make_optims(), x[:1024], acts[:1024], old[:1024], adv[:1024], ret[:1024], iters=10 ** 6)
+        sweep[k] = {"threads": k, "forward_n256": f, "ppo_iter_B1024": _timed(lambda: next(gen), 1, 3, 4.0)}
+    cands = dict(sweep, **{k_all: full, 1: one})
+    best = min(cands, key=lambda k: per_env_step(cands[k]))
+    out = {"value": round(1.0 / per_env_step(cands[best]), 2), "unit": "env-steps/s", "cores": best, "kind": "port",
            "sample": "oracle (torch-CPU fp32 restatement of PPO.forward / learn / GAE, pinned to the reference by tests/golden) on "
                      "synthetic inputs (rng 1234): value = 1 / (forward n=256 per sample + 10 x PPO iteration B=1024 per sample) at "
-                     "%d threads; every figure below is a median over `reps` repetitions" % k_all,
+                     "the fastest thread count of {1, 8, 16, 32, 64, all physical cores} = %d; k_all / k_1 are the legs "
+                     "BASELINE.md section 3 prescribes; every figure is a median over `reps` repetitions" % best,
            "cpu_model": model, "host_logical_cpus": logical, "host_physical_cores": physical,
-           "torch_threads_used": k_all, "k_all": full, "k_1": one}
-    torch.set_num_threads(k_all)
+           "torch_threads_used": best, "value_at_all_physical_cores": round(1.0 / per_env_step(full), 2),
+           "value_at_one_core": round(1.0 / per_env_step(one), 2), "k_all": full, "k_1": one,
+           "k_sweep": {str(k): {"forward_n256_ms": v["forward_n256"]["median_ms"], "ppo_iter_B1024_ms": v["ppo_iter_B1024"]["median_ms"],
+                                "env_steps_per_s": round(1.0 / per_env_step(v), 2)} for k, v in sweep.items()}}
+    torch.set_num_threads(best)
     out["same_gpu_torch"] = torch_rocm_baseline_child()
     return out
 

@@ -420,3 +420,56 @@ def test_rccl_communicator_through_the_c_abi(net):
     assert torch.equal(hp.grads, before)
     comm.close()
     net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+
+
+def test_backward_trainer_publish_save_and_checkpoint_offsets(net, golden, tmp_path):
+    """The consumer loop of BackwardTrainThread.run (backward.py:168-217): publish at start and every
+    MODEL_TO_REDIS_FREQUENCY updates, checkpoint every SAVE_FREQUENCY, LOAD_CHECKPOINT restores + offsets the counter."""
+    from ddrl4nav_amd.data import Experience
+    from ddrl4nav_amd.server import BackwardTrainer
+    c = _configs()
+    cfg, cfg_nn = c["config"], c["config_nn"]
+    cfg.SAVE_MODEL_PATH, cfg.SAVE_FREQUENCY, cfg.LOG_LOSS_FREQUENCY = str(tmp_path / "pong"), 5, 2
+    assert cfg_nn.MODEL_TO_REDIS_FREQUENCY == 10 and cfg.UPDATE_TAG_KEY == "UPDATE_TAG"
+    store, ops = {}, []
+
+    class Pipe:
+        def set(self, k, v):
+            store[k] = v
+            ops.append(("set", k))
+
+        def incr(self, k):
+            store[k] = store.get(k, 0) + 1
+
+        def execute(self):
+            ops.append(("exec", None))
+
+    g3 = golden("f3_loss")
+    w0 = {k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()}
+    net.load_state_dict(w0)
+    net.hot_path.reset_optimizer()
+    net.update_time = 0
+    logged = []
+    tr = BackwardTrainer(net, cfg, cfg_nn, pipe=Pipe(), log=lambda k, v, t: logged.append((k, t)))
+    batch = lambda: Experience(states=[g3["frames"]], advs=g3["advs"], actions=g3["actions"], old_logps=g3["old_logps"],
+                               values=g3["rets"].reshape(1, -1))
+    assert tr.consume(batch(), {"RewardEpisode": 1.0}) == 10
+    tag = cfg.TASK_NAME + cfg.UPDATE_TAG_KEY
+    assert tr.published == 2 and store[tag] == 2                 # at start + after update 10 (backward.py:179,196-197)
+    assert store[net.model_key] == net.model_bytes()            # the published blob is the current arena
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["pong_10.pt", "pong_5.pt"] and tr.saved == 2
+    assert store[cfg.TASK_NAME + cfg.TRAIN_LOCK_KEY] == 0 and tr.data_len == 64
+    assert [t for k, t in logged if k == "VLoss"] == [2, 4, 6, 8, 10] and ("RewardEpisode", 64) in logged
+    # resume: LOAD_CHECKPOINT restores pong_5.pt and offsets every update_time by LOAD_EPISODE
+    after10 = net.hot_path.params.clone()
+    cfg.LOAD_CHECKPOINT, cfg.LOAD_CHECKPOINT_PATH, cfg.LOAD_EPISODE = True, str(tmp_path / "pong_5.pt"), 5
+    net.update_time = 0
+    tr2 = BackwardTrainer(net, cfg, cfg_nn, pipe=Pipe())
+    tr2.start()
+    assert not torch.equal(net.hot_path.params, after10)          # the 5-update checkpoint is back
+    sd5 = torch.load(str(tmp_path / "pong_5.pt"))
+    assert torch.equal(dict(net.named_parameters())["critic.pre.linear.bias"].detach().cpu(), sd5["critic.pre.linear.bias"].cpu())
+    assert tr2.consume(batch()) == 15
+    assert (tmp_path / "pong_15.pt").exists() and tr2.published == 2   # start + update 10 (5 + 5)
+    cfg.LOAD_CHECKPOINT = False
+    net.load_state_dict(w0)
