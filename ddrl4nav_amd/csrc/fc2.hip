@@ -638,6 +638,153 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense-layer weight gradient as bf16x6:  part[s][e][n][k] = sum_{b in split s} dh[b][n] a3[b][k]  (+ the bias partial).
+// Both operands are "reduction-major" in memory ([b][n] and [b][k]): they are staged as they lie -- rows = 32 samples of
+// the k-block, 128 columns, split into three bf16 planes on the way into LDS -- and the MFMA fragments (8 consecutive
+// SAMPLES of one column per lane) are read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group
+// fetches a 4-row x 16-column block and every lane receives one column of it, two reads per fragment.
+// Image row pitch 320 B = 256 B of data + 64 B pad: the four rows of a block fall into the four bank quarters, so the
+// two groups of a 32-lane half (32 columns x 4 rows = 256 B) read conflict-free.
+// 128 x 128 tile, 4 waves as 2 x 2 of 64 x 64, k-block = 32 samples = 2 MFMA k-groups, ONE LDS stage; the next k-block
+// waits in registers and is split + committed between two barriers while the CU's other workgroup computes.
+// ------------------------------------------------------------------------------------------------
+using s4v = __attribute__((ext_vector_type(4))) short;
+struct FcWgradB {
+  static constexpr int KB = 32, PITCH = 320, PLANE = KB * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
+  static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena (= FcWgrad2::SLAB)
+};
+
+__device__ __forceinline__ bf8f tr_fragment(const char* lds, int byte_off) {
+  typedef s4v __attribute__((address_space(3))) * lds_s4;
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + byte_off));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + byte_off + 4 * FcWgradB::PITCH));
+  typedef __attribute__((ext_vector_type(8))) short s8v;
+  const s8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf8f, v);
+}
+
+__global__ __launch_bounds__(256) void fc_wgrad_bf16x6_kernel(const float* __restrict__ dh, int64_t dh_es, const float* __restrict__ a3,
+                                                              int64_t a3_es, float* __restrict__ part, int n, int nsplit, int ne) {
+  using K = FcWgradB;
+  extern __shared__ __attribute__((aligned(16))) char ldsw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int e = blockIdx.z % ne, split = blockIdx.z / ne;
+  const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  const int nkb = (n + K::KB - 1) / K::KB;
+  const int per = (nkb + nsplit - 1) / nsplit;
+  const int kb_begin = split * per, kb_end = min(nkb, kb_begin + per);
+  // staging map: thread -> 4 columns (c4) of rows kk + 8 j of the k-block
+  const int c4 = tid & 31, kk = tid >> 5;
+  const float* dsrc = dh + e * dh_es + n0 + c4 * 4;
+  const float* asrc = a3 + e * a3_es + min(k0 + c4 * 4, FLAT - 4);   // columns past the matrix re-read its last quad (never stored)
+  // fragment addresses: 16-lane group g16 covers columns 16 (g16 & 1) .. +15 of the 32-column fragment and samples
+  // 8 (g16 >> 1) .. +3 (second read: +4); inside the group lane 4 q + p supplies row q, columns 4 p .. 4 p + 3
+  const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  int aA[2], bB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aA[i] = (8 * (g16 >> 1) + q) * K::PITCH + (wr * 64 + i * 32 + 16 * (g16 & 1) + 4 * pp) * 2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (8 * (g16 >> 1) + q) * K::PITCH + (wc * 64 + j * 32 + 16 * (g16 & 1) + 4 * pp) * 2;
+  f4 dr[4], ar[4];
+  f4 bsum = zero4();
+  const bool bias_owner = (blockIdx.x == 0);
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = min(kb * K::KB + kk + 8 * j, n - 1);  // unconditional loads from clamped rows; masked at commit
+      dr[j] = ld4(dsrc + row * FEAT);
+      ar[j] = ld4(asrc + row * FLAT);
+    }
+  };
+  auto commit = [&](int kb) {
+    if (kb * K::KB + K::KB > n) {  // ragged last k-block: samples >= n contribute zero
+      rare_path();
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (kb * K::KB + kk + 8 * j >= n) dr[j] = zero4();
+      rare_path();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* d = ldsw + (kk + 8 * j) * K::PITCH + c4 * 8;
+      unsigned p0a, p0b, p1a, p1b, p2a, p2b;
+      split_bf16x3(dr[j].x, dr[j].y, p0a, p1a, p2a);
+      split_bf16x3(dr[j].z, dr[j].w, p0b, p1b, p2b);
+      *(uint2*)(d) = make_uint2(p0a, p0b);
+      *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
+      *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+      split_bf16x3(ar[j].x, ar[j].y, p0a, p1a, p2a);
+      split_bf16x3(ar[j].z, ar[j].w, p0b, p1b, p2b);
+      *(uint2*)(d + K::B_OFF) = make_uint2(p0a, p0b);
+      *(uint2*)(d + K::B_OFF + K::PLANE) = make_uint2(p1a, p1b);
+      *(uint2*)(d + K::B_OFF + 2 * K::PLANE) = make_uint2(p2a, p2b);
+    }
+    if (bias_owner) bsum += (dr[0] + dr[1]) + (dr[2] + dr[3]);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  if (kb_begin < kb_end) {
+    fetch(kb_begin);
+    commit(kb_begin);
+    if (kb_begin + 1 < kb_end) fetch(kb_begin + 1);
+    __syncthreads();
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        bf8f a[3][2], b[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[p][i] = tr_fragment(ldsw, aA[i] + p * K::PLANE + kg * 16 * K::PITCH);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[p][j] = tr_fragment(ldsw, bB[j] + p * K::PLANE + kg * 16 * K::PITCH);
+        }
+        DDRL_BF16X6_PRODUCTS;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();  // every wave is done with the stage
+      if (kb + 1 < kb_end) {
+        commit(kb + 1);
+        if (kb + 2 < kb_end) fetch(kb + 2);
+      }
+      __syncthreads();
+    }
+  }
+  float* slab = part + ((int64_t)split * 2 + e) * K::SLAB;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = k0 + wc * 64 + j * 32 + l31;
+    if (k >= FLAT) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[(int64_t)(n0 + wr * 64 + i * 32 + acc_row(r, hi)) * FLAT + k] = acc[i][j][r];
+  }
+  if (bias_owner) {  // one column tile per (row tile, split, e) owns the bias partial
+    float* red = (float*)ldsw;
+    st4(red + kk * 128 + c4 * 4, bsum);
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s += red[t * 128 + tid];
+      slab[(int64_t)FEAT * FLAT + n0 + tid] = s;
+    }
+  }
+}
+
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int part) {  // part: 0 = both, 1 = data gradient only, 2 = weight gradient only
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -646,7 +793,18 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
   if (part != 1) {
     FcWgrad2::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S, L.NE};
     ProfRange pr(c.prof, "FcWgrad", st);
+#ifndef DDRL_FCWGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCWGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+    static bool configured_w = false;
+    if (!configured_w) {
+      (void)hipFuncSetAttribute((const void*)fc_wgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcWgradB::LDS_BYTES);
+      configured_w = true;
+    }
+    hipLaunchKernelGGL(fc_wgrad_bf16x6_kernel, dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
+                       MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S, L.NE);
+    (void)p;
+#else
     launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), p, st);
+#endif
   }
   if (part != 1) {
     ProfRange pr(c.prof, "reduce_partials", st);

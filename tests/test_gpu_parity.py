@@ -465,6 +465,28 @@ def test_dense_data_gradient_is_at_least_fp32_accurate(hp):
         P.MARGINS.check("accuracy", "dense_dgrad_mean_vs_torch_fp32", np.abs(dz3 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
+def test_dense_weight_gradient_is_at_least_fp32_accurate(hp):
+    """fc_wgrad_bf16x6_kernel (dh and a3 split into three bf16 planes while staged, fragments through the transposing LDS
+    read, six plane products, split over the batch and summed in fixed order): given the kernel's own dh and a3,
+    dW = dh^T a3 and db = column sums of dh against float64, beside torch's fp32 matmul.  n = 333 leaves a ragged last
+    k-block and k-tile 24 is the half-empty one (3136 = 24.5 x 128)."""
+    n = 333
+    _bwd_setup(hp, n, 44)
+    got = _grad_views(hp)
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        dh = hp.debug_buffer(7, (512,), n, enc).cpu()
+        a3 = hp.debug_buffer(2, (3136,), n, enc).cpu()
+        ref = (dh.double().T @ a3.double()).numpy()
+        f32 = (dh.T @ a3).numpy().astype(np.float64)
+        k = got[pre + ".linear.weight"].astype(np.float64)
+        err_kernel, err_f32 = np.abs(k - ref).max(), np.abs(f32 - ref).max()
+        mass = float((dh.double().abs().T @ a3.double().abs()).max())
+        P.MARGINS.check("accuracy", "dense_wgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
+        P.MARGINS.check("accuracy", "dense_wgrad_mean_vs_torch_fp32", np.abs(k - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
+        db = got[pre + ".linear.bias"].astype(np.float64)
+        np.testing.assert_allclose(db, dh.double().sum(0).numpy(), rtol=0, atol=4 * 2.0 ** -24 * float(dh.double().abs().sum(0).max()))
+
+
 def test_conv3_data_gradient_is_at_least_fp32_accurate(hp):
     """conv_dgrad3_bf16x6_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
     against float64."""
