@@ -476,16 +476,231 @@ struct ConvWgrad3v2 {
 };
 
 // ================================================================================================
+// ================================================================================================
+// conv3 weight gradient as bf16x6 (both operands fp32: dz3 and a2, split into three bf16 planes while staged, six plane
+// products, fp32 accumulation):
+//   part[s][e][oc][ic][tap] = sum_{b in split s} sum_p dz3[b][oc][p] * a2[b][ic][pos(p, tap)],   pos = (p/7 + ky) 9 + p%7 + kx
+// GEMM rows = oc (64), columns = (tap, ic) (9 x 64), reduction index kappa = (sample, output pixel).
+// The reduction index is the SLOW index of both operands in memory.  gfx950's transposing LDS read
+// (ds_read_b64_tr_b16) removes the need for a k-contiguous layout: every lane of a 16-lane group supplies the address
+// of 4 contiguous 16-bit elements (one of 4 "rows" x 4 chunks) and receives one column of the 4 rows, so an MFMA
+// fragment's 8 k-values may sit ANYWHERE in LDS as long as 4 neighbouring lanes (channels) are contiguous.  Both blocks
+// are therefore staged channel-innermost -- dz3 as [kappa][64 oc], a2 as [sample pixel][64 ic], 128-byte rows -- and
+// a lane's k-values are 8 consecutive kappa: rows kappa (dz3) and rows rho(kappa) + tap offset (a2), rho from a table.
+// One stage = 2 whole samples = 98 kappa = 7 k-groups (the last one 2/16 full: 12.5 % of the MFMAs meet zero rows).
+// A workgroup owns the WHOLE 64 x 576 gradient: wave (i, j) = (oc half, ic half) x 9 taps = 9 fragment tiles, so every
+// staged element is used by all 9 taps and 32 channels; 256 workgroups = 128 sample splits x 2 encoders, slabs summed in
+// fixed order by reduce_partials.  LDS: 3 x 14 KB (dz3, rows 98..111 zero) + 3 x 20.25 KB (a2) = 103 KB, one stage; the
+// next stage waits in registers (80 VGPRs) and is split + committed between two barriers.
+// dz3 rows carry a half-swap swizzle (64-byte halves swapped on rows with bit 1 set) so that the four rows of a read
+// fall into four different bank quarters; the a2 rows are read 2-way conflicted (their row index varies with the tap).
+// ================================================================================================
+using s4w = __attribute__((ext_vector_type(4))) short;
+using bf8w = __attribute__((ext_vector_type(8))) __bf16;
+using u4w = __attribute__((ext_vector_type(4))) unsigned;
+struct Wgrad3B {
+  static constexpr int NB = 2, KAPPA = NB * 49, NKG = 7, AROWS = NKG * 16, BROWS = NB * 81;
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 128, B_OFF = 3 * A_PLANE;
+  static constexpr int LDS_BYTES = 3 * A_PLANE + 3 * B_PLANE;      // 43,008 + 62,208
+  static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 8;   // (row, 8-channel group) staging units: 784 / 1,296
+  static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;  // per thread: 4 / 6
+  static constexpr int64_t SLAB = 64 * 576 + 64;
+};
+
+__device__ __forceinline__ bf8w tr_frag3(const char* lds, int off_lo, int off_hi) {
+  typedef s4w __attribute__((address_space(3))) * lds_s4;
+  const s4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + off_lo));
+  const s4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + off_hi));
+  typedef __attribute__((ext_vector_type(8))) short s8w;
+  return __builtin_bit_cast(bf8w, (s8w)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const float* __restrict__ dz3,
+                                                                 int64_t dz_es, float* __restrict__ part, int n, int nsplit, int ne) {
+  using K = Wgrad3B;
+  extern __shared__ __attribute__((aligned(16))) char ldsw3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int e = blockIdx.x % ne, split = blockIdx.x / ne;
+  const int nst = (n + K::NB - 1) / K::NB;
+  const int per = (nst + nsplit - 1) / nsplit;
+  const int st_begin = split * per, st_end = min(nst, st_begin + per);
+  // zero rows of the dz3 image (kappa >= 98): written once
+  for (int i = tid; i < 3 * (K::AROWS - K::KAPPA) * 8; i += 256) {
+    const int pl = i / ((K::AROWS - K::KAPPA) * 8), r = i % ((K::AROWS - K::KAPPA) * 8);
+    *(u4w*)(ldsw3 + pl * K::A_PLANE + K::KAPPA * 128 + r * 16) = (u4w){0u, 0u, 0u, 0u};
+  }
+  // ---- staging maps: unit u = tid + 256 t -> (8-channel group u / rows, row u % rows); a lane's neighbours hold
+  // neighbouring pixels of the same channels (coalesced dword loads at stride 49 / 81 floats over the 8 channels)
+  const float* asrc[K::NA];
+  const float* bsrc[K::NBU];
+  int awr[K::NA], bwr[K::NBU], asmp[K::NA], bsmp[K::NBU];
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t) {
+    const int u = min(tid + 256 * t, K::A_UNITS - 1);
+    const int c8 = u / K::KAPPA, kap = u % K::KAPPA, bl = kap / 49, px = kap % 49;
+    asmp[t] = bl;
+    asrc[t] = dz3 + e * dz_es + (c8 * 8) * 49 + px;                                 // + sample * FLAT, + c * 49
+    awr[t] = kap * 128 + ((c8 * 16) ^ (((kap >> 1) & 1) * 64));
+  }
+#pragma unroll
+  for (int t = 0; t < K::NBU; ++t) {
+    const int u = min(tid + 256 * t, K::B_UNITS - 1);
+    const int c8 = u / K::BROWS, rho = u % K::BROWS, bl = rho / 81, pos = rho % 81;
+    bsmp[t] = bl;
+    bsrc[t] = a2 + e * a2_es + (c8 * 8) * 81 + pos;                                 // + sample * 5184, + c * 81
+    bwr[t] = K::B_OFF + rho * 128 + c8 * 16;
+  }
+  // ---- fragment addresses.  16-lane group g16: columns 16 (g16 & 1) .. +15 of the 32-channel fragment, k-values
+  // 8 (g16 >> 1) .. +7; inside the group lane 4 q + pp supplies row q (first read) / q + 4 (second), chunk pp.
+  const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int sw = (q >> 1) & 1;  // the half swap of rows kappa = 16 g + 8 h + q (+4): bit 1 of kappa = bit 1 of q
+  const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
+  const int b_lane = K::B_OFF + wj * 64 + (g16 & 1) * 32 + pp * 8;
+  int brow[K::NKG][2];  // byte offset of the a2 row that belongs to this lane's kappa (tap 0), first / second read
+#pragma unroll
+  for (int g = 0; g < K::NKG; ++g)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kap = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
+      const int bl = kap / 49, px = kap % 49;
+      brow[g][r] = kap < K::KAPPA ? (bl * 81 + (px / 7) * 9 + px % 7) * 128 : 0;  // padded kappa: any row (dz3 is zero there)
+    }
+  float ar[K::NA][8], br[K::NBU][8];
+  float bsum[K::NA][8];
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bsum[t][c] = 0.0f;
+  auto fetch = [&](int st) {
+    const int s0 = st * K::NB;
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      const float* src = asrc[t] + (int64_t)min(s0 + asmp[t], n - 1) * FLAT;  // clamped sample, masked at commit
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ar[t][c] = src[c * 49];
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      const float* src = bsrc[t] + (int64_t)min(s0 + bsmp[t], n - 1) * 5184;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) br[t][c] = src[c * 81];
+    }
+  };
+  auto commit = [&](int st) {
+    const int s0 = st * K::NB;
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+        if (s0 + asmp[t] >= n) {  // second sample of a ragged last stage: contributes zero
+#pragma unroll
+          for (int c = 0; c < 8; ++c) ar[t][c] = 0.0f;
+        }
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_bf16x3(ar[t][2 * c], ar[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        char* d = ldsw3 + awr[t];
+        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
+        *(u4w*)(d + K::A_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
+        *(u4w*)(d + 2 * K::A_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      if (t + 1 < K::NBU || tid + 256 * t < K::B_UNITS) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_bf16x3(br[t][2 * c], br[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        char* d = ldsw3 + bwr[t];
+        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
+        *(u4w*)(d + K::B_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
+        *(u4w*)(d + 2 * K::B_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+      }
+    }
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  if (st_begin < st_end) {
+    fetch(st_begin);
+    commit(st_begin);
+    if (st_begin + 1 < st_end) fetch(st_begin + 1);
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st) {
+#pragma unroll
+      for (int g = 0; g < K::NKG; ++g) {
+        bf8w a[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = tr_frag3(ldsw3, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        DDRL_BF16X6_PRODUCTS;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int toff = ((t / 3) * 9 + t % 3) * 128;
+          bf8w b[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = tr_frag3(ldsw3, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[m]], b[PB[m]], acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();  // every wave is done with the stage
+      if (st + 1 < st_end) {
+        commit(st + 1);
+        if (st + 2 < st_end) fetch(st + 2);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: slab[oc][ic][tap] (torch layout of conv3.weight), then the bias partial
+  float* slab = part + ((int64_t)split * 2 + e) * K::SLAB;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 576 + (wj * 32 + l31) * 9 + t] = acc[t][r];
+  __syncthreads();
+  float* red = (float*)ldsw3;  // [unit][8]
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t)
+    if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[(tid + 256 * t) * 8 + c] = bsum[t][c];
+    }
+  __syncthreads();
+  if (tid < 64) {  // oc = tid: units (c8 = tid / 8) * 98 .. +97, channel tid % 8
+    float sacc = 0.0f;
+    for (int k = 0; k < K::KAPPA; ++k) sacc += red[((tid >> 3) * K::KAPPA + k) * 8 + (tid & 7)];
+    slab[64 * 576 + tid] = sacc;
+  }
+}
+
 void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
+#ifndef DDRL_WGRAD3_F32  // default: the bf16x6 kernel; -DDDRL_WGRAD3_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+  const int S = c.splits->c3 < 256 / L.NE ? c.splits->c3 : 256 / L.NE;  // one workgroup per CU
+  {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad3B::LDS_BYTES);
+      configured = true;
+    }
+    ProfRange pr(c.prof, "ConvWgrad3", st);
+    hipLaunchKernelGGL(conv_wgrad3_bf16x6_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad3B::LDS_BYTES, st, w.a2, MB * 5184, w.dz3, MB * FLAT,
+                       w.wpart, c.n, S, L.NE);
+  }
+#else
   const int S = c.splits->c3;
   {
     ConvWgrad3v2::Params p{w.a2, MB * 5184, w.dz3, MB * FLAT, w.wpart, c.n, S};
     ProfRange pr(c.prof, "ConvWgrad3", st);
     launch_engine2<ConvWgrad3v2>(dim3(3, S, L.NE), p, st);
   }
+#endif
   ProfRange pr(c.prof, "reduce_partials", st);
   launch_reduce_partials(w.wpart, S, ConvWgrad3v2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);
 }
@@ -517,10 +732,8 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
 //   [sample][ch][8 rows][q = x mod 4][24], so that the 8 pixels 4 (ox0 + j) + kx of a fragment are contiguous in
 //   plane kx mod 4 from index ox0 + kx / 4; the one-element shift of kx >= 4 is done with v_alignbit on 5 dwords.
 // ================================================================================================
-using bf8w = __attribute__((ext_vector_type(8))) __bf16;
 using bf2w = __attribute__((ext_vector_type(2))) __bf16;
 using f2w = __attribute__((ext_vector_type(2))) float;
-using u4w = __attribute__((ext_vector_type(4))) unsigned;
 
 template <int NE>
 struct Wgrad1B {

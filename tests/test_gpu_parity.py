@@ -487,6 +487,29 @@ def test_dense_weight_gradient_is_at_least_fp32_accurate(hp):
         np.testing.assert_allclose(db, dh.double().sum(0).numpy(), rtol=0, atol=4 * 2.0 ** -24 * float(dh.double().abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("n", [101, 6])
+def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n):
+    """conv_wgrad3_bf16x6_kernel (dz3 and a2 staged channel-innermost as three bf16 planes each, fragments through the
+    transposing LDS read, 2 samples per stage, 128 sample splits summed in fixed order): given the kernel's own dz3 and
+    a2, dW3 and db3 against float64, beside torch's fp32 weight gradient.  n = 101 leaves a one-sample last stage and
+    most of the 128 splits empty; n = 6 leaves all but three empty."""
+    _bwd_setup(hp, n, 45)
+    got = _grad_views(hp)
+    g = torch.nn.grad
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        dz3 = hp.debug_buffer(6, (64, 7, 7), n, enc).cpu()
+        a2 = hp.debug_buffer(1, (64, 9, 9), n, enc).cpu()
+        ref = g.conv2d_weight(a2.double(), (64, 64, 3, 3), dz3.double()).numpy()
+        f32 = g.conv2d_weight(a2, (64, 64, 3, 3), dz3).numpy().astype(np.float64)
+        k = got[pre + ".conv3.weight"].astype(np.float64)
+        err_kernel, err_f32 = np.abs(k - ref).max(), np.abs(f32 - ref).max()
+        mass = float(g.conv2d_weight(a2.double().abs(), (64, 64, 3, 3), dz3.double().abs()).max())
+        P.MARGINS.check("accuracy", "conv3_wgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s n=%d: kernel %.3e, fp32 %.3e)" % (pre, n, err_kernel, err_f32))
+        db = got[pre + ".conv3.bias"].astype(np.float64)
+        np.testing.assert_allclose(db, dz3.double().sum((0, 2, 3)).numpy(), rtol=0,
+                                   atol=8 * 2.0 ** -24 * float(dz3.double().abs().sum((0, 2, 3)).max()))
+
+
 def test_conv3_data_gradient_is_at_least_fp32_accurate(hp):
     """conv_dgrad3_bf16x6_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
     against float64."""
