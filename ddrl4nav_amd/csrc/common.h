@@ -117,7 +117,7 @@ inline Splits choose_splits(int max_batch, int NE = 2) {
   s.c1 = cap(1024, pairs);      // 1 column tile, encoders fused
   const int k = 2 / NE;         // one encoder: twice the splits keep the same number of workgroups
   s.c2 = cap(256 * k, pairs);   // 2 column tiles x 2 encoders
-  s.c3 = cap(171 * k, pairs);   // 3 column tiles x 2 encoders
+  s.c3 = cap(256 * k, pairs);   // conv_wgrad3_bf16x6: one workgroup per (split, encoder), up to two per CU
   s.fc = cap(5 * k, (max_batch + 31) / 32);  // 25 x 4 tiles x 2 encoders
   return s;
 }

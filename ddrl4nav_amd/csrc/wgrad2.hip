@@ -499,12 +499,15 @@ using s4w = __attribute__((ext_vector_type(4))) short;
 using bf8w = __attribute__((ext_vector_type(8))) __bf16;
 using u4w = __attribute__((ext_vector_type(4))) unsigned;
 struct Wgrad3B {
-  static constexpr int NB = 2, KAPPA = NB * 49, NKG = 7, AROWS = NKG * 16, BROWS = NB * 81;
+  // whole samples per stage.  One sample per stage (56 KB of LDS, two workgroups per CU, 4 k-groups 49/64 full) measured
+  // 3.22 against 3.07 ms: the second workgroup hides the commit, the extra zero rows cost more.
+  static constexpr int NB = 2, KAPPA = NB * 49, NKG = (KAPPA + 15) / 16, AROWS = NKG * 16, BROWS = NB * 81;
   static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 128, B_OFF = 3 * A_PLANE;
-  static constexpr int LDS_BYTES = 3 * A_PLANE + 3 * B_PLANE;      // 43,008 + 62,208
+  static constexpr int LDS_BYTES = 3 * A_PLANE + 3 * B_PLANE;      // NB = 2: 43,008 + 62,208
   static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 8;   // (row, 8-channel group) staging units: 784 / 1,296
   static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;  // per thread: 4 / 6
   static constexpr int64_t SLAB = 64 * 576 + 64;
+  static constexpr int WG_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
 };
 
 __device__ __forceinline__ bf8w tr_frag3(const char* lds, int off_lo, int off_hi) {
@@ -682,7 +685,8 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
 #ifndef DDRL_WGRAD3_F32  // default: the bf16x6 kernel; -DDDRL_WGRAD3_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-  const int S = c.splits->c3 < 256 / L.NE ? c.splits->c3 : 256 / L.NE;  // one workgroup per CU
+  const int want = 256 * Wgrad3B::WG_PER_CU / L.NE;  // as many workgroups as fit the chip at once
+  const int S = c.splits->c3 < want ? c.splits->c3 : want;
   {
     static bool configured = false;
     if (!configured) {
