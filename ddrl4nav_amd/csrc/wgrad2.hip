@@ -709,16 +709,196 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
   launch_reduce_partials(w.wpart, S, ConvWgrad3v2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);
 }
 
+// ================================================================================================
+// conv2 weight gradient as bf16x6, the conv3 design above on conv2's geometry:
+//   part[s][e][oc][ic][ky][kx] = sum_{b in split s} sum_p dz2[b][oc][p] * a1[b][ic][(2 y + ky) 20 + 2 x + kx],   p = 9 y + x
+// rows = oc (64), columns = (tap, ic) (16 x 32), reduction kappa = output pixel of ONE sample per stage (81 -> 6 k-groups,
+// the last one 1/16 full: 15.6 % of the MFMAs meet zero rows; two samples do not fit LDS).  dz2 is staged as
+// [kappa][64 oc] (128-byte rows, half-swap swizzle), a1 as [input pixel 400][32 ic] (64-byte rows: one 32-channel
+// fragment; the four rows of a read are 2 rows apart -> 2-way conflicted).  Wave (i, tg) = oc half x tap rows
+// {2 tg, 2 tg + 1} = 8 fragment tiles.  LDS 3 x 12 KB + 3 x 25 KB = 111 KB, one stage, next stage in registers.
+// ================================================================================================
+struct Wgrad2B {
+  static constexpr int KAPPA = 81, NKG = 6, AROWS = NKG * 16, BROWS = 400;
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 64, B_OFF = 3 * A_PLANE;
+  static constexpr int LDS_BYTES = 3 * A_PLANE + 3 * B_PLANE;      // 36,864 + 76,800
+  static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 4;   // (row, 8-channel group) staging units: 648 / 1,600
+  static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;  // per thread: 3 / 7
+  static constexpr int64_t SLAB = 64 * 512 + 64;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const float* __restrict__ dz2,
+                                                                 int64_t dz_es, float* __restrict__ part, int n, int nsplit, int ne) {
+  using K = Wgrad2B;
+  extern __shared__ __attribute__((aligned(16))) char ldsw2[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave >> 1, tg = wave & 1;
+  const int e = blockIdx.x % ne, split = blockIdx.x / ne;
+  const int per = (n + nsplit - 1) / nsplit;
+  const int st_begin = split * per, st_end = min(n, st_begin + per);
+  for (int i = tid; i < 3 * (K::AROWS - K::KAPPA) * 8; i += 256) {  // zero rows of the dz2 image (kappa >= 81): written once
+    const int pl = i / ((K::AROWS - K::KAPPA) * 8), r = i % ((K::AROWS - K::KAPPA) * 8);
+    *(u4w*)(ldsw2 + pl * K::A_PLANE + K::KAPPA * 128 + r * 16) = (u4w){0u, 0u, 0u, 0u};
+  }
+  // ---- staging maps (see conv_wgrad3_bf16x6_kernel)
+  const float* asrc[K::NA];
+  const float* bsrc[K::NBU];
+  int awr[K::NA], bwr[K::NBU];
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t) {
+    const int u = min(tid + 256 * t, K::A_UNITS - 1);
+    const int c8 = u / K::KAPPA, kap = u % K::KAPPA;
+    asrc[t] = dz2 + e * dz_es + (c8 * 8) * 81 + kap;                                // + sample * 5184, + c * 81
+    awr[t] = kap * 128 + ((c8 * 16) ^ (((kap >> 1) & 1) * 64));
+  }
+#pragma unroll
+  for (int t = 0; t < K::NBU; ++t) {
+    const int u = min(tid + 256 * t, K::B_UNITS - 1);
+    const int c8 = u / K::BROWS, pos = u % K::BROWS;
+    bsrc[t] = a1 + e * a1_es + (c8 * 8) * 400 + pos;                                // + sample * 12800, + c * 400
+    bwr[t] = K::B_OFF + pos * 64 + c8 * 16;
+  }
+  const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int sw = (q >> 1) & 1;
+  const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
+  const int b_lane = K::B_OFF + tg * (2 * 20 * 64) + (g16 & 1) * 32 + pp * 8;
+  int brow[K::NKG][2];  // byte offset of the a1 row (2 y) 20 + 2 x of this lane's kappa, first / second read
+#pragma unroll
+  for (int g = 0; g < K::NKG; ++g)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kap = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
+      brow[g][r] = kap < K::KAPPA ? ((kap / 9) * 40 + (kap % 9) * 2) * 64 : 0;
+    }
+  float ar[K::NA][8], br[K::NBU][8];
+  float bsum[K::NA][8];
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bsum[t][c] = 0.0f;
+  auto fetch = [&](int st) {
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      const float* src = asrc[t] + (int64_t)st * 5184;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ar[t][c] = src[c * 81];
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      const float* src = bsrc[t] + (int64_t)st * 12800;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) br[t][c] = src[c * 400];
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_bf16x3(ar[t][2 * c], ar[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        char* d = ldsw2 + awr[t];
+        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
+        *(u4w*)(d + K::A_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
+        *(u4w*)(d + 2 * K::A_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      if (t + 1 < K::NBU || tid + 256 * t < K::B_UNITS) {
+        unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_bf16x3(br[t][2 * c], br[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        char* d = ldsw2 + bwr[t];
+        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
+        *(u4w*)(d + K::B_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
+        *(u4w*)(d + 2 * K::B_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+      }
+    }
+  };
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  if (st_begin < st_end) {
+    fetch(st_begin);
+    commit();
+    if (st_begin + 1 < st_end) fetch(st_begin + 1);
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st) {
+#pragma unroll
+      for (int g = 0; g < K::NKG; ++g) {
+        bf8w a[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = tr_frag3(ldsw2, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        DDRL_BF16X6_PRODUCTS;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int toff = ((t / 4) * 20 + t % 4) * 64;
+          bf8w b[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = tr_frag3(ldsw2, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[m]], b[PB[m]], acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();  // every wave is done with the stage
+      if (st + 1 < st_end) {
+        commit();
+        if (st + 2 < st_end) fetch(st + 2);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: slab[oc][ic][ky][kx] (torch layout of conv2.weight), then the bias partial
+  float* slab = part + ((int64_t)split * 2 + e) * K::SLAB;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 512 + l31 * 16 + (2 * tg + t / 4) * 4 + t % 4] = acc[t][r];
+  __syncthreads();
+  float* red = (float*)ldsw2;  // [unit][8]
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t)
+    if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[(tid + 256 * t) * 8 + c] = bsum[t][c];
+    }
+  __syncthreads();
+  if (tid < 64) {
+    float sacc = 0.0f;
+    for (int k = 0; k < K::KAPPA; ++k) sacc += red[((tid >> 3) * K::KAPPA + k) * 8 + (tid & 7)];
+    slab[64 * 512 + tid] = sacc;
+  }
+}
+
 void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
+#ifndef DDRL_WGRAD2_F32  // default: the bf16x6 kernel; -DDDRL_WGRAD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
+  const int S = c.splits->c2 < 256 / L.NE ? c.splits->c2 : 256 / L.NE;  // one workgroup per CU
+  {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad2_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad2B::LDS_BYTES);
+      configured = true;
+    }
+    ProfRange pr(c.prof, "ConvWgrad2", st);
+    hipLaunchKernelGGL(conv_wgrad2_bf16x6_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad2B::LDS_BYTES, st, w.a1, MB * 12800, w.dz2, MB * 5184,
+                       w.wpart, c.n, S, L.NE);
+  }
+#else
   const int S = c.splits->c2;
   {
     ConvWgrad2v2::Params p{w.a1, MB * 12800, w.dz2, MB * 5184, w.wpart, c.n, S};
     ProfRange pr(c.prof, "ConvWgrad2", st);
     launch_engine2<ConvWgrad2v2>(dim3(2, S, L.NE), p, st);
   }
+#endif
   ProfRange pr(c.prof, "reduce_partials", st);
   launch_reduce_partials(w.wpart, S, ConvWgrad2v2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
 }

@@ -510,6 +510,27 @@ def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n):
                                    atol=8 * 2.0 ** -24 * float(dz3.double().abs().sum((0, 2, 3)).max()))
 
 
+@pytest.mark.parametrize("n", [77, 3])
+def test_conv2_weight_gradient_is_at_least_fp32_accurate(hp, n):
+    """conv_wgrad2_bf16x6_kernel (dz2 and a1 staged channel-innermost as three bf16 planes each, one sample per stage,
+    fragments through the transposing LDS read): given the kernel's own dz2 and a1, dW2 and db2 against float64."""
+    _bwd_setup(hp, n, 46)
+    got = _grad_views(hp)
+    g = torch.nn.grad
+    for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
+        dz2 = hp.debug_buffer(5, (64, 9, 9), n, enc).cpu()
+        a1 = hp.debug_buffer(0, (32, 20, 20), n, enc).cpu()
+        ref = g.conv2d_weight(a1.double(), (64, 32, 4, 4), dz2.double(), stride=2).numpy()
+        f32 = g.conv2d_weight(a1, (64, 32, 4, 4), dz2, stride=2).numpy().astype(np.float64)
+        k = got[pre + ".conv2.weight"].astype(np.float64)
+        err_kernel, err_f32 = np.abs(k - ref).max(), np.abs(f32 - ref).max()
+        mass = float(g.conv2d_weight(a1.double().abs(), (64, 32, 4, 4), dz2.double().abs(), stride=2).max())
+        P.MARGINS.check("accuracy", "conv2_wgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s n=%d: kernel %.3e, fp32 %.3e)" % (pre, n, err_kernel, err_f32))
+        db = got[pre + ".conv2.bias"].astype(np.float64)
+        np.testing.assert_allclose(db, dz2.double().sum((0, 2, 3)).numpy(), rtol=0,
+                                   atol=8 * 2.0 ** -24 * float(dz2.double().abs().sum((0, 2, 3)).max()))
+
+
 def test_conv3_data_gradient_is_at_least_fp32_accurate(hp):
     """conv_dgrad3_bf16x6_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
     against float64."""
