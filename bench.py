@@ -34,6 +34,16 @@ MAC = {"ConvFwd1": 32 * 400 * 256, "ConvFwd2": 64 * 81 * 512, "ConvFwd3": 64 * 4
 FLOP_ACT_PER_STEP = 37_379_072          # per env-step, both encoders + heads
 FLOP_TRAIN_PER_SAMPLE = 99_030_016      # per sample per PPO iteration
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense f32-input MFMA = fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
+# Matrix pipe and plane products of every GEMM kernel of a TRAINING launch (csrc/*.hip): "bf16x6" = both fp32 operands as three
+# bf16 planes, six products; "bf16x3" = one operand exact in bf16 (the uint8 pixels), three products.  The ceiling a kernel
+# is priced against is the bf16 peak / products, in fp32-equivalent (algorithmic) TFLOP/s.
+PIPE = {"ConvFwd1": ("bf16x3", 3), "ConvWgrad1": ("bf16x3", 3), "ConvFwd2": ("bf16x6", 6), "ConvFwd3": ("bf16x6", 6),
+        "FcFwd": ("bf16x6", 6), "FcDgrad": ("bf16x6", 6), "ConvDgrad3": ("bf16x6", 6), "ConvDgrad2": ("bf16x6", 6),
+        "FcWgrad": ("bf16x6", 6), "ConvWgrad3": ("bf16x6", 6), "ConvWgrad2": ("bf16x6", 6)}
+# executed / algorithmic MFMA work of the kernels that walk padded operands
+EXECUTED_OVER_ALGORITHMIC = {"ConvDgrad3": 1.84, "ConvDgrad2": 1.23, "ConvFwd3": 1.11, "ConvWgrad3": 112.0 / 98.0,
+                             "ConvWgrad2": 96.0 / 81.0}
 PEAK_HBM_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # algorithmic HBM bytes per launch of the HBM-bound kernels, f(N envs, B samples, P params)
 HBM_BYTES = {
@@ -512,6 +522,12 @@ def main():
                 per_launch = 2 * 2 * MAC[base] * (N if k.endswith(".act") else B)
                 ent["tflops"] = round(per_launch * calls / (ms * 1e-3) / 1e12, 2)
                 ent["flop_per_launch"] = per_launch
+                if k in PIPE:
+                    pipe, products = PIPE[k]
+                    ent["pipe"] = pipe
+                    ent["pipe_ceiling_tflops"] = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
+                    ent["frac_of_pipe_ceiling"] = round(ent["tflops"] / (PEAK_BF16_MFMA_TFLOPS / products), 4)
+                    ent["executed_over_algorithmic"] = round(EXECUTED_OVER_ALGORITHMIC.get(k, 1.0), 3)
             elif k in HBM_BYTES:
                 # HBM-bound kernels: algorithmic bytes per launch / launch time
                 per_launch = HBM_BYTES[k](N, B, hp.n_params)
@@ -525,14 +541,24 @@ def main():
         if gemm:
             dom = max(gemm, key=lambda k: gemm[k]["ms_total"])
             d = gemm[dom]
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+            pipe, products = PIPE.get(dom, ("f32", None))
+            peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
                         "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch"),  # HBM bytes per launch (PMC)
                         "traffic_detail": pmc_traffic(dom),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
-                        "algorithmic_flop_per_launch": d["flop_per_launch"],
-                        "note": "dominant training kernel; f32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32; HIP events "
-                                "around each launch on the launch stream; algorithmic FLOP = 2*2*MAC/sample (both encoders) x B"}
+                        "algorithmic_flop_per_launch": d["flop_per_launch"], "pipe": pipe,
+                        "executed_over_algorithmic": round(EXECUTED_OVER_ALGORITHMIC.get(dom, 1.0), 3),
+                        "note": "dominant training kernel (largest accumulated time).  achieved = ALGORITHMIC fp32 FLOP (2*2*MAC per "
+                                "sample, both encoders, x B) / launch time from HIP events on the launch stream; peak = the ceiling of the "
+                                "pipe the kernel runs on: dense bf16 MFMA 2.5 PFLOP/s / plane products (6 for two fp32 operands as "
+                                "three bf16 planes each, 3 when one operand is exact in bf16), or the f32-input MFMA peak 157.3"}
+            # every GEMM kernel against ITS pipe's ceiling, and the time-weighted mean over the training kernels
+            tw = sum(v["ms_total"] for k, v in gemm.items() if "frac_of_pipe_ceiling" in v)
+            if tw > 0:
+                roofline["time_weighted_frac_all_gemm_kernels"] = round(
+                    sum(v["ms_total"] * v["frac_of_pipe_ceiling"] for v in gemm.values() if "frac_of_pipe_ceiling" in v) / tw, 4)
         upd_ms = phase["update_ms"] / steps
         total_flop = env_steps / world * (FLOP_ACT_PER_STEP + ITERS * FLOP_TRAIN_PER_SAMPLE)
         out = {
@@ -546,8 +572,9 @@ def main():
             "ppo_update_ms": round(upd_ms, 2), "ppo_iter_ms": round(upd_ms / ITERS, 3),
             "acting_ms_per_rollout": round(phase["act_ms"] / steps, 2), "gae_ms": round(phase["gae_ms"] / steps, 4),
             "acting_env_steps_per_s_per_gpu": round(N * (T + 1) / (phase["act_ms"] / steps * 1e-3), 1),
+            # fp32-equivalent (algorithmic) work of the whole step per second.  NOT a roofline fraction: the GEMM kernels run on
+            # the bf16 matrix pipe (fp32-accurate plane products); each kernel's fraction of its pipe's ceiling is in `kernels`
             "whole_step_tflops_per_gpu": round(total_flop / elapsed / 1e12, 2),
-            "whole_step_frac_of_f32_peak": round(total_flop / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             # section 8e: one SUM all-reduce of the 13,487,420-byte gradient arena (+ loss tail) per PPO iteration, bracketed by
             # events on the compute stream of rank 0 (includes waiting for the slowest rank to arrive)
             "allreduce": None if world == 1 else {
@@ -557,11 +584,12 @@ def main():
                 "algbw_gbps": round(hp.grads.numel() * 4 / (float(np.median(ar_ms)) * 1e-3) / 1e9, 2)},
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
-            "dtype_note": "fp32 accumulation everywhere; the GEMM kernels use the f32-input MFMA except conv1's forward and weight "
-                          "gradient (exact-bf16 pixels 0..255 x three bf16 planes of the other fp32 operand) and the training-launch "
-                          "forwards and the data gradients of conv2, conv3 and the dense layer (three bf16 planes of "
-                          "both operands, six products), which run on the bf16 MFMA with errors against "
-                          "float64 no larger than an fp32 chain's; their 'tflops' is fp32-equivalent work",
+            "dtype_note": "fp32 operands, fp32 accumulation, fp32-accurate results everywhere.  Every GEMM kernel of a training launch "
+                          "runs on the bf16 MFMA as exact plane products: conv1's forward and weight gradient with exact-bf16 pixels "
+                          "0..255 x three bf16 planes of the other operand (bf16x3), all others with three bf16 planes of BOTH fp32 "
+                          "operands and the six products that matter (bf16x6); errors against float64 are no larger than an fp32 "
+                          "chain's (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  'tflops' is fp32-equivalent (algorithmic) "
+                          "work; acting launches below 192 envs use the f32-input MFMA",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
                              "(*.act, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
         }
