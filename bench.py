@@ -244,8 +244,14 @@ def pmc_traffic(kernel):
                    key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
         return None
+    # names in the PMC summaries follow the device functions (tools/pmc_to_profiles.py), bench names the launch sites
+    alias = {"ConvFwd1": "conv_fwd1_bf16x3", "ConvWgrad1": "conv_wgrad1_bf16x3", "ConvFwd2": "conv_fwd2_bf16x6",
+             "ConvFwd3": "conv_fwd3_bf16x6", "FcFwd": "fc_fwd_bf16x6", "FcDgrad": "fc_dgrad_bf16x6", "FcWgrad": "fc_wgrad_bf16x6",
+             "ConvDgrad3": "conv_dgrad3_bf16x6", "ConvDgrad2": "conv_dgrad2_bf16x6", "ConvWgrad3": "conv_wgrad3_bf16x6",
+             "ConvWgrad2": "conv_wgrad2_bf16x6"}
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        ks = json.load(open(files[-1]))["kernels"]
+        k = ks.get(kernel) or ks.get(alias.get(kernel, ""))
         return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes"], "fetch_bytes": k["fetch_bytes"],
                                        "write_bytes": k["write_bytes"], "mfma_busy_frac": k["mfma_busy_frac"],
                                        "clock_ghz": k["clock_ghz"], "source": os.path.basename(files[-1])}
