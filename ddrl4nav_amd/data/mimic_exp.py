@@ -27,15 +27,28 @@ class MimicExpReader:
             if "||" not in line:
                 continue
             files, label = line.split("||")
-            try:
-                for name in files.split(","):
-                    if name not in self.data:
-                        self.data[name] = np.load(os.path.join(save_dir, name))[None]   # [84, 84] -> [1, 84, 84]
-                if self.regression:
+            if self.regression:
+                # MimicExpRegressionReader.to_memory (mimic_exp.py:219-229): a sample counts once, if ALL its files load
+                try:
+                    for name in files.split(","):
+                        if self.data.get(name) is None:
+                            self.data[name] = np.load(os.path.join(save_dir, name))[None]
                     self.data[label] = np.load(os.path.join(save_dir, label))
-            except (OSError, ValueError):
-                continue
-            self.line_list.append(line)
+                except (OSError, ValueError):
+                    continue
+                self.line_list.append(line)
+            else:
+                # MimicExpAtariReader.to_memory (mimic_exp.py:240-251), quirks included: the writer stores only the FIRST frame
+                # of every stacked sample, so a sample's later frames are the first frames of later steps; a line is appended
+                # once per frame file it is the first to load, and a file that is missing when first asked for is marked and
+                # never retried -- samples near the end of an episode therefore drop out and early ones repeat
+                for name in files.split(","):
+                    if self.data.get(name) is None:
+                        try:
+                            self.data[name] = np.load(os.path.join(save_dir, name))[None]   # [84, 84] -> [1, 84, 84]
+                            self.line_list.append(line)
+                        except (OSError, ValueError):
+                            self.data[name] = -1
 
     def _label(self, label):
         if self.regression:
@@ -79,6 +92,7 @@ class batches:
 
     def __iter__(self):
         n = len(self.dataset)
+        torch.empty((), dtype=torch.int64).random_()   # DataLoader's iterator draws its worker base seed first (_BaseDataLoaderIter)
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         g = torch.Generator()
         g.manual_seed(seed)

@@ -171,3 +171,29 @@ def test_create_net_rejects_unknown_task_and_needs_gpu():
         cfg.TASK_TYPE = "classical"
         with pytest.raises(_lib.DdrlError):   # no CPU fallback for the generic nets either
             create_net({"config": cfg, "config_nn": ConfigNN(env), "config_env": env})
+
+
+@pytest.mark.parametrize("kind", ["classical", "atari"])
+def test_mimic_dataset_reader_and_batch_order_match_reference(golden, tmp_path, kind):
+    """Expert data sets written by the reference's MimicExpWriter (fixture F19 carries the files) read back identically, and
+    the batches follow torch's RandomSampler exactly as the reference's DataLoader(shuffle=True) does (GAIL.py:49-57)."""
+    from ddrl4nav_amd.data.mimic_exp import MimicExpFactory, batches
+    g = golden("f19_mimic")
+    d = tmp_path / kind
+    d.mkdir()
+    for f in g[kind + "/files"]:
+        (d / str(f)).write_bytes(g["%s/file/%s" % (kind, f)].tobytes())
+    ds = MimicExpFactory().mimic_reader(kind, str(d) + "/")
+    assert len(ds) == int(g[kind + "/len"])
+    xs, ys = zip(*[ds[i] for i in range(len(ds))])
+    assert np.array_equal(np.stack(xs), g[kind + "/x"])
+    assert np.array_equal(np.stack([np.asarray(y, np.float32) for y in ys]), g[kind + "/y"])
+    torch.manual_seed(190)
+    loader = batches(ds, 8)
+    assert len(loader) == 4
+    for epoch in range(2):
+        for bi, batch in enumerate(loader):
+            assert np.array_equal(batch[0].numpy(), g["%s/epoch%d/batch%d/x" % (kind, epoch, bi)]), (epoch, bi)
+            assert np.array_equal(batch[1].numpy(), g["%s/epoch%d/batch%d/y" % (kind, epoch, bi)])
+            if bi == 1:
+                break
