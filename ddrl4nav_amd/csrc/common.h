@@ -83,7 +83,7 @@ struct Workspace {
   // conv3 weights for the data gradient as three bf16 planes [e][k-block 8][tap pair 5][plane 3][ic 64][tap parity 2][oc 8]
   unsigned short* wd3b;
   // conv3 weights for the exact-tap data gradient (conv_dgrad3_exact_kernel): three bf16 planes
-  // [e][k-block 4 (16 oc)][tap 9][plane 3][oc half 2][ic 64][oc 8]
+  // [e][k-block 8 (8 oc)][tap 9][plane 3][ic 64][oc 8]
   unsigned short* wd3c;
   // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_bf16x6_kernel)
   unsigned short* wlb;
@@ -145,7 +145,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);
   w.wd3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
-  w.wd3c = (unsigned short*)take(2 * 4 * 9 * 3 * 2 * 64 * 8 / 2);
+  w.wd3c = (unsigned short*)take(2 * 8 * 9 * 3 * 64 * 8 / 2);
   w.wp2 = take(2 * 16 * 16 * 2 * 64);
   w.wp3 = take(2 * 16 * 18 * 2 * 64);
   w.wd3p = take(2 * 16 * 18 * 2 * 64);

@@ -1439,57 +1439,71 @@ static void launch_dgrad3_bf16x6(const EncCall& c, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv3 data gradient with EXACTLY the valid taps (bf16x6).  The gather kernel above walks 81 x 9 (+ a padded tenth tap)
-// products per sample and channel pair, of which 49 x 9 are non-zero: border pixels of the 9 x 9 input see fewer taps,
-// but a column fragment of 32 neighbouring pixels mixes borders and interior.  Here the LANES of a fragment are 32
-// SAMPLES at ONE input pixel u, so the whole fragment shares u's tap set and only valid (u, tap) pairs are ever issued:
-//   dz2[b][ic][u] = leaky'(a2[b][ic][u]) * sum_{tap valid at u} sum_oc W3[oc][ic][tap] dz3[b][oc][u - tap]
-// MFMA rows = ic (A = pre-split weight planes, kept in registers for a k-block), columns = samples (B = dz3 staged
-// channel-innermost: [plane][sample][pixel][16 oc], one 16-byte fragment per lane half, plain ds_read_b128), k-group =
-// 16 oc of one tap, k-block = 16 oc.  A workgroup owns 32 samples x 2 input rows (18 pixels = 36 fragment tiles):
-// wave (i, j) = ic half i x pixels of column parity j.  Row group rg needs dz3 rows max(0, 2 rg - 2) .. min(6, 2 rg + 1)
-// (three input rows per task would read less -- 11 instead of 14 dz3 rows per sample -- but 240 accumulator registers
-// next to the 72 of the register-staged next k-block made the compiler spill the staged loads, which serialises them).
-// Executed / algorithmic MFMA work 1.00 (the gather kernel: 1.84).  The five row groups of a sample tile get block ids 8
-// apart (same XCD, same time) so that the dz3 rows they share are served by that XCD's L2.
-// Epilogue per input row: accumulators -> LDS [sample][ic][9 px] -> lanes along (ic, px), i.e. along memory: the a2 mask
-// loads and the dz2 stores are runs of 9 contiguous floats.
+// conv3 data gradient with EXACTLY the valid taps (bf16x6), -DDDRL_DGRAD3_EXACT.  The gather kernel above walks 81 x 9
+// (+ a padded tenth tap) products per sample and channel pair, of which 49 x 9 are non-zero: border pixels of the 9 x 9
+// input see fewer taps, but a column fragment of 32 neighbouring pixels mixes borders and interior.  Here the LANES of a
+// fragment are 32 SAMPLES at ONE input pixel u, so the whole fragment shares u's tap set and only valid (u, tap) pairs are
+// issued:   dz2[b][ic][u] = leaky'(a2[b][ic][u]) * sum_{tap valid at u} sum_oc W3[oc][ic][tap] dz3[b][oc][u - tap]
+// MFMA rows = ic (A = pre-split weight planes), columns = samples (B = dz3 staged channel-innermost:
+// [plane][sample][pixel][8 oc], one 16-byte fragment per lane, plain ds_read_b128).  k-block = 8 oc; one k-group = TWO
+// taps x 8 oc (lane half h takes the pair's tap h; a pixel with an odd number of valid taps meets a zero weight block
+// once): executed / algorithmic MFMA work 490 / 441 = 1.11 (the gather kernel: 1.84).  A workgroup owns 32 samples x ONE
+// input row (9 pixels = 18 fragment tiles): wave (i, j) = ic half i x pixels of column parity j; 80 accumulator registers,
+// which is what lets TWO workgroups share a CU (two rows: 160 + staging did not fit 256 registers, 714 spills).  Input
+// row rg reads dz3 rows max(0, rg - 2) .. min(6, rg).  LDS: stage 3 x 11.5 KB + the k-block's weights
+// [tap 9 + zero][plane][ic][8 oc] 30 KB (copied LDS-direct, no registers) = 66 KB, epilogue buffer 74 KB -> two workgroups
+// per CU, which hide each other's prologue, commits and epilogue (version 1 -- k-block 16 oc, weights from L2 in
+// registers, two rows, 87 KB, one workgroup per CU -- issued 0.54 x the MFMAs of the gather kernel and still tied it at
+// 4.4 ms because those phases were exposed).  The nine rows of a sample tile get block ids 8 apart (same XCD, same time):
+// the dz3 rows they share (each is read by three of them) come from that XCD's L2.
+// Epilogue per input row: accumulators -> LDS [sample][ic][9 px] -> lanes along (ic, px), i.e. along memory.
 // ================================================================================================
 struct Dgrad3X {
-  static constexpr int NS = 32, MAXROWS = 4, KB = 16, RPT = 2, NRG = 5;   // input rows per task, row groups per sample tile
-  static constexpr int SSTRIDE = MAXROWS * 7 * 32 + 16;        // bytes per sample and plane: 28 px x 32 B + 16 (odd multiple of 16: conflict-free)
-  static constexpr int PLANE = NS * SSTRIDE;                   // 29,184
-  static constexpr int STAGE_BYTES = 3 * PLANE;                // 87,552
-  static constexpr int ESTRIDE = 64 * 9 + 1;                   // floats per sample in the epilogue buffer
-  static constexpr int LDS_BYTES = STAGE_BYTES;                // the epilogue buffer (32 x 577 x 4 = 73,856) reuses the stage
-  static constexpr int UNITS = NS * MAXROWS * 7 * 2, NU = (UNITS + 255) / 256;  // (sample, pixel, 8-oc group): 1,792 -> 7 per thread
+  static constexpr int NS = 32, MAXROWS = 3, NRG = 9, KB = 8, NKB = 8;   // one input row per task
+  static constexpr int SSTRIDE = MAXROWS * 7 * 16 + 32;        // bytes per sample and plane: 21 px x 16 B + 32 (odd multiple of 16: conflict-free)
+  static constexpr int PLANE = NS * SSTRIDE, STAGE = 3 * PLANE;  // 11,776 / 35,328
+  static constexpr int W_OFF = STAGE, W_TAP = 3 * 64 * 16, W_BYTES = 9 * W_TAP;  // per k-block: [tap][plane][ic][8 oc] bf16 = 27,648 B (+ a zero tap)
+  static constexpr int ESTRIDE = 64 * 9 + 1;                   // floats per sample in the epilogue buffer (73,856 B, reuses everything)
+  static constexpr int LDS_BYTES = NS * ESTRIDE * 4;            // 73,856: the epilogue buffer is the larger user (stage + weights: 66,048)
 };
 
+// n-th valid tap (ky-major) of input pixel (uy, ux), or 9 = "none": tap (ky, kx) is valid when 0 <= uy - ky, ux - kx <= 6
+__host__ __device__ constexpr int d3x_nth_tap(int uy, int ux, int n) {
+  int seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int y = uy - t / 3, x = ux - t % 3;
+    if (y < 0 || y > 6 || x < 0 || x > 6) continue;
+    if (seen == n) return t;
+    ++seen;
+  }
+  return 9;
+}
+
 template <int RG, int WJ>
-__device__ __forceinline__ void dgrad3x_body(const float* __restrict__ dz3, const unsigned short* __restrict__ wd3c, const float* __restrict__ a2,
+__device__ __forceinline__ void dgrad3x_body(const float* __restrict__ dz3, const unsigned short* __restrict__ wd3e, const float* __restrict__ a2,
                                              float* __restrict__ dz2, int b0, int n, char* lds) {
   using K = Dgrad3X;
-  // input rows 2 RG, 2 RG + 1 (RG = 4: row 8 only) read dz3 rows max(0, 2 RG - 2) .. min(6, 2 RG + 1)
-  constexpr int Y0 = RG <= 1 ? 0 : 2 * RG - 2, Y1 = RG >= 3 ? 6 : 2 * RG + 1, NROWS = Y1 - Y0 + 1, NPX = NROWS * 7;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  // input row RG reads dz3 rows max(0, RG - 2) .. min(6, RG)
+  constexpr int Y0 = RG <= 2 ? 0 : RG - 2, Y1 = RG >= 6 ? 6 : RG, NROWS = Y1 - Y0 + 1, NPX = NROWS * 7;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_u(), l31 = lane & 31, hi = lane >> 5;
   const int wi = wave >> 1;
-  // ---- staging: unit = (sample s, staged pixel px, oc octet o): 8 strided dwords -> one 16-byte fragment per plane
-  constexpr int UNITS = K::NS * NPX * 2, NU = (UNITS + 255) / 256;
+  // ---- staging: unit = (sample s, staged pixel px): the k-block's 8 oc as 8 strided dwords -> one 16-byte fragment per plane
+  constexpr int UNITS = K::NS * NPX, NU = (UNITS + 255) / 256;
   const float* usrc[NU];
   int uwr[NU];
 #pragma unroll
   for (int t = 0; t < NU; ++t) {
     const int u = min(tid + 256 * t, UNITS - 1);
-    const int o = u / (K::NS * NPX), r = u % (K::NS * NPX), s = r / NPX, px = r % NPX;
-    usrc[t] = dz3 + (int64_t)min(b0 + s, n - 1) * FLAT + (o * 8) * 49 + Y0 * 7 + px;   // + (16 kb + c) * 49
-    uwr[t] = s * K::SSTRIDE + px * 32 + o * 16;
+    const int sidx = u / NPX, px = u % NPX;
+    usrc[t] = dz3 + (int64_t)min(b0 + sidx, n - 1) * FLAT + Y0 * 7 + px;   // + (8 kb + c) * 49
+    uwr[t] = sidx * K::SSTRIDE + px * 16;
   }
   float ur[NU][8];
   auto fetch = [&](int kb) {
 #pragma unroll
     for (int t = 0; t < NU; ++t)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ur[t][c] = usrc[t][(kb * 16 + c) * 49];
+      for (int c = 0; c < 8; ++c) ur[t][c] = usrc[t][(kb * 8 + c) * 49];
   };
   auto commit = [&]() {
 #pragma unroll
@@ -1504,65 +1518,78 @@ __device__ __forceinline__ void dgrad3x_body(const float* __restrict__ dz3, cons
         *(u4v*)(d + 2 * K::PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
       }
   };
-  // this wave's pixels: input rows 2 RG, 2 RG + 1, columns ux = WJ, WJ + 2, ... (5 or 4 per row); acc[row][column index]
-  f32x16 acc[2][5];
+  // the k-block's weight planes: 27 chunks of 1 KB, LDS-direct (wave w moves chunks w, w + 4, ...)
+  auto weights = [&](int kb) {
+    const unsigned short* src = wd3e + (int64_t)kb * (K::W_BYTES / 2);
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+    for (int j = 0; j < 7; ++j) {
+      const int chunk = wave + 4 * j;
+      if (chunk < 27) ld16_to_lds(src, (uint32_t)((chunk * 64 + lane) * 16), (float*)(lds + K::W_OFF + chunk * 1024));
+    }
+  };
+  for (int i = tid; i < K::W_TAP / 16; i += 256) *(u4v*)(lds + K::W_OFF + 9 * K::W_TAP + i * 16) = (u4v){0u, 0u, 0u, 0u};  // the zero tap
+  f32x16 acc[5];   // pixels ux = WJ, WJ + 2, ... of input row RG
 #pragma unroll
-    for (int c = 0; c < 5; ++c)
+  for (int c = 0; c < 5; ++c)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.0f;
-  const int b_lane = l31 * K::SSTRIDE + hi * 16;
-  const unsigned short* wlane = wd3c + hi * 512 + (wi * 32 + l31) * 8;   // + ((kb * 9 + tap) * 3 + plane) * 1024
+    for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+  const int b_lane = l31 * K::SSTRIDE;
+  const int a_lane = K::W_OFF + (wi * 32 + l31) * 16;
+  weights(0);
   fetch(0);
   commit();
   fetch(1);
+  wait_vmcnt<NU * 8>();  // the weight chunks (older than fetch(1)'s loads) have landed
   __syncthreads();
 #pragma unroll 1
-  for (int kb = 0; kb < 4; ++kb) {
+  for (int kb = 0; kb < K::NKB; ++kb) {
     DDRL_BF16X6_PRODUCTS;
+    {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int ky = t / 3, kx = t % 3;
-      bf8 wa[3];  // weight fragments of tap t for this wave's ic half: 3 planes (L2-resident, 16 B per lane)
+      for (int c = 0; c < 5; ++c) {
+        const int uy = RG, ux = 2 * c + WJ;
+        if (ux > 8) continue;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wa[p] = *(const bf8*)(wlane + ((kb * 9 + t) * 3 + p) * 1024);
+        for (int pr = 0; pr < 5; ++pr) {
+          const int tA = d3x_nth_tap(uy, ux, 2 * pr), tB = d3x_nth_tap(uy, ux, 2 * pr + 1);
+          if (tA == 9) continue;
+          const int offA = ((uy - tA / 3 - Y0) * 7 + (ux - tA % 3)) * 16;
+          const int offB = tB == 9 ? offA : ((uy - tB / 3 - Y0) * 7 + (ux - tB % 3)) * 16;
+          const int wsel = hi ? tB * K::W_TAP : tA * K::W_TAP, bsel = hi ? offB : offA;
+          bf8 wa[3], b[3];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int uy = 2 * RG + r, y = uy - ky;
-        if (uy > 8 || y < 0 || y > 6) continue;
+          for (int p = 0; p < 3; ++p) {
+            wa[p] = *(const bf8*)(lds + a_lane + wsel + p * 1024);
+            b[p] = *(const bf8*)(lds + b_lane + bsel + p * K::PLANE);
+          }
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-          const int ux = 2 * c + WJ, x = ux - kx;
-          if (ux > 8 || x < 0 || x > 6) continue;
-          const int off = ((y - Y0) * 7 + x) * 32;
-          bf8 b[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) b[p] = *(const bf8*)(lds + b_lane + off + p * K::PLANE);
-#pragma unroll
-          for (int m = 0; m < 6; ++m) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PA[m]], b[PB[m]], acc[r][c], 0, 0, 0);
+          for (int m = 0; m < 6; ++m) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PA[m]], b[PB[m]], acc[c], 0, 0, 0);
         }
       }
     }
-    __syncthreads();  // every wave is done with the stage
-    if (kb + 1 < 4) {
-      commit();
-      if (kb + 2 < 4) fetch(kb + 2);
+    __syncthreads();  // every wave is done with the stage and the weights
+    if (kb + 1 < K::NKB) {
+      weights(kb + 1);
+      commit();       // waits for fetch(kb + 1), which is older than the weight chunks
+      if (kb + 2 < K::NKB) {
+        fetch(kb + 2);
+        wait_vmcnt<NU * 8>();
+      } else {
+        wait_vmcnt<0>();
+      }
     }
     __syncthreads();
   }
-  // ---- epilogue, one input row at a time through LDS
+  // ---- epilogue through LDS
   float* ebuf = (float*)lds;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int uy = 2 * RG + r;
-    if (uy > 8) continue;
+  {
+    const int uy = RG;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
       const int ux = 2 * c + WJ;
       if (ux > 8) continue;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) ebuf[l31 * K::ESTRIDE + (wi * 32 + acc_row(q, hi)) * 9 + ux] = acc[r][c][q];
+      for (int q = 0; q < 16; ++q) ebuf[l31 * K::ESTRIDE + (wi * 32 + acc_row(q, hi)) * 9 + ux] = acc[c][q];
     }
     __syncthreads();
     // wave w handles samples 8 w .. 8 w + 7; lanes run along (ic, px) = along memory.  All mask loads of four samples
@@ -1600,21 +1627,21 @@ __device__ __forceinline__ void dgrad3x_body(const float* __restrict__ dz3, cons
   }
 }
 
-__global__ __launch_bounds__(256) void conv_dgrad3_exact_kernel(const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3c,
-                                                                const float* __restrict__ a2, float* __restrict__ dz2, int64_t a2_es, int n,
-                                                                int ntiles, int ne) {
+__global__ __launch_bounds__(256, 2) void conv_dgrad3_exact_kernel(const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3e,
+                                                                   const float* __restrict__ a2, float* __restrict__ dz2, int64_t a2_es, int n,
+                                                                   int ntiles, int ne) {
   extern __shared__ __attribute__((aligned(16))) char ldsx3[];
-  // block id -> (encoder, sample tile, row group); the three row groups of a tile are 8 ids apart
+  // block id -> (encoder, sample tile, row group); the row groups of a tile are 8 ids apart
   const int per_e = ((ntiles + 7) / 8) * 8 * Dgrad3X::NRG;
   const int e = blockIdx.x / per_e, id = blockIdx.x % per_e;
   const int rg = (id >> 3) % Dgrad3X::NRG, tile = (id / (8 * Dgrad3X::NRG)) * 8 + (id & 7);
   if (tile >= ntiles) return;
   const int b0 = tile * Dgrad3X::NS;
   const float* dz = dz3 + e * dz_es;
-  const unsigned short* w = wd3c + (int64_t)e * (4 * 9 * 3 * 2 * 512);
+  const unsigned short* w = wd3e + (int64_t)e * (Dgrad3X::NKB * Dgrad3X::W_BYTES / 2);
   const float* m = a2 + e * a2_es;
   float* out = dz2 + e * a2_es;
-  const int wj = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1;  // pixel-column parity of this wave
+  const int wj = wave_u() & 1;  // pixel-column parity of this wave
 #define DDRL_D3X(RG_)                                                                                     \
   if (wj == 0) dgrad3x_body<RG_, 0>(dz, w, m, out, b0, n, ldsx3); else dgrad3x_body<RG_, 1>(dz, w, m, out, b0, n, ldsx3)
   switch (rg) {
@@ -1622,7 +1649,11 @@ __global__ __launch_bounds__(256) void conv_dgrad3_exact_kernel(const float* __r
     case 1: DDRL_D3X(1); break;
     case 2: DDRL_D3X(2); break;
     case 3: DDRL_D3X(3); break;
-    default: DDRL_D3X(4); break;
+    case 4: DDRL_D3X(4); break;
+    case 5: DDRL_D3X(5); break;
+    case 6: DDRL_D3X(6); break;
+    case 7: DDRL_D3X(7); break;
+    default: DDRL_D3X(8); break;
   }
 #undef DDRL_D3X
 }
@@ -1645,8 +1676,8 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
   const int64_t MB = c.max_batch;
   ProfRange pr(c.prof, "ConvDgrad3", st);
 #if !defined(DDRL_DGRAD3_GATHER) && !defined(DDRL_DGRAD3_SCATTER)  // default: the bf16x6 gather kernel over zero-padded images
-#ifdef DDRL_DGRAD3_EXACT  // exact taps, lanes = samples: 0.54 x the MFMAs, same 4.4 ms (one workgroup per CU: prologue, 4 commits and
-  launch_dgrad3_exact(c, st);  // the LDS-transposed epilogue of its 55 us tasks are not hidden); kept for the next step, see DESIGN.md
+#ifdef DDRL_DGRAD3_EXACT  // exact taps, lanes = samples (conv_dgrad3_exact_kernel): 0.60 x the MFMAs, 4.49 ms against 4.39 -- its
+  launch_dgrad3_exact(c, st);  // k-blocks of 8 oc carry only ~100 MFMAs per wave between two barriers and a 27 KB weight copy
 #else
   launch_dgrad3_bf16x6(c, st);
 #endif

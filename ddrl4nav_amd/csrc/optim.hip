@@ -193,23 +193,24 @@ __global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __re
   d[2 * 64 * 16] = p2;
 }
 
-// conv3 weights for the exact-tap data gradient: wd3c[e][kb 4][tap 9][plane 3][h 2][ic 64][o 8] = W3[oc = 16 kb + 8 h + o][ic][tap]
+// conv3 weights for the exact-tap data gradient: wd3c[e][kb 8][tap 9][plane 3][ic 64][o 8] = W3[oc = 8 kb + o][ic][tap]
+// (one k-block = 27,648 contiguous bytes: copied LDS-direct by conv_dgrad3_exact_kernel)
 __global__ __launch_bounds__(256) void pack_dgrad3c_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
   const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, tap, h, ic, o)
-  if (i >= 4 * 9 * 2 * 64 * 8) return;
-  const int o = i & 7, ic = (i >> 3) & 63, h = (i >> 9) & 1, tap = (i >> 10) % 9, kb = (i >> 10) / 9;
-  const float w = params[L.enc_base[e] + L.enc.c3w + ((16 * kb + 8 * h + o) * 64 + ic) * 9 + tap];
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, tap, ic, o)
+  if (i >= 8 * 9 * 64 * 8) return;
+  const int o = i & 7, ic = (i >> 3) & 63, tap = (i >> 9) % 9, kb = (i >> 9) / 9;
+  const float w = params[L.enc_base[e] + L.enc.c3w + ((8 * kb + o) * 64 + ic) * 9 + tap];
   unsigned short p0, p1, p2;
   bf16_planes(w, p0, p1, p2);
-  unsigned short* d = dst + ((((int64_t)(e * 4 + kb) * 9 + tap) * 3) * 2 + h) * 512 + ic * 8 + o;
+  unsigned short* d = dst + (((int64_t)(e * 8 + kb) * 9 + tap) * 3) * 512 + ic * 8 + o;
   d[0] = p0;
-  d[2 * 512] = p1;
-  d[4 * 512] = p2;
+  d[512] = p1;
+  d[1024] = p2;
 }
 
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
-  hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(4 * 9 * 2 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
+  hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(8 * 9 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
   hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b);
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b);
