@@ -35,12 +35,13 @@ FLOP_ACT_PER_STEP = 37_379_072          # per env-step, both encoders + heads
 FLOP_TRAIN_PER_SAMPLE = 99_030_016      # per sample per PPO iteration
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense f32-input MFMA = fp32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
-# Matrix pipe and plane products of every GEMM kernel of a TRAINING launch (csrc/*.hip): "bf16x6" = both fp32 operands as three
-# bf16 planes, six products; "bf16x3" = one operand exact in bf16 (the uint8 pixels), three products.  The ceiling a kernel
-# is priced against is the bf16 peak / products, in fp32-equivalent (algorithmic) TFLOP/s.
-PIPE = {"ConvFwd1": ("bf16x3", 3), "ConvWgrad1": ("bf16x3", 3), "ConvFwd2": ("bf16x6", 6), "ConvFwd3": ("bf16x6", 6),
-        "FcFwd": ("bf16x6", 6), "FcDgrad": ("bf16x6", 6), "ConvDgrad3": ("bf16x6", 6), "ConvDgrad2": ("bf16x6", 6),
-        "FcWgrad": ("bf16x6", 6), "ConvWgrad3": ("bf16x6", 6), "ConvWgrad2": ("bf16x6", 6)}
+# Matrix pipe and plane products of every GEMM kernel of a TRAINING launch (csrc/*.hip): "f16x3" = both fp32 operands as two
+# scaled fp16 planes each, three products (csrc/engine2.h "plane scheme"); "bf16x3" = one operand exact in bf16 (the uint8
+# pixels), the other as three bf16 planes, three products.  The ceiling a kernel is priced against is the dense 16-bit MFMA
+# peak (2.5 PFLOP/s, bf16 and fp16 alike) / products, in fp32-equivalent (algorithmic) TFLOP/s.
+PIPE = {"ConvFwd1": ("bf16x3", 3), "ConvWgrad1": ("bf16x3", 3), "ConvFwd2": ("f16x3", 3), "ConvFwd3": ("f16x3", 3),
+        "FcFwd": ("f16x3", 3), "FcDgrad": ("f16x3", 3), "ConvDgrad3": ("f16x3", 3), "ConvDgrad2": ("f16x3", 3),
+        "FcWgrad": ("f16x3", 3), "ConvWgrad3": ("f16x3", 3), "ConvWgrad2": ("f16x3", 3)}
 # executed / algorithmic MFMA work of the kernels that walk padded operands
 EXECUTED_OVER_ALGORITHMIC = {"ConvDgrad3": 1.84, "ConvDgrad2": 1.23, "ConvFwd3": 1.11, "ConvWgrad3": 112.0 / 98.0,
                              "ConvWgrad2": 96.0 / 81.0}
@@ -151,7 +152,7 @@ def cpu_baseline():
             f = _timed(lambda: net(x[:256]), 1, 3, 2.0)
         gen = O.learn(net, net.make_optims(), x[:1024], acts[:1024], old[:1024], adv[:1024], ret[:1024], iters=10 ** 6)
         sweep[k] = {"threads": k, "forward_n256": f, "ppo_iter_B1024": _timed(lambda: next(gen), 1, 3, 4.0)}
-    cands = dict(sweep, **{k_all: full, 1: one})
+    cands = {**sweep, k_all: full, 1: one}
     best = min(cands, key=lambda k: per_env_step(cands[k]))
     out = {"value": round(1.0 / per_env_step(cands[best]), 2), "unit": "env-steps/s", "cores": best, "kind": "port",
            "sample": "oracle (torch-CPU fp32 restatement of PPO.forward / learn / GAE, pinned to the reference by tests/golden) on "
@@ -245,10 +246,10 @@ def pmc_traffic(kernel):
     if not files:
         return None
     # names in the PMC summaries follow the device functions (tools/pmc_to_profiles.py), bench names the launch sites
-    alias = {"ConvFwd1": "conv_fwd1_bf16x3", "ConvWgrad1": "conv_wgrad1_bf16x3", "ConvFwd2": "conv_fwd2_bf16x6",
-             "ConvFwd3": "conv_fwd3_bf16x6", "FcFwd": "fc_fwd_bf16x6", "FcDgrad": "fc_dgrad_bf16x6", "FcWgrad": "fc_wgrad_bf16x6",
-             "ConvDgrad3": "conv_dgrad3_bf16x6", "ConvDgrad2": "conv_dgrad2_bf16x6", "ConvWgrad3": "conv_wgrad3_bf16x6",
-             "ConvWgrad2": "conv_wgrad2_bf16x6"}
+    alias = {"ConvFwd1": "conv_fwd1_bf16x3", "ConvWgrad1": "conv_wgrad1_bf16x3", "ConvFwd2": "conv_fwd2_planes",
+             "ConvFwd3": "conv_fwd3_planes", "FcFwd": "fc_fwd_planes", "FcDgrad": "fc_dgrad_planes", "FcWgrad": "fc_wgrad_planes",
+             "ConvDgrad3": "conv_dgrad3_planes", "ConvDgrad2": "conv_dgrad2_planes", "ConvWgrad3": "conv_wgrad3_planes",
+             "ConvWgrad2": "conv_wgrad2_planes"}
     try:
         ks = json.load(open(files[-1]))["kernels"]
         k = ks.get(kernel) or ks.get(alias.get(kernel, ""))
@@ -558,8 +559,9 @@ def main():
                         "executed_over_algorithmic": round(EXECUTED_OVER_ALGORITHMIC.get(dom, 1.0), 3),
                         "note": "dominant training kernel (largest accumulated time).  achieved = ALGORITHMIC fp32 FLOP (2*2*MAC per "
                                 "sample, both encoders, x B) / launch time from HIP events on the launch stream; peak = the ceiling of the "
-                                "pipe the kernel runs on: dense bf16 MFMA 2.5 PFLOP/s / plane products (6 for two fp32 operands as "
-                                "three bf16 planes each, 3 when one operand is exact in bf16), or the f32-input MFMA peak 157.3"}
+                                "pipe the kernel runs on: dense 16-bit MFMA 2.5 PFLOP/s / plane products (3 for two fp32 operands as two "
+                                "scaled fp16 planes each, 3 when one operand is exact in bf16 and the other three bf16 planes), or the "
+                                "f32-input MFMA peak 157.3"}
             # every GEMM kernel against ITS pipe's ceiling, and the time-weighted mean over the training kernels
             tw = sum(v["ms_total"] for k, v in gemm.items() if "frac_of_pipe_ceiling" in v)
             if tw > 0:
@@ -591,10 +593,10 @@ def main():
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
             "dtype_note": "fp32 operands, fp32 accumulation, fp32-accurate results everywhere.  Every GEMM kernel of a training launch "
-                          "runs on the bf16 MFMA as exact plane products: conv1's forward and weight gradient with exact-bf16 pixels "
-                          "0..255 x three bf16 planes of the other operand (bf16x3), all others with three bf16 planes of BOTH fp32 "
-                          "operands and the six products that matter (bf16x6); errors against float64 are no larger than an fp32 "
-                          "chain's (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  'tflops' is fp32-equivalent (algorithmic) "
+                          "runs on the 16-bit MFMA as plane products: conv1's forward and weight gradient with exact-bf16 pixels "
+                          "0..255 x three bf16 planes of the other operand (bf16x3), all others with two scaled fp16 planes of BOTH "
+                          "fp32 operands (22 bits) and the three products that matter (f16x3); errors against float64 are no larger "
+                          "than an fp32 chain's (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  'tflops' is fp32-equivalent (algorithmic) "
                           "work; acting launches below 192 envs use the f32-input MFMA",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
                              "(*.act, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",

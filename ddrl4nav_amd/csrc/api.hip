@@ -184,6 +184,12 @@ int32_t ddrl_set_step(ddrl_ctx* ctx, int64_t step) {
   return DDRL_OK;
 }
 
+// the activation slots of Workspace::amax start every forward at zero (the conv epilogues raise them); the gradient slots
+// are reset by launch_encoder_backward
+static void amax_begin(ddrl_ctx* ctx, hipStream_t st) {
+  (void)hipMemsetAsync(ctx->ws.amax + amax_idx(AMAX_FIRST_ACT, 0), 0, (AMAX_DH - AMAX_FIRST_ACT) * 2 * sizeof(float), st);
+}
+
 static void ensure_packed(ddrl_ctx* ctx, hipStream_t st) {
   if (!ctx->dirty) return;
   ProfRange ps(ctx->profile ? ctx : nullptr, "pack_weights", st);
@@ -197,6 +203,7 @@ int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const floa
   if (n < 1 || n > ctx->cfg.max_batch) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
+  amax_begin(ctx, st);
   // HIP events around launches of tens of microseconds cost about as much as the launches (an event
   // record drains the queue): the acting path is only timed when asked for explicitly (on = 1)
   Profiler* prof = ctx->profile && ctx->profile_acting ? ctx : nullptr;
@@ -250,6 +257,7 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   if (B < 1 || B > ctx->cfg.max_batch || B_global < B) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
+  amax_begin(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
   launch_encoder_forward(ec, false, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, B, ctx->cfg.max_batch};
@@ -278,6 +286,7 @@ int32_t ddrl_encoder_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, vo
   if (!ctx || !frames || n < 1 || n > ctx->cfg.max_batch || ctx->L.NE != 1) return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   ensure_packed(ctx, st);
+  amax_begin(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
   launch_encoder_forward(ec, false, st);  // complete features (no split-K partials left for a head kernel to sum)
   ctx->last_n = n;

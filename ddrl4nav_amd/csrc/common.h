@@ -74,9 +74,9 @@ struct Workspace {
   // conv1 weights split into three bf16 planes (W = W1 + W2 + W3 to 24 bits), conv2.hip conv_fwd1_bf16x3_kernel:
   // [channel 4][ky pair 4][plane 3][lane half 2][row 32 NE][kx 8] bf16
   unsigned short* wp1b;
-  // conv2 weights as three bf16 planes [e][in channel 32][plane 3][oc 64][tap 16] (conv2.hip conv_fwd2_bf16x6_kernel)
+  // conv2 weights as three bf16 planes [e][in channel 32][plane 3][oc 64][tap 16] (conv2.hip conv_fwd2_planes_kernel)
   unsigned short* wp2b;
-  // conv3 weights as three bf16 planes [e][k-block 8][tap pair 5][plane 3][oc 64][tap parity 2][channel 8] (conv_fwd3_bf16x6_kernel)
+  // conv3 weights as three bf16 planes [e][k-block 8][tap pair 5][plane 3][oc 64][tap parity 2][channel 8] (conv_fwd3_planes_kernel)
   unsigned short* wp3b;
   // conv2 weights for the data gradient as three bf16 planes [e][row parity 2][k-block 8][u 2][plane 3][(c, ic) 64][v 2][oc 8]
   unsigned short* wd2b;
@@ -85,10 +85,11 @@ struct Workspace {
   // conv3 weights for the exact-tap data gradient (conv_dgrad3_exact_kernel): three bf16 planes
   // [e][k-block 8 (8 oc)][tap 9][plane 3][ic 64][oc 8]
   unsigned short* wd3c;
-  // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_bf16x6_kernel)
+  // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_planes_kernel)
   unsigned short* wlb;
-  // the same planes transposed, [e][plane 3][3136][512] (fc2.hip fc_dgrad_bf16x6_kernel)
+  // the same planes transposed, [e][plane 3][3136][512] (fc2.hip fc_dgrad_planes_kernel)
   unsigned short* wdlb;
+  float* amax;  // [AMAX_SLOTS][2 encoders], see AMAX_* below
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
@@ -103,6 +104,20 @@ struct Workspace {
   int64_t total_bytes;
 };
 
+// ---- running |max| of the tensors that are split into scaled fp16 planes (engine2.h "plane scheme") --------------------
+// amax[slot][encoder]: the weight slots are refreshed by pack_weights; the activation slots are zeroed at the start of every
+// forward (ddrl_forward, ddrl_ppo_iter, ddrl_encoder_forward) and raised by the conv epilogues (atomic max); the gradient
+// slots are zeroed by launch_encoder_backward, which measures dh and lets the data-gradient epilogues raise dz3 / dz2.
+constexpr int AMAX_WL = 0, AMAX_W2 = 1, AMAX_W3 = 2, AMAX_A1 = 3, AMAX_A2 = 4, AMAX_A3 = 5, AMAX_DH = 6, AMAX_DZ3 = 7, AMAX_DZ2 = 8,
+              AMAX_SLOTS = 9, AMAX_FIRST_ACT = AMAX_A1;
+__host__ __device__ inline int amax_idx(int slot, int e) { return slot * 2 + e; }
+// power-of-two scale that puts a tensor whose largest magnitude is m into [2^12, 2^13)
+__host__ __device__ inline float f16_scale(float m) {
+  if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f;
+  int e;
+  frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, 13 - e);
+}
 constexpr int HEAD_WG = 256;   // workgroups of the heads/loss kernel (fixed -> deterministic)
 constexpr int NORM_WG = 1024;  // workgroups of the grad-norm kernel
 
@@ -141,6 +156,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.wdlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
+  w.amax = take(64);
   w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);

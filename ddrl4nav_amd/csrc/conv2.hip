@@ -604,8 +604,8 @@ struct Fwd1B {
 
 template <int NE>
 __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
-                                                               const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
-                                                               float* __restrict__ out, int64_t out_es, int n) {
+                                                               float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
+                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd1B<NE>;
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -715,6 +715,9 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
     __syncthreads();
   }
   const float r255 = 1.0f / 255.0f;
+  float big[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) big[i] = 0.0f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = c0 + wc * 64 + j * 32 + l31;
@@ -727,10 +730,14 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = acc_row(r, hi);
-        st1_so(base + acc_row(r, 0) * 400, lanep, leaky_f(acc[i][j][r] * r255 + bias[i * 32 + oc]));
+        const float y = leaky_f(acc[i][j][r] * r255 + bias[i * 32 + oc]);
+        st1_so(base + acc_row(r, 0) * 400, lanep, y);
+        big[i] = fmaxf(big[i], fabsf(y));
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) amax_update(big[i], amax + amax_idx(AMAX_A1, i));
 }
 
 template <int NE>
@@ -744,11 +751,11 @@ static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
     configured = true;
   }
   hipLaunchKernelGGL(conv_fwd1_bf16x3_kernel<NE>, dim3((unsigned)(((int64_t)c.n * 400 + 255) / 256)), dim3(256), K::LDS_BYTES, st, c.frames,
-                     w.wp1b, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n);
+                     w.wp1b, w.amax, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n);
 }
 
 // ================================================================================================
-// conv2 forward on the bf16 matrix pipe, fp32-accurate ("bf16x6", see fc2.hip fc_fwd_bf16x6_kernel): the weights come
+// conv2 forward on the bf16 matrix pipe, fp32-accurate ("bf16x6", see fc2.hip fc_fwd_planes_kernel): the weights come
 // as three bf16 planes from optim.hip (wp2b), the a1 values are split into three planes while they are staged, and the
 // six plane products that reach 2^-18 of the largest are accumulated in fp32.  One MFMA k-group (16) = the 4 x 4 taps
 // of ONE input channel: lane (pixel, h) holds taps (ky = 2h, kx = 0..3) and (ky = 2h + 1, kx = 0..3) = two runs of four
@@ -778,7 +785,7 @@ struct Fwd2B {
   // image row pitch 26 bf16 (13 words): the 5 input-row pairs a 32-pixel column tile reads in one instruction start
   // 26 words apart = banks {0, 26, 52, 14, 40} + c, ten words each, disjoint (pitch 20: 2-way conflicts, 46 % of LDS cycles)
   static constexpr int ROW = DDRL_F2B_ROW, CH = 20 * ROW, IMG_PLANE = SPT * KC * CH;  // 12,480 B at KC = 4
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = KC * 3 * 64 * 32;  // 37,440 + 24,576 at KC = 4
+  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = KC * NPL * 64 * 32;
   static constexpr int BIAS_OFF = W_OFF + W_BYTES;
   static constexpr int NIU = SPT * KC * 100, NIJ = (NIU + 255) / 256;      // image units of 4 pixels, per thread
   static constexpr int NWJ = W_BYTES / 16 / 256;                          // weight quads per thread (6)
@@ -789,13 +796,14 @@ struct __attribute__((packed, aligned(4))) lds_u2 {
 };
 using u4v = __attribute__((ext_vector_type(4))) unsigned;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WPE, DDRL_F2B_WPE))) void conv_fwd2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
-                                                               const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
-                                                               float* __restrict__ out, int64_t out_es, int n) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WPE, DDRL_F2B_WPE))) void conv_fwd2_planes_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
+                                                               float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
+                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd2B;
   extern __shared__ __attribute__((aligned(16))) char ldsc2[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
+  const float sa = plane_scale(amax[amax_idx(AMAX_A1, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W2, e)]));
   if (tid < 64) ((float*)(ldsc2 + K::BIAS_OFF))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
   // ---- staging maps.  image unit u = tid + 256 j: sample u / 400, channel (u % 400) / 100, pixel quad u % 100
   // (row q / 5, quad q % 5).  Missing samples of the last tile read the last sample.
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
     isrc[j] = a1 + e * a1_es + (int64_t)min(b0 + s, n - 1) * 12800 + rem * 4;  // + kb * 1600
     idst[j] = (s * K::KC + rem / 100) * K::CH + (q / 5) * K::ROW + (q % 5) * 8;
   }
-  const unsigned short* wsrc = wp2b + (int64_t)e * (32 * 3 * 64 * 16) + tid * 8;  // + kb * 12288 + j * 2048
+  const unsigned short* wsrc = wp2b + (int64_t)e * (32 * NPL * 64 * 16) + tid * 8;  // + kb * KC * NPL * 1024 + j * 2048
   // ---- operand bases
   int aA[2], bB[2];
 #pragma unroll
@@ -825,24 +833,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) ir[j] = ld4(isrc[j] + kb * (400 * K::KC));
 #pragma unroll
-    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * (K::KC * 3072) + j * 2048);
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * (K::KC * NPL * 1024) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + 256 * j < K::NIU) {
         const f4 v = ir[j];
-#if DDRL_F2B_KO == 1  // knock-out (timing only): no residual planes
-        const unsigned p0a = pack_bf16x2(v.x, v.y), p0b = pack_bf16x2(v.z, v.w), p1a = p0a, p1b = p0b, p2a = p0a, p2b = p0b;
-#else
-        unsigned p0a, p0b, p1a, p1b, p2a, p2b;
-        split_bf16x3(v.x, v.y, p0a, p1a, p2a);
-        split_bf16x3(v.z, v.w, p0b, p1b, p2b);
-#endif
+        unsigned pa[NPL], pb[NPL];
+        split_planes(v.x, v.y, sa, pa);
+        split_planes(v.z, v.w, sa, pb);
         char* d = ldsc2 + idst[j];  // 4-byte aligned (odd rows start at 4 mod 8)
-        *(lds_u2*)(d) = lds_u2{p0a, p0b};
-        *(lds_u2*)(d + K::IMG_PLANE) = lds_u2{p1a, p1b};
-        *(lds_u2*)(d + 2 * K::IMG_PLANE) = lds_u2{p2a, p2b};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(lds_u2*)(d + p * K::IMG_PLANE) = lds_u2{pa[p], pb[p]};
       }
     }
 #pragma unroll
@@ -863,37 +866,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < K::KC; ++kg) {
-      bf8 a[3][2], b[3][2];
+      frag8 a[NPL][2], b[NPL][2];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8*)(ldsc2 + aA[i] + (kg * 3 + p) * 2048);
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const frag8*)(ldsc2 + aA[i] + (kg * NPL + p) * 2048);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const char* q = ldsc2 + bB[j] + p * K::IMG_PLANE + kg * K::CH;
           const lds_u2 lo = *(const lds_u2*)q, up = *(const lds_u2*)(q + K::ROW);
-          b[p][j] = __builtin_bit_cast(bf8, (u4v){lo.x, lo.y, up.x, up.y});
+          b[p][j] = __builtin_bit_cast(frag8, (u4v){lo.x, lo.y, up.x, up.y});
         }
       }
       // smallest products first
-      DDRL_BF16X6_PRODUCTS;
+      DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
       commit();
-#if DDRL_F2B_KO != 2  // knock-out 2 (timing only): no global loads inside the loop
       if (kb + 2 < NKB) fetch(kb + 2);
-#endif
     }
     __syncthreads();
   }
   const float* bias = (const float*)(ldsc2 + K::BIAS_OFF);
+  float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = wc * 64 + j * 32 + l31;
@@ -906,26 +908,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = i * 32 + acc_row(r, hi);
-        st1_so(base + (i * 32 + acc_row(r, 0)) * 81, lb, leaky_f(acc[i][j][r] + bias[oc]));
+        const float y = leaky_f(acc[i][j][r] * inv + bias[oc]);
+        st1_so(base + (i * 32 + acc_row(r, 0)) * 81, lb, y);
+        big = fmaxf(big, fabsf(y));
       }
   }
+  amax_update(big, amax + amax_idx(AMAX_A2, e));
 }
-static void launch_fwd2_bf16x6(const EncCall& c, hipStream_t st) {
+static void launch_fwd2_planes(const EncCall& c, hipStream_t st) {
   using K = Fwd2B;
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd2_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_fwd2_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_fwd2_bf16x6_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a1,
-                     c.max_batch * 12800, w.wp2b, c.params, L.enc_base[0] + L.enc.c2b, L.enc_base[L.NE - 1] + L.enc.c2b, w.a2, c.max_batch * 5184,
+  hipLaunchKernelGGL(conv_fwd2_planes_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a1,
+                     c.max_batch * 12800, w.wp2b, w.amax, c.params, L.enc_base[0] + L.enc.c2b, L.enc_base[L.NE - 1] + L.enc.c2b, w.a2, c.max_batch * 5184,
                      c.n);
 }
 
 // ================================================================================================
-// conv3 forward as bf16x6 (see conv_fwd2_bf16x6_kernel).  Nine taps per input channel do not fill an MFMA k-group, so the
+// conv3 forward as bf16x6 (see conv_fwd2_planes_kernel).  Nine taps per input channel do not fill an MFMA k-group, so the
 // k index runs over CHANNELS: the a2 block is staged channel-innermost ([plane][sample][pixel][8 channels] bf16, one
 // 16-byte fragment per pixel) and one k-group = (two taps) x (8 channels): lane half h reads tap 2 kg + h.  Nine taps =
 // 4.5 pairs: the tenth "tap" re-reads tap 8 against zero weights (10 % of the MFMAs).  Tile = 64 output channels x 5
@@ -942,20 +947,21 @@ struct Fwd3B {
   // column tiles per wave (2 x 4 fragment tiles = 10 samples per tile measured 3.00 vs 2.70 ms: not a general win); whole samples per tile
   static constexpr int TN = DDRL_F3B_TN, SPT = (128 * TN) / 49, NPX = SPT * 81;
   static constexpr int IMG_PLANE = NPX * 16;                      // 6,480 B
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 19,440 + 30,720
+  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 5 * NPL * 64 * 32;
   static constexpr int BIAS_OFF = W_OFF + W_BYTES;
   static constexpr int NIJ = (NPX + 255) / 256;                   // pixel units per thread (2)
   static constexpr int NWJ = (W_BYTES / 16 + 255) / 256;          // weight quads per thread (8, the last one partial)
   static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WPE, DDRL_F3B_WPE))) void conv_fwd3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
-                                                               const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
-                                                               float* __restrict__ out, int64_t out_es, int n) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WPE, DDRL_F3B_WPE))) void conv_fwd3_planes_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
+                                                               float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
+                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd3B;
   extern __shared__ __attribute__((aligned(16))) char ldsc3[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
+  const float sa = plane_scale(amax[amax_idx(AMAX_A2, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W3, e)]));
   if (tid < 64) ((float*)(ldsc3 + K::BIAS_OFF))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
   // ---- staging maps.  pixel unit u = tid + 256 j: sample u / 81, pixel u % 81; it loads the 8 channels of the k-block
   // (stride 81 floats) and writes one 16-byte fragment per plane.  Missing samples of the last tile read the last one.
@@ -966,7 +972,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WP
     const int s = u / 81, px = u % 81;
     isrc[j] = a2 + e * a2_es + (int64_t)min(b0 + s, n - 1) * 5184 + px;  // + (8 kb + c) * 81
   }
-  const unsigned short* wsrc = wp3b + (int64_t)e * (8 * 5 * 3 * 64 * 16) + tid * 8;  // + kb * 15360 + j * 2048
+  const unsigned short* wsrc = wp3b + (int64_t)e * (8 * 5 * NPL * 64 * 16) + tid * 8;  // + kb * 5 * NPL * 1024 + j * 2048
   // ---- operand bases
   int aA[2], bB[K::TN], tapoff[5];
 #pragma unroll
@@ -992,19 +998,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WP
       for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 81];
 #pragma unroll
     for (int j = 0; j < K::NWJ; ++j)
-      if (j + 1 < K::NWJ || tid + 256 * j < K::W_BYTES / 16) wr[j] = *(const f4*)(wsrc + kb * 15360 + j * 2048);
+      if (j + 1 < K::NWJ || tid + 256 * j < K::W_BYTES / 16) wr[j] = *(const f4*)(wsrc + kb * (5 * NPL * 1024) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + 256 * j < K::NPX) {
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(ir[j][2 * c], ir[j][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], sa, pl[c]);
         char* d = ldsc3 + (tid + 256 * j) * 16;
-        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
-        *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
-        *(u4v*)(d + 2 * K::IMG_PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
       }
     }
 #pragma unroll
@@ -1026,21 +1031,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WP
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < 5; ++kg) {
-      bf8 a[3][2], b[3][K::TN];
+      frag8 a[NPL][2], b[NPL][K::TN];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8*)(ldsc3 + aA[i] + (kg * 3 + p) * 2048);
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const frag8*)(ldsc3 + aA[i] + (kg * NPL + p) * 2048);
 #pragma unroll
-        for (int j = 0; j < K::TN; ++j) b[p][j] = *(const bf8*)(ldsc3 + bB[j] + tapoff[kg] + p * K::IMG_PLANE);
+        for (int j = 0; j < K::TN; ++j) b[p][j] = *(const frag8*)(ldsc3 + bB[j] + tapoff[kg] + p * K::IMG_PLANE);
       }
-      DDRL_BF16X6_PRODUCTS;
+      DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < K::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -1050,6 +1055,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WP
     __syncthreads();
   }
   const float* bias = (const float*)(ldsc3 + K::BIAS_OFF);
+  float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < K::TN; ++j) {
     const int c = wc * (32 * K::TN) + j * 32 + l31;
@@ -1062,21 +1068,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WP
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = i * 32 + acc_row(r, hi);
-        st1_so(base + (i * 32 + acc_row(r, 0)) * 49, lb, leaky_f(acc[i][j][r] + bias[oc]));
+        const float y = leaky_f(acc[i][j][r] * inv + bias[oc]);
+        st1_so(base + (i * 32 + acc_row(r, 0)) * 49, lb, y);
+        big = fmaxf(big, fabsf(y));
       }
   }
+  amax_update(big, amax + amax_idx(AMAX_A3, e));
 }
-static void launch_fwd3_bf16x6(const EncCall& c, hipStream_t st) {
+static void launch_fwd3_planes(const EncCall& c, hipStream_t st) {
   using K = Fwd3B;
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd3_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_fwd3_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_fwd3_bf16x6_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a2,
-                     c.max_batch * 5184, w.wp3b, c.params, L.enc_base[0] + L.enc.c3b, L.enc_base[L.NE - 1] + L.enc.c3b, w.a3, c.max_batch * FLAT,
+  hipLaunchKernelGGL(conv_fwd3_planes_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a2,
+                     c.max_batch * 5184, w.wp3b, w.amax, c.params, L.enc_base[0] + L.enc.c3b, L.enc_base[L.NE - 1] + L.enc.c3b, w.a3, c.max_batch * FLAT,
                      c.n);
 }
 
@@ -1118,7 +1127,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
 #ifndef DDRL_FWD2_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
-      launch_fwd2_bf16x6(c, st);
+      launch_fwd2_planes(c, st);
     } else
 #endif
     if (narrow(81)) {
@@ -1133,7 +1142,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
 #ifndef DDRL_FWD3_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD3_F32 keeps the fp32-MFMA kernel
     if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
-      launch_fwd3_bf16x6(c, st);
+      launch_fwd3_planes(c, st);
     } else
 #endif
     if (narrow(49)) {
@@ -1281,7 +1290,7 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
 }
 
 // ================================================================================================
-// conv3 data gradient as bf16x6, gather form (see conv_fwd3_bf16x6_kernel, whose mirror image it is):
+// conv3 data gradient as bf16x6, gather form (see conv_fwd3_planes_kernel, whose mirror image it is):
 //   dz2[b][ic][y][x] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][y-ky][x-kx] W3[oc][ic][ky][kx]
 // dz3 is staged channel-innermost into zero-bordered 11 x 11 images (data at +2, +2; [plane][sample][pixel][8 oc] bf16),
 // one MFMA k-group = (two taps) x 8 oc, the tenth tap padded with zero weights; tile = 64 ic x 3 whole samples (243
@@ -1297,19 +1306,20 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
 struct Dgrad3B {
   static constexpr int THREADS = 256, TN = DDRL_D3B_TN, SPT = (128 * TN) / 81;  // column tiles per wave, whole samples per tile
   static constexpr int IMG_PLANE = SPT * 121 * 16;                // 5,808 B
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 5 * 3 * 64 * 32;  // 17,424 + 30,720
+  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 5 * NPL * 64 * 32;
   static constexpr int NIU = SPT * 49, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 147 -> 1 per thread
   static constexpr int NWQ = W_BYTES / 16, NWJ = (NWQ + THREADS - 1) / THREADS;  // 1,920 weight quads -> 8 per thread (last partial)
   static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad3_bf16x6_kernel(
-    const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3b, const float* __restrict__ a2, float* __restrict__ out,
-    int64_t out_es, int n) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad3_planes_kernel(
+    const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3b, float* __restrict__ amax, const float* __restrict__ a2,
+    float* __restrict__ out, int64_t out_es, int n) {
   using K = Dgrad3B;
   extern __shared__ __attribute__((aligned(16))) char ldsd3[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
+  const float sa = plane_scale(amax[amax_idx(AMAX_DZ3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W3, e)]));
   for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd3 + i * 16) = zero4();  // images incl. their zero borders
   // ---- staging maps.  unit u = tid + 256 j: sample u / 49, pixel u % 49 -> 8 loads of stride 49 (the k-block's 8 oc)
   const float* isrc[K::NIJ];
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     isrc[j] = dz3 + e * dz_es + (int64_t)min(b0 + s, n - 1) * FLAT + px;  // + (8 kb + c) * 49
     idst[j] = (s * 121 + (px / 7 + 2) * 11 + px % 7 + 2) * 16;
   }
-  const unsigned short* wsrc = wd3b + (int64_t)e * (8 * 5 * 3 * 64 * 16) + tid * 8;  // + kb * 15360 + j * 2048
+  const unsigned short* wsrc = wd3b + (int64_t)e * (8 * 5 * NPL * 64 * 16) + tid * 8;  // + kb * 5 * NPL * 1024 + j * 2048
   // ---- operand bases
   int aA[2], bB[K::TN], tapoff[5];
 #pragma unroll
@@ -1347,19 +1357,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 49];
 #pragma unroll
     for (int j = 0; j < K::NWJ; ++j)
-      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * 15360 + j * 2048);
+      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * (5 * NPL * 1024) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(ir[j][2 * c], ir[j][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], sa, pl[c]);
         char* d = ldsd3 + idst[j];
-        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
-        *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
-        *(u4v*)(d + 2 * K::IMG_PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
       }
     }
 #pragma unroll
@@ -1382,22 +1391,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < 5; ++kg) {
-      bf8 af[3][2], bfr[3][K::TN];
+      frag8 af[NPL][2], bfr[NPL][K::TN];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[p][i] = *(const bf8*)(ldsd3 + aA[i] + (kg * 3 + p) * 2048);
+        for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(ldsd3 + aA[i] + (kg * NPL + p) * 2048);
 #pragma unroll
-        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const bf8*)(ldsd3 + bB[j] - tapoff[kg] + p * K::IMG_PLANE);
+        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const frag8*)(ldsd3 + bB[j] - tapoff[kg] + p * K::IMG_PLANE);
       }
-      DDRL_BF16X6_PRODUCTS;
+      DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < K::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bfr[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -1407,6 +1415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
   }
   // dz2 = leaky'(a2) * sum; a2 is read here, one column tile (32 values per lane) at a time
+  float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < K::TN; ++j) {
     const int c = wc * (32 * K::TN) + j * 32 + l31;
@@ -1423,19 +1432,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) op[(i * 32 + acc_row(r, 0)) * 81] = leaky_g(av[i][r], acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) {
+        const float g = leaky_g(av[i][r], acc[i][j][r] * inv);
+        op[(i * 32 + acc_row(r, 0)) * 81] = g;
+        big = fmaxf(big, fabsf(g));
+      }
   }
+  amax_update(big, amax + amax_idx(AMAX_DZ2, e));
 }
-static void launch_dgrad3_bf16x6(const EncCall& c, hipStream_t st) {
+static void launch_dgrad3_planes(const EncCall& c, hipStream_t st) {
   using K = Dgrad3B;
   const Workspace& w = *c.ws;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_dgrad3_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_dgrad3_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_dgrad3_bf16x6_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)c.L->NE), dim3(K::THREADS), K::LDS_BYTES, st,
-                     w.dz3, c.max_batch * FLAT, w.wd3b, w.a2, w.dz2, c.max_batch * 5184, c.n);
+  hipLaunchKernelGGL(conv_dgrad3_planes_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)c.L->NE), dim3(K::THREADS), K::LDS_BYTES, st,
+                     w.dz3, c.max_batch * FLAT, w.wd3b, w.amax, w.a2, w.dz2, c.max_batch * 5184, c.n);
 }
 
 // ================================================================================================
@@ -1679,7 +1693,7 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 #ifdef DDRL_DGRAD3_EXACT  // exact taps, lanes = samples (conv_dgrad3_exact_kernel): 0.60 x the MFMAs, 4.49 ms against 4.39 -- its
   launch_dgrad3_exact(c, st);  // k-blocks of 8 oc carry only ~100 MFMAs per wave between two barriers and a 27 KB weight copy
 #else
-  launch_dgrad3_bf16x6(c, st);
+  launch_dgrad3_planes(c, st);
 #endif
   (void)MB;
   return;
@@ -1709,7 +1723,7 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv2 data gradient as bf16x6 (see conv_fwd2_bf16x6_kernel / conv_fwd3_bf16x6_kernel):
+// conv2 data gradient as bf16x6 (see conv_fwd2_planes_kernel / conv_fwd3_planes_kernel):
 //   da1[b][ic][2p+a][2q+c] = sum_{oc,u,v} dz2[b][oc][p-u][q-v] W2[oc][ic][2u+a][2v+c]
 // A workgroup owns one row parity a, both column parities c (rows = (c, ic) = 64) and 5 whole samples
 // (cols = (sample, p, q) = 500, wave w = columns 128 w .. 128 w + 127, 2 x 4 fragment tiles per wave).  dz2 is staged
@@ -1723,14 +1737,14 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 struct Dgrad2B {
   static constexpr int SPT = 5, THREADS = 256, TN = 4;
   static constexpr int IMG_PLANE = SPT * 121 * 16;                // 9,680 B
-  static constexpr int W_OFF = 3 * IMG_PLANE, W_BYTES = 2 * 3 * 64 * 32;  // 29,040 + 12,288
+  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 2 * NPL * 64 * 32;
   static constexpr int NIU = SPT * 81, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 405 -> 2 per thread
   static constexpr int NWQ = W_BYTES / 16, NWJ = NWQ / THREADS;              // 768 weight quads -> 3 per thread
   static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad2_bf16x6_kernel(const float* __restrict__ dz2, int64_t dz_es, const unsigned short* __restrict__ wd2b,
-                                                                 float* __restrict__ out, int64_t out_es, int n) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad2_planes_kernel(const float* __restrict__ dz2, int64_t dz_es, const unsigned short* __restrict__ wd2b,
+                                                                 const float* __restrict__ amax, float* __restrict__ out, int64_t out_es, int n) {
   using K = Dgrad2B;
   extern __shared__ __attribute__((aligned(16))) char ldsd2[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -1740,6 +1754,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int e = blockIdx.y, a = (blockIdx.x >> 3) & 1, tile = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
   const int b0 = tile * K::SPT;
   if (b0 >= n) return;  // padding of the tile count to a multiple of 8 (whole workgroup, before any barrier)
+  const float sa = plane_scale(amax[amax_idx(AMAX_DZ2, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W2, e)]));
   for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd2 + i * 16) = zero4();  // images incl. their zero borders
   // ---- staging maps.  unit u = tid + 256 j: sample u / 81, pixel u % 81 -> 8 loads of stride 81 (the k-block's 8 oc)
   const float* isrc[K::NIJ];
@@ -1751,7 +1766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     isrc[j] = dz2 + e * dz_es + (int64_t)min(b0 + s, n - 1) * 5184 + px;  // + (8 kb + c) * 81
     idst[j] = (s * 121 + (px / 9 + 1) * 11 + px % 9 + 1) * 16;
   }
-  const unsigned short* wsrc = wd2b + (int64_t)(e * 2 + a) * (8 * 2 * 3 * 64 * 16) + tid * 8;  // + kb * 6144 + j * 2048
+  const unsigned short* wsrc = wd2b + (int64_t)(e * 2 + a) * (8 * 2 * NPL * 64 * 16) + tid * 8;  // + kb * 2 * NPL * 1024 + j * 2048
   // ---- operand bases
   int aA[2], bB[K::TN];
 #pragma unroll
@@ -1771,19 +1786,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 81];
 #pragma unroll
-    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * 6144 + j * 2048);
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * (2 * NPL * 1024) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(ir[j][2 * c], ir[j][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], sa, pl[c]);
         char* d = ldsd2 + idst[j];
-        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
-        *(u4v*)(d + K::IMG_PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
-        *(u4v*)(d + 2 * K::IMG_PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
       }
     }
 #pragma unroll
@@ -1805,22 +1819,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {  // kg = u
-      bf8 af[3][2], bfr[3][K::TN];
+      frag8 af[NPL][2], bfr[NPL][K::TN];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[p][i] = *(const bf8*)(ldsd2 + aA[i] + (kg * 3 + p) * 2048);
+        for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(ldsd2 + aA[i] + (kg * NPL + p) * 2048);
 #pragma unroll
-        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const bf8*)(ldsd2 + bB[j] + p * K::IMG_PLANE - kg * (11 * 16));
+        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const frag8*)(ldsd2 + bB[j] + p * K::IMG_PLANE - kg * (11 * 16));
       }
-      DDRL_BF16X6_PRODUCTS;
+      DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < K::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bfr[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -1837,20 +1850,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (c >= K::SPT * 100 || b0 + s >= n) continue;
     float* base = out + e * out_es + (int64_t)(b0 + s) * 12800 + (2 * (pq / 10) + a) * 20 + 2 * (pq % 10);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) *(float2*)(base + acc_row(r, hi) * 400) = make_float2(acc[0][j][r], acc[1][j][r]);
+    for (int r = 0; r < 16; ++r) *(float2*)(base + acc_row(r, hi) * 400) = make_float2(acc[0][j][r] * inv, acc[1][j][r] * inv);
   }
 }
-static void launch_dgrad2_bf16x6(const EncCall& c, hipStream_t st) {
+static void launch_dgrad2_planes(const EncCall& c, hipStream_t st) {
   using K = Dgrad2B;
   const Workspace& w = *c.ws;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_dgrad2_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_dgrad2_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
   const unsigned tiles8 = (unsigned)(((c.n + K::SPT - 1) / K::SPT + 7) / 8 * 8);
-  hipLaunchKernelGGL(conv_dgrad2_bf16x6_kernel, dim3(tiles8 * 2, (unsigned)c.L->NE, 1), dim3(K::THREADS),
-                     K::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.dz1, c.max_batch * 12800, c.n);
+  hipLaunchKernelGGL(conv_dgrad2_planes_kernel, dim3(tiles8 * 2, (unsigned)c.L->NE, 1), dim3(K::THREADS),
+                     K::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.amax, w.dz1, c.max_batch * 12800, c.n);
 }
 
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
@@ -1859,7 +1872,7 @@ void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
   ConvDgrad2v2::Params p{w.dz2, MB * 5184, w.wd2p, w.a1, w.dz1, MB * 12800, c.n};
   ProfRange pr(c.prof, "ConvDgrad2", st);
 #ifndef DDRL_DGRAD2_F32  // default: the bf16x6 kernel; -DDDRL_DGRAD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-  launch_dgrad2_bf16x6(c, st);
+  launch_dgrad2_planes(c, st);
   (void)p;
   return;
 #endif

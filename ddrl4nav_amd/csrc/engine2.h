@@ -429,4 +429,67 @@ __device__ __forceinline__ void split_bf16x3(float x, float y, unsigned& p0, uns
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// ---- plane scheme of the kernels with TWO fp32 operands -----------------------------------------------------------
+// Default "f16x3": every operand as TWO scaled fp16 planes, x S = h0 + h1 to 22 bits (h0 = fp16(x S), h1 = fp16(x S - h0),
+// round-to-nearest-even; S = f16_scale(largest magnitude of the tensor), a power of two, so scaling and un-scaling are
+// exact), and the three products h0 g0, h0 g1, h1 g0 on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  What is left out
+// (h1 g1 and the representation error) is <= 3 x 2^-22 |a b| per term with zero mean; measured against float64 it does not
+// show next to the rounding of the fp32 accumulation itself (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  Half the
+// matrix instructions and two thirds of the LDS planes of "bf16x6" (three bf16 planes per operand, six products), which
+// -DDDRL_PLANES_BF16 keeps: bf16 has fp32's exponent range and needs no scale.
+// Range: with the tensor's maximum at [2^12, 2^13) every element down to 2^-16 of it keeps its 22 bits (fp16 normal range
+// 2^-14), below that the absolute error stays <= 2^-25 / S, i.e. <= 2^-38 of the maximum -- far below 2^-24 of any sum that
+// the large elements take part in.
+using f16x2_t = __attribute__((ext_vector_type(2))) _Float16;
+using h8v = __attribute__((ext_vector_type(8))) _Float16;
+using b8v = __attribute__((ext_vector_type(8))) __bf16;
+#ifndef DDRL_PLANES_BF16
+constexpr int NPL = 2, NPROD = 3;
+using frag8 = h8v;
+#define DDRL_PLANE_PRODUCTS constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0} /* smallest first: h1 g0, h0 g1, h0 g0 */
+__device__ __forceinline__ void split_planes(float x, float y, float scale, unsigned (&p)[NPL]) {
+  const float xs = x * scale, ys = y * scale;
+  const f16x2_t a = {(_Float16)xs, (_Float16)ys};
+  const f16x2_t b = {(_Float16)(xs - (float)a[0]), (_Float16)(ys - (float)a[1])};
+  p[0] = __builtin_bit_cast(unsigned, a);
+  p[1] = __builtin_bit_cast(unsigned, b);
+}
+__device__ __forceinline__ f32x16 mfma_planes(frag8 a, frag8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__host__ __device__ inline float plane_scale(float amax) { return f16_scale(amax); }
+__host__ __device__ inline void planes_of(float w, float scale, unsigned short (&p)[NPL]) {
+  const float ws = w * scale;
+  const _Float16 h0 = (_Float16)ws;
+  const _Float16 h1 = (_Float16)(ws - (float)h0);
+  p[0] = __builtin_bit_cast(unsigned short, h0);
+  p[1] = __builtin_bit_cast(unsigned short, h1);
+}
+#else
+constexpr int NPL = 3, NPROD = 6;
+using frag8 = b8v;
+#define DDRL_PLANE_PRODUCTS constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0}
+__device__ __forceinline__ void split_planes(float x, float y, float, unsigned (&p)[NPL]) { split_bf16x3(x, y, p[0], p[1], p[2]); }
+__device__ __forceinline__ f32x16 mfma_planes(frag8 a, frag8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__host__ __device__ inline float plane_scale(float) { return 1.0f; }
+__host__ __device__ inline void planes_of(float w, float, unsigned short (&p)[NPL]) {
+  auto rne = [](float v) { unsigned u = __builtin_bit_cast(unsigned, v); return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+  p[0] = rne(w);
+  const float r1 = w - __builtin_bit_cast(float, (unsigned)p[0] << 16);
+  p[1] = rne(r1);
+  p[2] = rne(r1 - __builtin_bit_cast(float, (unsigned)p[1] << 16));
+}
+#endif
+// largest magnitude of the values a thread wrote -> the tensor's running maximum (float bits of non-negative values order like
+// unsigned integers; the maximum does not depend on the order of the atomics, so the result is deterministic).
+// One atomic per wave on ONE address serialises in the memory system (25,600 of them cost conv1's forward 6 ms): a wave
+// first LOOKS at the slot and only sends the atomic when it would raise it -- after the first few waves almost none does.
+// A stale look can only be too small (the slot never decreases), i.e. it costs an atomic, never a missed maximum.
+__device__ __forceinline__ void amax_update(float m, float* slot) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load((unsigned*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)slot, bits);
+  }
+}
+
 }  // namespace ddrl

@@ -390,17 +390,18 @@ struct FcWgrad2 : FcCommon {
 using bf8f = __attribute__((ext_vector_type(8))) __bf16;
 
 struct FcFwdB {
-  static constexpr int PITCH = 80, PLANE = 128 * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
+  static constexpr int PITCH = 80, PLANE = 128 * PITCH, B_OFF = NPL * PLANE, LDS_BYTES = 2 * NPL * PLANE;
 };
 
-__global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
-                                                            const float* __restrict__ params, int64_t bias_off0, int64_t bias_off1,
-                                                            float* __restrict__ h, int64_t h_es, int n) {
+__global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
+                                                            const float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
+                                                            int64_t bias_off1, float* __restrict__ h, int64_t h_es, int n) {
   using K = FcFwdB;
   extern __shared__ __attribute__((aligned(16))) char ldsf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
   const int e = blockIdx.z, n0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+  const float sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: activations = 4 quads of 4 k per thread (row rr + 32 j, k4), weights = 2 x 3 fragments of 8 k
   const int k4 = tid & 7, rr = tid >> 3;
   const float* asrc[4];
@@ -413,31 +414,30 @@ __global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restr
   for (int i = 0; i < 2; ++i) aA[i] = (wr * 64 + i * 32 + l31) * K::PITCH + hi * 16;
 #pragma unroll
   for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (wc * 64 + j * 32 + l31) * K::PITCH + hi * 16;
-  f4 ar[4], wrg[2][3];
+  f4 ar[4], wrg[2][NPL];
   auto fetch = [&](int kb) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ar[j] = ld4(asrc[j] + kb * 32);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wrg[j][p] = *(const f4*)(wsrc + (int64_t)p * FLAT * FEAT + (int64_t)j * 64 * FLAT + kb * 32);
+      for (int p = 0; p < NPL; ++p) wrg[j][p] = *(const f4*)(wsrc + (int64_t)p * FLAT * FEAT + (int64_t)j * 64 * FLAT + kb * 32);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f4 v = ar[j];
-      unsigned p0a, p0b, p1a, p1b, p2a, p2b;
-      split_bf16x3(v.x, v.y, p0a, p1a, p2a);
-      split_bf16x3(v.z, v.w, p0b, p1b, p2b);
+      unsigned pa[NPL], pb[NPL];
+      split_planes(v.x, v.y, sa, pa);
+      split_planes(v.z, v.w, sa, pb);
       char* d = ldsf + (rr + 32 * j) * K::PITCH + k4 * 8;
-      *(uint2*)(d) = make_uint2(p0a, p0b);
-      *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
-      *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(f4*)(ldsf + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + k8 * 16) = wrg[j][p];
+      for (int p = 0; p < NPL; ++p) *(f4*)(ldsf + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + k8 * 16) = wrg[j][p];
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -454,21 +454,21 @@ __global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restr
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
-      bf8f a[3][2], b[3][2];
+      frag8 a[NPL][2], b[NPL][2];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8f*)(ldsf + aA[i] + p * K::PLANE + kg * 32);
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const frag8*)(ldsf + aA[i] + p * K::PLANE + kg * 32);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8f*)(ldsf + bB[j] + p * K::PLANE + kg * 32);
+        for (int j = 0; j < 2; ++j) b[p][j] = *(const frag8*)(ldsf + bB[j] + p * K::PLANE + kg * 32);
       }
-      DDRL_BF16X6_PRODUCTS;
+      DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void fc_fwd_bf16x6_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-        if (b < n) dst[(int64_t)b * FEAT + nn] = acc[i][j][r] + bias;
+        if (b < n) dst[(int64_t)b * FEAT + nn] = acc[i][j][r] * inv + bias;
       }
   }
 }
@@ -504,11 +504,11 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   if (nsplit == 1) {
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)fc_fwd_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)fc_fwd_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
       configured = true;
     }
-    hipLaunchKernelGGL(fc_fwd_bf16x6_kernel, dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE), dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT,
-                       w.wlb, c.params, c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n);
+    hipLaunchKernelGGL(fc_fwd_planes_kernel, dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE), dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT,
+                       w.wlb, w.amax, c.params, c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n);
     return;
   }
 #endif
@@ -516,7 +516,7 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense-layer data gradient as bf16x6 (same structure as fc_fwd_bf16x6_kernel with the roles K = 512 features,
+// Dense-layer data gradient as bf16x6 (same structure as fc_fwd_planes_kernel with the roles K = 512 features,
 // N = 3,136 conv3 outputs):  dz3[b][k] = leaky'(a3[b][k]) * sum_n dh[b][n] Wl[n][k].
 // dh is split into three bf16 planes while it is staged, the weights come pre-split and transposed from optim.hip
 // (wdlb[e][plane][k 3136][n 512]); 128 x 128 tile, k-block 32 = 2 MFMA k-groups, one LDS stage.
@@ -528,17 +528,18 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
 #define DDRL_FCD_WPE 2
 #endif
 struct FcDgradB {  // k-block KBK = 32 or 16 features; row pitch = data + 16 B so that 16 lanes' fragments hit distinct banks
-  static constexpr int KBK = DDRL_FCD_KBK, WPE = DDRL_FCD_WPE, PITCH = 2 * KBK + 16, PLANE = 128 * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
+  static constexpr int KBK = DDRL_FCD_KBK, WPE = DDRL_FCD_WPE, PITCH = 2 * KBK + 16, PLANE = 128 * PITCH, B_OFF = NPL * PLANE, LDS_BYTES = 2 * NPL * PLANE;
   static constexpr int NAQ = KBK / 4, ARJ = 128 * NAQ / 256, AROWS = 256 / NAQ;  // dh: quads of 4 features per row, per thread, rows per round
   static constexpr int NWF = KBK / 8, WJ = 128 * NWF / 256, WCOLS = 256 / NWF;   // weights: fragments of 8 features per column
 };
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::WPE, FcDgradB::WPE))) void fc_dgrad_bf16x6_kernel(const float* __restrict__ dh, int64_t dh_es, const unsigned short* __restrict__ wdlb,
-                                                              const float* __restrict__ a3, float* __restrict__ dz3, int64_t a3_es, int n) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::WPE, FcDgradB::WPE))) void fc_dgrad_planes_kernel(const float* __restrict__ dh, int64_t dh_es, const unsigned short* __restrict__ wdlb,
+                                                              float* __restrict__ amax, const float* __restrict__ a3, float* __restrict__ dz3, int64_t a3_es, int n) {
   using K = FcDgradB;
   extern __shared__ __attribute__((aligned(16))) char ldsg[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
   const int e = blockIdx.z, k0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+  const float sa = plane_scale(amax[amax_idx(AMAX_DH, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: dh = 4 quads of 4 n per thread (row rr + 32 j, n4), weights = 2 x 3 fragments of 8 n (column cc + 64 j)
   const int n4 = tid % K::NAQ, rr = tid / K::NAQ;
   const float* asrc[K::ARJ];
@@ -553,31 +554,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
   for (int i = 0; i < 2; ++i) aA[i] = (wr * 64 + i * 32 + l31) * K::PITCH + hi * 16;
 #pragma unroll
   for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (wc * 64 + j * 32 + l31) * K::PITCH + hi * 16;
-  f4 ar[K::ARJ], wrg[K::WJ][3];
+  f4 ar[K::ARJ], wrg[K::WJ][NPL];
   auto fetch = [&](int kb) {
 #pragma unroll
     for (int j = 0; j < K::ARJ; ++j) ar[j] = ld4(asrc[j] + kb * K::KBK);
 #pragma unroll
     for (int j = 0; j < K::WJ; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wrg[j][p] = *(const f4*)(wsrc[j] + (int64_t)p * FLAT * FEAT + kb * K::KBK);
+      for (int p = 0; p < NPL; ++p) wrg[j][p] = *(const f4*)(wsrc[j] + (int64_t)p * FLAT * FEAT + kb * K::KBK);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::ARJ; ++j) {
       const f4 v = ar[j];
-      unsigned p0a, p0b, p1a, p1b, p2a, p2b;
-      split_bf16x3(v.x, v.y, p0a, p1a, p2a);
-      split_bf16x3(v.z, v.w, p0b, p1b, p2b);
+      unsigned pa[NPL], pb[NPL];
+      split_planes(v.x, v.y, sa, pa);
+      split_planes(v.z, v.w, sa, pb);
       char* d = ldsg + (rr + K::AROWS * j) * K::PITCH + n4 * 8;
-      *(uint2*)(d) = make_uint2(p0a, p0b);
-      *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
-      *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
     }
 #pragma unroll
     for (int j = 0; j < K::WJ; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *(f4*)(ldsg + K::B_OFF + p * K::PLANE + (cc + K::WCOLS * j) * K::PITCH + n8 * 16) = wrg[j][p];
+      for (int p = 0; p < NPL; ++p) *(f4*)(ldsg + K::B_OFF + p * K::PLANE + (cc + K::WCOLS * j) * K::PITCH + n8 * 16) = wrg[j][p];
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -594,21 +594,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
   for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < K::KBK / 16; ++kg) {
-      bf8f a[3][2], b[3][2];
+      frag8 a[NPL][2], b[NPL][2];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[p][i] = *(const bf8f*)(ldsg + aA[i] + p * K::PLANE + kg * 32);
+        for (int i = 0; i < 2; ++i) a[p][i] = *(const frag8*)(ldsg + aA[i] + p * K::PLANE + kg * 32);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[p][j] = *(const bf8f*)(ldsg + bB[j] + p * K::PLANE + kg * 32);
+        for (int j = 0; j < 2; ++j) b[p][j] = *(const frag8*)(ldsg + bB[j] + p * K::PLANE + kg * 32);
       }
-      DDRL_BF16X6_PRODUCTS;
+      DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < NPROD; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
     }
     __syncthreads();
   }
+  float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int k = k0 + wc * 64 + j * 32 + l31;
@@ -632,10 +633,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-        if (b < n) dz3[e * a3_es + (int64_t)b * FLAT + k] = leaky_g(av[r], acc[i][j][r]);
+        const float g = leaky_g(av[r], acc[i][j][r] * inv);
+        if (b < n) {
+          dz3[e * a3_es + (int64_t)b * FLAT + k] = g;
+          big = fmaxf(big, fabsf(g));
+        }
       }
     }
   }
+  amax_update(big, amax + amax_idx(AMAX_DZ3, e));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,26 +657,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
 // ------------------------------------------------------------------------------------------------
 using s4v = __attribute__((ext_vector_type(4))) short;
 struct FcWgradB {
-  static constexpr int KB = 32, PITCH = 320, PLANE = KB * PITCH, B_OFF = 3 * PLANE, LDS_BYTES = 6 * PLANE;
+  static constexpr int KB = 32, PITCH = 320, PLANE = KB * PITCH, B_OFF = NPL * PLANE, LDS_BYTES = 2 * NPL * PLANE;
   static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena (= FcWgrad2::SLAB)
 };
 
-__device__ __forceinline__ bf8f tr_fragment(const char* lds, int byte_off) {
+__device__ __forceinline__ frag8 tr_fragment(const char* lds, int byte_off) {
   typedef s4v __attribute__((address_space(3))) * lds_s4;
   const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + byte_off));
   const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + byte_off + 4 * FcWgradB::PITCH));
   typedef __attribute__((ext_vector_type(8))) short s8v;
   const s8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf8f, v);
+  return __builtin_bit_cast(frag8, v);
 }
 
-__global__ __launch_bounds__(256) void fc_wgrad_bf16x6_kernel(const float* __restrict__ dh, int64_t dh_es, const float* __restrict__ a3,
-                                                              int64_t a3_es, float* __restrict__ part, int n, int nsplit, int ne) {
+__global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __restrict__ dh, int64_t dh_es, const float* __restrict__ a3,
+                                                              int64_t a3_es, const float* __restrict__ amax, float* __restrict__ part, int n,
+                                                              int nsplit, int ne) {
   using K = FcWgradB;
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
   const int e = blockIdx.z % ne, split = blockIdx.z / ne;
+  const float sd = plane_scale(amax[amax_idx(AMAX_DH, e)]), sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sd * sa);
   const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
   const int nkb = (n + K::KB - 1) / K::KB;
   const int per = (nkb + nsplit - 1) / nsplit;
@@ -709,17 +717,15 @@ __global__ __launch_bounds__(256) void fc_wgrad_bf16x6_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       char* d = ldsw + (kk + 8 * j) * K::PITCH + c4 * 8;
-      unsigned p0a, p0b, p1a, p1b, p2a, p2b;
-      split_bf16x3(dr[j].x, dr[j].y, p0a, p1a, p2a);
-      split_bf16x3(dr[j].z, dr[j].w, p0b, p1b, p2b);
-      *(uint2*)(d) = make_uint2(p0a, p0b);
-      *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
-      *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
-      split_bf16x3(ar[j].x, ar[j].y, p0a, p1a, p2a);
-      split_bf16x3(ar[j].z, ar[j].w, p0b, p1b, p2b);
-      *(uint2*)(d + K::B_OFF) = make_uint2(p0a, p0b);
-      *(uint2*)(d + K::B_OFF + K::PLANE) = make_uint2(p1a, p1b);
-      *(uint2*)(d + K::B_OFF + 2 * K::PLANE) = make_uint2(p2a, p2b);
+      unsigned pa[NPL], pb[NPL];
+      split_planes(dr[j].x, dr[j].y, sd, pa);
+      split_planes(dr[j].z, dr[j].w, sd, pb);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
+      split_planes(ar[j].x, ar[j].y, sa, pa);
+      split_planes(ar[j].z, ar[j].w, sa, pb);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(uint2*)(d + K::B_OFF + p * K::PLANE) = make_uint2(pa[p], pb[p]);
     }
     if (bias_owner) bsum += (dr[0] + dr[1]) + (dr[2] + dr[3]);
   };
@@ -738,21 +744,21 @@ __global__ __launch_bounds__(256) void fc_wgrad_bf16x6_kernel(const float* __res
     for (int kb = kb_begin; kb < kb_end; ++kb) {
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
-        bf8f a[3][2], b[3][2];
+        frag8 a[NPL][2], b[NPL][2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[p][i] = tr_fragment(ldsw, aA[i] + p * K::PLANE + kg * 16 * K::PITCH);
 #pragma unroll
           for (int j = 0; j < 2; ++j) b[p][j] = tr_fragment(ldsw, bB[j] + p * K::PLANE + kg * 16 * K::PITCH);
         }
-        DDRL_BF16X6_PRODUCTS;
+        DDRL_PLANE_PRODUCTS;
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < NPROD; ++t)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
       }
       __syncthreads();  // every wave is done with the stage
       if (kb + 1 < kb_end) {
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_bf16x6_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[(int64_t)(n0 + wr * 64 + i * 32 + acc_row(r, hi)) * FLAT + k] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) slab[(int64_t)(n0 + wr * 64 + i * 32 + acc_row(r, hi)) * FLAT + k] = acc[i][j][r] * inv;
   }
   if (bias_owner) {  // one column tile per (row tile, split, e) owns the bias partial
     float* red = (float*)ldsw;
@@ -796,11 +802,11 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
 #ifndef DDRL_FCWGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCWGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     static bool configured_w = false;
     if (!configured_w) {
-      (void)hipFuncSetAttribute((const void*)fc_wgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcWgradB::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)fc_wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcWgradB::LDS_BYTES);
       configured_w = true;
     }
-    hipLaunchKernelGGL(fc_wgrad_bf16x6_kernel, dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
-                       MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S, L.NE);
+    hipLaunchKernelGGL(fc_wgrad_planes_kernel, dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
+                       MB * FEAT, w.a3, MB * FLAT, w.amax, w.wpart, c.n, S, L.NE);
     (void)p;
 #else
     launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), p, st);
@@ -816,11 +822,11 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
 #ifndef DDRL_FCDGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCDGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)fc_dgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcDgradB::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)fc_dgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcDgradB::LDS_BYTES);
       configured = true;
     }
-    hipLaunchKernelGGL(fc_dgrad_bf16x6_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcDgradB::LDS_BYTES, st, w.dh, MB * FEAT,
-                       w.wdlb, w.a3, w.dz3, MB * FLAT, c.n);
+    hipLaunchKernelGGL(fc_dgrad_planes_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcDgradB::LDS_BYTES, st, w.dh, MB * FEAT,
+                       w.wdlb, w.amax, w.a3, w.dz3, MB * FLAT, c.n);
     (void)p;
     return;
 #endif

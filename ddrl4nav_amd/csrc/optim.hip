@@ -110,87 +110,81 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
 
 // dense-layer weights as three bf16 planes (see pack_conv1_bf16_kernel): wlb[e][plane][n][k]
 __global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
-                                                           unsigned short* __restrict__ dst_t) {
+                                                           unsigned short* __restrict__ dst_t, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)FLAT * FEAT) return;
   const float w = params[L.enc_base[e] + L.enc.lw + i];
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
+  unsigned short pl[NPL];
+  planes_of(w, plane_scale(amax[amax_idx(AMAX_WL, e)]), pl);
   unsigned short* d = dst + (int64_t)e * 3 * FLAT * FEAT + i;
-  d[0] = p0;
-  d[(int64_t)FLAT * FEAT] = p1;
-  d[2 * (int64_t)FLAT * FEAT] = p2;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) d[p * (int64_t)FLAT * FEAT] = pl[p];
   // transposed copy [plane][k][n] for the data gradient
   const int nn = (int)(i / FLAT), kk = (int)(i % FLAT);
   unsigned short* t = dst_t + (int64_t)e * 3 * FLAT * FEAT + (int64_t)kk * FEAT + nn;
-  t[0] = p0;
-  t[(int64_t)FLAT * FEAT] = p1;
-  t[2 * (int64_t)FLAT * FEAT] = p2;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) t[p * (int64_t)FLAT * FEAT] = pl[p];
 }
 
 // conv2 weights as three bf16 planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
-__global__ __launch_bounds__(256) void pack_conv2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_conv2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (oc, ch, tap) in parameter order
   if (i >= 64 * 32 * 16) return;
   const int tap = i & 15, ch = (i >> 4) & 31, oc = i >> 9;
   const float w = params[L.enc_base[e] + L.enc.c2w + i];
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
-  unsigned short* d = dst + (((int64_t)(e * 32 + ch) * 3) * 64 + oc) * 16 + tap;
-  d[0] = p0;
-  d[64 * 16] = p1;
-  d[2 * 64 * 16] = p2;
+  unsigned short pl[NPL];
+  planes_of(w, plane_scale(amax[amax_idx(AMAX_W2, e)]), pl);
+  unsigned short* d = dst + (((int64_t)(e * 32 + ch) * NPL) * 64 + oc) * 16 + tap;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
 // conv3 weights as three bf16 planes: wp3b[e][k-block = ic / 8][tap pair][plane][oc][tap parity][ic % 8]; the tenth tap is zero
-__global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, kg, oc, h, c)
   if (i >= 8 * 5 * 64 * 16) return;
   const int c = i & 7, h = (i >> 3) & 1, oc = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
   const int tap = 2 * kg + h;
   const float w = tap < 9 ? params[L.enc_base[e] + L.enc.c3w + (oc * 64 + kb * 8 + c) * 9 + tap] : 0.0f;
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
-  unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * 3) * 64 + oc) * 16 + h * 8 + c;
-  d[0] = p0;
-  d[64 * 16] = p1;
-  d[2 * 64 * 16] = p2;
+  unsigned short pl[NPL];
+  planes_of(w, plane_scale(amax[amax_idx(AMAX_W3, e)]), pl);
+  unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * NPL) * 64 + oc) * 16 + h * 8 + c;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
 // conv2 weights for the bf16x6 data gradient: wd2b[e][a][kb 8][u 2][plane][row = c * 32 + ic][v][o]
 //   = W2[oc = 8 kb + o][ic][2 u + a][2 v + c]
-__global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (a, kb, u, row, v, o)
   if (i >= 2 * 8 * 2 * 64 * 16) return;
   const int o = i & 7, v = (i >> 3) & 1, row = (i >> 4) & 63, u = (i >> 10) & 1, kb = (i >> 11) & 7, a = i >> 14;
   const int c = row >> 5, ic = row & 31, oc = 8 * kb + o;
   const float w = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + (2 * u + a) * 4 + 2 * v + c];
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
-  unsigned short* d = dst + (((((int64_t)(e * 2 + a) * 8 + kb) * 2 + u) * 3) * 64 + row) * 16 + v * 8 + o;
-  d[0] = p0;
-  d[64 * 16] = p1;
-  d[2 * 64 * 16] = p2;
+  unsigned short pl[NPL];
+  planes_of(w, plane_scale(amax[amax_idx(AMAX_W2, e)]), pl);
+  unsigned short* d = dst + (((((int64_t)(e * 2 + a) * 8 + kb) * 2 + u) * NPL) * 64 + row) * 16 + v * 8 + o;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
 // conv3 weights for the bf16x6 data gradient: wd3b[e][kb][tap pair][plane][ic][tap parity][o] = W3[oc = 8 kb + o][ic][tap]
-__global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, kg, ic, h, o)
   if (i >= 8 * 5 * 64 * 16) return;
   const int o = i & 7, h = (i >> 3) & 1, ic = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
   const int tap = 2 * kg + h;
   const float w = tap < 9 ? params[L.enc_base[e] + L.enc.c3w + ((8 * kb + o) * 64 + ic) * 9 + tap] : 0.0f;
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
-  unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * 3) * 64 + ic) * 16 + h * 8 + o;
-  d[0] = p0;
-  d[64 * 16] = p1;
-  d[2 * 64 * 16] = p2;
+  unsigned short pl[NPL];
+  planes_of(w, plane_scale(amax[amax_idx(AMAX_W3, e)]), pl);
+  unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * NPL) * 64 + ic) * 16 + h * 8 + o;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
 // conv3 weights for the exact-tap data gradient: wd3c[e][kb 8][tap 9][plane 3][ic 64][o 8] = W3[oc = 8 kb + o][ic][tap]
@@ -209,13 +203,28 @@ __global__ __launch_bounds__(256) void pack_dgrad3c_bf16_kernel(const float* __r
   d[1024] = p2;
 }
 
+// largest magnitude of linear.weight / conv2.weight / conv3.weight per encoder -> Workspace::amax weight slots (the
+// power-of-two scale of their fp16 planes, engine2.h plane scheme); grid (64, 3 tensors, NE), slots zeroed before
+__global__ __launch_bounds__(256) void weights_amax_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ amax) {
+  const int t = blockIdx.y, e = blockIdx.z;
+  const int64_t off = t == 0 ? L.enc.lw : t == 1 ? L.enc.c2w : L.enc.c3w;
+  const int64_t cnt = t == 0 ? (int64_t)FEAT * FLAT : t == 1 ? (int64_t)C2_OC * C2_K : (int64_t)C3_OC * C3_K;
+  const float* src = params + L.enc_base[e] + off;
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+  amax_update(m, amax + amax_idx(t == 0 ? AMAX_WL : t == 1 ? AMAX_W2 : AMAX_W3, e));
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
+  static_assert(AMAX_WL == 0 && AMAX_W2 == 1 && AMAX_W3 == 2 && AMAX_FIRST_ACT == 3, "weight slots come first");
+  (void)hipMemsetAsync(w.amax, 0, AMAX_FIRST_ACT * 2 * sizeof(float), st);
+  hipLaunchKernelGGL(weights_amax_kernel, dim3(64, 3, L.NE), dim3(256), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(8 * 9 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
-  hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b);
-  hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b);
-  hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b);
-  hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b);
-  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb);
+  hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
+  hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
+  hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
+  hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
+  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
   hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b);
   {
     const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);

@@ -502,34 +502,36 @@ struct Wgrad3B {
   // whole samples per stage.  One sample per stage (56 KB of LDS, two workgroups per CU, 4 k-groups 49/64 full) measured
   // 3.22 against 3.07 ms: the second workgroup hides the commit, the extra zero rows cost more.
   static constexpr int NB = 2, KAPPA = NB * 49, NKG = (KAPPA + 15) / 16, AROWS = NKG * 16, BROWS = NB * 81;
-  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 128, B_OFF = 3 * A_PLANE;
-  static constexpr int LDS_BYTES = 3 * A_PLANE + 3 * B_PLANE;      // NB = 2: 43,008 + 62,208
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 128, B_OFF = NPL * A_PLANE;
+  static constexpr int LDS_BYTES = NPL * (A_PLANE + B_PLANE);      // NB = 2: 14,336 + 20,736 per plane
   static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 8;   // (row, 8-channel group) staging units: 784 / 1,296
   static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;  // per thread: 4 / 6
   static constexpr int64_t SLAB = 64 * 576 + 64;
   static constexpr int WG_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
 };
 
-__device__ __forceinline__ bf8w tr_frag3(const char* lds, int off_lo, int off_hi) {
+__device__ __forceinline__ frag8 tr_frag3(const char* lds, int off_lo, int off_hi) {
   typedef s4w __attribute__((address_space(3))) * lds_s4;
   const s4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + off_lo));
   const s4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + off_hi));
   typedef __attribute__((ext_vector_type(8))) short s8w;
-  return __builtin_bit_cast(bf8w, (s8w)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  return __builtin_bit_cast(frag8, (s8w)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad3_bf16x6_kernel(const float* __restrict__ a2, int64_t a2_es, const float* __restrict__ dz3,
-                                                                 int64_t dz_es, float* __restrict__ part, int n, int nsplit, int ne) {
+__global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __restrict__ a2, int64_t a2_es, const float* __restrict__ dz3,
+                                                                 int64_t dz_es, const float* __restrict__ amax, float* __restrict__ part, int n,
+                                                                 int nsplit, int ne) {
   using K = Wgrad3B;
   extern __shared__ __attribute__((aligned(16))) char ldsw3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wi = wave >> 1, wj = wave & 1;
   const int e = blockIdx.x % ne, split = blockIdx.x / ne;
+  const float sd = plane_scale(amax[amax_idx(AMAX_DZ3, e)]), sa = plane_scale(amax[amax_idx(AMAX_A2, e)]), inv = 1.0f / (sd * sa);
   const int nst = (n + K::NB - 1) / K::NB;
   const int per = (nst + nsplit - 1) / nsplit;
   const int st_begin = split * per, st_end = min(nst, st_begin + per);
   // zero rows of the dz3 image (kappa >= 98): written once
-  for (int i = tid; i < 3 * (K::AROWS - K::KAPPA) * 8; i += 256) {
+  for (int i = tid; i < NPL * (K::AROWS - K::KAPPA) * 8; i += 256) {
     const int pl = i / ((K::AROWS - K::KAPPA) * 8), r = i % ((K::AROWS - K::KAPPA) * 8);
     *(u4w*)(ldsw3 + pl * K::A_PLANE + K::KAPPA * 128 + r * 16) = (u4w){0u, 0u, 0u, 0u};
   }
@@ -599,13 +601,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_bf16x6_kernel(const float* __
 #pragma unroll
           for (int c = 0; c < 8; ++c) ar[t][c] = 0.0f;
         }
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(ar[t][2 * c], ar[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
         char* d = ldsw3 + awr[t];
-        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
-        *(u4w*)(d + K::A_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
-        *(u4w*)(d + 2 * K::A_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::A_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
 #pragma unroll
         for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
       }
@@ -613,13 +614,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_bf16x6_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < K::NBU; ++t) {
       if (t + 1 < K::NBU || tid + 256 * t < K::B_UNITS) {
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(br[t][2 * c], br[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(br[t][2 * c], br[t][2 * c + 1], sa, pl[c]);
         char* d = ldsw3 + bwr[t];
-        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
-        *(u4w*)(d + K::B_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
-        *(u4w*)(d + 2 * K::B_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::B_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
       }
     }
   };
@@ -636,18 +636,18 @@ __global__ __launch_bounds__(256) void conv_wgrad3_bf16x6_kernel(const float* __
     for (int st = st_begin; st < st_end; ++st) {
 #pragma unroll
       for (int g = 0; g < K::NKG; ++g) {
-        bf8w a[3];
+        frag8 a[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = tr_frag3(ldsw3, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
-        DDRL_BF16X6_PRODUCTS;
+        for (int p = 0; p < NPL; ++p) a[p] = tr_frag3(ldsw3, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        DDRL_PLANE_PRODUCTS;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int toff = ((t / 3) * 9 + t % 3) * 128;
-          bf8w b[3];
+          frag8 b[NPL];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) b[p] = tr_frag3(ldsw3, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
+          for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(ldsw3, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
 #pragma unroll
-          for (int m = 0; m < 6; ++m) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[m]], b[PB[m]], acc[t], 0, 0, 0);
+          for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[PA[m]], b[PB[m]], acc[t]);
         }
       }
       __syncthreads();  // every wave is done with the stage
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_bf16x6_kernel(const float* __
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 576 + (wj * 32 + l31) * 9 + t] = acc[t][r];
+    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 576 + (wj * 32 + l31) * 9 + t] = acc[t][r] * inv;
   __syncthreads();
   float* red = (float*)ldsw3;  // [unit][8]
 #pragma unroll
@@ -690,12 +690,12 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
   {
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad3_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad3B::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad3B::LDS_BYTES);
       configured = true;
     }
     ProfRange pr(c.prof, "ConvWgrad3", st);
-    hipLaunchKernelGGL(conv_wgrad3_bf16x6_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad3B::LDS_BYTES, st, w.a2, MB * 5184, w.dz3, MB * FLAT,
-                       w.wpart, c.n, S, L.NE);
+    hipLaunchKernelGGL(conv_wgrad3_planes_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad3B::LDS_BYTES, st, w.a2, MB * 5184, w.dz3, MB * FLAT,
+                       w.amax, w.wpart, c.n, S, L.NE);
   }
 #else
   const int S = c.splits->c3;
@@ -720,27 +720,30 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
 // ================================================================================================
 struct Wgrad2B {
   static constexpr int KAPPA = 81, NKG = 6, AROWS = NKG * 16, BROWS = 400;
-  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 64, B_OFF = 3 * A_PLANE;
-  static constexpr int LDS_BYTES = 3 * A_PLANE + 3 * B_PLANE;      // 36,864 + 76,800
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 64, B_OFF = NPL * A_PLANE;
+  static constexpr int LDS_BYTES = NPL * (A_PLANE + B_PLANE);      // 12,288 + 25,600 per plane
+  static constexpr int WG_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
   static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 4;   // (row, 8-channel group) staging units: 648 / 1,600
   static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;  // per thread: 3 / 7
   static constexpr int64_t SLAB = 64 * 512 + 64;
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad2_bf16x6_kernel(const float* __restrict__ a1, int64_t a1_es, const float* __restrict__ dz2,
-                                                                 int64_t dz_es, float* __restrict__ part, int n, int nsplit, int ne) {
+__global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __restrict__ a1, int64_t a1_es, const float* __restrict__ dz2,
+                                                                 int64_t dz_es, const float* __restrict__ amax, float* __restrict__ part, int n,
+                                                                 int nsplit, int ne) {
   using K = Wgrad2B;
   extern __shared__ __attribute__((aligned(16))) char ldsw2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wi = wave >> 1, tg = wave & 1;
   const int e = blockIdx.x % ne, split = blockIdx.x / ne;
+  const float sd = plane_scale(amax[amax_idx(AMAX_DZ2, e)]), sa = plane_scale(amax[amax_idx(AMAX_A1, e)]), inv = 1.0f / (sd * sa);
   const int per = (n + nsplit - 1) / nsplit;
   const int st_begin = split * per, st_end = min(n, st_begin + per);
-  for (int i = tid; i < 3 * (K::AROWS - K::KAPPA) * 8; i += 256) {  // zero rows of the dz2 image (kappa >= 81): written once
+  for (int i = tid; i < NPL * (K::AROWS - K::KAPPA) * 8; i += 256) {  // zero rows of the dz2 image (kappa >= 81): written once
     const int pl = i / ((K::AROWS - K::KAPPA) * 8), r = i % ((K::AROWS - K::KAPPA) * 8);
     *(u4w*)(ldsw2 + pl * K::A_PLANE + K::KAPPA * 128 + r * 16) = (u4w){0u, 0u, 0u, 0u};
   }
-  // ---- staging maps (see conv_wgrad3_bf16x6_kernel)
+  // ---- staging maps (see conv_wgrad3_planes_kernel)
   const float* asrc[K::NA];
   const float* bsrc[K::NBU];
   int awr[K::NA], bwr[K::NBU];
@@ -794,13 +797,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_bf16x6_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < K::NA; ++t) {
       if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(ar[t][2 * c], ar[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
         char* d = ldsw2 + awr[t];
-        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
-        *(u4w*)(d + K::A_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
-        *(u4w*)(d + 2 * K::A_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::A_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
 #pragma unroll
         for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
       }
@@ -808,13 +810,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_bf16x6_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < K::NBU; ++t) {
       if (t + 1 < K::NBU || tid + 256 * t < K::B_UNITS) {
-        unsigned p0[4], p1[4], p2[4];
+        unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(br[t][2 * c], br[t][2 * c + 1], p0[c], p1[c], p2[c]);
+        for (int c = 0; c < 4; ++c) split_planes(br[t][2 * c], br[t][2 * c + 1], sa, pl[c]);
         char* d = ldsw2 + bwr[t];
-        *(u4w*)(d) = (u4w){p0[0], p0[1], p0[2], p0[3]};
-        *(u4w*)(d + K::B_PLANE) = (u4w){p1[0], p1[1], p1[2], p1[3]};
-        *(u4w*)(d + 2 * K::B_PLANE) = (u4w){p2[0], p2[1], p2[2], p2[3]};
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::B_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
       }
     }
   };
@@ -831,18 +832,18 @@ __global__ __launch_bounds__(256) void conv_wgrad2_bf16x6_kernel(const float* __
     for (int st = st_begin; st < st_end; ++st) {
 #pragma unroll
       for (int g = 0; g < K::NKG; ++g) {
-        bf8w a[3];
+        frag8 a[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = tr_frag3(ldsw2, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
-        DDRL_BF16X6_PRODUCTS;
+        for (int p = 0; p < NPL; ++p) a[p] = tr_frag3(ldsw2, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        DDRL_PLANE_PRODUCTS;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const int toff = ((t / 4) * 20 + t % 4) * 64;
-          bf8w b[3];
+          frag8 b[NPL];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) b[p] = tr_frag3(ldsw2, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
+          for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(ldsw2, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
 #pragma unroll
-          for (int m = 0; m < 6; ++m) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[m]], b[PB[m]], acc[t], 0, 0, 0);
+          for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[PA[m]], b[PB[m]], acc[t]);
         }
       }
       __syncthreads();  // every wave is done with the stage
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_bf16x6_kernel(const float* __
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 512 + l31 * 16 + (2 * tg + t / 4) * 4 + t % 4] = acc[t][r];
+    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 512 + l31 * 16 + (2 * tg + t / 4) * 4 + t % 4] = acc[t][r] * inv;
   __syncthreads();
   float* red = (float*)ldsw2;  // [unit][8]
 #pragma unroll
@@ -880,16 +881,17 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
 #ifndef DDRL_WGRAD2_F32  // default: the bf16x6 kernel; -DDDRL_WGRAD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-  const int S = c.splits->c2 < 256 / L.NE ? c.splits->c2 : 256 / L.NE;  // one workgroup per CU
+  const int want = 256 * Wgrad2B::WG_PER_CU / L.NE;  // as many workgroups as fit the chip at once
+  const int S = c.splits->c2 < want ? c.splits->c2 : want;
   {
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad2_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad2B::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad2_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad2B::LDS_BYTES);
       configured = true;
     }
     ProfRange pr(c.prof, "ConvWgrad2", st);
-    hipLaunchKernelGGL(conv_wgrad2_bf16x6_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad2B::LDS_BYTES, st, w.a1, MB * 12800, w.dz2, MB * 5184,
-                       w.wpart, c.n, S, L.NE);
+    hipLaunchKernelGGL(conv_wgrad2_planes_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad2B::LDS_BYTES, st, w.a1, MB * 12800, w.dz2, MB * 5184,
+                       w.amax, w.wpart, c.n, S, L.NE);
   }
 #else
   const int S = c.splits->c2;

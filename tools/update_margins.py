@@ -6,7 +6,7 @@ measured to gpurun_out/margins_measured.json; this script turns them into the co
 limit = measured x 1.5, rounded up to two significant digits.  Entries keep the measured value and the box run
 they came from, so the headroom of every bound is on record ("make the parity bounds falsifiable").
 
-usage: python tools/update_margins.py [--source gpurun_out/margins_measured.json] [--note "r02 v23, MI355X"]
+usage: python tools/update_margins.py [--source gpurun_out/margins_measured.json] [--note "r02 v23, MI355X"] [--reset]
 """
 import argparse
 import json
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--source", default=os.path.join(ROOT, "gpurun_out", "margins_measured.json"))
     ap.add_argument("--note", default="")
     ap.add_argument("--headroom", type=float, default=1.5)
+    ap.add_argument("--reset", action="store_true", help="forget earlier runs (after a kernel change): limits from this run only")
     args = ap.parse_args()
     measured = json.load(open(args.source))
     path = os.path.join(ROOT, "tests", "golden", "margins.json")
@@ -35,7 +36,7 @@ def main():
     for test, d in measured.items():
         slot = out.setdefault(test, {})
         for key, v in d.items():
-            prev = slot.get(key, {}).get("measured", 0.0)
+            prev = 0.0 if args.reset else slot.get(key, {}).get("measured", 0.0)
             m = max(prev, v)  # several boxes / runs: keep the largest ratio seen
             # a ratio that is ~0 on one box (e.g. losses inside the single-step tolerance) still gets a usable limit
             slot[key] = {"measured": round(m, 4), "limit": max(round_up(m * args.headroom), 0.5), "note": args.note or slot.get(key, {}).get("note", "")}
