@@ -36,10 +36,10 @@ FLOP_TRAIN_PER_SAMPLE = 99_030_016      # per sample per PPO iteration
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense f32-input MFMA = fp32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 # Matrix pipe and plane products of every GEMM kernel of a TRAINING launch (csrc/*.hip): "f16x3" = both fp32 operands as two
-# scaled fp16 planes each, three products (csrc/engine2.h "plane scheme"); "bf16x3" = one operand exact in bf16 (the uint8
-# pixels), the other as three bf16 planes, three products.  The ceiling a kernel is priced against is the dense 16-bit MFMA
+# scaled fp16 planes each, three products (csrc/engine2.h "plane scheme"); "f16x2" = one operand exact in fp16 (the uint8
+# pixels), the other as two scaled fp16 planes, two products.  The ceiling a kernel is priced against is the dense 16-bit MFMA
 # peak (2.5 PFLOP/s, bf16 and fp16 alike) / products, in fp32-equivalent (algorithmic) TFLOP/s.
-PIPE = {"ConvFwd1": ("bf16x3", 3), "ConvWgrad1": ("bf16x3", 3), "ConvFwd2": ("f16x3", 3), "ConvFwd3": ("f16x3", 3),
+PIPE = {"ConvFwd1": ("f16x2", 2), "ConvWgrad1": ("f16x2", 2), "ConvFwd2": ("f16x3", 3), "ConvFwd3": ("f16x3", 3),
         "FcFwd": ("f16x3", 3), "FcDgrad": ("f16x3", 3), "ConvDgrad3": ("f16x3", 3), "ConvDgrad2": ("f16x3", 3),
         "FcWgrad": ("f16x3", 3), "ConvWgrad3": ("f16x3", 3), "ConvWgrad2": ("f16x3", 3)}
 # executed / algorithmic MFMA work of the kernels that walk padded operands
@@ -246,7 +246,7 @@ def pmc_traffic(kernel):
     if not files:
         return None
     # names in the PMC summaries follow the device functions (tools/pmc_to_profiles.py), bench names the launch sites
-    alias = {"ConvFwd1": "conv_fwd1_bf16x3", "ConvWgrad1": "conv_wgrad1_bf16x3", "ConvFwd2": "conv_fwd2_planes",
+    alias = {"ConvFwd1": "conv_fwd1_planes", "ConvWgrad1": "conv_wgrad1_planes", "ConvFwd2": "conv_fwd2_planes",
              "ConvFwd3": "conv_fwd3_planes", "FcFwd": "fc_fwd_planes", "FcDgrad": "fc_dgrad_planes", "FcWgrad": "fc_wgrad_planes",
              "ConvDgrad3": "conv_dgrad3_planes", "ConvDgrad2": "conv_dgrad2_planes", "ConvWgrad3": "conv_wgrad3_planes",
              "ConvWgrad2": "conv_wgrad2_planes"}
@@ -560,7 +560,7 @@ def main():
                         "note": "dominant training kernel (largest accumulated time).  achieved = ALGORITHMIC fp32 FLOP (2*2*MAC per "
                                 "sample, both encoders, x B) / launch time from HIP events on the launch stream; peak = the ceiling of the "
                                 "pipe the kernel runs on: dense 16-bit MFMA 2.5 PFLOP/s / plane products (3 for two fp32 operands as two "
-                                "scaled fp16 planes each, 3 when one operand is exact in bf16 and the other three bf16 planes), or the "
+                                "scaled fp16 planes each, 2 when one operand -- the pixels -- is exact in fp16), or the "
                                 "f32-input MFMA peak 157.3"}
             # every GEMM kernel against ITS pipe's ceiling, and the time-weighted mean over the training kernels
             tw = sum(v["ms_total"] for k, v in gemm.items() if "frac_of_pipe_ceiling" in v)
@@ -593,8 +593,8 @@ def main():
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
             "dtype_note": "fp32 operands, fp32 accumulation, fp32-accurate results everywhere.  Every GEMM kernel of a training launch "
-                          "runs on the 16-bit MFMA as plane products: conv1's forward and weight gradient with exact-bf16 pixels "
-                          "0..255 x three bf16 planes of the other operand (bf16x3), all others with two scaled fp16 planes of BOTH "
+                          "runs on the 16-bit MFMA as plane products: conv1's forward and weight gradient with exact-fp16 pixels "
+                          "0..255 x two scaled fp16 planes of the other operand (f16x2), all others with two scaled fp16 planes of BOTH "
                           "fp32 operands (22 bits) and the three products that matter (f16x3); errors against float64 are no larger "
                           "than an fp32 chain's (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  'tflops' is fp32-equivalent (algorithmic) "
                           "work; acting launches below 192 envs use the f32-input MFMA",

@@ -72,7 +72,7 @@ struct Workspace {
   // v2 packed weights: [k-block][k-step][lane half][row], see conv2.hip / wgrad2.hip
   float *wp1, *wp2, *wp3, *wd3p, *wd2p;
   // conv1 weights split into three bf16 planes (W = W1 + W2 + W3 to 24 bits), conv2.hip conv_fwd1_bf16x3_kernel:
-  // [channel 4][ky pair 4][plane 3][lane half 2][row 32 NE][kx 8] bf16
+  // [channel 4][ky pair 4][plane NPL][lane half 2][row 32 NE][kx 8] 16-bit
   unsigned short* wp1b;
   // conv2 weights as three bf16 planes [e][in channel 32][plane 3][oc 64][tap 16] (conv2.hip conv_fwd2_planes_kernel)
   unsigned short* wp2b;
@@ -108,8 +108,8 @@ struct Workspace {
 // amax[slot][encoder]: the weight slots are refreshed by pack_weights; the activation slots are zeroed at the start of every
 // forward (ddrl_forward, ddrl_ppo_iter, ddrl_encoder_forward) and raised by the conv epilogues (atomic max); the gradient
 // slots are zeroed by launch_encoder_backward, which measures dh and lets the data-gradient epilogues raise dz3 / dz2.
-constexpr int AMAX_WL = 0, AMAX_W2 = 1, AMAX_W3 = 2, AMAX_A1 = 3, AMAX_A2 = 4, AMAX_A3 = 5, AMAX_DH = 6, AMAX_DZ3 = 7, AMAX_DZ2 = 8,
-              AMAX_SLOTS = 9, AMAX_FIRST_ACT = AMAX_A1;
+constexpr int AMAX_WL = 0, AMAX_W2 = 1, AMAX_W3 = 2, AMAX_W1 = 3, AMAX_A1 = 4, AMAX_A2 = 5, AMAX_A3 = 6, AMAX_DH = 7, AMAX_DZ3 = 8,
+              AMAX_DZ2 = 9, AMAX_DZ1 = 10, AMAX_SLOTS = 11, AMAX_FIRST_ACT = AMAX_A1;
 __host__ __device__ inline int amax_idx(int slot, int e) { return slot * 2 + e; }
 // power-of-two scale that puts a tensor whose largest magnitude is m into [2^12, 2^13)
 __host__ __device__ inline float f16_scale(float m) {

@@ -582,28 +582,30 @@ struct ConvDgrad2v2 {
 };
 
 // ================================================================================================
-// conv1 forward on the bf16 matrix rate, fp32-accurate.  The input pixels are integers 0..255 and therefore EXACT
-// in bf16; the weights are split into three bf16 planes whose sum reproduces them to 24 bits (optim.hip).  Every
-// product plane x pixel is exact in fp32, the MFMA accumulates in fp32, and the 1/255 of the reference's frame
-// normalisation is applied once to the sum:  z = (sum_k (W1 + W2 + W3)[k] x[k]) / 255 + b.  Three
-// v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each).
+// conv1 forward on the 16-bit matrix pipe, fp32-accurate.  The input pixels are integers 0..255 and therefore EXACT in
+// fp16 (and bf16); the weights come as NPL planes from optim.hip (two scaled fp16 planes whose sum reproduces them to 22
+// bits; -DDDRL_PLANES_BF16: three bf16 planes, 24 bits).  Every product plane x pixel is exact in fp32, the MFMA
+// accumulates in fp32, and the 1/255 of the reference's frame normalisation (and the planes' scale) is applied once to the
+// sum:  z = (sum_k (W0 + W1)[k] x[k]) / (255 S) + b.  Two v_mfma_f32_32x32x16_f16 (32 cycles each) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each).
 //   rows = (e, oc), cols = b*400 + pix (256 per workgroup), k-block = one input channel = 4 k-groups of 16:
 //   k = (ky = 2 g + h, kx = j): lane half h picks the image row, the 8 elements of a fragment are 8 consecutive
 //   pixels of that row (stride-4 convolution: x = 4 ox + kx), i.e. one 16-byte LDS read per operand.
-// The image is kept as bf16 rows (pitch 176 B) in natural pixel order.
+// The image is kept as 16-bit rows (pitch 176 B) in natural pixel order.
 // ================================================================================================
 using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+using u4v = __attribute__((ext_vector_type(4))) unsigned;
 using bf4 = __attribute__((ext_vector_type(4))) __bf16;
 
 template <int NE>
 struct Fwd1B {
-  static constexpr int ROWS = 32 * NE, A_BYTES = 4 * 3 * 2 * ROWS * 16, PITCH = 176, IMG_BYTES = 64 * PITCH;
+  static constexpr int ROWS = 32 * NE, A_BYTES = 4 * NPL * 2 * ROWS * 16, PITCH = 176, IMG_BYTES = 64 * PITCH;
   static constexpr int STAGE_BYTES = A_BYTES + IMG_BYTES, AQ = A_BYTES / 16, NAJ = AQ / 256;  // weight quads per thread
   static constexpr size_t LDS_BYTES = 2 * STAGE_BYTES + ROWS * 4;
 };
 
 template <int NE>
-__global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
+__global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
                                                                float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
                                                                int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
   using K = Fwd1B<NE>;
@@ -662,13 +664,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
     for (int j = 0; j < 6; ++j) {
       if (tid + 256 * j < nd_total) {
         const unsigned v = imreg[ch][j];
-        // float(byte) has at most 8 significant bits: its upper 16 bits ARE the bf16 value
-        const unsigned f0 = __float_as_uint((float)(v & 255u)), f1 = __float_as_uint((float)((v >> 8) & 255u));
-        const unsigned f2 = __float_as_uint((float)((v >> 16) & 255u)), f3 = __float_as_uint((float)(v >> 24));
-        uint2 pk;
-        pk.x = (f0 >> 16) | (f1 & 0xFFFF0000u);
-        pk.y = (f2 >> 16) | (f3 & 0xFFFF0000u);
-        *(uint2*)(st + imdst[j]) = pk;
+        *(uint2*)(st + imdst[j]) = make_uint2(pixel_pair(v & 255u, (v >> 8) & 255u), pixel_pair((v >> 16) & 255u, v >> 24));
       }
     }
   };
@@ -690,22 +686,22 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
     if (ch + 1 < 4) stage_w(ch + 1, nxt);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf8 b[2];
+      frag8 b[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {  // 8-byte aligned: two 8-byte reads
-        const bf4 lo = *(const bf4*)(cur + bbase[j] + g * (2 * K::PITCH));
-        const bf4 hi4 = *(const bf4*)(cur + bbase[j] + g * (2 * K::PITCH) + 8);
-        b[j] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        const uint2 lo = *(const uint2*)(cur + bbase[j] + g * (2 * K::PITCH));
+        const uint2 hi4 = *(const uint2*)(cur + bbase[j] + g * (2 * K::PITCH) + 8);
+        b[j] = __builtin_bit_cast(frag8, (u4v){lo.x, lo.y, hi4.x, hi4.y});
       }
 #pragma unroll
-      for (int p = 2; p >= 0; --p) {  // smallest plane first
-        bf8 a[NE];
+      for (int p = NPL - 1; p >= 0; --p) {  // smallest plane first
+        frag8 a[NE];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) a[i] = *(const bf8*)(cur + abase[i] + ((g * 3 + p) * 2) * K::ROWS * 16);
+        for (int i = 0; i < NE; ++i) a[i] = *(const frag8*)(cur + abase[i] + ((g * NPL + p) * 2) * K::ROWS * 16);
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[i], b[j], acc[i][j]);
       }
     }
     if (ch + 1 < 4) {
@@ -714,7 +710,9 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
     }
     __syncthreads();
   }
-  const float r255 = 1.0f / 255.0f;
+  float r255[NE];  // 1/255 of the frame normalisation and the scale of the encoder's weight planes
+#pragma unroll
+  for (int i = 0; i < NE; ++i) r255[i] = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_W1, i)]));
   float big[NE];
 #pragma unroll
   for (int i = 0; i < NE; ++i) big[i] = 0.0f;
@@ -730,7 +728,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = acc_row(r, hi);
-        const float y = leaky_f(acc[i][j][r] * r255 + bias[i * 32 + oc]);
+        const float y = leaky_f(acc[i][j][r] * r255[i] + bias[i * 32 + oc]);
         st1_so(base + acc_row(r, 0) * 400, lanep, y);
         big[i] = fmaxf(big[i], fabsf(y));
       }
@@ -741,16 +739,16 @@ __global__ __launch_bounds__(256) void conv_fwd1_bf16x3_kernel(const uint8_t* __
 }
 
 template <int NE>
-static void launch_fwd1_bf16x3(const EncCall& c, hipStream_t st) {
+static void launch_fwd1_planes(const EncCall& c, hipStream_t st) {
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
   using K = Fwd1B<NE>;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd1_bf16x3_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_fwd1_planes_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_fwd1_bf16x3_kernel<NE>, dim3((unsigned)(((int64_t)c.n * 400 + 255) / 256)), dim3(256), K::LDS_BYTES, st, c.frames,
+  hipLaunchKernelGGL(conv_fwd1_planes_kernel<NE>, dim3((unsigned)(((int64_t)c.n * 400 + 255) / 256)), dim3(256), K::LDS_BYTES, st, c.frames,
                      w.wp1b, w.amax, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n);
 }
 
@@ -794,7 +792,6 @@ struct Fwd2B {
 struct __attribute__((packed, aligned(4))) lds_u2 {
   unsigned x, y;
 };
-using u4v = __attribute__((ext_vector_type(4))) unsigned;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WPE, DDRL_F2B_WPE))) void conv_fwd2_planes_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
                                                                float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
@@ -1105,9 +1102,9 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     const dim3 grid((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1);
 #ifndef DDRL_FWD1_F32  // default: the bf16x3 kernel; -DDDRL_FWD1_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (L.NE == 2) {
-      launch_fwd1_bf16x3<2>(c, st);
+      launch_fwd1_planes<2>(c, st);
     } else {
-      launch_fwd1_bf16x3<1>(c, st);
+      launch_fwd1_planes<1>(c, st);
     }
     (void)grid;
 #else
@@ -1690,6 +1687,9 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
   const int64_t MB = c.max_batch;
   ProfRange pr(c.prof, "ConvDgrad3", st);
 #if !defined(DDRL_DGRAD3_GATHER) && !defined(DDRL_DGRAD3_SCATTER)  // default: the bf16x6 gather kernel over zero-padded images
+#if defined(DDRL_DGRAD3_EXACT) && !defined(DDRL_PLANES_BF16)
+#error "conv_dgrad3_exact_kernel is a bf16x6 kernel: build it with -DDDRL_PLANES_BF16"
+#endif
 #ifdef DDRL_DGRAD3_EXACT  // exact taps, lanes = samples (conv_dgrad3_exact_kernel): 0.60 x the MFMAs, 4.49 ms against 4.39 -- its
   launch_dgrad3_exact(c, st);  // k-blocks of 8 oc carry only ~100 MFMAs per wave between two barriers and a 27 KB weight copy
 #else
@@ -1744,7 +1744,7 @@ struct Dgrad2B {
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad2_planes_kernel(const float* __restrict__ dz2, int64_t dz_es, const unsigned short* __restrict__ wd2b,
-                                                                 const float* __restrict__ amax, float* __restrict__ out, int64_t out_es, int n) {
+                                                                 float* __restrict__ amax, float* __restrict__ out, int64_t out_es, int n) {
   using K = Dgrad2B;
   extern __shared__ __attribute__((aligned(16))) char ldsd2[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -1843,6 +1843,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
   }
   // rows i = column parity c: the two classes of one (p, q) are horizontally adjacent pixels -> one 8-byte store
+  float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < K::TN; ++j) {
     const int c = wc * (32 * K::TN) + j * 32 + l31;
@@ -1850,8 +1851,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (c >= K::SPT * 100 || b0 + s >= n) continue;
     float* base = out + e * out_es + (int64_t)(b0 + s) * 12800 + (2 * (pq / 10) + a) * 20 + 2 * (pq % 10);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) *(float2*)(base + acc_row(r, hi) * 400) = make_float2(acc[0][j][r] * inv, acc[1][j][r] * inv);
+    for (int r = 0; r < 16; ++r) {
+      const float g0 = acc[0][j][r] * inv, g1 = acc[1][j][r] * inv;
+      *(float2*)(base + acc_row(r, hi) * 400) = make_float2(g0, g1);
+      big = fmaxf(big, fmaxf(fabsf(g0), fabsf(g1)));
+    }
   }
+  amax_update(big, amax + amax_idx(AMAX_DZ1, e));  // da1 before the leaky mask: an upper bound of what conv1's weight gradient stages
 }
 static void launch_dgrad2_planes(const EncCall& c, hipStream_t st) {
   using K = Dgrad2B;

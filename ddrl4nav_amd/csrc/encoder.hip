@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256) void dh_amax_kernel(const float* __restrict__ 
   amax_update(m, amax + amax_idx(AMAX_DH, e));
 }
 static void launch_backward_amax(const EncCall& c, hipStream_t st) {
-  static_assert(AMAX_DZ3 == AMAX_DH + 1 && AMAX_DZ2 == AMAX_DH + 2 && AMAX_SLOTS == AMAX_DH + 3, "gradient slots are the last three");
+  static_assert(AMAX_DZ3 == AMAX_DH + 1 && AMAX_DZ2 == AMAX_DH + 2 && AMAX_DZ1 == AMAX_DH + 3 && AMAX_SLOTS == AMAX_DH + 4,
+                "gradient slots are the last four");
   const Workspace& w = *c.ws;
-  (void)hipMemsetAsync(w.amax + amax_idx(AMAX_DH, 0), 0, 3 * 2 * sizeof(float), st);  // dz3 / dz2 are raised by their producers
+  (void)hipMemsetAsync(w.amax + amax_idx(AMAX_DH, 0), 0, 4 * 2 * sizeof(float), st);  // dz3 / dz2 / dz1 are raised by their producers
   const int64_t count = (int64_t)c.n * FEAT;
   int wgs = (int)((count / 4 + 255) / 256);
   if (wgs > 512) wgs = 512;

@@ -447,15 +447,26 @@ using b8v = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int NPL = 2, NPROD = 3;
 using frag8 = h8v;
 #define DDRL_PLANE_PRODUCTS constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0} /* smallest first: h1 g0, h0 g1, h0 g0 */
+// written so that the compiler emits six VALU instructions per PAIR (v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16,
+// v_pk_fma_f32, v_cvt_pk_f16_f32); the element-wise form above compiled to ten, and the kernels issue 3 - 9 VALU
+// instructions per MFMA, most of them this split.  x S and x S - h0 are exact in fp32, so the fma changes no bit.
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void split_planes(float x, float y, float scale, unsigned (&p)[NPL]) {
-  const float xs = x * scale, ys = y * scale;
-  const f16x2_t a = {(_Float16)xs, (_Float16)ys};
-  const f16x2_t b = {(_Float16)(xs - (float)a[0]), (_Float16)(ys - (float)a[1])};
+  const f32x2_t xs = {x * scale, y * scale};
+  const f16x2_t a = __builtin_convertvector(xs, f16x2_t);
+  const f32x2_t r = {__builtin_fmaf(x, scale, -(float)a[0]), __builtin_fmaf(y, scale, -(float)a[1])};
+  const f16x2_t b = __builtin_convertvector(r, f16x2_t);
   p[0] = __builtin_bit_cast(unsigned, a);
   p[1] = __builtin_bit_cast(unsigned, b);
 }
 __device__ __forceinline__ f32x16 mfma_planes(frag8 a, frag8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __host__ __device__ inline float plane_scale(float amax) { return f16_scale(amax); }
+// frame bytes 0..255 are exact in fp16 (and in bf16): the pixel operand of conv1 is ONE plane, "f16x2" = NPL products
+__device__ __forceinline__ unsigned pixel_pair(unsigned a, unsigned b) {
+  const f16x2_t v = {(_Float16)(float)a, (_Float16)(float)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned short pixel_one(unsigned a) { return __builtin_bit_cast(unsigned short, (_Float16)(float)a); }
 __host__ __device__ inline void planes_of(float w, float scale, unsigned short (&p)[NPL]) {
   const float ws = w * scale;
   const _Float16 h0 = (_Float16)ws;
@@ -470,6 +481,11 @@ using frag8 = b8v;
 __device__ __forceinline__ void split_planes(float x, float y, float, unsigned (&p)[NPL]) { split_bf16x3(x, y, p[0], p[1], p[2]); }
 __device__ __forceinline__ f32x16 mfma_planes(frag8 a, frag8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __host__ __device__ inline float plane_scale(float) { return 1.0f; }
+// float(byte) has at most 8 significant bits: its upper 16 bits ARE the bf16 value
+__device__ __forceinline__ unsigned pixel_pair(unsigned a, unsigned b) {
+  return (__float_as_uint((float)a) >> 16) | (__float_as_uint((float)b) & 0xFFFF0000u);
+}
+__device__ __forceinline__ unsigned short pixel_one(unsigned a) { return (unsigned short)(__float_as_uint((float)a) >> 16); }
 __host__ __device__ inline void planes_of(float w, float, unsigned short (&p)[NPL]) {
   auto rne = [](float v) { unsigned u = __builtin_bit_cast(unsigned, v); return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
   p[0] = rne(w);

@@ -92,7 +92,8 @@ __device__ __forceinline__ void bf16_planes(float w, unsigned short& p0, unsigne
   const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
   p2 = bf16_rne(r2);
 }
-__global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
+__global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
+                                                              const float* __restrict__ amax) {
   const int rows = 32 * L.NE;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 4 * 4 * 2 * rows * 8) return;
@@ -100,12 +101,11 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
   const int h = r & 1, g = (r >> 1) & 3, c = r >> 3;
   const int e = row >> 5, oc = row & 31, ky = 2 * g + h;
   const float w = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + c) * 8 + ky) * 8 + j];
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
-  const int base = (c * 4 + g) * 3;
-  dst[(((base + 0) * 2 + h) * rows + row) * 8 + j] = p0;
-  dst[(((base + 1) * 2 + h) * rows + row) * 8 + j] = p1;
-  dst[(((base + 2) * 2 + h) * rows + row) * 8 + j] = p2;
+  unsigned short pl[NPL];
+  planes_of(w, plane_scale(amax[amax_idx(AMAX_W1, e)]), pl);
+  const int base = (c * 4 + g) * NPL;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) dst[(((base + p) * 2 + h) * rows + row) * 8 + j] = pl[p];
 }
 
 // dense-layer weights as three bf16 planes (see pack_conv1_bf16_kernel): wlb[e][plane][n][k]
@@ -203,29 +203,30 @@ __global__ __launch_bounds__(256) void pack_dgrad3c_bf16_kernel(const float* __r
   d[1024] = p2;
 }
 
-// largest magnitude of linear.weight / conv2.weight / conv3.weight per encoder -> Workspace::amax weight slots (the
-// power-of-two scale of their fp16 planes, engine2.h plane scheme); grid (64, 3 tensors, NE), slots zeroed before
+// largest magnitude of linear.weight / conv2.weight / conv3.weight / conv1.weight per encoder -> Workspace::amax weight slots
+// (the power-of-two scale of their fp16 planes, engine2.h plane scheme); grid (64, 4 tensors, NE), slots zeroed before
 __global__ __launch_bounds__(256) void weights_amax_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ amax) {
-  const int t = blockIdx.y, e = blockIdx.z;
-  const int64_t off = t == 0 ? L.enc.lw : t == 1 ? L.enc.c2w : L.enc.c3w;
-  const int64_t cnt = t == 0 ? (int64_t)FEAT * FLAT : t == 1 ? (int64_t)C2_OC * C2_K : (int64_t)C3_OC * C3_K;
+  const int t = blockIdx.y, e = blockIdx.z;  // t = slot
+  const int64_t off = t == AMAX_WL ? L.enc.lw : t == AMAX_W2 ? L.enc.c2w : t == AMAX_W3 ? L.enc.c3w : L.enc.c1w;
+  const int64_t cnt = t == AMAX_WL ? (int64_t)FEAT * FLAT : t == AMAX_W2 ? (int64_t)C2_OC * C2_K : t == AMAX_W3 ? (int64_t)C3_OC * C3_K
+                                                                                                              : (int64_t)C1_OC * L.C * 64;
   const float* src = params + L.enc_base[e] + off;
   float m = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
-  amax_update(m, amax + amax_idx(t == 0 ? AMAX_WL : t == 1 ? AMAX_W2 : AMAX_W3, e));
+  amax_update(m, amax + amax_idx(t, e));
 }
 
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
-  static_assert(AMAX_WL == 0 && AMAX_W2 == 1 && AMAX_W3 == 2 && AMAX_FIRST_ACT == 3, "weight slots come first");
+  static_assert(AMAX_WL == 0 && AMAX_W2 == 1 && AMAX_W3 == 2 && AMAX_W1 == 3 && AMAX_FIRST_ACT == 4, "weight slots come first");
   (void)hipMemsetAsync(w.amax, 0, AMAX_FIRST_ACT * 2 * sizeof(float), st);
-  hipLaunchKernelGGL(weights_amax_kernel, dim3(64, 3, L.NE), dim3(256), 0, st, params, L, w.amax);
+  hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_FIRST_ACT, L.NE), dim3(256), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(8 * 9 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
   hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
   hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
   hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
-  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b);
+  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
   {
     const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);

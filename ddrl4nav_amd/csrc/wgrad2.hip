@@ -906,15 +906,15 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv1 weight gradient on the bf16 matrix pipe, fp32-accurate (the counterpart of conv_fwd1_bf16x3_kernel).
+// conv1 weight gradient on the 16-bit matrix pipe, fp32-accurate (the counterpart of conv_fwd1_planes_kernel).
 //   dW1[(e,oc)][tap] = (1/255) sum_{b,oy,ox} dz1[b][(e,oc)][oy][ox] * pixel[b][ch][4 oy + ky][4 ox + kx]
-// The pixels (0..255) are exact in bf16; dz1 = leaky'(a1) * da1 is split into three bf16 planes while it is
-// staged (p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1): exact to 24 bits), the products are exact in
-// fp32 and accumulated in fp32 by v_mfma_f32_32x32x16_bf16; 1/255 is applied to the accumulators.
+// The pixels (0..255) are exact in fp16; dz1 = leaky'(a1) * da1 is split into NPL planes while it is staged (two scaled
+// fp16 planes, 22 bits; -DDDRL_PLANES_BF16: three bf16 planes), the products are exact in fp32 and accumulated in fp32 by
+// the MFMA; 1/255 and the planes' scale are applied to the accumulators.
 //   rows = (e, oc), cols = 256 taps (wave w: taps 64 w ..), k-block = (sample pair, output row oy) as in
 //   ConvWgrad1v2; its 2 x 20 output pixels form 6 fragments of 8 consecutive ox (ox 0-7, 8-15, 16-19 + 4 zeros
 //   per sample) = 3 MFMAs of K = 16 (lane half h takes fragment 2 m + h).
-// LDS: dz planes [sample][fragment][plane][row][8 bf16]; the image rows de-interleaved by x mod 4 as bf16
+// LDS: dz planes [sample][fragment][plane][row][8 x 16 bit]; the image rows de-interleaved by x mod 4 as 16-bit values
 //   [sample][ch][8 rows][q = x mod 4][24], so that the 8 pixels 4 (ox0 + j) + kx of a fragment are contiguous in
 //   plane kx mod 4 from index ox0 + kx / 4; the one-element shift of kx >= 4 is done with v_alignbit on 5 dwords.
 // ================================================================================================
@@ -923,7 +923,7 @@ using f2w = __attribute__((ext_vector_type(2))) float;
 
 template <int NE>
 struct Wgrad1B {
-  static constexpr int ROWS = 32 * NE, PLANE = ROWS * 16, A_BYTES = 2 * 3 * 3 * PLANE;
+  static constexpr int ROWS = 32 * NE, PLANE = ROWS * 16, A_BYTES = 2 * 3 * NPL * PLANE;
   // image: a ring of 16 rows (4 groups of 4) per (sample, channel), NOT part of the double-buffered stage: consecutive
   // k-blocks (output rows) share 4 of their 8 input rows, so only the 4 new ones are loaded, converted and written per block
   static constexpr int IMG_OFF = 2 * A_BYTES, IMG_BYTES = 2 * 4 * 16 * 192 + 64, STAGE = A_BYTES;
@@ -932,18 +932,10 @@ struct Wgrad1B {
   static constexpr size_t LDS_BYTES = 2 * A_BYTES + IMG_BYTES;
 };
 
-// two fp32 -> one dword of two bf16 (round to nearest even), and back
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-  const bf2w v = __builtin_convertvector((f2w){a, b}, bf2w);
-  return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ float bf_lo(unsigned pk) { return __uint_as_float(pk << 16); }
-__device__ __forceinline__ float bf_hi(unsigned pk) { return __uint_as_float(pk & 0xFFFF0000u); }
-
 template <int NE>
-__global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ dz,
-                                                                 const float* __restrict__ act, int64_t dz_es, float* __restrict__ part,
-                                                                 int n, int nsplit) {
+__global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ dz,
+                                                                 const float* __restrict__ act, int64_t dz_es, const float* __restrict__ amax,
+                                                                 float* __restrict__ part, int n, int nsplit) {
   using K = Wgrad1B<NE>;
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -964,7 +956,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
     const int idx = te + K::TPE * j, c = min(idx, K::QPE - 1);
     const int row5 = c / 5, q4 = c % 5, smp = row5 >> 5, oc = row5 & 31, f = q4 >> 1, half = q4 & 1;
     dzoff[j] = (uint32_t)((smp * 12800 + oc * 400 + q4 * 4) * 4);
-    adst[j] = ((smp * 3 + f) * 3 * K::ROWS + ew * 32 + oc) * 16 + half * 8;
+    adst[j] = ((smp * 3 + f) * NPL * K::ROWS + ew * 32 + oc) * 16 + half * 8;
     dz_s1 |= (unsigned)smp << j;
     dz_ok |= (idx < K::QPE ? 1u : 0u) << j;
     bacc[j] = 0.0f;
@@ -988,13 +980,14 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
     im_tail |= (g == 5 ? 1u : 0u) << k;
   }
   const bool lone_group_wave = __builtin_amdgcn_readfirstlane(tid) < 192;  // waves 0 .. 2
+  const float sd = plane_scale(amax[amax_idx(AMAX_DZ1, ew)]);  // this thread stages encoder ew's dz1
   // ---- operand lane bases: MFMA m of a k-block, lane half hi -> fragment fi = 2 m + hi = (sample fi / 3, frag fi % 3)
   int aa[NE][3], bb[2][3], shamt[2], kyhi[2], kylo[2];
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     const int fi = 2 * m + hi, fs = fi / 3, ff = fi % 3;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) aa[i][m] = ((fs * 3 + ff) * 3 * K::ROWS + i * 32 + l31) * 16;
+    for (int i = 0; i < NE; ++i) aa[i][m] = ((fs * 3 + ff) * NPL * K::ROWS + i * 32 + l31) * 16;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = wc * 64 + j * 32 + l31, ch = c >> 6, ky = (c >> 3) & 7, kx = c & 7;
@@ -1042,16 +1035,12 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
                     leaky_g(actr[j].w, dzr[j].w)};
         if (!full && ((dz_s1 >> j) & 1u)) g = zero4();
         bacc[j] += (g.x + g.y) + (g.z + g.w);  // the bias gradient rides along (fp32)
-        // three bf16 planes; the subtractions are exact in fp32
-        const unsigned p0a = pk_bf16(g.x, g.y), p0b = pk_bf16(g.z, g.w);
-        const float r1x = g.x - bf_lo(p0a), r1y = g.y - bf_hi(p0a), r1z = g.z - bf_lo(p0b), r1w = g.w - bf_hi(p0b);
-        const unsigned p1a = pk_bf16(r1x, r1y), p1b = pk_bf16(r1z, r1w);
-        const float r2x = r1x - bf_lo(p1a), r2y = r1y - bf_hi(p1a), r2z = r1z - bf_lo(p1b), r2w = r1w - bf_hi(p1b);
-        const unsigned p2a = pk_bf16(r2x, r2y), p2b = pk_bf16(r2z, r2w);
+        unsigned pa[NPL], pb[NPL];
+        split_planes(g.x, g.y, sd, pa);
+        split_planes(g.z, g.w, sd, pb);
         char* d = st + adst[j];
-        *(uint2*)(d) = make_uint2(p0a, p0b);
-        *(uint2*)(d + K::PLANE) = make_uint2(p1a, p1b);
-        *(uint2*)(d + 2 * K::PLANE) = make_uint2(p2a, p2b);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
       }
     }
     const unsigned im_ok = imfirst ? im_ok2 : im_ok1;
@@ -1060,21 +1049,16 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
       if ((im_ok >> k) & 1u) {
         char* d = ldsw + bdst[k] + ((imam + (int)((im_g1 >> k) & 1u)) & 3) * (4 * 192);
         if (!((im_tail >> k) & 1u)) {
-          // 16 pixels x0 .. x0+15: plane q gets pixels x0+q, +4, +8, +12 = byte q of the four dwords, as bf16
-          // (float(byte) has <= 8 significant bits: its upper half IS the bf16)
+          // 16 pixels x0 .. x0+15: plane q gets pixels x0+q, +4, +8, +12 = byte q of the four dwords, as 16-bit floats
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const unsigned f0 = __float_as_uint((float)((imr[k][0] >> (8 * q)) & 255u));
-            const unsigned f1 = __float_as_uint((float)((imr[k][1] >> (8 * q)) & 255u));
-            const unsigned f2 = __float_as_uint((float)((imr[k][2] >> (8 * q)) & 255u));
-            const unsigned f3 = __float_as_uint((float)((imr[k][3] >> (8 * q)) & 255u));
-            *(uint2*)(d + q * 48) = make_uint2((f0 >> 16) | (f1 & 0xFFFF0000u), (f2 >> 16) | (f3 & 0xFFFF0000u));
-          }
+          for (int q = 0; q < 4; ++q)
+            *(uint2*)(d + q * 48) = make_uint2(pixel_pair((imr[k][0] >> (8 * q)) & 255u, (imr[k][1] >> (8 * q)) & 255u),
+                                               pixel_pair((imr[k][2] >> (8 * q)) & 255u, (imr[k][3] >> (8 * q)) & 255u));
         } else {
           const unsigned v = imr[k][3];  // pixels 80..83 -> element 20 of each plane
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *(unsigned short*)(d + q * 48) = (unsigned short)(__float_as_uint((float)((v >> (8 * q)) & 255u)) >> 16);
+            *(unsigned short*)(d + q * 48) = pixel_one((v >> (8 * q)) & 255u);
         }
       }
     }
@@ -1102,7 +1086,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
     for (int j = 0; j < 2; ++j) rowoff[j] = ((((am + kyhi[j]) & 3) << 2) | kylo[j]) * 192;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      bf8w b[2];
+      frag8 b[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const char* q = ldsw + bb[j][m] + rowoff[j];
@@ -1110,17 +1094,17 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
         const unsigned w4 = *(const unsigned*)(q + 16);
         const u4w o = (u4w){__builtin_amdgcn_alignbit(w01.y, w01.x, shamt[j]), __builtin_amdgcn_alignbit(w23.x, w01.y, shamt[j]),
                             __builtin_amdgcn_alignbit(w23.y, w23.x, shamt[j]), __builtin_amdgcn_alignbit(w4, w23.y, shamt[j])};
-        b[j] = __builtin_bit_cast(bf8w, o);
+        b[j] = __builtin_bit_cast(frag8, o);
       }
 #pragma unroll
-      for (int p = 2; p >= 0; --p) {  // smallest plane first
-        bf8w a[NE];
+      for (int p = NPL - 1; p >= 0; --p) {  // smallest plane first
+        frag8 a[NE];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) a[i] = *(const bf8w*)(cur + aa[i][m] + p * K::PLANE);
+        for (int i = 0; i < NE; ++i) a[i] = *(const frag8*)(cur + aa[i][m] + p * K::PLANE);
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[i], b[j], acc[i][j]);
       }
     }
     if (kb + 1 < kb_end) {
@@ -1130,9 +1114,9 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
     __syncthreads();
   }
   // slabs: weights (scaled by the 1/255 of the frame normalisation), then the bias partial
-  const float r255 = 1.0f / 255.0f;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
+    const float r255 = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_DZ1, i)]));
     float* slab = part + ((int64_t)split * 2 + i) * K::SLAB;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1158,16 +1142,16 @@ __global__ __launch_bounds__(256) void conv_wgrad1_bf16x3_kernel(const uint8_t* 
 }
 
 template <int NE>
-static void launch_wgrad1_bf16x3(const EncCall& c, int S, hipStream_t st) {
+static void launch_wgrad1_planes(const EncCall& c, int S, hipStream_t st) {
   using K = Wgrad1B<NE>;
   const Workspace& w = *c.ws;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad1_bf16x3_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad1_planes_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_wgrad1_bf16x3_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.a1, c.max_batch * 12800,
-                     w.wpart, c.n, S);
+  hipLaunchKernelGGL(conv_wgrad1_planes_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.a1, c.max_batch * 12800,
+                     w.amax, w.wpart, c.n, S);
 }
 
 void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
@@ -1179,9 +1163,9 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
     ProfRange pr(c.prof, "ConvWgrad1", st);
 #ifndef DDRL_WGRAD1_F32  // default: the bf16x3 kernel; -DDDRL_WGRAD1_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (L.NE == 2) {
-      launch_wgrad1_bf16x3<2>(c, S, st);
+      launch_wgrad1_planes<2>(c, S, st);
     } else {
-      launch_wgrad1_bf16x3<1>(c, S, st);
+      launch_wgrad1_planes<1>(c, S, st);
     }
     (void)MB;
 #else
