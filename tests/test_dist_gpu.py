@@ -3,8 +3,9 @@ one GPU of the test box over gloo (DDRL_DIST_BACKEND=gloo) -- each run create_ne
 the F4 batch.  Asserted: every rank ends every iteration with bit-identical parameters and losses, and the
 sharded run obeys the SAME bounds against the reference's trajectory as the single-rank run (section 8e's
 "the F4 fixture split N ways must match the 1-GPU result within the stated tolerance"), for even, uneven
-(40/24), 4-way and 8-way splits.  The children are started as ordinary child processes (never exec'd over a
-process that has touched the GPU)."""
+(40/24), 4-way and ragged 5-way splits (the GPU boxes admit at most six processes on the card at once: five ranks + the
+test runner; more ranks than that are covered on the CPU by tests/test_surface_cpu.py).  The children are started as
+ordinary child processes (never exec'd over a process that has touched the GPU)."""
 import os
 import socket
 import subprocess
@@ -51,7 +52,7 @@ def _run_world(tmp_path, mode, bounds, tag):
 
 
 SPLITS = [("w2_even", [0, 32, 64]), ("w2_uneven", [0, 40, 64]), ("w4", [0, 16, 32, 48, 64]),
-          ("w8_ragged", [0, 8, 16, 24, 32, 40, 48, 57, 64])]
+          ("w5_ragged", [0, 13, 26, 38, 51, 64])]
 
 
 @pytest.mark.parametrize("tag,bounds", SPLITS, ids=[t for t, _ in SPLITS])
