@@ -93,6 +93,11 @@ struct Workspace {
   float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
+  // sign bits of a1 (1 = NOT positive: the leaky slope applies), written by conv1's forward for the leaky-ReLU mask of the conv1 weight gradient (which would
+  // otherwise re-read all of a1 for its signs): [e][column] 32-bit words, column = sample * 400 + output pixel, bit m1_bit(oc) of
+  // the word = output channel oc (the order in which an MFMA lane holds its 16 accumulator rows, so that the producer shifts
+  // the bits in as it walks its registers and stores its half-word).  m1_words(max_batch) words per encoder.
+  unsigned* m1;
   float *dz1, *dz2, *dz3, *dh;
   float* dlogits;  // [max_batch][A] (diagnostics / tests)
   float* dvalue;   // [max_batch]
@@ -105,11 +110,14 @@ struct Workspace {
 };
 
 // ---- running |max| of the tensors that are split into scaled fp16 planes (engine2.h "plane scheme") --------------------
-// amax[slot][encoder]: the weight slots are refreshed by pack_weights; the activation slots are zeroed at the start of every
+// amax[slot][encoder]: the weight slots (and the bound of a1, below) are refreshed by pack_weights; the activation slots are zeroed at the start of every
 // forward (ddrl_forward, ddrl_ppo_iter, ddrl_encoder_forward) and raised by the conv epilogues (atomic max); the gradient
 // slots are zeroed by launch_encoder_backward, which measures dh and lets the data-gradient epilogues raise dz3 / dz2.
 constexpr int AMAX_WL = 0, AMAX_W2 = 1, AMAX_W3 = 2, AMAX_W1 = 3, AMAX_A1 = 4, AMAX_A2 = 5, AMAX_A3 = 6, AMAX_DH = 7, AMAX_DZ3 = 8,
-              AMAX_DZ2 = 9, AMAX_DZ1 = 10, AMAX_SLOTS = 11, AMAX_FIRST_ACT = AMAX_A1;
+              AMAX_DZ2 = 9, AMAX_DZ1 = 10, AMAX_SLOTS = 11, AMAX_FIRST_ACT = AMAX_A2;
+// AMAX_A1 is not measured: pixels / 255 lie in [0, 1], so |a1[oc]| <= sum_k |w1[oc][k]| + |b1[oc]|; pack_weights stores the largest
+// such bound with the weight slots (a few times the measured maximum: two of the sixteen spare binades of the fp16 planes),
+// which spares conv1's epilogue a maximum per output and an atomic per wave
 __host__ __device__ inline int amax_idx(int slot, int e) { return slot * 2 + e; }
 // power-of-two scale that puts a tensor whose largest magnitude is m into [2^12, 2^13)
 __host__ __device__ inline float f16_scale(float m) {
@@ -122,8 +130,16 @@ constexpr int HEAD_WG = 256;   // workgroups of the heads/loss kernel (fixed -> 
 constexpr int NORM_WG = 1024;  // workgroups of the grad-norm kernel
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+// words of the a1 sign mask per encoder (one per column), and the bit of output channel oc inside a column's word: lane half
+// hi = (oc >> 2) & 1 of the 32x32 MFMA tile holds oc as accumulator register r = (oc & 3) + 4 (oc >> 3) and shifts its 16 signs in
+// first register first, i.e. register r ends at bit 15 - r of half-word hi
+__host__ __device__ inline int64_t m1_words(int64_t max_batch) { return max_batch * 400; }
+__host__ __device__ inline int m1_bit(int oc) { return ((oc >> 2) & 1) * 16 + 15 - ((oc & 3) + 4 * (oc >> 3)); }
 
 // split counts for the weight-gradient GEMMs (fixed per context -> deterministic sums)
+#ifndef DDRL_C1_SPLITS
+#define DDRL_C1_SPLITS 512  // two workgroups per CU in ONE round: 3.37 ms against 3.66 at 768 / 1024 / 1536, 4.1 at 256 / 384 / 640 (profiles/README.md)
+#endif
 struct Splits {
   int c1, c2, c3, fc;
 };
@@ -132,7 +148,7 @@ inline Splits choose_splits(int max_batch, int NE = 2) {
   const int pairs = (max_batch + 1) / 2;
   auto cap = [&](int want, int limit) { return want < limit ? (want < 1 ? 1 : want) : (limit < 1 ? 1 : limit); };
   Splits s;
-  s.c1 = cap(1024, pairs);      // 1 column tile, encoders fused
+  s.c1 = cap(DDRL_C1_SPLITS, pairs);      // 1 column tile, encoders fused
   const int k = 2 / NE;         // one encoder: twice the splits keep the same number of workgroups
   s.c2 = cap(256 * k, pairs);   // 2 column tiles x 2 encoders
   s.c3 = cap(256 * k, pairs);   // conv_wgrad3_bf16x6: one workgroup per (split, encoder), up to two per CU
@@ -167,6 +183,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wd3p = take(2 * 16 * 18 * 2 * 64);
   w.wd2p = take(2 * 8 * 16 * 2 * 128);
   w.a1 = take(2 * MB * 32 * 400);
+  w.m1 = (unsigned*)take(2 * m1_words(MB));
   w.a2 = take(2 * MB * 64 * 81);
   w.a3 = take(2 * MB * FLAT);
   w.h = take(2 * MB * FEAT);

@@ -607,7 +607,8 @@ struct Fwd1B {
 template <int NE>
 __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
                                                                float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
-                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
+                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n,
+                                                               unsigned* __restrict__ m1, int64_t m1_es) {
   using K = Fwd1B<NE>;
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -713,9 +714,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   float r255[NE];  // 1/255 of the frame normalisation and the scale of the encoder's weight planes
 #pragma unroll
   for (int i = 0; i < NE; ++i) r255[i] = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_W1, i)]));
-  float big[NE];
-#pragma unroll
-  for (int i = 0; i < NE; ++i) big[i] = 0.0f;
+  // (the scale of a1's planes comes from a bound that pack_weights derives from the weights, common.h AMAX_A1: no maximum here)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = c0 + wc * 64 + j * 32 + l31;
@@ -725,21 +724,25 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
 #pragma unroll
     for (int i = 0; i < NE; ++i) {  // i = encoder
       float* base = out + i * out_es;
+      // sign mask of a1 (common.h Workspace::m1; bit SET = not positive): the lane shifts the signs of its 16 output channels into
+      // a half-word
+      unsigned bits = 0u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = acc_row(r, hi);
-        const float y = leaky_f(acc[i][j][r] * r255[i] + bias[i * 32 + oc]);
+        const float y = leaky_f(__builtin_fmaf(acc[i][j][r], r255[i], bias[i * 32 + oc]));  // one rounding less than mul + add
         st1_so(base + acc_row(r, 0) * 400, lanep, y);
-        big[i] = fmaxf(big[i], fabsf(y));
+        // y > 0 <=> its bit pattern, as a signed integer, is >= 1 <=> (pattern -sat 1) has a clear sign; alignbit shifts that sign
+        // in: two VALU instructions per output (compare + select + or: three and two s_nop)
+        bits = __builtin_amdgcn_alignbit(bits, (unsigned)__builtin_elementwise_sub_sat((int)__float_as_uint(y), 1), 31);
       }
+      if (m1 != nullptr) ((unsigned short*)(m1 + i * m1_es))[2 * (int64_t)c + hi] = (unsigned short)bits;
     }
   }
-#pragma unroll
-  for (int i = 0; i < NE; ++i) amax_update(big[i], amax + amax_idx(AMAX_A1, i));
 }
 
 template <int NE>
-static void launch_fwd1_planes(const EncCall& c, hipStream_t st) {
+static void launch_fwd1_planes(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
   using K = Fwd1B<NE>;
@@ -749,7 +752,8 @@ static void launch_fwd1_planes(const EncCall& c, hipStream_t st) {
     configured = true;
   }
   hipLaunchKernelGGL(conv_fwd1_planes_kernel<NE>, dim3((unsigned)(((int64_t)c.n * 400 + 255) / 256)), dim3(256), K::LDS_BYTES, st, c.frames,
-                     w.wp1b, w.amax, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n);
+                     w.wp1b, w.amax, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n,
+                     acting ? (unsigned*)nullptr : w.m1, m1_words(c.max_batch));
 }
 
 // ================================================================================================
@@ -1092,6 +1096,9 @@ static void launch_fwd3_planes(const EncCall& c, hipStream_t st) {
 // narrow-tile kernels vs bf16x6: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7, 2048: 606.2 / 480.9)
 #define DDRL_ACT_BF16X6_MIN 192
 #endif
+#if defined(DDRL_FWD1_F32) && !defined(DDRL_WGRAD1_F32)
+#error "-DDDRL_FWD1_F32 needs -DDDRL_WGRAD1_F32: only conv_fwd1_planes_kernel writes the a1 sign mask that conv_wgrad1_planes_kernel reads"
+#endif
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -1102,9 +1109,9 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     const dim3 grid((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1);
 #ifndef DDRL_FWD1_F32  // default: the bf16x3 kernel; -DDDRL_FWD1_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (L.NE == 2) {
-      launch_fwd1_planes<2>(c, st);
+      launch_fwd1_planes<2>(c, acting, st);
     } else {
-      launch_fwd1_planes<1>(c, st);
+      launch_fwd1_planes<1>(c, acting, st);
     }
     (void)grid;
 #else

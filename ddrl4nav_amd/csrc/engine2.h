@@ -97,6 +97,12 @@ __device__ __forceinline__ unsigned ld1u_so(const void* uniform_base, uint32_t l
 // compare/select form, signed zeros included)
 __device__ __forceinline__ float leaky_f(float v) { return __builtin_fmaxf(v, v * LEAKY); }
 __device__ __forceinline__ float leaky_g(float act, float g) { return act > 0.0f ? g : g * LEAKY; }
+// the same with the decision taken from bit `bit` of a sign mask (bit SET = act is not positive): g * LEAKY or g * 1 without a
+// compare (bfe, bfi, mul)
+__device__ __forceinline__ float leaky_bit(unsigned mask, int bit, float g) {
+  const unsigned sel = (unsigned)__builtin_amdgcn_sbfe((int)mask, bit, 1);  // 0 or ~0
+  return g * __uint_as_float((__float_as_uint(LEAKY) & sel) | (0x3F800000u & ~sel));
+}
 
 // float32(u8/255.0), correctly rounded, in three vector instructions (convert, multiply, fma): 1/255 is
 // split into float32 hi + lo parts and x*hi + fl(x*lo) is rounded once.  Exhaustively equal to the

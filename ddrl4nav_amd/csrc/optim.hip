@@ -216,10 +216,23 @@ __global__ __launch_bounds__(256) void weights_amax_kernel(const float* __restri
   amax_update(m, amax + amax_idx(t, e));
 }
 
+// upper bound of |a1| per encoder -> slot AMAX_A1 (common.h): max over oc of sum_k |w1[oc][k]| + |b1[oc]|; grid (32 oc, NE), one wave
+__global__ __launch_bounds__(64) void a1_bound_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ amax) {
+  const int oc = blockIdx.x, e = blockIdx.y, K = L.C * 64;
+  const float* wsrc = params + L.enc_base[e] + L.enc.c1w + (int64_t)oc * K;
+  float s = 0.0f;
+  for (int k = threadIdx.x; k < K; k += 64) s += fabsf(wsrc[k]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  amax_update(s + fabsf(params[L.enc_base[e] + L.enc.c1b + oc]), amax + amax_idx(AMAX_A1, e));
+}
+
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
-  static_assert(AMAX_WL == 0 && AMAX_W2 == 1 && AMAX_W3 == 2 && AMAX_W1 == 3 && AMAX_FIRST_ACT == 4, "weight slots come first");
+  static_assert(AMAX_WL == 0 && AMAX_W2 == 1 && AMAX_W3 == 2 && AMAX_W1 == 3 && AMAX_A1 == 4 && AMAX_FIRST_ACT == 5,
+                "weight slots and the bound of a1 come first");
   (void)hipMemsetAsync(w.amax, 0, AMAX_FIRST_ACT * 2 * sizeof(float), st);
-  hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_FIRST_ACT, L.NE), dim3(256), 0, st, params, L, w.amax);
+  hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_A1, L.NE), dim3(256), 0, st, params, L, w.amax);
+  hipLaunchKernelGGL(a1_bound_kernel, dim3(32, L.NE), dim3(64), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(8 * 9 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
   hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);

@@ -921,6 +921,12 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
 using bf2w = __attribute__((ext_vector_type(2))) __bf16;
 using f2w = __attribute__((ext_vector_type(2))) float;
 
+// Timing-only knock-outs (-DDDRL_W1_KO=bits; results are WRONG, only the kernel time means something):
+// 1 no a1 load / leaky mask, 2 no plane split of dz1, 4 no image loads / conversion, 8 no MFMAs, 16 no alignbit shift of the pixel fragments,
+// 32 no dz1 / a1 loads at all (values made up in registers)
+#ifndef DDRL_W1_KO
+#define DDRL_W1_KO 0
+#endif
 template <int NE>
 struct Wgrad1B {
   static constexpr int ROWS = 32 * NE, PLANE = ROWS * 16, A_BYTES = 2 * 3 * NPL * PLANE;
@@ -934,8 +940,8 @@ struct Wgrad1B {
 
 template <int NE>
 __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ dz,
-                                                                 const float* __restrict__ act, int64_t dz_es, const float* __restrict__ amax,
-                                                                 float* __restrict__ part, int n, int nsplit) {
+                                                                 const unsigned* __restrict__ m1, int64_t m1_es, int64_t dz_es,
+                                                                 const float* __restrict__ amax, float* __restrict__ part, int n, int nsplit) {
   using K = Wgrad1B<NE>;
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -947,7 +953,8 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
   for (int i = tid; i < (int)(K::LDS_BYTES / 16); i += 256) *(f4*)(ldsw + i * 16) = zero4();
   // ---- dz staging map (as ConvWgrad1v2: threads split by encoder so that the encoder's base is wave-uniform)
   const int ew = __builtin_amdgcn_readfirstlane(tid / K::TPE), te = tid % K::TPE;
-  uint32_t dzoff[K::NDZ_J];
+  uint32_t dzoff[K::NDZ_J], mcol[K::NDZ_J];
+  int mbit[K::NDZ_J];
   int adst[K::NDZ_J];
   unsigned dz_s1 = 0, dz_ok = 0;
   float bacc[K::NDZ_J];
@@ -956,6 +963,8 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
     const int idx = te + K::TPE * j, c = min(idx, K::QPE - 1);
     const int row5 = c / 5, q4 = c % 5, smp = row5 >> 5, oc = row5 & 31, f = q4 >> 1, half = q4 & 1;
     dzoff[j] = (uint32_t)((smp * 12800 + oc * 400 + q4 * 4) * 4);
+    mcol[j] = (uint32_t)((smp * 400 + q4 * 4) * 4);  // byte offset of the quad's four mask words inside the pair's output row
+    mbit[j] = m1_bit(oc);
     adst[j] = ((smp * 3 + f) * NPL * K::ROWS + ew * 32 + oc) * 16 + half * 8;
     dz_s1 |= (unsigned)smp << j;
     dz_ok |= (idx < K::QPE ? 1u : 0u) << j;
@@ -997,7 +1006,8 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
       kylo[j] = ky & 3;
     }
   }
-  f4 dzr[K::NDZ_J], actr[K::NDZ_J];
+  f4 dzr[K::NDZ_J];
+  u4w mkr[K::NDZ_J];  // the sign-mask words of the four pixels of dzr (written by conv1's forward, common.h Workspace::m1): bit mbit set = a1 is not positive
   u4w imr[2] = {(u4w){0u, 0u, 0u, 0u}, (u4w){0u, 0u, 0u, 0u}};
   bool full = true, imfirst = true;
   int imam = 0;  // ring group (mod 4) of the first group this fetch stages
@@ -1009,17 +1019,20 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
     imam = (21 * pair + oy + gfirst) & 3;
     const int64_t sb = ew * dz_es + (int64_t)pair * (2 * 12800) + oy * 20;
     const char* dzb = (const char*)(dz + sb);
-    const char* acb = (const char*)(act + sb);
+    const char* mb = (const char*)(m1 + ew * m1_es + (int64_t)pair * 800 + oy * 20);
     const char* fp = (const char*)frames + (int64_t)pair * (2 * 28224) + (oy + gfirst) * 336;
     // odd batch tail: the second sample does not exist -> its slots read the first sample, commit() zeroes its dz
 #pragma unroll
     for (int j = 0; j < K::NDZ_J; ++j) {
       const uint32_t o = full ? dzoff[j] : dzoff[j] - ((dz_s1 >> j) & 1u) * (12800u * 4u);
+      if (DDRL_W1_KO & 32) { dzr[j] = (f4){(float)o, 1.0f, 2.0f, (float)kb}; mkr[j] = (u4w){o, o, o, o}; continue; }
       dzr[j] = *(const f4*)(dzb + o);
-      actr[j] = *(const f4*)(acb + o);
+      // the lanes of one (sample, quad) -- all 32 output channels -- read the same 16 bytes: one cache line per wave instruction
+      if (!(DDRL_W1_KO & 1)) mkr[j] = *(const u4w*)(mb + (full ? mcol[j] : mcol[j] - ((dz_s1 >> j) & 1u) * 1600u));
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
+      if (DDRL_W1_KO & 4) continue;
       // wave-uniform skips: a lone group has no k = 1 units and none in wave 3 (their loads were the cost, not the conversion)
       if (!imfirst && (k == 1 || !lone_group_wave)) continue;
       const uint32_t o = full ? imoff[k] : imoff[k] - ((im_s1 >> k) & 1u) * 28224u;
@@ -1031,19 +1044,24 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
 #pragma unroll
     for (int j = 0; j < K::NDZ_J; ++j) {
       if (j + 1 < K::NDZ_J || ((dz_ok >> j) & 1u)) {
-        f4 g = (f4){leaky_g(actr[j].x, dzr[j].x), leaky_g(actr[j].y, dzr[j].y), leaky_g(actr[j].z, dzr[j].z),
-                    leaky_g(actr[j].w, dzr[j].w)};
+        f4 g = (DDRL_W1_KO & 1) ? dzr[j]
+                                : (f4){leaky_bit(mkr[j][0], mbit[j], dzr[j].x), leaky_bit(mkr[j][1], mbit[j], dzr[j].y),
+                                       leaky_bit(mkr[j][2], mbit[j], dzr[j].z), leaky_bit(mkr[j][3], mbit[j], dzr[j].w)};
         if (!full && ((dz_s1 >> j) & 1u)) g = zero4();
         bacc[j] += (g.x + g.y) + (g.z + g.w);  // the bias gradient rides along (fp32)
         unsigned pa[NPL], pb[NPL];
+        if (DDRL_W1_KO & 2) {
+          for (int p = 0; p < NPL; ++p) { pa[p] = __float_as_uint(g.x) ^ __float_as_uint(g.y); pb[p] = __float_as_uint(g.z) ^ __float_as_uint(g.w); }
+        } else {
         split_planes(g.x, g.y, sd, pa);
         split_planes(g.z, g.w, sd, pb);
+        }
         char* d = st + adst[j];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
       }
     }
-    const unsigned im_ok = imfirst ? im_ok2 : im_ok1;
+    const unsigned im_ok = (DDRL_W1_KO & 4) ? 0u : imfirst ? im_ok2 : im_ok1;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if ((im_ok >> k) & 1u) {
@@ -1092,8 +1110,9 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
         const char* q = ldsw + bb[j][m] + rowoff[j];
         const uint2 w01 = *(const uint2*)q, w23 = *(const uint2*)(q + 8);
         const unsigned w4 = *(const unsigned*)(q + 16);
-        const u4w o = (u4w){__builtin_amdgcn_alignbit(w01.y, w01.x, shamt[j]), __builtin_amdgcn_alignbit(w23.x, w01.y, shamt[j]),
-                            __builtin_amdgcn_alignbit(w23.y, w23.x, shamt[j]), __builtin_amdgcn_alignbit(w4, w23.y, shamt[j])};
+        const u4w o = (DDRL_W1_KO & 16) ? (u4w){w01.x, w01.y, w23.x, w23.y ^ w4}
+                                        : (u4w){__builtin_amdgcn_alignbit(w01.y, w01.x, shamt[j]), __builtin_amdgcn_alignbit(w23.x, w01.y, shamt[j]),
+                                                __builtin_amdgcn_alignbit(w23.y, w23.x, shamt[j]), __builtin_amdgcn_alignbit(w4, w23.y, shamt[j])};
         b[j] = __builtin_bit_cast(frag8, o);
       }
 #pragma unroll
@@ -1104,7 +1123,10 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
 #pragma unroll
         for (int i = 0; i < NE; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < 2; ++j) {
+            if (DDRL_W1_KO & 8) { acc[i][j][0] += (float)a[i][0] + (float)b[j][0]; } else
+            acc[i][j] = mfma_planes(a[i], b[j], acc[i][j]);
+          }
       }
     }
     if (kb + 1 < kb_end) {
@@ -1150,8 +1172,8 @@ static void launch_wgrad1_planes(const EncCall& c, int S, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad1_planes_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(conv_wgrad1_planes_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.a1, c.max_batch * 12800,
-                     w.amax, w.wpart, c.n, S);
+  hipLaunchKernelGGL(conv_wgrad1_planes_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.m1, m1_words(c.max_batch),
+                     c.max_batch * 12800, w.amax, w.wpart, c.n, S);
 }
 
 void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {

@@ -67,7 +67,7 @@ def test_sharded_learn_matches_reference_trajectory(tmp_path, golden, tag, bound
     assert sum(int(r["local_batch"]) for r in ranks) == 64
     g4 = golden("f4_learn")
     ref = g4["losses"]
-    env = P.loss_envelope(ref, g4["losses_f64"], g4["losses_f32t8"])
+    env = P.mode_loss_envelope("default", ref, g4["losses_f64"], g4["losses_f32t8"])
     rows = iter(r0["losses"])
     state = {"it": 0}
 

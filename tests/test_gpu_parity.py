@@ -278,7 +278,7 @@ def test_learn_sequence_golden_f4(hp, golden):
     hp.set_params(flatten(make_weights(0)))
     hp.reset_optimizer()
     ref = g4["losses"]
-    env = P.loss_envelope(ref, g4["losses_f64"], g4["losses_f32t8"])
+    env = P.mode_loss_envelope("default", ref, g4["losses_f64"], g4["losses_f32t8"])
 
     def step():
         hp.ppo_iter(frames, actions, old_logps, advs, rets)

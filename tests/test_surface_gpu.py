@@ -82,7 +82,7 @@ def test_learn_generator_protocol_golden_f4(net, golden):
     exp.to_tensor(dtype=torch.float32, device="cuda")
     import parity_util as P
     ref = g4["losses"]
-    env = P.loss_envelope(ref, g4["losses_f64"], g4["losses_f32t8"])
+    env = P.mode_loss_envelope("default", ref, g4["losses_f64"], g4["losses_f32t8"])
     gen = net.learn(exp)
     seen = [0]
 

@@ -34,7 +34,7 @@ hp.reset_optimizer()
 ref = g4["losses"]
 f64 = g4["losses_f64"]
 others = [g4[k] for k in ("losses_f64", "losses_f32t8") if k in g4.files]
-env = P.loss_envelope(ref, *others)
+env = P.mode_loss_envelope(mode, ref, *others)
 traj = P.f64_trajectory(mode)
 print("%s  mode %s  lib %s" % (tag, mode, _lib.LIB_PATH))
 print("it | |got-ref| total actor v ent | envelope | ratio | |got-f64| | |ref-f64| | param ratios l2 max 1mcos")

@@ -3,7 +3,7 @@
 
 `DDRL_RECORD_MARGINS=1 python -m pytest tests -m gpu` (on the MI355X box) writes every envelope-type ratio it
 measured to gpurun_out/margins_measured.json; this script turns them into the committed limits:
-limit = measured x 1.5, rounded up to two significant digits.  Entries keep the measured value and the box run
+limit = max(measured x 1.5, 1.0), rounded up to two significant digits.  Entries keep the measured value and the box run
 they came from, so the headroom of every bound is on record ("make the parity bounds falsifiable").
 
 usage: python tools/update_margins.py [--source gpurun_out/margins_measured.json] [--note "r02 v23, MI355X"] [--reset]
@@ -39,9 +39,11 @@ def main():
             prev = 0.0 if args.reset else slot.get(key, {}).get("measured", 0.0)
             m = max(prev, v)  # several boxes / runs: keep the largest ratio seen
             # a ratio that is ~0 on one box (e.g. losses inside the single-step tolerance) still gets a usable limit
-            slot[key] = {"measured": round(m, 4), "limit": max(round_up(m * args.headroom), 0.5), "note": args.note or slot.get(key, {}).get("note", "")}
+            # 1.0 = "as far from float64 as the reference's own fp32 evaluations" (or one rounding unit / torch's own error for
+            # the accuracy entries): no limit is set below that -- a ratio of 0.3 on one box and 0.6 after an fma is the same verdict
+            slot[key] = {"measured": round(m, 4), "limit": max(round_up(m * args.headroom), 1.0), "note": args.note or slot.get(key, {}).get("note", "")}
     out["_doc"] = ("ratio = deviation of the HIP path / the reference's own deviation (tests/parity_util.py); "
-                   "limit = largest measured ratio x %.1f, rounded up; regenerate with tools/update_margins.py" % args.headroom)
+                   "limit = max(largest measured ratio x %.1f, 1.0), rounded up; regenerate with tools/update_margins.py" % args.headroom)
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)
 
