@@ -98,6 +98,13 @@ struct Workspace {
   // the word = output channel oc (the order in which an MFMA lane holds its 16 accumulator rows, so that the producer shifts
   // the bits in as it walks its registers and stores its half-word).  m1_words(max_batch) words per encoder.
   unsigned* m1;
+  // sign bits of a2 for conv3's data gradient, whose epilogue has conv2's forward tile layout (column = (sample, pixel), lane half
+  // hi, accumulator register r <-> channel i * 32 + acc_row(r, hi)): [e][sample][pixel 81][hi 2] words, bit 16 i + 15 - r set =
+  // that channel's a2 is not positive.  2.7 GB of a2 reads become 85 MB.
+  unsigned* m2;
+  // sign bits of a3 for the dense layer's data gradient, in conv3's forward tile layout: [e][sample][pixel 49][hi 2] words, bit
+  // 16 i + 15 - r as above (channel = i * 32 + acc_row(r, hi))
+  unsigned* m3;
   float *dz1, *dz2, *dz3, *dh;
   float* dlogits;  // [max_batch][A] (diagnostics / tests)
   float* dvalue;   // [max_batch]
@@ -184,6 +191,8 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wd2p = take(2 * 8 * 16 * 2 * 128);
   w.a1 = take(2 * MB * 32 * 400);
   w.m1 = (unsigned*)take(2 * m1_words(MB));
+  w.m2 = (unsigned*)take(2 * MB * 81 * 2);
+  w.m3 = (unsigned*)take(2 * MB * 49 * 2);
   w.a2 = take(2 * MB * 64 * 81);
   w.a3 = take(2 * MB * FLAT);
   w.h = take(2 * MB * FEAT);

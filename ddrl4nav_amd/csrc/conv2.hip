@@ -799,7 +799,8 @@ struct __attribute__((packed, aligned(4))) lds_u2 {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WPE, DDRL_F2B_WPE))) void conv_fwd2_planes_kernel(const float* __restrict__ a1, int64_t a1_es, const unsigned short* __restrict__ wp2b,
                                                                float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
-                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
+                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n,
+                                                               unsigned* __restrict__ m2) {
   using K = Fwd2B;
   extern __shared__ __attribute__((aligned(16))) char ldsc2[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -904,19 +905,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
     if (c >= K::SPT * 81 || b0 + s >= n) continue;
     float* base = out + e * out_es + (int64_t)b0 * 5184;
     const uint32_t lb = (uint32_t)((s * 5184 + pix + hi * (4 * 81)) * 4);
+    unsigned bits = 0u;  // sign mask of a2 (common.h Workspace::m2): the signs of the lane's 32 channels, shifted in register by register
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = i * 32 + acc_row(r, hi);
-        const float y = leaky_f(acc[i][j][r] * inv + bias[oc]);
+        const float y = leaky_f(__builtin_fmaf(acc[i][j][r], inv, bias[oc]));
         st1_so(base + (i * 32 + acc_row(r, 0)) * 81, lb, y);
         big = fmaxf(big, fabsf(y));
+        bits = __builtin_amdgcn_alignbit(bits, (unsigned)__builtin_elementwise_sub_sat((int)__float_as_uint(y), 1), 31);  // conv1's epilogue
       }
+    // i = 0 went in first and now sits in the upper half: swap so that bit 16 i + 15 - r belongs to register r of half i
+    if (m2 != nullptr) m2[(e * (out_es / 5184) + b0 + s) * 162 + pix * 2 + hi] = (bits >> 16) | (bits << 16);
   }
   amax_update(big, amax + amax_idx(AMAX_A2, e));
 }
-static void launch_fwd2_planes(const EncCall& c, hipStream_t st) {
+static void launch_fwd2_planes(const EncCall& c, bool acting, hipStream_t st) {
   using K = Fwd2B;
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
@@ -927,7 +932,7 @@ static void launch_fwd2_planes(const EncCall& c, hipStream_t st) {
   }
   hipLaunchKernelGGL(conv_fwd2_planes_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a1,
                      c.max_batch * 12800, w.wp2b, w.amax, c.params, L.enc_base[0] + L.enc.c2b, L.enc_base[L.NE - 1] + L.enc.c2b, w.a2, c.max_batch * 5184,
-                     c.n);
+                     c.n, acting ? (unsigned*)nullptr : w.m2);
 }
 
 // ================================================================================================
@@ -957,7 +962,8 @@ struct Fwd3B {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WPE, DDRL_F3B_WPE))) void conv_fwd3_planes_kernel(const float* __restrict__ a2, int64_t a2_es, const unsigned short* __restrict__ wp3b,
                                                                float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
-                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n) {
+                                                               int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n,
+                                                               unsigned* __restrict__ m3) {
   using K = Fwd3B;
   extern __shared__ __attribute__((aligned(16))) char ldsc3[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -1064,19 +1070,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F3B_WP
     if (c >= K::SPT * 49 || b0 + s >= n) continue;
     float* base = out + e * out_es + (int64_t)b0 * FLAT;
     const uint32_t lb = (uint32_t)((s * FLAT + pix + hi * (4 * 49)) * 4);
+    unsigned bits = 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = i * 32 + acc_row(r, hi);
-        const float y = leaky_f(acc[i][j][r] * inv + bias[oc]);
+        const float y = leaky_f(__builtin_fmaf(acc[i][j][r], inv, bias[oc]));
         st1_so(base + (i * 32 + acc_row(r, 0)) * 49, lb, y);
         big = fmaxf(big, fabsf(y));
+        bits = __builtin_amdgcn_alignbit(bits, (unsigned)__builtin_elementwise_sub_sat((int)__float_as_uint(y), 1), 31);  // conv1's epilogue
       }
+    // sign mask of a3 (common.h Workspace::m3): bit 16 i + 15 - r = register r of half i is not positive
+    if (m3 != nullptr) m3[(e * (out_es / FLAT) + b0 + s) * 98 + pix * 2 + hi] = (bits >> 16) | (bits << 16);
   }
   amax_update(big, amax + amax_idx(AMAX_A3, e));
 }
-static void launch_fwd3_planes(const EncCall& c, hipStream_t st) {
+static void launch_fwd3_planes(const EncCall& c, bool acting, hipStream_t st) {
   using K = Fwd3B;
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
@@ -1087,7 +1097,7 @@ static void launch_fwd3_planes(const EncCall& c, hipStream_t st) {
   }
   hipLaunchKernelGGL(conv_fwd3_planes_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)L.NE), dim3(256), K::LDS_BYTES, st, w.a2,
                      c.max_batch * 5184, w.wp3b, w.amax, c.params, L.enc_base[0] + L.enc.c3b, L.enc_base[L.NE - 1] + L.enc.c3b, w.a3, c.max_batch * FLAT,
-                     c.n);
+                     c.n, acting ? (unsigned*)nullptr : w.m3);
 }
 
 // ================================================================================================
@@ -1098,6 +1108,9 @@ static void launch_fwd3_planes(const EncCall& c, hipStream_t st) {
 #endif
 #if defined(DDRL_FWD1_F32) && !defined(DDRL_WGRAD1_F32)
 #error "-DDDRL_FWD1_F32 needs -DDDRL_WGRAD1_F32: only conv_fwd1_planes_kernel writes the a1 sign mask that conv_wgrad1_planes_kernel reads"
+#endif
+#if (defined(DDRL_FWD2_F32) || defined(DDRL_FWD3_F32)) && !defined(DDRL_MASK_FROM_ACT)
+#error "the fp32-MFMA conv2 / conv3 forwards do not write the sign masks that conv_dgrad3_planes_kernel / fc_dgrad_planes_kernel read"
 #endif
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
@@ -1131,7 +1144,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
 #ifndef DDRL_FWD2_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
-      launch_fwd2_planes(c, st);
+      launch_fwd2_planes(c, acting, st);
     } else
 #endif
     if (narrow(81)) {
@@ -1146,7 +1159,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
 #ifndef DDRL_FWD3_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD3_F32 keeps the fp32-MFMA kernel
     if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
-      launch_fwd3_planes(c, st);
+      launch_fwd3_planes(c, acting, st);
     } else
 #endif
     if (narrow(49)) {
@@ -1317,7 +1330,7 @@ struct Dgrad3B {
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad3_planes_kernel(
-    const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3b, float* __restrict__ amax, const float* __restrict__ a2,
+    const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3b, float* __restrict__ amax, const unsigned* __restrict__ m2,
     float* __restrict__ out, int64_t out_es, int n) {
   using K = Dgrad3B;
   extern __shared__ __attribute__((aligned(16))) char ldsd3[];
@@ -1426,18 +1439,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int s = c / 81, pix = c % 81;
     if (c >= K::SPT * 81 || b0 + s >= n) continue;
     const int64_t off = (int64_t)(b0 + s) * 5184 + pix + hi * (4 * 81);
-    const float* ap = a2 + e * out_es + off;
     float* op = out + e * out_es + off;
-    float av[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) av[i][r] = ap[(i * 32 + acc_row(r, 0)) * 81];
+    // the signs of a2 at this lane's 32 (channel, pixel) positions: one word written by conv2's forward, whose tile layout
+    // this epilogue shares (common.h Workspace::m2) -- not 32 reads of a2
+    const unsigned mw = m2[(e * (out_es / 5184) + b0 + s) * 162 + pix * 2 + hi];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float g = leaky_g(av[i][r], acc[i][j][r] * inv);
+        const float g = leaky_bit(mw, 16 * i + 15 - r, acc[i][j][r] * inv);
         op[(i * 32 + acc_row(r, 0)) * 81] = g;
         big = fmaxf(big, fabsf(g));
       }
@@ -1453,7 +1463,7 @@ static void launch_dgrad3_planes(const EncCall& c, hipStream_t st) {
     configured = true;
   }
   hipLaunchKernelGGL(conv_dgrad3_planes_kernel, dim3((unsigned)((c.n + K::SPT - 1) / K::SPT), 1, (unsigned)c.L->NE), dim3(K::THREADS), K::LDS_BYTES, st,
-                     w.dz3, c.max_batch * FLAT, w.wd3b, w.amax, w.a2, w.dz2, c.max_batch * 5184, c.n);
+                     w.dz3, c.max_batch * FLAT, w.wd3b, w.amax, w.m2, w.dz2, c.max_batch * 5184, c.n);
 }
 
 // ================================================================================================

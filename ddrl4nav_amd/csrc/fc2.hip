@@ -533,7 +533,7 @@ struct FcDgradB {  // k-block KBK = 32 or 16 features; row pitch = data + 16 B s
   static constexpr int NWF = KBK / 8, WJ = 128 * NWF / 256, WCOLS = 256 / NWF;   // weights: fragments of 8 features per column
 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::WPE, FcDgradB::WPE))) void fc_dgrad_planes_kernel(const float* __restrict__ dh, int64_t dh_es, const unsigned short* __restrict__ wdlb,
-                                                              float* __restrict__ amax, const float* __restrict__ a3, float* __restrict__ dz3, int64_t a3_es, int n) {
+                                                              float* __restrict__ amax, const unsigned* __restrict__ m3, float* __restrict__ dz3, int64_t a3_es, int n) {
   using K = FcDgradB;
   extern __shared__ __attribute__((aligned(16))) char ldsg[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -622,18 +622,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
   for (int j = 0; j < 2; ++j) {
     const int k = k0 + wc * 64 + j * 32 + l31;
     if (k >= FLAT) continue;
+    // the sign of a3[b][k] comes from the mask conv3's forward wrote in ITS tile layout (common.h Workspace::m3): k = (channel, pixel),
+    // channel = 32 i' + acc_row(r', hi') there -> word (b, pixel, hi'), bit 16 i' + 15 - r'; 51 MB instead of the 1.6 GB of a3
+    const int ch = k / 49, pix = k % 49;
+    const int mbit = 16 * (ch >> 5) + 15 - ((ch & 3) + 4 * ((ch & 31) >> 3));
+    const unsigned* mp = m3 + (int64_t)e * (a3_es / FLAT) * 98 + pix * 2 + ((ch >> 2) & 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float av[16];
+      unsigned mw[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int b = min(b0 + wr * 64 + i * 32 + acc_row(r, hi), n - 1);
-        av[r] = a3[e * a3_es + (int64_t)b * FLAT + k];
+        mw[r] = mp[(int64_t)b * 98];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-        const float g = leaky_g(av[r], acc[i][j][r] * inv);
+        const float g = leaky_bit(mw[r], mbit, acc[i][j][r] * inv);
         if (b < n) {
           dz3[e * a3_es + (int64_t)b * FLAT + k] = g;
           big = fmaxf(big, fabsf(g));
@@ -826,7 +831,7 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
       configured = true;
     }
     hipLaunchKernelGGL(fc_dgrad_planes_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcDgradB::LDS_BYTES, st, w.dh, MB * FEAT,
-                       w.wdlb, w.amax, w.a3, w.dz3, MB * FLAT, c.n);
+                       w.wdlb, w.amax, w.m3, w.dz3, MB * FLAT, c.n);
     (void)p;
     return;
 #endif
