@@ -389,6 +389,17 @@ struct FcWgrad2 : FcCommon {
 // ------------------------------------------------------------------------------------------------
 using bf8f = __attribute__((ext_vector_type(8))) __bf16;
 
+// xcd_note: XCD-aware tile order of the three dense-layer kernels (-DDDRL_FC_SWZ=0 switches it off).  The hardware deals
+// workgroups to the chip's 8 XCDs round-robin by linear id and an XCD runs about 64 of them at a time; each XCD has its own
+// 4 MB L2.  In launch order the workgroups that share an operand tile land on different XCDs and every L2 fetches its own copy
+// (FETCH_SIZE 2-3 x the algorithmic bytes, profiles/r02_v27_pmc_traffic.json).  The kernels therefore derive their tile from
+// (xcd = id mod 8, position = id / 8) so that sharers sit next to each other on one XCD.  FETCH_SIZE per launch at B = 65,536,
+// off -> on: forward 3.39 -> 1.23 GB, data gradient 4.63 -> 1.27 GB (blocks of 8 x 5 tiles; 3.38 one batch tile at a time), weight
+// gradient 5.04 -> 3.60 GB; the kernels' times move by 0-4 % (they are not bandwidth-bound), the neighbours' clocks gain.
+#ifndef DDRL_FC_SWZ
+#define DDRL_FC_SWZ 1
+#endif
+
 struct FcFwdB {
   static constexpr int PITCH = 80, PLANE = 128 * PITCH, B_OFF = NPL * PLANE, LDS_BYTES = 2 * NPL * PLANE;
 };
@@ -400,7 +411,12 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
   extern __shared__ __attribute__((aligned(16))) char ldsf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int e = blockIdx.z, n0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (DDRL_FC_SWZ != 0 && (gridDim.y & 7) == 0) {  // XCD-aware tile order, see xcd_note above
+    const int lin = bx + 4 * by, xcd = lin & 7, q = lin >> 3;
+    bx = q & 3, by = (q >> 2) * 8 + xcd;  // an XCD owns the batch tiles = xcd mod 8; the 4 feature tiles of one run together and share its a3 rows
+  }
+  const int e = blockIdx.z, n0 = bx * 128, b0 = by * 128;
   const float sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: activations = 4 quads of 4 k per thread (row rr + 32 j, k4), weights = 2 x 3 fragments of 8 k
   const int k4 = tid & 7, rr = tid >> 3;
@@ -538,7 +554,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
   extern __shared__ __attribute__((aligned(16))) char ldsg[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int e = blockIdx.z, k0 = blockIdx.x * 128, b0 = blockIdx.y * 128;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (DDRL_FC_SWZ != 0 && (gridDim.y & 7) == 0) {  // XCD-aware tile order, see xcd_note above; gridDim.x = 25
+    const int lin = bx + 25 * by, xcd = lin & 7, q = lin >> 3;
+    if ((gridDim.y & 63) != 0) {
+      bx = q % 25, by = (q / 25) * 8 + xcd;  // an XCD owns batch tiles = xcd mod 8 and walks their 25 column tiles one batch tile at a time
+    } else {                                 // ... in blocks of 8 batch tiles x 5 column tiles (2.1 + 1.3 MB of operands shared by 40 workgroups)
+      const int blk = q / 40, r = q % 40;
+      bx = (blk % 5) * 5 + r % 5, by = ((blk / 5) * 8 + r / 5) * 8 + xcd;
+    }
+  }
+  const int e = blockIdx.z, k0 = bx * 128, b0 = by * 128;
   const float sa = plane_scale(amax[amax_idx(AMAX_DH, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: dh = 4 quads of 4 n per thread (row rr + 32 j, n4), weights = 2 x 3 fragments of 8 n (column cc + 64 j)
   const int n4 = tid % K::NAQ, rr = tid / K::NAQ;
@@ -682,9 +708,18 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int e = blockIdx.z % ne, split = blockIdx.z / ne;
+#if DDRL_FC_SWZ != 0
+  // 1-D grid (launch site): linear id = xcd + 8 (t + 4 m): the four feature tiles t of one (column tile, split, encoder) unit run
+  // together on ONE XCD and share the unit's a3 columns through its L2 (6.7 MB per unit, read once instead of four times)
+  const int unit = (int)(blockIdx.x >> 5) * 8 + (int)(blockIdx.x & 7);
+  if (unit >= 25 * ne * nsplit) return;
+  const int bx = unit % 25, by = (int)(blockIdx.x >> 3) & 3, bz = unit / 25;
+#else
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#endif
+  const int e = bz % ne, split = bz / ne;
   const float sd = plane_scale(amax[amax_idx(AMAX_DH, e)]), sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sd * sa);
-  const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  const int k0 = bx * 128, n0 = by * 128;
   const int nkb = (n + K::KB - 1) / K::KB;
   const int per = (nkb + nsplit - 1) / nsplit;
   const int kb_begin = split * per, kb_end = min(nkb, kb_begin + per);
@@ -702,7 +737,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
   for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (8 * (g16 >> 1) + q) * K::PITCH + (wc * 64 + j * 32 + 16 * (g16 & 1) + 4 * pp) * 2;
   f4 dr[4], ar[4];
   f4 bsum = zero4();
-  const bool bias_owner = (blockIdx.x == 0);
+  const bool bias_owner = (bx == 0);
   auto fetch = [&](int kb) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -810,7 +845,12 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
       (void)hipFuncSetAttribute((const void*)fc_wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcWgradB::LDS_BYTES);
       configured_w = true;
     }
-    hipLaunchKernelGGL(fc_wgrad_planes_kernel, dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
+#if DDRL_FC_SWZ != 0
+    const dim3 wgrid((unsigned)((25 * L.NE * S + 7) / 8 * 32));
+#else
+    const dim3 wgrid((FLAT + 127) / 128, FEAT / 128, L.NE * S);
+#endif
+    hipLaunchKernelGGL(fc_wgrad_planes_kernel, wgrid, dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
                        MB * FEAT, w.a3, MB * FLAT, w.amax, w.wpart, c.n, S, L.NE);
     (void)p;
 #else

@@ -8,6 +8,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from ddrl4nav_amd import _lib  # noqa: E402
+if os.environ.get("DDRL_ABL_LIB"):
+    _lib.LIB_PATH = os.environ["DDRL_ABL_LIB"]  # A/B builds under tools/_scratch_abl/
 from ddrl4nav_amd.engine import HotPath  # noqa: E402
 from ddrl4nav_amd.utils.recipe import flatten, make_weights  # noqa: E402
 
