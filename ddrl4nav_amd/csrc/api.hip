@@ -187,7 +187,12 @@ int32_t ddrl_set_step(ddrl_ctx* ctx, int64_t step) {
 // the activation slots of Workspace::amax start every forward at zero (the conv epilogues raise them); the gradient slots
 // are reset by launch_encoder_backward
 static void amax_begin(ddrl_ctx* ctx, hipStream_t st) {
+#ifdef DDRL_FWD1_F32  // conv_fwd1_planes_kernel, the first launch of every forward, zeroes them itself
   (void)hipMemsetAsync(ctx->ws.amax + amax_idx(AMAX_FIRST_ACT, 0), 0, (AMAX_DH - AMAX_FIRST_ACT) * 2 * sizeof(float), st);
+#else
+  (void)ctx;
+  (void)st;
+#endif
 }
 
 static void ensure_packed(ddrl_ctx* ctx, hipStream_t st) {

@@ -631,6 +631,9 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   const int64_t src0 = (int64_t)b0 * 28224 + iy0_start * 84, src1 = (int64_t)b1 * 28224;
   float* bias = (float*)(ldsb + 2 * K::STAGE_BYTES);
   if (tid < K::ROWS) bias[tid] = params[(tid >> 5 ? bias_off1 : bias_off0) + (tid & 31)];
+  // this kernel opens every forward: it also resets the running maxima that the conv2 / conv3 epilogues raise afterwards (a
+  // separate 16-byte memset is a kernel of its own: 5 of the ~100 us of an acting step)
+  if (blockIdx.x == 0 && tid < (AMAX_DH - AMAX_FIRST_ACT) * 2) amax[amax_idx(AMAX_FIRST_ACT, 0) + tid] = 0.0f;
   int64_t imsrc[6];
   int imdst[6];
 #pragma unroll

@@ -498,11 +498,18 @@ struct ConvWgrad3v2 {
 using s4w = __attribute__((ext_vector_type(4))) short;
 using bf8w = __attribute__((ext_vector_type(8))) __bf16;
 using u4w = __attribute__((ext_vector_type(4))) unsigned;
+#ifndef DDRL_W3_BPITCH
+#define DDRL_W3_BPITCH 64
+#endif
 struct Wgrad3B {
   // whole samples per stage.  One sample per stage (56 KB of LDS, two workgroups per CU, 4 k-groups 49/64 full) measured
   // 3.22 against 3.07 ms: the second workgroup hides the commit, the extra zero rows cost more.
   static constexpr int NB = 2, KAPPA = NB * 49, NKG = (KAPPA + 15) / 16, AROWS = NKG * 16, BROWS = NB * 81;
-  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 128, B_OFF = NPL * A_PLANE;
+  // a2 as [ic half][sample pixel][32 ic]: 64-byte rows at a pitch of 64 B, so that the four rows of a transposing read (four
+  // consecutive pixels) fall into the four 64-byte bank quarters.  (As [pixel][64 ic] with 128-byte rows they shared two quarters:
+  // 2-way conflicts on 62 % of the LDS cycles of a kernel that three plane products per fragment pair made LDS-bound.)
+  static constexpr int BP = DDRL_W3_BPITCH, B_HALF = BROWS * BP;
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE = 2 * B_HALF, B_OFF = NPL * A_PLANE;
   static constexpr int LDS_BYTES = NPL * (A_PLANE + B_PLANE);      // NB = 2: 14,336 + 20,736 per plane
   static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 8;   // (row, 8-channel group) staging units: 784 / 1,296
   static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;  // per thread: 4 / 6
@@ -554,14 +561,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __
     const int c8 = u / K::BROWS, rho = u % K::BROWS, bl = rho / 81, pos = rho % 81;
     bsmp[t] = bl;
     bsrc[t] = a2 + e * a2_es + (c8 * 8) * 81 + pos;                                 // + sample * 5184, + c * 81
-    bwr[t] = K::B_OFF + rho * 128 + c8 * 16;
+    bwr[t] = K::B_OFF + (c8 >> 2) * K::B_HALF + rho * K::BP + (c8 & 3) * 16;
   }
   // ---- fragment addresses.  16-lane group g16: columns 16 (g16 & 1) .. +15 of the 32-channel fragment, k-values
   // 8 (g16 >> 1) .. +7; inside the group lane 4 q + pp supplies row q (first read) / q + 4 (second), chunk pp.
   const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int sw = (q >> 1) & 1;  // the half swap of rows kappa = 16 g + 8 h + q (+4): bit 1 of kappa = bit 1 of q
   const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
-  const int b_lane = K::B_OFF + wj * 64 + (g16 & 1) * 32 + pp * 8;
+  const int b_lane = K::B_OFF + wj * K::B_HALF + (g16 & 1) * 32 + pp * 8;
   int brow[K::NKG][2];  // byte offset of the a2 row that belongs to this lane's kappa (tap 0), first / second read
 #pragma unroll
   for (int g = 0; g < K::NKG; ++g)
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __
     for (int r = 0; r < 2; ++r) {
       const int kap = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
       const int bl = kap / 49, px = kap % 49;
-      brow[g][r] = kap < K::KAPPA ? (bl * 81 + (px / 7) * 9 + px % 7) * 128 : 0;  // padded kappa: any row (dz3 is zero there)
+      brow[g][r] = kap < K::KAPPA ? (bl * 81 + (px / 7) * 9 + px % 7) * K::BP : 0;  // padded kappa: any row (dz3 is zero there)
     }
   float ar[K::NA][8], br[K::NBU][8];
   float bsum[K::NA][8];
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __
         DDRL_PLANE_PRODUCTS;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int toff = ((t / 3) * 9 + t % 3) * 128;
+          const int toff = ((t / 3) * 9 + t % 3) * K::BP;
           frag8 b[NPL];
 #pragma unroll
           for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(ldsw3, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
@@ -718,9 +725,17 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
 // fragment; the four rows of a read are 2 rows apart -> 2-way conflicted).  Wave (i, tg) = oc half x tap rows
 // {2 tg, 2 tg + 1} = 8 fragment tiles.  LDS 3 x 12 KB + 3 x 25 KB = 111 KB, one stage, next stage in registers.
 // ================================================================================================
+#ifndef DDRL_W2_BPITCH
+#define DDRL_W2_BPITCH 96
+#endif
 struct Wgrad2B {
   static constexpr int KAPPA = 81, NKG = 6, AROWS = NKG * 16, BROWS = 400;
-  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * 64, B_OFF = NPL * A_PLANE;
+  // a1 rows (one input pixel, 32 channels = 64 B) at a pitch of 96 B: the four rows of a transposing read are two pixels apart, so
+  // their 32-byte pieces start 192 B apart and the eight pieces of a 32-lane half fall into eight different 32-byte bank groups
+  // (pitch 64: two rows per group, SQ_LDS_BANK_CONFLICT 59 % of the LDS cycles -- and with three plane products per fragment pair
+  // instead of six the kernel is bound by LDS bandwidth: 768 B per MFMA)
+  static constexpr int BP = DDRL_W2_BPITCH;
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE = BROWS * BP, B_OFF = NPL * A_PLANE;
   static constexpr int LDS_BYTES = NPL * (A_PLANE + B_PLANE);      // 12,288 + 25,600 per plane
   static constexpr int WG_PER_CU = LDS_BYTES <= 80 * 1024 ? 2 : 1;
   static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BROWS * 4;   // (row, 8-channel group) staging units: 648 / 1,600
@@ -759,19 +774,19 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
     const int u = min(tid + 256 * t, K::B_UNITS - 1);
     const int c8 = u / K::BROWS, pos = u % K::BROWS;
     bsrc[t] = a1 + e * a1_es + (c8 * 8) * 400 + pos;                                // + sample * 12800, + c * 400
-    bwr[t] = K::B_OFF + pos * 64 + c8 * 16;
+    bwr[t] = K::B_OFF + pos * K::BP + c8 * 16;
   }
   const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int sw = (q >> 1) & 1;
   const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
-  const int b_lane = K::B_OFF + tg * (2 * 20 * 64) + (g16 & 1) * 32 + pp * 8;
+  const int b_lane = K::B_OFF + tg * (2 * 20 * K::BP) + (g16 & 1) * 32 + pp * 8;
   int brow[K::NKG][2];  // byte offset of the a1 row (2 y) 20 + 2 x of this lane's kappa, first / second read
 #pragma unroll
   for (int g = 0; g < K::NKG; ++g)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int kap = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
-      brow[g][r] = kap < K::KAPPA ? ((kap / 9) * 40 + (kap % 9) * 2) * 64 : 0;
+      brow[g][r] = kap < K::KAPPA ? ((kap / 9) * 40 + (kap % 9) * 2) * K::BP : 0;
     }
   float ar[K::NA][8], br[K::NBU][8];
   float bsum[K::NA][8];
@@ -838,7 +853,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
         DDRL_PLANE_PRODUCTS;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const int toff = ((t / 4) * 20 + t % 4) * 64;
+          const int toff = ((t / 4) * 20 + t % 4) * K::BP;
           frag8 b[NPL];
 #pragma unroll
           for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(ldsw2, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
