@@ -749,7 +749,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
   using K = Wgrad2B;
   extern __shared__ __attribute__((aligned(16))) char ldsw2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int wi = wave >> 1, tg = wave & 1;
+  // wave = tap row ky (4 column tiles: kx = 0..3) x BOTH oc halves: a k-group reads 2 x 2 dz2 fragments and 4 x 2 a1 fragments for its 24
+  // MFMAs (one oc half x two tap rows read 1 x 2 + 8 x 2: a third more LDS bytes per MFMA in a kernel that LDS bandwidth bounds)
   const int e = blockIdx.x % ne, split = blockIdx.x / ne;
   const float sd = plane_scale(amax[amax_idx(AMAX_DZ2, e)]), sa = plane_scale(amax[amax_idx(AMAX_A1, e)]), inv = 1.0f / (sd * sa);
   const int per = (n + nsplit - 1) / nsplit;
@@ -778,8 +779,10 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
   }
   const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int sw = (q >> 1) & 1;
-  const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
-  const int b_lane = K::B_OFF + tg * (2 * 20 * K::BP) + (g16 & 1) * 32 + pp * 8;
+  int a_lane[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_lane[i] = (8 * (g16 >> 1) + q) * 128 + (((i ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
+  const int b_lane = K::B_OFF + wave * (20 * K::BP) + (g16 & 1) * 32 + pp * 8;
   int brow[K::NKG][2];  // byte offset of the a1 row (2 y) 20 + 2 x of this lane's kappa, first / second read
 #pragma unroll
   for (int g = 0; g < K::NKG; ++g)
@@ -847,18 +850,22 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
     for (int st = st_begin; st < st_end; ++st) {
 #pragma unroll
       for (int g = 0; g < K::NKG; ++g) {
-        frag8 a[NPL];
+        frag8 a[2][NPL];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) a[p] = tr_frag3(ldsw2, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            a[i][p] = tr_frag3(ldsw2, a_lane[i] + p * K::A_PLANE + g * 2048, a_lane[i] + p * K::A_PLANE + g * 2048 + 512);
         DDRL_PLANE_PRODUCTS;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int toff = ((t / 4) * 20 + t % 4) * K::BP;
+        for (int t = 0; t < 4; ++t) {  // kx
           frag8 b[NPL];
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(ldsw2, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
+          for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(ldsw2, b_lane + p * K::B_PLANE + brow[g][0] + t * K::BP, b_lane + p * K::B_PLANE + brow[g][1] + t * K::BP);
 #pragma unroll
-          for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[PA[m]], b[PB[m]], acc[t]);
+          for (int m = 0; m < NPROD; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[4 * i + t] = mfma_planes(a[i][PA[m]], b[PB[m]], acc[4 * i + t]);
         }
       }
       __syncthreads();  // every wave is done with the stage
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 512 + l31 * 16 + (2 * tg + t / 4) * 4 + t % 4] = acc[t][r] * inv;
+    for (int r = 0; r < 16; ++r) slab[((t / 4) * 32 + acc_row(r, hi)) * 512 + l31 * 16 + wave * 4 + t % 4] = acc[t][r] * inv;
   __syncthreads();
   float* red = (float*)ldsw2;  // [unit][8]
 #pragma unroll
