@@ -602,9 +602,15 @@ using bf4 = __attribute__((ext_vector_type(4))) __bf16;
 #ifndef DDRL_F1_KO
 #define DDRL_F1_KO 0
 #endif
+#ifndef DDRL_F1_PITCH
+#define DDRL_F1_PITCH 168
+#endif
 template <int NE>
 struct Fwd1B {
-  static constexpr int ROWS = 32 * NE, A_BYTES = 4 * NPL * 2 * ROWS * 16, PITCH = 176, IMG_BYTES = 64 * PITCH;
+  // image row pitch 168 B = the 84 pixels of a row, no pad: a 32-pixel column tile reads 20 pixels of one row and 12 of the row 4 below,
+  // whose banks (4 x 168 B = 40 words further) follow the first 20 pixels without overlap, and 2 x (16 KB + 10.5 KB) lets THREE workgroups
+  // share a CU (at pitch 176 the third missed by 1.4 KB)
+  static constexpr int ROWS = 32 * NE, A_BYTES = 4 * NPL * 2 * ROWS * 16, PITCH = DDRL_F1_PITCH, IMG_BYTES = 64 * PITCH;
   static constexpr int STAGE_BYTES = A_BYTES + IMG_BYTES, AQ = A_BYTES / 16, NAJ = AQ / 256;  // weight quads per thread
   static constexpr size_t LDS_BYTES = 2 * STAGE_BYTES + ROWS * 4;
 };
