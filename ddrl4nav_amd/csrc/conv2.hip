@@ -1776,6 +1776,11 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 // (A first version with 5-wave workgroups of 3 samples kept only ONE workgroup resident per CU -- SQ_WAVE_CYCLES -- and
 // ran at 6.7 ms.)
 // ================================================================================================
+// Timing-only knock-outs (-DDDRL_D2_KO=bits; results are WRONG): 1 no dz1 stores, 2 no MFMAs, 4 no dz2 loads, 8 no weight loads,
+// 16 no dz2 split / LDS writes
+#ifndef DDRL_D2_KO
+#define DDRL_D2_KO 0
+#endif
 struct Dgrad2B {
   static constexpr int SPT = 5, THREADS = 256, TN = 4;
   static constexpr int IMG_PLANE = SPT * 121 * 16;                // 9,680 B
@@ -1826,13 +1831,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 81];
+      for (int c = 0; c < 8; ++c) ir[j][c] = (DDRL_D2_KO & 4) ? (float)(kb + c) : isrc[j][(kb * 8 + c) * 81];
 #pragma unroll
-    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * (2 * NPL * 1024) + j * 2048);
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = (DDRL_D2_KO & 8) ? (f4){(float)kb, 1.0f, 2.0f, 3.0f} : *(const f4*)(wsrc + kb * (2 * NPL * 1024) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
+      if (DDRL_D2_KO & 16) continue;
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
         unsigned pl[4][NPL];
 #pragma unroll
@@ -1875,7 +1881,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
+          for (int j = 0; j < K::TN; ++j) {
+            if (DDRL_D2_KO & 2) acc[i][j][0] += (float)af[PA[t]][i][0] + (float)bfr[PB[t]][j][0];
+            else acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
+          }
     }
     __syncthreads();  // every wave is done with the stage
     if (kb + 1 < NKB) {
@@ -1895,7 +1904,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float g0 = acc[0][j][r] * inv, g1 = acc[1][j][r] * inv;
-      *(float2*)(base + acc_row(r, hi) * 400) = make_float2(g0, g1);
+      if (!(DDRL_D2_KO & 1) || g0 == 1.2345f) *(float2*)(base + acc_row(r, hi) * 400) = make_float2(g0, g1);
       big = fmaxf(big, fmaxf(fabsf(g0), fabsf(g1)));
     }
   }

@@ -453,17 +453,30 @@ using b8v = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int NPL = 2, NPROD = 3;
 using frag8 = h8v;
 #define DDRL_PLANE_PRODUCTS constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0} /* smallest first: h1 g0, h0 g1, h0 g0 */
-// written so that the compiler emits six VALU instructions per PAIR (v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16,
-// v_pk_fma_f32, v_cvt_pk_f16_f32); the element-wise form above compiled to ten, and the kernels issue 3 - 9 VALU
-// instructions per MFMA, most of them this split.  x S and x S - h0 are exact in fp32, so the fma changes no bit.
+// FOUR VALU instructions per PAIR: v_fma_mixlo_f16 / v_fma_mixhi_f16 compute fma(x, S, c) in fp32 and write the result as fp16 into
+// the low / high half of the destination, with c an fp32 or (op_sel_hi) an fp16 source: h0 = fp16(x S + 0), h1 = fp16(x S - h0)
+// straight from the h0 halves.  x S and x S - h0 are exact in fp32, so each value is rounded once, as in the plain form
+// (v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_fma_f32, v_cvt_pk_f16_f32: six; element-wise C compiled to ten).
+// Bit-identical to it on 12.6 M values over 60 binades and three scales; only -0 comes out as +0.  The kernels issue 3 - 8 VALU
+// instructions per MFMA, most of them this split.
 using f32x2_t = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void split_planes(float x, float y, float scale, unsigned (&p)[NPL]) {
+#ifndef DDRL_SPLIT_PLAIN
+  unsigned h0, h1;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(x), "v"(scale));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(y), "v"(scale));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h1) : "v"(x), "v"(scale), "v"(h0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h1) : "v"(y), "v"(scale), "v"(h0));
+  p[0] = h0;
+  p[1] = h1;
+#else
   const f32x2_t xs = {x * scale, y * scale};
   const f16x2_t a = __builtin_convertvector(xs, f16x2_t);
   const f32x2_t r = {__builtin_fmaf(x, scale, -(float)a[0]), __builtin_fmaf(y, scale, -(float)a[1])};
   const f16x2_t b = __builtin_convertvector(r, f16x2_t);
   p[0] = __builtin_bit_cast(unsigned, a);
   p[1] = __builtin_bit_cast(unsigned, b);
+#endif
 }
 __device__ __forceinline__ f32x16 mfma_planes(frag8 a, frag8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __host__ __device__ inline float plane_scale(float amax) { return f16_scale(amax); }
