@@ -15,8 +15,21 @@ class Actor(nn.Module):
     def log_prob_from_distribution(self, pi, act):
         return self._log_prob_from_distribution(pi, act)
 
+    def _bind_owner(self, net):
+        """The net whose fused forward evaluates this head (a weak reference: the net owns the module, not the reverse)."""
+        import weakref
+        object.__setattr__(self, "_owner", weakref.ref(net))
+
     def forward(self, x, act=None, play_mode=False):
-        raise RuntimeError("actor heads run inside ddrl4nav_amd.nn.PPO (HIP kernels)")
+        """actor.py:27-40: ``(pi, log_p)`` for the raw observation ``x`` when the actor has its own encoder (``pre``).  The
+        arithmetic is the owning net's fused forward (the HIP kernels evaluate both heads in one pass; the value is dropped
+        here).  With a shared prenet the reference feeds FEATURES to the bare head: not offered on this path."""
+        owner = getattr(self, "_owner", lambda: None)()
+        if owner is None:
+            raise RuntimeError("this actor head is not bound to a ddrl4nav_amd net (its arithmetic lives in the net's HIP kernels)")
+        if self.pre is None:
+            raise NotImplementedError("net.actor(features) with a shared prenet: call net(states) -- the heads are fused into it")
+        return owner.forward(x, act, play_mode)[0]
 
 
 class CategoricalActor(Actor):

@@ -25,6 +25,16 @@ class Critic(nn.Module):
         self.add_module("pre", pre) if pre is not None else setattr(self, "pre", None)
         self.device = device
 
-    def forward(self, features):
-        raise RuntimeError("Critic is evaluated inside ddrl4nav_amd.nn.PPO / GenericPPO by the HIP head kernels; "
-                           "it cannot be called on its own")
+    def _bind_owner(self, net):
+        import weakref
+        object.__setattr__(self, "_owner", weakref.ref(net))
+
+    def forward(self, x):
+        """critic.py:14-21: V(x) ``[n, 1]`` for the raw observation when the critic has its own encoder.  Evaluated by the owning
+        net's fused forward (play mode: nothing is sampled); with a shared prenet the reference passes features -- not offered."""
+        owner = getattr(self, "_owner", lambda: None)()
+        if owner is None:
+            raise RuntimeError("this critic is not bound to a ddrl4nav_amd net (its arithmetic lives in the net's HIP kernels)")
+        if self.pre is None:
+            raise NotImplementedError("net.critic(features) with a shared prenet: call net(states) -- the heads are fused into it")
+        return owner.forward(x, None, True)[1][0]

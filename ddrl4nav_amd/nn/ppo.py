@@ -59,6 +59,8 @@ class PPO(Basenn):
         in_ch = (prenet if prenet is not None else actor.pre).conv1.in_channels
         cap = int(max_batch if max_batch is not None else max(2 * config_nn.TRAINING_MIN_BATCH, 2048))
         self._build(cap, n_actions, in_ch)
+        actor._bind_owner(self)    # net.actor(x) / net.critic(x) as the reference offers them (actor.py:27-40, critic.py:14-21)
+        critic._bind_owner(self)
 
     # ---- arena binding --------------------------------------------------------------------------
     def _hot_path_kwargs(self):

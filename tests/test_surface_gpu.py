@@ -71,6 +71,22 @@ def test_forward_protocol_matches_reference_shapes(net, golden):
     assert torch.argmax(probs, dim=1).shape == (8,)
 
 
+def test_actor_and_critic_are_callable_like_the_reference(net, golden):
+    """net.actor(states, act) / net.critic(states) (reference actor.py:27-40, critic.py:14-21; ppo.py:75 composes exactly these)
+    return what the fused forward returns, pinned to golden F1."""
+    g = golden("f1_forward")
+    x = [torch.from_numpy(g["frames"])]
+    dist, logp = net.actor(x, torch.from_numpy(g["actions"]))
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dist.probs.cpu().numpy(), g["p_hat"], rtol=1e-5, atol=1e-6)
+    v = net.critic(x)
+    assert v.shape == (8, 1)
+    np.testing.assert_allclose(v.cpu().numpy()[:, 0], g["value"], rtol=1e-5, atol=1e-6)
+    probs, none = net.actor(x, play_mode=True)
+    assert none is None
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=1e-5, atol=1e-6)
+
+
 def test_learn_generator_protocol_golden_f4(net, golden):
     from ddrl4nav_amd.data import Experience
     g3, g4 = golden("f3_loss"), golden("f4_learn")
