@@ -43,8 +43,8 @@ PIPE = {"ConvFwd1": ("f16x2", 2), "ConvWgrad1": ("f16x2", 2), "ConvFwd2": ("f16x
         "FcFwd": ("f16x3", 3), "FcDgrad": ("f16x3", 3), "ConvDgrad3": ("f16x3", 3), "ConvDgrad2": ("f16x3", 3),
         "FcWgrad": ("f16x3", 3), "ConvWgrad3": ("f16x3", 3), "ConvWgrad2": ("f16x3", 3)}
 # executed / algorithmic MFMA work of the kernels that walk padded operands
-EXECUTED_OVER_ALGORITHMIC = {"ConvDgrad3": 1.84, "ConvDgrad2": 1.23, "ConvFwd3": 1.11, "ConvWgrad3": 112.0 / 98.0,
-                             "ConvWgrad2": 96.0 / 81.0}
+EXECUTED_OVER_ALGORITHMIC = {"ConvDgrad3": 81.0 / 49.0, "ConvDgrad2": 1.23, "ConvFwd3": 1.11, "ConvWgrad3": 112.0 / 98.0,
+                             "ConvWgrad2": 96.0 / 81.0, "ConvWgrad1": 48.0 / 40.0}
 PEAK_HBM_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # algorithmic HBM bytes per launch of the HBM-bound kernels, f(N envs, B samples, P params)
 HBM_BYTES = {

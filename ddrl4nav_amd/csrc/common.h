@@ -80,7 +80,7 @@ struct Workspace {
   unsigned short* wp3b;
   // conv2 weights for the data gradient as three bf16 planes [e][row parity 2][k-block 8][u 2][plane 3][(c, ic) 64][v 2][oc 8]
   unsigned short* wd2b;
-  // conv3 weights for the data gradient as three bf16 planes [e][k-block 8][tap pair 5][plane 3][ic 64][tap parity 2][oc 8]
+  // conv3 weights for the data gradient as planes [e][k-block 4 (16 oc)][tap 9][plane][ic 64][oc half 2][oc 8]
   unsigned short* wd3b;
   // conv3 weights for the exact-tap data gradient (conv_dgrad3_exact_kernel): three bf16 planes
   // [e][k-block 8 (8 oc)][tap 9][plane 3][ic 64][oc 8]

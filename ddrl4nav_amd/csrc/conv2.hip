@@ -602,6 +602,9 @@ using bf4 = __attribute__((ext_vector_type(4))) __bf16;
 #ifndef DDRL_F1_KO
 #define DDRL_F1_KO 0
 #endif
+#ifndef DDRL_F1_LDS_PAD
+#define DDRL_F1_LDS_PAD 0  // A/B: 256 restores the two-workgroups-per-CU footprint
+#endif
 #ifndef DDRL_F1_PITCH
 #define DDRL_F1_PITCH 168
 #endif
@@ -612,7 +615,9 @@ struct Fwd1B {
   // share a CU (at pitch 176 the third missed by 1.4 KB)
   static constexpr int ROWS = 32 * NE, A_BYTES = 4 * NPL * 2 * ROWS * 16, PITCH = DDRL_F1_PITCH, IMG_BYTES = 64 * PITCH;
   static constexpr int STAGE_BYTES = A_BYTES + IMG_BYTES, AQ = A_BYTES / 16, NAJ = AQ / 256;  // weight quads per thread
-  static constexpr size_t LDS_BYTES = 2 * STAGE_BYTES + ROWS * 4;
+  // 54,272 B = 106 allocation units of 512 B: THREE workgroups share a CU's 160 KB (the bias used to sit behind the stages: 54,528 B
+  // -> 107 units -> two workgroups).  The epilogue reads the bias from stage 0, which is free by then.
+  static constexpr size_t LDS_BYTES = 2 * STAGE_BYTES + DDRL_F1_LDS_PAD;
 };
 
 template <int NE>
@@ -635,8 +640,6 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   }
   const int nd0 = nrows0 * 21, nd_total = nd0 + nrows1 * 21;
   const int64_t src0 = (int64_t)b0 * 28224 + iy0_start * 84, src1 = (int64_t)b1 * 28224;
-  float* bias = (float*)(ldsb + 2 * K::STAGE_BYTES);
-  if (tid < K::ROWS) bias[tid] = params[(tid >> 5 ? bias_off1 : bias_off0) + (tid & 31)];
   // this kernel opens every forward: it also resets the running maxima that the conv2 / conv3 epilogues raise afterwards (a
   // separate 16-byte memset is a kernel of its own: 5 of the ~100 us of an acting step)
   if (blockIdx.x == 0 && tid < (AMAX_DH - AMAX_FIRST_ACT) * 2) amax[amax_idx(AMAX_FIRST_ACT, 0) + tid] = 0.0f;
@@ -730,6 +733,9 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
     }
     __syncthreads();
   }
+  float* bias = (float*)ldsb;  // stage 0 is free: the last k-block read stage 1 and every wave has passed the loop's final barrier
+  if (tid < K::ROWS) bias[tid] = params[(tid >> 5 ? bias_off1 : bias_off0) + (tid & 31)];
+  __syncthreads();
   float r255[NE];  // 1/255 of the frame normalisation and the scale of the encoder's weight planes
 #pragma unroll
   for (int i = 0; i < NE; ++i) r255[i] = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_W1, i)]));
@@ -1334,23 +1340,27 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
 // ================================================================================================
 // conv3 data gradient as bf16x6, gather form (see conv_fwd3_planes_kernel, whose mirror image it is):
 //   dz2[b][ic][y][x] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][y-ky][x-kx] W3[oc][ic][ky][kx]
-// dz3 is staged channel-innermost into zero-bordered 11 x 11 images (data at +2, +2; [plane][sample][pixel][8 oc] bf16),
-// one MFMA k-group = (two taps) x 8 oc, the tenth tap padded with zero weights; tile = 64 ic x 3 whole samples (243
-// columns, wave w = columns 64 w .., 2 x 2 fragment tiles), k-block = 8 oc = 5 k-groups, 8 k-blocks, one LDS stage.
+// dz3 is staged channel-innermost into zero-bordered 11 x 11 images (data at +2, +2; [plane][sample][pixel][16 oc] 16-bit),
+// one MFMA k-group = one tap x 16 oc; tile = 64 ic x 3 whole samples (243 columns, wave w = columns 64 w .., 2 x 2 fragment
+// tiles), k-block = 16 oc = 9 k-groups, 4 k-blocks, one LDS stage.
 // (Requesting the a2 values of the mask before the last k-block instead of in the epilogue: no gain, 4.37 vs 4.33 ms.)
 // It walks all 81 x 9 tap products of which 49 x 9 are non-zero (the scatter form, conv_dgrad3_scatter_kernel, does
 // not) and still wins: 192 instead of 512 matrix-pipe cycles per 16 k.
-// Weights: wd3b[e][k-block 8][tap pair 5][plane 3][ic 64][tap parity 2][oc 8] (optim.hip).
+// Weights: wd3b[e][k-block 4][tap 9][plane][ic 64][oc half 2][oc 8] (optim.hip).
 // ================================================================================================
 #ifndef DDRL_D3B_TN
-#define DDRL_D3B_TN 2  // 2 x 2 fragment tiles, 3 samples per tile: 4.19 vs 4.27 ms for 2 x 4 / 6 samples
+#define DDRL_D3B_TN 2  // 2 x 2 fragment tiles, 3 samples per tile: 4.19 vs 4.27 ms for 2 x 4 / 6 samples (re-measured under f16 planes: 2.54 vs 2.60)
 #endif
 struct Dgrad3B {
+  // one MFMA k-group = ONE tap x 16 oc (lane half h = oc 8 h .. 8 h + 7): nine k-groups per k-block of 16 oc, no padded tenth tap
+  // (tap pairs x 8 oc walked ten: executed / algorithmic 1.84 -> 1.65), the tap shift is a compile-time LDS offset, four k-blocks
+  // instead of eight.  Weights: wd3b[e][k-block 4][tap 9][plane NPL][ic 64][oc half 2][oc 8] (optim.hip pack_dgrad3_bf16_kernel).
   static constexpr int THREADS = 256, TN = DDRL_D3B_TN, SPT = (128 * TN) / 81;  // column tiles per wave, whole samples per tile
-  static constexpr int IMG_PLANE = SPT * 121 * 16;                // 5,808 B
-  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 5 * NPL * 64 * 32;
-  static constexpr int NIU = SPT * 49, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 147 -> 1 per thread
-  static constexpr int NWQ = W_BYTES / 16, NWJ = (NWQ + THREADS - 1) / THREADS;  // 1,920 weight quads -> 8 per thread (last partial)
+  static constexpr int KOC = 16, NKB = 64 / KOC, PIXB = 2 * KOC;  // oc per k-block, k-blocks, bytes per pixel and plane
+  static constexpr int IMG_PLANE = SPT * 121 * PIXB;              // 11,616 B
+  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 9 * NPL * 64 * 32;
+  static constexpr int NIU = SPT * 49, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (16 oc each): 147 -> 1 per thread
+  static constexpr int NWQ = W_BYTES / 16, NWJ = (NWQ + THREADS - 1) / THREADS;  // 2,304 weight quads -> 9 per thread
   static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
 };
 
@@ -1363,19 +1373,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
   const float sa = plane_scale(amax[amax_idx(AMAX_DZ3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W3, e)]));
   for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd3 + i * 16) = zero4();  // images incl. their zero borders
-  // ---- staging maps.  unit u = tid + 256 j: sample u / 49, pixel u % 49 -> 8 loads of stride 49 (the k-block's 8 oc)
+  // ---- staging maps.  unit u = tid + 256 j: sample u / 49, pixel u % 49 -> 16 loads of stride 49 (the k-block's 16 oc)
   const float* isrc[K::NIJ];
   int idst[K::NIJ];
 #pragma unroll
   for (int j = 0; j < K::NIJ; ++j) {
     const int u = min(tid + K::THREADS * j, K::NIU - 1);
     const int s = u / 49, px = u % 49;
-    isrc[j] = dz3 + e * dz_es + (int64_t)min(b0 + s, n - 1) * FLAT + px;  // + (8 kb + c) * 49
-    idst[j] = (s * 121 + (px / 7 + 2) * 11 + px % 7 + 2) * 16;
+    isrc[j] = dz3 + e * dz_es + (int64_t)min(b0 + s, n - 1) * FLAT + px;  // + (16 kb + c) * 49
+    idst[j] = (s * 121 + (px / 7 + 2) * 11 + px % 7 + 2) * K::PIXB;
   }
-  const unsigned short* wsrc = wd3b + (int64_t)e * (8 * 5 * NPL * 64 * 16) + tid * 8;  // + kb * 5 * NPL * 1024 + j * 2048
+  const unsigned short* wsrc = wd3b + (int64_t)e * (K::NKB * 9 * NPL * 64 * 16) + tid * 8;  // + kb * 9 * NPL * 1024 + j * 2048
   // ---- operand bases
-  int aA[2], bB[K::TN], tapoff[5];
+  int aA[2], bB[K::TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
 #pragma unroll
@@ -1383,34 +1393,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int c = wc * (32 * K::TN) + j * 32 + l31;
     if (c >= K::SPT * 81) c = 0;
     const int s = c / 81, pix = c % 81;
-    bB[j] = (s * 121 + (pix / 9 + 2) * 11 + pix % 9 + 2) * 16;
+    bB[j] = (s * 121 + (pix / 9 + 2) * 11 + pix % 9 + 2) * K::PIXB + hi * 16;
   }
-#pragma unroll
-  for (int kg = 0; kg < 5; ++kg) {
-    const int tap = min(2 * kg + hi, 8);
-    tapoff[kg] = ((tap / 3) * 11 + tap % 3) * 16;  // subtracted: source pixel (y - ky, x - kx)
-  }
-  float ir[K::NIJ][8];
+  float ir[K::NIJ][K::KOC];
   f4 wr[K::NWJ];
   auto fetch = [&](int kb) {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ir[j][c] = isrc[j][(kb * 8 + c) * 49];
+      for (int c = 0; c < K::KOC; ++c) ir[j][c] = isrc[j][(kb * K::KOC + c) * 49];
 #pragma unroll
     for (int j = 0; j < K::NWJ; ++j)
-      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * (5 * NPL * 1024) + j * 2048);
+      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * (9 * NPL * 1024) + j * 2048);
   };
   auto commit = [&]() {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
-        unsigned pl[4][NPL];
+        unsigned pl[K::KOC / 2][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], sa, pl[c]);
+        for (int c = 0; c < K::KOC / 2; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], sa, pl[c]);
         char* d = ldsd3 + idst[j];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+        for (int p = 0; p < NPL; ++p) {
+          *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+          *(u4v*)(d + p * K::IMG_PLANE + 16) = (u4v){pl[4][p], pl[5][p], pl[6][p], pl[7][p]};
+        }
       }
     }
 #pragma unroll
@@ -1424,39 +1432,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < K::TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  constexpr int NKB = 8;
   fetch(0);
   __syncthreads();  // zero fill complete
   commit();
   fetch(1);
   __syncthreads();
-  for (int kb = 0; kb < NKB; ++kb) {
+  for (int kb = 0; kb < K::NKB; ++kb) {
 #pragma unroll
-    for (int kg = 0; kg < 5; ++kg) {
+    for (int t = 0; t < 9; ++t) {  // tap (ky, kx) = (t / 3, t % 3): source pixel (y - ky, x - kx)
+      constexpr int ROW11 = 11;
+      const int toff = ((t / 3) * ROW11 + t % 3) * K::PIXB;
       frag8 af[NPL][2], bfr[NPL][K::TN];
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(ldsd3 + aA[i] + (kg * NPL + p) * 2048);
+        for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(ldsd3 + aA[i] + (t * NPL + p) * 2048);
 #pragma unroll
-        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const frag8*)(ldsd3 + bB[j] - tapoff[kg] + p * K::IMG_PLANE);
+        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const frag8*)(ldsd3 + bB[j] - toff + p * K::IMG_PLANE);
       }
       DDRL_PLANE_PRODUCTS;
 #pragma unroll
-      for (int t = 0; t < NPROD; ++t)
+      for (int m = 0; m < NPROD; ++m)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
+          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(af[PA[m]][i], bfr[PB[m]][j], acc[i][j]);
     }
     __syncthreads();  // every wave is done with the stage
-    if (kb + 1 < NKB) {
+    if (kb + 1 < K::NKB) {
       commit();
-      if (kb + 2 < NKB) fetch(kb + 2);
+      if (kb + 2 < K::NKB) fetch(kb + 2);
     }
     __syncthreads();
   }
-  // dz2 = leaky'(a2) * sum; a2 is read here, one column tile (32 values per lane) at a time
+  // dz2 = leaky'(a2) * sum
   float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < K::TN; ++j) {

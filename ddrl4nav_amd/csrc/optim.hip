@@ -172,17 +172,16 @@ __global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __re
   for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
-// conv3 weights for the bf16x6 data gradient: wd3b[e][kb][tap pair][plane][ic][tap parity][o] = W3[oc = 8 kb + o][ic][tap]
+// conv3 weights for the data gradient on planes (conv2.hip conv_dgrad3_planes_kernel): k-blocks of 16 oc, one k-group per tap
 __global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, kg, ic, h, o)
-  if (i >= 8 * 5 * 64 * 16) return;
-  const int o = i & 7, h = (i >> 3) & 1, ic = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
-  const int tap = 2 * kg + h;
-  const float w = tap < 9 ? params[L.enc_base[e] + L.enc.c3w + ((8 * kb + o) * 64 + ic) * 9 + tap] : 0.0f;
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb 4, tap 9, ic 64, h 2, o 8): wd3b[e][kb][tap][plane][ic][h][o] = W3[oc = 16 kb + 8 h + o][ic][tap]
+  if (i >= 4 * 9 * 64 * 16) return;
+  const int o = i & 7, h = (i >> 3) & 1, ic = (i >> 4) & 63, tap = (i >> 10) % 9, kb = (i >> 10) / 9;
+  const float w = params[L.enc_base[e] + L.enc.c3w + ((16 * kb + 8 * h + o) * 64 + ic) * 9 + tap];
   unsigned short pl[NPL];
   planes_of(w, plane_scale(amax[amax_idx(AMAX_W3, e)]), pl);
-  unsigned short* d = dst + ((((int64_t)(e * 8 + kb) * 5 + kg) * NPL) * 64 + ic) * 16 + h * 8 + o;
+  unsigned short* d = dst + ((((int64_t)(e * 4 + kb) * 9 + tap) * NPL) * 64 + ic) * 16 + h * 8 + o;
 #pragma unroll
   for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
@@ -234,7 +233,7 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_A1, L.NE), dim3(256), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(a1_bound_kernel, dim3(32, L.NE), dim3(64), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(8 * 9 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
-  hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
+  hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(4 * 9 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
   hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
