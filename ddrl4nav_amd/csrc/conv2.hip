@@ -813,6 +813,9 @@ static void launch_fwd1_planes(const EncCall& c, bool acting, hipStream_t st) {
 #ifndef DDRL_F2B_WPE
 #define DDRL_F2B_WPE 3  // waves per SIMD the register budget is cut for
 #endif
+#ifndef DDRL_F2B_STAGES
+#define DDRL_F2B_STAGES 1  // 2 = double-buffered LDS, one barrier per k-block: measured 2.40 against 2.335 ms (same box, f16 planes)
+#endif
 struct Fwd2B {
   static constexpr int SPT = 3, KC = DDRL_F2B_KC;                 // samples per tile, input channels per k-block
   // image row pitch 26 bf16 (13 words): the 5 input-row pairs a 32-pixel column tile reads in one instruction start
@@ -822,7 +825,13 @@ struct Fwd2B {
   static constexpr int BIAS_OFF = W_OFF + W_BYTES;
   static constexpr int NIU = SPT * KC * 100, NIJ = (NIU + 255) / 256;      // image units of 4 pixels, per thread
   static constexpr int NWJ = W_BYTES / 16 / 256;                          // weight quads per thread (6)
-  static constexpr size_t LDS_BYTES = BIAS_OFF + 64 * 4;
+  // ONE LDS stage, the next k-block committed between two barriers while the CU's other workgroups compute.  With two planes
+  // instead of three a second stage fits (2 x 20.7 KB, still three workgroups per CU; -DDDRL_F2B_STAGES=2: the next k-block is
+  // committed into the other stage while this one feeds the matrix pipe, one barrier per k-block) -- and loses 3 %: vector-ALU
+  // work does not overlap the matrix pipe of its own SIMD (tools/mfma16_peak.hip), so the commit costs the same either way and
+  // the second stage only takes LDS from the neighbours.
+  static constexpr int STAGES = DDRL_F2B_STAGES, STAGE_BYTES = BIAS_OFF;
+  static constexpr size_t LDS_BYTES = STAGES * STAGE_BYTES + 64 * 4;
 };
 struct __attribute__((packed, aligned(4))) lds_u2 {
   unsigned x, y;
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int e = blockIdx.z, b0 = blockIdx.x * K::SPT;
   const float sa = plane_scale(amax[amax_idx(AMAX_A1, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W2, e)]));
-  if (tid < 64) ((float*)(ldsc2 + K::BIAS_OFF))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
+  if (tid < 64) ((float*)(ldsc2 + K::STAGES * K::STAGE_BYTES))[tid] = params[(e ? bias_off1 : bias_off0) + tid];
   // ---- staging maps.  image unit u = tid + 256 j: sample u / 400, channel (u % 400) / 100, pixel quad u % 100
   // (row q / 5, quad q % 5).  Missing samples of the last tile read the last sample.
   const float* isrc[K::NIJ];
@@ -868,7 +877,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
 #pragma unroll
     for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc + kb * (K::KC * NPL * 1024) + j * 2048);
   };
-  auto commit = [&]() {
+  auto commit = [&](char* ldsc2) {  // shadows the kernel's base: the stage to write
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + 256 * j < K::NIU) {
@@ -892,11 +901,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   constexpr int NKB = 32 / K::KC;
-  fetch(0);
-  commit();
-  fetch(1);
-  __syncthreads();
-  for (int kb = 0; kb < NKB; ++kb) {
+  auto compute = [&](const char* ldsc2) {  // shadows the kernel's base: the stage to read
 #pragma unroll
     for (int kg = 0; kg < K::KC; ++kg) {
       frag8 a[NPL][2], b[NPL][2];
@@ -920,14 +925,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDRL_F2B_WP
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
     }
-    __syncthreads();  // every wave is done with the stage
-    if (kb + 1 < NKB) {
-      commit();
-      if (kb + 2 < NKB) fetch(kb + 2);
+  };
+  fetch(0);
+  commit(ldsc2);
+  fetch(1);
+  __syncthreads();
+  if (K::STAGES == 1) {
+    for (int kb = 0; kb < NKB; ++kb) {
+      compute(ldsc2);
+      __syncthreads();  // every wave is done with the stage
+      if (kb + 1 < NKB) {
+        commit(ldsc2);
+        if (kb + 2 < NKB) fetch(kb + 2);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    static_assert(NKB % 2 == 0, "unrolled by the two stages: every LDS address stays register + immediate");
+    for (int kb = 0; kb < NKB; kb += 2) {
+      compute(ldsc2);                      // stage 0; stage 1 was last read before the previous barrier
+      commit(ldsc2 + K::STAGE_BYTES);      // k-block kb + 1 (always exists)
+      if (kb + 2 < NKB) fetch(kb + 2);
+      __syncthreads();
+      compute(ldsc2 + K::STAGE_BYTES);
+      if (kb + 2 < NKB) {
+        commit(ldsc2);
+        if (kb + 3 < NKB) fetch(kb + 3);
+      }
+      __syncthreads();
+    }
   }
-  const float* bias = (const float*)(ldsc2 + K::BIAS_OFF);
+  const float* bias = (const float*)(ldsc2 + K::STAGES * K::STAGE_BYTES);
   float big = 0.0f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
