@@ -144,6 +144,9 @@ __host__ __device__ inline int64_t m1_words(int64_t max_batch) { return max_batc
 __host__ __device__ inline int m1_bit(int oc) { return ((oc >> 2) & 1) * 16 + 15 - ((oc & 3) + 4 * (oc >> 3)); }
 
 // split counts for the weight-gradient GEMMs (fixed per context -> deterministic sums)
+#ifndef DDRL_FC_ACT_SPLITS
+#define DDRL_FC_ACT_SPLITS 14  // split-K factor of the dense layer's forward in acting launches: a divisor of its 98 k-blocks
+#endif
 #ifndef DDRL_C1_SPLITS
 #define DDRL_C1_SPLITS 512  // two workgroups per CU in ONE round: 3.37 ms against 3.66 at 768 / 1024 / 1536, 4.1 at 256 / 384 / 640 (profiles/README.md)
 #endif
@@ -213,7 +216,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   if (p3 > pm) pm = p3;
   if (pf > pm) pm = pf;
   // the acting path parks the split-K partial sums of the FC forward here (fc_forward_splits)
-  const int64_t pact = (int64_t)14 * 2 * (MB < 1024 ? MB : 1024) * FEAT;
+  const int64_t pact = (int64_t)DDRL_FC_ACT_SPLITS * 2 * (MB < 1024 ? MB : 1024) * FEAT;
   if (pact > pm) pm = pact;
   w.wpart_floats = pm;
   w.wpart = take(pm);

@@ -1160,11 +1160,7 @@ static void launch_fwd3_planes(const EncCall& c, bool acting, hipStream_t st) {
 }
 
 // ================================================================================================
-#ifndef DDRL_ACT_BF16X6_MIN
-// acting launches of at least this many envs use the bf16x6 conv2 / conv3 kernels too (us per ddrl_forward, fp32-MFMA
-// narrow-tile kernels vs bf16x6: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7, 2048: 606.2 / 480.9)
-#define DDRL_ACT_BF16X6_MIN 192
-#endif
+
 #if defined(DDRL_FWD1_F32) && !defined(DDRL_WGRAD1_F32)
 #error "-DDDRL_FWD1_F32 needs -DDDRL_WGRAD1_F32: only conv_fwd1_planes_kernel writes the a1 sign mask that conv_wgrad1_planes_kernel reads"
 #endif

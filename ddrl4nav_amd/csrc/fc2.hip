@@ -406,7 +406,8 @@ struct FcFwdB {
 
 __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
                                                             const float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
-                                                            int64_t bias_off1, float* __restrict__ h, int64_t h_es, int n) {
+                                                            int64_t bias_off1, float* __restrict__ h, int64_t h_es, int n, int ne, int nsplit,
+                                                            float* __restrict__ part) {
   using K = FcFwdB;
   extern __shared__ __attribute__((aligned(16))) char ldsf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -416,7 +417,9 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
     const int lin = bx + 4 * by, xcd = lin & 7, q = lin >> 3;
     bx = q & 3, by = (q >> 2) * 8 + xcd;  // an XCD owns the batch tiles = xcd mod 8; the 4 feature tiles of one run together and share its a3 rows
   }
-  const int e = blockIdx.z, n0 = bx * 128, b0 = by * 128;
+  // nsplit > 1 (acting launches): split-K, blockIdx.z = e + ne * split, bias-free partial sums part[split][e][n][512] that
+  // heads_act adds up (the slab format of the f32-MFMA FcFwd2)
+  const int e = blockIdx.z % ne, split = blockIdx.z / ne, n0 = bx * 128, b0 = by * 128;
   const float sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: activations = 4 quads of 4 k per thread (row rr + 32 j, k4), weights = 2 x 3 fragments of 8 k
   const int k4 = tid & 7, rr = tid >> 3;
@@ -462,12 +465,12 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  constexpr int NKB = FLAT / 32;
-  fetch(0);
+  const int per = (FLAT / 32) / nsplit, kb0 = split * per, NKB = kb0 + per;  // 98 k-blocks, nsplit divides them
+  fetch(kb0);
   commit();
-  fetch(1);
+  if (kb0 + 1 < NKB) fetch(kb0 + 1);
   __syncthreads();
-  for (int kb = 0; kb < NKB; ++kb) {
+  for (int kb = kb0; kb < NKB; ++kb) {
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       frag8 a[NPL][2], b[NPL][2];
@@ -496,8 +499,8 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int nn = n0 + wc * 64 + j * 32 + l31;
-    const float bias = params[(e ? bias_off1 : bias_off0) + nn];
-    float* dst = h + e * h_es;
+    const float bias = nsplit > 1 ? 0.0f : params[(e ? bias_off1 : bias_off0) + nn];
+    float* dst = nsplit > 1 ? part + ((int64_t)split * 2 + e) * n * FEAT : h + e * h_es;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -517,14 +520,17 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
                    w.h, MB * FEAT, c.n, nsplit, w.wpart, c.L->NE};
   ProfRange pr(c.prof, nsplit > 1 ? "FcFwdSplit" : "FcFwd", st);
 #ifndef DDRL_FC_F32  // default: the bf16x6 kernel for full launches; -DDDRL_FC_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-  if (nsplit == 1) {
+  // split launches (acting) of at least DDRL_ACT_BF16X6_MIN envs run on the planes too: conv3's planes kernel has measured a3's
+  // maximum there (the f32 conv3 kernel of smaller launches does not)
+  if (nsplit == 1 || c.n >= DDRL_ACT_BF16X6_MIN) {
     static bool configured = false;
     if (!configured) {
       (void)hipFuncSetAttribute((const void*)fc_fwd_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
       configured = true;
     }
-    hipLaunchKernelGGL(fc_fwd_planes_kernel, dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE), dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT,
-                       w.wlb, w.amax, c.params, c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n);
+    hipLaunchKernelGGL(fc_fwd_planes_kernel, dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT,
+                       w.wlb, w.amax, c.params, c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n,
+                       c.L->NE, nsplit, w.wpart);
     return;
   }
 #endif

@@ -37,9 +37,14 @@ void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st);
 void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
 
 // fc2.hip (v2 engine)
+#ifndef DDRL_ACT_BF16X6_MIN
+// acting launches of at least this many envs use the bf16x6 conv2 / conv3 kernels too (us per ddrl_forward, fp32-MFMA
+// narrow-tile kernels vs bf16x6: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7, 2048: 606.2 / 480.9)
+#define DDRL_ACT_BF16X6_MIN 192
+#endif
 // Split-K factor of the FC forward for a batch of n samples (1 = plain; >1 only on the acting
 // path, where heads_act sums the partials).  7 k-blocks of 32 per split.
-inline int fc_forward_splits(int n) { return n <= 1024 ? 14 : 1; }
+inline int fc_forward_splits(int n) { return n <= 1024 ? DDRL_FC_ACT_SPLITS : 1; }
 void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st);
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int part = 0);
 
