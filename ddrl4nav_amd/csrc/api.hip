@@ -100,7 +100,10 @@ static int32_t validate(const ddrl_config* c) {
   if (!c) return DDRL_ERR_INVALID_ARG;
   if (c->max_batch < 1) return DDRL_ERR_INVALID_ARG;
   if (c->n_actions < 2 || c->n_actions > 18) return DDRL_ERR_UNSUPPORTED;  // heads kernels: A <= 18 (full Atari set)
-  if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // int_frame_stack = 4
+  if (c->in_channels < 1 || c->in_channels > 4) return DDRL_ERR_UNSUPPORTED;  // stacked frames: conv1's kernels give each of their four waves one channel
+#if defined(DDRL_FWD1_F32) || defined(DDRL_WGRAD1_F32)
+  if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // the f32-MFMA conv1 kernels (A/B builds) are written for four frames
+#endif
   if (c->share_cnn_net != 0 && c->share_cnn_net != 1) return DDRL_ERR_INVALID_ARG;
   // 32-bit element indexing inside one encoder's activation tensor
   // the kernels address a1 / da1 with 32-bit BYTE offsets from wave-uniform bases (max_batch <= 83,886)

@@ -624,7 +624,7 @@ template <int NE>
 __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
                                                                float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
                                                                int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n,
-                                                               unsigned* __restrict__ m1, int64_t m1_es) {
+                                                               unsigned* __restrict__ m1, int64_t m1_es, int C) {
   using K = Fwd1B<NE>;
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
     nrows1 = 4 * ((clast % 400) / 20) + 8;
   }
   const int nd0 = nrows0 * 21, nd_total = nd0 + nrows1 * 21;
-  const int64_t src0 = (int64_t)b0 * 28224 + iy0_start * 84, src1 = (int64_t)b1 * 28224;
+  const int64_t src0 = (int64_t)b0 * (C * 7056) + iy0_start * 84, src1 = (int64_t)b1 * (C * 7056);  // C stacked frames per sample (1..4)
   // this kernel opens every forward: it also resets the running maxima that the conv2 / conv3 epilogues raise afterwards (a
   // separate 16-byte memset is a kernel of its own: 5 of the ~100 us of an acting step)
   if (blockIdx.x == 0 && tid < (AMAX_DH - AMAX_FIRST_ACT) * 2) amax[amax_idx(AMAX_FIRST_ACT, 0) + tid] = 0.0f;
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) imreg[ch][j] = *(const unsigned*)(frames + ch * 7056 + imsrc[j]);  // unconditional, clamped
+    for (int j = 0; j < 6; ++j) imreg[ch][j] = *(const unsigned*)(frames + (ch < C ? ch : C - 1) * 7056 + imsrc[j]);  // unconditional, clamped
   // the weight planes of a channel are a plain copy of global memory: LDS-direct, one k-block ahead (L2-resident)
   const int wave = wave_u();
   uint32_t woff[K::NAJ];
@@ -701,9 +701,10 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   __syncthreads();
 #pragma unroll
   for (int ch = 0; ch < 4; ++ch) {
+    if (ch >= C) break;  // wave-uniform: fewer stacked frames = fewer k-blocks (the last one run reads stage (C - 1) & 1)
     const char* cur = ldsb + (ch & 1) * K::STAGE_BYTES;
     char* nxt = ldsb + ((ch + 1) & 1) * K::STAGE_BYTES;
-    if (ch + 1 < 4) stage_w(ch + 1, nxt);
+    if (ch + 1 < C) stage_w(ch + 1, nxt);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       frag8 b[2];
@@ -727,13 +728,13 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
           }
       }
     }
-    if (ch + 1 < 4) {
+    if (ch + 1 < C) {
       commit_img(nxt, ch + 1);
       wait_vmcnt<0>();
     }
     __syncthreads();
   }
-  float* bias = (float*)ldsb;  // stage 0 is free: the last k-block read stage 1 and every wave has passed the loop's final barrier
+  float* bias = (float*)ldsb;  // both stages are free: every wave has passed the loop's final barrier
   if (tid < K::ROWS) bias[tid] = params[(tid >> 5 ? bias_off1 : bias_off0) + (tid & 31)];
   __syncthreads();
   float r255[NE];  // 1/255 of the frame normalisation and the scale of the encoder's weight planes
@@ -784,7 +785,7 @@ static void launch_fwd1_planes(const EncCall& c, bool acting, hipStream_t st) {
   }
   hipLaunchKernelGGL(conv_fwd1_planes_kernel<NE>, dim3((unsigned)(((int64_t)c.n * 400 + 255) / 256)), dim3(256), K::LDS_BYTES, st, c.frames,
                      w.wp1b, w.amax, c.params, L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n,
-                     acting ? (unsigned*)nullptr : w.m1, m1_words(c.max_batch));
+                     acting ? (unsigned*)nullptr : w.m1, m1_words(c.max_batch), L.C);
 }
 
 // ================================================================================================

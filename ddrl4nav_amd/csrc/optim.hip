@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ pa
     const int row = i % rows1, r = i / rows1;
     const int hi = r & 1, s = (r >> 1) & 31, kb = r >> 6;
     const int e = row >> 5, oc = row & 31;
-    w.wp1[i] = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + kb) * 8 + (s >> 2)) * 8 + 2 * (s & 3) + hi];
+    // (the f32-MFMA conv1 kernels this layout feeds are A/B builds for four stacked frames; other stacks: an in-range dummy)
+    w.wp1[i] = params[L.enc_base[e] + L.enc.c1w + ((oc * L.C + (kb < L.C ? kb : L.C - 1)) * 8 + (s >> 2)) * 8 + 2 * (s & 3) + hi];
     return;
   }
   i -= n1;
@@ -96,11 +97,11 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
                                                               const float* __restrict__ amax) {
   const int rows = 32 * L.NE;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 4 * 4 * 2 * rows * 8) return;
+  if (idx >= L.C * 4 * 2 * rows * 8) return;  // [channel C][ky pair 4][plane][lane half 2][row][kx 8]
   const int j = idx & 7, row = (idx >> 3) % rows, r = (idx >> 3) / rows;
   const int h = r & 1, g = (r >> 1) & 3, c = r >> 3;
   const int e = row >> 5, oc = row & 31, ky = 2 * g + h;
-  const float w = params[L.enc_base[e] + L.enc.c1w + ((oc * 4 + c) * 8 + ky) * 8 + j];
+  const float w = params[L.enc_base[e] + L.enc.c1w + ((oc * L.C + c) * 8 + ky) * 8 + j];
   unsigned short pl[NPL];
   planes_of(w, plane_scale(amax[amax_idx(AMAX_W1, e)]), pl);
   const int base = (c * 4 + g) * NPL;
@@ -238,7 +239,7 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
   hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
   hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
-  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((4 * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
+  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
   {
     const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);

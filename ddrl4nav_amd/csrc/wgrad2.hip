@@ -963,8 +963,9 @@ struct Wgrad1B {
 template <int NE>
 __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ dz,
                                                                  const unsigned* __restrict__ m1, int64_t m1_es, int64_t dz_es,
-                                                                 const float* __restrict__ amax, float* __restrict__ part, int n, int nsplit) {
+                                                                 const float* __restrict__ amax, float* __restrict__ part, int n, int nsplit, int C) {
   using K = Wgrad1B<NE>;
+  const int fs = C * 7056;  // bytes of one sample's C stacked frames (1..4); wave wc owns the 64 taps of channel wc and idles past C
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int split = blockIdx.y;
@@ -1001,8 +1002,8 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int u = tid + 256 * k, uc = min(u, 383);
-    const int R = uc / 6, g = uc % 6, gsel = R >> 5, smp = (R >> 4) & 1, ch = (R >> 2) & 3, r = R & 3;
-    imoff[k] = (uint32_t)(smp * 28224 + ch * 7056 + (4 * gsel + r) * 84 + (g < 5 ? g * 16 : 68));  // g = 5: bytes 68..83, last dword
+    const int R = uc / 6, g = uc % 6, gsel = R >> 5, smp = (R >> 4) & 1, ch = min((R >> 2) & 3, C - 1), r = R & 3;  // missing channels re-read the last one
+    imoff[k] = (uint32_t)(smp * fs + ch * 7056 + (4 * gsel + r) * 84 + (g < 5 ? g * 16 : 68));  // g = 5: bytes 68..83, last dword
     bdst[k] = K::IMG_OFF + ((smp * 4 + ch) * 16 + r) * 192 + (g < 5 ? g * 8 : 40);              // + ring group * 4 * 192
     im_s1 |= (unsigned)smp << k;
     im_g1 |= (unsigned)gsel << k;
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
     const int64_t sb = ew * dz_es + (int64_t)pair * (2 * 12800) + oy * 20;
     const char* dzb = (const char*)(dz + sb);
     const char* mb = (const char*)(m1 + ew * m1_es + (int64_t)pair * 800 + oy * 20);
-    const char* fp = (const char*)frames + (int64_t)pair * (2 * 28224) + (oy + gfirst) * 336;
+    const char* fp = (const char*)frames + (int64_t)pair * (2 * fs) + (oy + gfirst) * 336;
     // odd batch tail: the second sample does not exist -> its slots read the first sample, commit() zeroes its dz
 #pragma unroll
     for (int j = 0; j < K::NDZ_J; ++j) {
@@ -1057,7 +1058,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
       if (DDRL_W1_KO & 4) continue;
       // wave-uniform skips: a lone group has no k = 1 units and none in wave 3 (their loads were the cost, not the conversion)
       if (!imfirst && (k == 1 || !lone_group_wave)) continue;
-      const uint32_t o = full ? imoff[k] : imoff[k] - ((im_s1 >> k) & 1u) * 28224u;
+      const uint32_t o = full ? imoff[k] : imoff[k] - ((im_s1 >> k) & 1u) * (uint32_t)fs;
       const unsigned* q = (const unsigned*)(fp + o);  // 4-byte aligned
       imr[k] = (u4w){q[0], q[1], q[2], q[3]};
     }
@@ -1157,16 +1158,21 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
     }
     __syncthreads();
   }
-  // slabs: weights (scaled by the 1/255 of the frame normalisation), then the bias partial
+  // slabs [32 oc][64 C taps] + [32] (the arena's conv1.weight, conv1.bias): weights (scaled by the 1/255 of the frame
+  // normalisation), then the bias partial
+  const int ktaps = 64 * C;
+  const int64_t slab_floats = 32 * ktaps + 32;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const float r255 = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_DZ1, i)]));
-    float* slab = part + ((int64_t)split * 2 + i) * K::SLAB;
+    float* slab = part + ((int64_t)split * 2 + i) * slab_floats;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wc * 64 + j * 32 + l31;
+      if (wc < C) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[acc_row(r, hi) * 256 + col] = acc[i][j][r] * r255;
+        for (int r = 0; r < 16; ++r) slab[acc_row(r, hi) * ktaps + col] = acc[i][j][r] * r255;
+      }
     }
   }
   float* red = (float*)ldsw;
@@ -1181,7 +1187,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
     for (int smp = 0; smp < 2; ++smp)
 #pragma unroll
       for (int q = 0; q < 5; ++q) sum += red[e * K::QPE + (smp * 32 + oc) * 5 + q];
-    part[((int64_t)split * 2 + e) * K::SLAB + 8192 + oc] = sum;
+    part[((int64_t)split * 2 + e) * slab_floats + 32 * ktaps + oc] = sum;
   }
 }
 
@@ -1195,7 +1201,7 @@ static void launch_wgrad1_planes(const EncCall& c, int S, hipStream_t st) {
     configured = true;
   }
   hipLaunchKernelGGL(conv_wgrad1_planes_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.m1, m1_words(c.max_batch),
-                     c.max_batch * 12800, w.amax, w.wpart, c.n, S);
+                     c.max_batch * 12800, w.amax, w.wpart, c.n, S, c.L->C);
 }
 
 void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
@@ -1223,7 +1229,7 @@ void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {
 #endif
   }
   ProfRange pr(c.prof, "reduce_partials", st);
-  launch_reduce_partials(w.wpart, S, ConvWgrad1v2<2>::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
+  launch_reduce_partials(w.wpart, S, (int64_t)32 * 64 * L.C + 32, L.NE, grads, L.enc_base[0] + L.enc.c1w, L.enc_base[1] + L.enc.c1w, st);
 }
 
 }  // namespace ddrl

@@ -16,7 +16,7 @@
  *   - one caller thread per context.
  *
  * Layouts (C-contiguous):
- *   frames   uint8  [n, C=4, 84, 84]   stacked frames exactly as the env wrapper emits them
+ *   frames   uint8  [n, C, 84, 84]     C = in_channels (1..4) stacked frames exactly as the env wrapper emits them
  *                                      before the /255.0 (reference warputils.py:274-301);
  *                                      the kernels apply float32(u8/255.0) themselves.
  *   params / grads / adam_m / adam_v   float32 flat arenas in the reference's
@@ -55,7 +55,7 @@ typedef struct ddrl_comm ddrl_comm;
 /* Hyper-parameters: the ConfigNN contract (USTC_lab/config/config_nn.py:19-57). */
 typedef struct ddrl_config {
   int32_t n_actions;      /* ACTION_OUTPUT_DIM, 6 for Pong                       */
-  int32_t in_channels;    /* int_frame_stack, 4                                   */
+  int32_t in_channels;    /* int_frame_stack: 1..4 (atari.yaml: 4)                */
   int32_t max_batch;      /* largest n / B any call will pass (sizes workspace);
                              1 .. 83,886 (32-bit byte offsets into the conv1 activations);
                              larger global batches: shard, or pass B_global to ddrl_ppo_iter */

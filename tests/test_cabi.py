@@ -49,7 +49,7 @@ def test_load_and_host_only_calls():
 def test_unsupported_configs_fail_loudly():
     lib = _lib.load()
     wb = ctypes.c_int64()
-    for bad in (dict(n_actions=19), dict(in_channels=3)):
+    for bad in (dict(n_actions=19), dict(in_channels=5), dict(in_channels=0)):
         cfg = _lib.default_config(max_batch=64, **bad)
         assert lib.ddrl_workspace_bytes(ctypes.byref(cfg), ctypes.byref(wb)) == -2
     cfg = _lib.default_config(max_batch=64, share_cnn_net=2)

@@ -901,3 +901,59 @@ def test_action_counts_vs_oracle(A):
         want_g = p.grad.numpy()
         assert np.abs(got[name] - want_g).max() <= 5e-5 * np.abs(want_g).max() + 1e-12, (name, A)
     h.close()
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_other_frame_stacks_golden_f20(golden, C):
+    """AtariPreNet with 1 / 3 stacked frames (reference nn/atari_encoder.py:12-14 takes `num_inputs`; golden F20 =
+    the reference's own forward and three PPO iterations, tests/golden/make_golden_channels.py): forward, losses and the whole
+    gradient of the first iteration against the oracle (itself pinned to F20 in tests/test_oracle_golden.py), losses of
+    iterations 2 and 3, parameter checksums after the third."""
+    from ddrl4nav_amd.engine import HotPath
+    g = golden("f20_channels")
+    p = "c%d/" % C
+    w = make_weights(seed=20 + C, num_inputs=C)
+    h = HotPath(max_batch=16, in_channels=C)
+    try:
+        h.set_params(flatten(w, num_inputs=C))
+        frames, acts = dev(g[p + "frames"]), dev(g[p + "actions"])
+        probs, value, _, logp = h.forward(frames, act=acts)
+        np.testing.assert_allclose(probs.cpu().numpy(), g[p + "probs"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(value.cpu().numpy(), g[p + "value"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(logp.cpu().numpy(), g[p + "logp"], rtol=1e-5, atol=1e-6)
+        old, advs, rets = dev(g[p + "old_logps"]), dev(g[p + "advs"]), dev(g[p + "rets"])
+        # gradient of iteration 1 against the oracle's autograd
+        net = O.OraclePPO(num_inputs=C)
+        net.load_weights(w)
+        x = O.frames_to_f32(g[p + "frames"])
+        t = lambda k: torch.from_numpy(g[p + k])
+        _, al, vl, _ = O.ppo_losses(net, x, t("actions"), t("old_logps"), t("advs"), t("rets"))
+        al.backward()
+        vl.backward()
+        h.ppo_iter(frames, acts, old, advs, rets)
+        flat = h.grads[:h.n_params].cpu().numpy()
+        off = 0
+        for name, q in net.named_parameters():
+            want = q.grad.numpy()
+            got = flat[off:off + want.size].reshape(want.shape)
+            off += want.size
+            scale = np.abs(want).max()
+            assert np.abs(got - want).max() <= 2e-5 * scale, (name, np.abs(got - want).max(), scale)
+        assert off == h.n_params
+        # three iterations: losses against the reference's (the same batch every iteration, as PPO.learn does)
+        for it in range(3):
+            if it:
+                h.ppo_iter(frames, acts, old, advs, rets)
+            h.clip_adam_step()
+            s = h.stats()
+            got = [s["PpoTotalLoss"], s["ActorLoss"], s["VLoss"], s["EntLoss"]]
+            np.testing.assert_allclose(got, g[p + "losses"][it], rtol=2e-5 * (1 + 4 * it), atol=2e-6 * (1 + 4 * it))
+        flat = h.params.cpu().numpy().astype(np.float64)
+        off = 0
+        for name, shape, _ in param_specs(C):
+            n = int(np.prod(shape))
+            a = flat[off:off + n]
+            off += n
+            np.testing.assert_allclose(np.sqrt((a ** 2).sum()), g[p + "it3/l2/" + name], rtol=2e-5)
+    finally:
+        h.close()

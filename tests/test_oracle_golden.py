@@ -276,6 +276,33 @@ def test_wide_spread_fixture_is_the_reference_under_other_batch_orders(golden):
             np.testing.assert_allclose(w[k], P._load("f4b_spread_default")[k], rtol=1e-12)
 
 
+@pytest.mark.parametrize("C", [1, 3])
+def test_oracle_other_frame_stacks_golden_f20(golden, C):
+    """The oracle with `num_inputs` = 1 / 3 against the reference's own AtariPreNet(num_inputs) net (F20,
+    tests/golden/make_golden_channels.py): forward bit-exact, three learn iterations to 1e-6."""
+    g = golden("f20_channels")
+    p = "c%d/" % C
+    net = O.OraclePPO(num_inputs=C)
+    net.load_weights(make_weights(seed=20 + C, num_inputs=C))
+    x = O.frames_to_f32(g[p + "frames"])
+    t = lambda k: torch.from_numpy(g[p + k])
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        with torch.no_grad():
+            probs, p_hat, logits, v = net(x)
+        assert np.array_equal(probs.numpy(), g[p + "probs"]) and np.array_equal(v.numpy()[:, 0], g[p + "value"])
+        assert np.array_equal(O.categorical_log_prob(logits, t("actions")).numpy(), g[p + "logp"])
+        got = [[ld[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")]
+               for ld, _, _ in O.learn(net, net.make_optims(), x, t("actions"), t("old_logps"), t("advs"), t("rets"), iters=3)]
+    finally:
+        torch.set_num_threads(threads)
+    np.testing.assert_allclose(np.asarray(got), g[p + "losses"], rtol=2e-6, atol=2e-7)
+    for name, q in net.named_parameters():
+        a = q.detach().double().numpy()
+        np.testing.assert_allclose(np.sqrt((a ** 2).sum()), g[p + "it3/l2/" + name], rtol=1e-6)
+
+
 def _gail_case(name, golden):
     from oracle import ddrl_oracle_gail as G
     from oracle import ddrl_oracle_nav as N
