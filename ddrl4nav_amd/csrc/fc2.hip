@@ -404,6 +404,7 @@ struct FcFwdB {
   static constexpr int PITCH = 80, PLANE = 128 * PITCH, B_OFF = NPL * PLANE, LDS_BYTES = 2 * NPL * PLANE;
 };
 
+template <bool SPLIT>  // SPLIT: acting launches, split-K with run-time k-block ranges; training launches keep compile-time loop bounds
 __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
                                                             const float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
                                                             int64_t bias_off1, float* __restrict__ h, int64_t h_es, int n, int ne, int nsplit,
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
   }
   // nsplit > 1 (acting launches): split-K, blockIdx.z = e + ne * split, bias-free partial sums part[split][e][n][512] that
   // heads_act adds up (the slab format of the f32-MFMA FcFwd2)
-  const int e = blockIdx.z % ne, split = blockIdx.z / ne, n0 = bx * 128, b0 = by * 128;
+  const int e = SPLIT ? (int)blockIdx.z % ne : (int)blockIdx.z, split = SPLIT ? (int)blockIdx.z / ne : 0, n0 = bx * 128, b0 = by * 128;
   const float sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: activations = 4 quads of 4 k per thread (row rr + 32 j, k4), weights = 2 x 3 fragments of 8 k
   const int k4 = tid & 7, rr = tid >> 3;
@@ -447,8 +448,8 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) {
       const f4 v = ar[j];
       unsigned pa[NPL], pb[NPL];
-      split_planes(v.x, v.y, sa, pa);
-      split_planes(v.z, v.w, sa, pb);
+      split_planes_c(v.x, v.y, sa, pa);
+      split_planes_c(v.z, v.w, sa, pb);
       char* d = ldsf + (rr + 32 * j) * K::PITCH + k4 * 8;
 #pragma unroll
       for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int per = (FLAT / 32) / nsplit, kb0 = split * per, NKB = kb0 + per;  // 98 k-blocks, nsplit divides them
+  const int per = SPLIT ? (FLAT / 32) / nsplit : FLAT / 32, kb0 = SPLIT ? split * per : 0, NKB = kb0 + per;  // 98 k-blocks, nsplit divides them
   fetch(kb0);
   commit();
   if (kb0 + 1 < NKB) fetch(kb0 + 1);
@@ -499,8 +500,8 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int nn = n0 + wc * 64 + j * 32 + l31;
-    const float bias = nsplit > 1 ? 0.0f : params[(e ? bias_off1 : bias_off0) + nn];
-    float* dst = nsplit > 1 ? part + ((int64_t)split * 2 + e) * n * FEAT : h + e * h_es;
+    const float bias = SPLIT ? 0.0f : params[(e ? bias_off1 : bias_off0) + nn];
+    float* dst = SPLIT ? part + ((int64_t)split * 2 + e) * n * FEAT : h + e * h_es;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -525,12 +526,17 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   if (nsplit == 1 || c.n >= DDRL_ACT_BF16X6_MIN) {
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)fc_fwd_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)fc_fwd_planes_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)fc_fwd_planes_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
       configured = true;
     }
-    hipLaunchKernelGGL(fc_fwd_planes_kernel, dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT,
-                       w.wlb, w.amax, c.params, c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n,
-                       c.L->NE, nsplit, w.wpart);
+    const dim3 grid(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit);
+    if (nsplit > 1)
+      hipLaunchKernelGGL(fc_fwd_planes_kernel<true>, grid, dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT, w.wlb, w.amax, c.params,
+                         c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, nsplit, w.wpart);
+    else
+      hipLaunchKernelGGL(fc_fwd_planes_kernel<false>, grid, dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT, w.wlb, w.amax, c.params,
+                         c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, 1, w.wpart);
     return;
   }
 #endif
@@ -600,8 +606,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
     for (int j = 0; j < K::ARJ; ++j) {
       const f4 v = ar[j];
       unsigned pa[NPL], pb[NPL];
-      split_planes(v.x, v.y, sa, pa);
-      split_planes(v.z, v.w, sa, pb);
+      split_planes_c(v.x, v.y, sa, pa);
+      split_planes_c(v.z, v.w, sa, pb);
       char* d = ldsg + (rr + K::AROWS * j) * K::PITCH + n4 * 8;
 #pragma unroll
       for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
       if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
         unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
+        for (int c = 0; c < 4; ++c) split_planes_c(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
         char* d = ldsw2 + awr[t];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::A_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
       if (t + 1 < K::NBU || tid + 256 * t < K::B_UNITS) {
         unsigned pl[4][NPL];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes(br[t][2 * c], br[t][2 * c + 1], sa, pl[c]);
+        for (int c = 0; c < 4; ++c) split_planes_c(br[t][2 * c], br[t][2 * c + 1], sa, pl[c]);
         char* d = ldsw2 + bwr[t];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::B_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
