@@ -1944,6 +1944,135 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   amax_update(big, amax + amax_idx(AMAX_DZ1, e));  // da1 before the leaky mask: an upper bound of what conv1's weight gradient stages
 }
+// ------------------------------------------------------------------------------------------------
+// The same data gradient with ONE workgroup per tile for BOTH row parities (-DDDRL_D2_BOTH=1): eight waves, rows = (a, c, ic) = 128
+// (four 32-row fragment tiles), wave w = columns 64 w .. 64 w + 63 (4 x 2 fragment tiles: the same LDS bytes per MFMA), dz2
+// staged ONCE per tile instead of once per parity (the knock-outs put that staging at a third of the two-workgroup kernel).
+// ------------------------------------------------------------------------------------------------
+struct Dgrad2Both {
+  static constexpr int SPT = 5, THREADS = 512, TN = 2;
+  static constexpr int IMG_PLANE = SPT * 121 * 16;                      // 9,680 B
+  static constexpr int W_HALF = 2 * NPL * 64 * 32;                      // one parity's k-block of weights (8 KB)
+  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 2 * W_HALF;
+  static constexpr int NIU = SPT * 81;                                  // 405 pixel units (8 oc each): threads 0 .. 404
+  static constexpr int NWQ = W_BYTES / 16, NWJ = NWQ / THREADS;         // 1,024 weight quads -> 2 per thread
+  static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad2_both_kernel(
+    const float* __restrict__ dz2, int64_t dz_es, const unsigned short* __restrict__ wd2b, float* __restrict__ amax, float* __restrict__ out,
+    int64_t out_es, int n) {
+  using K = Dgrad2Both;
+  extern __shared__ __attribute__((aligned(16))) char ldsd2[];
+  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int e = blockIdx.y, b0 = blockIdx.x * K::SPT;
+  const float sa = plane_scale(amax[amax_idx(AMAX_DZ2, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W2, e)]));
+  for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd2 + i * 16) = zero4();  // images incl. their zero borders
+  // ---- staging maps.  unit u = tid: sample u / 81, pixel u % 81 -> 8 loads of stride 81 (the k-block's 8 oc)
+  const int u = min(tid, K::NIU - 1);
+  const float* isrc = dz2 + e * dz_es + (int64_t)min(b0 + u / 81, n - 1) * 5184 + u % 81;  // + (8 kb + c) * 81
+  const int idst = ((u / 81) * 121 + ((u % 81) / 9 + 1) * 11 + (u % 81) % 9 + 1) * 16;
+  // weight quad q = tid + 512 j of the two parities' k-blocks (W_HALF bytes each, one after the other in LDS)
+  const unsigned short* wsrc[K::NWJ];
+#pragma unroll
+  for (int j = 0; j < K::NWJ; ++j) {
+    const int q = tid + K::THREADS * j, par = q / (K::W_HALF / 16), qh = q % (K::W_HALF / 16);
+    wsrc[j] = wd2b + (int64_t)(e * 2 + par) * (8 * 2 * NPL * 64 * 16) + qh * 8;  // + kb * 2 * NPL * 1024
+  }
+  // ---- operand bases: row tile i = 2 a + c
+  int aA[4], bB[K::TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aA[i] = K::W_OFF + (i >> 1) * K::W_HALF + ((i & 1) * 32 + l31) * 32 + hi * 16;
+#pragma unroll
+  for (int j = 0; j < K::TN; ++j) {
+    int c = wc * (32 * K::TN) + j * 32 + l31;
+    if (c >= K::SPT * 100) c = 0;
+    const int s = c / 100, pq = c % 100;
+    bB[j] = (s * 121 + (pq / 10 + 1) * 11 + (pq % 10 + 1) - hi) * 16;  // pixel (p, q - v) of the padded image, v = lane half
+  }
+  float ir[8];
+  f4 wr[K::NWJ];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ir[c] = isrc[(kb * 8 + c) * 81];
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j) wr[j] = *(const f4*)(wsrc[j] + kb * (2 * NPL * 1024));
+  };
+  auto commit = [&]() {
+    if (tid < K::NIU) {
+      unsigned pl[4][NPL];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split_planes(ir[2 * c], ir[2 * c + 1], sa, pl[c]);
+      char* d = ldsd2 + idst;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+    }
+#pragma unroll
+    for (int j = 0; j < K::NWJ; ++j) *(f4*)(ldsd2 + K::W_OFF + (tid + K::THREADS * j) * 16) = wr[j];
+  };
+  f32x16 acc[4][K::TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < K::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  constexpr int NKB = 8;
+  fetch(0);
+  __syncthreads();  // zero fill complete
+  commit();
+  fetch(1);
+  __syncthreads();
+  for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {  // kg = u
+      frag8 af[NPL][4], bfr[NPL][K::TN];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[p][i] = *(const frag8*)(ldsd2 + aA[i] + (kg * NPL + p) * 2048);
+#pragma unroll
+        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const frag8*)(ldsd2 + bB[j] + p * K::IMG_PLANE - kg * (11 * 16));
+      }
+      DDRL_PLANE_PRODUCTS;
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < K::TN; ++j) acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
+    }
+    __syncthreads();  // every wave is done with the stage
+    if (kb + 1 < NKB) {
+      commit();
+      if (kb + 2 < NKB) fetch(kb + 2);
+    }
+    __syncthreads();
+  }
+  // row tiles (2 a, 2 a + 1) = the two column parities of row parity a: horizontally adjacent pixels -> one 8-byte store
+  float big = 0.0f;
+#pragma unroll
+  for (int j = 0; j < K::TN; ++j) {
+    const int c = wc * (32 * K::TN) + j * 32 + l31;
+    const int s = c / 100, pq = c % 100;
+    if (c >= K::SPT * 100 || b0 + s >= n) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float* base = out + e * out_es + (int64_t)(b0 + s) * 12800 + (2 * (pq / 10) + a) * 20 + 2 * (pq % 10);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float g0 = acc[2 * a][j][r] * inv, g1 = acc[2 * a + 1][j][r] * inv;
+        *(float2*)(base + acc_row(r, hi) * 400) = make_float2(g0, g1);
+        big = fmaxf(big, fmaxf(fabsf(g0), fabsf(g1)));
+      }
+    }
+  }
+  amax_update(big, amax + amax_idx(AMAX_DZ1, e));  // da1 before the leaky mask: an upper bound of what conv1's weight gradient stages
+}
+
+#ifndef DDRL_D2_BOTH
+#define DDRL_D2_BOTH 1
+#endif
 static void launch_dgrad2_planes(const EncCall& c, hipStream_t st) {
   using K = Dgrad2B;
   const Workspace& w = *c.ws;
@@ -1952,6 +2081,16 @@ static void launch_dgrad2_planes(const EncCall& c, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_dgrad2_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
+#if DDRL_D2_BOTH
+  static bool configured_b = false;
+  if (!configured_b) {
+    (void)hipFuncSetAttribute((const void*)conv_dgrad2_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dgrad2Both::LDS_BYTES);
+    configured_b = true;
+  }
+  hipLaunchKernelGGL(conv_dgrad2_both_kernel, dim3((unsigned)((c.n + Dgrad2Both::SPT - 1) / Dgrad2Both::SPT), (unsigned)c.L->NE, 1),
+                     dim3(Dgrad2Both::THREADS), Dgrad2Both::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.amax, w.dz1, c.max_batch * 12800, c.n);
+  return;
+#endif
   const unsigned tiles8 = (unsigned)(((c.n + K::SPT - 1) / K::SPT + 7) / 8 * 8);
   hipLaunchKernelGGL(conv_dgrad2_planes_kernel, dim3(tiles8 * 2, (unsigned)c.L->NE, 1), dim3(K::THREADS),
                      K::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.amax, w.dz1, c.max_batch * 12800, c.n);
