@@ -1373,6 +1373,9 @@ __global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(c
 // not) and still wins: 192 instead of 512 matrix-pipe cycles per 16 k.
 // Weights: wd3b[e][k-block 4][tap 9][plane][ic 64][oc half 2][oc 8] (optim.hip).
 // ================================================================================================
+#ifndef DDRL_D3B_THREADS
+#define DDRL_D3B_THREADS 256  // 512 (eight waves, 6 samples share one copy of the weights): 2.52 vs 2.43 ms -- unlike conv2's data gradient
+#endif
 #ifndef DDRL_D3B_TN
 #define DDRL_D3B_TN 2  // 2 x 2 fragment tiles, 3 samples per tile: 4.19 vs 4.27 ms for 2 x 4 / 6 samples (re-measured under f16 planes: 2.54 vs 2.60)
 #endif
@@ -1380,7 +1383,9 @@ struct Dgrad3B {
   // one MFMA k-group = ONE tap x 16 oc (lane half h = oc 8 h .. 8 h + 7): nine k-groups per k-block of 16 oc, no padded tenth tap
   // (tap pairs x 8 oc walked ten: executed / algorithmic 1.84 -> 1.65), the tap shift is a compile-time LDS offset, four k-blocks
   // instead of eight.  Weights: wd3b[e][k-block 4][tap 9][plane NPL][ic 64][oc half 2][oc 8] (optim.hip pack_dgrad3_bf16_kernel).
-  static constexpr int THREADS = 256, TN = DDRL_D3B_TN, SPT = (128 * TN) / 81;  // column tiles per wave, whole samples per tile
+  // four waves / 3 samples per workgroup, two workgroups per CU.  (-DDDRL_D3B_THREADS=512: eight waves / 6 samples share one copy of
+  // the k-block's 37 KB of weights, one workgroup per CU: measured slower.)
+  static constexpr int THREADS = DDRL_D3B_THREADS, TN = DDRL_D3B_TN, SPT = ((THREADS / 64) * 32 * TN) / 81;  // column tiles per wave, whole samples per tile
   static constexpr int KOC = 16, NKB = 64 / KOC, PIXB = 2 * KOC;  // oc per k-block, k-blocks, bytes per pixel and plane
   static constexpr int IMG_PLANE = SPT * 121 * PIXB;              // 11,616 B
   static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 9 * NPL * 64 * 32;
@@ -1389,7 +1394,7 @@ struct Dgrad3B {
   static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad3_planes_kernel(
+__global__ __launch_bounds__(Dgrad3B::THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad3_planes_kernel(
     const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3b, float* __restrict__ amax, const unsigned* __restrict__ m2,
     float* __restrict__ out, int64_t out_es, int n) {
   using K = Dgrad3B;
@@ -1408,7 +1413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     isrc[j] = dz3 + e * dz_es + (int64_t)min(b0 + s, n - 1) * FLAT + px;  // + (16 kb + c) * 49
     idst[j] = (s * 121 + (px / 7 + 2) * 11 + px % 7 + 2) * K::PIXB;
   }
-  const unsigned short* wsrc = wd3b + (int64_t)e * (K::NKB * 9 * NPL * 64 * 16) + tid * 8;  // + kb * 9 * NPL * 1024 + j * 2048
+  const unsigned short* wsrc = wd3b + (int64_t)e * (K::NKB * 9 * NPL * 64 * 16) + tid * 8;  // + kb * 9 * NPL * 1024 + j * THREADS * 8
   // ---- operand bases
   int aA[2], bB[K::TN];
 #pragma unroll
@@ -1429,7 +1434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int c = 0; c < K::KOC; ++c) ir[j][c] = isrc[j][(kb * K::KOC + c) * 49];
 #pragma unroll
     for (int j = 0; j < K::NWJ; ++j)
-      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * (9 * NPL * 1024) + j * 2048);
+      if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + kb * (9 * NPL * 1024) + j * (K::THREADS * 8));
   };
   auto commit = [&]() {
 #pragma unroll
