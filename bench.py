@@ -248,7 +248,7 @@ def pmc_traffic(kernel):
     # names in the PMC summaries follow the device functions (tools/pmc_to_profiles.py), bench names the launch sites
     alias = {"ConvFwd1": "conv_fwd1_planes", "ConvWgrad1": "conv_wgrad1_planes", "ConvFwd2": "conv_fwd2_planes",
              "ConvFwd3": "conv_fwd3_planes", "FcFwd": "fc_fwd_planes", "FcDgrad": "fc_dgrad_planes", "FcWgrad": "fc_wgrad_planes",
-             "ConvDgrad3": "conv_dgrad3_planes", "ConvDgrad2": "conv_dgrad2_planes", "ConvWgrad3": "conv_wgrad3_planes",
+             "ConvDgrad3": "conv_dgrad3_planes", "ConvDgrad2": "conv_dgrad2_both", "ConvWgrad3": "conv_wgrad3_planes",
              "ConvWgrad2": "conv_wgrad2_planes"}
     try:
         ks = json.load(open(files[-1]))["kernels"]
