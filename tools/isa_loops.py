@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Instruction mix of the loops of a kernel in a hipcc -S listing (device assembly): for every backward branch, the
 instruction classes between its target label and the branch.  Shows what a k loop issues per matrix instruction.
-usage: python tools/isa_loops.py file.s kernel_name_substring"""
+usage: python tools/isa_loops.py file.s kernel_name_substring
+Produce file.s with the Makefile's flags, INCLUDING  -Xclang -target-feature -Xclang -load-store-opt  (hipcc -S --cuda-device-only):
+the "not a recognized feature" warning of a normal build comes from the HOST pass; the device pass honours it (no ds_read2 merging)."""
 import re
 import sys
 from collections import Counter
