@@ -8,13 +8,13 @@ echo "hwmon nodes: $(echo $NODES | wc -w)  power1_cap_uW=$(cat $(echo $NODES | c
 python3 "$(dirname "$0")/../bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-async > /tmp/sample_hwmon_bench.json 2>/dev/null &
 BP=$!
 sleep 0.5
-for i in $(seq 1 160); do
+for i in $(seq 1 700); do
   best=0; line=""
   for H in $NODES; do
     p=$(cat $H/power1_input 2>/dev/null || echo 0)
     if [ "$p" -gt "$best" ]; then best=$p; line="power_uW=$p sclk_Hz=$(cat $H/freq1_input 2>/dev/null) tj_mC=$(cat $H/temp2_input 2>/dev/null) node=$(basename $H)"; fi
   done
   echo "$i $line"
-  sleep 0.03
+  sleep 0.02
 done
 wait $BP
