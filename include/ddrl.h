@@ -177,7 +177,10 @@ int32_t ddrl_u8_table(float* out256, void* stream);
 
 /* Diagnostic view into the workspace, for parity tests of intermediate tensors:
  * which = 0 a1, 1 a2, 2 a3, 3 h, 4 dz1, 5 dz2, 6 dz3, 7 dh (all [e][max_batch][...], e stride
- * returned in floats), 8 dlogits [B,A], 9 dvalue [B]. */
+ * returned in floats), 8 dlogits [B,A], 9 dvalue [B]; 10 / 11 / 12: the sign masks of a1 / a2 / a3 that
+ * the forward writes for the backward's leaky-ReLU decisions (32-bit words behind the float pointer,
+ * bit set = activation not positive; m1 [e][max_batch * 400 columns], bit per output channel;
+ * m2 [e][max_batch][81 pixels][2], m3 [e][max_batch][49 pixels][2], bit per channel of a lane half). */
 int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* enc_stride);
 
 /* ---- pinned-host ring: replaces the Redis LPUSH/BRPOP shuttle of frames between env workers

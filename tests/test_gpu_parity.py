@@ -957,3 +957,41 @@ def test_other_frame_stacks_golden_f20(golden, C):
             np.testing.assert_allclose(np.sqrt((a ** 2).sum()), g[p + "it3/l2/" + name], rtol=2e-5)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("n", [5, 37, 300])
+def test_sign_masks_equal_the_signs_of_the_stored_activations(n):
+    """The backward takes its leaky-ReLU decisions from sign masks the forward epilogues write: every bit of
+    m1 / m2 / m3 must say `activation <= 0` of the STORED a1 / a2 / a3 -- the reference's `act > 0` -- in the layouts of
+    csrc/common.h (m1: word per column, bit m1_bit(oc); m2 / m3: word per (sample, pixel, lane half), bit 16 i + 15 - r for
+    channel 32 i + acc_row(r, half))."""
+    from ddrl4nav_amd.engine import HotPath
+    h = HotPath(max_batch=max(n, 8))
+    try:
+        h.set_params(flatten(make_weights(0)))
+        rng = np.random.default_rng(100 + n)
+        frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+        frames[0] = 87   # flat samples: many activations on the leaky branch
+        frames[n - 1, :, :, :40] = 0
+        B = n
+        f32 = lambda a: dev(np.asarray(a, np.float32))
+        h.ppo_iter(dev(frames), f32(rng.integers(0, 6, size=B)), f32(np.full(B, -1.79)), f32(rng.normal(size=B)), f32(rng.normal(size=B)))
+        words = lambda which, per, e: h.debug_buffer(which, (per,), n, e).view(torch.int32).cpu().numpy().astype(np.uint32)
+        acc_row = lambda r, hi: (r & 3) + 8 * (r >> 2) + 4 * hi
+        for e in range(2):
+            a1 = h.debug_buffer(0, (32, 400), n, e).cpu().numpy()
+            m1 = words(10, 400, e).reshape(n, 400)
+            for oc in range(32):
+                bit = ((oc >> 2) & 1) * 16 + 15 - ((oc & 3) + 4 * (oc >> 3))
+                assert np.array_equal(((m1 >> bit) & 1).astype(bool), a1[:, oc, :] <= 0), ("m1", e, oc)
+            for which, am, ch_pix in ((11, 1, 81), (12, 2, 49)):
+                act = h.debug_buffer(am, (64, ch_pix), n, e).cpu().numpy()
+                m = words(which, ch_pix * 2, e).reshape(n, ch_pix, 2)
+                for i in range(2):
+                    for half in range(2):
+                        for r in range(16):
+                            ch = 32 * i + acc_row(r, half)
+                            got = ((m[:, :, half] >> (16 * i + 15 - r)) & 1).astype(bool)
+                            assert np.array_equal(got, act[:, ch, :] <= 0), ("m%d" % (which - 9), e, ch)
+    finally:
+        h.close()
