@@ -11,6 +11,7 @@ import torch
 
 from ddrl4nav_amd.agent.agent import gae_device
 from ddrl4nav_amd.data import Experience
+from ddrl4nav_amd.utils.staging import copy_into
 
 
 class DeviceRollout:
@@ -38,7 +39,7 @@ class DeviceRollout:
     # ---- ingest ---------------------------------------------------------------------------------
     def put_frames(self, t, frames):
         """Device (or pinned host) uint8 frames [N,C,84,84] -> pool slot t."""
-        self.frames[t].copy_(frames, non_blocking=True)
+        copy_into(self.frames[t], frames)
 
     def put_frames_from_ring(self, t, ring):
         """hipMemcpyAsync from the pinned ring on the copy stream; the compute stream waits on it."""
@@ -58,8 +59,8 @@ class DeviceRollout:
                         value=self.values[self.T], action=self._scratch_a, logp=self._scratch_l)
 
     def record(self, t, rewards, dones):
-        self.rewards[t].copy_(rewards, non_blocking=True)
-        self.dones[t].copy_(dones, non_blocking=True)
+        copy_into(self.rewards[t], rewards)
+        copy_into(self.dones[t], dones)
 
     # ---- GAE + learner batch ----------------------------------------------------------------------
     def finish(self):
@@ -105,7 +106,7 @@ class StateRollout:
     def put_states(self, t, states):
         """Device or pinned-host tensors, one per observation component -> pool slot t."""
         for pool, s in zip(self.states, states):
-            pool[t].copy_(torch.as_tensor(s).reshape(pool[t].shape), non_blocking=True)
+            copy_into(pool[t], torch.as_tensor(s).reshape(pool[t].shape))
 
     def put_state_from_ring(self, t, index, ring):
         """Component `index` of slot t from a pinned ring (raw fp32 bytes), on the copy stream."""
@@ -125,8 +126,8 @@ class StateRollout:
         self.values[self.T].copy_(values[0][:, 0])
 
     def record(self, t, rewards, dones):
-        self.rewards[t].copy_(rewards, non_blocking=True)
-        self.dones[t].copy_(dones, non_blocking=True)
+        copy_into(self.rewards[t], rewards)
+        copy_into(self.dones[t], dones)
 
     def finish(self):
         gae_device(self.values, self.rewards, self.dones, self.gamma, self.landa, adv=self.adv, ret=self.ret)

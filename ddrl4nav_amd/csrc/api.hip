@@ -335,7 +335,7 @@ int32_t ddrl_u8_table(float* out256, void* stream) {
 }
 
 // Diagnostic views into the workspace (tests): which = 0 a1,1 a2,2 a3,3 h,4 dz1,5 dz2,6 dz3,7 dh,
-// 8 dlogits, 9 dvalue, 10 / 11 / 12 the sign masks m1 / m2 / m3.  Returns the device pointer and the encoder stride in floats (words).
+// 8 dlogits, 9 dvalue, 10 / 11 / 12 the sign masks m1 / m2 / m3, 13 the per-sample scales of 4..7.  Returns the device pointer and the encoder stride in floats (words).
 int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* enc_stride) {
   if (!ctx || !ptr || !enc_stride) return DDRL_ERR_INVALID_ARG;
   const int64_t MB = ctx->cfg.max_batch;
@@ -355,6 +355,10 @@ int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* en
     case 10: *ptr = (float*)w.m1; *enc_stride = m1_words(MB); break;
     case 11: *ptr = (float*)w.m2; *enc_stride = MB * 81 * 2; break;
     case 12: *ptr = (float*)w.m3; *enc_stride = MB * 49 * 2; break;
+    // per-sample scale g_s of the normalised backward (common.h Workspace::gsc): buffers 4..7 hold g_s^-1 x the true gradients
+    case 13: *ptr = w.gsc; *enc_stride = MB; break;
+    // running maxima / bounds behind the plane scales, amax[slot][encoder] (common.h AMAX_*): enc_stride = 1, slot stride = 2
+    case 14: *ptr = w.amax; *enc_stride = 1; break;
     default: return DDRL_ERR_INVALID_ARG;
   }
   return DDRL_OK;

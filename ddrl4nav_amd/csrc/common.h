@@ -106,6 +106,11 @@ struct Workspace {
   // 16 i + 15 - r as above (channel = i * 32 + acc_row(r, hi))
   unsigned* m3;
   float *dz1, *dz2, *dz3, *dh;
+  // per-sample power-of-two scale of the backward, [e][max_batch]: the data-gradient chain runs on NORMALISED gradients
+  // (dh / dz3 / dz2 / dz1 hold g_s^-1 x the true per-sample gradient, g_s = 2^floor(log2 max|dh_s|), written by dh_normalise_kernel in
+  // encoder.hip), so that every sample keeps the full 22 bits of the fp16 planes whatever its advantage; the weight-gradient
+  // kernels multiply g_s back in while they stage a sample (exact: a power of two)
+  float* gsc;
   float* dlogits;  // [max_batch][A] (diagnostics / tests)
   float* dvalue;   // [max_batch]
   float* wpart;    // split-K partial slabs for the weight gradients
@@ -121,7 +126,16 @@ struct Workspace {
 // forward (ddrl_forward, ddrl_ppo_iter, ddrl_encoder_forward) and raised by the conv epilogues (atomic max); the gradient
 // slots are zeroed by launch_encoder_backward, which measures dh and lets the data-gradient epilogues raise dz3 / dz2.
 constexpr int AMAX_WL = 0, AMAX_W2 = 1, AMAX_W3 = 2, AMAX_W1 = 3, AMAX_A1 = 4, AMAX_A2 = 5, AMAX_A3 = 6, AMAX_DH = 7, AMAX_DZ3 = 8,
-              AMAX_DZ2 = 9, AMAX_DZ1 = 10, AMAX_SLOTS = 11, AMAX_FIRST_ACT = AMAX_A2;
+              AMAX_DZ2 = 9, AMAX_DZ1 = 10, AMAX_GMAX = 11, AMAX_SLOTS = 12, AMAX_FIRST_ACT = AMAX_A2;
+// The gradient slots hold the maxima of the NORMALISED tensors (Workspace::gsc); AMAX_GMAX = the largest per-sample scale g_s of
+// the batch: a weight gradient stages sample s with the factor  plane_scale(slot) x g_s / g_max  (<= plane_scale(slot): no
+// overflow) and multiplies its sums by g_max / (the two plane scales).
+// A weight gradient stages sample s at  plane_scale(normalised maximum) x g_s / g_max: the batch's largest RAW element lands at
+// or below [2^12, 2^13) -- below when the sample with the largest g_s is not the one with the largest normalised gradient (a few
+// binades at most).  Two of the three spare binades under fp16's 65,504 go back into the scale (top < 2^15), so that the
+// absolute error floor of the planes (2^-25 of their unit) does not rise against the per-tensor scheme.
+constexpr float WGRAD_HEADROOM = 4.0f;
+constexpr int GSC_EXP_MIN = -60, GSC_EXP_MAX = 60;  // clamp of log2 g_s: keeps plane_scale / g_max and g_max / scales inside fp32
 // AMAX_A1 is not measured: pixels / 255 lie in [0, 1], so |a1[oc]| <= sum_k |w1[oc][k]| + |b1[oc]|; pack_weights stores the largest
 // such bound with the weight slots (a few times the measured maximum: two of the sixteen spare binades of the fp16 planes),
 // which spares conv1's epilogue a maximum per output and an atomic per wave
@@ -203,6 +217,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.dz2 = take(2 * MB * 64 * 81);
   w.dz3 = take(2 * MB * FLAT);
   w.dh = take(2 * MB * FEAT);
+  w.gsc = take(2 * MB);
   w.dlogits = take(MB * A);
   w.dvalue = take(MB);
   Splits s = choose_splits(c.max_batch, c.share_cnn_net ? 1 : 2);

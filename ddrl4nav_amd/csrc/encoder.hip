@@ -6,27 +6,49 @@
 
 namespace ddrl {
 
-// largest |dh| per encoder -> Workspace::amax (scale of dh's fp16 planes, engine2.h plane scheme).  dh comes from
-// heads_loss, from the GAIL critic's value head on top of it, or from the caller (ddrl_encoder_backward): measured here.
-__global__ __launch_bounds__(256) void dh_amax_kernel(const float* __restrict__ dh, int64_t dh_es, int64_t count, float* __restrict__ amax) {
-  const int e = blockIdx.y;
-  const f4* src = (const f4*)(dh + e * dh_es);
-  float m = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count / 4; i += (int64_t)gridDim.x * 256) {
-    const f4 v = src[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+// Per-sample normalisation of the backward (common.h Workspace::gsc).  dh comes from heads_loss, from the GAIL critic's value head on
+// top of it, or from the caller (ddrl_encoder_backward).  One wave per (sample, encoder): g_s = 2^floor(log2 max_k |dh[s][k]|)
+// (clamped to 2^+-60; 2^-60 for an all-zero row), dh[s][:] *= 1 / g_s in place (exact), gsc[e][s] = g_s.  The whole data-gradient
+// chain is linear per sample, so dz3 / dz2 / dz1 come out normalised by the same g_s and a sample whose advantage is 10^6 x below
+// the batch's largest keeps the same 22 bits as the largest; only the weight gradients, which SUM over samples, multiply g_s back
+// in (wgrad2.hip, fc2.hip).  Slots: AMAX_DH = largest normalised |dh| (in [1, 2) unless clamped), AMAX_GMAX = largest g_s.
+__global__ __launch_bounds__(256) void dh_normalise_kernel(float* __restrict__ dh, int64_t dh_es, int n, float* __restrict__ gsc, int64_t gsc_es,
+                                                           float* __restrict__ amax) {
+  const int e = blockIdx.y, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n) return;  // wave-uniform
+  f4* row = (f4*)(dh + e * dh_es + (int64_t)b * FEAT) + lane * 2;
+  f4 v0 = row[0], v1 = row[1];
+  float m = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))),
+                  fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  int ex = GSC_EXP_MIN;
+  if (m > 0.0f && m < 3.0e38f) {
+    frexpf(m, &ex);  // m = f 2^ex, f in [0.5, 1)
+    ex = min(max(ex - 1, GSC_EXP_MIN), GSC_EXP_MAX);
   }
-  amax_update(m, amax + amax_idx(AMAX_DH, e));
+  const float g = ldexpf(1.0f, ex), gi = ldexpf(1.0f, -ex);
+  row[0] = v0 * gi;
+  row[1] = v1 * gi;
+  if (lane == 0) {
+    gsc[e * gsc_es + b] = g;
+    const unsigned gb = __float_as_uint(g), mb = __float_as_uint(m * gi);  // non-negative floats order like unsigned integers
+    unsigned* sg = (unsigned*)(amax + amax_idx(AMAX_GMAX, e));
+    unsigned* sm = (unsigned*)(amax + amax_idx(AMAX_DH, e));
+    // look first: after the first few waves almost no atomic is sent (engine2.h amax_update)
+    if (gb > __hip_atomic_load(sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sg, gb);
+    if (mb > __hip_atomic_load(sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sm, mb);
+  }
 }
 static void launch_backward_amax(const EncCall& c, hipStream_t st) {
-  static_assert(AMAX_DZ3 == AMAX_DH + 1 && AMAX_DZ2 == AMAX_DH + 2 && AMAX_DZ1 == AMAX_DH + 3 && AMAX_SLOTS == AMAX_DH + 4,
-                "gradient slots are the last four");
+  static_assert(AMAX_DZ3 == AMAX_DH + 1 && AMAX_DZ2 == AMAX_DH + 2 && AMAX_DZ1 == AMAX_DH + 3 && AMAX_GMAX == AMAX_DH + 4 &&
+                    AMAX_SLOTS == AMAX_DH + 5,
+                "gradient slots are the last five");
   const Workspace& w = *c.ws;
-  (void)hipMemsetAsync(w.amax + amax_idx(AMAX_DH, 0), 0, 4 * 2 * sizeof(float), st);  // dz3 / dz2 / dz1 are raised by their producers
-  const int64_t count = (int64_t)c.n * FEAT;
-  int wgs = (int)((count / 4 + 255) / 256);
-  if (wgs > 512) wgs = 512;
-  hipLaunchKernelGGL(dh_amax_kernel, dim3(wgs, c.L->NE), dim3(256), 0, st, w.dh, c.max_batch * FEAT, count, w.amax);
+  (void)hipMemsetAsync(w.amax + amax_idx(AMAX_DH, 0), 0, 5 * 2 * sizeof(float), st);  // dz3 / dz2 / dz1 are raised by their producers
+  hipLaunchKernelGGL(dh_normalise_kernel, dim3((c.n + 3) / 4, c.L->NE), dim3(256), 0, st, w.dh, c.max_batch * FEAT, c.n, w.gsc, c.max_batch,
+                     w.amax);
 }
 
 void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st) {

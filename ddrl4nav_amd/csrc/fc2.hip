@@ -714,8 +714,8 @@ __device__ __forceinline__ frag8 tr_fragment(const char* lds, int byte_off) {
 }
 
 __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __restrict__ dh, int64_t dh_es, const float* __restrict__ a3,
-                                                              int64_t a3_es, const float* __restrict__ amax, float* __restrict__ part, int n,
-                                                              int nsplit, int ne) {
+                                                              int64_t a3_es, const float* __restrict__ amax, const float* __restrict__ gsc,
+                                                              int64_t gsc_es, float* __restrict__ part, int n, int nsplit, int ne) {
   using K = FcWgradB;
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -730,7 +730,11 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
 #endif
   const int e = bz % ne, split = bz / ne;
-  const float sd = plane_scale(amax[amax_idx(AMAX_DH, e)]), sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sd * sa);
+  // dh is NORMALISED per sample (common.h Workspace::gsc): sample s is staged with the factor sd g_s / g_max (<= sd) and the sums are
+  // multiplied by g_max / (sd sa); the bias gradient sums g_s dh[s] in fp32
+  const float sd = WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DH, e)]) / amax[amax_idx(AMAX_GMAX, e)], sa = plane_scale(amax[amax_idx(AMAX_A3, e)]),
+              inv = 1.0f / (sd * sa);
+  const float* gs = gsc + e * gsc_es;
   const int k0 = bx * 128, n0 = by * 128;
   const int nkb = (n + K::KB - 1) / K::KB;
   const int per = (nkb + nsplit - 1) / nsplit;
@@ -748,6 +752,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (8 * (g16 >> 1) + q) * K::PITCH + (wc * 64 + j * 32 + 16 * (g16 & 1) + 4 * pp) * 2;
   f4 dr[4], ar[4];
+  float gr[4];
   f4 bsum = zero4();
   const bool bias_owner = (bx == 0);
   auto fetch = [&](int kb) {
@@ -756,6 +761,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
       const int64_t row = min(kb * K::KB + kk + 8 * j, n - 1);  // unconditional loads from clamped rows; masked at commit
       dr[j] = ld4(dsrc + row * FEAT);
       ar[j] = ld4(asrc + row * FLAT);
+      gr[j] = gs[row];
     }
   };
   auto commit = [&](int kb) {
@@ -770,8 +776,9 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
     for (int j = 0; j < 4; ++j) {
       char* d = ldsw + (kk + 8 * j) * K::PITCH + c4 * 8;
       unsigned pa[NPL], pb[NPL];
-      split_planes(dr[j].x, dr[j].y, sd, pa);
-      split_planes(dr[j].z, dr[j].w, sd, pb);
+      const float sdj = sd * gr[j];
+      split_planes(dr[j].x, dr[j].y, sdj, pa);
+      split_planes(dr[j].z, dr[j].w, sdj, pb);
 #pragma unroll
       for (int p = 0; p < NPL; ++p) *(uint2*)(d + p * K::PLANE) = make_uint2(pa[p], pb[p]);
       split_planes(ar[j].x, ar[j].y, sa, pa);
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_planes_kernel(const float* __res
 #pragma unroll
       for (int p = 0; p < NPL; ++p) *(uint2*)(d + K::B_OFF + p * K::PLANE) = make_uint2(pa[p], pb[p]);
     }
-    if (bias_owner) bsum += (dr[0] + dr[1]) + (dr[2] + dr[3]);
+    if (bias_owner) bsum += (dr[0] * gr[0] + dr[1] * gr[1]) + (dr[2] * gr[2] + dr[3] * gr[3]);
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -863,7 +870,7 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
     const dim3 wgrid((FLAT + 127) / 128, FEAT / 128, L.NE * S);
 #endif
     hipLaunchKernelGGL(fc_wgrad_planes_kernel, wgrid, dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
-                       MB * FEAT, w.a3, MB * FLAT, w.amax, w.wpart, c.n, S, L.NE);
+                       MB * FEAT, w.a3, MB * FLAT, w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
     (void)p;
 #else
     launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), p, st);

@@ -514,7 +514,7 @@ void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, ui
   if (wgs > 1024) wgs = 1024;
   const int nsplit = c.plain_features ? 1 : fc_forward_splits(c.n);
   auto kern = c.L->A <= MAXA_SMALL ? heads_act_kernel<MAXA_SMALL, false> : heads_act_kernel<MAXA_LARGE, true>;
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, st, c.ws->h, c.h_es >= 0 ? c.h_es : c.max_batch * FEAT,
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT,
                      nsplit > 1 ? c.ws->wpart : nullptr, nsplit > 1 ? nsplit : 0, c.params, *c.L, c.n,
                      act_in, seed, stream_id, probs, value, action_out, logp_out);
 }
@@ -524,9 +524,9 @@ void launch_heads_loss(const HeadsCall& c, const float* actions, const float* ol
   const int64_t hs = hpart_stride(c.L->A);
   const bool large = c.L->A > MAXA_SMALL;
   auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : heads_loss_kernel<MAXA_SMALL, false>;
-  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(LOSS_WAVES * 64), 0, st, c.ws->h, c.h_es >= 0 ? c.h_es : c.max_batch * FEAT, c.params,
+  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(LOSS_WAVES * 64), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT, c.params,
                      *c.L, *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh,
-                     c.dh_es >= 0 ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs);
+                     c.dh_es != HeadsCall::ES_UNSET ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs);
   if (large)
     hipLaunchKernelGGL(head_wgrad_kernel<MAXA_LARGE>, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.ws->dlogits, c.n,
                        c.L->A, c.ws->hpart, hs);

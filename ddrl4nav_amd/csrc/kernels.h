@@ -78,7 +78,11 @@ struct HeadsCall {
   int64_t max_batch;
   // generic callers (ddrl_op_heads_*): explicit actor->critic feature / gradient strides and no
   // split-K FC partials to fold in; the Atari context leaves these at their defaults
-  int64_t h_es = -1, dh_es = -1;
+  // (a difference of two independent allocations: ANY value, negative included, is a valid stride -- the "unset" mark is a
+  // separate sentinel; a plain "< 0" test once sent every net whose critic buffer happened to lie below its actor buffer to
+  // h + max_batch * 512: wrong values, out-of-bounds reads)
+  static constexpr int64_t ES_UNSET = INT64_MIN;
+  int64_t h_es = ES_UNSET, dh_es = ES_UNSET;
   bool plain_features = false;
 };
 void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id,

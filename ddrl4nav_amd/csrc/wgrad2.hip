@@ -17,6 +17,13 @@
 namespace ddrl {
 
 
+// per-sample scale g_s through the VECTOR memory path: the index is wave-uniform, and a scalar load would make every consumer wait
+// for lgkmcnt(0) -- the counter the k loop's LDS reads live on (ConvWgrad1 12.2 instead of 2.7 ms with s_load_dword in its fetch)
+__device__ __forceinline__ float ld_gs(const float* gs, int idx) {
+  asm volatile("" : "+v"(idx));
+  return gs[idx];
+}
+
 struct WgradSplit {
   int pair_begin, pair_end;
   __device__ __forceinline__ void set(int n, int nsplit, int split) {
@@ -526,14 +533,18 @@ __device__ __forceinline__ frag8 tr_frag3(const char* lds, int off_lo, int off_h
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __restrict__ a2, int64_t a2_es, const float* __restrict__ dz3,
-                                                                 int64_t dz_es, const float* __restrict__ amax, float* __restrict__ part, int n,
-                                                                 int nsplit, int ne) {
+                                                                 int64_t dz_es, const float* __restrict__ amax, const float* __restrict__ gsc,
+                                                                 int64_t gsc_es, float* __restrict__ part, int n, int nsplit, int ne) {
   using K = Wgrad3B;
   extern __shared__ __attribute__((aligned(16))) char ldsw3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wi = wave >> 1, wj = wave & 1;
   const int e = blockIdx.x % ne, split = blockIdx.x / ne;
-  const float sd = plane_scale(amax[amax_idx(AMAX_DZ3, e)]), sa = plane_scale(amax[amax_idx(AMAX_A2, e)]), inv = 1.0f / (sd * sa);
+  // dz3 is NORMALISED per sample (common.h Workspace::gsc): sample s is staged with the factor sd g_s / g_max (<= sd), the sums are
+  // multiplied by g_max / (sd sa), the bias gradient sums g_s dz3[s] in fp32
+  const float sd = WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ3, e)]) / amax[amax_idx(AMAX_GMAX, e)], sa = plane_scale(amax[amax_idx(AMAX_A2, e)]),
+              inv = 1.0f / (sd * sa);
+  const float* gs = gsc + e * gsc_es;
   const int nst = (n + K::NB - 1) / K::NB;
   const int per = (nst + nsplit - 1) / nsplit;
   const int st_begin = split * per, st_end = min(nst, st_begin + per);
@@ -580,12 +591,15 @@ __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __
     }
   float ar[K::NA][8], br[K::NBU][8];
   float bsum[K::NA][8];
+  float gs0 = 0.0f, gs1 = 0.0f;  // g_s of the stage's two samples (wave-uniform)
 #pragma unroll
   for (int t = 0; t < K::NA; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) bsum[t][c] = 0.0f;
   auto fetch = [&](int st) {
     const int s0 = st * K::NB;
+    gs0 = ld_gs(gs, min(s0, n - 1));
+    gs1 = ld_gs(gs, min(s0 + 1, n - 1));
 #pragma unroll
     for (int t = 0; t < K::NA; ++t) {
       const float* src = asrc[t] + (int64_t)min(s0 + asmp[t], n - 1) * FLAT;  // clamped sample, masked at commit
@@ -609,13 +623,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __
           for (int c = 0; c < 8; ++c) ar[t][c] = 0.0f;
         }
         unsigned pl[4][NPL];
+        const float gt = asmp[t] ? gs1 : gs0, sdt = sd * gt;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
+        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sdt, pl[c]);
         char* d = ldsw3 + awr[t];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::A_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
+        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c] * gt;
       }
     }
 #pragma unroll
@@ -702,7 +717,7 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
     }
     ProfRange pr(c.prof, "ConvWgrad3", st);
     hipLaunchKernelGGL(conv_wgrad3_planes_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad3B::LDS_BYTES, st, w.a2, MB * 5184, w.dz3, MB * FLAT,
-                       w.amax, w.wpart, c.n, S, L.NE);
+                       w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
   }
 #else
   const int S = c.splits->c3;
@@ -744,15 +759,18 @@ struct Wgrad2B {
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __restrict__ a1, int64_t a1_es, const float* __restrict__ dz2,
-                                                                 int64_t dz_es, const float* __restrict__ amax, float* __restrict__ part, int n,
-                                                                 int nsplit, int ne) {
+                                                                 int64_t dz_es, const float* __restrict__ amax, const float* __restrict__ gsc,
+                                                                 int64_t gsc_es, float* __restrict__ part, int n, int nsplit, int ne) {
   using K = Wgrad2B;
   extern __shared__ __attribute__((aligned(16))) char ldsw2[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   // wave = tap row ky (4 column tiles: kx = 0..3) x BOTH oc halves: a k-group reads 2 x 2 dz2 fragments and 4 x 2 a1 fragments for its 24
   // MFMAs (one oc half x two tap rows read 1 x 2 + 8 x 2: a third more LDS bytes per MFMA in a kernel that LDS bandwidth bounds)
   const int e = blockIdx.x % ne, split = blockIdx.x / ne;
-  const float sd = plane_scale(amax[amax_idx(AMAX_DZ2, e)]), sa = plane_scale(amax[amax_idx(AMAX_A1, e)]), inv = 1.0f / (sd * sa);
+  // dz2 is NORMALISED per sample (see conv_wgrad3_planes_kernel): the stage's one sample is staged with sd g_s / g_max
+  const float sd = WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ2, e)]) / amax[amax_idx(AMAX_GMAX, e)], sa = plane_scale(amax[amax_idx(AMAX_A1, e)]),
+              inv = 1.0f / (sd * sa);
+  const float* gs = gsc + e * gsc_es;
   const int per = (n + nsplit - 1) / nsplit;
   const int st_begin = split * per, st_end = min(n, st_begin + per);
   for (int i = tid; i < NPL * (K::AROWS - K::KAPPA) * 8; i += 256) {  // zero rows of the dz2 image (kappa >= 81): written once
@@ -797,7 +815,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
   for (int t = 0; t < K::NA; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) bsum[t][c] = 0.0f;
+  float gst = 0.0f;  // g_s of the staged sample (wave-uniform)
   auto fetch = [&](int st) {
+    gst = ld_gs(gs, st);
 #pragma unroll
     for (int t = 0; t < K::NA; ++t) {
       const float* src = asrc[t] + (int64_t)st * 5184;
@@ -816,13 +836,14 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
     for (int t = 0; t < K::NA; ++t) {
       if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
         unsigned pl[4][NPL];
+        const float sdt = sd * gst;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes_c(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
+        for (int c = 0; c < 4; ++c) split_planes_c(ar[t][2 * c], ar[t][2 * c + 1], sdt, pl[c]);
         char* d = ldsw2 + awr[t];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::A_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
+        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c] * gst;
       }
     }
 #pragma unroll
@@ -913,7 +934,7 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
     }
     ProfRange pr(c.prof, "ConvWgrad2", st);
     hipLaunchKernelGGL(conv_wgrad2_planes_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad2B::LDS_BYTES, st, w.a1, MB * 12800, w.dz2, MB * 5184,
-                       w.amax, w.wpart, c.n, S, L.NE);
+                       w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
   }
 #else
   const int S = c.splits->c2;
@@ -963,7 +984,8 @@ struct Wgrad1B {
 template <int NE>
 __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ dz,
                                                                  const unsigned* __restrict__ m1, int64_t m1_es, int64_t dz_es,
-                                                                 const float* __restrict__ amax, float* __restrict__ part, int n, int nsplit, int C) {
+                                                                 const float* __restrict__ amax, const float* __restrict__ gsc, int64_t gsc_es,
+                                                                 float* __restrict__ part, int n, int nsplit, int C) {
   using K = Wgrad1B<NE>;
   const int fs = C * 7056;  // bytes of one sample's C stacked frames (1..4); wave wc owns the 64 taps of channel wc and idles past C
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
@@ -1012,7 +1034,13 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
     im_tail |= (g == 5 ? 1u : 0u) << k;
   }
   const bool lone_group_wave = __builtin_amdgcn_readfirstlane(tid) < 192;  // waves 0 .. 2
-  const float sd = plane_scale(amax[amax_idx(AMAX_DZ1, ew)]);  // this thread stages encoder ew's dz1
+  // this thread stages encoder ew's dz1, which is NORMALISED per sample (see conv_wgrad3_planes_kernel): staged with sd g_s / g_max
+  const float sd = WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ1, ew)]) / amax[amax_idx(AMAX_GMAX, ew)];
+  const float* gs = gsc + ew * gsc_es;
+  // g_s of the sample each of this thread's dz quads belongs to, fetched per lane next to the quad.  (NOT two wave-uniform values
+  // and a select in commit(): a select between two by-reference lambda captures becomes a load through a selected POINTER, the
+  // closure's address escapes and every captured array of the kernel lands in scratch -- 12.2 instead of 2.7 ms.)
+  float gsj[K::NDZ_J];
   // ---- operand lane bases: MFMA m of a k-block, lane half hi -> fragment fi = 2 m + hi = (sample fi / 3, frag fi % 3)
   int aa[NE][3], bb[2][3], shamt[2], kyhi[2], kylo[2];
 #pragma unroll
@@ -1034,12 +1062,16 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
   u4w imr[2] = {(u4w){0u, 0u, 0u, 0u}, (u4w){0u, 0u, 0u, 0u}};
   bool full = true, imfirst = true;
   int imam = 0;  // ring group (mod 4) of the first group this fetch stages
-  auto fetch = [&](int kb) {
+  auto fetch = [&](int kb) __attribute__((always_inline)) {
     const int pair = kb / 20, oy = kb % 20;
     full = 2 * pair + 1 < n;
     imfirst = kb == kb_begin || oy == 0;        // first block of a pair: both of its row groups are new
     const int gfirst = imfirst ? 0 : 1;
     imam = (21 * pair + oy + gfirst) & 3;
+    if (imfirst) {  // wave-uniform: the 20 k-blocks of a sample pair share their scales
+#pragma unroll
+      for (int j = 0; j < K::NDZ_J; ++j) gsj[j] = ld_gs(gs, min(2 * pair + (int)((dz_s1 >> j) & 1u), n - 1));
+    }
     const int64_t sb = ew * dz_es + (int64_t)pair * (2 * 12800) + oy * 20;
     const char* dzb = (const char*)(dz + sb);
     const char* mb = (const char*)(m1 + ew * m1_es + (int64_t)pair * 800 + oy * 20);
@@ -1063,7 +1095,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
       imr[k] = (u4w){q[0], q[1], q[2], q[3]};
     }
   };
-  auto commit = [&](char* st) {
+  auto commit = [&](char* st) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < K::NDZ_J; ++j) {
       if (j + 1 < K::NDZ_J || ((dz_ok >> j) & 1u)) {
@@ -1071,13 +1103,14 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
                                 : (f4){leaky_bit(mkr[j][0], mbit[j], dzr[j].x), leaky_bit(mkr[j][1], mbit[j], dzr[j].y),
                                        leaky_bit(mkr[j][2], mbit[j], dzr[j].z), leaky_bit(mkr[j][3], mbit[j], dzr[j].w)};
         if (!full && ((dz_s1 >> j) & 1u)) g = zero4();
-        bacc[j] += (g.x + g.y) + (g.z + g.w);  // the bias gradient rides along (fp32)
+        const float gj = gsj[j], sdj = sd * gj;
+        bacc[j] += ((g.x + g.y) + (g.z + g.w)) * gj;  // the bias gradient rides along (fp32)
         unsigned pa[NPL], pb[NPL];
         if (DDRL_W1_KO & 2) {
           for (int p = 0; p < NPL; ++p) { pa[p] = __float_as_uint(g.x) ^ __float_as_uint(g.y); pb[p] = __float_as_uint(g.z) ^ __float_as_uint(g.w); }
         } else {
-        split_planes(g.x, g.y, sd, pa);
-        split_planes(g.z, g.w, sd, pb);
+        split_planes(g.x, g.y, sdj, pa);
+        split_planes(g.z, g.w, sdj, pb);
         }
         char* d = st + adst[j];
 #pragma unroll
@@ -1164,7 +1197,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
   const int64_t slab_floats = 32 * ktaps + 32;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const float r255 = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_DZ1, i)]));
+    const float r255 = amax[amax_idx(AMAX_GMAX, i)] / (255.0f * WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ1, i)]));
     float* slab = part + ((int64_t)split * 2 + i) * slab_floats;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1201,7 +1234,7 @@ static void launch_wgrad1_planes(const EncCall& c, int S, hipStream_t st) {
     configured = true;
   }
   hipLaunchKernelGGL(conv_wgrad1_planes_kernel<NE>, dim3(1, S, 1), dim3(256), K::LDS_BYTES, st, c.frames, w.dz1, w.m1, m1_words(c.max_batch),
-                     c.max_batch * 12800, w.amax, w.wpart, c.n, S, c.L->C);
+                     c.max_batch * 12800, w.amax, w.gsc, c.max_batch, w.wpart, c.n, S, c.L->C);
 }
 
 void launch_conv_wgrad1_2(const EncCall& c, float* grads, hipStream_t st) {

@@ -197,14 +197,35 @@ class HotPath:
                 "GradNorm": float(s[4]), "ClipCoef": float(s[5])}
 
     # ---- diagnostics ------------------------------------------------------------------------
-    def debug_buffer(self, which, shape_per_sample, n, enc):
-        """Copy of a workspace tensor: [n, *shape_per_sample] for encoder `enc`."""
+    def debug_buffer(self, which, shape_per_sample, n, enc, raw=False):
+        """Copy of a workspace tensor: [n, *shape_per_sample] for encoder `enc`.  The gradient tensors of the data-gradient
+        chain (4 dz1, 5 dz2, 6 dz3, 7 dh) are stored NORMALISED per sample (csrc/common.h Workspace::gsc); unless `raw`
+        they are returned multiplied by their per-sample power-of-two scale, i.e. as the true gradients."""
         p, es = c_void_p(), c_int64()
         check(self.lib.ddrl_debug_buffer(self.ctx, which, byref(p), byref(es)))
         count = int(np.prod(shape_per_sample)) * n
         off = (p.value - self.workspace.data_ptr()) // 4 + enc * es.value
         flat = self.workspace.view(torch.float32)[off:off + count]
-        return flat.clone().reshape((n,) + tuple(shape_per_sample))
+        out = flat.clone().reshape((n,) + tuple(shape_per_sample))
+        if which in (4, 5, 6, 7) and not raw:
+            g = self.debug_buffer(13, (), n, enc)
+            out = out * g.reshape((n,) + (1,) * len(tuple(shape_per_sample)))
+        return out
+
+    def debug_view(self, which, shape_per_sample, n, enc):
+        """WRITABLE view (no copy, no rescaling) of a workspace tensor -- tests use it to hand the encoder-only entry points
+        a crafted dh (ddrl_encoder_backward reads the context's dh buffer)."""
+        p, es = c_void_p(), c_int64()
+        check(self.lib.ddrl_debug_buffer(self.ctx, which, byref(p), byref(es)))
+        count = int(np.prod(shape_per_sample)) * n
+        off = (p.value - self.workspace.data_ptr()) // 4 + enc * es.value
+        return self.workspace.view(torch.float32)[off:off + count].view((n,) + tuple(shape_per_sample))
+
+    def plane_maxima(self):
+        """{slot name: [per encoder]} of the running maxima / bounds behind the fp16 plane scales (csrc/common.h AMAX_*)."""
+        names = ("wl", "w2", "w3", "w1", "a1", "a2", "a3", "dh", "dz3", "dz2", "dz1", "gmax")
+        v = self.debug_buffer(14, (), 2 * len(names), 0).cpu().numpy()
+        return {k: v[2 * i:2 * i + 2].copy() for i, k in enumerate(names)}
 
     def u8_table(self):
         out = torch.empty(256, dtype=torch.float32, device=self.device)

@@ -25,6 +25,7 @@ import torch
 from torch import nn
 
 from ddrl4nav_amd.nn.base import PreNet
+from ddrl4nav_amd.utils.staging import to_device
 
 _GEOMETRY = (("conv1", 32, 8, 4), ("conv2", 64, 4, 2), ("conv3", 64, 3, 1))  # name, out channels, kernel, stride
 _FLAT = 64 * 7 * 7
@@ -37,7 +38,7 @@ def frames_u8(states, device):
     x = torch.as_tensor(x)
     if x.dtype != torch.uint8:
         x = torch.round(x.to(torch.float32) * 255.0).clamp_(0, 255).to(torch.uint8)
-    return x.to(device, non_blocking=True).contiguous()
+    return to_device(x, device).contiguous()
 
 
 class AtariPreNet(PreNet):

@@ -28,6 +28,7 @@ from ddrl4nav_amd.data import Experience
 from ddrl4nav_amd.nn.base import Basenn
 from ddrl4nav_amd.nn.generic import FEAT, _pad4, dense_layer, mlp
 from ddrl4nav_amd.ops import _p, _st
+from ddrl4nav_amd.utils.staging import to_device
 
 
 class Discriminator(Basenn):
@@ -141,7 +142,7 @@ class Discriminator(Basenn):
         states = states if isinstance(states, (list, tuple)) else [states]
         if self._raw_u8:
             return [torch.as_tensor(s)[lo:hi] for s in states]
-        return [torch.as_tensor(s)[lo:hi].to(self.device, torch.float32, non_blocking=True) for s in states]
+        return [to_device(torch.as_tensor(s)[lo:hi], self.device, torch.float32) for s in states]
 
     def _forward_chunk(self, st, action, n):
         """scores of one micro-batch -> self._act[-1][:n, 0]; activations stay in place for the backward."""

@@ -20,6 +20,7 @@ from ddrl4nav_amd._lib import STATS_FLOATS, HeadsDesc, check
 from ddrl4nav_amd.data import Experience
 from ddrl4nav_amd.nn.base import Basenn, PreNet
 from ddrl4nav_amd.ops import Conv, Linear, maxpool2, maxpool2_relu_backward, _p, _st
+from ddrl4nav_amd.utils.staging import to_device
 
 FEAT = 512
 
@@ -501,7 +502,7 @@ class GenericPPO(Basenn):
     def _stage(self, states, lo, hi):
         if self._raw_u8:
             return [torch.as_tensor(s)[lo:hi] for s in states]
-        return [torch.as_tensor(s)[lo:hi].to(self.device, torch.float32, non_blocking=True) for s in states]
+        return [to_device(torch.as_tensor(s)[lo:hi], self.device, torch.float32) for s in states]
 
     def _features(self, st, n):
         hs = [e.forward_dev(st, n) for e in self._encs]
@@ -632,7 +633,7 @@ class GenericPPO(Basenn):
             from ddrl4nav_amd.nn.atari_encoder import frames_u8
             dstates = [frames_u8(states, self.device)]
         else:
-            dstates = [torch.as_tensor(s).to(self.device, torch.float32, non_blocking=True) for s in states]
+            dstates = [to_device(s, self.device, torch.float32) for s in states]
         for _ in range(self.training_iter_time):
             t0 = time.time()
             self._ensure_packed()

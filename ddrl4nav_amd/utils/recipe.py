@@ -108,3 +108,57 @@ def hash_weights(named_shapes, seed=0):
         bound = np.float32(1.0 / np.sqrt(np.float64(fan_in)))
         out[name] = ((u * np.float32(2.0) - np.float32(1.0)) * bound).astype(np.float32).reshape(shape)
     return out
+
+
+def _area_weights(dst, src):
+    """[dst, src] INTEGER weights of exact area averaging (cv2.INTER_AREA's arithmetic for a non-integer
+    shrink): with g = gcd(dst, src) a destination cell spans src / g units of 1 / (dst / g) source pixels, and
+    entry (i, j) is the overlap of cell i with source pixel j in those units (rows sum to src / g)."""
+    g = int(np.gcd(dst, src))
+    a, b = src // g, dst // g          # cell i = [a i, a i + a), pixel j = [b j, b j + b)
+    w = np.zeros((dst, src), np.float64)
+    for i in range(dst):
+        for j in range(src):
+            w[i, j] = max(0, min(a * i + a, b * j + b) - max(a * i, b * j))
+    return w, a
+
+
+def pong_frames(seed, n, stack=4, chunk=1024):
+    """Synthetic Pong observations, uint8 [n, stack, 84, 84], shaped like what the reference's frame
+    wrapper emits before its ``/ 255.0`` (env/gym_env/wrapper/warputils.py:274-301: grayscale, rows
+    34..193 of the 210 x 160 screen, area-resized to 84 x 84): background 87, a 4 x 16 paddle of gray
+    148 (left) and 147 (right), a 2 x 4 ball of gray 236, drawn on the 160 x 160 playfield and shrunk with
+    exact area averaging (integer-valued float64 products: bit-reproducible on any BLAS), so paddle and ball
+    edges carry the in-between grays a real frame has.  The ``stack`` frames of a sample are consecutive: the
+    ball moves with a per-sample velocity, the paddles drift.  Mostly-flat images like these are the realistic
+    input of the encoder; dense random bytes are its worst case for time, not for
+    numerics."""
+    rng = np.random.default_rng(int(seed))
+    w, a = _area_weights(84, 160)
+    out = np.empty((n, stack, 84, 84), np.uint8)
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        py_l = rng.integers(0, 160 - 16, size=m)
+        py_r = rng.integers(0, 160 - 16, size=m)
+        dpy_l = rng.integers(-4, 5, size=m)
+        dpy_r = rng.integers(-4, 5, size=m)
+        bx = rng.integers(20, 140, size=m)
+        by = rng.integers(4, 152, size=m)
+        vx = rng.integers(-6, 7, size=m)
+        vy = rng.integers(-6, 7, size=m)
+        no_ball = rng.random(m) < 0.1        # between points the ball is off screen
+        field = np.full((m, stack, 160, 160), 87.0, np.float64)
+        for f in range(stack):
+            for i in range(m):
+                yl = int(np.clip(py_l[i] + f * dpy_l[i], 0, 144))
+                yr = int(np.clip(py_r[i] + f * dpy_r[i], 0, 144))
+                field[i, f, yl:yl + 16, 16:20] = 148.0
+                field[i, f, yr:yr + 16, 140:144] = 147.0
+                if not no_ball[i]:
+                    x = int(np.clip(bx[i] + f * vx[i], 0, 158))
+                    y = int(np.clip(by[i] + f * vy[i], 0, 156))
+                    field[i, f, y:y + 4, x:x + 2] = 236.0
+        small = np.matmul(np.matmul(w, field), w.T)            # integers < 2^53: exact in any summation order
+        q = np.floor((small + (a * a) // 2) / (a * a))           # round half up, exact
+        out[c0:c0 + m] = q.astype(np.uint8)
+    return out

@@ -180,7 +180,10 @@ int32_t ddrl_u8_table(float* out256, void* stream);
  * returned in floats), 8 dlogits [B,A], 9 dvalue [B]; 10 / 11 / 12: the sign masks of a1 / a2 / a3 that
  * the forward writes for the backward's leaky-ReLU decisions (32-bit words behind the float pointer,
  * bit set = activation not positive; m1 [e][max_batch * 400 columns], bit per output channel;
- * m2 [e][max_batch][81 pixels][2], m3 [e][max_batch][49 pixels][2], bit per channel of a lane half). */
+ * m2 [e][max_batch][81 pixels][2], m3 [e][max_batch][49 pixels][2], bit per channel of a lane half).
+ * The backward runs on per-sample NORMALISED gradients: 4..7 hold the true per-sample gradient divided by the
+ * power of two g_s = 2^floor(log2 max|dh_s|); 13 = g_s [e][max_batch].  14 = the running maxima / bounds behind
+ * the fp16 plane scales, [slot][encoder] (e stride 1). */
 int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* enc_stride);
 
 /* ---- pinned-host ring: replaces the Redis LPUSH/BRPOP shuttle of frames between env workers
@@ -349,7 +352,9 @@ int32_t ddrl_op_accumulate(float* dst, const float* src, int64_t count, void* st
  * the context's grad arena (encoder slots only; the head slots are not touched).  The context is created with
  * share_cnn_net = 1; `params` / `grads` point at the encoder's first parameter (prenet.conv1.weight) inside
  * the caller's arenas; adam_m / adam_v may be NULL for such a context (ddrl_clip_adam_step then fails).
- * ddrl_encoder_buffers returns the device addresses of h [max_batch][512] and dh [max_batch][512]. */
+ * ddrl_encoder_buffers returns the device addresses of h [max_batch][512] and dh [max_batch][512].
+ * ddrl_encoder_backward CONSUMES dh: its rows are rescaled in place by per-sample powers of two (the backward
+ * runs on normalised gradients); write dh again before every call. */
 int32_t ddrl_encoder_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream);
 int32_t ddrl_encoder_backward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, void* stream);
 int32_t ddrl_encoder_buffers(ddrl_ctx* ctx, float** h, float** dh);

@@ -71,7 +71,9 @@ class Encoder(nn.Module):
     """AtariPreNet (atari_encoder.py:12-32): 3 x conv + leaky_relu(0.01), flatten, linear.
 
     Test hooks (not part of the reference): ``last_z`` keeps the three pre-activations of the latest forward;
-    ``forced`` = [pos1, pos2, pos3] (bool tensors) makes the backward use those decisions (_LeakyForced)."""
+    ``forced`` = [pos1, pos2, pos3] (bool tensors) makes the backward use those decisions (_LeakyForced);
+    ``tap`` = {} collects, at the next backward, d loss / d (conv1 pre-activation) as "z1", d loss / d (conv2 / conv3
+    pre-activation) as "z2" / "z3" and d loss / d (encoder output) as "h" (per-sample gradient tensors)."""
 
     def __init__(self, num_inputs=4):
         super().__init__()
@@ -81,9 +83,15 @@ class Encoder(nn.Module):
         self.linear = nn.Linear(3136, 512)
         self.forced = None
         self.last_z = None
+        self.tap = None
+
+    def _tap(self, t, key):
+        if self.tap is not None and t.requires_grad:
+            t.register_hook(lambda g, d=self.tap, k=key: d.__setitem__(k, g.detach().clone()))
 
     def _act(self, z, k):
         self.last_z.append(z.detach())
+        self._tap(z, "z%d" % (k + 1))
         return F.leaky_relu(z) if self.forced is None else _LeakyForced.apply(z, self.forced[k])
 
     def forward(self, x):
@@ -91,7 +99,9 @@ class Encoder(nn.Module):
         x = self._act(self.conv1(x), 0)
         x = self._act(self.conv2(x), 1)
         x = self._act(self.conv3(x), 2)
-        return self.linear(x.view(x.size(0), -1))
+        h = self.linear(x.view(x.size(0), -1))
+        self._tap(h, "h")
+        return h
 
 
 class ActorHead(nn.Module):

@@ -25,6 +25,12 @@
     }                                                      \
   } while (0)
 
+#define STAGE(msg)              \
+  do {                          \
+    fprintf(stderr, "[abi_smoke] %s\n", msg); \
+    fflush(stderr);             \
+  } while (0)
+
 int main(void) {
   enum { N = 8, T = 4, B = N * T };
   ddrl_config cfg;
@@ -75,19 +81,25 @@ int main(void) {
 
   ddrl_ctx* ctx = NULL;
   CHECK(ddrl_ctx_create(&cfg, params, grads, m, v, ws, ws_bytes, &ctx));
+  STAGE("context created");
   const size_t fstep = (size_t)N * 4 * 84 * 84;
   for (int t = 0; t <= T; ++t)
     CHECK(ddrl_forward(ctx, frames + t * fstep, N, NULL, 7, (uint64_t)t, probs, values + t * N, actions + t * N,
                        logps + t * N, NULL));
   CHECK(ddrl_gae(values, rewards, dones, T, N, 0.99f, 0.95f, adv, ret, NULL));
+  HIP(hipDeviceSynchronize());
+  STAGE("acting + GAE done");
   /* the multi-GPU step of INTEGRATION.md section 2 with a communicator of ONE rank (a one-GPU box cannot hold two RCCL
    * ranks): unique id -> communicator -> parameter broadcast -> gradient all-reduce between ppo_iter and clip_adam */
   uint8_t id[128];
   ddrl_comm* comm = NULL;
   int32_t cs = ddrl_comm_unique_id(id);
   if (cs == DDRL_OK) {
+    STAGE("creating the one-rank RCCL communicator");
     CHECK(ddrl_comm_create(id, 0, 1, &comm));
     CHECK(ddrl_params_broadcast(ctx, comm, 0, NULL));
+    HIP(hipDeviceSynchronize());
+    STAGE("communicator + broadcast done");
   } else if (cs != DDRL_ERR_UNSUPPORTED) { /* UNSUPPORTED = no librccl on this host */
     fprintf(stderr, "ddrl_comm_unique_id -> %s\n", ddrl_status_string(cs));
     return 5;
@@ -96,6 +108,8 @@ int main(void) {
     CHECK(ddrl_ppo_iter(ctx, frames, actions, logps, adv, ret, B, B, NULL));
     if (comm) CHECK(ddrl_grad_allreduce(ctx, comm, NULL));
     CHECK(ddrl_clip_adam_step(ctx, NULL));
+    HIP(hipDeviceSynchronize());
+    STAGE("PPO iteration done");
   }
   HIP(hipDeviceSynchronize());
   float stats[DDRL_STATS_FLOATS], hprobs[N * 6];

@@ -7,8 +7,8 @@
 * ``param_deviation``: per parameter tensor, how far a flat fp32 parameter arena sits from p64 -- as a RATIO
   to how far the reference's own fp32 evaluations (1 thread, 8 threads, three batch orders) sit from it.
 * ``Margins``: every envelope-type bound of the tests is  measured_ratio <= limit  with the limits read from
-  tests/golden/margins.json (= the ratios measured on an MI355X + 50 %, rounded up).  ``DDRL_RECORD_MARGINS=1``
-  switches the asserts off and writes what was measured to gpurun_out/margins_measured.json instead.
+  tests/golden/margins.json (= the ratios measured on an MI355X + 50 %, rounded up) and CAPPED at 4 (8 rounding units
+  for the absolute accuracy entries); there is no switch that turns the asserts off.
 """
 import json
 import os
@@ -22,7 +22,6 @@ from oracle import ddrl_oracle as O
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 _MARGINS = os.path.join(GOLDEN, "margins.json")
-_RECORD = os.environ.get("DDRL_RECORD_MARGINS") == "1"
 _MEASURED_OUT = os.path.join(os.path.dirname(HERE), "gpurun_out", "margins_measured.json")
 
 MODES = {
@@ -30,6 +29,8 @@ MODES = {
     "default": ("f4b_spread_default", "f4_learn", "f4_learn", False, False),
     "shared": ("f10b_spread_shared", "f10_shared", "f10_shared", True, False),
     "smooth": ("f11c_spread_smooth", "f3_loss", "f11_smooth_l1", False, True),
+    # F21: Pong-like frames (regenerated from the recipe), advantages over eight decades, B = 512; the one file holds batch and spread
+    "pong": ("f21_pong_wide", "f21_pong_wide", "f21_pong_wide", False, False),
 }
 
 
@@ -37,11 +38,25 @@ def _load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
+_FRAMES = {}
+
+
+def mode_frames(mode):
+    if mode not in _FRAMES:
+        if mode == "pong":
+            from ddrl4nav_amd.utils.recipe import pong_frames
+            g = _load("f21_pong_wide")
+            _FRAMES[mode] = pong_frames(int(g["frame_seed"]), g["actions"].size)
+        else:
+            _FRAMES[mode] = _load("f3_loss")["frames"]
+    return _FRAMES[mode]
+
+
 def mode_batch(mode):
     """(frames u8, actions, old_logps, advs, rets) of a learner mode's fixture."""
     _, src, rsrc, _, _ = MODES[mode]
     g, r = _load(src), _load(rsrc)
-    return _load("f3_loss")["frames"], g["actions"], g["old_logps"], g["advs"], r["rets"]
+    return mode_frames(mode), g["actions"], g["old_logps"], g["advs"], r["rets"]
 
 
 _TRAJ = {}
@@ -157,24 +172,42 @@ def param_deviation(mode, it, flat_params):
     return deviation_ratios(got, traj["params"][it], traj["p0"], spread(mode), lambda n: "it%d/%s" % (it, n), group)
 
 
+# No envelope-type limit may exceed CAP: a ratio of 4 = "four times as far from the float64 run as the reference's own fp32
+# evaluations are", which is still inside the noise of a sign-like optimiser step; a wrong slice, sign or index shows up at
+# 50-1000 (deviation_ratios).  The "accuracy" entries are absolute (rounding units of sum |a b|) and capped at ACCURACY_CAP.
+# A key without an entry in margins.json gets the cap itself, so a new test can fail before anything was ever recorded.
+CAP = 4.0
+ACCURACY_CAP = 8.0
+
+
 class Margins:
-    """limit lookup + measurement log.  check(test, key, measured) asserts measured <= margins.json[test][key]."""
+    """limit lookup + measurement log.  check(test, key, measured) ALWAYS asserts measured <= min(margins.json[test][key], cap);
+    what was measured is logged to gpurun_out/margins_measured.json (input of tools/update_margins.py, which can only lower or
+    keep limits below the cap)."""
 
     def __init__(self):
         self.limits = json.load(open(_MARGINS)) if os.path.exists(_MARGINS) else {}
         self.measured = {}
 
+    def limit(self, test, key):
+        if test == "accuracy":
+            # absolute statements, not fitted to a run: a plane-product kernel's error against float64 stays within
+            # ACCURACY_CAP rounding units (2^-24) of sum |a b| (measured 0.6 - 4.3; an fp32 fma chain over K terms has up to K / 2),
+            # and its MEAN error within twice that of torch's own fp32 operator on the same inputs
+            return 2.0 if key.endswith("vs_torch_fp32") else ACCURACY_CAP
+        entry = self.limits.get(test, {}).get(key)
+        return min(float(entry["limit"]), CAP) if entry is not None else CAP
+
     def check(self, test, key, measured, where=""):
         measured = float(measured)
         slot = self.measured.setdefault(test, {})
         slot[key] = max(slot.get(key, 0.0), measured)
-        if _RECORD:
+        try:
             self._flush()
-            return
-        limit = self.limits.get(test, {}).get(key)
-        assert limit is not None, "tests/golden/margins.json has no limit for %s / %s (measured %.4g)" % (test, key, measured)
-        assert measured <= limit["limit"], "%s / %s: measured ratio %.4g exceeds the limit %.4g %s" % (
-            test, key, measured, limit["limit"], where)
+        except OSError:
+            pass
+        limit = self.limit(test, key)
+        assert measured <= limit, "%s / %s: measured ratio %.4g exceeds the limit %.4g %s" % (test, key, measured, limit, where)
 
     def _flush(self):
         os.makedirs(os.path.dirname(_MEASURED_OUT), exist_ok=True)
@@ -189,7 +222,6 @@ class Margins:
             for k, v in d.items():
                 o[k] = max(o.get(k, 0.0), v)
         json.dump(old, open(_MEASURED_OUT, "w"), indent=1, sort_keys=True)
-
 
 MARGINS = Margins()
 

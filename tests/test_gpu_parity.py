@@ -302,13 +302,13 @@ def test_clip_coefficient_and_norm(hp, onet, golden):
     np.testing.assert_allclose(s["ClipCoef"], min(1.0, 0.5 / (gn + 1e-6)), rtol=1e-6)
 
 
-def test_conv1_forward_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv1_forward_is_at_least_fp32_accurate(hp, kind):
     """The conv1 forward runs on the bf16 matrix pipe (exact-bf16 pixels x three bf16 planes of the fp32 weights,
     fp32 accumulation).  That is not a precision trade: against a float64 evaluation of the reference arithmetic its
     error must not exceed that of torch's own fp32 convolution (measured: about half of it)."""
     n = 96
-    rng = np.random.default_rng(31)
-    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+    frames = _inputs(n, 31, kind)[0]
     w = make_weights(0)
     hp.set_params(flatten(w))
     probs = torch.empty((n, 6), device="cuda")
@@ -326,17 +326,13 @@ def test_conv1_forward_is_at_least_fp32_accurate(hp):
         assert np.abs(a1 - ref).mean() <= 1.25 * np.abs(t32 - ref).mean() + 1e-12, pre
 
 
-def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp, kind):
     """Same statement for the conv1 weight gradient (dz1 split into three bf16 planes x exact-bf16 pixels): given
     the kernel's own dz1 and the frames, its dW1 must be as close to the float64 sum as an fp32 evaluation is."""
     n = 64
-    rng = np.random.default_rng(32)
-    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
-    acts = rng.integers(0, 6, size=n).astype(np.float32)
-    old = np.full(n, -1.79, dtype=np.float32)
-    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
-    hp.set_params(flatten(make_weights(0)))
-    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    frames = _inputs(n, 32, kind)[0]
+    _bwd_setup(hp, n, 32, kind)
     got = _grad_views(hp)
     x64 = torch.from_numpy(frames.astype(np.float64) / 255.0)
     cols64 = torch.nn.functional.unfold(x64, kernel_size=8, stride=4)          # [n, 256, 400]
@@ -352,20 +348,14 @@ def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp):
         assert err_kernel <= 1.5 * err_f32 + 1e-12, (pre, err_kernel, err_f32)
 
 
-def test_dense_forward_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_dense_forward_is_at_least_fp32_accurate(hp, kind):
     """The dense layer's forward in a training launch splits BOTH operands into three bf16 planes and sums six plane
     products in fp32 (fc_bf16x6_kernel).  Given the kernel's own a3, the error of h against the float64 product must
     stay within a few rounding units (2^-24) of sum_k |a_k w_k| (limit: tests/golden/margins.json = measured x 1.5) -- far below the n * eps bound of a sequential fp32
     chain over K = 3,136 (torch's blocked CPU matmul, whose error is reported alongside, is closer still)."""
     n = 200
-    rng = np.random.default_rng(33)
-    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
-    acts = rng.integers(0, 6, size=n).astype(np.float32)
-    old = np.full(n, -1.79, dtype=np.float32)
-    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
-    w = make_weights(0)
-    hp.set_params(flatten(w))
-    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    w = _bwd_setup(hp, n, 33, kind)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         a3 = hp.debug_buffer(2, (3136,), n, enc).cpu()
         h = hp.debug_buffer(3, (512,), n, enc).cpu().numpy().astype(np.float64)
@@ -377,19 +367,13 @@ def test_dense_forward_is_at_least_fp32_accurate(hp):
         P.MARGINS.check("accuracy", "dense_fwd_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
 
 
-def test_conv2_forward_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv2_forward_is_at_least_fp32_accurate(hp, kind):
     """conv2's forward in a training launch is a bf16x6 kernel too (conv_fwd2_bf16x6_kernel: weights pre-split, a1 split
     while staged, one MFMA k-group = the 16 taps of one input channel).  Given the kernel's own a1, a2 must be as close
     to the float64 convolution as torch's fp32 convolution is, and within a few rounding units of sum |a w| (margins.json)."""
     n = 100  # 34 tiles of 3 samples, the last one holds a single sample
-    rng = np.random.default_rng(34)
-    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
-    acts = rng.integers(0, 6, size=n).astype(np.float32)
-    old = np.full(n, -1.79, dtype=np.float32)
-    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
-    w = make_weights(0)
-    hp.set_params(flatten(w))
-    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    w = _bwd_setup(hp, n, 34, kind)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         a1 = hp.debug_buffer(0, (32, 20, 20), n, enc).cpu()
         a2 = hp.debug_buffer(1, (64, 9, 9), n, enc).cpu().numpy().astype(np.float64)
@@ -404,18 +388,12 @@ def test_conv2_forward_is_at_least_fp32_accurate(hp):
         print(pre, "conv2 fwd err", err_kernel, "torch f32", err_f32, "units of mass", err_kernel / (2.0 ** -24 * mass))
 
 
-def test_conv3_forward_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv3_forward_is_at_least_fp32_accurate(hp, kind):
     """Same statement for conv3's training-launch forward (conv_fwd3_bf16x6_kernel: a2 staged channel-innermost, one
     MFMA k-group = two taps x eight channels, the tenth tap padded with zero weights)."""
     n = 101  # 21 tiles of 5 samples, the last one holds a single sample
-    rng = np.random.default_rng(35)
-    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
-    acts = rng.integers(0, 6, size=n).astype(np.float32)
-    old = np.full(n, -1.79, dtype=np.float32)
-    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
-    w = make_weights(0)
-    hp.set_params(flatten(w))
-    hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
+    w = _bwd_setup(hp, n, 35, kind)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         a2 = hp.debug_buffer(1, (64, 9, 9), n, enc).cpu()
         a3 = hp.debug_buffer(2, (64, 7, 7), n, enc).cpu().numpy().astype(np.float64)
@@ -428,12 +406,30 @@ def test_conv3_forward_is_at_least_fp32_accurate(hp):
         assert np.abs(a3 - ref).mean() <= 1.5 * np.abs(f32 - ref).mean() + 1e-12, (pre, np.abs(a3 - ref).mean(), np.abs(f32 - ref).mean())
 
 
-def _bwd_setup(hp, n, seed):
+KINDS = ["uniform", "pong_wide"]
+
+
+def _inputs(n, seed, kind="uniform"):
+    """(frames u8, actions, old_logps, advs, rets).  "uniform": dense random bytes, N(0,1) advantages (the worst case for time).
+    "pong_wide": mostly flat Pong frames (utils.recipe.pong_frames) and advantages log-uniform over 1e-4 .. 10 with one sample
+    x 1000 -- the realistic input and a dynamic range of eight decades across the samples."""
     rng = np.random.default_rng(seed)
-    frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
     acts = rng.integers(0, 6, size=n).astype(np.float32)
     old = np.full(n, -1.79, dtype=np.float32)
-    adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    if kind == "uniform":
+        frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+        adv, ret = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    else:
+        from ddrl4nav_amd.utils.recipe import pong_frames
+        frames = pong_frames(seed, n)
+        adv = (rng.choice(np.array([-1.0, 1.0]), size=n) * 10.0 ** rng.uniform(-4.0, 1.0, size=n)).astype(np.float32)
+        adv[n // 2] *= np.float32(1000.0)
+        ret = (adv + rng.normal(size=n).astype(np.float32) * np.float32(0.1)).astype(np.float32)
+    return frames, acts, old, adv, ret
+
+
+def _bwd_setup(hp, n, seed, kind="uniform"):
+    frames, acts, old, adv, ret = _inputs(n, seed, kind)
     w = make_weights(0)
     hp.set_params(flatten(w))
     hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
@@ -445,12 +441,13 @@ def _leaky_mask(a, g):
     return torch.where(a > 0, g, g * 0.01)
 
 
-def test_dense_data_gradient_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_dense_data_gradient_is_at_least_fp32_accurate(hp, kind):
     """fc_dgrad_bf16x6_kernel (dh and the transposed weight planes split into three bf16 planes each, six plane products,
     leaky mask in the epilogue): given the kernel's own dh and a3, dz3 against the float64 product, in rounding units of
     sum_k |dh_k w_k| and beside torch's fp32 matmul."""
     n = 200
-    w = _bwd_setup(hp, n, 41)
+    w = _bwd_setup(hp, n, 41, kind)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         dh = hp.debug_buffer(7, (512,), n, enc).cpu()
         a3 = hp.debug_buffer(2, (3136,), n, enc).cpu()
@@ -465,13 +462,14 @@ def test_dense_data_gradient_is_at_least_fp32_accurate(hp):
         P.MARGINS.check("accuracy", "dense_dgrad_mean_vs_torch_fp32", np.abs(dz3 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
-def test_dense_weight_gradient_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_dense_weight_gradient_is_at_least_fp32_accurate(hp, kind):
     """fc_wgrad_bf16x6_kernel (dh and a3 split into three bf16 planes while staged, fragments through the transposing LDS
     read, six plane products, split over the batch and summed in fixed order): given the kernel's own dh and a3,
     dW = dh^T a3 and db = column sums of dh against float64, beside torch's fp32 matmul.  n = 333 leaves a ragged last
     k-block and k-tile 24 is the half-empty one (3136 = 24.5 x 128)."""
     n = 333
-    _bwd_setup(hp, n, 44)
+    _bwd_setup(hp, n, 44, kind)
     got = _grad_views(hp)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         dh = hp.debug_buffer(7, (512,), n, enc).cpu()
@@ -488,12 +486,13 @@ def test_dense_weight_gradient_is_at_least_fp32_accurate(hp):
 
 
 @pytest.mark.parametrize("n", [101, 6])
-def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n, kind):
     """conv_wgrad3_bf16x6_kernel (dz3 and a2 staged channel-innermost as three bf16 planes each, fragments through the
     transposing LDS read, 2 samples per stage, 128 sample splits summed in fixed order): given the kernel's own dz3 and
     a2, dW3 and db3 against float64, beside torch's fp32 weight gradient.  n = 101 leaves a one-sample last stage and
     most of the 128 splits empty; n = 6 leaves all but three empty."""
-    _bwd_setup(hp, n, 45)
+    _bwd_setup(hp, n, 45, kind)
     got = _grad_views(hp)
     g = torch.nn.grad
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
@@ -511,10 +510,11 @@ def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n):
 
 
 @pytest.mark.parametrize("n", [77, 3])
-def test_conv2_weight_gradient_is_at_least_fp32_accurate(hp, n):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv2_weight_gradient_is_at_least_fp32_accurate(hp, n, kind):
     """conv_wgrad2_bf16x6_kernel (dz2 and a1 staged channel-innermost as three bf16 planes each, one sample per stage,
     fragments through the transposing LDS read): given the kernel's own dz2 and a1, dW2 and db2 against float64."""
-    _bwd_setup(hp, n, 46)
+    _bwd_setup(hp, n, 46, kind)
     got = _grad_views(hp)
     g = torch.nn.grad
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
@@ -531,11 +531,12 @@ def test_conv2_weight_gradient_is_at_least_fp32_accurate(hp, n):
                                    atol=8 * 2.0 ** -24 * float(dz2.double().abs().sum((0, 2, 3)).max()))
 
 
-def test_conv3_data_gradient_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv3_data_gradient_is_at_least_fp32_accurate(hp, kind):
     """conv_dgrad3_bf16x6_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
     against float64."""
     n = 101
-    w = _bwd_setup(hp, n, 42)
+    w = _bwd_setup(hp, n, 42, kind)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         dz3 = hp.debug_buffer(6, (64, 7, 7), n, enc).cpu()
         a2 = hp.debug_buffer(1, (64, 9, 9), n, enc).cpu()
@@ -551,11 +552,12 @@ def test_conv3_data_gradient_is_at_least_fp32_accurate(hp):
         P.MARGINS.check("accuracy", "conv3_dgrad_mean_vs_torch_fp32", np.abs(dz2 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
-def test_conv2_data_gradient_is_at_least_fp32_accurate(hp):
+@pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
+def test_conv2_data_gradient_is_at_least_fp32_accurate(hp, kind):
     """conv_dgrad2_bf16x6_kernel: given the kernel's own dz2, the RAW gradient w.r.t. a1 (conv1's leaky mask is applied
     later, by the conv1 weight gradient) = conv_transpose(dz2, W2, stride 2) against float64."""
     n = 100
-    w = _bwd_setup(hp, n, 43)
+    w = _bwd_setup(hp, n, 43, kind)
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         dz2 = hp.debug_buffer(5, (64, 9, 9), n, enc).cpu()
         da1 = hp.debug_buffer(4, (32, 20, 20), n, enc).cpu().numpy().astype(np.float64)

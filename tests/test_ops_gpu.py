@@ -177,3 +177,51 @@ def test_conv_full_batch_size_vs_torch_gpu(shape):
     conv.wgrad(x.detach(), dz, dw, db)
     close(dw, wt.grad, tol=2e-4)   # sums over 512 x oh x ow signed terms
     close(db, b.grad, tol=2e-4)
+
+
+@pytest.mark.parametrize("order", ["critic_below_actor", "critic_above_actor"])
+def test_heads_take_the_two_feature_buffers_at_any_relative_address(order):
+    """ddrl_op_heads_act / ddrl_op_heads_loss receive the actor's and the critic's feature (and gradient) buffers as two
+    independent pointers; the kernels address the critic's as actor + stride, and that stride may be NEGATIVE.  (A "stride < 0
+    means unset" test once sent every net whose critic buffer lay below its actor buffer to actor + n * 512: wrong values in a
+    fresh process, right ones whenever the allocator happened to order the two the other way.)"""
+    from ctypes import byref, c_void_p
+    from ddrl4nav_amd import _lib
+    from ddrl4nav_amd._lib import HeadsDesc, check, default_config
+    lib = _lib.load()
+    n, A = 37, 5
+    g = torch.Generator().manual_seed(5)
+    Wa, ba = torch.randn(A, 512, generator=g) * 0.05, torch.randn(A, generator=g) * 0.1
+    wc, bc = torch.randn(512, generator=g) * 0.05, torch.randn(1, generator=g)
+    params = torch.cat([Wa.reshape(-1), ba, wc, bc]).cuda()
+    d = HeadsDesc()
+    d.continuous, d.n_actions, d.shared = 0, A, 0
+    d.actor_w, d.actor_b, d.critic_w, d.critic_b, d.n_params = 0, A * 512, A * 512 + A, A * 512 + A + 512, params.numel()
+    feats = torch.randn(2, n, 512, generator=g).cuda()
+    ia, ic = (1, 0) if order == "critic_below_actor" else (0, 1)
+    ha, hc = feats[ia], feats[ic]
+    acts = torch.randint(0, A, (n,), generator=g).float().cuda()
+    f = dict(dtype=torch.float32, device="cuda")
+    probs, value, logp = torch.empty((n, A), **f), torch.empty(n, **f), torch.empty(n, **f)
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: c_void_p(t.data_ptr())
+    check(lib.ddrl_op_heads_act(byref(d), p(params), p(ha), p(hc), n, p(acts), 0, 0, p(probs), p(value), c_void_p(0), p(logp), st))
+    want_v = hc.cpu() @ wc + bc
+    want_p = torch.softmax(ha.cpu() @ Wa.T + ba, dim=-1)
+    close(value, want_v)
+    close(probs, want_p)
+    # loss + head backward: d loss / d h of BOTH encoders land in their own buffers
+    from ctypes import c_int64
+    wf = c_int64()
+    check(lib.ddrl_op_heads_ws_floats(byref(d), n, byref(wf)))
+    ws = torch.empty(wf.value, **f)
+    dh = torch.zeros(2, n, 512, **f)
+    grads = torch.zeros(params.numel() + 8, **f)
+    cfg = default_config(max_batch=n, n_actions=A)
+    old = (torch.log(want_p.gather(1, acts.cpu().long()[:, None])[:, 0]) + 0.1 * torch.randn(n, generator=g)).cuda()
+    adv, ret = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    check(lib.ddrl_op_heads_loss(byref(d), byref(cfg), p(params), p(ha), p(hc), n, p(acts), p(old), p(adv), p(ret), n, p(dh[ia]),
+                                 p(dh[ic]), p(grads), p(ws), st))
+    want_dv = (want_v - ret.cpu()) / n                      # d (mean((ret - v)^2) / 2) / d v
+    close(dh[ic], want_dv[:, None] * wc[None, :])
+    assert float(dh[ia].abs().max()) > 0

@@ -405,3 +405,71 @@ def test_nav_oracle_float64_trajectory_pinned(name):
         for k, a in tr["params"][it].items():
             np.testing.assert_allclose(np.sqrt((a ** 2).sum()), sp["f64_l2/it%d/%s" % (it, k)], rtol=1e-11)
             np.testing.assert_allclose(a.ravel()[:8], sp["f64_head/it%d/%s" % (it, k)], rtol=0, atol=1e-12)
+
+
+# ---- F21: Pong-like frames, advantages over eight decades (tests/golden/make_golden_pong.py) ---------------------------
+def _f21(golden):
+    import hashlib
+    from ddrl4nav_amd.utils.recipe import pong_frames
+    g = golden("f21_pong_wide")
+    frames = pong_frames(int(g["frame_seed"]), g["actions"].size)
+    assert hashlib.sha256(frames.tobytes()).digest() == g["frames_sha256"].tobytes(), "pong_frames recipe changed"
+    t = lambda k: torch.from_numpy(g[k])
+    return g, frames, O.frames_to_f32(frames), t("actions"), t("old_logps"), t("advs"), t("rets")
+
+
+def test_f21_pong_forward_losses_gradients_and_per_sample_norms(golden):
+    """The oracle on the realistic / wide-range fixture: forward and losses bit-exact, the full gradient's checksums and
+    samples, and the PER-SAMPLE L2 norms of d loss / d conv1-pre-activation and d loss / d encoder output -- the quantities
+    the GPU tests' per-sample relative bounds are scaled by -- against the reference's own autograd."""
+    g, frames, x, a, ol, adv, ret = _f21(golden)
+    assert (frames == 87).mean() > 0.98 and float(np.abs(g["advs"]).max() / np.abs(g["advs"]).min()) > 1e7
+    torch.set_num_threads(1)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    with torch.no_grad():
+        probs, _, logits, v = net(x)
+    assert np.array_equal(probs.numpy(), g["probs"]) and np.array_equal(v.numpy()[:, 0], g["value"])
+    assert np.array_equal(O.categorical_log_prob(logits, a).numpy(), g["logp"])
+    net.actor.pre.tap, net.critic.pre.tap = {}, {}
+    total, al, vl, ent = O.ppo_losses(net, x, a, ol, adv, ret)
+    assert (np.float32(al.item()), np.float32(vl.item()), np.float32(ent.item()), np.float32(total.item())) == (
+        g["actor_loss"], g["v_loss"], g["ent"], g["total"])
+    al.backward()
+    vl.backward()
+    B = a.numel()
+    for e, enc in enumerate((net.actor.pre, net.critic.pre)):
+        for key, name in (("z1", "dz1_l2"), ("h", "dh_l2")):
+            got = enc.tap[key].double().reshape(B, -1).norm(dim=1).numpy()
+            np.testing.assert_allclose(got, g[name][e], rtol=1e-12, atol=0)
+        enc.tap = None
+    assert float(g["dz1_l2"].max() / g["dz1_l2"][g["dz1_l2"] > 0].min()) > 1e6  # per-sample gradients span > 20 binades
+    for k, p in net.named_parameters():
+        gr = p.grad.numpy()
+        assert np.array_equal(gr.reshape(-1)[:64], g["ghead/" + k]), k
+        assert np.array_equal(gr.reshape(-1)[::max(1, gr.size // 257)][:257], g["gstride/" + k]), k
+        np.testing.assert_allclose(np.sqrt((gr.astype(np.float64) ** 2).sum()), g["gl2/" + k], rtol=1e-12)
+
+
+def test_f21_pong_learn_sequence_fp32_and_float64(golden):
+    g, _, x, a, ol, adv, ret = _f21(golden)
+    torch.set_num_threads(1)
+    net = O.OraclePPO()
+    net.load_weights(make_weights(0))
+    for it, (ld, ut, last) in enumerate(O.learn(net, net.make_optims(), x, a, ol, adv, ret), 1):
+        got = [ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]]
+        np.testing.assert_allclose(got, g["losses"][it - 1], rtol=1e-6, atol=1e-7)
+        if it in (1, 10):
+            for k, p in net.named_parameters():
+                arr = p.detach().numpy().reshape(-1)
+                np.testing.assert_allclose(arr[::max(1, arr.size // 257)][:257], g["it%d/stride/%s" % (it, k)], rtol=1e-6, atol=2e-8)
+    assert it == 10
+    # the float64 run = the yardstick of the GPU sequence test (parity_util.f64_trajectory("pong"))
+    import parity_util as P
+    traj = P.f64_trajectory("pong")
+    np.testing.assert_allclose(traj["losses"], g["losses_f64"], rtol=1e-11, atol=1e-13)
+    for it in (1, 10):
+        for k, arr in traj["params"][it].items():
+            key = "it%d/%s" % (it, k)
+            np.testing.assert_allclose(arr.sum(), g["f64_sum/" + key], rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(arr.ravel()[:8], g["f64_head/" + key], rtol=1e-10, atol=1e-14)

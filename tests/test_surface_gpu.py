@@ -316,7 +316,10 @@ def test_c_abi_from_plain_c(tmp_path):
                     "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include", "-L", lib_dir, "-L", "/opt/rocm/lib",
                     "-lddrl_hip", "-lamdhip64", "-lm", "-o", exe], check=True, timeout=300)
     env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    try:
+        out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    except subprocess.TimeoutExpired as e:  # the stage markers on stderr say where it stopped
+        raise AssertionError("abi_smoke hung; stderr so far:\n%s" % (e.stderr.decode() if isinstance(e.stderr, bytes) else e.stderr))
     assert out.returncode == 0, out.stderr
     assert "C ABI OK" in out.stdout
 
