@@ -42,7 +42,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA (
 PIPE = {"ConvFwd1": ("f16x2", 2), "ConvWgrad1": ("f16x2", 2), "ConvFwd2": ("f16x3", 3), "ConvFwd3": ("f16x3", 3),
         "FcFwd": ("f16x3", 3), "FcDgrad": ("f16x3", 3), "ConvDgrad3": ("f16x3", 3), "ConvDgrad2": ("f16x3", 3),
         "FcWgrad": ("f16x3", 3), "ConvWgrad3": ("f16x3", 3), "ConvWgrad2": ("f16x3", 3)}
-# executed / algorithmic MFMA work of the kernels that walk padded operands
+# executed / algorithmic MFMA work of the kernels that walk padded operands: the DESIGN figures, used only
+# when the newest committed PMC profile carries no SQ_INSTS_MFMA for a kernel (executed_over_algorithmic() below)
 EXECUTED_OVER_ALGORITHMIC = {"ConvDgrad3": 81.0 / 49.0, "ConvDgrad2": 1.23, "ConvFwd3": 1.11, "ConvWgrad3": 112.0 / 98.0,
                              "ConvWgrad2": 96.0 / 81.0, "ConvWgrad1": 48.0 / 40.0}
 PEAK_HBM_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -251,13 +252,30 @@ def pmc_traffic(kernel):
              "ConvDgrad3": "conv_dgrad3_planes", "ConvDgrad2": "conv_dgrad2_both", "ConvWgrad3": "conv_wgrad3_planes",
              "ConvWgrad2": "conv_wgrad2_planes"}
     try:
-        ks = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        ks = doc["kernels"]
         k = ks.get(kernel) or ks.get(alias.get(kernel, ""))
-        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes"], "fetch_bytes": k["fetch_bytes"],
-                                       "write_bytes": k["write_bytes"], "mfma_busy_frac": k["mfma_busy_frac"],
-                                       "clock_ghz": k["clock_ghz"], "source": os.path.basename(files[-1])}
+        if k is None:
+            return None
+        out = {"hbm_bytes_per_launch": k["hbm_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
+               "mfma_busy_frac": k["mfma_busy_frac"], "clock_ghz": k["clock_ghz"], "source": os.path.basename(files[-1]),
+               # NOT this run: the committed rocprofv3 --pmc passes of the named build on the named box (bench.py never profiles)
+               "measured_on": {"build": doc.get("build", ""), "box": doc.get("box", ""), "batch": doc.get("batch", 65536)}}
+        if "mfma_insts" in k and kernel in MAC and kernel in PIPE:
+            # executed / algorithmic matrix work from SQ_INSTS_MFMA: one v_mfma_f32_32x32x16_f16 = 16,384 MAC per wave
+            alg = MAC[kernel] * doc.get("batch", 65536) * 2 * PIPE[kernel][1] / 16384.0
+            out["executed_over_algorithmic"] = round(k["mfma_insts"] / alg, 3)
+            if "valu_insts" in k:
+                out["valu_per_mfma"] = round(k["valu_insts"] / k["mfma_insts"], 2)
+        return out
     except Exception:
         return None
+
+
+def executed_over_algorithmic(kernel):
+    """From the newest committed PMC profile (SQ_INSTS_MFMA) where it has the counter, else the design figure."""
+    t = pmc_traffic(kernel) or {}
+    return t.get("executed_over_algorithmic", round(EXECUTED_OVER_ALGORITHMIC.get(kernel, 1.0), 3))
 
 
 def async_actor_leg(net, config_nn, N, T, ITERS, dev, steps=3):
@@ -409,6 +427,46 @@ def build_net(n_envs, horizon, iters, max_batch=None):
                       max_batch=max_batch if max_batch is not None else n_envs * horizon), config_nn
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes -- fresh interpreters, one per GPU, RCCL ("nccl")
+    between them -- BEFORE this process makes any GPU call (it never does: a process that has initialised the GPU must not be
+    replaced or forked into ranks), wait for all of them, pass rank 0's JSON line through and fail when any rank fails.  The
+    driver's own form (python -m torch.distributed.run ... bench.py --gpus N) sets WORLD_SIZE and takes the other path."""
+    import socket
+    import subprocess
+    n = args.gpus
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+    env_base = dict(os.environ)
+    if ndev < n:
+        if not args.share_gpu:
+            sys.stderr.write("bench.py: --gpus %d but this host shows %d GPU(s); pass --share-gpu for a gloo rehearsal of the "
+                             "rank plumbing (not a scaling measurement)\n" % (n, ndev))
+            return 2
+        env_base["DDRL_DIST_BACKEND"] = "gloo"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    procs = []
+    for r in range(n):
+        env = dict(env_base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DDRL_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if any(codes) or not line:
+        sys.stderr.write("bench.py: rank exit codes %s, %d JSON line(s) from rank 0\n" % (codes, len(line)))
+        return 1
+    got = json.loads(line[-1])
+    if got.get("n_gpus") != n or got.get("ranks_joined") != n:
+        sys.stderr.write("bench.py: %s of %d ranks joined\n" % (got.get("ranks_joined"), n))
+        return 1
+    print(line[-1])
+    return 0
+
+
 def main():
     if "--torch-leg" in sys.argv:  # child process of cpu_baseline(): the same-GPU PyTorch-ROCm comparison
         return torch_leg_main()
@@ -423,7 +481,15 @@ def main():
     ap.add_argument("--no-async", action="store_true", help="skip the asynchronous actor/learner leg")
     ap.add_argument("--no-ingest", action="store_true", help="skip the leg that feeds the frames through the pinned-host ring")
     ap.add_argument("--ingest-memcpy", action="store_true", help="ingest leg: the producer also copies 7.2 MB per step into the slot")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: the ranks share the devices round-robin and reduce over gloo "
+                         "(DDRL_DIST_BACKEND=gloo); never a measurement of scaling")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s\n" % (args.gpus, os.environ["WORLD_SIZE"]))
+        return 2
 
     from ddrl4nav_amd.dist import broadcast_params, init_from_env
     rank, world, local_rank = init_from_env()
@@ -498,10 +564,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
+        elapsed = max(per_rank)
     stats = hp.stats()
     ar_ms = hp.allreduce_ms() if world > 1 else []
     hp.time_allreduce(False)
@@ -534,7 +603,7 @@ def main():
                     ent["pipe"] = pipe
                     ent["pipe_ceiling_tflops"] = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
                     ent["frac_of_pipe_ceiling"] = round(ent["tflops"] / (PEAK_BF16_MFMA_TFLOPS / products), 4)
-                    ent["executed_over_algorithmic"] = round(EXECUTED_OVER_ALGORITHMIC.get(k, 1.0), 3)
+                    ent["executed_over_algorithmic"] = executed_over_algorithmic(k)
             elif k in HBM_BYTES:
                 # HBM-bound kernels: algorithmic bytes per launch / launch time
                 per_launch = HBM_BYTES[k](N, B, hp.n_params)
@@ -556,7 +625,7 @@ def main():
                         "traffic_detail": pmc_traffic(dom),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
                         "algorithmic_flop_per_launch": d["flop_per_launch"], "pipe": pipe,
-                        "executed_over_algorithmic": round(EXECUTED_OVER_ALGORITHMIC.get(dom, 1.0), 3),
+                        "executed_over_algorithmic": executed_over_algorithmic(dom),
                         "note": "dominant training kernel (largest accumulated time).  achieved = ALGORITHMIC fp32 FLOP (2*2*MAC per "
                                 "sample, both encoders, x B) / launch time from HIP events on the launch stream; peak = the ceiling of the "
                                 "pipe the kernel runs on: dense 16-bit MFMA 2.5 PFLOP/s / plane products (3 for two fp32 operands as two "
@@ -573,10 +642,17 @@ def main():
             "metric": "env-steps/sec (whole node) + PPO update ms, Pong 256 envs at 1/2/4/8 GPUs",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "arithmetic": "f16x3 split-plane MFMA (f16x2 where the pixels are exact), fp32 accumulate, "
+                                                                "per-sample power-of-two scales in the backward",
+            "data": "synthetic",
             "config": {"workload": "PongNoFrameskip-v4 shape, %d envs/GPU x T=%d, %d PPO iterations on B=%d samples/GPU, "
                                    "2 AtariPreNet encoders (SHARE_CNN_NET=False), A=6" % (N, T, ITERS, B),
                        "envs_per_gpu": N, "horizon": T, "ppo_iters": ITERS, "parallelism": "dp%d" % world},
+            "ranks_joined": world if world == 1 else dist.get_world_size(),
+            "launcher": os.environ.get("DDRL_BENCH_LAUNCHER") or ("torchrun" if world > 1 else "none"),
+            "elapsed_s_per_rank": [round(t, 4) for t in per_rank],
+            "devices": {"visible": torch.cuda.device_count(), "rank0": torch.cuda.get_device_name(dev),
+                        "shared_by_ranks": bool(world > torch.cuda.device_count())},
             "ppo_update_ms": round(upd_ms, 2), "ppo_iter_ms": round(upd_ms / ITERS, 3),
             "acting_ms_per_rollout": round(phase["act_ms"] / steps, 2), "gae_ms": round(phase["gae_ms"] / steps, 4),
             "acting_env_steps_per_s_per_gpu": round(N * (T + 1) / (phase["act_ms"] / steps * 1e-3), 1),
@@ -623,4 +699,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -97,3 +97,24 @@ def test_single_rank_worker_equals_in_process_run(tmp_path, golden):
         assert [s["PpoTotalLoss"], s["ActorLoss"], s["VLoss"], s["EntLoss"]] == list(r0["losses"][it - 1])
     assert np.array_equal(h.params.cpu().numpy(), r0["params_it10"])
     h.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun): two fresh rank processes, started before any GPU call of the parent, join one
+    process group and rank 0 prints ONE line with n_gpus = 2.  This box has one GPU, so the ranks share it and reduce over gloo
+    (--share-gpu: a rehearsal of the plumbing, not a scaling measurement); on an 8-GPU node the same path runs over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "1",
+                          "--envs", "32", "--horizon", "16", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["launcher"] == "self" and len(d["elapsed_s_per_rank"]) == 2
+    assert d["allreduce"]["calls"] == 10 and d["allreduce"]["backend"] in ("gloo", "nccl")
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0

@@ -197,3 +197,23 @@ def test_mimic_dataset_reader_and_batch_order_match_reference(golden, tmp_path, 
             assert np.array_equal(batch[1].numpy(), g["%s/epoch%d/batch%d/y" % (kind, epoch, bi)])
             if bi == 1:
                 break
+
+
+def test_bench_gpus_n_refuses_to_pretend(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself; on a host with fewer GPUs it must fail loudly
+    (exit code 2) instead of running one GPU and printing n_gpus: 1."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return  # a multi-GPU host runs the real thing (tests/test_dist_gpu.py covers the one-GPU rehearsal)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "--gpus 2" in out.stderr and not out.stdout.strip()
+    # a launcher that disagrees with --gpus is refused as well
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr

@@ -77,7 +77,16 @@ def main():
             if "SQ_VALU_MFMA_BUSY_CYCLES" in a and cyc > 0:
                 # the counter ticks once per busy cycle per SIMD -> busy fraction = sum / (SIMDs x cycles)
                 e["mfma_busy_frac"] = round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cyc), 4)
+        # exact wave-instruction counts (SQ_INSTS_MFMA of ConvFwd1 / FcFwd equals their algorithmic count to four digits):
+        # bench.py derives executed / algorithmic matrix work and VALU per MFMA from them
+        if "SQ_INSTS_MFMA" in a:
+            e["mfma_insts"] = a["SQ_INSTS_MFMA"]
+        if "SQ_INSTS_VALU" in a:
+            e["valu_insts"] = a["SQ_INSTS_VALU"]
         traffic["kernels"][k] = e
+    traffic["batch"] = int(os.environ.get("DDRL_PROFILE_BATCH", "65536"))  # tools/profile_iter.py's B (training launches)
+    traffic["build"] = os.environ.get("DDRL_PROFILE_BUILD", "")            # git revision / note of the profiled build
+    traffic["box"] = os.environ.get("DDRL_PROFILE_BOX", "")                # host the passes ran on
     with open(tag + "_pmc_traffic.json", "w") as out:
         json.dump(traffic, out, indent=1, sort_keys=True)
     print("wrote", tag + "_pmc_per_kernel.csv", tag + "_pmc_traffic.json", "(%d kernels)" % len(agg))
