@@ -2,7 +2,7 @@
 library is missing or a call fails this module raises."""
 import ctypes
 import os
-from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_float, c_int32, c_int64, c_uint64,
+from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_float, c_int32, c_int64, c_uint64,
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -142,7 +142,7 @@ SIGNATURES = {
     "ddrl_op_wgan_terms": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_float, c_void_p, c_int64, c_int32, c_void_p,
                                      c_int32, c_void_p]),
     "ddrl_op_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
-    "ddrl_op_clip_rmsprop": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
+    "ddrl_op_clip_rmsprop": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_double, c_float, c_float, c_void_p,
                                        c_void_p]),
 }
 

@@ -48,9 +48,12 @@ class Agents:
         self.discounts_tmp, self.landa = [config_nn.EXTRINSIC_DISCOUNT], config_nn.LANDA
         self.T = getattr(config, "TIME_MAX", 256)
         self.value_dim_num = self.reward_dim_num = 1
-        # The reference hard-codes network_type = 'ppo' here (agent.py:95), which switches its own GAIL branch off; this
-        # mirror follows the config so that NETWORK_TYPE = "gail" gets the second value / reward row (agent.py:97-101).
-        self.network_type = getattr(config_nn, "NETWORK_TYPE", "ppo")
+        # The reference hard-codes network_type = 'ppo' here (agent.py:95), which switches its own GAIL branch (agent.py:97-101) off:
+        # its GAIL runs carry ONE value / reward row and ppo.py's data.values[-1] is the extrinsic return.  Identical results are
+        # the contract, so that is the default here too; config_nn.GAIL_TWO_ROW_VALUES = True opts into the second (GAIL)
+        # value / reward row the dead branch describes (a deviation from the reference, listed in INTEGRATION.md).
+        two_rows = getattr(config_nn, "NETWORK_TYPE", "ppo") == "gail" and bool(getattr(config_nn, "GAIL_TWO_ROW_VALUES", False))
+        self.network_type = "gail" if two_rows else "ppo"
         if self.network_type == 'gail':
             self.reward_dim_num += 1
             if config_nn.GAN_VALUE_TRICK:

@@ -70,6 +70,7 @@ const char* ddrl_status_string(int32_t s) {
     case DDRL_ERR_HIP: return "HIP runtime error";
     case DDRL_ERR_NO_DEVICE: return "no HIP device";
     case DDRL_ERR_TIMEOUT: return "timeout";
+    case DDRL_ERR_NO_MEMORY: return "out of host memory";
     default: return "unknown status";
   }
 }
@@ -138,7 +139,7 @@ int32_t ddrl_ctx_create(const ddrl_config* c, float* params, float* grads, float
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DDRL_ERR_NO_DEVICE;
   ddrl_ctx* ctx = new (std::nothrow) ddrl_ctx();
-  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  if (!ctx) return DDRL_ERR_NO_MEMORY;
   ctx->cfg = *c;
   ctx->L = make_layout(c->n_actions, c->in_channels, c->share_cnn_net != 0);
   const int64_t need = carve(ctx->ws, *c, workspace);
@@ -401,7 +402,7 @@ int32_t ddrl_ring_create(int64_t slot_bytes, int32_t n_slots, ddrl_ring** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DDRL_ERR_NO_DEVICE;
   ddrl_ring* r = new (std::nothrow) ddrl_ring();
-  if (!r) return DDRL_ERR_INVALID_ARG;
+  if (!r) return DDRL_ERR_NO_MEMORY;
   r->slot_bytes = (slot_bytes + 255) / 256 * 256;
   r->n_slots = n_slots;
   void* p = nullptr;
@@ -495,7 +496,7 @@ struct ddrl_timer {
 int32_t ddrl_timer_create(void** t) {
   if (!t) return DDRL_ERR_INVALID_ARG;
   ddrl_timer* x = new (std::nothrow) ddrl_timer();
-  if (!x) return DDRL_ERR_INVALID_ARG;
+  if (!x) return DDRL_ERR_NO_MEMORY;
   if (hipEventCreate(&x->a) != hipSuccess || hipEventCreate(&x->b) != hipSuccess) {
     delete x;
     return DDRL_ERR_HIP;

@@ -82,7 +82,7 @@ int32_t ddrl_comm_create(const uint8_t* id128, int32_t rank, int32_t world, ddrl
   Rccl& r = rccl();
   if (!r.ok) return DDRL_ERR_UNSUPPORTED;
   ddrl_comm* c = new (std::nothrow) ddrl_comm();
-  if (!c) return DDRL_ERR_INVALID_ARG;
+  if (!c) return DDRL_ERR_NO_MEMORY;
   nccl_unique_id id;
   std::memcpy(id.internal, id128, 128);
   if (r.comm_init_rank(&c->comm, world, id, rank) != 0) {

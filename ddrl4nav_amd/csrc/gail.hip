@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 struct RmsArgs {
-  float lr, alpha, eps, max_norm;
+  float lr, alpha, one_minus_alpha, eps, max_norm;  // one_minus_alpha = float(1.0 - alpha) in DOUBLE, as torch casts `value = 1 - alpha`
 };
 
 // clip_grad_norm_ over the whole arena, then torch.optim.RMSprop (no momentum, not centered):
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void clip_rmsprop_kernel(float* __restrict__ p
   const float coef = s_coef;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * coef;
-    const float si = sq[i] * a.alpha + ((1.0f - a.alpha) * gi) * gi;
+    const float si = sq[i] * a.alpha + (a.one_minus_alpha * gi) * gi;
     const float avg = sqrtf(si) + a.eps;
     p[i] = p[i] + ((-a.lr) * gi) / avg;
     sq[i] = si;
@@ -269,13 +269,15 @@ int32_t ddrl_op_colsum(const float* x, int64_t ld, int32_t n, int32_t width, flo
   return g_check();
 }
 
-int32_t ddrl_op_clip_rmsprop(float* params, float* grads, float* square_avg, int64_t n_params, float lr, float alpha, float eps,
+int32_t ddrl_op_clip_rmsprop(float* params, float* grads, float* square_avg, int64_t n_params, float lr, double alpha, float eps,
                              float max_norm, void* ws, void* stream) {
-  if (!params || !grads || !square_avg || !ws || n_params < 1 || !(lr > 0.0f) || !(alpha >= 0.0f) || !(max_norm > 0.0f))
+  if (!params || !grads || !square_avg || !ws || n_params < 1 || !(lr > 0.0f) || !(alpha >= 0.0) || !(max_norm > 0.0f))
     return DDRL_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(sqnorm2_kernel, dim3(NORM_WG), dim3(256), 0, st, grads, n_params, (double*)ws);
-  RmsArgs a{lr, alpha, eps, max_norm};
+  // torch.optim.RMSprop: square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha) -- alpha and 1 - alpha are Python doubles, each
+  // cast to float32 once: float(1 - 0.9) = 0.1f, whereas 1.0f - 0.9f = 0.100000024f (2.4e-7 off in every step)
+  RmsArgs a{lr, (float)alpha, (float)(1.0 - alpha), eps, max_norm};
   hipLaunchKernelGGL(clip_rmsprop_kernel, dim3(2048), dim3(256), 0, st, params, grads, square_avg, n_params, (const double*)ws,
                      NORM_WG, a);
   return g_check();

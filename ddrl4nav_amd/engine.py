@@ -56,9 +56,19 @@ class HotPath:
         if os.environ.get("DDRL_ALLREDUCE") == "rccl" and tdist.is_available() and tdist.is_initialized() \
                 and tdist.get_world_size(process_group) > 1:
             from .dist import RcclComm
-            self.comm = RcclComm(tdist.get_rank(process_group), tdist.get_world_size(process_group), group=process_group)
+            world = tdist.get_world_size(process_group)
+            # one RCCL rank per device: ranks that share a GPU (the gloo rehearsal of single-GPU boxes) would hang or fail inside
+            # ncclCommInitRank on duplicate devices -- refuse before creating the communicator
+            if tdist.get_backend(process_group) == "gloo" or world > torch.cuda.device_count():
+                raise _lib.DdrlError("DDRL_ALLREDUCE=rccl needs one GPU per rank (world %d, %d device(s), torch backend %s); "
+                                     "ranks sharing a device reduce through torch.distributed" % (
+                                         world, torch.cuda.device_count(), tdist.get_backend(process_group)))
+            self.comm = RcclComm(tdist.get_rank(process_group), world, group=process_group)
 
     def close(self):
+        if getattr(self, "comm", None) is not None:
+            self.comm.close()
+            self.comm = None
         if getattr(self, "ctx", None):
             self.lib.ddrl_ctx_destroy(self.ctx)
             self.ctx = None

@@ -57,6 +57,10 @@ class Discriminator(Basenn):
         self.update_time = 0
         self.action_dim = int(config.ACTIONS_DIM)
         self.cap = int(kwargs.get('max_batch') or 4096)
+        # data-parallel ranks (one per GPU): every rank holds a shard of the policy batch and its own expert batches; the two WGAN
+        # means run over the UNION of the shards (1 / n_total inside ddrl_op_wgan_terms) and the flat gradient + loss are summed
+        # across ranks before the clip, exactly as the generator's (BASELINE config 5 is an 8-GPU config)
+        self._process_group = kwargs.get('process_group')
         self.expert_data = kwargs.get('expert_data')
         if self.expert_data is None:
             self.expert_data = self._get_data(config.MIMIC_START_LOAD_PATH, config.TASK_TYPE, config_nn.GAN_D_BATCH_SIZE)
@@ -183,14 +187,16 @@ class Discriminator(Basenn):
     # ---- one WGAN step (GAIL.py:73-94) ------------------------------------------------------------------------------------
     def _pass(self, states, action, sign, first):
         """forward + backward of one term  sign * mean(D(states, action)); gradients are accumulated into self.grads."""
+        from ddrl4nav_amd.dist import global_batch
         states = states if isinstance(states, (list, tuple)) else [states]
         n = int(torch.as_tensor(states[0]).shape[0])
+        n_total = global_batch(n, self._process_group)   # one collective per term: every rank runs the same two terms per step
         action = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(n, self.action_dim)
         total = self.n_params + STATS_FLOATS
         for lo in range(0, n, self.cap):
             hi = min(n, lo + self.cap)
             score = self._forward_chunk(self._stage(states, lo, hi), action[lo:hi], hi - lo)
-            check(self.lib.ddrl_op_wgan_terms(_p(score), self._ld[-1], hi - lo, n, float(sign), _p(self._dact[-1]), self._ld[-1],
+            check(self.lib.ddrl_op_wgan_terms(_p(score), self._ld[-1], hi - lo, n_total, float(sign), _p(self._dact[-1]), self._ld[-1],
                                               self._ld[-1], _p(self._loss), 0 if first else 1, _st()))
             self._backward_chunk(hi - lo)
             if first:
@@ -216,6 +222,11 @@ class Discriminator(Basenn):
                 # g_loss = mean(D(data.states, data.actions)); expert_loss = -mean(D(expert)) (GAIL.py:78-80)
                 self._pass(data.states, torch.as_tensor(data.actions), +1.0, True)
                 self._pass(self._expert_states(expert_batch[0]), expert_batch[1], -1.0, False)
+                import torch.distributed as tdist
+                if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(self._process_group) > 1:
+                    from ddrl4nav_amd.dist import allreduce_flat
+                    allreduce_flat(self.grads, self._process_group)     # SUM of shard gradients pre-scaled by 1 / n_total
+                    allreduce_flat(self._loss, self._process_group)
                 check(self.lib.ddrl_op_clip_rmsprop(_p(self.params), _p(self.grads), _p(self.square_avg), self.n_params, self.lr,
                                                     self.alpha, self.eps, self.WGAN_clip_grad_num, _p(self._opt_ws), _st()))
                 self._dirty = True

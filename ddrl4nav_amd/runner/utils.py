@@ -97,7 +97,8 @@ def _create_gail_net(config, config_nn, config_env, max_batch, process_group, ex
     d_prenet = copy.deepcopy(prenet)
     # the generator is the operator-composed PPO for every encoder (the fused Atari iteration has no slot for a second value head)
     ppo_net = GenericPPO(actor, critic, prenet, None, config, config_nn, max_batch=max_batch, process_group=process_group)
-    d_net = Discriminator(pre=d_prenet, config=config, config_nn=config_nn, max_batch=max_batch, expert_data=expert_data)
+    d_net = Discriminator(pre=d_prenet, config=config, config_nn=config_nn, max_batch=max_batch, expert_data=expert_data,
+                          process_group=process_group)
     return GAIL(generator=ppo_net, discriminator=d_net, gail_critic=gail_critic)
 
 

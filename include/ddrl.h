@@ -44,6 +44,7 @@ extern "C" {
 #define DDRL_ERR_HIP (-4)
 #define DDRL_ERR_NO_DEVICE (-5)
 #define DDRL_ERR_TIMEOUT (-6)
+#define DDRL_ERR_NO_MEMORY (-7) /* host allocation of a handle failed */
 
 #define DDRL_ABI_VERSION 1
 #define DDRL_STATS_FLOATS 8 /* tail of the grad arena, see ddrl_ppo_iter */
@@ -381,8 +382,9 @@ int32_t ddrl_op_wgan_terms(const float* score, int64_t ld, int32_t n, int64_t n_
  * narrow dense layer, e.g. the discriminator's 1-wide score layer). */
 int32_t ddrl_op_colsum(const float* x, int64_t ld, int32_t n, int32_t width, float* out, void* stream);
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.RMSprop(lr, alpha, eps).step() (GAIL.py:28,83-84)
- * on flat arenas; grads[n_params + 4] <- grad norm, grads[n_params + 5] <- clip coefficient.  ws: as ddrl_op_clip_adam. */
-int32_t ddrl_op_clip_rmsprop(float* params, float* grads, float* square_avg, int64_t n_params, float lr, float alpha, float eps,
+ * on flat arenas; grads[n_params + 4] <- grad norm, grads[n_params + 5] <- clip coefficient.  ws: as ddrl_op_clip_adam.
+ * alpha is a double: torch casts alpha and (1 - alpha) to float32 separately, and 1 - alpha must be formed in double. */
+int32_t ddrl_op_clip_rmsprop(float* params, float* grads, float* square_avg, int64_t n_params, float lr, double alpha, float eps,
                              float max_norm, void* ws, void* stream);
 
 #ifdef __cplusplus

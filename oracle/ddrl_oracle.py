@@ -71,7 +71,8 @@ class Encoder(nn.Module):
     """AtariPreNet (atari_encoder.py:12-32): 3 x conv + leaky_relu(0.01), flatten, linear.
 
     Test hooks (not part of the reference): ``last_z`` keeps the three pre-activations of the latest forward;
-    ``forced`` = [pos1, pos2, pos3] (bool tensors) makes the backward use those decisions (_LeakyForced);
+    ``forced`` = [pos1, pos2, pos3] (bool tensors) makes the backward use those decisions (_LeakyForced); ``forced_seq`` = a list
+    of such triples, one per successive forward (the discriminator step runs the encoder on two batches);
     ``tap`` = {} collects, at the next backward, d loss / d (conv1 pre-activation) as "z1", d loss / d (conv2 / conv3
     pre-activation) as "z2" / "z3" and d loss / d (encoder output) as "h" (per-sample gradient tensors)."""
 
@@ -82,6 +83,8 @@ class Encoder(nn.Module):
         self.conv3 = nn.Conv2d(64, 64, 3, stride=1)
         self.linear = nn.Linear(3136, 512)
         self.forced = None
+        self.forced_seq = None   # [[pos1, pos2, pos3], ...]: decisions of the successive forwards of one step (GAIL's D runs two), cyclic
+        self._forward_calls = 0
         self.last_z = None
         self.tap = None
 
@@ -96,6 +99,9 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         self.last_z = []
+        if self.forced_seq is not None:
+            self.forced = self.forced_seq[self._forward_calls % len(self.forced_seq)]
+            self._forward_calls += 1
         x = self._act(self.conv1(x), 0)
         x = self._act(self.conv2(x), 1)
         x = self._act(self.conv3(x), 2)

@@ -124,15 +124,20 @@ def learn(net, optims, states, actions, old_logps, advs, rets2, expert_states, e
         item, ut, _ = d_step(net, d_optim, d_sched, states, actions, expert_states, expert_actions)
         yield item, ut, False
     for _ in range(iters):
-        t0 = time.time()
-        total, actor_loss, v_loss, ent = g_losses(net, states, actions, old_logps, advs, rets2)
-        g_optim.zero_grad()
-        total.backward()   # SHARE_CNN_NET branch (ppo.py:110-117); the GAIL critic's .grad accumulates, nobody reads it
-        gnorm = torch.nn.utils.clip_grad_norm_(net.generator.parameters(), O.CLIP_GRAD_NUM)
-        g_optim.step()
-        net.g_updates += 1
-        yield ({"PpoTotalLoss": total.item(), "ActorLoss": actor_loss.item(), "VLoss": v_loss.item(), "EntLoss": ent.item(),
-                "PpoBackUpTime": time.time() - t0, "GradNorm": float(gnorm)}, net.g_updates, True)
+        yield g_step(net, g_optim, states, actions, old_logps, advs, rets2)
+
+
+def g_step(net, g_optim, states, actions, old_logps, advs, rets2):
+    """One generator iteration of GAIL.learn (the PPO iteration of ppo.py:82-129 with the GAIL critic's value loss)."""
+    t0 = time.time()
+    total, actor_loss, v_loss, ent = g_losses(net, states, actions, old_logps, advs, rets2)
+    g_optim.zero_grad()
+    total.backward()   # SHARE_CNN_NET branch (ppo.py:110-117); the GAIL critic's .grad accumulates, nobody reads it
+    gnorm = torch.nn.utils.clip_grad_norm_(net.generator.parameters(), O.CLIP_GRAD_NUM)
+    g_optim.step()
+    net.g_updates += 1
+    return ({"PpoTotalLoss": total.item(), "ActorLoss": actor_loss.item(), "VLoss": v_loss.item(), "EntLoss": ent.item(),
+             "PpoBackUpTime": time.time() - t0, "GradNorm": float(gnorm)}, net.g_updates, True)
 
 
 def gae_rows(values, rewards, dones, discounts, landa=O.LANDA):

@@ -31,6 +31,8 @@ def main():
 
     rank, world, _ = init_from_env()
     assert world == len(bounds) - 1
+    if mode.startswith("gail:"):
+        return gail_rank(outdir, mode[5:], bounds, rank, world)
     _, _, _, shared, smooth = P.MODES[mode]
     env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "int_frame_stack": 4, "discrete_action": True,
            "discrete_actions": list(range(6)), "agent_num_per_env": 1, "batch_num_per_env": 8}
@@ -56,6 +58,63 @@ def main():
     st = net.hot_path.stats()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), losses=np.asarray(losses, np.float64), digest1=digests[1],
              digest10=digests[10], gradnorm=st["GradNorm"], local_batch=hi - lo, **keep)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def gail_rank(outdir, name, bounds, rank, world):
+    """One rank of a data-parallel GAIL.learn (BASELINE config 5): its shard of the policy batch AND of the expert batch; the
+    discriminator's two WGAN means run over the union of the shards (nn/gail.py)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ddrl4nav_amd.config import BaseConfig, ConfigNN
+    from ddrl4nav_amd.data import Experience
+    from ddrl4nav_amd.runner import create_net
+    from ddrl4nav_amd.utils.recipe import hash_weights
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    if name == "f16_gail_classical":
+        env = {"env_type": "gym", "env_name": "CartPole-v1", "env_num": 8, "discrete_action": True, "discrete_actions": [0, 1], "input_dim": 4}
+        states, seed = g["states"], 16
+    else:
+        env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "int_frame_stack": 4, "discrete_action": True,
+               "discrete_actions": list(range(6))}
+        states, seed = np.load(os.path.join(HERE, "golden", "f3_loss.npz"))["frames"], 17
+    cfg = BaseConfig(types.SimpleNamespace(task="gail", ip="127.0.0.1"), env)
+    cfg_nn = ConfigNN(env)
+    cfg_nn.NETWORK_TYPE, cfg_nn.SHARE_CNN_NET = "gail", True
+    hidden = int(g["d_mlp_hidden"])
+    cfg.GAN_D_MLP_LIST = [(512 + cfg.ACTIONS_DIM, hidden, "relu"), (hidden, 1, None)]
+    # bounds are given in 64ths of a batch: the policy batch (B samples) and the expert batch (E samples) are cut at the same fractions
+    B, E = len(g["actions"]), len(g["expert_actions"])
+    lo, hi = bounds[rank] * B // bounds[-1], bounds[rank + 1] * B // bounds[-1]
+    elo, ehi = bounds[rank] * E // bounds[-1], bounds[rank + 1] * E // bounds[-1]
+    ex_states = states[g["expert_index"]][::-1].copy()
+    expert = [(ex_states[elo:ehi][None], g["expert_actions"][elo:ehi])]
+    net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=256, expert_data=expert)
+    w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()}, strict=False)
+    exp = Experience(states=[states[lo:hi]], advs=g["advs"][lo:hi], actions=g["actions"][lo:hi], old_logps=g["old_logps"][lo:hi],
+                     values=g["rets"][:, lo:hi])
+    d_loss, losses, keep, digests = [], [], {}, {}
+    for item, ut, last in net.learn(exp):
+        params = {k: p.detach().cpu().numpy().copy() for k, p in net.named_parameters()}
+        dig = hashlib.sha256(b"".join(params[k].tobytes() for k in sorted(params))).hexdigest()
+        if not last:
+            d_loss.append(item["Gail[D]Loss"])
+            digests["D1"] = dig
+            if rank == 0:
+                keep.update({"D1/" + k: v for k, v in params.items()})
+        else:
+            losses.append([item[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
+            if ut == 10:
+                digests["it10"] = dig
+                if rank == 0:
+                    keep.update({"it10/" + k: v for k, v in params.items()})
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), d_loss=np.asarray(d_loss), losses=np.asarray(losses, np.float64),
+             digest_d1=digests["D1"], digest_it10=digests["it10"], local_batch=hi - lo, **keep)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -143,7 +143,7 @@ def main():
     net = PPO(actor, critic, None, None, cfg, cfg_nn).to("cpu")
     load_recipe(net, 13)
     rng = np.random.default_rng(13)
-    B = 20
+    B = 64   # round 3: 20 samples made the critic's lr = 1e-3 trajectory a knife edge (see make_golden_nav_spread.py)
     laser = rng.uniform(0.05, 1.0, size=(B, 1, 960)).astype(np.float32)
     vec = rng.normal(0, 1, size=(B, 5)).astype(np.float32)
     ped = (rng.random((B, 3, 48, 48)) < 0.15).astype(np.float32) * rng.uniform(0.5, 1.0, size=(B, 3, 48, 48)).astype(np.float32)
@@ -166,7 +166,7 @@ def main():
     net = PPO(actor, critic, prenet, None, cfg, cfg_nn).to("cpu")
     load_recipe(net, 14)
     rng = np.random.default_rng(14)
-    B = 18
+    B = 64
     img = (rng.random((B, 1, 48, 48)) < 0.3).astype(np.float32)
     vec = rng.normal(0, 1, size=(B, 9)).astype(np.float32)
     ped = (rng.random((B, 3, 48, 48)) < 0.1).astype(np.float32)

@@ -266,10 +266,15 @@ def gail_oracle(name):
 _GTRAJ = {}
 
 
-def gail_f64_trajectory(name):
-    """The oracle's GAIL.learn in float64: {"D1" | 1 | 10: {param name: float64 array}}, losses, p0."""
-    if name in _GTRAJ:
-        return _GTRAJ[name]
+def gail_f64_trajectory(name, d_forced=None):
+    """The oracle's GAIL.learn in float64: {"D1" | 1 | 10: {param name: float64 array}}, losses, p0.
+    d_forced = [[pos1, pos2, pos3] of the policy batch, ... of the expert batch]: the discriminator's Atari encoder takes these
+    leaky-ReLU decisions in its step (the kernel's own, test_gail_gpu._d_decisions) -- a pre-activation within fp32 noise of zero
+    comes out on either side depending on the summation order, and ONE such element moves hundreds of conv weight-gradient
+    elements by a few 1e-3 of their size; under the sign-like first RMSprop step that is hundreds of flipped updates."""
+    key = name if d_forced is None else (name, "forced")
+    if key in _GTRAJ and d_forced is None:
+        return _GTRAJ[key]
     from ddrl4nav_amd.utils.recipe import hash_weights
     from oracle import ddrl_oracle_gail as G
     g, net, states_np, seed = gail_oracle(name)
@@ -282,6 +287,8 @@ def gail_f64_trajectory(name):
     threads = torch.get_num_threads()
     torch.set_num_threads(min(8, max(1, os.cpu_count() or 1)))
     snaps, d_loss, losses = {}, [], []
+    if d_forced is not None:
+        net.discriminator.pre.forced_seq = [[m.clone() for m in trip] for trip in d_forced]
     try:
         for item, ut, last in G.learn(net, net.make_optims(), states, t("actions"), t("old_logps"), t("advs"), t("rets"), ex_states,
                                       t("expert_actions")):
@@ -289,20 +296,81 @@ def gail_f64_trajectory(name):
             if not last:
                 d_loss.append(item["Gail[D]Loss"])
                 snaps["D1"] = snap
+                if d_forced is not None:
+                    net.discriminator.pre.forced_seq, net.discriminator.pre.forced = None, None
             else:
                 losses.append([item[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
                 if ut in (1, 10):
                     snaps["it%d" % ut] = snap
     finally:
         torch.set_num_threads(threads)
-    _GTRAJ[name] = {"params": snaps, "d_loss": np.asarray(d_loss), "losses": np.asarray(losses),
-                    "p0": {k: np.asarray(v, np.float64) for k, v in w.items()}, "weights": w}
-    return _GTRAJ[name]
+    _GTRAJ[key] = {"params": snaps, "d_loss": np.asarray(d_loss), "losses": np.asarray(losses),
+                   "p0": {k: np.asarray(v, np.float64) for k, v in w.items()}, "weights": w}
+    return _GTRAJ[key]
 
 
-def gail_param_deviation(name, tag, got):
+class GailStepper:
+    """The GAIL oracle in float64, one step per call, each under the leaky-ReLU decisions of another implementation's forward of
+    the same step (Atari encoders; None = the oracle's own): d_step(forced_seq) for the discriminator's two batches, g_step(forced)
+    for a generator iteration.  The yardstick of tests/test_gail_gpu.py::test_gail_learn_matches_reference."""
+
+    def __init__(self, name):
+        from ddrl4nav_amd.utils.recipe import hash_weights
+        from oracle import ddrl_oracle_gail as G
+        g, net, states_np, seed = gail_oracle(name)
+        w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
+        net.load_weights(w)
+        net.double()
+        self.G, self.net, self.w = G, net, w
+        self.p0 = {k: np.asarray(v, np.float64) for k, v in w.items()}
+        t = lambda k: torch.from_numpy(g[k]).double()
+        self.states = [torch.from_numpy(states_np).double()]
+        self.ex_states = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy()).double()]
+        self.batch = (t("actions"), t("old_logps"), t("advs"), t("rets"))
+        self.expert_actions = t("expert_actions")
+        self.g_optim, self.d_optim, self.d_sched = net.make_optims()
+
+    def _threads(self):
+        return min(8, max(1, os.cpu_count() or 1))
+
+    def d_step(self, forced_seq=None):
+        pre, old = self.net.discriminator.pre, torch.get_num_threads()
+        torch.set_num_threads(self._threads())
+        try:
+            if forced_seq is not None:
+                pre.forced_seq, pre._forward_calls = forced_seq, 0
+            item, _, _ = self.G.d_step(self.net, self.d_optim, self.d_sched, self.states, self.batch[0], self.ex_states, self.expert_actions)
+        finally:
+            if forced_seq is not None:
+                pre.forced_seq = pre.forced = None
+            torch.set_num_threads(old)
+        return item["Gail[D]Loss"]
+
+    def g_step(self, forced=None):
+        pre, old = self.net.generator.prenet, torch.get_num_threads()
+        torch.set_num_threads(self._threads())
+        try:
+            if forced is not None:
+                pre.forced = forced
+            ld, _, _ = self.G.g_step(self.net, self.g_optim, self.states, *self.batch)
+        finally:
+            if forced is not None:
+                pre.forced = None
+            torch.set_num_threads(old)
+        return [ld[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")]
+
+    def params(self):
+        return {k: p.detach().numpy().copy() for k, p in self.net.named_parameters()}
+
+
+def gail_deviation_from(name, tag, got, p64, p0):
+    """deviation_ratios of `got` against a given float64 state (GailStepper.params()), in the currency of the fixture's spread."""
+    return deviation_ratios(got, p64, p0, _load(name), lambda n: "%s/%s" % (tag, n), lambda n: n.split(".")[0])
+
+
+def gail_param_deviation(name, tag, got, d_forced=None):
     """deviation_ratios for a GAIL fixture: `got` = {param name: array}, tag in ("D1", "it1", "it10")."""
-    traj = gail_f64_trajectory(name)
+    traj = _GTRAJ.get((name, "forced")) if d_forced is not None and (name, "forced") in _GTRAJ else gail_f64_trajectory(name, d_forced)
     return deviation_ratios(got, traj["params"][tag], traj["p0"], _load(name), lambda n: "%s/%s" % (tag, n),
                             lambda n: n.split(".")[0])      # generator (Adam) | discriminator (RMSprop) | gail_critic (none)
 
@@ -342,7 +410,50 @@ def nav_f64_trajectory(name):
     return _NTRAJ[name]
 
 
-def nav_param_deviation(name, it, got):
+class NavStepper:
+    """The nav oracle's learn() in float64, ONE iteration per call, each taking the ReLU / max-pool decisions of another
+    implementation's forward of the same iteration (oracle/ddrl_oracle_nav.py:_act): the yardstick of the GPU learn-sequence
+    test.  `sub` = [{site: relu output}] per encoder in OracleNet order (prenet | actor.pre, critic.pre)."""
+
+    def __init__(self, name):
+        from ddrl4nav_amd.utils.recipe import hash_weights
+        from oracle import ddrl_oracle_nav as N
+        enc, ch, n_out, gaussian, shared, seed = NAV_CASES[name]
+        make_pre = (lambda: N.MLPPreNet(4, 512)) if enc == "MLPPreNet" else (lambda: getattr(N, enc)(ch))
+        g = _load(name)
+        self.N, self.net = N, N.OracleNet(make_pre, n_out, gaussian, shared)
+        w = hash_weights([(k, tuple(p.shape)) for k, p in self.net.named_parameters()], seed)
+        self.net.load_weights(w)
+        self.net.double()
+        self.p0 = {k: np.asarray(v, np.float64) for k, v in w.items()}
+        self.states = [torch.from_numpy(g["state%d" % i]).double() for i in range(len([k for k in g.files if k.startswith("state")]))]
+        t = lambda k: torch.from_numpy(g[k]).double()
+        self.args = (t("actions"), t("old_logps"), t("advs"), t("rets"))
+        self.optims = self.net.make_optims()
+        self.encoders = [self.net.prenet] if shared else [self.net.actor.pre, self.net.critic.pre]
+
+    def step(self, sub):
+        threads = torch.get_num_threads()
+        torch.set_num_threads(min(8, max(1, os.cpu_count() or 1)))
+        try:
+            for e, s in zip(self.encoders, sub):
+                e.sub = s
+            ld = next(self.N.learn(self.net, self.optims, self.states, *self.args, iters=1))[0]
+        finally:
+            for e in self.encoders:
+                e.sub = None
+            torch.set_num_threads(threads)
+        return [ld["PpoTotalLoss"], ld["ActorLoss"], ld["VLoss"], ld["EntLoss"]]
+
+    def params(self):
+        return {k: p.detach().numpy().copy() for k, p in self.net.named_parameters()}
+
+
+def nav_param_deviation(name, it, got, p64=None, p0=None):
+    if p64 is not None:
+        shared = NAV_CASES[name][4]
+        group = (lambda n: "all") if shared else (lambda n: n.split(".")[0])
+        return deviation_ratios(got, p64, p0, _load(name[:3] + "b_spread"), lambda n: "it%d/%s" % (it, n), group)
     traj = nav_f64_trajectory(name)
     shared = NAV_CASES[name][4]
     group = (lambda n: "all") if shared else (lambda n: n.split(".")[0])

@@ -78,6 +78,28 @@ def test_sharded_learn_matches_reference_trajectory(tmp_path, golden, tag, bound
     P.check_sequence("learn_f4_sharded", "default", step, lambda: r0["params_it%d" % state["it"]], ref, env)
 
 
+@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])
+def test_data_parallel_gail_discriminator_and_generator(tmp_path, golden, name):
+    """BASELINE config 5 (GAIL on several GPUs): two ranks, each with its shard (40 / 24) of the policy batch and of the expert
+    batch.  The discriminator's WGAN means run over the UNION of the shards and its flat gradient + loss are all-reduced before
+    the clip (reference semantics of GAIL.py:73-94 on the whole batch), then the generator's PPO iterations as for any net:
+    D and G replicas bit-identical after the D step and after ten PPO iterations; the D loss equals the one-rank value; for
+    the MLP fixture the D-step parameters obey the same bounds against the reference as the one-rank run (the Atari fixture's
+    bounds need the kernel's leaky-ReLU decisions, tests/test_gail_gpu.py)."""
+    import parity_util as P
+    ranks = _run_world(tmp_path, "gail:" + name, [0, 40, 64], "gail_w2_" + name[:3])
+    r0, r1 = ranks
+    assert str(r0["digest_d1"]) == str(r1["digest_d1"]) and str(r0["digest_it10"]) == str(r1["digest_it10"])
+    assert np.array_equal(r0["d_loss"], r1["d_loss"]) and np.array_equal(r0["losses"], r1["losses"])
+    g = golden(name)
+    np.testing.assert_allclose(r0["d_loss"][0], g["d_loss"][0], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(r0["losses"][0], g["losses"][0], rtol=2e-5, atol=2e-6)   # first PPO iteration: same D step behind it
+    if name == "f16_gail_classical":
+        got = {k[3:]: r0[k] for k in r0.files if k.startswith("D1/")}
+        for k, (v, pname) in P.gail_param_deviation(name, "D1", got).items():
+            P.MARGINS.check("gail_f16_sharded", "D1_param_" + k, v, "(%s)" % pname)
+
+
 def test_single_rank_worker_equals_in_process_run(tmp_path, golden):
     """world_size 1 through the same worker: the plumbing adds nothing (bit-identical to HotPath driven directly)."""
     import torch

@@ -81,10 +81,51 @@ def test_generic_net_forward_loss_gradients_golden(golden, name):
         np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), l2, rtol=1e-4, atol=1e-9, err_msg=k)
         scale = max(np.abs(got).max(), l2 / np.sqrt(n))
         d = np.abs(got[::max(1, n // 129)][:129] - g["gstride/" + k])
-        # an activation within rounding of the ReLU / max-pool decision boundary flips with the
-        # summation order and moves the few gradient elements it feeds by one term: allow 2 % outliers
-        assert (d > 5e-5 * scale + 1e-9).sum() <= max(1, 0.02 * d.size), (k, d.max(), scale)
+        # beside the reference's stored samples: a ReLU / max-pool decision within rounding of its boundary flips with the
+        # summation order and moves every gradient element upstream of it by ~1e-3 -- bounded here, pinned below
         assert d.max() <= 5e-3 * scale + 1e-9, (k, d.max(), scale)
+    # ... and the FULL gradient against the float64 oracle under the kernels' own ReLU / max-pool decisions: 2e-5 max|g| per tensor
+    import parity_util as P
+    ora = P.NavStepper(name)
+    for e, sub in zip(ora.encoders, _relu_outputs(net, B)):
+        e.sub = sub
+    total, al, vl, _ = ora.N.losses(ora.net, ora.states, *ora.args)
+    if ora.net.shared:
+        total.backward()
+    else:
+        al.backward()
+        vl.backward()
+    off, worst = 0, {}
+    for k, p in ora.net.named_parameters():
+        n = p.numel()
+        want, got = p.grad.numpy().ravel(), flat[off:off + n].astype(np.float64)
+        off += n
+        scale = float(np.abs(want).max())
+        if scale == 0.0:
+            continue
+        worst[k] = float(np.abs(got - want).max()) / scale
+        assert worst[k] <= 2e-5, (k, worst[k])
+    print(name, "gradient vs float64 under the kernels' decisions, worst tensor: %.2e" % max(worst.values()))
+
+
+def _relu_outputs(net, n):
+    """[{site: ReLU output of the latest forward}] per encoder of a GenericPPO, in the oracle's encoder order: what
+    oracle_nav._act substitutes so that the float64 yardstick takes the kernels' ReLU / max-pool decisions."""
+    out = []
+    for e in net._encs:
+        d = {}
+        for site in ("c1", "c2", "c3"):
+            if hasattr(e, site):
+                d["conv" + site[1]] = getattr(e, site).a[:n].detach().cpu().clone()
+        if hasattr(e, "cat"):       # the nav tails: fc0 writes its ReLU output into the cat buffer, fc1 into f1
+            d["fc0"] = e.cat[:n, e.extra:e.extra + 512].detach().cpu().clone()
+            d["fc1"] = e.f1[:n].detach().cpu().clone()
+            if e.extra:             # NavPreNet1D: fc_1d -> cat[:, 0:256]
+                d["fc_1d"] = e.cat[:n, :e.extra].detach().cpu().clone()
+        else:                       # MLPPreNet: h = relu(fc0)
+            d["fc0"] = e.h[:n].detach().cpu().clone()
+        out.append(d)
+    return out
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -97,22 +138,32 @@ def test_generic_net_learn_sequence_golden(golden, name):
     from ddrl4nav_amd.data import Experience
     g = golden(name)
     sp = golden(name[:3] + "b_spread")
-    net, _ = _make(name)
+    net, _ = _make(name, max_batch=256)   # one micro-batch: the activation buffers then hold the whole batch's decisions
     exp = Experience(states=_states(g), advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"],
                      values=g["rets"].reshape(1, -1))
     ref = g["losses"]
-    env = P.loss_envelope(ref, sp["losses_f64"], g["losses_f32t8"], sp["losses_perm"])
+    env = P.loss_envelope(ref, sp["losses_f64"], g["losses_f32t8"], sp["losses_perm"], *([sp["losses_noise"]] if "losses_noise" in sp.files else []))
     tag = "generic_" + name[:3]
     seen = 0
+    # the float64 yardstick advances one iteration behind the kernels and takes THEIR ReLU / max-pool decisions (one flipped
+    # decision moves every conv-weight gradient upstream of it by ~1e-3, and Adam's sign-like first steps turn that into
+    # hundreds of flipped updates); its arithmetic, weights and optimiser state stay its own
+    ora = P.NavStepper(name)
+    B = len(g["advs"])
     for loss_items, update_time, last in net.learn(exp):
         seen += 1
         assert update_time == seen and last is True
         got = np.array([loss_items[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
-        # single-step tolerance of the forward / loss tests (1e-4 relative: conv sums over thousands of signed terms)
-        excess = np.abs(got - ref[seen - 1]) - (1e-4 * np.abs(ref[seen - 1]) + 1e-5)
+        l64 = np.array(ora.step(_relu_outputs(net, B)))
+        # iteration 1 (nothing stepped yet): the reference's stored losses at the single-step tolerance of the forward / loss tests
+        # (1e-4 relative: conv sums over thousands of signed terms); later iterations: the decision-aligned float64 yardstick
+        # within c x the reference's own envelope
+        row = ref[0] if seen == 1 else l64
+        excess = np.abs(got - row) - (1e-4 * np.abs(row) + 1e-5)
         P.MARGINS.check(tag, "loss_env", max(0.0, float(np.max(excess / np.maximum(env[seen - 1], 1e-12)))), "(iteration %d)" % seen)
         if seen in (1, 10):
-            worst = P.nav_param_deviation(name, seen, {k: p.detach().cpu().numpy() for k, p in net.named_parameters()})
+            worst = P.nav_param_deviation(name, seen, {k: p.detach().cpu().numpy() for k, p in net.named_parameters()},
+                                          p64=ora.params(), p0=ora.p0)
             for k, (v, pname) in worst.items():
                 P.MARGINS.check(tag, "param_%s_it%d" % (k, seen), v, "(%s)" % pname)
     assert seen == 10

@@ -11,7 +11,7 @@ name = sys.argv[1]
 g = np.load(os.path.join(ROOT, "tests/golden/%s.npz" % name)); sp = P._load(name[:3] + "b_spread")
 net, _ = _make(name)
 exp = Experience(states=_states(g), advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"].reshape(1, -1))
-env = P.loss_envelope(g["losses"], sp["losses_f64"], g["losses_f32t8"], sp["losses_perm"])
+env = P.loss_envelope(g["losses"], sp["losses_f64"], g["losses_f32t8"], sp["losses_perm"], *([sp["losses_noise"]] if "losses_noise" in sp.files else []))
 tr = P.nav_f64_trajectory(name)
 for it, (li, ut, last) in enumerate(net.learn(exp), 1):
     got = np.array([li[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
