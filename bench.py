@@ -506,6 +506,7 @@ def main():
     B = N * T
     net, config_nn = build_net(N, T, ITERS)
     net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    net.deferred_stats = True   # one host sync per update instead of one per iteration (nn/ppo.py:learn); same values, same keys
     hp = net.hot_path
     broadcast_params(hp.params)
     hp.params_changed()
@@ -665,6 +666,9 @@ def main():
                 "bytes": int(hp.grads.numel() * 4), "calls": len(ar_ms), "ms_avg": round(float(np.mean(ar_ms)), 4),
                 "ms_p50": round(float(np.median(ar_ms)), 4), "ms_max": round(float(np.max(ar_ms)), 4),
                 "ms_per_update": round(float(np.sum(ar_ms)) / steps, 3), "backend": dist.get_backend(),
+                # overlapped = layer buckets reduced on a second stream under the rest of the backward: the span above is then the
+                # EXPOSED part (what the compute stream waited for before clip + Adam)
+                "overlapped_with_backward": bool(hp._overlap), "exposed_ms_per_iteration": round(float(np.mean(ar_ms)), 4),
                 "algbw_gbps": round(hp.grads.numel() * 4 / (float(np.median(ar_ms)) * 1e-3) / 1e9, 2)},
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,

@@ -142,6 +142,11 @@ SIGNATURES = {
     "ddrl_op_wgan_terms": (c_int32, [c_void_p, c_int64, c_int32, c_int64, c_float, c_void_p, c_int64, c_int32, c_void_p,
                                      c_int32, c_void_p]),
     "ddrl_op_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_grad_buckets_enable": (c_int32, [c_void_p]),
+    "ddrl_grad_bucket_count": (c_int32, [c_void_p, POINTER(c_int32)]),
+    "ddrl_grad_bucket_info": (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
+    "ddrl_grad_bucket_wait": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "ddrl_grad_allreduce_overlapped": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_clip_rmsprop": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_double, c_float, c_float, c_void_p,
                                        c_void_p]),
 }

@@ -28,6 +28,9 @@ struct ddrl_ctx : public ddrl::Profiler {
   int last_n;
   bool profile;
   bool profile_acting;  // ddrl_profile_enable(on = 1): also time the (small, latency-bound) ddrl_forward launches
+  hipEvent_t bucket_ev[GRAD_BUCKETS];
+  hipEvent_t comm_done;
+  bool buckets;  // ddrl_grad_buckets_enable: record the bucket events in every ddrl_ppo_iter
   std::vector<ProfEntry> prof_pending;
   std::vector<std::string> prof_names;
   std::vector<double> prof_ms;
@@ -157,6 +160,7 @@ int32_t ddrl_ctx_create(const ddrl_config* c, float* params, float* grads, float
   ctx->last_n = 0;
   ctx->profile = false;
   ctx->profile_acting = false;
+  ctx->buckets = false;
   *out = ctx;
   return DDRL_OK;
 }
@@ -166,6 +170,10 @@ int32_t ddrl_ctx_destroy(ddrl_ctx* ctx) {
   for (auto& e : ctx->prof_pending) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
+  }
+  if (ctx->buckets) {
+    for (int b = 0; b < GRAD_BUCKETS; ++b) hipEventDestroy(ctx->bucket_ev[b]);
+    hipEventDestroy(ctx->comm_done);
   }
   delete ctx;
   return DDRL_OK;
@@ -268,12 +276,14 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   ensure_packed(ctx, st);
   amax_begin(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
+  if (ctx->buckets) ec.bucket_ev = ctx->bucket_ev;
   launch_encoder_forward(ec, false, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, B, ctx->cfg.max_batch};
   {
     ProfRange ps(ctx->profile ? ctx : nullptr, "heads_loss", st);
     launch_heads_loss(hc, actions, old_logps, advs, rets, (float)(1.0 / (double)B_global), ctx->grads, st);
   }
+  bucket_done(ec, BUCKET_HEADS, st);  // head-layer gradients and the three loss shares of the tail are final
   launch_encoder_backward(ec, ctx->grads, st);
   ctx->last_n = B;
   return check_launch();
@@ -282,6 +292,82 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
 int32_t ddrl_grad_allreduce(ddrl_ctx* ctx, ddrl_comm* comm, void* stream) {
   if (!ctx || !comm) return DDRL_ERR_INVALID_ARG;
   return ddrl_allreduce_f32(comm, ctx->grads, ctx->L.n_params + DDRL_STATS_FLOATS, stream);
+}
+
+// ---- layer buckets of the gradient all-reduce ----------------------------------------------------------
+// ranges (offset, count in floats) of bucket b inside the grad arena: one per encoder for the encoder layers; the head layers are
+// one contiguous run (actor_linear, critic_linear) and carry the DDRL_STATS_FLOATS tail as their second range
+static int bucket_ranges(const ddrl_ctx* ctx, int b, int64_t (&off)[2], int64_t (&cnt)[2]) {
+  const ParamLayout& L = ctx->L;
+  const EncLayout& E = L.enc;
+  const int64_t C = ctx->cfg.in_channels;
+  if (b == BUCKET_HEADS) {
+    off[0] = L.actor_w;
+    cnt[0] = (L.critic_b + 1) - L.actor_w;
+    off[1] = L.n_params;
+    cnt[1] = DDRL_STATS_FLOATS;
+    return 2;
+  }
+  int64_t o, n;
+  switch (b) {
+    case BUCKET_CONV1: o = E.c1w; n = (int64_t)C1_OC * C * 64 + C1_OC; break;
+    case BUCKET_CONV2: o = E.c2w; n = (int64_t)C2_OC * C2_K + C2_OC; break;
+    case BUCKET_CONV3: o = E.c3w; n = (int64_t)C3_OC * C3_K + C3_OC; break;
+    case BUCKET_FC: o = E.lw; n = (int64_t)FEAT * FLAT + FEAT; break;
+    default: return 0;
+  }
+  for (int e = 0; e < L.NE; ++e) {
+    off[e] = L.enc_base[e] + o;
+    cnt[e] = n;
+  }
+  return L.NE;
+}
+
+int32_t ddrl_grad_buckets_enable(ddrl_ctx* ctx) {
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  if (ctx->buckets) return DDRL_OK;
+  for (int b = 0; b < GRAD_BUCKETS; ++b) HIP_TRY(hipEventCreateWithFlags(&ctx->bucket_ev[b], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ctx->comm_done, hipEventDisableTiming));
+  ctx->buckets = true;
+  return DDRL_OK;
+}
+
+int32_t ddrl_grad_bucket_count(const ddrl_ctx* ctx, int32_t* n) {
+  if (!ctx || !n) return DDRL_ERR_INVALID_ARG;
+  *n = GRAD_BUCKETS;
+  return DDRL_OK;
+}
+
+int32_t ddrl_grad_bucket_info(const ddrl_ctx* ctx, int32_t b, int64_t* offsets2, int64_t* counts2, int32_t* n_ranges) {
+  if (!ctx || !offsets2 || !counts2 || !n_ranges || b < 0 || b >= GRAD_BUCKETS) return DDRL_ERR_INVALID_ARG;
+  int64_t off[2] = {0, 0}, cnt[2] = {0, 0};
+  *n_ranges = bucket_ranges(ctx, b, off, cnt);
+  offsets2[0] = off[0]; offsets2[1] = off[1];
+  counts2[0] = cnt[0]; counts2[1] = cnt[1];
+  return DDRL_OK;
+}
+
+int32_t ddrl_grad_bucket_wait(ddrl_ctx* ctx, int32_t b, void* stream) {
+  if (!ctx || !ctx->buckets || b < 0 || b >= GRAD_BUCKETS) return DDRL_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->bucket_ev[b], 0));
+  return DDRL_OK;
+}
+
+int32_t ddrl_grad_allreduce_overlapped(ddrl_ctx* ctx, ddrl_comm* comm, void* comm_stream, void* compute_stream) {
+  if (!ctx || !comm || !ctx->buckets || comm_stream == compute_stream) return DDRL_ERR_INVALID_ARG;
+  hipStream_t cs = (hipStream_t)comm_stream;
+  for (int b = 0; b < GRAD_BUCKETS; ++b) {  // bucket order = completion order of the last ddrl_ppo_iter
+    HIP_TRY(hipStreamWaitEvent(cs, ctx->bucket_ev[b], 0));
+    int64_t off[2], cnt[2];
+    const int nr = bucket_ranges(ctx, b, off, cnt);
+    for (int r = 0; r < nr; ++r) {
+      const int32_t s = ddrl_allreduce_f32(comm, ctx->grads + off[r], cnt[r], comm_stream);
+      if (s != DDRL_OK) return s;
+    }
+  }
+  HIP_TRY(hipEventRecord(ctx->comm_done, cs));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)compute_stream, ctx->comm_done, 0));  // ddrl_clip_adam_step sees the reduced arena
+  return DDRL_OK;
 }
 
 int32_t ddrl_params_broadcast(ddrl_ctx* ctx, ddrl_comm* comm, int32_t root, void* stream) {

@@ -70,16 +70,24 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
   launch_conv_dgrad3_2(c, st);
   launch_conv_dgrad2_2(c, st);
   launch_conv_wgrad1_2(c, grads, st);  // no data gradient for conv1: the frames are leaves
+  bucket_done(c, BUCKET_CONV1, st);
   launch_fc_backward2(c, grads, st, 2);
+  bucket_done(c, BUCKET_FC, st);       // 95 % of the arena's bytes: its all-reduce runs under the two conv weight gradients below
   launch_conv_wgrad3_2(c, grads, st);
+  bucket_done(c, BUCKET_CONV3, st);
   launch_conv_wgrad2_2(c, grads, st);
+  bucket_done(c, BUCKET_CONV2, st);
 #else
   launch_fc_backward2(c, grads, st);
+  bucket_done(c, BUCKET_FC, st);
   launch_conv_wgrad3_2(c, grads, st);
+  bucket_done(c, BUCKET_CONV3, st);
   launch_conv_dgrad3_2(c, st);
   launch_conv_wgrad2_2(c, grads, st);
+  bucket_done(c, BUCKET_CONV2, st);
   launch_conv_dgrad2_2(c, st);
   launch_conv_wgrad1_2(c, grads, st);
+  bucket_done(c, BUCKET_CONV1, st);
 #endif
 }
 

@@ -21,6 +21,12 @@ struct ProfRange {
   }
 };
 
+// Gradient buckets of the data-parallel all-reduce, in the order the backward COMPLETES them ("bucket by layer so
+// that the all-reduce of the early buckets overlaps the rest of the backward"): heads + loss tail (after heads_loss), conv1 (its
+// weight gradient runs right after the data-gradient chain), dense, conv3, conv2.  launch_encoder_backward records bucket_ev[b] on
+// the compute stream once bucket b's slabs are reduced into the arena; a communication stream waits for it (api.hip).
+constexpr int GRAD_BUCKETS = 5, BUCKET_HEADS = 0, BUCKET_CONV1 = 1, BUCKET_FC = 2, BUCKET_CONV3 = 3, BUCKET_CONV2 = 4;
+
 struct EncCall {
   Profiler* prof;
   const Workspace* ws;
@@ -30,7 +36,11 @@ struct EncCall {
   const uint8_t* frames;  // [n][4][84][84]
   int n;
   int64_t max_batch;
+  hipEvent_t* bucket_ev = nullptr;  // [GRAD_BUCKETS] or null (single rank: nothing to overlap)
 };
+inline void bucket_done(const EncCall& c, int b, hipStream_t st) {
+  if (c.bucket_ev) (void)hipEventRecord(c.bucket_ev[b], st);
+}
 
 // encoder.hip
 void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st);

@@ -64,6 +64,14 @@ class HotPath:
                                      "ranks sharing a device reduce through torch.distributed" % (
                                          world, torch.cuda.device_count(), tdist.get_backend(process_group)))
             self.comm = RcclComm(tdist.get_rank(process_group), world, group=process_group)
+        # layer-bucketed all-reduce that overlaps the backward: RCCL ranks only (gloo stages through the host)
+        self._overlap = False
+        self._comm_stream = self._comm_done = None
+        self._buckets = []
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(process_group) > 1 \
+                and os.environ.get("DDRL_ALLREDUCE_OVERLAP", "1") != "0" \
+                and (self.comm is not None or tdist.get_backend(process_group) == "nccl"):
+            self.enable_overlap()
 
     def close(self):
         if getattr(self, "comm", None) is not None:
@@ -165,13 +173,51 @@ class HotPath:
         check(self.lib.ddrl_ppo_iter(self.ctx, _ptr(frames), _ptr(actions), _ptr(old_logps), _ptr(advs), _ptr(rets),
                                      B, int(b_global if b_global is not None else B), _stream()))
 
+    def enable_overlap(self):
+        """Record the per-layer bucket events in every ppo_iter and reduce bucket by bucket on a second stream."""
+        from ctypes import c_int32
+        check(self.lib.ddrl_grad_buckets_enable(self.ctx))
+        n = c_int32()
+        check(self.lib.ddrl_grad_bucket_count(self.ctx, byref(n)))
+        self._buckets = []
+        for b in range(n.value):
+            off, cnt, nr = (c_int64 * 2)(), (c_int64 * 2)(), c_int32()
+            check(self.lib.ddrl_grad_bucket_info(self.ctx, b, off, cnt, byref(nr)))
+            self._buckets.append([(int(off[r]), int(cnt[r])) for r in range(nr.value)])
+        self._comm_stream = torch.cuda.Stream(device=self.device)
+        self._comm_done = torch.cuda.Event()
+        self._overlap = True
+
+    def grad_buckets(self):
+        """[[(offset, count), ...] per bucket] in completion order of the backward (after enable_overlap)."""
+        return [list(b) for b in self._buckets]
+
+    def _allreduce_overlapped(self):
+        """Bucket b's ranges are reduced on the communication stream as soon as the compute stream has passed the event the
+        backward recorded for it; the compute stream then waits for the last one (only the small conv2 bucket is exposed)."""
+        cs = self._comm_stream
+        if self.comm is not None:
+            check(self.lib.ddrl_grad_allreduce_overlapped(self.ctx, self.comm.h, c_void_p(cs.cuda_stream), _stream()))
+            return
+        import torch.distributed as tdist
+        for b, ranges in enumerate(self._buckets):
+            check(self.lib.ddrl_grad_bucket_wait(self.ctx, b, c_void_p(cs.cuda_stream)))
+            with torch.cuda.stream(cs):
+                for off, cnt in ranges:
+                    tdist.all_reduce(self.grads[off:off + cnt], op=tdist.ReduceOp.SUM, group=self.process_group)
+        self._comm_done.record(cs)
+        torch.cuda.current_stream().wait_event(self._comm_done)
+
     def allreduce_grads(self):
-        """One RCCL all-reduce (sum) of the flat gradient arena + loss tail per PPO iteration
-        (SURVEY.md section 8e); gradients were pre-scaled by 1/B_global."""
+        """The SUM all-reduce of the flat gradient arena + loss tail of one PPO iteration; gradients were
+        pre-scaled by 1/B_global.  RCCL ranks reduce in layer buckets that overlap the rest of the backward; the timed span
+        (time_allreduce) is then what the compute stream actually waits for."""
         from .dist import allreduce_flat
 
         def run():
-            if self.comm is not None:
+            if self._overlap:
+                self._allreduce_overlapped()
+            elif self.comm is not None:
                 check(self.lib.ddrl_grad_allreduce(self.ctx, self.comm.h, _stream()))
             else:
                 allreduce_flat(self.grads, self.process_group)
@@ -199,6 +245,17 @@ class HotPath:
 
     def clip_adam_step(self):
         check(self.lib.ddrl_clip_adam_step(self.ctx, _stream()))
+
+    def stats_async(self, out_row):
+        """Enqueue the copy of the 8-float statistics tail into `out_row` (a pinned host tensor row); no sync.  The values are
+        those of stats() once the stream has passed this point."""
+        out_row.copy_(self.grads[self.n_params:self.n_params + STATS_FLOATS], non_blocking=True)
+
+    @staticmethod
+    def stats_dict(row):
+        s = row.numpy() if hasattr(row, "numpy") else row
+        return {"ActorLoss": float(s[0]), "VLoss": float(s[1]), "EntLoss": float(s[2]), "PpoTotalLoss": float(s[3]),
+                "GradNorm": float(s[4]), "ClipCoef": float(s[5])}
 
     def stats(self):
         """Host copy of (actor_loss, v_loss, entropy, total, grad_norm, clip_coef) -- one sync."""

@@ -170,6 +170,18 @@ int32_t ddrl_comm_destroy(ddrl_comm* comm);
 int32_t ddrl_allreduce_f32(ddrl_comm* comm, float* buf, int64_t count, void* stream);
 int32_t ddrl_broadcast_f32(ddrl_comm* comm, float* buf, int64_t count, int32_t root, void* stream);
 int32_t ddrl_grad_allreduce(ddrl_ctx* ctx, ddrl_comm* comm, void* stream);
+/* The same reduction in LAYER BUCKETS that overlap the backward.  After ddrl_grad_buckets_enable every
+ * ddrl_ppo_iter records one event per bucket on its stream, in completion order: 0 head layers + loss tail, 1 conv1, 2 dense
+ * (95 % of the bytes; ready before the conv3 / conv2 weight gradients run), 3 conv3, 4 conv2.  ddrl_grad_allreduce_overlapped
+ * makes `comm_stream` wait for each event and reduces the bucket's ranges there, then makes `compute_stream` wait for the last
+ * one: only the small conv2 bucket is exposed.  Call it right after ddrl_ppo_iter (it does not block the host).
+ * ddrl_grad_bucket_info / _wait expose the ranges (offset, count in floats; up to two per bucket) and the stream wait, for
+ * hosts that reduce through another communicator (torch.distributed in the Python mirror). */
+int32_t ddrl_grad_buckets_enable(ddrl_ctx* ctx);
+int32_t ddrl_grad_bucket_count(const ddrl_ctx* ctx, int32_t* n);
+int32_t ddrl_grad_bucket_info(const ddrl_ctx* ctx, int32_t bucket, int64_t* offsets2, int64_t* counts2, int32_t* n_ranges);
+int32_t ddrl_grad_bucket_wait(ddrl_ctx* ctx, int32_t bucket, void* stream);
+int32_t ddrl_grad_allreduce_overlapped(ddrl_ctx* ctx, ddrl_comm* comm, void* comm_stream, void* compute_stream);
 int32_t ddrl_params_broadcast(ddrl_ctx* ctx, ddrl_comm* comm, int32_t root, void* stream);
 
 /* float32(uint8/255.0) for all 256 byte values, computed with the conv1 loader's arithmetic

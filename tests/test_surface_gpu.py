@@ -492,3 +492,60 @@ def test_backward_trainer_publish_save_and_checkpoint_offsets(net, golden, tmp_p
     assert (tmp_path / "pong_15.pt").exists() and tr2.published == 2   # start + update 10 (5 + 5)
     cfg.LOAD_CHECKPOINT = False
     net.load_state_dict(w0)
+
+
+def test_deferred_loss_readback_yields_the_same_values(golden):
+    """net.deferred_stats = True (bench.py, DEFERRED_LOSS_READBACK): all iterations enqueued, one host sync, then the yields --
+    bit-identical loss dicts and parameters to the per-iteration protocol."""
+    from ddrl4nav_amd.data import Experience
+    import parity_util as P
+    frames, actions, old_logps, advs, rets = P.mode_batch("default")
+    out = []
+    for deferred in (False, True):
+        from ddrl4nav_amd.runner import create_net
+        from ddrl4nav_amd.utils.recipe import make_weights
+        net = create_net(_configs(), max_batch=64)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+        net.deferred_stats = deferred
+        exp = Experience(states=[frames], advs=advs, actions=actions, old_logps=old_logps, values=rets.reshape(1, -1))
+        rows = [(tuple(l[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")), ut, last) for l, ut, last in net.learn(exp)]
+        out.append((rows, net.hot_path.params.cpu().numpy().copy()))
+    assert out[0][0] == out[1][0] and [r[1] for r in out[1][0]] == list(range(1, 11))
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_gradient_buckets_cover_the_arena_and_the_overlapped_allreduce_is_the_flat_one():
+    """the all-reduce runs in layer buckets, in the order the backward completes them.  The buckets' ranges
+    tile [0, n_params + 8) exactly once; with a one-rank RCCL communicator (all this one-GPU box can hold) the bucketed reduction
+    on the communication stream leaves the arena exactly as the flat one does, and clip + Adam on the compute stream see it."""
+    from ddrl4nav_amd.dist import RcclComm
+    from ddrl4nav_amd.engine import HotPath
+    from ddrl4nav_amd.utils.recipe import flatten, make_weights
+    import parity_util as P
+    frames, actions, old_logps, advs, rets = P.mode_batch("default")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = (d(frames), d(actions), d(old_logps), d(advs), d(rets))
+    res = []
+    for overlap in (False, True):
+        h = HotPath(max_batch=64)
+        h.set_params(flatten(make_weights(0)))
+        try:
+            h.comm = RcclComm(0, 1)
+        except Exception as e:  # no librccl on this host
+            h.close()
+            pytest.skip("RCCL not available: %r" % (e,))
+        if overlap:
+            h.enable_overlap()
+            cover = np.zeros(h.n_params + 8, np.int32)
+            for ranges in h.grad_buckets():
+                for off, cnt in ranges:
+                    cover[off:off + cnt] += 1
+            assert (cover == 1).all()
+            assert sum(c for o, c in h.grad_buckets()[2]) >= 0.9 * h.n_params     # the dense layer's bucket: ready before conv3 / conv2
+        for _ in range(3):
+            h.ppo_iter(*args)
+            h.allreduce_grads()
+            h.clip_adam_step()
+        res.append((h.params.cpu().numpy().copy(), h.stats()))
+        h.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
