@@ -105,9 +105,6 @@ static int32_t validate(const ddrl_config* c) {
   if (c->max_batch < 1) return DDRL_ERR_INVALID_ARG;
   if (c->n_actions < 2 || c->n_actions > 18) return DDRL_ERR_UNSUPPORTED;  // heads kernels: A <= 18 (full Atari set)
   if (c->in_channels < 1 || c->in_channels > 4) return DDRL_ERR_UNSUPPORTED;  // stacked frames: conv1's kernels give each of their four waves one channel
-#if defined(DDRL_FWD1_F32) || defined(DDRL_WGRAD1_F32)
-  if (c->in_channels != 4) return DDRL_ERR_UNSUPPORTED;                   // the f32-MFMA conv1 kernels (A/B builds) are written for four frames
-#endif
   if (c->share_cnn_net != 0 && c->share_cnn_net != 1) return DDRL_ERR_INVALID_ARG;
   // 32-bit element indexing inside one encoder's activation tensor
   // the kernels address a1 / da1 with 32-bit BYTE offsets from wave-uniform bases (max_batch <= 83,886)
@@ -175,6 +172,7 @@ int32_t ddrl_ctx_destroy(ddrl_ctx* ctx) {
     for (int b = 0; b < GRAD_BUCKETS; ++b) hipEventDestroy(ctx->bucket_ev[b]);
     hipEventDestroy(ctx->comm_done);
   }
+
   delete ctx;
   return DDRL_OK;
 }
@@ -196,16 +194,9 @@ int32_t ddrl_set_step(ddrl_ctx* ctx, int64_t step) {
   return DDRL_OK;
 }
 
-// the activation slots of Workspace::amax start every forward at zero (the conv epilogues raise them); the gradient slots
-// are reset by launch_encoder_backward
-static void amax_begin(ddrl_ctx* ctx, hipStream_t st) {
-#ifdef DDRL_FWD1_F32  // conv_fwd1_planes_kernel, the first launch of every forward, zeroes them itself
-  (void)hipMemsetAsync(ctx->ws.amax + amax_idx(AMAX_FIRST_ACT, 0), 0, (AMAX_DH - AMAX_FIRST_ACT) * 2 * sizeof(float), st);
-#else
-  (void)ctx;
-  (void)st;
-#endif
-}
+// the activation slots of Workspace::amax start every forward at zero: conv_fwd1_planes_kernel, the first launch of every forward,
+// zeroes them itself (the conv epilogues then raise them); the gradient slots are reset by launch_encoder_backward
+static void amax_begin(ddrl_ctx*, hipStream_t) {}
 
 static void ensure_packed(ddrl_ctx* ctx, hipStream_t st) {
   if (!ctx->dirty) return;

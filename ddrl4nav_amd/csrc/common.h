@@ -69,8 +69,8 @@ inline ParamLayout make_layout(int A, int C, bool shared = false) {
 struct Workspace {
   // derived weight layouts, [e] major
   float* wlt;  // [2][3136][512]    FC fwd B operand
-  // v2 packed weights: [k-block][k-step][lane half][row], see conv2.hip / wgrad2.hip
-  float *wp1, *wp2, *wp3, *wd3p, *wd2p;
+  // f32 packed weights of conv2 / conv3 for the f32-input MFMA kernels of small acting launches: [k-block][k-step][lane half][row]
+  float *wp2, *wp3;
   // conv1 weights split into three bf16 planes (W = W1 + W2 + W3 to 24 bits), conv2.hip conv_fwd1_bf16x3_kernel:
   // [channel 4][ky pair 4][plane NPL][lane half 2][row 32 NE][kx 8] 16-bit
   unsigned short* wp1b;
@@ -82,15 +82,11 @@ struct Workspace {
   unsigned short* wd2b;
   // conv3 weights for the data gradient as planes [e][k-block 4 (16 oc)][tap 9][plane][ic 64][oc half 2][oc 8]
   unsigned short* wd3b;
-  // conv3 weights for the exact-tap data gradient (conv_dgrad3_exact_kernel): three bf16 planes
-  // [e][k-block 8 (8 oc)][tap 9][plane 3][ic 64][oc 8]
-  unsigned short* wd3c;
   // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_planes_kernel)
   unsigned short* wlb;
   // the same planes transposed, [e][plane 3][3136][512] (fc2.hip fc_dgrad_planes_kernel)
   unsigned short* wdlb;
   float* amax;  // [AMAX_SLOTS][2 encoders], see AMAX_* below
-  float* wln;  // [2][512][3136]    16-byte aligned copy of linear.weight (FC dgrad B operand)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
   // sign bits of a1 (1 = NOT positive: the leaky slope applies), written by conv1's forward for the leaky-ReLU mask of the conv1 weight gradient (which would
@@ -191,8 +187,6 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
     return p;
   };
   w.wlt = take(2 * (int64_t)FLAT * FEAT);
-  w.wln = take(2 * (int64_t)FLAT * FEAT);
-  w.wp1 = take(4 * 32 * 2 * 64);
   w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.wdlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
@@ -201,11 +195,8 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);
   w.wd3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
-  w.wd3c = (unsigned short*)take(2 * 8 * 9 * 3 * 64 * 8 / 2);
   w.wp2 = take(2 * 16 * 16 * 2 * 64);
   w.wp3 = take(2 * 16 * 18 * 2 * 64);
-  w.wd3p = take(2 * 16 * 18 * 2 * 64);
-  w.wd2p = take(2 * 8 * 16 * 2 * 128);
   w.a1 = take(2 * MB * 32 * 400);
   w.m1 = (unsigned*)take(2 * m1_words(MB));
   w.m2 = (unsigned*)take(2 * MB * 81 * 2);

@@ -223,365 +223,6 @@ struct ConvFwd3v2 {
 };
 
 // ================================================================================================
-// conv1 forward, BOTH encoders in one GEMM (they read the same frames): rows = (e, oc) = 64,
-// cols = b*400+pix (256 per workgroup, <= 2 samples), k-block = one input channel (64 taps),
-// MFMA k pairs = (kx, kx+1).  The uint8 rows are converted with u8_unit() while being written to
-// LDS, de-interleaved by x mod 4 so that a stride-4 tap walk is bank-conflict free:
-//     pixel (row lr, x)  ->  lr*84 + (x&3)*21 + (x>>2)
-// ================================================================================================
-// NE = number of encoders whose conv1 shares one launch (rows = NE x 32 output channels)
-template <int NE>
-struct ConvFwd1v2 {
-  static constexpr int THREADS = 256, TM = NE, TN = 2, KSTEPS = 32, ROWS = 32 * NE;
-  static constexpr int W_FLOATS = 64 * ROWS, IMG_OFF = W_FLOATS, IMG_ROWS = 64, IMG_FLOATS = IMG_ROWS * 84;
-  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
-  static constexpr int EXTRA = 64;  // bias of the NE encoders
-  struct Params {
-    const uint8_t* frames;
-    const float* wp;  // [4][32][2][ROWS]
-    const float* params;
-    int64_t bias_off[2];
-    float* out;  // a1 [e][n][32][400]
-    int64_t out_es;
-    int n;
-  };
-  struct Regs {
-    f4 w[2 * NE];
-    unsigned im[6];
-  };
-  int abase[NE], bbase[2], kb_begin, kb_end;
-  int c0, l31, hi, wc;
-  int b0, nd0, nd_total;     // dwords of part 0 / both parts
-  int64_t src0, src1;        // byte offsets of the two row ranges inside channel 0
-  int64_t imsrc[6];          // per-thread byte offset of its j-th staged dword (clamped when unused)
-  static constexpr int aoff(int s) { return 2 * s * ROWS; }
-  static constexpr int boff(int s) { return (s / 4) * 84 + ((2 * (s % 4)) & 3) * 21 + ((2 * (s % 4)) >> 2); }
-  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
-    const int lane = tid & 63;
-    wc = tid >> 6;
-    l31 = lane & 31;
-    hi = lane >> 5;
-    c0 = blockIdx.x * 256;
-    kb_begin = 0;
-    kb_end = 4;
-    const int ctot = p.n * 400;
-    const int clast = min(c0 + 255, ctot - 1);
-    b0 = c0 / 400;
-    const int b1 = clast / 400;
-    const int oyf0 = (c0 % 400) / 20;
-    int iy0_start = 4 * oyf0, nrows0, nrows1 = 0;
-    if (b1 == b0) {
-      nrows0 = 4 * ((clast % 400) / 20 - oyf0) + 8;
-    } else {
-      nrows0 = 84 - iy0_start;
-      nrows1 = 4 * ((clast % 400) / 20) + 8;
-    }
-    nd0 = nrows0 * 21;
-    nd_total = nd0 + nrows1 * 21;
-    src0 = (int64_t)b0 * 28224 + iy0_start * 84;
-    src1 = (int64_t)b1 * 28224;
-    if (tid < ROWS) lds[2 * STAGE + tid] = p.params[p.bias_off[tid >> 5] + (tid & 31)];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int idx = tid + 256 * j;
-      imsrc[j] = (idx >= nd_total) ? src0 : (idx < nd0 ? src0 + idx * 4 : src1 + (idx - nd0) * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < NE; ++i) abase[i] = hi * ROWS + i * 32 + l31;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int c = c0 + wc * 64 + j * 32 + l31;
-      if (c >= ctot) c = c0;
-      const int b = c / 400, pix = c % 400;
-      const int oy = pix / 20, ox = pix % 20;
-      const int lr = (b == b0) ? (4 * oy - iy0_start) : (nrows0 + 4 * oy);
-      bbase[j] = IMG_OFF + lr * 84 + ox + hi * 21;
-    }
-  }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 2 * NE; ++j) r.w[j] = ld4(p.wp + kb * W_FLOATS + (tid + 256 * j) * 4);
-    const uint8_t* ch = p.frames + kb * 7056;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) r.im[j] = *(const unsigned*)(ch + imsrc[j]);  // unconditional, clamped
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 2 * NE; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < nd_total) {
-        const int lr = idx / 21, xq = idx % 21;
-        float* d = buf + IMG_OFF + lr * 84 + xq;
-        const unsigned v = r.im[j];
-        d[0] = u8_unit(v & 255u);
-        d[21] = u8_unit((v >> 8) & 255u);
-        d[42] = u8_unit((v >> 16) & 255u);
-        d[63] = u8_unit(v >> 24);
-      }
-    }
-  }
-  __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[NE][2], float* lds) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + l31;
-      if (c >= p.n * 400) continue;
-      const int b = c / 400, pix = c % 400;
-      const uint32_t lane = (uint32_t)((b * 12800 + pix + hi * (4 * 400)) * 4);  // < 2^32: ddrl_ctx_create checks max_batch
-#pragma unroll
-      for (int i = 0; i < NE; ++i) {  // i = encoder
-        float* base = p.out + i * p.out_es;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int oc = acc_row(r, hi);
-          st1_so(base + acc_row(r, 0) * 400, lane, leaky_f(acc[i][j][r] + lds[2 * STAGE + i * 32 + oc]));
-        }
-      }
-    }
-  }
-};
-
-// ================================================================================================
-// conv3 data gradient: dz3 [e][n][64][7][7] -> dz2 [e][n][64][9][9]
-//   dz2[b][ic][iy][ix] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][iy-ky][ix-kx] W3[oc][ic][ky][kx]
-// rows = ic (64), cols = b*81 + iy*9 + ix (<= 5 samples), k-block = 4 oc x 9 taps; the dz3 planes
-// sit in zero-padded 11x11 LDS images (data at +2,+2), so no tap needs a bounds test.
-// ================================================================================================
-struct ConvDgrad3v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 18;
-  static constexpr int NS = 5, W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = 2432;  // 5*4*121 = 2420
-  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
-  struct Params {
-    const float* dz;  // dz3
-    int64_t dz_es;
-    const float* wp;   // [e][16][18][2][64 ic]
-    const float* act;  // a2
-    float* out;        // dz2
-    int64_t out_es;
-    int n;
-  };
-  struct Regs {
-    f4 w[3], im;
-  };
-  int abase[2], bbase[2], kb_begin, kb_end;
-  int e, c0, b_first, l31, hi, wc;
-  int imoff;
-  const float* dz;
-  const float* wp;
-  static constexpr int aoff(int s) { return 2 * s * 64; }
-  static constexpr int boff(int s) { return (s / 9) * 242 + (2 - (s % 9) / 3) * 11 + (2 - (s % 3)); }
-  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
-    const int lane = tid & 63;
-    wc = tid >> 6;
-    l31 = lane & 31;
-    hi = lane >> 5;
-    e = blockIdx.z;
-    c0 = blockIdx.x * 256;
-    b_first = c0 / 81;
-    kb_begin = 0;
-    kb_end = 16;
-    dz = p.dz + e * p.dz_es;
-    wp = p.wp + (int64_t)e * 16 * 2304;
-    for (int i = tid; i < IMG_FLOATS; i += 256) {
-      lds[IMG_OFF + i] = 0.0f;
-      lds[STAGE + IMG_OFF + i] = 0.0f;
-    }
-    __syncthreads();
-    {
-      const bool has = tid < NS * 49;
-      const int b = min(b_first + (has ? tid / 49 : 0), p.n - 1);
-      imoff = b * FLAT + (has ? (tid % 49) * 4 : 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int c = c0 + wc * 64 + j * 32 + l31;
-      if (c >= p.n * 81) c = c0;
-      const int b = c / 81, pix = c % 81;
-      bbase[j] = IMG_OFF + (b - b_first) * 484 + (pix / 9) * 11 + (pix % 9) + hi * 121;
-    }
-  }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r.w[j] = ld4(wp + kb * 2304 + min(tid + 256 * j, 575) * 4);
-    r.im = ld4(dz + imoff + kb * 196);  // unconditional, clamped (see ConvFwd2v2::init)
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 576) st4(buf + idx * 4, r.w[j]);
-    }
-    if (tid < NS * 49) {
-      const int bl = tid / 49, q = tid % 49;
-      const float v[4] = {r.im.x, r.im.y, r.im.z, r.im.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int el = q * 4 + i;
-        const int cc = el / 49, rr = el % 49;
-        buf[IMG_OFF + (bl * 4 + cc) * 121 + (rr / 7 + 2) * 11 + (rr % 7) + 2] = v[i];
-      }
-    }
-  }
-  __device__ __forceinline__ void extra(const float*) {}
-  // a2 values for the leaky-ReLU mask: loaded (unconditionally, clamped) before the last k-block
-  static constexpr int PRE_EPILOGUE = 1;
-  float actv[2][2][16];
-  __device__ __forceinline__ int64_t out_base(const Params& p, int j, bool& ok) const {
-    const int c = c0 + wc * 64 + j * 32 + l31;
-    ok = c < p.n * 81;
-    const int cc = ok ? c : c0;
-    return e * p.out_es + (int64_t)(cc / 81) * 5184 + cc % 81;
-  }
-  __device__ __forceinline__ void pre_epilogue(const Params& p) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bool ok;
-      const int64_t base = out_base(p, j, ok);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) actv[i][j][r] = p.act[base + (i * 32 + acc_row(r, hi)) * 81];
-    }
-  }
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bool ok;
-      const int64_t base = out_base(p, j, ok);
-      if (!ok) continue;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p.out[base + (i * 32 + acc_row(r, hi)) * 81] = leaky_g(actv[i][j][r], acc[i][j][r]);
-    }
-  }
-};
-
-// ================================================================================================
-// conv2 data gradient, the four input-parity classes in ONE GEMM (they share the dz2 image and
-// the tap offsets; only the weights differ):
-//   da1[b][ic][2p+a][2q+c] = sum_{oc,u,v} dz2[b][oc][p-u][q-v] W2[oc][ic][2u+a][2v+c]   (leaky' applied by ConvWgrad1)
-// rows = (cls=a*2+c, ic) = 128, cols = b*100 + p*10 + q (<= 4 samples), k-block = 8 oc x 4 taps.
-// dz2 planes sit in zero-padded 11x11 LDS images (data at +1,+1).
-// ================================================================================================
-struct ConvDgrad2v2 {
-  static constexpr int THREADS = 256, TM = 4, TN = 2, KSTEPS = 16;
-  static constexpr int OCC = 2;  // 128 accumulators: keep the total <= 256 VGPRs for 2 waves/SIMD
-  static constexpr int NS = 4, W_FLOATS = 32 * 128, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 8 * 121;
-  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
-  struct Params {
-    const float* dz;  // dz2
-    int64_t dz_es;
-    const float* wp;   // [e][8][16][2][128]
-    const float* act;  // a1
-    float* out;        // dz1
-    int64_t out_es;
-    int n;
-  };
-  struct Regs {
-    f4 w[4], im[3];
-  };
-  int abase[4], bbase[2], kb_begin, kb_end;
-  int e, c0, b_first, l31, hi, wc;
-  int imoff[3];
-  const float* dz;
-  const float* wp;
-  static constexpr int aoff(int s) { return 2 * s * 128; }
-  static constexpr int boff(int s) { return (s / 4) * 242 + (1 - ((s % 4) >> 1)) * 11 + (1 - (s & 1)); }
-  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
-    const int lane = tid & 63;
-    wc = tid >> 6;
-    l31 = lane & 31;
-    hi = lane >> 5;
-    e = blockIdx.z;
-    c0 = blockIdx.x * 256;
-    b_first = c0 / 100;
-    kb_begin = 0;
-    kb_end = 8;
-    dz = p.dz + e * p.dz_es;
-    wp = p.wp + (int64_t)e * 8 * 4096;
-    for (int i = tid; i < IMG_FLOATS; i += 256) {
-      lds[IMG_OFF + i] = 0.0f;
-      lds[STAGE + IMG_OFF + i] = 0.0f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {  // unconditional, clamped loads (see ConvFwd2v2::init)
-      const int idx = tid + 256 * j;
-      const bool has = idx < NS * 162;
-      const int b = min(b_first + (has ? idx / 162 : 0), p.n - 1);
-      imoff[j] = b * 5184 + (has ? (idx % 162) * 4 : 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) abase[i] = hi * 128 + i * 32 + l31;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int c = c0 + wc * 64 + j * 32 + l31;
-      if (c >= p.n * 100) c = c0;
-      const int b = c / 100, pq = c % 100;
-      bbase[j] = IMG_OFF + (b - b_first) * 968 + (pq / 10) * 11 + (pq % 10) + hi * 121;
-    }
-  }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.w[j] = ld4(wp + kb * 4096 + (tid + 256 * j) * 4);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r.im[j] = ld4(dz + imoff[j] + kb * 648);
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < NS * 162) {
-        const int bl = idx / 162, q = idx % 162;
-        const float v[4] = {r.im[j].x, r.im[j].y, r.im[j].z, r.im[j].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int el = q * 4 + i;
-          const int cc = el / 81, rr = el % 81;
-          buf[IMG_OFF + (bl * 8 + cc) * 121 + (rr / 9 + 1) * 11 + (rr % 9) + 1] = v[i];
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[4][2], float*) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wc * 64 + j * 32 + l31;
-      if (c >= p.n * 100) continue;
-      const int b = c / 100, pq = c % 100;
-      const int pp = pq / 10, qq = pq % 10;
-      // classes (a,0) and (a,1) of one (p,q) are horizontally adjacent pixels: pair them into one
-      // 8-byte access so that a wave writes whole contiguous output rows
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int64_t base = e * p.out_es + (int64_t)b * 12800 + (2 * pp + a) * 20 + 2 * qq;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t idx = base + acc_row(r, hi) * 400;
-          // raw d(loss)/d(a1): the leaky-ReLU mask is applied by the only consumer, ConvWgrad1, whose
-          // prefetch pipeline hides the a1 load (here it cost 2.6 of 10.4 ms in exposed latency)
-          *(float2*)(p.out + idx) = make_float2(acc[2 * a][j][r], acc[2 * a + 1][j][r]);
-        }
-      }
-    }
-  }
-};
-
-// ================================================================================================
 // conv1 forward on the 16-bit matrix pipe, fp32-accurate.  The input pixels are integers 0..255 and therefore EXACT in
 // fp16 (and bf16); the weights come as NPL planes from optim.hip (two scaled fp16 planes whose sum reproduces them to 22
 // bits; -DDDRL_PLANES_BF16: three bf16 planes, 24 bits).  Every product plane x pixel is exact in fp32, the MFMA
@@ -628,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   using K = Fwd1B<NE>;
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  // tile geometry: 256 output pixels of at most two samples and the input rows they need (as ConvFwd1v2)
+  // tile geometry: 256 output pixels of at most two samples and the input rows they need
   const int c0 = blockIdx.x * 256, ctot = n * 400, clast = min(c0 + 255, ctot - 1);
   const int b0 = c0 / 400, b1 = clast / 400, oyf0 = (c0 % 400) / 20, iy0_start = 4 * oyf0;
   int nrows0, nrows1 = 0;
@@ -1162,12 +803,8 @@ static void launch_fwd3_planes(const EncCall& c, bool acting, hipStream_t st) {
 
 // ================================================================================================
 
-#if defined(DDRL_FWD1_F32) && !defined(DDRL_WGRAD1_F32)
-#error "-DDDRL_FWD1_F32 needs -DDDRL_WGRAD1_F32: only conv_fwd1_planes_kernel writes the a1 sign mask that conv_wgrad1_planes_kernel reads"
-#endif
-#if (defined(DDRL_FWD2_F32) || defined(DDRL_FWD3_F32)) && !defined(DDRL_MASK_FROM_ACT)
-#error "the fp32-MFMA conv2 / conv3 forwards do not write the sign masks that conv_dgrad3_planes_kernel / fc_dgrad_planes_kernel read"
-#endif
+// Training launches, and acting launches of at least DDRL_ACT_BF16X6_MIN envs, run the plane kernels above (they also write the sign
+// masks the backward reads); smaller acting launches keep the f32-input MFMA forms of conv2 / conv3 (narrow tiles, no masks needed).
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -1175,35 +812,20 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   const int n = c.n;
   {
     ProfRange pr(c.prof, acting ? "ConvFwd1.act" : "ConvFwd1", st);
-    const dim3 grid((unsigned)(((int64_t)n * 400 + 255) / 256), 1, 1);
-#ifndef DDRL_FWD1_F32  // default: the bf16x3 kernel; -DDDRL_FWD1_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (L.NE == 2) {
       launch_fwd1_planes<2>(c, acting, st);
     } else {
       launch_fwd1_planes<1>(c, acting, st);
     }
-    (void)grid;
-#else
-    if (L.NE == 2) {
-      ConvFwd1v2<2>::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[1] + L.enc.c1b}, w.a1, MB * 12800, n};
-      launch_engine2<ConvFwd1v2<2>>(grid, p, st);
-    } else {
-      ConvFwd1v2<1>::Params p{c.frames, w.wp1, c.params, {L.enc_base[0] + L.enc.c1b, L.enc_base[0] + L.enc.c1b}, w.a1, MB * 12800, n};
-      launch_engine2<ConvFwd1v2<1>>(grid, p, st);
-    }
-#endif
   }
   // 128-column tiles when 256-column tiles would give fewer than ~1.5 workgroups per CU (small acting batches)
   const auto narrow = [&](int pix) { return (((int64_t)n * pix + 255) / 256) * L.NE < 384; };
   {
     ConvFwd2v2<2>::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
-#ifndef DDRL_FWD2_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
       launch_fwd2_planes(c, acting, st);
-    } else
-#endif
-    if (narrow(81)) {
+    } else if (narrow(81)) {
       ConvFwd2v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
       launch_engine2<ConvFwd2v2<1>>(dim3((unsigned)(((int64_t)n * 81 + 127) / 128), 1, (unsigned)c.L->NE), q, st);
     } else {
@@ -1213,151 +835,13 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
   {
     ConvFwd3v2<2>::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
-#ifndef DDRL_FWD3_F32  // default for training launches: the bf16x6 kernel; -DDDRL_FWD3_F32 keeps the fp32-MFMA kernel
     if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
       launch_fwd3_planes(c, acting, st);
-    } else
-#endif
-    if (narrow(49)) {
+    } else if (narrow(49)) {
       ConvFwd3v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
       launch_engine2<ConvFwd3v2<1>>(dim3((unsigned)(((int64_t)n * 49 + 127) / 128), 1, (unsigned)c.L->NE), q, st);
     } else {
       launch_engine2<ConvFwd3v2<2>>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
-    }
-  }
-}
-
-// ================================================================================================
-// conv3 data gradient, scatter form ("col2im in LDS").  The gather form above (ConvDgrad3v2) walks all 9 taps
-// for all 81 output pixels of the zero-padded image and so executes 81 x 9 tap-products per (oc, ic) where
-// only 49 x 9 are non-zero (1.65x).  Here a workgroup owns 5 samples and, one after the other, the two halves of the
-// input channels (32 each; the staged dz3 block serves both), and runs, per tap t,
-// the exact GEMM   P_t[ic][(s, oy, ox)] = sum_oc W3[oc][ic][t] dz3[s][oc][oy][ox]   (rows = ic, cols = the 245
-// dz3 pixels of its samples, K = 64) and adds P_t into an LDS image of dz2 at (oy + ky, ox + kx): one
-// ds_add_f32 per accumulator element, no two lanes on the same address within a tap, taps separated by
-// barriers -- the summation order is fixed.  The dz3 block (5 x 3,136 floats, contiguous in global memory)
-// is staged once, LDS-direct; the 32 x 64 weight slice of a tap is double buffered.  8 waves: wave w owns
-// columns 32 w .. 32 w + 31.  Executed / algorithmic FLOP = 256 / 245.  Workgroups are persistent (one per CU) and
-// stream the next tile's dz3 block in under the last epilogue of the current one.
-// ================================================================================================
-struct Dgrad3S {
-  static constexpr int THREADS = 512, NS = 5, RI = 32, NCOL = NS * 49;
-  static constexpr int D_FLOATS = NS * FLAT, DQ = D_FLOATS / 4;          // dz3 of the samples: [s][oc][49]
-  static constexpr int A_OFF = D_FLOATS, A_FLOATS = 64 * RI;             // per buffer: [oc pair][hi][32 ic]
-  static constexpr int O_OFF = A_OFF + 2 * A_FLOATS, OS = NS * 81, O_FLOATS = RI * OS;  // [ic][s][81]
-  static constexpr int LDS_FLOATS = O_OFF + O_FLOATS;
-};
-
-__global__ __launch_bounds__(Dgrad3S::THREADS) void conv_dgrad3_scatter_kernel(const float* __restrict__ dz3, int64_t dz_es,
-                                                                               const float* __restrict__ wd3p,
-                                                                               const float* __restrict__ a2, float* __restrict__ dz2,
-                                                                               int64_t out_es, int n, int nb, int ntiles) {
-  using K = Dgrad3S;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int wave = wave_u();
-  // thread -> (oc pair s_, lane half h_, 4 input channels) of a weight slice;
-  // wd3p[e][kb][s][hi][ic] with oc = 4 kb + 2 (s / 9) + hi, tap = s % 9 (optim.hip)
-  const int s_ = tid >> 4, h_ = (tid >> 3) & 1, icq = tid & 7;
-  const int woff = ((s_ >> 1) * 18 + (s_ & 1) * 9) * 128 + h_ * 64 + icq * 4;
-  const int wdst = K::A_OFF + (s_ * 2 + h_) * K::RI + icq * 4;
-  // lane constants: column = dz3 pixel (sample cs, position cp)
-  const int col = wave * 32 + l31;
-  const bool cval = col < K::NCOL;
-  const int cc = cval ? col : 0;
-  const int cs = cc / 49, cp = cc % 49;
-  const float* Bp = lds + cs * FLAT + cp + hi * 49;                       // + 98 per oc pair
-  const float* Ap = lds + K::A_OFF + hi * K::RI + l31;                    // + 64 per oc pair (+ buffer)
-  float* Op = lds + K::O_OFF + cs * 81 + (cp / 7) * 9 + cp % 7 + 4 * hi * K::OS;  // + acc_row(r, 0) * OS + tap offset
-  constexpr int NEJ = (K::O_FLOATS + 511) / 512;
-
-  // the dz3 block of a tile's samples, LDS-direct (quad q -> LDS quad q); it serves both halves of the channels
-  auto stage_dz3 = [&](int tile) {
-    const int e = tile / nb, b0 = (tile % nb) * K::NS;
-    const int nvalid = min(K::NS, n - b0);
-    const float* dz = dz3 + e * dz_es + (int64_t)b0 * FLAT;
-#pragma unroll
-    for (int j = 0; j < (K::DQ + 511) / 512; ++j) {
-      const int q = tid + 512 * j;
-      if (q < K::DQ) {
-        // a sample beyond the batch (last tile) reads the last valid one instead: its columns are never stored
-        const int sq = q / 784, over = sq - (nvalid - 1);
-        const int src = over > 0 ? q - over * 784 : q;
-        ld16_to_lds(dz, (uint32_t)(src * 16), lds + (64 * wave + 512 * j) * 4);
-      }
-    }
-  };
-
-  // persistent workgroups (one per CU: the 131 KB of LDS allow no second one), tiles = (encoder, 5 samples)
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  stage_dz3(tile);
-  for (int i = tid; i < K::O_FLOATS / 4; i += 512) st4(lds + K::O_OFF + i * 4, zero4());
-  st4(lds + wdst, ld4(wd3p + (int64_t)(tile / nb) * (16 * 18 * 128) + woff));  // weight slice of (half 0, tap 0)
-  wait_vmcnt<0>();
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int e = tile / nb, b0 = (tile % nb) * K::NS;
-    const int nvalid = min(K::NS, n - b0);
-    const int next = tile + (int)gridDim.x;
-    const bool has_next = next < ntiles;
-    const float* wbase = wd3p + (int64_t)e * (16 * 18 * 128) + woff;
-    const float* a2w = a2 + e * out_es + (int64_t)b0 * 5184;
-    float* dz2w = dz2 + e * out_es + (int64_t)b0 * 5184;
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {  // the two halves of the 64 input channels
-      // the a2 values the leaky-ReLU mask of this half's epilogue needs are loaded now, so that they arrive under
-      // the MFMAs (element i = tid + 512 j of the [ic][s][81] image; offsets relative to the first sample)
-      float actv[NEJ];
-      int eoff[NEJ];  // < 0: nothing to store
-#pragma unroll
-      for (int j = 0; j < NEJ; ++j) {
-        const int i = tid + 512 * j;
-        const int ic = i / K::OS, r = i % K::OS, sm = r / 81, px = r % 81;
-        const bool ok = i < K::O_FLOATS && sm < nvalid;
-        eoff[j] = ok ? sm * 5184 + (ih * K::RI + ic) * 81 + px : -1;
-        actv[j] = a2w[ok ? eoff[j] : 0];
-      }
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int step = ih * 9 + t;  // the weight slices alternate between the two buffers over all 18 steps
-        f4 wnext = zero4();
-        if (step + 1 < 18) {
-          wnext = ld4(wbase + (t + 1 < 9 ? ih * K::RI + (t + 1) * 128 : K::RI));
-        } else if (has_next) {  // (half 0, tap 0) of the next tile
-          wnext = ld4(wd3p + (int64_t)(next / nb) * (16 * 18 * 128) + woff);
-        }
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-        const float* A = Ap + (step & 1) * K::A_FLOATS;
-#pragma unroll
-        for (int sp = 0; sp < 32; sp += 2) {  // two accumulators: consecutive MFMAs are independent
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sp * 64], Bp[sp * 98], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(sp + 1) * 64], Bp[(sp + 1) * 98], acc1, 0, 0, 0);
-        }
-        if (cval) {
-          // one lane per address within a tap: plain read-add-write (ds_add_f32 measured ~3 cycles per LANE here)
-          float* o = Op + (t / 3) * 9 + t % 3;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[acc_row(r, 0) * K::OS] += acc0[r] + acc1[r];
-        }
-        st4(lds + wdst + ((step + 1) & 1) * K::A_FLOATS, wnext);  // (step 17 without a next tile: zeros, never read)
-        __syncthreads();
-      }
-      // the dz3 block is free after the last tap: the next tile's streams in under this epilogue
-      if (ih == 1 && has_next) stage_dz3(next);
-      // dz2 = leaky'(a2) * image, coalesced along the 81 pixels of a (sample, channel) plane; the image is
-      // cleared for the next half / tile by the thread that read it
-#pragma unroll
-      for (int j = 0; j < NEJ; ++j) {
-        const int i = min(tid + 512 * j, K::O_FLOATS - 1);
-        const float v = lds[K::O_OFF + i];
-        if (eoff[j] >= 0) dz2w[eoff[j]] = leaky_g(actv[j], v);
-        if (tid + 512 * j < K::O_FLOATS) lds[K::O_OFF + i] = 0.0f;
-      }
-      if (ih == 1) wait_vmcnt<0>();  // the next tile's dz3 block (and this tile's stores)
-      __syncthreads();
     }
   }
 }
@@ -1530,277 +1014,9 @@ static void launch_dgrad3_planes(const EncCall& c, hipStream_t st) {
                      w.dz3, c.max_batch * FLAT, w.wd3b, w.amax, w.m2, w.dz2, c.max_batch * 5184, c.n);
 }
 
-// ================================================================================================
-// conv3 data gradient with EXACTLY the valid taps (bf16x6), -DDDRL_DGRAD3_EXACT.  The gather kernel above walks 81 x 9
-// (+ a padded tenth tap) products per sample and channel pair, of which 49 x 9 are non-zero: border pixels of the 9 x 9
-// input see fewer taps, but a column fragment of 32 neighbouring pixels mixes borders and interior.  Here the LANES of a
-// fragment are 32 SAMPLES at ONE input pixel u, so the whole fragment shares u's tap set and only valid (u, tap) pairs are
-// issued:   dz2[b][ic][u] = leaky'(a2[b][ic][u]) * sum_{tap valid at u} sum_oc W3[oc][ic][tap] dz3[b][oc][u - tap]
-// MFMA rows = ic (A = pre-split weight planes), columns = samples (B = dz3 staged channel-innermost:
-// [plane][sample][pixel][8 oc], one 16-byte fragment per lane, plain ds_read_b128).  k-block = 8 oc; one k-group = TWO
-// taps x 8 oc (lane half h takes the pair's tap h; a pixel with an odd number of valid taps meets a zero weight block
-// once): executed / algorithmic MFMA work 490 / 441 = 1.11 (the gather kernel: 1.84).  A workgroup owns 32 samples x ONE
-// input row (9 pixels = 18 fragment tiles): wave (i, j) = ic half i x pixels of column parity j; 80 accumulator registers,
-// which is what lets TWO workgroups share a CU (two rows: 160 + staging did not fit 256 registers, 714 spills).  Input
-// row rg reads dz3 rows max(0, rg - 2) .. min(6, rg).  LDS: stage 3 x 11.5 KB + the k-block's weights
-// [tap 9 + zero][plane][ic][8 oc] 30 KB (copied LDS-direct, no registers) = 66 KB, epilogue buffer 74 KB -> two workgroups
-// per CU, which hide each other's prologue, commits and epilogue (version 1 -- k-block 16 oc, weights from L2 in
-// registers, two rows, 87 KB, one workgroup per CU -- issued 0.54 x the MFMAs of the gather kernel and still tied it at
-// 4.4 ms because those phases were exposed).  The nine rows of a sample tile get block ids 8 apart (same XCD, same time):
-// the dz3 rows they share (each is read by three of them) come from that XCD's L2.
-// Epilogue per input row: accumulators -> LDS [sample][ic][9 px] -> lanes along (ic, px), i.e. along memory.
-// ================================================================================================
-struct Dgrad3X {
-  static constexpr int NS = 32, MAXROWS = 3, NRG = 9, KB = 8, NKB = 8;   // one input row per task
-  static constexpr int SSTRIDE = MAXROWS * 7 * 16 + 32;        // bytes per sample and plane: 21 px x 16 B + 32 (odd multiple of 16: conflict-free)
-  static constexpr int PLANE = NS * SSTRIDE, STAGE = 3 * PLANE;  // 11,776 / 35,328
-  static constexpr int W_OFF = STAGE, W_TAP = 3 * 64 * 16, W_BYTES = 9 * W_TAP;  // per k-block: [tap][plane][ic][8 oc] bf16 = 27,648 B (+ a zero tap)
-  static constexpr int ESTRIDE = 64 * 9 + 1;                   // floats per sample in the epilogue buffer (73,856 B, reuses everything)
-  static constexpr int LDS_BYTES = NS * ESTRIDE * 4;            // 73,856: the epilogue buffer is the larger user (stage + weights: 66,048)
-};
-
-// n-th valid tap (ky-major) of input pixel (uy, ux), or 9 = "none": tap (ky, kx) is valid when 0 <= uy - ky, ux - kx <= 6
-__host__ __device__ constexpr int d3x_nth_tap(int uy, int ux, int n) {
-  int seen = 0;
-  for (int t = 0; t < 9; ++t) {
-    const int y = uy - t / 3, x = ux - t % 3;
-    if (y < 0 || y > 6 || x < 0 || x > 6) continue;
-    if (seen == n) return t;
-    ++seen;
-  }
-  return 9;
-}
-
-template <int RG, int WJ>
-__device__ __forceinline__ void dgrad3x_body(const float* __restrict__ dz3, const unsigned short* __restrict__ wd3e, const float* __restrict__ a2,
-                                             float* __restrict__ dz2, int b0, int n, char* lds) {
-  using K = Dgrad3X;
-  // input row RG reads dz3 rows max(0, RG - 2) .. min(6, RG)
-  constexpr int Y0 = RG <= 2 ? 0 : RG - 2, Y1 = RG >= 6 ? 6 : RG, NROWS = Y1 - Y0 + 1, NPX = NROWS * 7;
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_u(), l31 = lane & 31, hi = lane >> 5;
-  const int wi = wave >> 1;
-  // ---- staging: unit = (sample s, staged pixel px): the k-block's 8 oc as 8 strided dwords -> one 16-byte fragment per plane
-  constexpr int UNITS = K::NS * NPX, NU = (UNITS + 255) / 256;
-  const float* usrc[NU];
-  int uwr[NU];
-#pragma unroll
-  for (int t = 0; t < NU; ++t) {
-    const int u = min(tid + 256 * t, UNITS - 1);
-    const int sidx = u / NPX, px = u % NPX;
-    usrc[t] = dz3 + (int64_t)min(b0 + sidx, n - 1) * FLAT + Y0 * 7 + px;   // + (8 kb + c) * 49
-    uwr[t] = sidx * K::SSTRIDE + px * 16;
-  }
-  float ur[NU][8];
-  auto fetch = [&](int kb) {
-#pragma unroll
-    for (int t = 0; t < NU; ++t)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) ur[t][c] = usrc[t][(kb * 8 + c) * 49];
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int t = 0; t < NU; ++t)
-      if (t + 1 < NU || tid + 256 * t < UNITS) {
-        unsigned p0[4], p1[4], p2[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) split_bf16x3(ur[t][2 * c], ur[t][2 * c + 1], p0[c], p1[c], p2[c]);
-        char* d = lds + uwr[t];
-        *(u4v*)(d) = (u4v){p0[0], p0[1], p0[2], p0[3]};
-        *(u4v*)(d + K::PLANE) = (u4v){p1[0], p1[1], p1[2], p1[3]};
-        *(u4v*)(d + 2 * K::PLANE) = (u4v){p2[0], p2[1], p2[2], p2[3]};
-      }
-  };
-  // the k-block's weight planes: 27 chunks of 1 KB, LDS-direct (wave w moves chunks w, w + 4, ...)
-  auto weights = [&](int kb) {
-    const unsigned short* src = wd3e + (int64_t)kb * (K::W_BYTES / 2);
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int chunk = wave + 4 * j;
-      if (chunk < 27) ld16_to_lds(src, (uint32_t)((chunk * 64 + lane) * 16), (float*)(lds + K::W_OFF + chunk * 1024));
-    }
-  };
-  for (int i = tid; i < K::W_TAP / 16; i += 256) *(u4v*)(lds + K::W_OFF + 9 * K::W_TAP + i * 16) = (u4v){0u, 0u, 0u, 0u};  // the zero tap
-  f32x16 acc[5];   // pixels ux = WJ, WJ + 2, ... of input row RG
-#pragma unroll
-  for (int c = 0; c < 5; ++c)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
-  const int b_lane = l31 * K::SSTRIDE;
-  const int a_lane = K::W_OFF + (wi * 32 + l31) * 16;
-  weights(0);
-  fetch(0);
-  commit();
-  fetch(1);
-  wait_vmcnt<NU * 8>();  // the weight chunks (older than fetch(1)'s loads) have landed
-  __syncthreads();
-#pragma unroll 1
-  for (int kb = 0; kb < K::NKB; ++kb) {
-    DDRL_BF16X6_PRODUCTS;
-    {
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        const int uy = RG, ux = 2 * c + WJ;
-        if (ux > 8) continue;
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {
-          const int tA = d3x_nth_tap(uy, ux, 2 * pr), tB = d3x_nth_tap(uy, ux, 2 * pr + 1);
-          if (tA == 9) continue;
-          const int offA = ((uy - tA / 3 - Y0) * 7 + (ux - tA % 3)) * 16;
-          const int offB = tB == 9 ? offA : ((uy - tB / 3 - Y0) * 7 + (ux - tB % 3)) * 16;
-          const int wsel = hi ? tB * K::W_TAP : tA * K::W_TAP, bsel = hi ? offB : offA;
-          bf8 wa[3], b[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            wa[p] = *(const bf8*)(lds + a_lane + wsel + p * 1024);
-            b[p] = *(const bf8*)(lds + b_lane + bsel + p * K::PLANE);
-          }
-#pragma unroll
-          for (int m = 0; m < 6; ++m) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PA[m]], b[PB[m]], acc[c], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();  // every wave is done with the stage and the weights
-    if (kb + 1 < K::NKB) {
-      weights(kb + 1);
-      commit();       // waits for fetch(kb + 1), which is older than the weight chunks
-      if (kb + 2 < K::NKB) {
-        fetch(kb + 2);
-        wait_vmcnt<NU * 8>();
-      } else {
-        wait_vmcnt<0>();
-      }
-    }
-    __syncthreads();
-  }
-  // ---- epilogue through LDS
-  float* ebuf = (float*)lds;
-  {
-    const int uy = RG;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int ux = 2 * c + WJ;
-      if (ux > 8) continue;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) ebuf[l31 * K::ESTRIDE + (wi * 32 + acc_row(q, hi)) * 9 + ux] = acc[c][q];
-    }
-    __syncthreads();
-    // wave w handles samples 8 w .. 8 w + 7; lanes run along (ic, px) = along memory.  All mask loads of four samples
-    // are issued before their first use (36 in flight per lane) so that the stores do not wait load by load.
-    int lidx[9];
-#pragma unroll
-    for (int it = 0; it < 9; ++it) {
-      const int el = lane + 64 * it, ic = el / 9;
-      lidx[it] = ic * 81 + (el - ic * 9);
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 2; ++s4) {
-      float m[4][9];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int sb = min(b0 + wave * 8 + s4 * 4 + k, n - 1);
-        const float* msrc = a2 + (int64_t)sb * 5184 + uy * 9;
-#pragma unroll
-        for (int it = 0; it < 9; ++it) m[k][it] = msrc[lidx[it]];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int sl = wave * 8 + s4 * 4 + k;
-        if (b0 + sl < n) {
-          float* dst = dz2 + (int64_t)(b0 + sl) * 5184 + uy * 9;
-#pragma unroll
-          for (int it = 0; it < 9; ++it) {
-            const float g = ebuf[sl * K::ESTRIDE + lane + 64 * it];
-            dst[lidx[it]] = m[k][it] > 0.0f ? g : g * LEAKY;
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void conv_dgrad3_exact_kernel(const float* __restrict__ dz3, int64_t dz_es, const unsigned short* __restrict__ wd3e,
-                                                                   const float* __restrict__ a2, float* __restrict__ dz2, int64_t a2_es, int n,
-                                                                   int ntiles, int ne) {
-  extern __shared__ __attribute__((aligned(16))) char ldsx3[];
-  // block id -> (encoder, sample tile, row group); the row groups of a tile are 8 ids apart
-  const int per_e = ((ntiles + 7) / 8) * 8 * Dgrad3X::NRG;
-  const int e = blockIdx.x / per_e, id = blockIdx.x % per_e;
-  const int rg = (id >> 3) % Dgrad3X::NRG, tile = (id / (8 * Dgrad3X::NRG)) * 8 + (id & 7);
-  if (tile >= ntiles) return;
-  const int b0 = tile * Dgrad3X::NS;
-  const float* dz = dz3 + e * dz_es;
-  const unsigned short* w = wd3e + (int64_t)e * (Dgrad3X::NKB * Dgrad3X::W_BYTES / 2);
-  const float* m = a2 + e * a2_es;
-  float* out = dz2 + e * a2_es;
-  const int wj = wave_u() & 1;  // pixel-column parity of this wave
-#define DDRL_D3X(RG_)                                                                                     \
-  if (wj == 0) dgrad3x_body<RG_, 0>(dz, w, m, out, b0, n, ldsx3); else dgrad3x_body<RG_, 1>(dz, w, m, out, b0, n, ldsx3)
-  switch (rg) {
-    case 0: DDRL_D3X(0); break;
-    case 1: DDRL_D3X(1); break;
-    case 2: DDRL_D3X(2); break;
-    case 3: DDRL_D3X(3); break;
-    case 4: DDRL_D3X(4); break;
-    case 5: DDRL_D3X(5); break;
-    case 6: DDRL_D3X(6); break;
-    case 7: DDRL_D3X(7); break;
-    default: DDRL_D3X(8); break;
-  }
-#undef DDRL_D3X
-}
-
-static void launch_dgrad3_exact(const EncCall& c, hipStream_t st) {
-  using K = Dgrad3X;
-  const Workspace& w = *c.ws;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_dgrad3_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
-    configured = true;
-  }
-  const int ntiles = (c.n + K::NS - 1) / K::NS, per_e = ((ntiles + 7) / 8) * 8 * K::NRG;
-  hipLaunchKernelGGL(conv_dgrad3_exact_kernel, dim3((unsigned)(per_e * c.L->NE)), dim3(256), K::LDS_BYTES, st, w.dz3, c.max_batch * FLAT, w.wd3c,
-                     w.a2, w.dz2, c.max_batch * 5184, c.n, ntiles, c.L->NE);
-}
-
 void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
-  const Workspace& w = *c.ws;
-  const int64_t MB = c.max_batch;
   ProfRange pr(c.prof, "ConvDgrad3", st);
-#if !defined(DDRL_DGRAD3_GATHER) && !defined(DDRL_DGRAD3_SCATTER)  // default: the bf16x6 gather kernel over zero-padded images
-#if defined(DDRL_DGRAD3_EXACT) && !defined(DDRL_PLANES_BF16)
-#error "conv_dgrad3_exact_kernel is a bf16x6 kernel: build it with -DDDRL_PLANES_BF16"
-#endif
-#ifdef DDRL_DGRAD3_EXACT  // exact taps, lanes = samples (conv_dgrad3_exact_kernel): 0.60 x the MFMAs, 4.49 ms against 4.39 -- its
-  launch_dgrad3_exact(c, st);  // k-blocks of 8 oc carry only ~100 MFMAs per wave between two barriers and a 27 KB weight copy
-#else
   launch_dgrad3_planes(c, st);
-#endif
-  (void)MB;
-  return;
-#endif
-#ifdef DDRL_DGRAD3_GATHER  // the fp32-MFMA gather form (A/B switch); -DDDRL_DGRAD3_SCATTER: the fp32-MFMA scatter form
-  ConvDgrad3v2::Params p{w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n};
-  launch_engine2<ConvDgrad3v2>(dim3((unsigned)(((int64_t)c.n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
-#else
-  constexpr size_t bytes = (size_t)Dgrad3S::LDS_FLOATS * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_dgrad3_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    configured = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-               ? prop.multiProcessorCount
-               : 256;
-  }
-  const int nb = (c.n + Dgrad3S::NS - 1) / Dgrad3S::NS, ntiles = nb * c.L->NE;
-  hipLaunchKernelGGL(conv_dgrad3_scatter_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(Dgrad3S::THREADS), bytes, st,
-                     w.dz3, MB * FLAT, w.wd3p, w.a2, w.dz2, MB * 5184, c.n, nb, ntiles);
-#endif
 }
 
 // ================================================================================================
@@ -1811,7 +1027,7 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 // channel-innermost into zero-bordered 11 x 11 images ([plane][sample][pixel][8 oc] bf16, 16 B per pixel): one MFMA
 // k-group = (u; v = lane half) x 8 oc, a k-block = 8 oc = 2 k-groups, 8 k-blocks.  One LDS stage; the border stays
 // zero because only interior pixels are ever written.  Weights: wd2b[e][a][k-block 8][u 2][plane 3][row 64][v 2][oc 8].
-// The output is the raw d(loss)/d(a1) as in ConvDgrad2v2 (the leaky mask is applied by its only consumer).
+// The output is the raw d(loss)/d(a1): the leaky mask is applied by its only consumer, conv1's weight gradient.
 // (A first version with 5-wave workgroups of 3 samples kept only ONE workgroup resident per CU -- SQ_WAVE_CYCLES -- and
 // ran at 6.7 ms.)
 // ================================================================================================
@@ -1820,137 +1036,8 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 #ifndef DDRL_D2_KO
 #define DDRL_D2_KO 0
 #endif
-struct Dgrad2B {
-  static constexpr int SPT = 5, THREADS = 256, TN = 4;
-  static constexpr int IMG_PLANE = SPT * 121 * 16;                // 9,680 B
-  static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = 2 * NPL * 64 * 32;
-  static constexpr int NIU = SPT * 81, NIJ = (NIU + THREADS - 1) / THREADS;  // pixel units (8 oc each): 405 -> 2 per thread
-  static constexpr int NWQ = W_BYTES / 16, NWJ = NWQ / THREADS;              // 768 weight quads -> 3 per thread
-  static constexpr size_t LDS_BYTES = W_OFF + W_BYTES;
-};
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_dgrad2_planes_kernel(const float* __restrict__ dz2, int64_t dz_es, const unsigned short* __restrict__ wd2b,
-                                                                 float* __restrict__ amax, float* __restrict__ out, int64_t out_es, int n) {
-  using K = Dgrad2B;
-  extern __shared__ __attribute__((aligned(16))) char ldsd2[];
-  const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  // The two row parities of one tile write interleaved rows of the same cache lines: workgroup ids are dealt round-robin
-  // to the 8 XCDs, so ids g and g + 8 are consecutive on ONE XCD -- they get the same tile, a = 0 and a = 1, run at the same
-  // time and their half-line stores merge in that XCD's L2 (with a in blockIdx.z they ran a whole launch apart: +7 %).
-  const int e = blockIdx.y, a = (blockIdx.x >> 3) & 1, tile = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
-  const int b0 = tile * K::SPT;
-  if (b0 >= n) return;  // padding of the tile count to a multiple of 8 (whole workgroup, before any barrier)
-  const float sa = plane_scale(amax[amax_idx(AMAX_DZ2, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_W2, e)]));
-  for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsd2 + i * 16) = zero4();  // images incl. their zero borders
-  // ---- staging maps.  unit u = tid + 256 j: sample u / 81, pixel u % 81 -> 8 loads of stride 81 (the k-block's 8 oc)
-  const float* isrc[K::NIJ];
-  int idst[K::NIJ];
-#pragma unroll
-  for (int j = 0; j < K::NIJ; ++j) {
-    const int u = min(tid + K::THREADS * j, K::NIU - 1);
-    const int s = u / 81, px = u % 81;
-    isrc[j] = dz2 + e * dz_es + (int64_t)min(b0 + s, n - 1) * 5184 + px;  // + (8 kb + c) * 81
-    idst[j] = (s * 121 + (px / 9 + 1) * 11 + px % 9 + 1) * 16;
-  }
-  const unsigned short* wsrc = wd2b + (int64_t)(e * 2 + a) * (8 * 2 * NPL * 64 * 16) + tid * 8;  // + kb * 2 * NPL * 1024 + j * 2048
-  // ---- operand bases
-  int aA[2], bB[K::TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
-#pragma unroll
-  for (int j = 0; j < K::TN; ++j) {
-    int c = wc * (32 * K::TN) + j * 32 + l31;
-    if (c >= K::SPT * 100) c = 0;
-    const int s = c / 100, pq = c % 100;
-    bB[j] = (s * 121 + (pq / 10 + 1) * 11 + (pq % 10 + 1) - hi) * 16;  // pixel (p, q - v) of the padded image, v = lane half
-  }
-  float ir[K::NIJ][8];
-  f4 wr[K::NWJ];
-  auto fetch = [&](int kb) {
-#pragma unroll
-    for (int j = 0; j < K::NIJ; ++j)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) ir[j][c] = (DDRL_D2_KO & 4) ? (float)(kb + c) : isrc[j][(kb * 8 + c) * 81];
-#pragma unroll
-    for (int j = 0; j < K::NWJ; ++j) wr[j] = (DDRL_D2_KO & 8) ? (f4){(float)kb, 1.0f, 2.0f, 3.0f} : *(const f4*)(wsrc + kb * (2 * NPL * 1024) + j * 2048);
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int j = 0; j < K::NIJ; ++j) {
-      if (DDRL_D2_KO & 16) continue;
-      if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
-        unsigned pl[4][NPL];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], sa, pl[c]);
-        char* d = ldsd2 + idst[j];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < K::NWJ; ++j) *(f4*)(ldsd2 + K::W_OFF + (tid + K::THREADS * j) * 16) = wr[j];
-  };
-  f32x16 acc[2][K::TN];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < K::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  constexpr int NKB = 8;
-  fetch(0);
-  __syncthreads();  // zero fill complete
-  commit();
-  fetch(1);
-  __syncthreads();
-  for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {  // kg = u
-      frag8 af[NPL][2], bfr[NPL][K::TN];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(ldsd2 + aA[i] + (kg * NPL + p) * 2048);
-#pragma unroll
-        for (int j = 0; j < K::TN; ++j) bfr[p][j] = *(const frag8*)(ldsd2 + bB[j] + p * K::IMG_PLANE - kg * (11 * 16));
-      }
-      DDRL_PLANE_PRODUCTS;
-#pragma unroll
-      for (int t = 0; t < NPROD; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < K::TN; ++j) {
-            if (DDRL_D2_KO & 2) acc[i][j][0] += (float)af[PA[t]][i][0] + (float)bfr[PB[t]][j][0];
-            else acc[i][j] = mfma_planes(af[PA[t]][i], bfr[PB[t]][j], acc[i][j]);
-          }
-    }
-    __syncthreads();  // every wave is done with the stage
-    if (kb + 1 < NKB) {
-      commit();
-      if (kb + 2 < NKB) fetch(kb + 2);
-    }
-    __syncthreads();
-  }
-  // rows i = column parity c: the two classes of one (p, q) are horizontally adjacent pixels -> one 8-byte store
-  float big = 0.0f;
-#pragma unroll
-  for (int j = 0; j < K::TN; ++j) {
-    const int c = wc * (32 * K::TN) + j * 32 + l31;
-    const int s = c / 100, pq = c % 100;
-    if (c >= K::SPT * 100 || b0 + s >= n) continue;
-    float* base = out + e * out_es + (int64_t)(b0 + s) * 12800 + (2 * (pq / 10) + a) * 20 + 2 * (pq % 10);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float g0 = acc[0][j][r] * inv, g1 = acc[1][j][r] * inv;
-      if (!(DDRL_D2_KO & 1) || g0 == 1.2345f) *(float2*)(base + acc_row(r, hi) * 400) = make_float2(g0, g1);
-      big = fmaxf(big, fmaxf(fabsf(g0), fabsf(g1)));
-    }
-  }
-  amax_update(big, amax + amax_idx(AMAX_DZ1, e));  // da1 before the leaky mask: an upper bound of what conv1's weight gradient stages
-}
 // ------------------------------------------------------------------------------------------------
-// The same data gradient with ONE workgroup per tile for BOTH row parities (-DDDRL_D2_BOTH=1): eight waves, rows = (a, c, ic) = 128
+// The kernel: ONE workgroup per tile for BOTH row parities: eight waves, rows = (a, c, ic) = 128
 // (four 32-row fragment tiles), wave w = columns 64 w .. 64 w + 63 (4 x 2 fragment tiles: the same LDS bytes per MFMA), dz2
 // staged ONCE per tile instead of once per parity (the knock-outs put that staging at a third of the two-workgroup kernel).
 // ------------------------------------------------------------------------------------------------
@@ -2075,43 +1162,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   amax_update(big, amax + amax_idx(AMAX_DZ1, e));  // da1 before the leaky mask: an upper bound of what conv1's weight gradient stages
 }
 
-#ifndef DDRL_D2_BOTH
-#define DDRL_D2_BOTH 1
-#endif
-static void launch_dgrad2_planes(const EncCall& c, hipStream_t st) {
-  using K = Dgrad2B;
+void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
   const Workspace& w = *c.ws;
+  ProfRange pr(c.prof, "ConvDgrad2", st);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)conv_dgrad2_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
-    configured = true;
-  }
-#if DDRL_D2_BOTH
-  static bool configured_b = false;
-  if (!configured_b) {
     (void)hipFuncSetAttribute((const void*)conv_dgrad2_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dgrad2Both::LDS_BYTES);
-    configured_b = true;
+    configured = true;
   }
   hipLaunchKernelGGL(conv_dgrad2_both_kernel, dim3((unsigned)((c.n + Dgrad2Both::SPT - 1) / Dgrad2Both::SPT), (unsigned)c.L->NE, 1),
                      dim3(Dgrad2Both::THREADS), Dgrad2Both::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.amax, w.dz1, c.max_batch * 12800, c.n);
-  return;
-#endif
-  const unsigned tiles8 = (unsigned)(((c.n + K::SPT - 1) / K::SPT + 7) / 8 * 8);
-  hipLaunchKernelGGL(conv_dgrad2_planes_kernel, dim3(tiles8 * 2, (unsigned)c.L->NE, 1), dim3(K::THREADS),
-                     K::LDS_BYTES, st, w.dz2, c.max_batch * 5184, w.wd2b, w.amax, w.dz1, c.max_batch * 12800, c.n);
-}
-
-void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st) {
-  const Workspace& w = *c.ws;
-  const int64_t MB = c.max_batch;
-  ConvDgrad2v2::Params p{w.dz2, MB * 5184, w.wd2p, w.a1, w.dz1, MB * 12800, c.n};
-  ProfRange pr(c.prof, "ConvDgrad2", st);
-#ifndef DDRL_DGRAD2_F32  // default: the bf16x6 kernel; -DDDRL_DGRAD2_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-  launch_dgrad2_planes(c, st);
-  (void)p;
-  return;
-#endif
-  launch_engine2<ConvDgrad2v2>(dim3((unsigned)(((int64_t)c.n * 100 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
 }
 
 }  // namespace ddrl

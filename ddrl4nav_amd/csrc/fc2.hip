@@ -174,211 +174,6 @@ struct FcFwd2 : FcCommon {
 };
 
 // ------------------------------------------------------------------------------------------------
-//  dz3[b][k] = leaky'(a3[b][k]) * sum_n dh[b][n] Wl[n][k]   rows = b, cols = k (3136), red = n (512)
-// ------------------------------------------------------------------------------------------------
-struct FcDgrad2 : FcCommon {
-  static constexpr int OCC = 2;  // the prefetched a3 values must not push the kernel to 1 wave/SIMD
-  static constexpr int A_OFF = 0, B_OFF = RowMajorTile::FLOATS, STAGE = RowMajorTile::FLOATS + KMajorTile::FLOATS;
-  struct Params {
-    const float* dh;
-    int64_t dh_es;
-    const float* wln;  // [e][512][3136] 16-byte aligned copy of linear.weight
-    const float* a3;
-    float* dz3;
-    int64_t a3_es;
-    int n;
-  };
-  static constexpr int DIRECT_PENDING = 4;  // the weight tile is staged LDS-direct, the 4 dh loads by register
-  struct Regs {
-    f4 a[4];
-  };
-  int e, b0, k0, wave;
-  const float* dh;   // + b0 rows
-  const float* wln;
-  uint32_t offa[4], offb[4];
-  static constexpr int aoff(int s) { return 2 * s; }
-  static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
-  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
-    lanes(tid);
-    e = blockIdx.z;
-    k0 = blockIdx.x * 128;
-    b0 = blockIdx.y * 128;
-    kb_begin = 0;
-    kb_end = FEAT / 32;
-    dh = p.dh + e * p.dh_es + (int64_t)b0 * FEAT;
-    wln = p.wln + (int64_t)e * FLAT * FEAT;
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    RowMajorTile::lane_offsets(FEAT, b0, p.n, tid, offa);
-    KMajorTile::lane_offsets(FLAT, k0, FLAT, tid, offb);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowMajorTile::LD + hi;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
-  }
-  __device__ __forceinline__ void direct(const Params&, int kb, float* stage) {
-    pin_offsets(offb);
-    KMajorTile::direct_full(wln + (int64_t)kb * 32 * FLAT, offb, stage + B_OFF, wave);  // FEAT = 16 x 32: every k-block is full
-  }
-  __device__ __forceinline__ void direct_done(const Params&, int, float*) {}
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    pin_offsets(offa);
-    RowMajorTile::fetch(dh + kb * 32, offa, r.a);
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) { RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a); }
-  // a3 values for the leaky-ReLU mask: loaded (unconditionally, clamped) before the last k-block
-  static constexpr int PRE_EPILOGUE = 1;
-  float actv[2][2][16];
-  __device__ __forceinline__ void pre_epilogue(const Params& p) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = min(k0 + wc * 64 + j * 32 + l31, FLAT - 1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int b = min(b0 + wr * 64 + i * 32 + acc_row(r, hi), p.n - 1);
-          actv[i][j][r] = p.a3[e * p.a3_es + (int64_t)b * FLAT + k];
-        }
-    }
-  }
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wc * 64 + j * 32 + l31;
-      if (k >= FLAT) continue;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-          if (b < p.n) p.dz3[e * p.a3_es + (int64_t)b * FLAT + k] = leaky_g(actv[i][j][r], acc[i][j][r]);
-        }
-    }
-  }
-};
-
-// ------------------------------------------------------------------------------------------------
-//  part[s][e][n][k] = sum_{b in split s} dh[b][n] a3[b][k] ; bias partial appended per slab
-//  rows = n (512), cols = k (3136), reduction = b
-// ------------------------------------------------------------------------------------------------
-struct FcWgrad2 : FcCommon {
-  // Both operand tiles are plain [32 k][128 col] copies of global memory: they are staged with LDS-direct
-  // loads (no staging registers, no commit), which also leaves room for a third wave per SIMD.
-  static constexpr int DIRECT_PENDING = 0;
-  static constexpr int A_OFF = 0, B_OFF = KMajorTile::FLOATS, STAGE = 2 * KMajorTile::FLOATS;
-  static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena
-  struct Params {
-    const float* dh;
-    int64_t dh_es;
-    const float* a3;
-    int64_t a3_es;
-    float* part;  // [nsplit][e][SLAB]
-    int n, nsplit;
-    int ne;
-  };
-  struct Regs {};
-  int e, split, n0, k0, wave;
-  const float* dh;
-  const float* a3;
-  uint32_t offa[4], offb[4];
-  f4 bsum;
-  static constexpr int aoff(int s) { return 2 * s * KMajorTile::LD; }
-  static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
-  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
-    lanes(tid);
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    e = blockIdx.z % p.ne;
-    split = blockIdx.z / p.ne;
-    k0 = blockIdx.x * 128;
-    n0 = blockIdx.y * 128;
-    const int nkb = (p.n + 31) / 32;
-    const int per = (nkb + p.nsplit - 1) / p.nsplit;
-    kb_begin = split * per;
-    kb_end = min(nkb, kb_begin + per);
-    dh = p.dh + e * p.dh_es;
-    a3 = p.a3 + e * p.a3_es;
-    bsum = zero4();
-    KMajorTile::lane_offsets(FEAT, n0, FEAT, tid, offa);
-    KMajorTile::lane_offsets(FLAT, k0, FLAT, tid, offb);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + hi * KMajorTile::LD + wr * 64 + i * 32 + l31;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
-  }
-  // thread -> (row kk + 8 j, 4 columns at c4 * 4): a wave covers rows 2 * wave + 8 j (+1), 1 KB contiguous in LDS
-  __device__ __forceinline__ void direct(const Params& p, int kb, float* stage) {
-    const int kbase = kb * 32;
-    pin_offsets(offa);
-    pin_offsets(offb);
-    if (kbase + 32 <= p.n) {
-      const float* da = dh + (int64_t)kbase * FEAT;
-      const float* db = a3 + (int64_t)kbase * FLAT;
-      KMajorTile::direct_full(da, offa, stage + A_OFF, wave);
-      KMajorTile::direct_full(db, offb, stage + B_OFF, wave);
-    } else {
-      // ragged last k-block: rows >= n are read from row n - 1 instead (direct_done() zeroes them in dh's tile)
-      rare_path();
-      const int kk = threadIdx.x >> 5;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t row = min(kbase + kk + 8 * j, p.n - 1);
-        const uint32_t ca = offa[j] - (uint32_t)((kk + 8 * j) * FEAT * 4), cb = offb[j] - (uint32_t)((kk + 8 * j) * FLAT * 4);
-        ld16_to_lds(dh + row * FEAT, ca, stage + A_OFF + (2 * wave + 8 * j) * KMajorTile::LD);
-        ld16_to_lds(a3 + row * FLAT, cb, stage + B_OFF + (2 * wave + 8 * j) * KMajorTile::LD);
-      }
-      rare_path();
-    }
-  }
-  __device__ __forceinline__ void direct_done(const Params& p, int kb, float* stage) {
-    if (kb * 32 + 32 > p.n) {  // samples >= n contribute zero: each thread clears what it loaded itself
-      rare_path();
-      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (kb * 32 + kk + 8 * j >= p.n) st4(stage + A_OFF + (kk + 8 * j) * KMajorTile::LD + c4 * 4, zero4());
-      rare_path();
-    }
-  }
-  __device__ __forceinline__ void fetch(const Params&, int, Regs&) {}
-  __device__ __forceinline__ void commit(const Regs&, float*) {}
-  __device__ __forceinline__ void extra(const float* cur) {
-    // bias gradient in the workgroups of column tile 0 (the epilogue's owner of the bias partial): every
-    // thread adds up its 4 columns of the 4 dh rows it staged
-    if (blockIdx.x == 0) {
-      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
-      const float* q = cur + A_OFF + kk * KMajorTile::LD + c4 * 4;
-      bsum += (ld4(q) + ld4(q + 8 * KMajorTile::LD)) + (ld4(q + 16 * KMajorTile::LD) + ld4(q + 24 * KMajorTile::LD));
-    }
-  }
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float* lds) {
-    float* slab = p.part + ((int64_t)split * 2 + e) * SLAB;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wc * 64 + j * 32 + l31;
-      if (k >= FLAT) continue;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = n0 + wr * 64 + i * 32 + acc_row(r, hi);
-          slab[(int64_t)n * FLAT + k] = acc[i][j][r];
-        }
-    }
-    if (blockIdx.x == 0) {  // one column tile per (row tile, split, e) owns the bias partial
-      const int c4 = threadIdx.x & 31, kk = threadIdx.x >> 5;
-      st4(lds + kk * 128 + c4 * 4, bsum);
-      __syncthreads();
-      if (threadIdx.x < 128) {
-        float s = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += lds[q * 128 + threadIdx.x];
-        slab[(int64_t)FEAT * FLAT + n0 + threadIdx.x] = s;
-      }
-    }
-  }
-};
-
-// ------------------------------------------------------------------------------------------------
 // Dense-layer forward on the bf16 matrix pipe, fp32-accurate ("bf16x6"): both operands are split into three bf16
 // planes (x = x0 + x1 + x2 to 24 bits; the weights once per optimiser step in optim.hip, the activations while they
 // are staged) and the six plane products whose magnitude reaches 2^-18 of the largest are accumulated in fp32:
@@ -520,7 +315,6 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
   FcFwd2::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
                    w.h, MB * FEAT, c.n, nsplit, w.wpart, c.L->NE};
   ProfRange pr(c.prof, nsplit > 1 ? "FcFwdSplit" : "FcFwd", st);
-#ifndef DDRL_FC_F32  // default: the bf16x6 kernel for full launches; -DDDRL_FC_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
   // split launches (acting) of at least DDRL_ACT_BF16X6_MIN envs run on the planes too: conv3's planes kernel has measured a3's
   // maximum there (the f32 conv3 kernel of smaller launches does not)
   if (nsplit == 1 || c.n >= DDRL_ACT_BF16X6_MIN) {
@@ -539,7 +333,6 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
                          c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, 1, w.wpart);
     return;
   }
-#endif
   launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), p, st);
 }
 
@@ -701,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
 using s4v = __attribute__((ext_vector_type(4))) short;
 struct FcWgradB {
   static constexpr int KB = 32, PITCH = 320, PLANE = KB * PITCH, B_OFF = NPL * PLANE, LDS_BYTES = 2 * NPL * PLANE;
-  static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena (= FcWgrad2::SLAB)
+  static constexpr int64_t SLAB = (int64_t)FEAT * FLAT + FEAT;  // weights then bias, like the arena (= FcWgradB::SLAB)
 };
 
 __device__ __forceinline__ frag8 tr_fragment(const char* lds, int byte_off) {
@@ -856,34 +649,26 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
   const ParamLayout& L = *c.L;
   const int S = c.splits->fc;
   if (part != 1) {
-    FcWgrad2::Params p{w.dh, MB * FEAT, w.a3, MB * FLAT, w.wpart, c.n, S, L.NE};
-    ProfRange pr(c.prof, "FcWgrad", st);
-#ifndef DDRL_FCWGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCWGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
-    static bool configured_w = false;
-    if (!configured_w) {
-      (void)hipFuncSetAttribute((const void*)fc_wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcWgradB::LDS_BYTES);
-      configured_w = true;
-    }
+    {
+      ProfRange pr(c.prof, "FcWgrad", st);
+      static bool configured_w = false;
+      if (!configured_w) {
+        (void)hipFuncSetAttribute((const void*)fc_wgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcWgradB::LDS_BYTES);
+        configured_w = true;
+      }
 #if DDRL_FC_SWZ != 0
-    const dim3 wgrid((unsigned)((25 * L.NE * S + 7) / 8 * 32));
+      const dim3 wgrid((unsigned)((25 * L.NE * S + 7) / 8 * 32));
 #else
-    const dim3 wgrid((FLAT + 127) / 128, FEAT / 128, L.NE * S);
+      const dim3 wgrid((FLAT + 127) / 128, FEAT / 128, L.NE * S);
 #endif
-    hipLaunchKernelGGL(fc_wgrad_planes_kernel, wgrid, dim3(256), FcWgradB::LDS_BYTES, st, w.dh,
-                       MB * FEAT, w.a3, MB * FLAT, w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
-    (void)p;
-#else
-    launch_engine2<FcWgrad2>(dim3((FLAT + 127) / 128, FEAT / 128, L.NE * S), p, st);
-#endif
-  }
-  if (part != 1) {
+      hipLaunchKernelGGL(fc_wgrad_planes_kernel, wgrid, dim3(256), FcWgradB::LDS_BYTES, st, w.dh, MB * FEAT, w.a3, MB * FLAT, w.amax, w.gsc, MB,
+                         w.wpart, c.n, S, L.NE);
+    }
     ProfRange pr(c.prof, "reduce_partials", st);
-    launch_reduce_partials(w.wpart, S, FcWgrad2::SLAB, L.NE, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
+    launch_reduce_partials(w.wpart, S, FcWgradB::SLAB, L.NE, grads, L.enc_base[0] + L.enc.lw, L.enc_base[1] + L.enc.lw, st);
   }
   if (part != 2) {
-    FcDgrad2::Params p{w.dh, MB * FEAT, w.wln, w.a3, w.dz3, MB * FLAT, c.n};
     ProfRange pr(c.prof, "FcDgrad", st);
-#ifndef DDRL_FCDGRAD_F32  // default: the bf16x6 kernel; -DDDRL_FCDGRAD_F32 keeps the fp32-MFMA kernel (A/B, cross-check)
     static bool configured = false;
     if (!configured) {
       (void)hipFuncSetAttribute((const void*)fc_dgrad_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcDgradB::LDS_BYTES);
@@ -891,10 +676,6 @@ void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int par
     }
     hipLaunchKernelGGL(fc_dgrad_planes_kernel, dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), dim3(256), FcDgradB::LDS_BYTES, st, w.dh, MB * FEAT,
                        w.wdlb, w.amax, w.m3, w.dz3, MB * FLAT, c.n);
-    (void)p;
-    return;
-#endif
-    launch_engine2<FcDgrad2>(dim3((FLAT + 127) / 128, (c.n + 127) / 128, L.NE), p, st);
   }
 }
 

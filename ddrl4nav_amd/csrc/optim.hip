@@ -11,13 +11,11 @@ namespace ddrl {
 // derived weight layouts (rebuilt after every optimiser step; 13.5 MB read, ~13.5 MB written)
 // --------------------------------------------------------------------------------------------
 // wlt[e][k][n] = Wl[n][k]   (512 x 3136 -> 3136 x 512), 32x32 LDS tiles
-__global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt,
-                                                      float* __restrict__ wln) {
+__global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt) {
   __shared__ float tile[32][33];
   const int e = blockIdx.z;
   const float* src = params + L.enc_base[e] + L.enc.lw;
   float* dst = wlt + (int64_t)e * FLAT * FEAT;
-  float* nat = wln + (int64_t)e * FLAT * FEAT;
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -25,7 +23,6 @@ __global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ 
     const int n = n0 + ty + 8 * j;
     const float v = src[(int64_t)n * FLAT + k0 + tx];
     tile[ty + 8 * j][tx] = v;
-    nat[(int64_t)n * FLAT + k0 + tx] = v;
   }
   __syncthreads();
 #pragma unroll
@@ -35,21 +32,12 @@ __global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ 
   }
 }
 
-// v2 layouts: [k-block][k-step s][lane half hi][row] -- the order in which the engine's MFMA
-// k indices walk (channel pairs on the lane halves; tap pairs for conv1).
+// f32 layouts of conv2 / conv3 for the f32-input MFMA kernels of SMALL acting launches (conv2.hip ConvFwd2v2 / ConvFwd3v2):
+// [k-block][k-step s][lane half hi][row] -- the order in which the engine's MFMA k indices walk (channel pairs on the lane halves)
 __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ params, ParamLayout L, Workspace w) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  const int NE = L.NE, rows1 = 32 * NE;
-  const int n1 = 4 * 32 * 2 * rows1, n2 = NE * 16 * 16 * 2 * 64, n3 = NE * 16 * 18 * 2 * 64, n4 = n3, n5 = NE * 8 * 16 * 2 * 128;
-  if (i < n1) {  // wp1[kb=ic][s][hi][e*32+oc] = W1_e[oc][ic][ky=s/4][kx=2*(s%4)+hi]
-    const int row = i % rows1, r = i / rows1;
-    const int hi = r & 1, s = (r >> 1) & 31, kb = r >> 6;
-    const int e = row >> 5, oc = row & 31;
-    // (the f32-MFMA conv1 kernels this layout feeds are A/B builds for four stacked frames; other stacks: an in-range dummy)
-    w.wp1[i] = params[L.enc_base[e] + L.enc.c1w + ((oc * L.C + (kb < L.C ? kb : L.C - 1)) * 8 + (s >> 2)) * 8 + 2 * (s & 3) + hi];
-    return;
-  }
-  i -= n1;
+  const int NE = L.NE;
+  const int n2 = NE * 16 * 16 * 2 * 64, n3 = NE * 16 * 18 * 2 * 64;
   if (i < n2) {  // wp2[e][kb][s][hi][oc] = W2[oc][2kb+hi][s/4][s%4]
     const int oc = i & 63, hi = (i >> 6) & 1, s = (i >> 7) & 15, kb = (i >> 11) & 15, e = i >> 15;
     w.wp2[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + 2 * kb + hi) * 16 + s];
@@ -60,39 +48,11 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ pa
     const int oc = i & 63, hi = (i >> 6) & 1, r = i >> 7;
     const int s = r % 18, kb = (r / 18) % 16, e = r / (18 * 16);
     w.wp3[i] = params[L.enc_base[e] + L.enc.c3w + (oc * 64 + 4 * kb + 2 * (s / 9) + hi) * 9 + s % 9];
-    return;
-  }
-  i -= n3;
-  if (i < n4) {  // wd3p[e][kb][s][hi][ic] = W3[oc=4kb+2(s/9)+hi][ic][s%9]
-    const int ic = i & 63, hi = (i >> 6) & 1, r = i >> 7;
-    const int s = r % 18, kb = (r / 18) % 16, e = r / (18 * 16);
-    w.wd3p[i] = params[L.enc_base[e] + L.enc.c3w + ((4 * kb + 2 * (s / 9) + hi) * 64 + ic) * 9 + s % 9];
-    return;
-  }
-  i -= n4;
-  if (i < n5) {  // wd2p[e][kb][s][hi][cls*32+ic] = W2[oc=8kb+2(s/4)+hi][ic][2u+a][2v+c]
-    const int row = i & 127, hi = (i >> 7) & 1, s = (i >> 8) & 15, kb = (i >> 12) & 7, e = i >> 15;
-    const int cls = row >> 5, ic = row & 31;
-    const int u = (s & 3) >> 1, v = s & 1;
-    const int oc = 8 * kb + 2 * (s >> 2) + hi;
-    w.wd2p[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + ic) * 16 + (2 * u + (cls >> 1)) * 4 + 2 * v + (cls & 1)];
   }
 }
 
-// conv1 weights as three bf16 planes: p0 = bf16(w), p1 = bf16(w - p0), p2 = bf16(w - p0 - p1) (round to nearest
-// even; the two subtractions are exact in fp32), so p0 + p1 + p2 reproduces w to 24 bits.  Layout: common.h wp1b.
-__device__ __forceinline__ unsigned short bf16_rne(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-// w = p0 + p1 + p2 to 24 bits (the two subtractions are exact in fp32)
-__device__ __forceinline__ void bf16_planes(float w, unsigned short& p0, unsigned short& p1, unsigned short& p2) {
-  p0 = bf16_rne(w);
-  const float r1 = w - __uint_as_float((unsigned)p0 << 16);
-  p1 = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float((unsigned)p1 << 16);
-  p2 = bf16_rne(r2);
-}
+// conv1 weights as the NPL planes of engine2.h's plane scheme (default: two scaled fp16 planes, h0 + h1 = w S to 22 bits; the
+// kernel names keep their history).  Layout: common.h wp1b.
 __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
                                                               const float* __restrict__ amax) {
   const int rows = 32 * L.NE;
@@ -187,22 +147,6 @@ __global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __re
   for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
-// conv3 weights for the exact-tap data gradient: wd3c[e][kb 8][tap 9][plane 3][ic 64][o 8] = W3[oc = 8 kb + o][ic][tap]
-// (one k-block = 27,648 contiguous bytes: copied LDS-direct by conv_dgrad3_exact_kernel)
-__global__ __launch_bounds__(256) void pack_dgrad3c_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst) {
-  const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, tap, ic, o)
-  if (i >= 8 * 9 * 64 * 8) return;
-  const int o = i & 7, ic = (i >> 3) & 63, tap = (i >> 9) % 9, kb = (i >> 9) / 9;
-  const float w = params[L.enc_base[e] + L.enc.c3w + ((8 * kb + o) * 64 + ic) * 9 + tap];
-  unsigned short p0, p1, p2;
-  bf16_planes(w, p0, p1, p2);
-  unsigned short* d = dst + (((int64_t)(e * 8 + kb) * 9 + tap) * 3) * 512 + ic * 8 + o;
-  d[0] = p0;
-  d[512] = p1;
-  d[1024] = p2;
-}
-
 // largest magnitude of linear.weight / conv2.weight / conv3.weight / conv1.weight per encoder -> Workspace::amax weight slots
 // (the power-of-two scale of their fp16 planes, engine2.h plane scheme); grid (64, 4 tensors, NE), slots zeroed before
 __global__ __launch_bounds__(256) void weights_amax_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ amax) {
@@ -233,7 +177,6 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   (void)hipMemsetAsync(w.amax, 0, AMAX_FIRST_ACT * 2 * sizeof(float), st);
   hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_A1, L.NE), dim3(256), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(a1_bound_kernel, dim3(32, L.NE), dim3(64), 0, st, params, L, w.amax);
-  hipLaunchKernelGGL(pack_dgrad3c_bf16_kernel, dim3(8 * 9 * 64 * 8 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3c);
   hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(4 * 9 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
   hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
   hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
@@ -241,10 +184,10 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
   hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
   {
-    const int total2 = L.NE * (4 * 32 * 2 * 32 + 16 * 16 * 2 * 64 + 2 * 16 * 18 * 2 * 64 + 8 * 16 * 2 * 128);
+    const int total2 = L.NE * (16 * 16 * 2 * 64 + 16 * 18 * 2 * 64);
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);
   }
-  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, L.NE), dim3(256), 0, st, params, L, w.wlt, w.wln);
+  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, L.NE), dim3(256), 0, st, params, L, w.wlt);
 }
 
 // --------------------------------------------------------------------------------------------
