@@ -163,8 +163,16 @@ int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn
 
 int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats) {
   if (!lin_ok(n, K, N) || !floats) return DDRL_ERR_INVALID_ARG;
-  const int64_t wg = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);
-  const int64_t fw = (int64_t)linear_fwd_splits(n, K, N) * n * N;  // split-K partials of the forward
+  const int64_t wg = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);   // non-decreasing in n
+  // split-K partials of the forward: splits(n') * n' * N floats for a launch of n' <= n samples.  FEWER samples take MORE splits
+  // (the split count fills the chip), so the product is NOT largest at n' = n: with tn = ceil(N / 128) column tiles,
+  // splits(n') <= min(cap_K, ceil(512 / (tn ceil(n' / 128)))) gives splits(n') n' <= min(cap_K n, 65536 / tn + n).  (Sizing by n alone
+  // once let a 40,000-sample launch of a 65,536-sample layer write 2 x 40,000 x N partials into 1 x 65,536 x N floats.)
+  const int64_t tn = (N + 127) / 128;
+  int64_t cap_k = ((K + 31) / 32) / 8;
+  if (cap_k < 1) cap_k = 1;
+  const int64_t by_k = cap_k * (int64_t)n, by_fill = 65536 / tn + (int64_t)n + 128;
+  const int64_t fw = (by_k < by_fill ? by_k : by_fill) * N;
   *floats = wg > fw ? wg : fw;
   return DDRL_OK;
 }

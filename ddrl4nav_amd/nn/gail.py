@@ -185,12 +185,14 @@ class Discriminator(Basenn):
         return out
 
     # ---- one WGAN step (GAIL.py:73-94) ------------------------------------------------------------------------------------
-    def _pass(self, states, action, sign, first):
-        """forward + backward of one term  sign * mean(D(states, action)); gradients are accumulated into self.grads."""
+    def _pass(self, states, action, sign, first, n_total=None):
+        """forward + backward of one term  sign * mean(D(states, action)); gradients are accumulated into self.grads.
+        n_total: the size of the whole batch the mean runs over (default: the sum of the ranks' shard sizes)."""
         from ddrl4nav_amd.dist import global_batch
         states = states if isinstance(states, (list, tuple)) else [states]
         n = int(torch.as_tensor(states[0]).shape[0])
-        n_total = global_batch(n, self._process_group)   # one collective per term: every rank runs the same two terms per step
+        if n_total is None:
+            n_total = global_batch(n, self._process_group)   # one collective per term: every rank runs the same two terms per step
         action = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(n, self.action_dim)
         total = self.n_params + STATS_FLOATS
         for lo in range(0, n, self.cap):

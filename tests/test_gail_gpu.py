@@ -263,3 +263,62 @@ def test_agents_two_row_gae_bit_exact(golden):
     assert len(out) == T
     assert np.array_equal(np.stack([e.advs for e in out]), g["adv"])
     assert np.array_equal(np.stack([e.values for e in out]), g["ret"])
+
+
+def test_gail_config5_full_size_properties(golden):
+    """BASELINE config 5 at the full per-GPU batch (256 envs x 256 steps = 65,536 samples through the Atari encoder): size-independent
+    properties of the discriminator step and of the generator's PPO iteration with the GAIL critic.
+    (a) data-parallel additivity of the discriminator: the gradient of mean(D(policy)) - mean(D(expert)) over the whole batch equals
+        the sum of two uneven shards' gradients when every shard divides by the TOTAL sizes -- what the all-reduce of nn/gail.py sums;
+    (b) duplicating policy and expert batch leaves the discriminator's mean gradient and loss unchanged;
+    (c) the generator's gradient over micro-batches (max_batch 20,000: three full chunks and a ragged one) equals the one-chunk one."""
+    g, net, _, _ = _net("f17_gail_atari", golden, max_batch=65536)
+    D = net.discriminator
+    B = 65536
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(505)
+    base = torch.randint(0, 256, (B // 2, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=gen)
+    frames = torch.cat([base, base])
+    half = lambda t: torch.cat([t, t]).contiguous()
+    acts = half(torch.randint(0, 6, (B // 2,), device="cuda", generator=gen).float())
+    ex_frames = frames.flip(0).contiguous()
+    ex_acts = half(torch.randint(0, 6, (B // 2,), device="cuda", generator=gen).float()).reshape(B, 1)
+    n = D.n_params
+    D._ensure_packed()
+
+    def d_grad(pol, pol_a, ex, ex_a, n_pol, n_ex):
+        D._pass([pol], pol_a, +1.0, True, n_total=n_pol)
+        D._pass([ex], ex_a, -1.0, False, n_total=n_ex)
+        return D.grads[:n].clone(), float(D._loss.item())
+
+    full, loss_full = d_grad(frames, acts, ex_frames, ex_acts, B, B)
+    scale = full.abs().max().item()
+    assert scale > 0
+    cut = 40000
+    acc, loss_acc = torch.zeros_like(full), 0.0
+    for sl in (slice(0, cut), slice(cut, B)):
+        gsh, lsh = d_grad(frames[sl], acts[sl], ex_frames[sl], ex_acts[sl], B, B)
+        acc += gsh
+        loss_acc += lsh
+    assert (acc - full).abs().max().item() <= 1e-4 * scale
+    np.testing.assert_allclose(loss_acc, loss_full, rtol=1e-4, atol=1e-7)
+    one, loss_one = d_grad(frames[:B // 2], acts[:B // 2], ex_frames[B // 2:], ex_acts[B // 2:], B // 2, B // 2)   # (b)
+    assert (one - full).abs().max().item() <= 1e-4 * scale
+    np.testing.assert_allclose(loss_one, loss_full, rtol=1e-4, atol=1e-7)
+    # (c) generator: micro-batched PPO iteration with the GAIL critic == one chunk
+    G = net.generator
+    old = half(torch.full((B // 2,), -1.79, device="cuda") + 0.2 * torch.randn(B // 2, device="cuda", generator=gen))
+    adv = half(torch.randn(B // 2, device="cuda", generator=gen))
+    rets = torch.stack([half(torch.randn(B // 2, device="cuda", generator=gen)) for _ in range(2)])
+    G._ensure_packed()
+    G._iter_chunk([frames], B, acts, old, adv, rets[0].contiguous(), B, [rets[1].contiguous()])
+    g_full = G.gtmp[:G.n_params + 3].clone()
+    acc = torch.zeros_like(g_full)
+    cap = 20000
+    for lo in range(0, B, cap):
+        hi = min(B, lo + cap)
+        G._iter_chunk([frames[lo:hi]], hi - lo, acts[lo:hi], old[lo:hi], adv[lo:hi], rets[0, lo:hi].contiguous(), B, [rets[1, lo:hi].contiguous()])
+        acc += G.gtmp[:G.n_params + 3]
+    gs = g_full[:G.n_params].abs().max().item()
+    assert (acc[:G.n_params] - g_full[:G.n_params]).abs().max().item() <= 1e-4 * gs
+    np.testing.assert_allclose(acc[G.n_params:].cpu().numpy(), g_full[G.n_params:].cpu().numpy(), rtol=1e-4, atol=1e-7)

@@ -225,3 +225,22 @@ def test_heads_take_the_two_feature_buffers_at_any_relative_address(order):
     want_dv = (want_v - ret.cpu()) / n                      # d (mean((ret - v)^2) / 2) / d v
     close(dh[ic], want_dv[:, None] * wc[None, :])
     assert float(dh[ia].abs().max()) > 0
+
+
+def test_linear_launch_smaller_than_capacity_takes_more_splits():
+    """A dense layer built for max_n samples and launched with fewer: the split-K count of the forward fills the chip, so 40,000
+    samples take two splits where 65,536 take one -- the partial-sum workspace must hold the LARGEST splits(n') n' N over n' <= max_n
+    (sizing by max_n alone overflowed it: a GPU memory fault, found by the full-size GAIL property test)."""
+    from ddrl4nav_amd.ops import Linear
+    K, N, cap = 516, 64, 65536
+    g = torch.Generator().manual_seed(3)
+    W, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g) * 0.1
+    lin = Linear(K, N, max_n=cap)
+    lin.pack(W.cuda())
+    guard = torch.full((1 << 20,), 7.0, device="cuda")      # a neighbour the old overflow would have written into
+    for n in (40000, 25536, 300, cap):
+        x = torch.randn(n, K, generator=g)
+        out = torch.empty((n, N), device="cuda")
+        lin.forward(x.cuda(), K, b.cuda(), True, out, N, n)
+        close(out, torch.relu(x @ W.T + b))
+    assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
