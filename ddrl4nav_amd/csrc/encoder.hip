@@ -23,12 +23,9 @@ __global__ __launch_bounds__(256) void dh_normalise_kernel(float* __restrict__ d
                   fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  int ex = GSC_EXP_MIN;
-  if (m > 0.0f && m < 3.0e38f) {
-    frexpf(m, &ex);  // m = f 2^ex, f in [0.5, 1)
-    ex = min(max(ex - 1, GSC_EXP_MIN), GSC_EXP_MAX);
-  }
-  const float g = ldexpf(1.0f, ex), gi = ldexpf(1.0f, -ex);
+  int ex = GSC_EXP_MIN;  // floor(log2 m) from the bit pattern (subnormal m clamps to the lower bound)
+  if (m > 0.0f && m < 3.0e38f) ex = min(max((int)((__float_as_uint(m) >> 23) & 0xFFu) - 127, GSC_EXP_MIN), GSC_EXP_MAX);
+  const float g = __uint_as_float((unsigned)(ex + 127) << 23), gi = __uint_as_float((unsigned)(127 - ex) << 23);
   row[0] = v0 * gi;
   row[1] = v1 * gi;
   if (lane == 0) {
@@ -41,12 +38,16 @@ __global__ __launch_bounds__(256) void dh_normalise_kernel(float* __restrict__ d
     if (mb > __hip_atomic_load(sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sm, mb);
   }
 }
-static void launch_backward_amax(const EncCall& c, hipStream_t st) {
+void launch_backward_amax_reset(const EncCall& c, hipStream_t st) {
   static_assert(AMAX_DZ3 == AMAX_DH + 1 && AMAX_DZ2 == AMAX_DH + 2 && AMAX_DZ1 == AMAX_DH + 3 && AMAX_GMAX == AMAX_DH + 4 &&
                     AMAX_SLOTS == AMAX_DH + 5,
                 "gradient slots are the last five");
+  (void)hipMemsetAsync(c.ws->amax + amax_idx(AMAX_DH, 0), 0, 5 * 2 * sizeof(float), st);  // dz3 / dz2 / dz1 are raised by their producers
+}
+static void launch_backward_amax(const EncCall& c, hipStream_t st) {
   const Workspace& w = *c.ws;
-  (void)hipMemsetAsync(w.amax + amax_idx(AMAX_DH, 0), 0, 5 * 2 * sizeof(float), st);  // dz3 / dz2 / dz1 are raised by their producers
+  launch_backward_amax_reset(c, st);
+  ProfRange pr(c.prof, "dh_normalise", st);
   hipLaunchKernelGGL(dh_normalise_kernel, dim3((c.n + 3) / 4, c.L->NE), dim3(256), 0, st, w.dh, c.max_batch * FEAT, c.n, w.gsc, c.max_batch,
                      w.amax);
 }
@@ -63,8 +64,8 @@ void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st) {
 // and the activations) is still intact then.  The layer-by-layer order (-DDDRL_BWD_LAYERWISE) alternates bf16-pipe and
 // fp32-pipe kernels, and each fp32 kernel that follows a bf16 one starts at the lower clock the denser pipe leaves
 // behind: 42.07 vs 41.84 ms per PPO iteration on one box.
-void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st) {
-  launch_backward_amax(c, st);
+void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st, bool dh_normalised) {
+  if (!dh_normalised) launch_backward_amax(c, st);  // dh from heads_loss arrives normalised (heads.hip); anyone else's is normalised here
 #ifndef DDRL_BWD_LAYERWISE
   launch_fc_backward2(c, grads, st, 1);
   launch_conv_dgrad3_2(c, st);

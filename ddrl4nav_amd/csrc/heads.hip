@@ -219,7 +219,8 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
     const float* __restrict__ actions, const float* __restrict__ old_logps, const float* __restrict__ advs,
     const float* __restrict__ rets, float inv_b, float* __restrict__ dh, int64_t dh_es, float* __restrict__ dlogits,
-    float* __restrict__ dvalue, float* __restrict__ hpart, int64_t hstride) {
+    float* __restrict__ dvalue, float* __restrict__ hpart, int64_t hstride, float* __restrict__ gsc, int64_t gsc_es,
+    float* __restrict__ amax) {
   __shared__ float red[(MAXA + 1) * FEAT + 2 * MAXA + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gw = blockIdx.x * LOSS_WAVES + wave;
@@ -238,7 +239,38 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) gwc[i] = 0.0f;
   double s_actor = 0.0, s_v = 0.0, s_ent = 0.0;
-
+  // per-sample normalisation of the backward fused into the producer of dh (encoder.hip dh_normalise_kernel is the stand-alone form
+  // for dh that arrives from elsewhere): running maxima of this wave's scales g_s and of its normalised |dh|
+  float run_g[2] = {0.0f, 0.0f}, run_m[2] = {0.0f, 0.0f};
+  float wc_absmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wc_absmax = fmaxf(wc_absmax, fabsf(R.wc[i]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) wc_absmax = fmaxf(wc_absmax, __shfl_xor(wc_absmax, off, 64));
+  // (exponent arithmetic on the bit pattern: frexpf / ldexpf are library calls, and this runs once per sample and encoder)
+  auto scale_of = [&](float m, float& g, float& gi) {
+    int ex = GSC_EXP_MIN;
+    if (m > 0.0f && m < 3.0e38f) ex = min(max((int)((__float_as_uint(m) >> 23) & 0xFFu) - 127, GSC_EXP_MIN), GSC_EXP_MAX);  // floor(log2 m); subnormals clamp
+    g = __uint_as_float((unsigned)(ex + 127) << 23);
+    gi = __uint_as_float((unsigned)(127 - ex) << 23);
+  };
+  auto normalise = [&](float (&d)[8], float m, int e, int b) {  // m = max_k |d[k]| over the whole wave
+    float g, gi;
+    scale_of(m, g, gi);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] *= gi;
+    if (lane == 0) gsc[e * gsc_es + b] = g;
+    run_g[e] = fmaxf(run_g[e], g);
+    run_m[e] = fmaxf(run_m[e], m * gi);
+  };
+  auto wave_absmax = [&](const float (&d)[8]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(d[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return m;
+  };
   // shared prenet (ppo.py:110-117): one backward of total_loss = actor_loss + theta_v * v_loss
   // - theta_e * entropy, so the value gradient carries theta_v, the entropy has a gradient, and
   // both heads feed the one encoder.  Non-shared (ppo.py:118-129): actor_loss.backward() and
@@ -338,8 +370,15 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     if (shared) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) da[i] += dc[i];
+      if (gsc != nullptr) normalise(da, wave_absmax(da), 0, b);
       store8(dh + (int64_t)b * FEAT + lane * 8, da);
     } else {
+      if (gsc != nullptr) {
+        normalise(da, wave_absmax(da), 0, b);
+        // the critic's row is gv * w_c: its largest magnitude is |gv| x the (loop-invariant) largest |w_c| -- exactly, since rounding
+        // a product is monotone in the factor -- so only the actor's row needs a reduction
+        normalise(dc, fabsf(gv) * wc_absmax, 1, b);
+      }
       store8(dh + (int64_t)b * FEAT + lane * 8, da);
       store8(dh + dh_es + (int64_t)b * FEAT + lane * 8, dc);
     }
@@ -347,6 +386,17 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     if (lane == 0) dvalue[b] = gv;
   }
 
+  if (gsc != nullptr && lane == 0) {  // AMAX_GMAX / AMAX_DH: one look (and rarely an atomic) per wave and encoder
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (e > ec) break;
+      const unsigned gb = __float_as_uint(run_g[e]), mb = __float_as_uint(run_m[e]);
+      unsigned* sg = (unsigned*)(amax + amax_idx(AMAX_GMAX, e));
+      unsigned* sm = (unsigned*)(amax + amax_idx(AMAX_DH, e));
+      if (gb > __hip_atomic_load(sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sg, gb);
+      if (mb > __hip_atomic_load(sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sm, mb);
+    }
+  }
   // ---- workgroup reduction, waves accumulate in turn (fixed order) -> hpart[blockIdx.x] ----
   constexpr int SCAL = (MAXA + 1) * FEAT;
   if constexpr (WLDS) __syncthreads();  // every wave is done with the LDS weights aliased by `red`
@@ -526,7 +576,8 @@ void launch_heads_loss(const HeadsCall& c, const float* actions, const float* ol
   auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : heads_loss_kernel<MAXA_SMALL, false>;
   hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(LOSS_WAVES * 64), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT, c.params,
                      *c.L, *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh,
-                     c.dh_es != HeadsCall::ES_UNSET ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs);
+                     c.dh_es != HeadsCall::ES_UNSET ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs,
+                     c.normalise_dh ? c.ws->gsc : nullptr, c.max_batch, c.ws->amax);
   if (large)
     hipLaunchKernelGGL(head_wgrad_kernel<MAXA_LARGE>, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.ws->dlogits, c.n,
                        c.L->A, c.ws->hpart, hs);

@@ -44,7 +44,8 @@ inline void bucket_done(const EncCall& c, int b, hipStream_t st) {
 
 // encoder.hip
 void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st);
-void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st);
+void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st, bool dh_normalised = false);
+void launch_backward_amax_reset(const EncCall& c, hipStream_t st);  // zeroes the gradient slots of Workspace::amax
 
 // fc2.hip (v2 engine)
 #ifndef DDRL_ACT_BF16X6_MIN
@@ -94,6 +95,9 @@ struct HeadsCall {
   static constexpr int64_t ES_UNSET = INT64_MIN;
   int64_t h_es = ES_UNSET, dh_es = ES_UNSET;
   bool plain_features = false;
+  // heads_loss also normalises dh per sample (Workspace::gsc, amax slots DH / GMAX, which the caller has zeroed): the Atari context's
+  // ddrl_ppo_iter; launch_encoder_backward is then told to skip its stand-alone dh_normalise_kernel
+  bool normalise_dh = false;
 };
 void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id,
                       float* probs, float* value, float* action_out, float* logp_out, hipStream_t st);

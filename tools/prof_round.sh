@@ -1,0 +1,16 @@
+#!/bin/bash
+# One gpurun call's worth of profiling for a round tag (e.g. r03_v1): the bench line, the same command under
+# rocprofv3 --kernel-trace --stats, and the PMC passes of tools/prof_pmc.sh.  Results land in gpurun_out/<tag>/;
+# tools/pmc_to_profiles.py + a copy of the summaries into profiles/ follow on the build host.
+# usage (on the GPU box, through gpurun):  bash tools/prof_round.sh r03_v1
+set -u
+TAG=${1:-rXX}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+python3 bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-async --no-ingest > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" ); echo "kernel-trace rc=$?"
+find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+bash tools/prof_pmc.sh "gpurun_out/$TAG/pmc"; echo "pmc rc=$?"
+hostname > "$OUT/box.txt"; rocm-smi --showproductname 2>/dev/null | head -8 >> "$OUT/box.txt"
+ls "$OUT" "$OUT/pmc" | head -40
