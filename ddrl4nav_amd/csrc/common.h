@@ -71,20 +71,20 @@ struct Workspace {
   float* wlt;  // [2][3136][512]    FC fwd B operand
   // f32 packed weights of conv2 / conv3 for the f32-input MFMA kernels of small acting launches: [k-block][k-step][lane half][row]
   float *wp2, *wp3;
-  // conv1 weights split into three bf16 planes (W = W1 + W2 + W3 to 24 bits), conv2.hip conv_fwd1_bf16x3_kernel:
+  // 16-bit weight planes, NPL per tensor (engine2.h: two scaled fp16 planes by default).  conv1, conv2.hip conv_fwd1_planes_kernel:
   // [channel 4][ky pair 4][plane NPL][lane half 2][row 32 NE][kx 8] 16-bit
   unsigned short* wp1b;
-  // conv2 weights as three bf16 planes [e][in channel 32][plane 3][oc 64][tap 16] (conv2.hip conv_fwd2_planes_kernel)
+  // conv2 weights as planes [e][in channel 32][plane NPL][oc 64][tap 16] (conv2.hip conv_fwd2_planes_kernel)
   unsigned short* wp2b;
-  // conv3 weights as three bf16 planes [e][k-block 8][tap pair 5][plane 3][oc 64][tap parity 2][channel 8] (conv_fwd3_planes_kernel)
+  // conv3 weights as planes [e][k-block 8][tap pair 5][plane NPL][oc 64][tap parity 2][channel 8] (conv_fwd3_planes_kernel)
   unsigned short* wp3b;
-  // conv2 weights for the data gradient as three bf16 planes [e][row parity 2][k-block 8][u 2][plane 3][(c, ic) 64][v 2][oc 8]
+  // conv2 weights for the data gradient as planes [e][row parity 2][k-block 8][u 2][plane NPL][(c, ic) 64][v 2][oc 8]
   unsigned short* wd2b;
   // conv3 weights for the data gradient as planes [e][k-block 4 (16 oc)][tap 9][plane][ic 64][oc half 2][oc 8]
   unsigned short* wd3b;
-  // dense-layer weights as three bf16 planes [e][plane 3][512][3136] (fc2.hip fc_fwd_planes_kernel)
+  // dense-layer weights as planes [e][plane NPL][512][3136] (fc2.hip fc_fwd_planes_kernel)
   unsigned short* wlb;
-  // the same planes transposed, [e][plane 3][3136][512] (fc2.hip fc_dgrad_planes_kernel)
+  // the same planes transposed, [e][plane NPL][3136][512] (fc2.hip fc_dgrad_planes_kernel)
   unsigned short* wdlb;
   float* amax;  // [AMAX_SLOTS][2 encoders], see AMAX_* below
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
@@ -171,7 +171,7 @@ inline Splits choose_splits(int max_batch, int NE = 2) {
   s.c1 = cap(DDRL_C1_SPLITS, pairs);      // 1 column tile, encoders fused
   const int k = 2 / NE;         // one encoder: twice the splits keep the same number of workgroups
   s.c2 = cap(256 * k, pairs);   // 2 column tiles x 2 encoders
-  s.c3 = cap(256 * k, pairs);   // conv_wgrad3_bf16x6: one workgroup per (split, encoder), up to two per CU
+  s.c3 = cap(256 * k, pairs);   // conv_wgrad3_planes_kernel: one workgroup per (split, encoder), up to two per CU
   s.fc = cap(5 * k, (max_batch + 31) / 32);  // 25 x 4 tiles x 2 encoders
   return s;
 }

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   for (int j = 0; j < 6; ++j) {
     const int idx = tid + 256 * j;
     imsrc[j] = (idx >= nd_total) ? src0 : (idx < nd0 ? src0 + idx * 4 : src1 + (idx - nd0) * 4);
-    imdst[j] = K::A_BYTES + (idx / 21) * K::PITCH + (idx % 21) * 8;  // 4 pixels -> 4 bf16
+    imdst[j] = K::A_BYTES + (idx / 21) * K::PITCH + (idx % 21) * 8;  // 4 pixels -> 4 halfwords
   }
   int abase[NE], bbase[2];
 #pragma unroll
@@ -430,13 +430,13 @@ static void launch_fwd1_planes(const EncCall& c, bool acting, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv2 forward on the bf16 matrix pipe, fp32-accurate ("bf16x6", see fc2.hip fc_fwd_planes_kernel): the weights come
-// as three bf16 planes from optim.hip (wp2b), the a1 values are split into three planes while they are staged, and the
+// conv2 forward on the 16-bit matrix pipe, fp32-accurate (plane products, see fc2.hip fc_fwd_planes_kernel): the weights come
+// as NPL planes from optim.hip (wp2b), the a1 values are split into NPL planes while they are staged, and the
 // six plane products that reach 2^-18 of the largest are accumulated in fp32.  One MFMA k-group (16) = the 4 x 4 taps
 // of ONE input channel: lane (pixel, h) holds taps (ky = 2h, kx = 0..3) and (ky = 2h + 1, kx = 0..3) = two runs of four
-// consecutive bf16 in the staged image (4-byte aligned 8-byte LDS reads), so the im2col stays implicit.
+// consecutive 16-bit values in the staged image (4-byte aligned 8-byte LDS reads), so the im2col stays implicit.
 // Tile = 64 output channels x 3 whole samples (243 columns in 8 column tiles of 32), k-block = 2 input channels (DDRL_F2B_KC);
-// LDS holds ONE stage (image planes [plane][sample][channel][20 rows of pitch 26] bf16 + weight planes [channel][plane][oc][16]):
+// LDS holds ONE stage (image planes [plane][sample][channel][20 rows of pitch 26] 16-bit + weight planes [channel][plane][oc][16]):
 // the next k-block waits in registers and is split / committed between two barriers while the CU's other
 // workgroups compute.
 // ================================================================================================
@@ -460,7 +460,7 @@ static void launch_fwd1_planes(const EncCall& c, bool acting, hipStream_t st) {
 #endif
 struct Fwd2B {
   static constexpr int SPT = 3, KC = DDRL_F2B_KC;                 // samples per tile, input channels per k-block
-  // image row pitch 26 bf16 (13 words): the 5 input-row pairs a 32-pixel column tile reads in one instruction start
+  // image row pitch 26 halfwords (13 words): the 5 input-row pairs a 32-pixel column tile reads in one instruction start
   // 26 words apart = banks {0, 26, 52, 14, 40} + c, ten words each, disjoint (pitch 20: 2-way conflicts, 46 % of LDS cycles)
   static constexpr int ROW = DDRL_F2B_ROW, CH = 20 * ROW, IMG_PLANE = SPT * KC * CH;  // 12,480 B at KC = 4
   static constexpr int W_OFF = NPL * IMG_PLANE, W_BYTES = KC * NPL * 64 * 32;
@@ -637,8 +637,8 @@ static void launch_fwd2_planes(const EncCall& c, bool acting, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv3 forward as bf16x6 (see conv_fwd2_planes_kernel).  Nine taps per input channel do not fill an MFMA k-group, so the
-// k index runs over CHANNELS: the a2 block is staged channel-innermost ([plane][sample][pixel][8 channels] bf16, one
+// conv3 forward as plane products (see conv_fwd2_planes_kernel).  Nine taps per input channel do not fill an MFMA k-group, so the
+// k index runs over CHANNELS: the a2 block is staged channel-innermost ([plane][sample][pixel][8 channels] 16-bit, one
 // 16-byte fragment per pixel) and one k-group = (two taps) x (8 channels): lane half h reads tap 2 kg + h.  Nine taps =
 // 4.5 pairs: the tenth "tap" re-reads tap 8 against zero weights (10 % of the MFMAs).  Tile = 64 output channels x 5
 // whole samples (245 columns in 8 column tiles), k-block = 8 input channels = 5 k-groups; one LDS stage, the next
@@ -847,7 +847,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv3 data gradient as bf16x6, gather form (see conv_fwd3_planes_kernel, whose mirror image it is):
+// conv3 data gradient as plane products, gather form (see conv_fwd3_planes_kernel, whose mirror image it is):
 //   dz2[b][ic][y][x] = leaky'(a2) * sum_{oc,ky,kx} dz3[b][oc][y-ky][x-kx] W3[oc][ic][ky][kx]
 // dz3 is staged channel-innermost into zero-bordered 11 x 11 images (data at +2, +2; [plane][sample][pixel][16 oc] 16-bit),
 // one MFMA k-group = one tap x 16 oc; tile = 64 ic x 3 whole samples (243 columns, wave w = columns 64 w .., 2 x 2 fragment
@@ -866,7 +866,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
 struct Dgrad3B {
   // one MFMA k-group = ONE tap x 16 oc (lane half h = oc 8 h .. 8 h + 7): nine k-groups per k-block of 16 oc, no padded tenth tap
   // (tap pairs x 8 oc walked ten: executed / algorithmic 1.84 -> 1.65), the tap shift is a compile-time LDS offset, four k-blocks
-  // instead of eight.  Weights: wd3b[e][k-block 4][tap 9][plane NPL][ic 64][oc half 2][oc 8] (optim.hip pack_dgrad3_bf16_kernel).
+  // instead of eight.  Weights: wd3b[e][k-block 4][tap 9][plane NPL][ic 64][oc half 2][oc 8] (optim.hip pack_dgrad3_planes_kernel).
   // four waves / 3 samples per workgroup, two workgroups per CU.  (-DDDRL_D3B_THREADS=512: eight waves / 6 samples share one copy of
   // the k-block's 37 KB of weights, one workgroup per CU: measured slower.)
   static constexpr int THREADS = DDRL_D3B_THREADS, TN = DDRL_D3B_TN, SPT = ((THREADS / 64) * 32 * TN) / 81;  // column tiles per wave, whole samples per tile
@@ -1020,11 +1020,11 @@ void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv2 data gradient as bf16x6 (see conv_fwd2_planes_kernel / conv_fwd3_planes_kernel):
+// conv2 data gradient as plane products (see conv_fwd2_planes_kernel / conv_fwd3_planes_kernel):
 //   da1[b][ic][2p+a][2q+c] = sum_{oc,u,v} dz2[b][oc][p-u][q-v] W2[oc][ic][2u+a][2v+c]
 // A workgroup owns one row parity a, both column parities c (rows = (c, ic) = 64) and 5 whole samples
 // (cols = (sample, p, q) = 500, wave w = columns 128 w .. 128 w + 127, 2 x 4 fragment tiles per wave).  dz2 is staged
-// channel-innermost into zero-bordered 11 x 11 images ([plane][sample][pixel][8 oc] bf16, 16 B per pixel): one MFMA
+// channel-innermost into zero-bordered 11 x 11 images ([plane][sample][pixel][8 oc] 16-bit, 16 B per pixel): one MFMA
 // k-group = (u; v = lane half) x 8 oc, a k-block = 8 oc = 2 k-groups, 8 k-blocks.  One LDS stage; the border stays
 // zero because only interior pixels are ever written.  Weights: wd2b[e][a][k-block 8][u 2][plane 3][row 64][v 2][oc 8].
 // The output is the raw d(loss)/d(a1): the leaky mask is applied by its only consumer, conv1's weight gradient.

@@ -415,7 +415,7 @@ inline void launch_engine2(dim3 grid, const typename Op::Params& p, hipStream_t 
 }
 
 // accumulator element r of tile (i,j) of this lane -> (row, col) inside the wave tile
-// ---- fp32 -> three bf16 planes (the "bf16x3 / bf16x6" kernels) --------------------------------------------------
+// ---- fp32 -> three bf16 planes (only the -DDDRL_PLANES_BF16 build uses them; the default planes are fp16, below) ------
 // x = p0 + p1 + p2 to 24 bits: p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1), round-to-nearest-even
 // (v_cvt_pk_bf16_f32); the two subtractions are exact in fp32.  Two values per dword: x in the low half, y in the high.
 using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
@@ -430,7 +430,7 @@ __device__ __forceinline__ void split_bf16x3(float x, float y, unsigned& p0, uns
   const float r2x = r1x - __uint_as_float(p1 << 16), r2y = r1y - __uint_as_float(p1 & 0xFFFF0000u);
   p2 = pack_bf16x2(r2x, r2y);
 }
-// the six plane products of a bf16x6 k-group, smallest first: (a plane, b plane)
+// the six plane products of a k-group under three bf16 planes per operand, smallest first: (a plane, b plane)
 #define DDRL_BF16X6_PRODUCTS constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0}
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -174,12 +174,12 @@ struct FcFwd2 : FcCommon {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Dense-layer forward on the bf16 matrix pipe, fp32-accurate ("bf16x6"): both operands are split into three bf16
+// Dense-layer forward on the 16-bit matrix pipe, fp32-accurate (plane products, engine2.h): both operands are split into NPL 16-bit
 // planes (x = x0 + x1 + x2 to 24 bits; the weights once per optimiser step in optim.hip, the activations while they
 // are staged) and the six plane products whose magnitude reaches 2^-18 of the largest are accumulated in fp32:
 // a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 (the dropped ones are below 2^-26).  192 matrix-pipe cycles per 16 k instead of
 // the 512 of eight f32 MFMAs.  128 x 128 tile, k-block 32 = 2 MFMA k-groups; LDS holds ONE stage
-// ([plane][row][32 k] bf16, row pitch 80 B so that 16 lanes' 16-byte fragments hit distinct banks): the next
+// ([plane][row][32 k] 16-bit, row pitch 80 B so that 16 lanes' 16-byte fragments hit distinct banks): the next
 // k-block waits in registers and is committed between two barriers while the CU's other workgroup computes.
 // ------------------------------------------------------------------------------------------------
 using bf8f = __attribute__((ext_vector_type(8))) __bf16;
@@ -337,9 +337,9 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense-layer data gradient as bf16x6 (same structure as fc_fwd_planes_kernel with the roles K = 512 features,
+// Dense-layer data gradient as plane products (same structure as fc_fwd_planes_kernel with the roles K = 512 features,
 // N = 3,136 conv3 outputs):  dz3[b][k] = leaky'(a3[b][k]) * sum_n dh[b][n] Wl[n][k].
-// dh is split into three bf16 planes while it is staged, the weights come pre-split and transposed from optim.hip
+// dh is split into NPL planes while it is staged, the weights come pre-split and transposed from optim.hip
 // (wdlb[e][plane][k 3136][n 512]); 128 x 128 tile, k-block 32 = 2 MFMA k-groups, one LDS stage.
 // ------------------------------------------------------------------------------------------------
 #ifndef DDRL_FCD_KBK
@@ -481,9 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FcDgradB::W
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense-layer weight gradient as bf16x6:  part[s][e][n][k] = sum_{b in split s} dh[b][n] a3[b][k]  (+ the bias partial).
+// Dense-layer weight gradient as plane products:  part[s][e][n][k] = sum_{b in split s} dh[b][n] a3[b][k]  (+ the bias partial).
 // Both operands are "reduction-major" in memory ([b][n] and [b][k]): they are staged as they lie -- rows = 32 samples of
-// the k-block, 128 columns, split into three bf16 planes on the way into LDS -- and the MFMA fragments (8 consecutive
+// the k-block, 128 columns, split into NPL planes on the way into LDS -- and the MFMA fragments (8 consecutive
 // SAMPLES of one column per lane) are read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group
 // fetches a 4-row x 16-column block and every lane receives one column of it, two reads per fragment.
 // Image row pitch 320 B = 256 B of data + 64 B pad: the four rows of a block fall into the four bank quarters, so the

@@ -49,8 +49,9 @@ void launch_backward_amax_reset(const EncCall& c, hipStream_t st);  // zeroes th
 
 // fc2.hip (v2 engine)
 #ifndef DDRL_ACT_BF16X6_MIN
-// acting launches of at least this many envs use the bf16x6 conv2 / conv3 kernels too (us per ddrl_forward, fp32-MFMA
-// narrow-tile kernels vs bf16x6: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7, 2048: 606.2 / 480.9)
+// acting launches of at least this many envs use the plane-product conv2 / conv3 kernels too (the macro keeps its round-1 name; us per
+// ddrl_forward measured then, fp32-MFMA narrow-tile kernels vs plane products: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7,
+// 2048: 606.2 / 480.9)
 #define DDRL_ACT_BF16X6_MIN 192
 #endif
 // Split-K factor of the FC forward for a batch of n samples (1 = plain; >1 only on the acting

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ pa
 
 // conv1 weights as the NPL planes of engine2.h's plane scheme (default: two scaled fp16 planes, h0 + h1 = w S to 22 bits; the
 // kernel names keep their history).  Layout: common.h wp1b.
-__global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
+__global__ __launch_bounds__(256) void pack_conv1_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
                                                               const float* __restrict__ amax) {
   const int rows = 32 * L.NE;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256) void pack_conv1_bf16_kernel(const float* __res
   for (int p = 0; p < NPL; ++p) dst[(((base + p) * 2 + h) * rows + row) * 8 + j] = pl[p];
 }
 
-// dense-layer weights as three bf16 planes (see pack_conv1_bf16_kernel): wlb[e][plane][n][k]
-__global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
+// dense-layer weights as NPL planes (see pack_conv1_planes_kernel): wlb[e][plane][n][k]
+__global__ __launch_bounds__(256) void pack_fc_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
                                                            unsigned short* __restrict__ dst_t, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void pack_fc_bf16_kernel(const float* __restri
   for (int p = 0; p < NPL; ++p) t[p * (int64_t)FLAT * FEAT] = pl[p];
 }
 
-// conv2 weights as three bf16 planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
-__global__ __launch_bounds__(256) void pack_conv2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
+// conv2 weights as NPL planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
+__global__ __launch_bounds__(256) void pack_conv2_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (oc, ch, tap) in parameter order
   if (i >= 64 * 32 * 16) return;
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void pack_conv2_bf16_kernel(const float* __res
   for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
-// conv3 weights as three bf16 planes: wp3b[e][k-block = ic / 8][tap pair][plane][oc][tap parity][ic % 8]; the tenth tap is zero
-__global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
+// conv3 weights as NPL planes: wp3b[e][k-block = ic / 8][tap pair][plane][oc][tap parity][ic % 8]; the tenth tap is zero
+__global__ __launch_bounds__(256) void pack_conv3_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, kg, oc, h, c)
   if (i >= 8 * 5 * 64 * 16) return;
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __res
   for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
-// conv2 weights for the bf16x6 data gradient: wd2b[e][a][kb 8][u 2][plane][row = c * 32 + ic][v][o]
+// conv2 weights for the plane-product data gradient: wd2b[e][a][kb 8][u 2][plane][row = c * 32 + ic][v][o]
 //   = W2[oc = 8 kb + o][ic][2 u + a][2 v + c]
-__global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void pack_dgrad2_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (a, kb, u, row, v, o)
   if (i >= 2 * 8 * 2 * 64 * 16) return;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void pack_dgrad2_bf16_kernel(const float* __re
 }
 
 // conv3 weights for the data gradient on planes (conv2.hip conv_dgrad3_planes_kernel): k-blocks of 16 oc, one k-group per tap
-__global__ __launch_bounds__(256) void pack_dgrad3_bf16_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void pack_dgrad3_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;  // (kb 4, tap 9, ic 64, h 2, o 8): wd3b[e][kb][tap][plane][ic][h][o] = W3[oc = 16 kb + 8 h + o][ic][tap]
   if (i >= 4 * 9 * 64 * 16) return;
@@ -177,12 +177,12 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   (void)hipMemsetAsync(w.amax, 0, AMAX_FIRST_ACT * 2 * sizeof(float), st);
   hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_A1, L.NE), dim3(256), 0, st, params, L, w.amax);
   hipLaunchKernelGGL(a1_bound_kernel, dim3(32, L.NE), dim3(64), 0, st, params, L, w.amax);
-  hipLaunchKernelGGL(pack_dgrad3_bf16_kernel, dim3(4 * 9 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
-  hipLaunchKernelGGL(pack_dgrad2_bf16_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
-  hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
-  hipLaunchKernelGGL(pack_conv2_bf16_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
-  hipLaunchKernelGGL(pack_fc_bf16_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
-  hipLaunchKernelGGL(pack_conv1_bf16_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
+  hipLaunchKernelGGL(pack_dgrad3_planes_kernel, dim3(4 * 9 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
+  hipLaunchKernelGGL(pack_dgrad2_planes_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
+  hipLaunchKernelGGL(pack_conv3_planes_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
+  hipLaunchKernelGGL(pack_conv2_planes_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
+  hipLaunchKernelGGL(pack_fc_planes_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
+  hipLaunchKernelGGL(pack_conv1_planes_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
   {
     const int total2 = L.NE * (16 * 16 * 2 * 64 + 16 * 18 * 2 * 64);
     hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);

@@ -33,7 +33,7 @@ struct WgradSplit {
 };
 
 // ================================================================================================
-// conv3 weight gradient as bf16x6 (both operands fp32: dz3 and a2, split into three bf16 planes while staged, six plane
+// conv3 weight gradient as plane products (both operands fp32: dz3 and a2, split into NPL 16-bit planes while staged, NPROD plane
 // products, fp32 accumulation):
 //   part[s][e][oc][ic][tap] = sum_{b in split s} sum_p dz3[b][oc][p] * a2[b][ic][pos(p, tap)],   pos = (p/7 + ky) 9 + p%7 + kx
 // GEMM rows = oc (64), columns = (tap, ic) (9 x 64), reduction index kappa = (sample, output pixel).
@@ -272,7 +272,7 @@ void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
 }
 
 // ================================================================================================
-// conv2 weight gradient as bf16x6, the conv3 design above on conv2's geometry:
+// conv2 weight gradient as plane products, the conv3 design above on conv2's geometry:
 //   part[s][e][oc][ic][ky][kx] = sum_{b in split s} sum_p dz2[b][oc][p] * a1[b][ic][(2 y + ky) 20 + 2 x + kx],   p = 9 y + x
 // rows = oc (64), columns = (tap, ic) (16 x 32), reduction kappa = output pixel of ONE sample per stage (81 -> 6 k-groups,
 // the last one 1/16 full: 15.6 % of the MFMAs meet zero rows; two samples do not fit LDS).  dz2 is staged as

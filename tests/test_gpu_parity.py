@@ -304,7 +304,7 @@ def test_clip_coefficient_and_norm(hp, onet, golden):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv1_forward_is_at_least_fp32_accurate(hp, kind):
-    """The conv1 forward runs on the bf16 matrix pipe (exact-bf16 pixels x three bf16 planes of the fp32 weights,
+    """The conv1 forward runs on the 16-bit matrix pipe (pixels 0..255, exact in fp16, x two scaled fp16 planes of the fp32 weights,
     fp32 accumulation).  That is not a precision trade: against a float64 evaluation of the reference arithmetic its
     error must not exceed that of torch's own fp32 convolution (measured: about half of it)."""
     n = 96
@@ -328,7 +328,7 @@ def test_conv1_forward_is_at_least_fp32_accurate(hp, kind):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp, kind):
-    """Same statement for the conv1 weight gradient (dz1 split into three bf16 planes x exact-bf16 pixels): given
+    """Same statement for the conv1 weight gradient (dz1 split into two scaled fp16 planes, per-sample power-of-two scales, x exact-fp16 pixels): given
     the kernel's own dz1 and the frames, its dW1 must be as close to the float64 sum as an fp32 evaluation is."""
     n = 64
     frames = _inputs(n, 32, kind)[0]
@@ -350,9 +350,9 @@ def test_conv1_weight_gradient_is_at_least_fp32_accurate(hp, kind):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_dense_forward_is_at_least_fp32_accurate(hp, kind):
-    """The dense layer's forward in a training launch splits BOTH operands into three bf16 planes and sums six plane
-    products in fp32 (fc_bf16x6_kernel).  Given the kernel's own a3, the error of h against the float64 product must
-    stay within a few rounding units (2^-24) of sum_k |a_k w_k| (limit: tests/golden/margins.json = measured x 1.5) -- far below the n * eps bound of a sequential fp32
+    """The dense layer's forward in a training launch splits BOTH operands into two scaled fp16 planes and sums three plane
+    products in fp32 (fc_fwd_planes_kernel).  Given the kernel's own a3, the error of h against the float64 product must
+    stay within a few rounding units (2^-24) of sum_k |a_k w_k| (stated limit: 8 units, tests/parity_util.py ACCURACY_CAP) -- far below the n * eps bound of a sequential fp32
     chain over K = 3,136 (torch's blocked CPU matmul, whose error is reported alongside, is closer still)."""
     n = 200
     w = _bwd_setup(hp, n, 33, kind)
@@ -369,7 +369,7 @@ def test_dense_forward_is_at_least_fp32_accurate(hp, kind):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv2_forward_is_at_least_fp32_accurate(hp, kind):
-    """conv2's forward in a training launch is a bf16x6 kernel too (conv_fwd2_bf16x6_kernel: weights pre-split, a1 split
+    """conv2's forward in a training launch is a plane-product kernel too (conv_fwd2_planes_kernel: weights pre-split, a1 split
     while staged, one MFMA k-group = the 16 taps of one input channel).  Given the kernel's own a1, a2 must be as close
     to the float64 convolution as torch's fp32 convolution is, and within a few rounding units of sum |a w| (margins.json)."""
     n = 100  # 34 tiles of 3 samples, the last one holds a single sample
@@ -390,7 +390,7 @@ def test_conv2_forward_is_at_least_fp32_accurate(hp, kind):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv3_forward_is_at_least_fp32_accurate(hp, kind):
-    """Same statement for conv3's training-launch forward (conv_fwd3_bf16x6_kernel: a2 staged channel-innermost, one
+    """Same statement for conv3's training-launch forward (conv_fwd3_planes_kernel: a2 staged channel-innermost, one
     MFMA k-group = two taps x eight channels, the tenth tap padded with zero weights)."""
     n = 101  # 21 tiles of 5 samples, the last one holds a single sample
     w = _bwd_setup(hp, n, 35, kind)
@@ -443,7 +443,7 @@ def _leaky_mask(a, g):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_dense_data_gradient_is_at_least_fp32_accurate(hp, kind):
-    """fc_dgrad_bf16x6_kernel (dh and the transposed weight planes split into three bf16 planes each, six plane products,
+    """fc_dgrad_planes_kernel (dh and the transposed weight planes as two scaled fp16 planes each, three plane products,
     leaky mask in the epilogue): given the kernel's own dh and a3, dz3 against the float64 product, in rounding units of
     sum_k |dh_k w_k| and beside torch's fp32 matmul."""
     n = 200
@@ -458,13 +458,13 @@ def test_dense_data_gradient_is_at_least_fp32_accurate(hp, kind):
         err_kernel, err_f32 = np.abs(dz3 - ref).max(), np.abs(f32 - ref).max()
         mass = float((dh.double().abs() @ W.double().abs()).max())
         P.MARGINS.check("accuracy", "dense_dgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
-        # mean error beside torch's fp32 operator (a bf16x6 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
+        # mean error beside torch's fp32 operator (an f16x3 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
         P.MARGINS.check("accuracy", "dense_dgrad_mean_vs_torch_fp32", np.abs(dz3 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_dense_weight_gradient_is_at_least_fp32_accurate(hp, kind):
-    """fc_wgrad_bf16x6_kernel (dh and a3 split into three bf16 planes while staged, fragments through the transposing LDS
+    """fc_wgrad_planes_kernel (dh and a3 split into two scaled fp16 planes while staged, fragments through the transposing LDS
     read, six plane products, split over the batch and summed in fixed order): given the kernel's own dh and a3,
     dW = dh^T a3 and db = column sums of dh against float64, beside torch's fp32 matmul.  n = 333 leaves a ragged last
     k-block and k-tile 24 is the half-empty one (3136 = 24.5 x 128)."""
@@ -488,7 +488,7 @@ def test_dense_weight_gradient_is_at_least_fp32_accurate(hp, kind):
 @pytest.mark.parametrize("n", [101, 6])
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n, kind):
-    """conv_wgrad3_bf16x6_kernel (dz3 and a2 staged channel-innermost as three bf16 planes each, fragments through the
+    """conv_wgrad3_planes_kernel (dz3 and a2 staged channel-innermost as two scaled fp16 planes each, fragments through the
     transposing LDS read, 2 samples per stage, 128 sample splits summed in fixed order): given the kernel's own dz3 and
     a2, dW3 and db3 against float64, beside torch's fp32 weight gradient.  n = 101 leaves a one-sample last stage and
     most of the 128 splits empty; n = 6 leaves all but three empty."""
@@ -512,7 +512,7 @@ def test_conv3_weight_gradient_is_at_least_fp32_accurate(hp, n, kind):
 @pytest.mark.parametrize("n", [77, 3])
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv2_weight_gradient_is_at_least_fp32_accurate(hp, n, kind):
-    """conv_wgrad2_bf16x6_kernel (dz2 and a1 staged channel-innermost as three bf16 planes each, one sample per stage,
+    """conv_wgrad2_planes_kernel (dz2 and a1 staged channel-innermost as two scaled fp16 planes each, one sample per stage,
     fragments through the transposing LDS read): given the kernel's own dz2 and a1, dW2 and db2 against float64."""
     _bwd_setup(hp, n, 46, kind)
     got = _grad_views(hp)
@@ -533,7 +533,7 @@ def test_conv2_weight_gradient_is_at_least_fp32_accurate(hp, n, kind):
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv3_data_gradient_is_at_least_fp32_accurate(hp, kind):
-    """conv_dgrad3_bf16x6_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
+    """conv_dgrad3_planes_kernel: given the kernel's own dz3 (as [n,64,7,7]) and a2, dz2 = leaky'(a2) * conv_transpose(dz3, W3)
     against float64."""
     n = 101
     w = _bwd_setup(hp, n, 42, kind)
@@ -548,13 +548,13 @@ def test_conv3_data_gradient_is_at_least_fp32_accurate(hp, kind):
         err_kernel, err_f32 = np.abs(dz2 - ref).max(), np.abs(f32 - ref).max()
         mass = float(ct(dz3.double().abs(), W.double().abs()).max())
         P.MARGINS.check("accuracy", "conv3_dgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
-        # mean error beside torch's fp32 operator (a bf16x6 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
+        # mean error beside torch's fp32 operator (an f16x3 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
         P.MARGINS.check("accuracy", "conv3_dgrad_mean_vs_torch_fp32", np.abs(dz2 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
 def test_conv2_data_gradient_is_at_least_fp32_accurate(hp, kind):
-    """conv_dgrad2_bf16x6_kernel: given the kernel's own dz2, the RAW gradient w.r.t. a1 (conv1's leaky mask is applied
+    """conv_dgrad2_both_kernel: given the kernel's own dz2, the RAW gradient w.r.t. a1 (conv1's leaky mask is applied
     later, by the conv1 weight gradient) = conv_transpose(dz2, W2, stride 2) against float64."""
     n = 100
     w = _bwd_setup(hp, n, 43, kind)
@@ -568,13 +568,13 @@ def test_conv2_data_gradient_is_at_least_fp32_accurate(hp, kind):
         err_kernel, err_f32 = np.abs(da1 - ref).max(), np.abs(f32 - ref).max()
         mass = float(ct(dz2.double().abs(), W.double().abs(), stride=2).max())
         P.MARGINS.check("accuracy", "conv2_dgrad_units", err_kernel / (2.0 ** -24 * mass), "(%s: kernel %.3e, fp32 %.3e)" % (pre, err_kernel, err_f32))
-        # mean error beside torch's fp32 operator (a bf16x6 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
+        # mean error beside torch's fp32 operator (an f16x3 product keeps ~2^-22 of every term; torch's blocked fp32 sums ~2^-24)
         P.MARGINS.check("accuracy", "conv2_dgrad_mean_vs_torch_fp32", np.abs(da1 - ref).mean() / np.abs(f32 - ref).mean(), "(%s)" % pre)
 
 
 def _adopt_kernel_decisions(h, net, n, x):
     """Leaky-ReLU decision boundaries.  A pre-activation within fp32 noise of zero can come out on either side
-    depending on the summation order (the conv1 forward is a bf16x3 kernel whose output is CLOSER to float64 than
+    depending on the summation order (the conv1 forward is a plane-product kernel whose output is CLOSER to float64 than
     an fp32 chain, but not the same bits), and ONE such element of conv2 changes hundreds of conv1 weight-gradient
     elements by a few 1e-3 of their size.  So the per-parameter gradient comparisons are made under identical
     decisions: this (1) runs the oracle forward, (2) checks that the kernel's activation signs differ from the
