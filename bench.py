@@ -605,6 +605,11 @@ def main():
                     ent["pipe_ceiling_tflops"] = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
                     ent["frac_of_pipe_ceiling"] = round(ent["tflops"] / (PEAK_BF16_MFMA_TFLOPS / products), 4)
                     ent["executed_over_algorithmic"] = executed_over_algorithmic(k)
+            elif k == "ActConvs":
+                # conv1 + conv2 + conv3 of an acting forward in one launch (csrc/act.hip), N samples
+                per_launch = 2 * 2 * (MAC["ConvFwd1"] + MAC["ConvFwd2"] + MAC["ConvFwd3"]) * N
+                ent["tflops"] = round(per_launch * calls / (ms * 1e-3) / 1e12, 2)
+                ent["flop_per_launch"] = per_launch
             elif k in HBM_BYTES:
                 # HBM-bound kernels: algorithmic bytes per launch / launch time
                 per_launch = HBM_BYTES[k](N, B, hp.n_params)
@@ -679,7 +684,7 @@ def main():
                           "than an fp32 chain's (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  'tflops' is fp32-equivalent (algorithmic) "
                           "work; acting launches below 192 envs use the f32-input MFMA",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
-                             "(*.act, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
+                             "(ActConvs, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
         }
         if world == 1 and not args.no_async:
             hp.profile(False)

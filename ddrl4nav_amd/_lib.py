@@ -75,6 +75,7 @@ SIGNATURES = {
     "ddrl_clip_adam_step": (c_int32, [c_void_p, c_void_p]),
     "ddrl_u8_table": (c_int32, [c_void_p, c_void_p]),
     "ddrl_debug_buffer": (c_int32, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64)]),
+    "ddrl_debug_keep_activations": (c_int32, [c_void_p, c_int32]),
     "ddrl_ring_create": (c_int32, [c_int64, c_int32, POINTER(c_void_p)]),
     "ddrl_ring_destroy": (c_int32, [c_void_p]),
     "ddrl_ring_acquire": (c_int32, [c_void_p, POINTER(c_void_p), c_int32]),

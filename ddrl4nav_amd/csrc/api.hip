@@ -28,6 +28,8 @@ struct ddrl_ctx : public ddrl::Profiler {
   int last_n;
   bool profile;
   bool profile_acting;  // ddrl_profile_enable(on = 1): also time the (small, latency-bound) ddrl_forward launches
+  bool keep_acts = false;   // ddrl_debug_keep_activations: ddrl_forward also stores a1 / a2 (its fused kernel keeps them on chip)
+  bool acts_stored = true;  // false after a ddrl_forward that left a1 / a2 on chip: ddrl_debug_buffer(0 / 1) refuses
   hipEvent_t bucket_ev[GRAD_BUCKETS];
   hipEvent_t comm_done;
   bool buckets;  // ddrl_grad_buckets_enable: record the bucket events in every ddrl_ppo_iter
@@ -216,6 +218,8 @@ int32_t ddrl_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, const floa
   // record drains the queue): the acting path is only timed when asked for explicitly (on = 1)
   Profiler* prof = ctx->profile && ctx->profile_acting ? ctx : nullptr;
   EncCall ec{prof, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  ec.keep_acts = ctx->keep_acts;
+  ctx->acts_stored = ctx->keep_acts || n > DDRL_ACT_FUSED_MAX;
   launch_encoder_forward(ec, true, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, n, ctx->cfg.max_batch};
   {
@@ -268,6 +272,7 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   amax_begin(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, B, ctx->cfg.max_batch};
   if (ctx->buckets) ec.bucket_ev = ctx->bucket_ev;
+  ctx->acts_stored = true;
   launch_encoder_forward(ec, false, st);
   HeadsCall hc{&ctx->ws, &ctx->L, &ctx->cfg, ctx->params, B, ctx->cfg.max_batch};
   hc.normalise_dh = true;  // dh leaves heads_loss already normalised per sample (268 MB less to re-read and re-write per iteration)
@@ -376,6 +381,7 @@ int32_t ddrl_encoder_forward(ddrl_ctx* ctx, const uint8_t* frames, int32_t n, vo
   ensure_packed(ctx, st);
   amax_begin(ctx, st);
   EncCall ec{ctx->profile ? ctx : nullptr, &ctx->ws, &ctx->L, &ctx->splits, ctx->params, frames, n, ctx->cfg.max_batch};
+  ctx->acts_stored = true;
   launch_encoder_forward(ec, false, st);  // complete features (no split-K partials left for a head kernel to sum)
   ctx->last_n = n;
   return check_launch();
@@ -421,8 +427,12 @@ int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* en
   const int64_t MB = ctx->cfg.max_batch;
   const Workspace& w = ctx->ws;
   switch (which) {
-    case 0: *ptr = w.a1; *enc_stride = MB * 32 * 400; break;
-    case 1: *ptr = w.a2; *enc_stride = MB * 64 * 81; break;
+    case 0:
+      if (!ctx->acts_stored) return DDRL_ERR_UNSUPPORTED;
+      *ptr = w.a1; *enc_stride = MB * 32 * 400; break;
+    case 1:
+      if (!ctx->acts_stored) return DDRL_ERR_UNSUPPORTED;
+      *ptr = w.a2; *enc_stride = MB * 64 * 81; break;
     case 2: *ptr = w.a3; *enc_stride = MB * FLAT; break;
     case 3: *ptr = w.h; *enc_stride = MB * FEAT; break;
     case 4: *ptr = w.dz1; *enc_stride = MB * 32 * 400; break;
@@ -606,6 +616,12 @@ int32_t ddrl_timer_elapsed_ms(void* t, float* ms) {
   ddrl_timer* x = (ddrl_timer*)t;
   HIP_TRY(hipEventSynchronize(x->b));
   HIP_TRY(hipEventElapsedTime(ms, x->a, x->b));
+  return DDRL_OK;
+}
+
+int32_t ddrl_debug_keep_activations(ddrl_ctx* ctx, int32_t on) {
+  if (!ctx) return DDRL_ERR_INVALID_ARG;
+  ctx->keep_acts = on != 0;
   return DDRL_OK;
 }
 

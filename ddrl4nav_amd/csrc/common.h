@@ -68,9 +68,6 @@ inline ParamLayout make_layout(int A, int C, bool shared = false) {
 // ---- device workspace carved out of the caller's buffer ------------------------------------
 struct Workspace {
   // derived weight layouts, [e] major
-  float* wlt;  // [2][3136][512]    FC fwd B operand
-  // f32 packed weights of conv2 / conv3 for the f32-input MFMA kernels of small acting launches: [k-block][k-step][lane half][row]
-  float *wp2, *wp3;
   // 16-bit weight planes, NPL per tensor (engine2.h: two scaled fp16 planes by default).  conv1, conv2.hip conv_fwd1_planes_kernel:
   // [channel 4][ky pair 4][plane NPL][lane half 2][row 32 NE][kx 8] 16-bit
   unsigned short* wp1b;
@@ -87,6 +84,7 @@ struct Workspace {
   // the same planes transposed, [e][plane NPL][3136][512] (fc2.hip fc_dgrad_planes_kernel)
   unsigned short* wdlb;
   float* amax;  // [AMAX_SLOTS][2 encoders], see AMAX_* below
+  float* actmax;  // [2 encoders][512]: largest |a3| per sample of the last fused acting forward (act.hip)
   // activations (post leaky-relu) and their gradients, [e][max_batch][...]
   float *a1, *a2, *a3, *h;
   // sign bits of a1 (1 = NOT positive: the leaky slope applies), written by conv1's forward for the leaky-ReLU mask of the conv1 weight gradient (which would
@@ -186,17 +184,15 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
     off += align_up(floats * 4, 256);
     return p;
   };
-  w.wlt = take(2 * (int64_t)FLAT * FEAT);
   w.wp1b = (unsigned short*)take(4 * 4 * 3 * 2 * 64 * 8 / 2);
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.wdlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.amax = take(64);
+  w.actmax = take(2 * 512);
   w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);
   w.wd3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
-  w.wp2 = take(2 * 16 * 16 * 2 * 64);
-  w.wp3 = take(2 * 16 * 18 * 2 * 64);
   w.a1 = take(2 * MB * 32 * 400);
   w.m1 = (unsigned*)take(2 * m1_words(MB));
   w.m2 = (unsigned*)take(2 * MB * 81 * 2);

@@ -1,226 +1,19 @@
-// v2 convolution kernels: forward and data-gradient as "direct convolution from an LDS image",
-// on the pipelined f32-MFMA engine (engine2.h).
+// Convolution kernels of the Atari encoder on the 16-bit matrix pipe: the three forwards and the data gradients of conv3 / conv2,
+// each "direct convolution from an LDS image".
 //
-// Instead of gathering an im2col tile, a workgroup stages the RAW input planes it needs
-// (coalesced 16-byte loads, each element fetched once per k-block) and every MFMA B operand is
-// one ds_read_b32 at  lane_base + immediate :
-//     lane_base  = position of the lane's output pixel inside the staged planes (+ hi * delta)
-//     immediate  = offset of the (channel, tap) of k-step s          (compile-time constant)
-// The two k indices of one 32x32x2 MFMA (lane halves) are always two adjacent input CHANNELS
-// of the same tap (delta = plane size), or two adjacent taps for conv1 (delta = one x-plane),
-// so a single per-lane base serves the whole k loop.  Weights are pre-packed per k-block in
-// exactly that order by pack_weights2 (optim.hip).
+// Instead of gathering an im2col tile, a workgroup stages the RAW input planes it needs (coalesced 16-byte loads, every element
+// fetched once per k-block, split into fp16 planes on the way into LDS: engine2.h "plane scheme") and every MFMA operand is one
+// 16-byte LDS read (or two 8-byte reads) at  lane_base + immediate :
+//     lane_base  = position of the lane's output pixel inside the staged planes (+ what the lane half adds)
+//     immediate  = offset of the k-group's (channel, taps)                      (compile-time constant)
+// Weights arrive pre-split into planes, in exactly the order the k index walks (optim.hip).
 //
-// Reference arithmetic: F.conv2d + F.leaky_relu (USTC_lab/nn/atari_encoder.py:26-28) and the
-// autograd data-gradients of conv3 / conv2 (ppo.py:122-123).
+// Reference arithmetic: F.conv2d + F.leaky_relu (USTC_lab/nn/atari_encoder.py:26-28) and the autograd data-gradients of conv3 /
+// conv2 (ppo.py:122-123).  Acting launches of at most DDRL_ACT_FUSED_MAX samples do not come here: act.hip.
 #include "engine2.h"
 
 namespace ddrl {
 
-
-// ================================================================================================
-// conv2 forward: a1 [e][n][32][20][20] -> a2 [e][n][64][9][9], k4 s2.   rows = oc (64),
-// cols = b*81+pix (256 per workgroup, <= 5 samples), k-block = 2 input channels x 16 taps.
-// ================================================================================================
-// TNV = 32-column groups per wave: 2 (256-column tiles) for training batches, 1 (128-column tiles, twice
-// the workgroups) when a small acting batch would otherwise leave most CUs without work.
-template <int TNV>
-struct ConvFwd2v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = TNV, KSTEPS = 16, CW = 128 * TNV;
-  static constexpr int NS = (CW - 1) / 81 + 2, NIMJ = (NS * 200 + 255) / 256, W_FLOATS = 32 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = NS * 2 * 400;
-  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
-  static constexpr int EXTRA = 64;  // bias vector, read by the epilogue from LDS
-  struct Params {
-    const float* in;  // a1
-    int64_t in_es;
-    const float* wp;  // [e][16][16][2][64]
-    const float* params;
-    int64_t bias_off[2];
-    float* out;  // a2
-    int64_t out_es;
-    int n;
-  };
-  struct Regs {
-    f4 w[2], im[NIMJ];
-  };
-  int abase[2], bbase[TN], kb_begin, kb_end;
-  int e, c0, b_first, l31, hi, wc;
-  int imoff[NIMJ];  // per-thread source offsets of the staged planes (k-block independent part)
-  const float* in;
-  const float* wp;
-  static constexpr int aoff(int s) { return 2 * s * 64; }
-  static constexpr int boff(int s) { return (s / 4) * 20 + (s % 4); }
-  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
-    const int lane = tid & 63;
-    wc = tid >> 6;
-    l31 = lane & 31;
-    hi = lane >> 5;
-    e = blockIdx.z;
-    c0 = blockIdx.x * CW;
-    b_first = c0 / 81;
-    kb_begin = 0;
-    kb_end = 16;
-    in = p.in + e * p.in_es;
-    wp = p.wp + (int64_t)e * 16 * 2048;
-    if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
-    // Loads in fetch() are UNCONDITIONAL (a guarded load makes hipcc branch and wait per load):
-    // out-of-range threads / samples read clamped, valid addresses; what they stage is either
-    // not stored (idx guard in commit) or only feeds output columns that are discarded.
-#pragma unroll
-    for (int j = 0; j < NIMJ; ++j) {
-      const int idx = tid + 256 * j;
-      const bool has = idx < NS * 200;
-      const int b = min(b_first + (has ? idx / 200 : 0), p.n - 1);
-      imoff[j] = b * 12800 + (has ? (idx % 200) * 4 : 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      int c = c0 + wc * (32 * TN) + j * 32 + l31;
-      if (c >= p.n * 81) c = c0;
-      const int b = c / 81, pix = c % 81;
-      bbase[j] = IMG_OFF + (b - b_first) * 800 + (pix / 9) * 40 + (pix % 9) * 2 + hi * 400;
-    }
-  }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) r.w[j] = ld4(wp + kb * 2048 + (tid + 256 * j) * 4);
-#pragma unroll
-    for (int j = 0; j < NIMJ; ++j) r.im[j] = ld4(in + imoff[j] + kb * 800);
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) st4(buf + (tid + 256 * j) * 4, r.w[j]);
-#pragma unroll
-    for (int j = 0; j < NIMJ; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < NS * 200) st4(buf + IMG_OFF + idx * 4, r.im[j]);
-    }
-  }
-  __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][TN], float* lds) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = c0 + wc * (32 * TN) + j * 32 + l31;
-      if (c >= p.n * 81) continue;
-      const int b = c / 81, pix = c % 81;
-      // stores: wave-uniform base per output channel + one 32-bit lane offset (no address VALU per store)
-      float* base = p.out + e * p.out_es;
-      const uint32_t lane = (uint32_t)((b * 5184 + pix + hi * (4 * 81)) * 4);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int oc = i * 32 + acc_row(r, hi);
-          st1_so(base + (i * 32 + acc_row(r, 0)) * 81, lane, leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]));
-        }
-    }
-  }
-};
-
-// ================================================================================================
-// conv3 forward: a2 [e][n][64][9][9] -> a3 [e][n][64][7][7], k3 s1.   rows = oc (64),
-// cols = b*49+pix (<= 7 samples), k-block = 4 input channels x 9 taps (pairs = channels).
-// ================================================================================================
-template <int TNV>  // see ConvFwd2v2
-struct ConvFwd3v2 {
-  static constexpr int THREADS = 256, TM = 2, TN = TNV, KSTEPS = 18, CW = 128 * TNV;
-  static constexpr int NS = (CW - 1) / 49 + 2, NIMJ = (NS * 81 + 255) / 256;
-  static constexpr int W_FLOATS = 36 * 64, IMG_OFF = W_FLOATS, IMG_FLOATS = (NS * 4 * 81 + 3) / 4 * 4;
-  static constexpr int STAGE = W_FLOATS + IMG_FLOATS;
-  static constexpr int EXTRA = 64;  // bias vector
-  struct Params {
-    const float* in;  // a2
-    int64_t in_es;
-    const float* wp;  // [e][16][18][2][64]
-    const float* params;
-    int64_t bias_off[2];
-    float* out;  // a3
-    int64_t out_es;
-    int n;
-  };
-  struct Regs {
-    f4 w[3], im[NIMJ];
-  };
-  int abase[2], bbase[TN], kb_begin, kb_end;
-  int e, c0, b_first, l31, hi, wc;
-  int imoff[NIMJ];
-  const float* in;
-  const float* wp;
-  static constexpr int aoff(int s) { return 2 * s * 64; }
-  static constexpr int boff(int s) { return (s / 9) * 162 + ((s % 9) / 3) * 9 + (s % 3); }
-  __device__ __forceinline__ void init(const Params& p, int tid, float* lds) {
-    const int lane = tid & 63;
-    wc = tid >> 6;
-    l31 = lane & 31;
-    hi = lane >> 5;
-    e = blockIdx.z;
-    c0 = blockIdx.x * CW;
-    b_first = c0 / 49;
-    kb_begin = 0;
-    kb_end = 16;
-    in = p.in + e * p.in_es;
-    wp = p.wp + (int64_t)e * 16 * 2304;
-    if (tid < 64) lds[2 * STAGE + tid] = p.params[p.bias_off[e] + tid];
-#pragma unroll
-    for (int j = 0; j < NIMJ; ++j) {  // unconditional, clamped loads (see ConvFwd2v2::init)
-      const int idx = tid + 256 * j;
-      const bool has = idx < NS * 81;
-      const int b = min(b_first + (has ? idx / 81 : 0), p.n - 1);
-      imoff[j] = b * 5184 + (has ? (idx % 81) * 4 : 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = hi * 64 + i * 32 + l31;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      int c = c0 + wc * (32 * TN) + j * 32 + l31;
-      if (c >= p.n * 49) c = c0;
-      const int b = c / 49, pix = c % 49;
-      bbase[j] = IMG_OFF + (b - b_first) * 324 + (pix / 7) * 9 + (pix % 7) + hi * 81;
-    }
-  }
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r.w[j] = ld4(wp + kb * 2304 + min(tid + 256 * j, 575) * 4);
-#pragma unroll
-    for (int j = 0; j < NIMJ; ++j) r.im[j] = ld4(in + imoff[j] + kb * 324);
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 576) st4(buf + idx * 4, r.w[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < NIMJ; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < NS * 81) st4(buf + IMG_OFF + idx * 4, r.im[j]);
-    }
-  }
-  __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][TN], float* lds) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = c0 + wc * (32 * TN) + j * 32 + l31;
-      if (c >= p.n * 49) continue;
-      const int b = c / 49, pix = c % 49;
-      float* base = p.out + e * p.out_es;
-      const uint32_t lane = (uint32_t)((b * FLAT + pix + hi * (4 * 49)) * 4);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int oc = i * 32 + acc_row(r, hi);
-          st1_so(base + (i * 32 + acc_row(r, 0)) * 49, lane, leaky_f(acc[i][j][r] + lds[2 * STAGE + oc]));
-        }
-    }
-  }
-};
 
 // ================================================================================================
 // conv1 forward on the 16-bit matrix pipe, fp32-accurate.  The input pixels are integers 0..255 and therefore EXACT in
@@ -803,46 +596,23 @@ static void launch_fwd3_planes(const EncCall& c, bool acting, hipStream_t st) {
 
 // ================================================================================================
 
-// Training launches, and acting launches of at least DDRL_ACT_BF16X6_MIN envs, run the plane kernels above (they also write the sign
-// masks the backward reads); smaller acting launches keep the f32-input MFMA forms of conv2 / conv3 (narrow tiles, no masks needed).
+// Training launches, and acting launches of more than DDRL_ACT_FUSED_MAX samples (they skip the sign masks only the backward reads)
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st) {
-  const Workspace& w = *c.ws;
-  const int64_t MB = c.max_batch;
-  const ParamLayout& L = *c.L;
-  const int n = c.n;
   {
     ProfRange pr(c.prof, acting ? "ConvFwd1.act" : "ConvFwd1", st);
-    if (L.NE == 2) {
+    if (c.L->NE == 2) {
       launch_fwd1_planes<2>(c, acting, st);
     } else {
       launch_fwd1_planes<1>(c, acting, st);
     }
   }
-  // 128-column tiles when 256-column tiles would give fewer than ~1.5 workgroups per CU (small acting batches)
-  const auto narrow = [&](int pix) { return (((int64_t)n * pix + 255) / 256) * L.NE < 384; };
   {
-    ConvFwd2v2<2>::Params p{w.a1, MB * 12800, w.wp2, c.params, {L.enc_base[0] + L.enc.c2b, L.enc_base[1] + L.enc.c2b}, w.a2, MB * 5184, n};
     ProfRange pr(c.prof, acting ? "ConvFwd2.act" : "ConvFwd2", st);
-    if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
-      launch_fwd2_planes(c, acting, st);
-    } else if (narrow(81)) {
-      ConvFwd2v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
-      launch_engine2<ConvFwd2v2<1>>(dim3((unsigned)(((int64_t)n * 81 + 127) / 128), 1, (unsigned)c.L->NE), q, st);
-    } else {
-      launch_engine2<ConvFwd2v2<2>>(dim3((unsigned)(((int64_t)n * 81 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
-    }
+    launch_fwd2_planes(c, acting, st);
   }
   {
-    ConvFwd3v2<2>::Params p{w.a2, MB * 5184, w.wp3, c.params, {L.enc_base[0] + L.enc.c3b, L.enc_base[1] + L.enc.c3b}, w.a3, MB * FLAT, n};
     ProfRange pr(c.prof, acting ? "ConvFwd3.act" : "ConvFwd3", st);
-    if (!acting || n >= DDRL_ACT_BF16X6_MIN) {
-      launch_fwd3_planes(c, acting, st);
-    } else if (narrow(49)) {
-      ConvFwd3v2<1>::Params q{p.in, p.in_es, p.wp, p.params, {p.bias_off[0], p.bias_off[1]}, p.out, p.out_es, p.n};
-      launch_engine2<ConvFwd3v2<1>>(dim3((unsigned)(((int64_t)n * 49 + 127) / 128), 1, (unsigned)c.L->NE), q, st);
-    } else {
-      launch_engine2<ConvFwd3v2<2>>(dim3((unsigned)(((int64_t)n * 49 + 255) / 256), 1, (unsigned)c.L->NE), p, st);
-    }
+    launch_fwd3_planes(c, acting, st);
   }
 }
 

@@ -53,6 +53,11 @@ static void launch_backward_amax(const EncCall& c, hipStream_t st) {
 }
 
 void launch_encoder_forward(const EncCall& c, bool acting, hipStream_t st) {
+  if (acting && c.n <= DDRL_ACT_FUSED_MAX) {  // latency-bound: one launch for the three convolutions (act.hip), then the batched dense layer
+    launch_act_convs(c, st);
+    launch_fc_forward2(c, true, st, true);
+    return;
+  }
   launch_conv_forward2(c, acting, st);
   launch_fc_forward2(c, acting, st);
 }

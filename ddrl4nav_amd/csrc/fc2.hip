@@ -1,184 +1,14 @@
-// v2 kernels of the 3136 -> 512 linear layer (forward, weight gradient, data gradient) on the
-// pipelined f32-MFMA engine.  Reference: nn.Linear(3136, 512) in USTC_lab/nn/atari_encoder.py:22,31
-// and its autograd backward (ppo.py:122-123).
+// The 3136 -> 512 linear layer (forward, data gradient, weight gradient) on the 16-bit matrix pipe (plane products, engine2.h).
+// Reference: nn.Linear(3136, 512) in USTC_lab/nn/atari_encoder.py:22,31 and its autograd backward (ppo.py:122-123).
 #include "engine2.h"
 
 namespace ddrl {
 
-// Loader helpers --------------------------------------------------------------------------------
-// "row-major": tile X[128 rows][32 k] of a K-contiguous matrix, stored in LDS as [row][34] so that
-// 32 lanes (= rows) hit 32 different banks (34 l mod 64 is distinct over l < 32) and the committed quads
-// are 8-byte aligned (two ds_write_b64 with immediate offsets).  4 f4 per thread.
-struct RowMajorTile {
-  static constexpr int LD = 34;
-  static constexpr int FLOATS = 128 * LD;
-  // Lane byte offsets of the 4 loads relative to  src + row0 * row_stride + kcol0  (loop invariant).
-  // Loads are unconditional from a clamped row: rows >= nrows only feed output rows that the epilogue
-  // discards (a guarded load would make hipcc branch and wait per load).
-  __device__ __forceinline__ static void lane_offsets(int row_stride, int row0, int nrows, int tid, uint32_t (&off)[4]) {
-    const int k4 = tid & 7, rr = tid >> 3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((min(row0 + rr + 32 * j, nrows - 1) - row0) * row_stride + k4 * 4) * 4);
-  }
-  __device__ __forceinline__ static void fetch(const float* __restrict__ uniform_base, const uint32_t (&off)[4], f4 (&r)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = ld4_so(uniform_base, off[j]);
-  }
-  __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4]) {
-    const int k4 = tid & 7, rr = tid >> 3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f2* p = (f2*)(dst + (rr + 32 * j) * LD + k4 * 4);
-      p[0] = (f2){r[j].x, r[j].y};
-      p[1] = (f2){r[j].z, r[j].w};
-    }
-  }
-};
-// "k-major": tile X[32 k][128 cols] of a col-contiguous matrix, stored as is.  4 f4 per thread.
-struct KMajorTile {
-  static constexpr int LD = 128;
-  static constexpr int FLOATS = 32 * LD;
-  // Unconditional loads from clamped (k, col); returns a 4-bit mask of the j whose k is in range.
-  // Out-of-range columns only feed discarded output columns; out-of-range k (the reduction index)
-  // must contribute zero, which commit_masked() enforces for ONE of the two operands.
-  // Lane byte offsets of the 4 loads of a FULL k-block relative to  src + k0 * k_stride  (loop invariant).
-  __device__ __forceinline__ static void lane_offsets(int k_stride, int col0, int ncols, int tid, uint32_t (&off)[4]) {
-    const int c4 = tid & 31, kk = tid >> 5;
-    const int col = (col0 + c4 * 4) < ncols ? col0 + c4 * 4 : 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) off[j] = (uint32_t)(((kk + 8 * j) * k_stride + col) * 4);
-  }
-  __device__ __forceinline__ static void fetch_full(const float* __restrict__ uniform_base, const uint32_t (&off)[4], f4 (&r)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = ld4_so(uniform_base, off[j]);
-  }
-  // the same 4 quads straight into LDS (a wave's 64 quads of one j are 1 KB contiguous: rows 2 * wave + 8 j, +1)
-  __device__ __forceinline__ static void direct_full(const float* __restrict__ uniform_base, const uint32_t (&off)[4], float* tile, int wave) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ld16_to_lds(uniform_base, off[j], tile + (2 * wave + 8 * j) * LD);
-  }
-  // k-block that crosses nk (the last one of a ragged reduction): clamped rows + mask
-  __device__ __forceinline__ static unsigned fetch_tail(const float* __restrict__ src, int64_t k_stride, int k0, int nk, int col0, int ncols, int tid,
-                                                        f4 (&r)[4]) {
-    const int c4 = tid & 31, kk = tid >> 5;
-    const int col = (col0 + c4 * 4) < ncols ? col0 + c4 * 4 : 0;
-    unsigned ok = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + kk + 8 * j;
-      ok |= (k < nk ? 1u : 0u) << j;
-      r[j] = ld4(src + (int64_t)min(k, nk - 1) * k_stride + col);
-    }
-    return ok;
-  }
-  __device__ __forceinline__ static void commit_masked(float* __restrict__ dst, int tid, const f4 (&r)[4], unsigned ok) {
-    const int c4 = tid & 31, kk = tid >> 5;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st4(dst + (kk + 8 * j) * LD + c4 * 4, ((ok >> j) & 1u) ? r[j] : zero4());
-  }
-  __device__ __forceinline__ static void commit(float* __restrict__ dst, int tid, const f4 (&r)[4]) {
-    const int c4 = tid & 31, kk = tid >> 5;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st4(dst + (kk + 8 * j) * LD + c4 * 4, r[j]);
-  }
-};
-
-struct FcCommon {
-  static constexpr int IGLP = 1;  // FcFwd 3.48 -> 3.33, FcDgrad 3.62 -> 3.53, FcWgrad 3.82 -> 3.64 ms
-  static constexpr int THREADS = 256, TM = 2, TN = 2, KSTEPS = 16;
-  int abase[2], bbase[2];
-  int kb_begin, kb_end;
-  int wr, wc, l31, hi;
-  __device__ __forceinline__ void extra(const float*) {}
-  __device__ __forceinline__ void lanes(int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    l31 = lane & 31;
-    hi = lane >> 5;
-    wr = wave >> 1;
-    wc = wave & 1;
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
-//  h[b][n] = sum_k a3[b][k] Wl[n][k] + bl[n]          rows = b, cols = n, reduction = k (3136)
-// ------------------------------------------------------------------------------------------------
-struct FcFwd2 : FcCommon {
-  static constexpr int A_OFF = 0, B_OFF = RowMajorTile::FLOATS, STAGE = RowMajorTile::FLOATS + KMajorTile::FLOATS;
-  struct Params {
-    const float* a3;
-    int64_t a3_es;
-    const float* wlt;  // [e][3136][512]
-    const float* params;
-    int64_t bias_off[2];
-    float* h;
-    int64_t h_es;
-    int n;
-    int nsplit;   // > 1: write bias-free partial sums part[split][e][n][512] (acting path)
-    float* part;
-    int ne;  // encoders (2, or 1 when the prenet is shared)
-  };
-  static constexpr int DIRECT_PENDING = 4;  // the weight tile is staged LDS-direct, the 4 activation loads by register
-  struct Regs {
-    f4 a[4];
-  };
-  int e, split, b0, n0, wave;
-  const float* a3;   // + b0 rows
-  const float* wlt;
-  uint32_t offa[4], offb[4];
-  static constexpr int aoff(int s) { return 2 * s; }
-  static constexpr int boff(int s) { return 2 * s * KMajorTile::LD; }
-  __device__ __forceinline__ void init(const Params& p, int tid, float*) {
-    lanes(tid);
-    e = blockIdx.z % p.ne;
-    split = blockIdx.z / p.ne;
-    n0 = blockIdx.x * 128;
-    b0 = blockIdx.y * 128;
-    const int per = (FLAT / 32) / p.nsplit;
-    kb_begin = split * per;
-    kb_end = kb_begin + per;
-    a3 = p.a3 + e * p.a3_es + (int64_t)b0 * FLAT;
-    wlt = p.wlt + (int64_t)e * FLAT * FEAT;
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    RowMajorTile::lane_offsets(FLAT, b0, p.n, tid, offa);
-    KMajorTile::lane_offsets(FEAT, n0, FEAT, tid, offb);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) abase[i] = A_OFF + (wr * 64 + i * 32 + l31) * RowMajorTile::LD + hi;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bbase[j] = B_OFF + hi * KMajorTile::LD + wc * 64 + j * 32 + l31;
-  }
-  __device__ __forceinline__ void direct(const Params&, int kb, float* stage) {
-    pin_offsets(offb);
-    KMajorTile::direct_full(wlt + (int64_t)kb * 32 * FEAT, offb, stage + B_OFF, wave);  // FLAT = 98 x 32: every k-block is full
-  }
-  __device__ __forceinline__ void direct_done(const Params&, int, float*) {}
-  __device__ __forceinline__ void fetch(const Params& p, int kb, Regs& r) {
-    pin_offsets(offa);
-    RowMajorTile::fetch(a3 + kb * 32, offa, r.a);
-  }
-  __device__ __forceinline__ void commit(const Regs& r, float* buf) { RowMajorTile::commit(buf + A_OFF, threadIdx.x, r.a); }
-  __device__ __forceinline__ void epilogue(const Params& p, f32x16 (&acc)[2][2], float*) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 64 + j * 32 + l31;
-      const float bias = (p.nsplit > 1) ? 0.0f : p.params[p.bias_off[e] + n];
-      float* dst = (p.nsplit > 1) ? p.part + ((int64_t)split * 2 + e) * p.n * FEAT : p.h + e * p.h_es;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int b = b0 + wr * 64 + i * 32 + acc_row(r, hi);
-          if (b < p.n) dst[(int64_t)b * FEAT + n] = acc[i][j][r] + bias;
-        }
-    }
-  }
-};
-
-// ------------------------------------------------------------------------------------------------
-// Dense-layer forward on the 16-bit matrix pipe, fp32-accurate (plane products, engine2.h): both operands are split into NPL 16-bit
-// planes (x = x0 + x1 + x2 to 24 bits; the weights once per optimiser step in optim.hip, the activations while they
-// are staged) and the six plane products whose magnitude reaches 2^-18 of the largest are accumulated in fp32:
-// a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 (the dropped ones are below 2^-26).  192 matrix-pipe cycles per 16 k instead of
-// the 512 of eight f32 MFMAs.  128 x 128 tile, k-block 32 = 2 MFMA k-groups; LDS holds ONE stage
+// Dense-layer forward:  h[b][n] = sum_k a3[b][k] Wl[n][k] + bl[n],  rows = b, cols = n, reduction = k (3136).
+// Both operands are split into NPL 16-bit planes (two scaled fp16 planes, 22 bits; the weights once per optimiser step in
+// optim.hip, the activations while they are staged) and the NPROD plane products that matter are accumulated in fp32 (f16x3:
+// h1 g0, h0 g1, h0 g0).  128 x 128 tile, k-block 32 = 2 MFMA k-groups; LDS holds ONE stage
 // ([plane][row][32 k] 16-bit, row pitch 80 B so that 16 lanes' 16-byte fragments hit distinct banks): the next
 // k-block waits in registers and is committed between two barriers while the CU's other workgroup computes.
 // ------------------------------------------------------------------------------------------------
@@ -203,20 +33,40 @@ template <bool SPLIT>  // SPLIT: acting launches, split-K with run-time k-block 
 __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restrict__ a3, int64_t a3_es, const unsigned short* __restrict__ wlb,
                                                             const float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
                                                             int64_t bias_off1, float* __restrict__ h, int64_t h_es, int n, int ne, int nsplit,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, const float* __restrict__ smax, int smax_es) {
   using K = FcFwdB;
   extern __shared__ __attribute__((aligned(16))) char ldsf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (DDRL_FC_SWZ != 0 && (gridDim.y & 7) == 0) {  // XCD-aware tile order, see xcd_note above
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (!SPLIT && DDRL_FC_SWZ != 0 && (gridDim.y & 7) == 0) {  // XCD-aware tile order, see xcd_note above
     const int lin = bx + 4 * by, xcd = lin & 7, q = lin >> 3;
     bx = q & 3, by = (q >> 2) * 8 + xcd;  // an XCD owns the batch tiles = xcd mod 8; the 4 feature tiles of one run together and share its a3 rows
   }
-  // nsplit > 1 (acting launches): split-K, blockIdx.z = e + ne * split, bias-free partial sums part[split][e][n][512] that
+  if (SPLIT && DDRL_FC_SWZ != 0) {
+    // Split launches: the G = 4 x gridDim.y workgroups of one (encoder, split) share that K range of a3 (per batch tile) and of the
+    // weights (per feature tile).  In dispatch order (x fastest, XCD = linear id mod 8) they would land on 8 different XCDs and every L2
+    // would fetch its own copy from the memory side (51 MB instead of 19 MB at n = 256); here groups 8 i .. 8 i + 7 take XCDs 0..7, one
+    // each, and the groups left over when gridDim.z is not a multiple of 8 take two XCDs each
+    const int G = 4 * (int)gridDim.y, nz = (int)gridDim.z, lin = bx + 4 * by + G * bz, full = (nz & ~7) * G;
+    int g, m;
+    if (lin < full) {
+      const int xcd = lin & 7, r = lin >> 3;
+      g = (r / G) * 8 + xcd, m = r % G;
+    } else {
+      const int l2 = lin - full, xcd = l2 & 7, rest = nz & 7;  // rest groups over 8 XCDs
+      if (rest == 4) {
+        g = (nz & ~7) + (xcd >> 1), m = (l2 >> 3) * 2 + (xcd & 1);
+      } else {
+        g = (nz & ~7) + l2 / G, m = l2 % G;  // other remainders: dispatch order
+      }
+    }
+    bz = g, bx = m & 3, by = m >> 2;
+  }
+  // nsplit > 1 (acting launches): split-K, bz = e + ne * split, bias-free partial sums part[split][e][n][512] that
   // heads_act adds up (the slab format of the f32-MFMA FcFwd2)
-  const int e = SPLIT ? (int)blockIdx.z % ne : (int)blockIdx.z, split = SPLIT ? (int)blockIdx.z / ne : 0, n0 = bx * 128, b0 = by * 128;
-  const float sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
+  const int e = SPLIT ? bz % ne : bz, split = SPLIT ? bz / ne : 0, n0 = bx * 128, b0 = by * 128;
+  float sa = plane_scale(amax[amax_idx(AMAX_A3, e)]), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
   // staging maps: activations = 4 quads of 4 k per thread (row rr + 32 j, k4), weights = 2 x 3 fragments of 8 k
   const int k4 = tid & 7, rr = tid >> 3;
   const float* asrc[4];
@@ -229,19 +79,23 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
   for (int i = 0; i < 2; ++i) aA[i] = (wr * 64 + i * 32 + l31) * K::PITCH + hi * 16;
 #pragma unroll
   for (int j = 0; j < 2; ++j) bB[j] = K::B_OFF + (wc * 64 + j * 32 + l31) * K::PITCH + hi * 16;
-  f4 ar[4], wrg[2][NPL];
-  auto fetch = [&](int kb) {
+  // SPLIT (acting) launches are latency chains of PER = 7 k-blocks per workgroup: DEPTH k-blocks of loads are kept in flight (a
+  // round trip to the weight planes in HBM is ~2 us, the 24 MFMAs of a k-block 0.3 us); training launches keep one set of
+  // staging registers (three waves per SIMD)
+  constexpr int DEPTH = SPLIT ? 4 : 1;
+  f4 ar[DEPTH][4], wrg[DEPTH][2][NPL];
+  auto fetch = [&](int kb, int slot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ar[j] = ld4(asrc[j] + kb * 32);
+    for (int j = 0; j < 4; ++j) ar[slot][j] = ld4(asrc[j] + kb * 32);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) wrg[j][p] = *(const f4*)(wsrc + (int64_t)p * FLAT * FEAT + (int64_t)j * 64 * FLAT + kb * 32);
+      for (int p = 0; p < NPL; ++p) wrg[slot][j][p] = *(const f4*)(wsrc + (int64_t)p * FLAT * FEAT + (int64_t)j * 64 * FLAT + kb * 32);
   };
-  auto commit = [&]() {
+  auto commit = [&](int slot) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f4 v = ar[j];
+      const f4 v = ar[slot][j];
       unsigned pa[NPL], pb[NPL];
       split_planes_c(v.x, v.y, sa, pa);
       split_planes_c(v.z, v.w, sa, pb);
@@ -252,7 +106,7 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) *(f4*)(ldsf + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + k8 * 16) = wrg[j][p];
+      for (int p = 0; p < NPL; ++p) *(f4*)(ldsf + K::B_OFF + p * K::PLANE + (cc + 64 * j) * K::PITCH + k8 * 16) = wrg[slot][j][p];
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -261,12 +115,7 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int per = SPLIT ? (FLAT / 32) / nsplit : FLAT / 32, kb0 = SPLIT ? split * per : 0, NKB = kb0 + per;  // 98 k-blocks, nsplit divides them
-  fetch(kb0);
-  commit();
-  if (kb0 + 1 < NKB) fetch(kb0 + 1);
-  __syncthreads();
-  for (int kb = kb0; kb < NKB; ++kb) {
+  auto compute = [&]() {
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       frag8 a[NPL][2], b[NPL][2];
@@ -285,12 +134,54 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[PA[t]][i], b[PB[t]][j], acc[i][j]);
     }
-    __syncthreads();  // every wave is done with the stage
-    if (kb + 1 < NKB) {
-      commit();
-      if (kb + 2 < NKB) fetch(kb + 2);
+  };
+  if constexpr (SPLIT) {
+    constexpr int PER = (FLAT / 32) / DDRL_FC_ACT_SPLITS;  // the launcher passes nsplit = DDRL_FC_ACT_SPLITS
+    const int kb0 = split * PER;
+#pragma unroll
+    for (int d = 0; d < DEPTH && d < PER; ++d) fetch(kb0 + d, d);
+    if (smax != nullptr) {
+      // after the fused acting convolutions (act.hip) a3's maximum is not in the slot: every sample left its own in smax[e][.] and
+      // the largest of them is taken here (order-free, hence deterministic; n <= 512 values), behind the loads just requested
+      float m = 0.0f;
+      for (int i = tid; i < n; i += 256) m = fmaxf(m, smax[e * smax_es + i]);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      float* red = (float*)ldsf;
+      if (lane == 0) red[wave] = m;
+      __syncthreads();
+      const float a3top = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      __syncthreads();  // the first commit below overwrites these words
+      sa = plane_scale(a3top), inv = 1.0f / (sa * plane_scale(amax[amax_idx(AMAX_WL, e)]));
     }
+    commit(0);
+    if (DEPTH < PER) fetch(kb0 + DEPTH, 0);
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      compute();
+      __syncthreads();  // every wave is done with the stage
+      if (k + 1 < PER) {
+        commit((k + 1) % DEPTH);
+        if (k + 1 + DEPTH < PER) fetch(kb0 + k + 1 + DEPTH, (k + 1) % DEPTH);
+      }
+      __syncthreads();
+    }
+  } else {
+    constexpr int NKB = FLAT / 32;  // 98 k-blocks
+    fetch(0, 0);
+    commit(0);
+    fetch(1, 0);
+    __syncthreads();
+    for (int kb = 0; kb < NKB; ++kb) {
+      compute();
+      __syncthreads();  // every wave is done with the stage
+      if (kb + 1 < NKB) {
+        commit(0);
+        if (kb + 2 < NKB) fetch(kb + 2, 0);
+      }
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -308,16 +199,12 @@ __global__ __launch_bounds__(256) void fc_fwd_planes_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
+void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st, bool per_sample_max) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   const int nsplit = allow_split ? fc_forward_splits(c.n) : 1;  // 98 k-blocks = 14 x 7
-  FcFwd2::Params p{w.a3, MB * FLAT, w.wlt, c.params, {c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[1] + c.L->enc.lb},
-                   w.h, MB * FEAT, c.n, nsplit, w.wpart, c.L->NE};
   ProfRange pr(c.prof, nsplit > 1 ? "FcFwdSplit" : "FcFwd", st);
-  // split launches (acting) of at least DDRL_ACT_BF16X6_MIN envs run on the planes too: conv3's planes kernel has measured a3's
-  // maximum there (the f32 conv3 kernel of smaller launches does not)
-  if (nsplit == 1 || c.n >= DDRL_ACT_BF16X6_MIN) {
+  {
     static bool configured = false;
     if (!configured) {
       (void)hipFuncSetAttribute((const void*)fc_fwd_planes_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FcFwdB::LDS_BYTES);
@@ -327,13 +214,13 @@ void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st) {
     const dim3 grid(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit);
     if (nsplit > 1)
       hipLaunchKernelGGL(fc_fwd_planes_kernel<true>, grid, dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT, w.wlb, w.amax, c.params,
-                         c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, nsplit, w.wpart);
+                         c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, nsplit, w.wpart,
+                         per_sample_max ? w.actmax : (const float*)nullptr, DDRL_ACT_FUSED_MAX);
     else
       hipLaunchKernelGGL(fc_fwd_planes_kernel<false>, grid, dim3(256), FcFwdB::LDS_BYTES, st, w.a3, MB * FLAT, w.wlb, w.amax, c.params,
-                         c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, 1, w.wpart);
-    return;
+                         c.L->enc_base[0] + c.L->enc.lb, c.L->enc_base[c.L->NE - 1] + c.L->enc.lb, w.h, MB * FEAT, c.n, c.L->NE, 1, w.wpart,
+                         (const float*)nullptr, 0);
   }
-  launch_engine2<FcFwd2>(dim3(FEAT / 128, (c.n + 127) / 128, c.L->NE * nsplit), p, st);
 }
 
 // ------------------------------------------------------------------------------------------------

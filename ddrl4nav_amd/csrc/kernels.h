@@ -37,6 +37,7 @@ struct EncCall {
   int n;
   int64_t max_batch;
   hipEvent_t* bucket_ev = nullptr;  // [GRAD_BUCKETS] or null (single rank: nothing to overlap)
+  bool keep_acts = false;           // acting launches: also store a1 / a2 (ddrl_debug_keep_activations; the fused kernel of act.hip keeps them on chip)
 };
 inline void bucket_done(const EncCall& c, int b, hipStream_t st) {
   if (c.bucket_ev) (void)hipEventRecord(c.bucket_ev[b], st);
@@ -48,20 +49,23 @@ void launch_encoder_backward(const EncCall& c, float* grads, hipStream_t st, boo
 void launch_backward_amax_reset(const EncCall& c, hipStream_t st);  // zeroes the gradient slots of Workspace::amax
 
 // fc2.hip (v2 engine)
-#ifndef DDRL_ACT_BF16X6_MIN
-// acting launches of at least this many envs use the plane-product conv2 / conv3 kernels too (the macro keeps its round-1 name; us per
-// ddrl_forward measured then, fp32-MFMA narrow-tile kernels vs plane products: n = 128: 88.8 / 93.0, 256: 111.9 / 103.3, 1024: 316.8 / 252.7,
-// 2048: 606.2 / 480.9)
-#define DDRL_ACT_BF16X6_MIN 192
-#endif
 // Split-K factor of the FC forward for a batch of n samples (1 = plain; >1 only on the acting
 // path, where heads_act sums the partials).  7 k-blocks of 32 per split.
 inline int fc_forward_splits(int n) { return n <= 1024 ? DDRL_FC_ACT_SPLITS : 1; }
-void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st);
+void launch_fc_forward2(const EncCall& c, bool allow_split, hipStream_t st, bool per_sample_max = false);
 void launch_fc_backward2(const EncCall& c, float* grads, hipStream_t st, int part = 0);
 
 // conv2.hip (v2 engine)
 void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st);
+
+// act.hip: conv1 + conv2 + conv3 of an acting forward in one launch, one workgroup per (sample, encoder); leaves a3 and every sample's
+// largest |a3| (Workspace::actmax), which the dense layer's split launch takes its plane scale from
+#ifdef DDRL_PLANES_BF16
+#define DDRL_ACT_FUSED_MAX 0    // three bf16 planes do not fit the fused kernel's LDS budget: every acting launch takes the batch-tiled kernels
+#elif !defined(DDRL_ACT_FUSED_MAX)
+#define DDRL_ACT_FUSED_MAX 512  // acting launches of at most this many samples (= the capacity of Workspace::actmax per encoder)
+#endif
+void launch_act_convs(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st);
 

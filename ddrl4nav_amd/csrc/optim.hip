@@ -8,49 +8,8 @@
 namespace ddrl {
 
 // --------------------------------------------------------------------------------------------
-// derived weight layouts (rebuilt after every optimiser step; 13.5 MB read, ~13.5 MB written)
+// derived weight layouts: 16-bit planes of every GEMM operand the weights take part in (rebuilt after every optimiser step)
 // --------------------------------------------------------------------------------------------
-// wlt[e][k][n] = Wl[n][k]   (512 x 3136 -> 3136 x 512), 32x32 LDS tiles
-__global__ __launch_bounds__(256) void pack_fc_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ wlt) {
-  __shared__ float tile[32][33];
-  const int e = blockIdx.z;
-  const float* src = params + L.enc_base[e] + L.enc.lw;
-  float* dst = wlt + (int64_t)e * FLAT * FEAT;
-  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + ty + 8 * j;
-    const float v = src[(int64_t)n * FLAT + k0 + tx];
-    tile[ty + 8 * j][tx] = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = k0 + ty + 8 * j;
-    dst[(int64_t)k * FEAT + n0 + tx] = tile[tx][ty + 8 * j];
-  }
-}
-
-// f32 layouts of conv2 / conv3 for the f32-input MFMA kernels of SMALL acting launches (conv2.hip ConvFwd2v2 / ConvFwd3v2):
-// [k-block][k-step s][lane half hi][row] -- the order in which the engine's MFMA k indices walk (channel pairs on the lane halves)
-__global__ __launch_bounds__(256) void pack2_kernel(const float* __restrict__ params, ParamLayout L, Workspace w) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  const int NE = L.NE;
-  const int n2 = NE * 16 * 16 * 2 * 64, n3 = NE * 16 * 18 * 2 * 64;
-  if (i < n2) {  // wp2[e][kb][s][hi][oc] = W2[oc][2kb+hi][s/4][s%4]
-    const int oc = i & 63, hi = (i >> 6) & 1, s = (i >> 7) & 15, kb = (i >> 11) & 15, e = i >> 15;
-    w.wp2[i] = params[L.enc_base[e] + L.enc.c2w + (oc * 32 + 2 * kb + hi) * 16 + s];
-    return;
-  }
-  i -= n2;
-  if (i < n3) {  // wp3[e][kb][s][hi][oc] = W3[oc][4kb+2(s/9)+hi][s%9]
-    const int oc = i & 63, hi = (i >> 6) & 1, r = i >> 7;
-    const int s = r % 18, kb = (r / 18) % 16, e = r / (18 * 16);
-    w.wp3[i] = params[L.enc_base[e] + L.enc.c3w + (oc * 64 + 4 * kb + 2 * (s / 9) + hi) * 9 + s % 9];
-  }
-}
-
 // conv1 weights as the NPL planes of engine2.h's plane scheme (default: two scaled fp16 planes, h0 + h1 = w S to 22 bits; the
 // kernel names keep their history).  Layout: common.h wp1b.
 __global__ __launch_bounds__(256) void pack_conv1_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
@@ -183,11 +142,6 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   hipLaunchKernelGGL(pack_conv2_planes_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
   hipLaunchKernelGGL(pack_fc_planes_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
   hipLaunchKernelGGL(pack_conv1_planes_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
-  {
-    const int total2 = L.NE * (16 * 16 * 2 * 64 + 16 * 18 * 2 * 64);
-    hipLaunchKernelGGL(pack2_kernel, dim3((total2 + 255) / 256), dim3(256), 0, st, params, L, w);
-  }
-  hipLaunchKernelGGL(pack_fc_kernel, dim3(FLAT / 32, FEAT / 32, L.NE), dim3(256), 0, st, params, L, w.wlt);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -264,6 +264,12 @@ class HotPath:
                 "GradNorm": float(s[4]), "ClipCoef": float(s[5])}
 
     # ---- diagnostics ------------------------------------------------------------------------
+    def keep_activations(self, on=True):
+        """forward() of at most 512 samples keeps a1 / a2 on chip (csrc/act.hip); on=True makes it store them as well, for
+        debug_buffer(0 / 1) after an acting forward.  Outputs are bit-identical either way."""
+        check(self.lib.ddrl_debug_keep_activations(self.ctx, 1 if on else 0))
+        return self
+
     def debug_buffer(self, which, shape_per_sample, n, enc, raw=False):
         """Copy of a workspace tensor: [n, *shape_per_sample] for encoder `enc`.  The gradient tensors of the data-gradient
         chain (4 dz1, 5 dz2, 6 dz3, 7 dh) are stored NORMALISED per sample (csrc/common.h Workspace::gsc); unless `raw`

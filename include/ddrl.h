@@ -198,6 +198,10 @@ int32_t ddrl_u8_table(float* out256, void* stream);
  * power of two g_s = 2^floor(log2 max|dh_s|); 13 = g_s [e][max_batch].  14 = the running maxima / bounds behind
  * the fp16 plane scales, [slot][encoder] (e stride 1). */
 int32_t ddrl_debug_buffer(ddrl_ctx* ctx, int32_t which, float** ptr, int64_t* enc_stride);
+/* ddrl_forward of at most 512 samples runs conv1-conv3 in one kernel that keeps a1 / a2 on chip (csrc/act.hip); buffers 0 and 1
+ * then hold nothing of that call and ddrl_debug_buffer answers DDRL_ERR_UNSUPPORTED for them.  on = 1: the same kernel also
+ * stores a1 / a2 (for tests that look at them; outputs are bit-identical either way).  Training launches always store them. */
+int32_t ddrl_debug_keep_activations(ddrl_ctx* ctx, int32_t on);
 
 /* ---- pinned-host ring: replaces the Redis LPUSH/BRPOP shuttle of frames between env workers
  * and the learner (USTC_lab/agent/multiqueue.py:83-130, server/backward.py:145-151). --------- */

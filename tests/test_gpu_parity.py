@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def hp():
     from ddrl4nav_amd.engine import HotPath
-    h = HotPath(max_batch=512)
+    h = HotPath(max_batch=512).keep_activations()  # tests read a1 / a2 after acting forwards too
     h.set_params(flatten(make_weights(0)))
     yield h
     h.close()
@@ -134,6 +134,57 @@ def test_gae_golden_f2_bit_exact(hp, golden):
         adv, ret = hp.gae(dev(g["values"][lo:lo + T + 1]), dev(g["rewards"][lo:lo + T]), dev(g["dones"][lo:lo + T]))
         assert np.array_equal(adv.cpu().numpy(), g[ka])
         assert np.array_equal(ret.cpu().numpy(), g[kr])
+
+
+@pytest.mark.parametrize("n", [3, 130, 512])
+def test_fused_acting_forward(onet, n):
+    """ddrl_forward of at most 512 samples runs conv1-conv3 in one kernel that keeps a1 / a2 on chip (csrc/act.hip), one workgroup
+    per (sample, encoder).  (a) The variant that also stores a1 / a2 (ddrl_debug_keep_activations) gives bit-identical outputs;
+    (b) without it ddrl_debug_buffer refuses a1 / a2 (nothing of this call is there) and still serves a3 / h; (c) the same samples
+    inside a forward of more than 512 (batch-tiled kernels, batch-wide plane scales) agree to fp32 rounding; (d) a3 against the
+    oracle."""
+    from ddrl4nav_amd.engine import HotPath
+    h = HotPath(max_batch=1024)
+    try:
+        h.set_params(flatten(make_weights(0)))
+        rng = np.random.default_rng(900 + n)
+        frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
+        frames[0] = 0
+        frames[1] = 255
+        acts = rng.integers(0, 6, size=n).astype(np.float32)
+        fd, ad = dev(frames), dev(acts)
+        p0, v0, _, l0 = (t.clone() for t in h.forward(fd, act=ad))
+        with pytest.raises(RuntimeError):
+            h.debug_buffer(0, (32, 20, 20), n, 0)
+        with pytest.raises(RuntimeError):
+            h.debug_buffer(1, (64, 9, 9), n, 1)
+        a3 = h.debug_buffer(2, (64, 7, 7), n, 0).cpu().numpy()
+        h.keep_activations(True)
+        p1, v1, _, l1 = h.forward(fd, act=ad)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(l0, l1)
+        a1k = h.debug_buffer(0, (32, 20, 20), n, 1).cpu().numpy()
+        h.keep_activations(False)
+        x = O.frames_to_f32(frames)
+        with torch.no_grad():
+            oprobs, _, _, ov = onet(x)
+            enc = onet.actor.pre
+            r3 = torch.nn.functional.leaky_relu(enc.conv3(torch.nn.functional.leaky_relu(enc.conv2(torch.nn.functional.leaky_relu(enc.conv1(x))))))
+            c1 = torch.nn.functional.leaky_relu(onet.critic.pre.conv1(x))
+        np.testing.assert_allclose(a3, r3.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a1k, c1.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(p0.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(v0.cpu().numpy(), ov.numpy().reshape(-1), rtol=1e-5, atol=2e-6)
+        # (c): the batch-tiled kernels on the same samples (padded to 600 with copies)
+        reps = -(-600 // n)
+        bigf = dev(np.concatenate([frames] * reps)[:600].copy() if n < 600 else frames)
+        biga = dev(np.concatenate([acts] * reps)[:600].copy())
+        pb, vb, _, lb = h.forward(bigf, act=biga)
+        m = min(n, 600)
+        np.testing.assert_allclose(pb[:m].cpu().numpy(), p0[:m].cpu().numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(vb[:m].cpu().numpy(), v0[:m].cpu().numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(lb[:m].cpu().numpy(), l0[:m].cpu().numpy(), rtol=1e-5, atol=2e-6)
+    finally:
+        h.close()
 
 
 @pytest.mark.parametrize("T,N", [(256, 256), (1, 3), (7, 65), (256, 2048)])
@@ -259,10 +310,13 @@ def test_full_size_properties_B65536():
     one = big.grads.clone()
     assert (one[:n] - full[:n]).abs().max().item() <= 1e-4 * scale
     np.testing.assert_allclose(one[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-4, atol=1e-7)
-    # (b): forward of the two copies is bit-identical although they sit in different tiles
-    probs, value, _, logp = big.forward(frames[B // 2 - 300:B // 2 + 300].contiguous(), act=acts[B // 2 - 300:B // 2 + 300].contiguous())
-    p2, v2, _, l2 = big.forward(frames[:300].contiguous(), act=acts[:300].contiguous())
-    assert torch.equal(probs[300:], p2) and torch.equal(value[300:], v2) and torch.equal(logp[300:], l2)
+    # (b): two copies of the same samples inside ONE forward come out bit-identical although they sit in different tiles / rows --
+    # 2 x 150 samples run the fused acting kernel (csrc/act.hip) + the split dense layer, 2 x 300 the batch-tiled kernels
+    for half in (150, 300):
+        both = torch.cat([frames[:half], frames[:half]]).contiguous()
+        a2x = torch.cat([acts[:half], acts[:half]]).contiguous()
+        probs, value, _, logp = big.forward(both, act=a2x)
+        assert torch.equal(probs[half:], probs[:half]) and torch.equal(value[half:], value[:half]) and torch.equal(logp[half:], logp[:half])
     big.close()
 
 
@@ -302,18 +356,22 @@ def test_clip_coefficient_and_norm(hp, onet, golden):
     np.testing.assert_allclose(s["ClipCoef"], min(1.0, 0.5 / (gn + 1e-6)), rtol=1e-6)
 
 
+@pytest.mark.parametrize("launch", ["acting", "training"])
 @pytest.mark.parametrize("kind", ["uniform", "pong_wide"])
-def test_conv1_forward_is_at_least_fp32_accurate(hp, kind):
+def test_conv1_forward_is_at_least_fp32_accurate(hp, kind, launch):
     """The conv1 forward runs on the 16-bit matrix pipe (pixels 0..255, exact in fp16, x two scaled fp16 planes of the fp32 weights,
     fp32 accumulation).  That is not a precision trade: against a float64 evaluation of the reference arithmetic its
     error must not exceed that of torch's own fp32 convolution (measured: about half of it)."""
     n = 96
-    frames = _inputs(n, 31, kind)[0]
+    frames, acts, old, adv, ret = _inputs(n, 31, kind)
     w = make_weights(0)
     hp.set_params(flatten(w))
-    probs = torch.empty((n, 6), device="cuda")
-    val, act, lp = (torch.empty(n, device="cuda") for _ in range(3))
-    hp.forward(dev(frames), seed=1, stream_id=0, probs=probs, value=val, action=act, logp=lp)
+    if launch == "acting":  # conv1 inside the fused kernel of csrc/act.hip (pixel tiles as the MFMA's rows)
+        probs = torch.empty((n, 6), device="cuda")
+        val, act, lp = (torch.empty(n, device="cuda") for _ in range(3))
+        hp.forward(dev(frames), seed=1, stream_id=0, probs=probs, value=val, action=act, logp=lp)
+    else:                   # conv_fwd1_planes_kernel (both encoders' output channels as the rows)
+        hp.ppo_iter(dev(frames), dev(acts), dev(old), dev(adv), dev(ret))
     for enc, pre in ((0, "actor.pre"), (1, "critic.pre")):
         a1 = hp.debug_buffer(0, (32, 20, 20), n, enc).cpu().numpy().astype(np.float64)
         W, b = torch.from_numpy(w[pre + ".conv1.weight"]), torch.from_numpy(w[pre + ".conv1.bias"])
@@ -695,7 +753,7 @@ def _step4(h, args):
 @pytest.fixture(scope="module")
 def hp_shared():
     from ddrl4nav_amd.engine import HotPath
-    h = HotPath(max_batch=512, share_cnn_net=1)
+    h = HotPath(max_batch=512, share_cnn_net=1).keep_activations()
     assert h.n_params == 1684128 + 6 * 512 + 6 + 513 and h.n_actor == h.n_params
     h.set_params(flatten(make_weights(0, shared=True)))
     yield h
@@ -968,7 +1026,7 @@ def test_sign_masks_equal_the_signs_of_the_stored_activations(n):
     csrc/common.h (m1: word per column, bit m1_bit(oc); m2 / m3: word per (sample, pixel, lane half), bit 16 i + 15 - r for
     channel 32 i + acc_row(r, half))."""
     from ddrl4nav_amd.engine import HotPath
-    h = HotPath(max_batch=max(n, 8))
+    h = HotPath(max_batch=max(n, 8)).keep_activations()
     try:
         h.set_params(flatten(make_weights(0)))
         rng = np.random.default_rng(100 + n)
