@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void act_convs_kernel(const ActArgs A) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = wave_u(), l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.x, e = blockIdx.y, C = A.C, ROWS = 32 * A.NE;
-  const float r255 = 1.0f / (255.0f * plane_scale(A.amax[amax_idx(AMAX_W1, e)]));
+  const float r255 = PIXEL_UNIT / (255.0f * plane_scale(A.amax[amax_idx(AMAX_W1, e)]));
   const float sa1 = plane_scale(A.amax[amax_idx(AMAX_A1, e)]);
   const float inv2 = 1.0f / (sa1 * plane_scale(A.amax[amax_idx(AMAX_W2, e)]));
   const float sw3 = plane_scale(A.amax[amax_idx(AMAX_W3, e)]);
@@ -118,8 +118,7 @@ __global__ __launch_bounds__(512) void act_convs_kernel(const ActArgs A) {
       const int idx = tid + 512 * j;
       if (ch < C && idx < 1764) {
         const unsigned v = fr[ch][j];
-        *(uint2*)(lds + ch * K::FR_CH + (idx / 21) * K::FR_PITCH + (idx % 21) * 8) =
-            make_uint2(pixel_pair(v & 255u, (v >> 8) & 255u), pixel_pair((v >> 16) & 255u, v >> 24));
+        *(uint2*)(lds + ch * K::FR_CH + (idx / 21) * K::FR_PITCH + (idx % 21) * 8) = pixel_quad(v);
       }
     }
 #pragma unroll

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
     for (int j = 0; j < 6; ++j) {
       if (tid + 256 * j < nd_total) {
         const unsigned v = imreg[ch][j];
-        *(uint2*)(st + imdst[j]) = make_uint2(pixel_pair(v & 255u, (v >> 8) & 255u), pixel_pair((v >> 16) & 255u, v >> 24));
+        *(uint2*)(st + imdst[j]) = pixel_quad(v);
       }
     }
   };
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   __syncthreads();
   float r255[NE];  // 1/255 of the frame normalisation and the scale of the encoder's weight planes
 #pragma unroll
-  for (int i = 0; i < NE; ++i) r255[i] = 1.0f / (255.0f * plane_scale(amax[amax_idx(AMAX_W1, i)]));
+  for (int i = 0; i < NE; ++i) r255[i] = PIXEL_UNIT / (255.0f * plane_scale(amax[amax_idx(AMAX_W1, i)]));
   // (the scale of a1's planes comes from a bound that pack_weights derives from the weights, common.h AMAX_A1: no maximum here)
   if (DDRL_F1_KO & 2) {
     float sum = 0.0f;

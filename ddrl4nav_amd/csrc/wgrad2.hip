@@ -655,10 +655,10 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
         char* d = ldsw + bdst[k] + ((imam + (int)((im_g1 >> k) & 1u)) & 3) * (4 * 192);
         if (!((im_tail >> k) & 1u)) {
           // 16 pixels x0 .. x0+15: plane q gets pixels x0+q, +4, +8, +12 = byte q of the four dwords, as 16-bit floats
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *(uint2*)(d + q * 48) = make_uint2(pixel_pair((imr[k][0] >> (8 * q)) & 255u, (imr[k][1] >> (8 * q)) & 255u),
-                                               pixel_pair((imr[k][2] >> (8 * q)) & 255u, (imr[k][3] >> (8 * q)) & 255u));
+          *(uint2*)(d + 0 * 48) = make_uint2(pixel_pair_sel<0, 0>(imr[k][0], imr[k][1]), pixel_pair_sel<0, 0>(imr[k][2], imr[k][3]));
+          *(uint2*)(d + 1 * 48) = make_uint2(pixel_pair_sel<1, 1>(imr[k][0], imr[k][1]), pixel_pair_sel<1, 1>(imr[k][2], imr[k][3]));
+          *(uint2*)(d + 2 * 48) = make_uint2(pixel_pair_sel<2, 2>(imr[k][0], imr[k][1]), pixel_pair_sel<2, 2>(imr[k][2], imr[k][3]));
+          *(uint2*)(d + 3 * 48) = make_uint2(pixel_pair_sel<3, 3>(imr[k][0], imr[k][1]), pixel_pair_sel<3, 3>(imr[k][2], imr[k][3]));
         } else {
           const unsigned v = imr[k][3];  // pixels 80..83 -> element 20 of each plane
 #pragma unroll
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1_planes_kernel(const uint8_t* 
   const int64_t slab_floats = 32 * ktaps + 32;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const float r255 = amax[amax_idx(AMAX_GMAX, i)] / (255.0f * WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ1, i)]));
+    const float r255 = amax[amax_idx(AMAX_GMAX, i)] * PIXEL_UNIT / (255.0f * WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ1, i)]));
     float* slab = part + ((int64_t)split * 2 + i) * slab_floats;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
