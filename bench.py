@@ -272,6 +272,35 @@ def pmc_traffic(kernel):
         return None
 
 
+def mix_model(kernel, measured_ms):
+    """Time the kernel's instruction / traffic MIX would take in the synthetic loop of tools/mfma16_mix.hip (matrix instructions with V
+    vector-ALU instructions and B HBM bytes each), from the committed microbenchmark and PMC counts: tools/cost_model.py, DESIGN.md
+    section 8.  `frac` above prices the kernel against the paper peak; this prices it against what the part sustains for the same mix."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import glob
+        import cost_model
+        mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma16_mix.txt")))
+        t = pmc_traffic(kernel)
+        if not mixes or not t:
+            return None
+        rate, c_valu, c_byte, _ = cost_model.fit(mixes[-1])
+        doc = json.load(open(os.path.join(ROOT, "profiles", t["source"])))["kernels"]
+        alias = {v: k for k, v in cost_model.NAMES.items()}
+        k = doc[alias[kernel]]
+        by = k["write_bytes"] + 2.0 * k["fetch_bytes"]  # FETCH_SIZE counts 16-byte-per-lane streams at half their bytes on gfx950
+        ms = lambda eq: eq * cost_model.FLOP_PER_MFMA / (rate * 1e12) * 1e3
+        parts = [ms(k["mfma_insts"]), ms(c_valu * k["valu_insts"]), ms(c_byte * by)]
+        return {"model_ms": round(sum(parts), 3), "mfma_ms": round(parts[0], 3), "valu_ms": round(parts[1], 3), "hbm_ms": round(parts[2], 3),
+                "measured_over_model": round(measured_ms / sum(parts), 3), "bare_mfma_loop_tflops": round(rate, 1),
+                "valu_cost_in_mfma": round(c_valu, 4), "hbm_byte_cost_in_mfma": round(c_byte, 6),
+                "sources": [os.path.basename(mixes[-1]), t["source"]],
+                "note": "what v_mfma_f32_32x32x16_f16 sustains on this part next to this kernel's vector-ALU instructions and HBM bytes per "
+                        "MFMA (synthetic loop, constants fitted to the microbenchmark only); counts from the committed PMC passes"}
+    except Exception as e:  # never let a diagnostic break the bench line
+        return {"error": repr(e)[:160]}
+
+
 def executed_over_algorithmic(kernel):
     """From the newest committed PMC profile (SQ_INSTS_MFMA) where it has the counter, else the design figure."""
     t = pmc_traffic(kernel) or {}
@@ -629,6 +658,7 @@ def main():
                         "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
                         "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch"),  # HBM bytes per launch (PMC)
                         "traffic_detail": pmc_traffic(dom),
+                        "mix_model": mix_model(dom, d["ms_avg"]),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
                         "algorithmic_flop_per_launch": d["flop_per_launch"], "pipe": pipe,
                         "executed_over_algorithmic": executed_over_algorithmic(dom),

@@ -108,9 +108,15 @@ __device__ __forceinline__ void softmax_categorical(const float* z, int A, Dist<
 
 template <int MAXA>
 __device__ __forceinline__ float pick(const float (&a)[MAXA], int idx) {
+  // a chain of selects on registers.  Left to itself the compiler turns it into an indexed load from a private (scratch) copy of
+  // the array: a dependent round trip through the vector memory path per call, four per sample in heads_loss; the empty asm keeps
+  // every step a v_cndmask
   float r = a[0];
 #pragma unroll
-  for (int j = 1; j < MAXA; ++j) r = (idx == j) ? a[j] : r;
+  for (int j = 1; j < MAXA; ++j) {
+    r = (idx == j) ? a[j] : r;
+    asm volatile("" : "+v"(r));
+  }
   return r;
 }
 
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
 // --------------------------------------------------------------------------------------------
 // WLDS (A > 8): the actor-head weight / bias gradient slots of hpart are written by
 // head_wgrad_kernel from dlogits instead (288 accumulator + weight registers do not fit a lane).
-constexpr int LOSS_WAVES = 8;  // waves per workgroup of heads_loss: two per SIMD keep the h / dh streams in flight
+constexpr int LOSS_WAVES = 4;  // waves per workgroup of heads_loss: one per SIMD, see the sample loop
 template <int MAXA, bool WLDS>
 __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
@@ -300,10 +306,19 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
   // v_loss.backward() only -- no theta_v, no entropy gradient.
   const bool shared = (L.NE == 1);
   const int ec = L.NE - 1;
+  // one wave per SIMD (284 registers: the 8 x 8 + 8 gradient accumulators, the head weights and a sample's working set; with two
+  // waves per SIMD 53 of them lived in scratch and every sample paid their round trips): the NEXT sample's operands are requested
+  // before this one's arithmetic, so the wave never waits for memory inside a sample
+  float ha[8], hc[8], s_act = 0.0f, s_adv = 0.0f, s_olp = 0.0f, s_ret = 0.0f;
+  auto request = [&](int b, float (&xa)[8], float (&xc)[8], float& a_, float& ad_, float& ol_, float& rt_) {
+    load8(h + (int64_t)b * FEAT + lane * 8, xa);
+    load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, xc);
+    a_ = actions[b], ad_ = advs[b], ol_ = old_logps[b], rt_ = rets[b];
+  };
+  if (gw < n) request(gw, ha, hc, s_act, s_adv, s_olp, s_ret);
   for (int b = gw; b < n; b += nw) {
-    float ha[8], hc[8];
-    load8(h + (int64_t)b * FEAT + lane * 8, ha);
-    load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, hc);
+    float na[8], nc[8], n_act = 0.0f, n_adv = 0.0f, n_olp = 0.0f, n_ret = 0.0f;
+    if (b + nw < n) request(b + nw, na, nc, n_act, n_adv, n_olp, n_ret);
     float z[MAXA];
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
@@ -319,12 +334,12 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     const float v = wave_sum(sv) + R.bc;
     Dist<MAXA> d;
     softmax_categorical(z, A, d);
-    const int a = (int)actions[b];
-    const float adv = advs[b];
+    const int a = (int)s_act;
+    const float adv = s_adv;
     const float logp = pick(d.lc, a);
-    const SurrogateTerm sg = ppo_surrogate(logp, old_logps[b], adv, cfg, inv_b);
+    const SurrogateTerm sg = ppo_surrogate(logp, s_olp, adv, cfg, inv_b);
     s_actor += (double)sg.term;
-    const float err = rets[b] - v;
+    const float err = s_ret - v;
     const float gv_unit = value_loss_element(err, cfg, s_v);  // d(v_loss element)/d(v) before the 1/B
     float ent = 0.0f;
 #pragma unroll
@@ -407,6 +422,12 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     }
     if (lane < A) dlogits[(int64_t)b * A + lane] = pick(gz, lane);
     if (lane == 0) dvalue[b] = gv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ha[i] = na[i];
+      hc[i] = nc[i];
+    }
+    s_act = n_act, s_adv = n_adv, s_olp = n_olp, s_ret = n_ret;
   }
 
   if (gsc != nullptr && lane == 0) {  // AMAX_GMAX / AMAX_DH: one look (and rarely an atomic) per wave and encoder
