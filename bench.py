@@ -266,7 +266,7 @@ def pmc_traffic(kernel):
             alg = MAC[kernel] * doc.get("batch", 65536) * 2 * PIPE[kernel][1] / 16384.0
             out["executed_over_algorithmic"] = round(k["mfma_insts"] / alg, 3)
             if "valu_insts" in k:
-                out["valu_per_mfma"] = round(k["valu_insts"] / k["mfma_insts"], 2)
+                out["valu_per_mfma"] = round(k["valu_insts"] / k["mfma_insts"] - 1.0, 2)  # SQ_INSTS_VALU counts the MFMAs too
         return out
     except Exception:
         return None
@@ -290,7 +290,7 @@ def mix_model(kernel, measured_ms):
         k = doc[alias[kernel]]
         by = k["write_bytes"] + 2.0 * k["fetch_bytes"]  # FETCH_SIZE counts 16-byte-per-lane streams at half their bytes on gfx950
         ms = lambda eq: eq * cost_model.FLOP_PER_MFMA / (rate * 1e12) * 1e3
-        parts = [ms(k["mfma_insts"]), ms(c_valu * k["valu_insts"]), ms(c_byte * by)]
+        parts = [ms(k["mfma_insts"]), ms(c_valu * (k["valu_insts"] - k["mfma_insts"])), ms(c_byte * by)]  # SQ_INSTS_VALU includes the MFMAs
         return {"model_ms": round(sum(parts), 3), "mfma_ms": round(parts[0], 3), "valu_ms": round(parts[1], 3), "hbm_ms": round(parts[2], 3),
                 "measured_over_model": round(measured_ms / sum(parts), 3), "bare_mfma_loop_tflops": round(rate, 1),
                 "valu_cost_in_mfma": round(c_valu, 4), "hbm_byte_cost_in_mfma": round(c_byte, 6),

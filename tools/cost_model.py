@@ -4,6 +4,7 @@
   profiles/*_mfma16_mix.txt       tools/mfma16_mix.hip: what v_mfma_f32_32x32x16_f16 sustains on this part next to V vector-ALU
                                   instructions and B bytes of HBM traffic per MFMA (a synthetic loop, all CUs, socket power limit)
   profiles/*_pmc_per_kernel / *_pmc_traffic.json + *_bench.json    MFMA / VALU instructions and HBM bytes per launch, ms per launch
+                                  (SQ_INSTS_VALU includes the MFMAs: vector-ALU instructions proper = SQ_INSTS_VALU - SQ_INSTS_MFMA)
 
 A launch costs  MFMA + C_VALU x VALU + C_BYTE x bytes  "MFMA equivalents", executed at the rate the bare MFMA loop sustains:
 
@@ -60,7 +61,8 @@ def main():
     tot = [0.0] * 5
     for k, n in NAMES.items():
         v = pmc[k]
-        mf, va = v["mfma_insts"], v["valu_insts"]
+        mf = v["mfma_insts"]
+        va = v["valu_insts"] - mf  # SQ_INSTS_VALU counts the matrix instructions too (checked on tools/mfma16_mix.hip: MFMA-only loop 2.66e8 against 2.62e8 MFMAs)
         by = v["write_bytes"] + 2.0 * v["fetch_bytes"]  # FETCH_SIZE counts 16-byte-per-lane streams at half their bytes on gfx950
         ms = lambda eq: eq * FLOP_PER_MFMA / (rate * 1e12) * 1e3
         parts = (ms(mf), ms(c_valu * va), ms(c_byte * by))

@@ -128,7 +128,7 @@ static void run(const char* name, kern_t k, int ld, int st, float* d, const char
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, 0);
   const int blocks = p.multiProcessorCount * 2;
@@ -140,9 +140,15 @@ int main() {
   hipMemset(src, 1, per_wave * blocks * 4);
   hipMemset(dst, 0, per_wave * blocks * 4);
   printf("%s, %d CUs, 2 workgroups x 4 waves per CU, v_mfma_f32_32x32x16_f16 with both operands from LDS\n", p.name, p.multiProcessorCount);
-  const int iters = 12000, reps = 6;
+  const bool quick = argc > 1;  // `mfma16_mix quick`: two lines, once (for a rocprofv3 --pmc pass: does SQ_INSTS_VALU count the MFMAs?)
+  const int iters = quick ? 2000 : 12000, reps = quick ? 1 : 6;
 #define RUN(NV, LD, ST, label) run(label, mix_loop<NV, LD, ST>, LD, ST, d, src, dst, per_wave, blocks, iters, reps)
 #define RUNOP(OP, label) run(label, mix_loop<4, 0, 0, OP>, 0, 0, d, src, dst, per_wave, blocks, iters, reps)
+  if (quick) {
+    RUN(0, 0, 0, "MFMA + LDS operands only");
+    RUN(3, 0, 0, "+ 3 VALU per MFMA");
+    return 0;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     printf("pass %d\n", pass);
     RUN(0, 0, 0, "MFMA + LDS operands only");
