@@ -158,6 +158,12 @@ __host__ __device__ inline int m1_bit(int oc) { return ((oc >> 2) & 1) * 16 + 15
 #ifndef DDRL_C1_SPLITS
 #define DDRL_C1_SPLITS 512  // two workgroups per CU in ONE round: 3.37 ms against 3.66 at 768 / 1024 / 1536, 4.1 at 256 / 384 / 640 (profiles/README.md)
 #endif
+#ifndef DDRL_C2_SPLITS
+#define DDRL_C2_SPLITS 256
+#endif
+#ifndef DDRL_C3_SPLITS
+#define DDRL_C3_SPLITS 256
+#endif
 struct Splits {
   int c1, c2, c3, fc;
 };
@@ -168,8 +174,8 @@ inline Splits choose_splits(int max_batch, int NE = 2) {
   Splits s;
   s.c1 = cap(DDRL_C1_SPLITS, pairs);      // 1 column tile, encoders fused
   const int k = 2 / NE;         // one encoder: twice the splits keep the same number of workgroups
-  s.c2 = cap(256 * k, pairs);   // 2 column tiles x 2 encoders
-  s.c3 = cap(256 * k, pairs);   // conv_wgrad3_planes_kernel: one workgroup per (split, encoder), up to two per CU
+  s.c2 = cap(DDRL_C2_SPLITS * k, pairs);   // 2 column tiles x 2 encoders
+  s.c3 = cap(DDRL_C3_SPLITS * k, pairs);   // conv_wgrad3_planes_kernel: one workgroup per (split, encoder), up to two per CU
   s.fc = cap(5 * k, (max_batch + 31) / 32);  // 25 x 4 tiles x 2 encoders
   return s;
 }
