@@ -712,7 +712,7 @@ def main():
                           "0..255 x two scaled fp16 planes of the other operand (f16x2), all others with two scaled fp16 planes of BOTH "
                           "fp32 operands (22 bits) and the three products that matter (f16x3); errors against float64 are no larger "
                           "than an fp32 chain's (tests/test_gpu_parity.py::*_is_at_least_fp32_accurate).  'tflops' is fp32-equivalent (algorithmic) "
-                          "work; acting launches below 192 envs use the f32-input MFMA",
+                          "work; acting launches of at most 512 envs run conv1-conv3 in one kernel (csrc/act.hip), same arithmetic",
             "kernel_timing": "training kernels: HIP events around every launch inside the timed region; acting launches "
                              "(ActConvs, FcFwdSplit, heads_act): a separate, untimed pass of 64 forwards after it",
         }
