@@ -53,17 +53,15 @@ __device__ __forceinline__ void load_head_weights(HeadRegs<MAXA, WLDS>& R, const
     R.wl = nullptr;
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
-      if (j < L.A) {
-        const float4* src = (const float4*)(params + L.actor_w + (int64_t)j * FEAT + lane * 8);
-        const float4 x = src[0], y = src[1];
-        R.wa[j][0] = x.x; R.wa[j][1] = x.y; R.wa[j][2] = x.z; R.wa[j][3] = x.w;
-        R.wa[j][4] = y.x; R.wa[j][5] = y.y; R.wa[j][6] = y.z; R.wa[j][7] = y.w;
-        R.ba[j] = params[L.actor_b + j];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) R.wa[j][i] = 0.0f;
-        R.ba[j] = 0.0f;
-      }
+      // rows past the last action repeat it: their logits are never read (softmax_categorical masks j >= A) and their gradients
+      // are exact zeros times finite weights.  No branch around the loads: a branch makes the compiler wait for them at its
+      // join, and every caller has more loads to request before it needs these
+      const int jj = min(j, L.A - 1);
+      const float4* src = (const float4*)(params + L.actor_w + (int64_t)jj * FEAT + lane * 8);
+      const float4 x = src[0], y = src[1];
+      R.wa[j][0] = x.x; R.wa[j][1] = x.y; R.wa[j][2] = x.z; R.wa[j][3] = x.w;
+      R.wa[j][4] = y.x; R.wa[j][5] = y.y; R.wa[j][6] = y.z; R.wa[j][7] = y.w;
+      R.ba[j] = params[L.actor_b + jj];
     }
   }
   // the flat arena is only 4-byte aligned at critic_w in general -> scalar loads
@@ -141,7 +139,15 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
   HeadRegs<MAXA, WLDS> R;
   load_head_weights(R, params, L, lane, wl);
   const int ec = L.NE - 1;  // encoder feeding the critic head (0 when the prenet is shared)
-  for (int b = gw; b < n; b += nw) {
+  float lba[8], lbc[8];  // the dense layer's bias (added here when the features arrive as split-K partial sums): requested with the head weights
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lba[i] = params[L.enc_base[0] + L.enc.lb + lane * 8 + i];  // unconditional (no branch, no join to wait at); only read when fc_nsplit > 0
+    lbc[i] = params[L.enc_base[1] + L.enc.lb + lane * 8 + i];
+  }
+  // one sample; called once outside the loop (the common case: one sample per wave) so that the loads above are only waited for
+  // where their values are used -- in front of a loop the compiler drains them first
+  auto one_sample = [&](const int b) {
     float ha[8], hc[8];
     if (fc_nsplit > 0) {
 #pragma unroll
@@ -150,26 +156,23 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
         hc[i] = 0.0f;
       }
       if (fc_nsplit == DDRL_FC_ACT_SPLITS) {
-        // the usual case: seven partials of each encoder requested at once (a loop with a run-time trip count waits for every
-        // pair before it asks for the next: 14 dependent round trips, 10 of this kernel's 13 us); same order of additions
-        constexpr int U = 7;
-        static_assert(DDRL_FC_ACT_SPLITS % U == 0, "split count in batches of seven");
+        // the usual case: ALL partials of both encoders requested at once (a loop with a run-time trip count waits for every pair
+        // before it asks for the next: 14 dependent round trips); same order of additions.  224 staging registers: this kernel
+        // runs one wave per SIMD
+        constexpr int U = DDRL_FC_ACT_SPLITS;
+        float ta[U][8], tc[U][8];
 #pragma unroll
-        for (int s0 = 0; s0 < DDRL_FC_ACT_SPLITS; s0 += U) {
-          float ta[U][8], tc[U][8];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            load8(fc_part + (((int64_t)(s0 + u) * 2 + 0) * n + b) * FEAT + lane * 8, ta[u]);
-            load8(fc_part + (((int64_t)(s0 + u) * 2 + ec) * n + b) * FEAT + lane * 8, tc[u]);
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              ha[i] += ta[u][i];
-              hc[i] += tc[u][i];
-            }
+        for (int u = 0; u < U; ++u) {
+          load8(fc_part + (((int64_t)u * 2 + 0) * n + b) * FEAT + lane * 8, ta[u]);
+          load8(fc_part + (((int64_t)u * 2 + ec) * n + b) * FEAT + lane * 8, tc[u]);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            ha[i] += ta[u][i];
+            hc[i] += tc[u][i];
+          }
       } else {
         for (int sp = 0; sp < fc_nsplit; ++sp) {
           float ta[8], tc[8];
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        ha[i] += params[L.enc_base[0] + L.enc.lb + lane * 8 + i];
-        hc[i] += params[L.enc_base[1] + L.enc.lb + lane * 8 + i];
+        ha[i] += lba[i];
+        hc[i] += lbc[i];
       }
       store8(h + (int64_t)b * FEAT + lane * 8, ha);
       if (ec) store8(h + h_es + (int64_t)b * FEAT + lane * 8, hc);
@@ -233,7 +236,9 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
       if (logp_out) logp_out[b] = pick(d.lc, a);
     }
     if (probs && lane < L.A) probs[(int64_t)b * L.A + lane] = pick(d.p, lane);
-  }
+  };
+  if (gw < n) one_sample(gw);
+  for (int b = gw + nw; b < n; b += nw) one_sample(b);
 }
 
 // --------------------------------------------------------------------------------------------
