@@ -16,8 +16,46 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
+def nccl_one_rank(outdir):
+    """The path N > 1 RCCL ranks take by default -- torch.distributed's nccl backend, gradient all-reduce in layer buckets on a second
+    stream behind the backward's events (engine.py _allreduce_overlapped) -- on the one GPU of a test box: a ONE-rank nccl group (the
+    reductions are identities, the stream / event choreography is the real one).  Writes the parameters after three iterations with
+    and without it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ddrl4nav_amd.engine import HotPath
+    from ddrl4nav_amd.utils.recipe import flatten, make_weights
+    import parity_util as P
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    frames, actions, old_logps, advs, rets = P.mode_batch("default")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = (d(frames), d(actions), d(old_logps), d(advs), d(rets))
+    out = {}
+    for overlap in (False, True):
+        h = HotPath(max_batch=64)
+        h.set_params(flatten(make_weights(0)))
+        assert h.comm is None and not h._overlap  # world 1: nothing is enabled by itself
+        if overlap:
+            h.enable_overlap()
+        for _ in range(3):
+            h.ppo_iter(*args)
+            h.allreduce_grads()
+            h.clip_adam_step()
+        out["params_%d" % overlap] = h.params.cpu().numpy().copy()
+        out["loss_%d" % overlap] = np.float64(h.stats()["PpoTotalLoss"])
+        h.close()
+    np.savez(os.path.join(outdir, "rank0.npz"), **out)
+    dist.destroy_process_group()
+
+
 def main():
     outdir, mode, bounds = sys.argv[1], sys.argv[2], [int(t) for t in sys.argv[3].split(",")]
+    if mode == "nccl1":
+        return nccl_one_rank(outdir)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -140,3 +140,18 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["launcher"] == "self" and len(d["elapsed_s_per_rank"]) == 2
     assert d["allreduce"]["calls"] == 10 and d["allreduce"]["backend"] in ("gloo", "nccl")
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+
+
+def test_torch_nccl_bucketed_allreduce_one_rank(tmp_path):
+    """What RCCL ranks run by default at N > 1 (torch.distributed nccl backend, layer buckets reduced on a communication stream behind
+    the backward's events, the compute stream waiting for the last one) on this one-GPU box: a one-rank nccl group in a fresh
+    process.  Three iterations with the bucketed path leave exactly the parameters of three iterations without it."""
+    out = tmp_path / "nccl1"
+    out.mkdir()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_worker.py"), str(out), "nccl1", "0,64"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    r = np.load(out / "rank0.npz")
+    assert np.array_equal(r["params_0"], r["params_1"]) and float(r["loss_0"]) == float(r["loss_1"])
