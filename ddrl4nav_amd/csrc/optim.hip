@@ -31,20 +31,33 @@ __global__ __launch_bounds__(256) void pack_conv1_planes_kernel(const float* __r
 // dense-layer weights as NPL planes (see pack_conv1_planes_kernel): wlb[e][plane][n][k]
 __global__ __launch_bounds__(256) void pack_fc_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
                                                            unsigned short* __restrict__ dst_t, const float* __restrict__ amax) {
-  const int e = blockIdx.y;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)FLAT * FEAT) return;
-  const float w = params[L.enc_base[e] + L.enc.lw + i];
-  unsigned short pl[NPL];
-  planes_of(w, plane_scale(amax[amax_idx(AMAX_WL, e)]), pl);
-  unsigned short* d = dst + (int64_t)e * 3 * FLAT * FEAT + i;
+  // one 32 (n) x 32 (k) tile per workgroup: the planes go out row-major as they come in and, through LDS, transposed for the data
+  // gradient ([plane][k][n]) -- both in 64-byte runs (element-wise the transposed copy was 2-byte stores 1 KB apart: 36 us per pack)
+  __shared__ unsigned short tile[NPL][32][33];
+  const int e = blockIdx.z, k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float sc = plane_scale(amax[amax_idx(AMAX_WL, e)]);
+  const float* src = params + L.enc_base[e] + L.enc.lw;
+  unsigned short* d = dst + (int64_t)e * 3 * FLAT * FEAT;
+  unsigned short* t = dst_t + (int64_t)e * 3 * FLAT * FEAT;
 #pragma unroll
-  for (int p = 0; p < NPL; ++p) d[p * (int64_t)FLAT * FEAT] = pl[p];
-  // transposed copy [plane][k][n] for the data gradient
-  const int nn = (int)(i / FLAT), kk = (int)(i % FLAT);
-  unsigned short* t = dst_t + (int64_t)e * 3 * FLAT * FEAT + (int64_t)kk * FEAT + nn;
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + ty + 8 * j, k = k0 + tx;
+    unsigned short pl[NPL];
+    planes_of(src[(int64_t)n * FLAT + k], sc, pl);
 #pragma unroll
-  for (int p = 0; p < NPL; ++p) t[p * (int64_t)FLAT * FEAT] = pl[p];
+    for (int p = 0; p < NPL; ++p) {
+      d[p * (int64_t)FLAT * FEAT + (int64_t)n * FLAT + k] = pl[p];
+      tile[p][ty + 8 * j][tx] = pl[p];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + ty + 8 * j, n = n0 + tx;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) t[p * (int64_t)FLAT * FEAT + (int64_t)k * FEAT + n] = tile[p][tx][ty + 8 * j];
+  }
 }
 
 // conv2 weights as NPL planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
@@ -116,7 +129,14 @@ __global__ __launch_bounds__(256) void weights_amax_kernel(const float* __restri
   const float* src = params + L.enc_base[e] + off;
   float m = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
-  amax_update(m, amax + amax_idx(t, e));
+  // one atomic per WORKGROUP: every wave of the grid looks at the (freshly zeroed) slot at the same moment, so the "look first" of
+  // amax_update saves nothing here and 2,048 atomics on eight addresses took 35 of this kernel's 42 us
+  __shared__ float wm[4];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax((unsigned*)(amax + amax_idx(t, e)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 // upper bound of |a1| per encoder -> slot AMAX_A1 (common.h): max over oc of sum_k |w1[oc][k]| + |b1[oc]|; grid (32 oc, NE), one wave
@@ -140,7 +160,8 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
   hipLaunchKernelGGL(pack_dgrad2_planes_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
   hipLaunchKernelGGL(pack_conv3_planes_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
   hipLaunchKernelGGL(pack_conv2_planes_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
-  hipLaunchKernelGGL(pack_fc_planes_kernel, dim3((FLAT * FEAT + 255) / 256, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
+  static_assert(FLAT % 32 == 0 && FEAT % 32 == 0, "whole 32 x 32 tiles");
+  hipLaunchKernelGGL(pack_fc_planes_kernel, dim3(FLAT / 32, FEAT / 32, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
   hipLaunchKernelGGL(pack_conv1_planes_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
 }
 
