@@ -83,8 +83,20 @@ __device__ __forceinline__ void pin_offsets(uint32_t (&off)[N]) {
 __device__ __forceinline__ f4 ld4_so(const void* uniform_base, uint32_t lane_bytes) {
   return *(const f4*)((const char*)uniform_base + lane_bytes);
 }
+#ifndef DDRL_ST_SBASE
+#define DDRL_ST_SBASE 0  // measured: 61 fewer vector instructions per ConvFwd1 workgroup, ConvFwd2 2.36 -> 2.51 ms, iteration 25.18 -> 25.40: off
+#endif
 __device__ __forceinline__ void st1_so(void* uniform_base, uint32_t lane_bytes, float v) {
+#if DDRL_ST_SBASE
+  // the row offset that callers fold into `uniform_base` (k x 1,600 B, k x 324 B ...) fits the store's 12-bit immediate only for the
+  // first few rows of an epilogue; beyond that the compiler rebuilds a 64-bit VECTOR address per store (v_add_co + v_addc, or
+  // v_lshl_add_u64 when the base is merely opaque).  Written out, the sum stays on the scalar ALU:
+  //   global_store_dword v_off, v_data, s[base:base+1]
+  // (a dword store reads its data register at issue: no hazard the compiler would have to know about)
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_bytes), "v"(v), "s"(uniform_base) : "memory");
+#else
   *(float*)((char*)uniform_base + lane_bytes) = v;
+#endif
 }
 __device__ __forceinline__ float ld1f_so(const void* uniform_base, uint32_t lane_bytes) {
   return *(const float*)((const char*)uniform_base + lane_bytes);
