@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
   float lba[8], lbc[8];  // the dense layer's bias (added here when the features arrive as split-K partial sums): requested with the head weights
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    lba[i] = params[L.enc_base[0] + L.enc.lb + lane * 8 + i];  // unconditional (no branch, no join to wait at); only read when fc_nsplit > 0
-    lbc[i] = params[L.enc_base[1] + L.enc.lb + lane * 8 + i];
+    // no branch around the loads (no join to wait at): with finished features (fc_nsplit = 0; the operator form has no encoder in
+    // its layout at all) they read the first 512 floats of the arena instead -- the actor head's, always there -- and are not used
+    lba[i] = params[(fc_nsplit > 0 ? L.enc_base[0] + L.enc.lb : L.actor_w) + lane * 8 + i];
+    lbc[i] = params[(fc_nsplit > 0 ? L.enc_base[1] + L.enc.lb : L.actor_w) + lane * 8 + i];
   }
   // one sample; called once outside the loop (the common case: one sample per wave) so that the loads above are only waited for
   // where their values are used -- in front of a loop the compiler drains them first
