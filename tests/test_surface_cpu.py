@@ -217,3 +217,32 @@ def test_bench_gpus_n_refuses_to_pretend(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_cost_model_reads_the_committed_profiles():
+    """tools/cost_model.py: three constants fitted to the committed microbenchmark lines, applied to the committed
+    PMC counts -- the newest profile set must parse, the constants must sit where the microbenchmark puts them, and the model's sum over
+    the eleven GEMM kernels must stay within 25 % of the measured sum (it is 10 % for r03_v3); bench.py's roofline.mix_model uses the same
+    code."""
+    import contextlib
+    import glob
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import cost_model
+    mix = sorted(glob.glob(os.path.join(root, "profiles", "*_mfma16_mix.txt")))[-1]
+    rate, c_valu, c_byte, rows = cost_model.fit(mix)
+    assert 1400 < rate < 1800 and 0.04 < c_valu < 0.15 and 0.002 < c_byte < 0.006, (rate, c_valu, c_byte)
+    assert rows["+ 3 VALU, 128 B read per MFMA"] < rows["+ 3 VALU per MFMA"] < rows["MFMA + LDS operands only"]
+    buf = io.StringIO()
+    argv = sys.argv
+    sys.argv = ["cost_model.py"]
+    try:
+        with contextlib.redirect_stdout(buf):
+            cost_model.main()
+    finally:
+        sys.argv = argv
+    last = buf.getvalue().strip().splitlines()[-1].split()
+    model, measured = float(last[-3]), float(last[-2])
+    assert last[0] == "sum" and 0.8 < measured / model < 1.25, buf.getvalue()
