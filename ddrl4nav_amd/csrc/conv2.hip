@@ -207,10 +207,190 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv1 forward of a TRAINING launch with the weight planes resident in LDS (-DDDRL_F1_RESIDENT=0: the kernel above for every launch).
+// conv_fwd1_planes_kernel copies a stacked frame's planes (16 KB) from L2 into LDS for every 256 output pixels: 6.5 GB per launch at
+// B = 65,536, and its timing knock-outs put 0.6 of the kernel's 2.7 ms there.  Here one workgroup per CU keeps all four frames' planes
+// (64 KB) for the whole launch and walks over the tiles: eight waves = two groups of four, each group with the tile geometry, image
+// rows (4 x 10.5 KB, all four stacked frames staged at once) and epilogue of the kernel above; the groups share the barriers (they
+// run the same phases), the next tile's frame bytes are in flight while the present one feeds the matrix pipe.
+// ------------------------------------------------------------------------------------------------
+#ifndef DDRL_F1_RESIDENT
+#define DDRL_F1_RESIDENT 1
+#endif
+template <int NE>
+struct Fwd1R {
+  static constexpr int ROWS = 32 * NE, A_BYTES = 4 * NPL * 2 * ROWS * 16, PITCH = DDRL_F1_PITCH, IMG_BYTES = 64 * PITCH;
+  static constexpr int W_BYTES = 4 * A_BYTES, IMG_OFF = W_BYTES, GROUP_IMG = 4 * IMG_BYTES;   // per group: four stacked frames
+  static constexpr int BIAS_OFF = IMG_OFF + 2 * GROUP_IMG;
+  static constexpr size_t LDS_BYTES = BIAS_OFF + ROWS * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+};
+
+template <int NE>
+__global__ __launch_bounds__(512) void conv_fwd1_resident_kernel(const uint8_t* __restrict__ frames, const unsigned short* __restrict__ wp1b,
+                                                                 float* __restrict__ amax, const float* __restrict__ params, int64_t bias_off0,
+                                                                 int64_t bias_off1, float* __restrict__ out, int64_t out_es, int n,
+                                                                 unsigned* __restrict__ m1, int64_t m1_es, int C) {
+  using K = Fwd1R<NE>;
+  extern __shared__ __attribute__((aligned(16))) char ldsr[];
+  const int tid = threadIdx.x, gq = tid >> 8, lt = tid & 255, lane = tid & 63, wc = (tid >> 6) & 3, l31 = lane & 31, hi = lane >> 5;
+  char* img = ldsr + K::IMG_OFF + gq * K::GROUP_IMG;
+  float* bias = (float*)(ldsr + K::BIAS_OFF);
+  const int ctot = n * 400, ntiles = (ctot + 255) / 256;
+  // this kernel opens every training forward: it resets the running maxima that the conv2 / conv3 epilogues raise afterwards
+  if (blockIdx.x == 0 && tid < (AMAX_DH - AMAX_FIRST_ACT) * 2) amax[amax_idx(AMAX_FIRST_ACT, 0) + tid] = 0.0f;
+  // weight planes of the C stacked frames: a plain copy of global memory, 1,024 quads per frame
+  for (int q = tid; q < C * (K::A_BYTES / 16); q += 512) *(f4*)(ldsr + q * 16) = *(const f4*)((const char*)wp1b + (size_t)q * 16);
+  if (tid < K::ROWS) bias[tid] = params[(tid >> 5 ? bias_off1 : bias_off0) + (tid & 31)];
+  float r255[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) r255[i] = PIXEL_UNIT / (255.0f * plane_scale(amax[amax_idx(AMAX_W1, i)]));
+  int abase[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) abase[i] = (hi * K::ROWS + i * 32 + l31) * 16;
+
+  // tile geometry (as in the kernel above): 256 output pixels of at most two samples and the input rows they need
+  struct Geo {
+    int c0, b0, iy0_start, nrows0, nd0, nd_total;
+    int64_t src0, src1;
+  };
+  auto geometry = [&](int t) {
+    Geo g;
+    g.c0 = t * 256;
+    const int clast = min(g.c0 + 255, ctot - 1);
+    g.b0 = g.c0 / 400;
+    const int b1 = clast / 400, oyf0 = (g.c0 % 400) / 20;
+    g.iy0_start = 4 * oyf0;
+    int nrows1 = 0;
+    if (b1 == g.b0) {
+      g.nrows0 = 4 * ((clast % 400) / 20 - oyf0) + 8;
+    } else {
+      g.nrows0 = 84 - g.iy0_start;
+      nrows1 = 4 * ((clast % 400) / 20) + 8;
+    }
+    g.nd0 = g.nrows0 * 21;
+    g.nd_total = g.nd0 + nrows1 * 21;
+    g.src0 = (int64_t)g.b0 * (C * 7056) + g.iy0_start * 84;
+    g.src1 = (int64_t)b1 * (C * 7056);
+    return g;
+  };
+  unsigned imreg[4][6];
+  auto request = [&](const Geo& g) {  // the frame bytes of all four stacked frames of the group's tile: 24 dwords per thread
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = lt + 256 * j;
+      const int64_t o = (idx >= g.nd_total) ? g.src0 : (idx < g.nd0 ? g.src0 + idx * 4 : g.src1 + (idx - g.nd0) * 4);
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) imreg[ch][j] = *(const unsigned*)(frames + (ch < C ? ch : C - 1) * 7056 + o);
+    }
+  };
+  int t = 2 * (int)blockIdx.x + gq;
+  Geo g = geometry(min(t, ntiles - 1));
+  request(g);
+  __syncthreads();  // weights and bias in place
+  for (; 2 * (t / 2) < ntiles; t += 2 * (int)gridDim.x) {  // both groups of a workgroup leave together: the barriers below are shared
+    const bool live = t < ntiles;
+    // ---- frame bytes -> fp16 rows of the group's image (the registers hold this tile's bytes)
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int idx = lt + 256 * j;
+        if (ch < C && idx < g.nd_total) *(uint2*)(img + ch * K::IMG_BYTES + (idx / 21) * K::PITCH + (idx % 21) * 8) = pixel_quad(imreg[ch][j]);
+      }
+    int bbase[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = g.c0 + wc * 64 + j * 32 + l31;
+      if (c >= ctot) c = g.c0;
+      const int b = c / 400, pix = c % 400, oy = pix / 20, ox = pix % 20;
+      const int lr = (b == g.b0) ? (4 * oy - g.iy0_start) : (g.nrows0 + 4 * oy);
+      bbase[j] = (lr + hi) * K::PITCH + ox * 8;
+    }
+    const Geo cur = g;
+    __syncthreads();  // image rows visible
+    // ---- the next tile's bytes travel while this one is multiplied
+    const int tn = t + 2 * (int)gridDim.x;
+    if (2 * (tn / 2) < ntiles) {
+      g = geometry(min(tn, ntiles - 1));
+      request(g);
+    }
+    f32x16 acc[NE][2];
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (ch >= C) break;
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk) {
+        frag8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* q = img + ch * K::IMG_BYTES + bbase[j] + gk * (2 * K::PITCH);
+          const uint2 lo = *(const uint2*)q, hi4 = *(const uint2*)(q + 8);
+          b[j] = __builtin_bit_cast(frag8, (u4v){lo.x, lo.y, hi4.x, hi4.y});
+        }
+#pragma unroll
+        for (int p = NPL - 1; p >= 0; --p) {  // smallest plane first
+          frag8 a[NE];
+#pragma unroll
+          for (int i = 0; i < NE; ++i) a[i] = *(const frag8*)(ldsr + ch * K::A_BYTES + abase[i] + ((gk * NPL + p) * 2) * K::ROWS * 16);
+#pragma unroll
+          for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_planes(a[i], b[j], acc[i][j]);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with the image rows: the next tile may overwrite them
+    if (!live) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = cur.c0 + wc * 64 + j * 32 + l31;
+      if (c >= ctot) continue;
+      const int b = c / 400, pix = c % 400;
+      const uint32_t lanep = (uint32_t)((b * 12800 + pix + hi * (4 * 400)) * 4);
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        float* base = out + i * out_es;
+        unsigned bits = 0u;  // sign mask of a1 (common.h Workspace::m1), as in the kernel above
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int oc = acc_row(r, hi);
+          const float y = leaky_f(__builtin_fmaf(acc[i][j][r], r255[i], bias[i * 32 + oc]));
+          st1_so(base + acc_row(r, 0) * 400, lanep, y);
+          bits = __builtin_amdgcn_alignbit(bits, (unsigned)__builtin_elementwise_sub_sat((int)__float_as_uint(y), 1), 31);
+        }
+        if (m1 != nullptr) ((unsigned short*)(m1 + i * m1_es))[2 * (int64_t)c + hi] = (unsigned short)bits;
+      }
+    }
+  }
+}
+
 template <int NE>
 static void launch_fwd1_planes(const EncCall& c, bool acting, hipStream_t st) {
   const Workspace& w = *c.ws;
   const ParamLayout& L = *c.L;
+  if (DDRL_F1_RESIDENT != 0 && !acting && (int64_t)c.n * 400 >= 256 * 2048) {  // at least ~8 tiles per workgroup: the 64 KB weight copy pays
+    using R = Fwd1R<NE>;
+    static bool configured_r = false;
+    static int cus = 256;
+    if (!configured_r) {
+      (void)hipFuncSetAttribute((const void*)conv_fwd1_resident_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_BYTES);
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      configured_r = true;
+    }
+    hipLaunchKernelGGL(conv_fwd1_resident_kernel<NE>, dim3((unsigned)cus), dim3(512), R::LDS_BYTES, st, c.frames, w.wp1b, w.amax, c.params,
+                       L.enc_base[0] + L.enc.c1b, L.enc_base[NE - 1] + L.enc.c1b, w.a1, c.max_batch * 12800, c.n, w.m1, m1_words(c.max_batch), L.C);
+    return;
+  }
   using K = Fwd1B<NE>;
   static bool configured = false;
   if (!configured) {
