@@ -254,7 +254,7 @@ def pmc_traffic(kernel):
     try:
         doc = json.load(open(files[-1]))
         ks = doc["kernels"]
-        k = ks.get(kernel) or ks.get(alias.get(kernel, ""))
+        k = ks.get(kernel) or (ks.get("conv_fwd1_resident") if kernel == "ConvFwd1" else None) or ks.get(alias.get(kernel, ""))
         if k is None:
             return None
         out = {"hbm_bytes_per_launch": k["hbm_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
@@ -287,7 +287,7 @@ def mix_model(kernel, measured_ms):
         rate, c_valu, c_byte, _ = cost_model.fit(mixes[-1])
         doc = json.load(open(os.path.join(ROOT, "profiles", t["source"])))["kernels"]
         alias = {v: k for k, v in cost_model.NAMES.items()}
-        k = doc[alias[kernel]]
+        k = doc.get("conv_fwd1_resident") if kernel == "ConvFwd1" and "conv_fwd1_resident" in doc else doc[alias[kernel]]
         by = k["write_bytes"] + 2.0 * k["fetch_bytes"]  # FETCH_SIZE counts 16-byte-per-lane streams at half their bytes on gfx950
         ms = lambda eq: eq * cost_model.FLOP_PER_MFMA / (rate * 1e12) * 1e3
         parts = [ms(k["mfma_insts"]), ms(c_valu * (k["valu_insts"] - k["mfma_insts"])), ms(c_byte * by)]  # SQ_INSTS_VALU includes the MFMAs

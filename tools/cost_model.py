@@ -60,6 +60,8 @@ def main():
     print("%-11s %8s %10s %8s | %7s %7s %7s | %8s %9s %6s" % ("kernel", "MFMA M", "VALU/MFMA", "B/MFMA", "mfma ms", "valu ms", "hbm ms", "model ms", "measured", "ratio"))
     tot = [0.0] * 5
     for k, n in NAMES.items():
+        if k == "conv_fwd1_planes" and "conv_fwd1_resident" in pmc:
+            k = "conv_fwd1_resident"  # training launches of round 3 and later (csrc/conv2.hip)
         v = pmc[k]
         mf = v["mfma_insts"]
         va = v["valu_insts"] - mf  # SQ_INSTS_VALU counts the matrix instructions too (checked on tools/mfma16_mix.hip: MFMA-only loop 2.66e8 against 2.62e8 MFMAs)

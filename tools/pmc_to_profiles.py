@@ -45,7 +45,7 @@ def main():
                 continue
             # acting-size launches of the forward kernels (small grids) are kept apart from the
             # training-size ones; every other kernel only runs in training (or is size-independent)
-            big = ("fwd" not in name.lower() and name != "heads_act") or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000
+            big = ("fwd" not in name.lower() and name != "heads_act") or name == "conv_fwd1_resident" or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000  # (the resident conv1 kernel: one workgroup per CU, training launches only)
             key = name + ("" if big else ":acting")
             c = agg[key][row["Counter_Name"]]
             c[0] += float(row["Counter_Value"])
