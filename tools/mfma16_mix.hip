@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u4v;
 
 // NV vector-ALU instructions per MFMA; LD 16-byte-per-lane loads (1 KB per wave) per iteration of 32 MFMAs, ST the same for stores
 template <int NV, int LD, int ST, int OP = 0>
-__global__ __launch_bounds__(256) void mix_loop(float* out, const char* src, char* dst, size_t per_wave, int iters) {
+__global__ __launch_bounds__(256) void mix_loop(float* out, const char* src, char* dst, size_t per_wave, int iters, size_t window) {
   __shared__ u4v lds[4096];  // 64 KB
   for (int i = threadIdx.x; i < 4096; i += 256) {
     unsigned s = i * 2654435761u;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void mix_loop(float* out, const char* src, cha
       asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(sink) : "memory");
     }
     off += (LD > ST ? LD : ST) * 1024;
-    if (off + 8 * 1024 > per_wave) off = 0;
+    if (off + 8 * 1024 > window) off = 0;  // window = per_wave: streams from HBM; a few KB: the same lines again and again (L2 hits)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       h8v a[2], b[2];
@@ -104,19 +104,20 @@ __global__ __launch_bounds__(256) void mix_loop(float* out, const char* src, cha
   out[blockIdx.x * 256 + threadIdx.x] = s + (float)(sink[0] & 1u);
 }
 
-typedef void (*kern_t)(float*, const char*, char*, size_t, int);
-static void run(const char* name, kern_t k, int ld, int st, float* d, const char* src, char* dst, size_t per_wave, int blocks, int iters, int reps) {
+typedef void (*kern_t)(float*, const char*, char*, size_t, int, size_t);
+static void run(const char* name, kern_t k, int ld, int st, float* d, const char* src, char* dst, size_t per_wave, int blocks, int iters, int reps, size_t window = 0) {
+  if (window == 0) window = per_wave;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, src, dst, per_wave, iters);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, src, dst, per_wave, iters, window);
   const hipError_t err = hipDeviceSynchronize();
   if (err != hipSuccess) {
     printf("  %s: %s\n", name, hipGetErrorString(err));
     exit(1);
   }
   hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, src, dst, per_wave, iters);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, src, dst, per_wave, iters, window);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -161,6 +162,10 @@ int main(int argc, char** argv) {
     RUN(3, 4, 0, "+ 3 VALU, 128 B read per MFMA");
     RUN(6, 2, 2, "+ 6 VALU, 64 B read + 64 B written per MFMA");
     RUN(6, 4, 0, "+ 6 VALU, 128 B read per MFMA");
+    // the same reads served by L2 (every wave cycles through a 16 KB window: 32 MB in all) -- what an L2 -> LDS / register weight copy costs
+    run("+ 128 B read per MFMA from L2", mix_loop<0, 4, 0>, 4, 0, d, src, dst, per_wave, blocks, iters, reps, 16384);
+    run("+ 256 B read per MFMA from L2", mix_loop<0, 8, 0>, 8, 0, d, src, dst, per_wave, blocks, iters, reps, 16384);
+    run("+ 3 VALU, 128 B read per MFMA from L2", mix_loop<3, 4, 0>, 4, 0, d, src, dst, per_wave, blocks, iters, reps, 16384);
     // which vector-ALU instructions cost what: 4 of one kind per MFMA, no memory traffic
     RUNOP(1, "+ 4 v_mov_b32 per MFMA");
     RUNOP(10, "+ 4 v_add_u32 per MFMA");
