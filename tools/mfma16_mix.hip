@@ -52,8 +52,13 @@ __global__ __launch_bounds__(256) void mix_loop(float* out, const char* src, cha
     // the memory traffic of the iteration: requested first, never waited for (the hardware's 64-deep counter is the only back pressure)
 #pragma unroll
     for (int l = 0; l < LD; ++l) {
-      const char* p = sp + off + l * 1024;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p) : "memory");  // "+": the registers stay reserved while loads are in flight
+      if (OP >= 100) {  // narrow form: 4 bytes per lane (256 B per instruction), lanes contiguous
+        const char* p = src + gw * per_wave + lane * 4 + off + l * 256;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink[0]) : "v"(p) : "memory");
+      } else {
+        const char* p = sp + off + l * 1024;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p) : "memory");  // "+": the registers stay reserved while loads are in flight
+      }
     }
 #pragma unroll
     for (int l = 0; l < ST; ++l) {
@@ -166,6 +171,9 @@ int main(int argc, char** argv) {
     run("+ 128 B read per MFMA from L2", mix_loop<0, 4, 0>, 4, 0, d, src, dst, per_wave, blocks, iters, reps, 16384);
     run("+ 256 B read per MFMA from L2", mix_loop<0, 8, 0>, 8, 0, d, src, dst, per_wave, blocks, iters, reps, 16384);
     run("+ 3 VALU, 128 B read per MFMA from L2", mix_loop<3, 4, 0>, 4, 0, d, src, dst, per_wave, blocks, iters, reps, 16384);
+    // 4-byte-per-lane loads: the same number of INSTRUCTIONS as the 128 B line above moves a quarter of the bytes
+    run("+ 4 dword loads per 32 MFMAs (32 B / MFMA)", mix_loop<0, 4, 0, 100>, 1, 0, d, src, dst, per_wave, blocks, iters, reps);
+    run("+ 16 dword loads per 32 MFMAs (128 B / MFMA)", mix_loop<0, 16, 0, 100>, 4, 0, d, src, dst, per_wave, blocks, iters, reps);
     // which vector-ALU instructions cost what: 4 of one kind per MFMA, no memory traffic
     RUNOP(1, "+ 4 v_mov_b32 per MFMA");
     RUNOP(10, "+ 4 v_add_u32 per MFMA");
