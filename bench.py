@@ -472,18 +472,58 @@ def self_launch(args):
                              "rank plumbing (not a scaling measurement)\n" % (n, ndev))
             return 2
         env_base["DDRL_DIST_BACKEND"] = "gloo"
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     argv = [a for a in sys.argv[1:]]
-    procs = []
-    for r in range(n):
-        env = dict(env_base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DDRL_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    import tempfile
+    import time as _t
+    deadline_s = float(os.environ.get("DDRL_BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    codes, out0 = [1] * n, ""
+    for attempt in range(3):  # a rendezvous port picked by bind-then-close can be taken before the ranks bind it: new port, again
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs, t0 = [], _t.time()
+        out_f = tempfile.TemporaryFile()   # rank 0's stdout: a file, so that polling never blocks on a full pipe
+        err_f = tempfile.TemporaryFile()   # rank 0's stderr is passed through AND searched for a rendezvous failure
+        for r in range(n):
+            env = dict(env_base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       DDRL_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out_f if r == 0 else subprocess.DEVNULL, stderr=err_f if r == 0 else None))
+        # poll ALL ranks: the first one that exits non-zero (or the deadline) ends the others -- a rank that died during init or
+        # inside a collective would otherwise leave rank 0 waiting for the collective's own timeout, if it has one
+        failed = None
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+            if bad or _t.time() - t0 > deadline_s:
+                failed = "rank %s exited with %s" % (bad[0], codes[bad[0]]) if bad else "no result after %.0f s" % deadline_s
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        p.wait()
+                codes = [p.returncode for p in procs]
+                break
+            _t.sleep(0.05)
+        out_f.seek(0)
+        out0 = out_f.read().decode(errors="replace")
+        err_f.seek(0)
+        err0 = err_f.read().decode(errors="replace")
+        out_f.close()
+        err_f.close()
+        sys.stderr.write(err0)
+        if failed:
+            sys.stderr.write("bench.py: %s; the other ranks were terminated\n" % failed)
+        rendezvous = any(k in err0 for k in ("Address already in use", "EADDRINUSE", "address already in use"))
+        if not (failed and rendezvous and attempt < 2):
+            break
+        sys.stderr.write("bench.py: rendezvous port %d was taken, retrying with a new one\n" % port)
     line = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if any(codes) or not line:
         sys.stderr.write("bench.py: rank exit codes %s, %d JSON line(s) from rank 0\n" % (codes, len(line)))

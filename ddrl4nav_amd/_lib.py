@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libddrl_hip.so")
 
 STATS_FLOATS = 8
+ABI_VERSION = 2  # include/ddrl.h DDRL_ABI_VERSION this binding was written against
 
 
 class DdrlError(RuntimeError):
@@ -70,6 +71,7 @@ SIGNATURES = {
     "ddrl_last_features": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_gae": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p,
                            c_void_p]),
+    "ddrl_episode_returns": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_ppo_iter": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
                                 c_void_p]),
     "ddrl_clip_adam_step": (c_int32, [c_void_p, c_void_p]),
@@ -147,6 +149,8 @@ SIGNATURES = {
     "ddrl_grad_bucket_count": (c_int32, [c_void_p, POINTER(c_int32)]),
     "ddrl_grad_bucket_info": (c_int32, [c_void_p, c_int32, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     "ddrl_grad_bucket_wait": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "ddrl_grad_buckets_begin": (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(c_int32)]),
+    "ddrl_grad_bucket_wait_last": (c_int32, [c_void_p, c_void_p]),
     "ddrl_grad_allreduce_overlapped": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_clip_rmsprop": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_double, c_float, c_float, c_void_p,
                                        c_void_p]),
@@ -172,8 +176,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.ddrl_abi_version() != 1:
-        raise DdrlError("libddrl_hip.so ABI version mismatch")
+    got = lib.ddrl_abi_version()
+    if got != ABI_VERSION:
+        raise DdrlError("libddrl_hip.so ABI version %d, this binding needs %d: rebuild with `make -C ddrl4nav_amd/csrc`"
+                        % (got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -6,16 +6,26 @@ Pool layout (all on the GPU, [time][env] major so that GAE loads are coalesced a
   frames  uint8 [T+1, N, C, 84, 84]    values f32 [T+1, N]     rewards f32 [T, N]
   actions f32 [T, N]   logps f32 [T, N]   dones u8 [T, N]      adv / ret f32 [T, N]
 Frames arrive either as device tensors or through a pinned-host ring (data/ring.py) with
-hipMemcpyAsync on a copy stream, overlapping the previous step's forward."""
+hipMemcpyAsync on a copy stream, overlapping the previous step's forward.
+
+Carry-over between rollouts (reference agent.py:286-292: ``rewards_step[0] = rewards_step[T]; exps = [exps[-1]]``): the
+reference keeps the WHOLE (T+1)-th Experience -- state, the action already sent to the env, its old log-prob, its value
+under the weights of that moment, its reward and done -- as step 0 of the next rollout and acts from step 1 on.
+``carry_over(keep_step=True)`` does exactly that (rows T of every pool, which ``bootstrap()`` / ``record(T, ...)`` fill,
+move to row 0; the next rollout starts at ``t0 == 1``).  The default, ``carry_over()``, carries the FRAME only and lets
+``act(0)`` re-evaluate it with the current weights (a fresh action, log-prob and value for slot 0): a deviation from the
+reference, listed in DESIGN.md section 7 -- it needs no env step between ``bootstrap()`` and ``finish()`` and its slot-0
+sample is on-policy for the weights the update starts from."""
 import torch
 
 from ddrl4nav_amd.agent.agent import gae_device
+from ddrl4nav_amd.agent.statistics import EpisodeReturns
 from ddrl4nav_amd.data import Experience
 from ddrl4nav_amd.utils.staging import copy_into
 
 
 class DeviceRollout:
-    def __init__(self, net, n_envs, horizon=256, channels=4, gamma=0.99, landa=0.95, device=None, seed=0):
+    def __init__(self, net, n_envs, horizon=256, channels=4, gamma=0.99, landa=0.95, device=None, seed=0, track_returns=False):
         self.hp = net.hot_path if hasattr(net, "hot_path") else net
         self.N, self.T, self.C = int(n_envs), int(horizon), int(channels)
         self.gamma, self.landa = gamma, landa
@@ -24,17 +34,21 @@ class DeviceRollout:
         N, T = self.N, self.T
         self.frames = torch.empty((T + 1, N, self.C, 84, 84), dtype=torch.uint8, device=dev)
         self.values = torch.zeros((T + 1, N), dtype=torch.float32, device=dev)
-        self.rewards = torch.zeros((T, N), dtype=torch.float32, device=dev)
-        self.dones = torch.zeros((T, N), dtype=torch.uint8, device=dev)
-        self.actions = torch.zeros((T, N), dtype=torch.float32, device=dev)
-        self.logps = torch.zeros((T, N), dtype=torch.float32, device=dev)
+        # rows 0..T-1 are the rollout (contiguous [T, N] views: what GAE and the learner batch read); row T holds the (T+1)-th
+        # step's reward / done / action / log-prob for carry_over(keep_step=True)
+        self._rewards = torch.zeros((T + 1, N), dtype=torch.float32, device=dev)
+        self._dones = torch.zeros((T + 1, N), dtype=torch.uint8, device=dev)
+        self._actions = torch.zeros((T + 1, N), dtype=torch.float32, device=dev)
+        self._logps = torch.zeros((T + 1, N), dtype=torch.float32, device=dev)
+        self.rewards, self.dones = self._rewards[:T], self._dones[:T]
+        self.actions, self.logps = self._actions[:T], self._logps[:T]
         self.adv = torch.empty((T, N), dtype=torch.float32, device=dev)
         self.ret = torch.empty((T, N), dtype=torch.float32, device=dev)
         self._probs = torch.empty((N, self.hp.n_actions), dtype=torch.float32, device=dev)
-        self._scratch_a = torch.empty(N, dtype=torch.float32, device=dev)
-        self._scratch_l = torch.empty(N, dtype=torch.float32, device=dev)
         self.seed, self.rollouts, self.t = int(seed), 0, 0
+        self.t0 = 0  # first step the next rollout has to act on: 1 after carry_over(keep_step=True), else 0
         self.copy_stream = torch.cuda.Stream(device=dev)
+        self.returns = EpisodeReturns(N, dev) if track_returns else None
 
     # ---- ingest ---------------------------------------------------------------------------------
     def put_frames(self, t, frames):
@@ -48,28 +62,46 @@ class DeviceRollout:
 
     # ---- acting ---------------------------------------------------------------------------------
     def act(self, t):
-        """Forward + sample on slot t: fills values[t], actions[t], logps[t]; returns actions[t]."""
+        """Forward + sample on slot t: fills values[t], actions[t], logps[t]; returns actions[t].  A slot below t0 was carried
+        over as a complete step (its action has already been sent to the env): nothing is evaluated, the kept action returns."""
+        if t < self.t0:
+            return self._actions[t]
         self.hp.forward(self.frames[t], seed=self.seed + self.rollouts, stream_id=t, probs=self._probs,
-                        value=self.values[t], action=self.actions[t], logp=self.logps[t])
-        return self.actions[t]
+                        value=self.values[t], action=self._actions[t], logp=self._logps[t])
+        return self._actions[t]
 
     def bootstrap(self):
-        """Value of the (T+1)-th stored step (agent.py:130); its action/logp are not kept."""
-        self.hp.forward(self.frames[self.T], seed=self.seed + self.rollouts, stream_id=self.T, probs=self._probs,
-                        value=self.values[self.T], action=self._scratch_a, logp=self._scratch_l)
+        """The (T+1)-th stored step: its value is the GAE bootstrap (agent.py:130); its action / log-prob land in row T, for a
+        host that steps the env with them and keeps the step (carry_over(keep_step=True)).  Returns the action."""
+        return self.act(self.T)
 
     def record(self, t, rewards, dones):
-        copy_into(self.rewards[t], rewards)
-        copy_into(self.dones[t], dones)
+        """Reward / done of step t (0..T; T = the (T+1)-th step, only needed for keep_step)."""
+        if t < self.t0:
+            raise ValueError("step %d was carried over from the previous rollout with its reward and done" % t)
+        copy_into(self._rewards[t], rewards)
+        copy_into(self._dones[t], dones)
 
     # ---- GAE + learner batch ----------------------------------------------------------------------
     def finish(self):
         gae_device(self.values, self.rewards, self.dones, self.gamma, self.landa, adv=self.adv, ret=self.ret)
+        if self.returns is not None:  # Status.update_reward_status over rows 0..T-1: every step once, also with keep_step
+            self.returns.update(self.rewards, self.dones)
         self.rollouts += 1
 
-    def carry_over(self):
-        """The last stored step becomes step 0 of the next rollout (agent.py:289-291)."""
-        self.frames[0].copy_(self.frames[self.T])
+    def carry_over(self, keep_step=False):
+        """The last stored step becomes step 0 of the next rollout (agent.py:286-292).  keep_step=True: the whole step, as the
+        reference keeps it (frame, action, old log-prob, value, reward, done of row T; the next rollout acts from t0 = 1);
+        False (default): the frame only, slot 0 is evaluated again by act(0) under the current weights."""
+        T = self.T
+        self.frames[0].copy_(self.frames[T])
+        if keep_step:
+            self.values[0].copy_(self.values[T])
+            for pool in (self._rewards, self._dones, self._actions, self._logps):
+                pool[0].copy_(pool[T])
+            self.t0 = 1
+        else:
+            self.t0 = 0
 
     def batch(self):
         """Zero-copy views in the layout net.learn expects (sample order is irrelevant to the maths)."""
@@ -84,7 +116,7 @@ class StateRollout:
     the action may be continuous.  Same pool layout idea ([time][env] major, everything on the GPU),
     same life cycle: put_states(t, ...) -> act(t) -> record(t, ...) ... bootstrap() -> finish() -> batch()."""
 
-    def __init__(self, net, n_envs, state_shapes, horizon=256, gamma=0.99, landa=0.95, device=None):
+    def __init__(self, net, n_envs, state_shapes, horizon=256, gamma=0.99, landa=0.95, device=None, track_returns=False):
         self.net = net
         self.N, self.T = int(n_envs), int(horizon)
         self.gamma, self.landa = gamma, landa
@@ -94,14 +126,18 @@ class StateRollout:
         f = dict(dtype=torch.float32, device=dev)
         self.states = [torch.empty((T + 1, N) + tuple(int(d) for d in shape), **f) for shape in state_shapes]
         self.values = torch.zeros((T + 1, N), **f)
-        self.rewards = torch.zeros((T, N), **f)
-        self.dones = torch.zeros((T, N), dtype=torch.uint8, device=dev)
-        act_shape = (T, N, net.n_actions) if getattr(net, "continuous", False) else (T, N)
-        self.actions = torch.zeros(act_shape, **f)
-        self.logps = torch.zeros((T, N), **f)
+        self._rewards = torch.zeros((T + 1, N), **f)
+        self._dones = torch.zeros((T + 1, N), dtype=torch.uint8, device=dev)
+        act_shape = (T + 1, N, net.n_actions) if getattr(net, "continuous", False) else (T + 1, N)
+        self._actions = torch.zeros(act_shape, **f)
+        self._logps = torch.zeros((T + 1, N), **f)
+        self.rewards, self.dones = self._rewards[:T], self._dones[:T]
+        self.actions, self.logps = self._actions[:T], self._logps[:T]
         self.adv = torch.empty((T, N), **f)
         self.ret = torch.empty((T, N), **f)
+        self.t0 = 0
         self.copy_stream = torch.cuda.Stream(device=dev)
+        self.returns = EpisodeReturns(N, dev) if track_returns else None
 
     def put_states(self, t, states):
         """Device or pinned-host tensors, one per observation component -> pool slot t."""
@@ -114,27 +150,47 @@ class StateRollout:
         torch.cuda.current_stream().wait_stream(self.copy_stream)
 
     def act(self, t):
+        if t < self.t0:  # carried over as a complete step (DeviceRollout.act)
+            return self._actions[t]
         (dist, _), values = self.net([p[t] for p in self.states])
         a = dist.sample()
         self.values[t].copy_(values[0][:, 0])
-        self.actions[t].copy_(a)
-        self.logps[t].copy_(self.net.actor.log_prob_from_distribution(dist, a))
-        return self.actions[t]
+        self._actions[t].copy_(a)
+        self._logps[t].copy_(self.net.actor.log_prob_from_distribution(dist, a))
+        return self._actions[t]
 
-    def bootstrap(self):
+    def bootstrap(self, sample=False):
+        """Value of the (T+1)-th stored step (agent.py:130).  sample=True also draws its action / log-prob into row T, for a
+        host that steps the env with them and keeps the step (carry_over(keep_step=True)); returns that action."""
+        if sample:
+            return self.act(self.T)
         (_, _), values = self.net([p[self.T] for p in self.states], play_mode=True)
         self.values[self.T].copy_(values[0][:, 0])
+        return None
 
     def record(self, t, rewards, dones):
-        copy_into(self.rewards[t], rewards)
-        copy_into(self.dones[t], dones)
+        if t < self.t0:
+            raise ValueError("step %d was carried over from the previous rollout with its reward and done" % t)
+        copy_into(self._rewards[t], rewards)
+        copy_into(self._dones[t], dones)
 
     def finish(self):
         gae_device(self.values, self.rewards, self.dones, self.gamma, self.landa, adv=self.adv, ret=self.ret)
+        if self.returns is not None:
+            self.returns.update(self.rewards, self.dones)
 
-    def carry_over(self):
+    def carry_over(self, keep_step=False):
+        """DeviceRollout.carry_over: keep_step=True keeps the whole (T+1)-th step as the reference does (agent.py:286-292)."""
+        T = self.T
         for p in self.states:
-            p[0].copy_(p[self.T])
+            p[0].copy_(p[T])
+        if keep_step:
+            self.values[0].copy_(self.values[T])
+            for pool in (self._rewards, self._dones, self._actions, self._logps):
+                pool[0].copy_(pool[T])
+            self.t0 = 1
+        else:
+            self.t0 = 0
 
     def batch(self):
         B = self.N * self.T

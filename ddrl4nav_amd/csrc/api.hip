@@ -32,7 +32,9 @@ struct ddrl_ctx : public ddrl::Profiler {
   bool acts_stored = true;  // false after a ddrl_forward that left a1 / a2 on chip: ddrl_debug_buffer(0 / 1) refuses
   hipEvent_t bucket_ev[GRAD_BUCKETS];
   hipEvent_t comm_done;
+  hipEvent_t call_ev;  // recorded on the compute stream when an overlapped reduction is requested (see ddrl_grad_allreduce_overlapped)
   bool buckets;  // ddrl_grad_buckets_enable: record the bucket events in every ddrl_ppo_iter
+  bool bucket_events_fresh = false;  // a ddrl_ppo_iter has recorded all bucket events since the last overlapped reduction
   std::vector<ProfEntry> prof_pending;
   std::vector<std::string> prof_names;
   std::vector<double> prof_ms;
@@ -173,6 +175,7 @@ int32_t ddrl_ctx_destroy(ddrl_ctx* ctx) {
   if (ctx->buckets) {
     for (int b = 0; b < GRAD_BUCKETS; ++b) hipEventDestroy(ctx->bucket_ev[b]);
     hipEventDestroy(ctx->comm_done);
+    hipEventDestroy(ctx->call_ev);
   }
 
   delete ctx;
@@ -263,6 +266,14 @@ int32_t ddrl_gae(const float* values, const float* rewards, const uint8_t* dones
   return check_launch();
 }
 
+int32_t ddrl_episode_returns(const float* rewards, const uint8_t* dones, int32_t T, int32_t N, float* rewards_sum,
+                             float* rewards_episode, float* trace, int32_t* episodes_finished, void* stream) {
+  if (!rewards || !dones || !rewards_sum || !rewards_episode || T < 0 || N < 1) return DDRL_ERR_INVALID_ARG;
+  if (T == 0) return DDRL_OK;
+  launch_episode_returns(rewards, dones, T, N, rewards_sum, rewards_episode, trace, episodes_finished, (hipStream_t)stream);
+  return check_launch();
+}
+
 int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions, const float* old_logps,
                       const float* advs, const float* rets, int32_t B, int64_t B_global, void* stream) {
   if (!ctx || !frames || !actions || !old_logps || !advs || !rets) return DDRL_ERR_INVALID_ARG;
@@ -284,6 +295,7 @@ int32_t ddrl_ppo_iter(ddrl_ctx* ctx, const uint8_t* frames, const float* actions
   bucket_done(ec, BUCKET_HEADS, st);  // head-layer gradients and the three loss shares of the tail are final
   launch_encoder_backward(ec, ctx->grads, st, true);
   ctx->last_n = B;
+  ctx->bucket_events_fresh = ctx->buckets;
   return check_launch();
 }
 
@@ -326,7 +338,9 @@ int32_t ddrl_grad_buckets_enable(ddrl_ctx* ctx) {
   if (ctx->buckets) return DDRL_OK;
   for (int b = 0; b < GRAD_BUCKETS; ++b) HIP_TRY(hipEventCreateWithFlags(&ctx->bucket_ev[b], hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ctx->comm_done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ctx->call_ev, hipEventDisableTiming));
   ctx->buckets = true;
+  ctx->bucket_events_fresh = false;
   return DDRL_OK;
 }
 
@@ -351,11 +365,35 @@ int32_t ddrl_grad_bucket_wait(ddrl_ctx* ctx, int32_t b, void* stream) {
   return DDRL_OK;
 }
 
+int32_t ddrl_grad_buckets_begin(ddrl_ctx* ctx, void* comm_stream, void* compute_stream, int32_t* fresh) {
+  if (!ctx || !ctx->buckets || comm_stream == compute_stream) return DDRL_ERR_INVALID_ARG;
+  // Whatever the compute stream holds AT THE CALL is ordered before the reduction: with fresh bucket events (a ddrl_ppo_iter
+  // directly before) the communication stream waits for this event only in front of the LAST bucket (the earlier buckets keep
+  // their overlap); with stale or never-recorded events (gradients from another producer, accumulation, a retried iteration --
+  // hipStreamWaitEvent on such an event returns at once) it waits for it in front of the FIRST bucket, i.e. no overlap, no race.
+  HIP_TRY(hipEventRecord(ctx->call_ev, (hipStream_t)compute_stream));
+  const bool f = ctx->bucket_events_fresh;
+  ctx->bucket_events_fresh = false;
+  if (!f) HIP_TRY(hipStreamWaitEvent((hipStream_t)comm_stream, ctx->call_ev, 0));
+  if (fresh) *fresh = f ? 1 : 0;
+  return DDRL_OK;
+}
+
+int32_t ddrl_grad_bucket_wait_last(ddrl_ctx* ctx, void* comm_stream) {
+  if (!ctx || !ctx->buckets) return DDRL_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)comm_stream, ctx->call_ev, 0));
+  return DDRL_OK;
+}
+
 int32_t ddrl_grad_allreduce_overlapped(ddrl_ctx* ctx, ddrl_comm* comm, void* comm_stream, void* compute_stream) {
   if (!ctx || !comm || !ctx->buckets || comm_stream == compute_stream) return DDRL_ERR_INVALID_ARG;
   hipStream_t cs = (hipStream_t)comm_stream;
+  int32_t fresh = 0;
+  const int32_t sb = ddrl_grad_buckets_begin(ctx, comm_stream, compute_stream, &fresh);
+  if (sb != DDRL_OK) return sb;
   for (int b = 0; b < GRAD_BUCKETS; ++b) {  // bucket order = completion order of the last ddrl_ppo_iter
-    HIP_TRY(hipStreamWaitEvent(cs, ctx->bucket_ev[b], 0));
+    if (fresh) HIP_TRY(hipStreamWaitEvent(cs, ctx->bucket_ev[b], 0));
+    if (b == GRAD_BUCKETS - 1) HIP_TRY(hipStreamWaitEvent(cs, ctx->call_ev, 0));
     int64_t off[2], cnt[2];
     const int nr = bucket_ranges(ctx, b, off, cnt);
     for (int r = 0; r < nr; ++r) {

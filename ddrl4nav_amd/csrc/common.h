@@ -151,10 +151,18 @@ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 __host__ __device__ inline int64_t m1_words(int64_t max_batch) { return max_batch * 400; }
 __host__ __device__ inline int m1_bit(int oc) { return ((oc >> 2) & 1) * 16 + 15 - ((oc & 3) + 4 * (oc >> 3)); }
 
+#ifdef DDRL_PLANES_BF16
+#define DDRL_ACT_FUSED_MAX 0    // three bf16 planes do not fit the fused kernel's LDS budget: every acting launch takes the batch-tiled kernels
+#elif !defined(DDRL_ACT_FUSED_MAX)
+#define DDRL_ACT_FUSED_MAX 512  // acting launches of at most this many samples (Workspace::actmax is carved for it)
+#endif
 // split counts for the weight-gradient GEMMs (fixed per context -> deterministic sums)
 #ifndef DDRL_FC_ACT_SPLITS
 #define DDRL_FC_ACT_SPLITS 14  // split-K factor of the dense layer's forward in acting launches: a divisor of its 98 k-blocks
 #endif
+// the fused acting kernel (act.hip) leaves a3's scale as per-sample maxima in Workspace::actmax, which only the SPLIT launch of the
+// dense forward reads (fc2.hip); an unsplit acting launch would read a stale AMAX_A3 slot
+static_assert(DDRL_FC_ACT_SPLITS > 1 && 98 % DDRL_FC_ACT_SPLITS == 0, "DDRL_FC_ACT_SPLITS: a divisor of 98 larger than 1");
 #ifndef DDRL_C1_SPLITS
 #define DDRL_C1_SPLITS 512  // two workgroups per CU in ONE round: 3.37 ms against 3.66 at 768 / 1024 / 1536, 4.1 at 256 / 384 / 640 (profiles/README.md)
 #endif
@@ -194,7 +202,7 @@ inline int64_t carve(Workspace& w, const ddrl_config& c, void* base) {
   w.wlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.wdlb = (unsigned short*)take(2 * 3 * (int64_t)FLAT * FEAT / 2);
   w.amax = take(64);
-  w.actmax = take(2 * 512);
+  w.actmax = take(2 * (DDRL_ACT_FUSED_MAX > 512 ? DDRL_ACT_FUSED_MAX : 512));  // [2 encoders][DDRL_ACT_FUSED_MAX]
   w.wp2b = (unsigned short*)take(2 * 32 * 3 * 64 * 16 / 2);
   w.wp3b = (unsigned short*)take(2 * 8 * 5 * 3 * 64 * 16 / 2);
   w.wd2b = (unsigned short*)take(2 * 2 * 4 * 4 * 3 * 64 * 16 / 2);

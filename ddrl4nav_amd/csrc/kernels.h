@@ -60,11 +60,7 @@ void launch_conv_forward2(const EncCall& c, bool acting, hipStream_t st);
 
 // act.hip: conv1 + conv2 + conv3 of an acting forward in one launch, one workgroup per (sample, encoder); leaves a3 and every sample's
 // largest |a3| (Workspace::actmax), which the dense layer's split launch takes its plane scale from
-#ifdef DDRL_PLANES_BF16
-#define DDRL_ACT_FUSED_MAX 0    // three bf16 planes do not fit the fused kernel's LDS budget: every acting launch takes the batch-tiled kernels
-#elif !defined(DDRL_ACT_FUSED_MAX)
-#define DDRL_ACT_FUSED_MAX 512  // acting launches of at most this many samples (= the capacity of Workspace::actmax per encoder)
-#endif
+// (DDRL_ACT_FUSED_MAX: common.h, next to the carve of Workspace::actmax)
 void launch_act_convs(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad3_2(const EncCall& c, hipStream_t st);
 void launch_conv_dgrad2_2(const EncCall& c, hipStream_t st);
@@ -80,6 +76,8 @@ void launch_reduce_partials(const float* part, int nsplit, int64_t count, int ne
                             int64_t off1, hipStream_t st);
 void launch_clip_adam(const ddrl_config& cfg, const ParamLayout& L, const Workspace& w, float* params,
                       float* grads, float* m, float* v, int64_t step, hipStream_t st);
+void launch_episode_returns(const float* rewards, const uint8_t* dones, int T, int N, float* rsum, float* rep, float* trace,
+                            int* finished, hipStream_t st);
 void launch_gae(const float* values, const float* rewards, const uint8_t* dones, int T, int N,
                 float gamma, float landa, float* adv, float* ret, hipStream_t st);
 void launch_fill_lut(float* lut, hipStream_t st);

@@ -330,6 +330,38 @@ void launch_gae(const float* values, const float* rewards, const uint8_t* dones,
                      ret);
 }
 
+// --------------------------------------------------------------------------------------------
+// Status.update_reward_status (USTC_lab/agent/statistics.py:118-123) over the T steps of a rollout: one lane per env, forward in
+// time, the reference's operation order (sum += r; episode = episode * (1 - d) + sum * d; sum *= (1 - d)); the running sum and the
+// latest finished episode's return persist in rsum / rep between calls
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void episode_returns_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones,
+                                                             int T, int N, float* __restrict__ rsum, float* __restrict__ rep,
+                                                             float* __restrict__ trace, int* __restrict__ finished) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  float s = rsum[n], e = rep[n];
+  int fin = finished ? finished[n] : 0;
+#pragma unroll 8
+  for (int t = 0; t < T; ++t) {
+    const int64_t i = (int64_t)t * N + n;
+    const float d = dones[i] ? 1.0f : 0.0f;
+    const float k = __fsub_rn(1.0f, d);
+    s = __fadd_rn(s, rewards[i]);
+    e = __fadd_rn(__fmul_rn(e, k), __fmul_rn(s, d));
+    s = __fmul_rn(s, k);
+    fin += dones[i] ? 1 : 0;
+    if (trace) trace[i] = e;
+  }
+  rsum[n] = s;
+  rep[n] = e;
+  if (finished) finished[n] = fin;
+}
+void launch_episode_returns(const float* rewards, const uint8_t* dones, int T, int N, float* rsum, float* rep, float* trace,
+                            int* finished, hipStream_t st) {
+  hipLaunchKernelGGL(episode_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, st, rewards, dones, T, N, rsum, rep, trace, finished);
+}
+
 // float32(u8/255.0) table via the function the conv1 loaders use (engine2.h)
 __global__ void fill_lut_kernel(float* lut) { lut[threadIdx.x] = u8_unit(threadIdx.x); }
 void launch_fill_lut(float* lut, hipStream_t st) { hipLaunchKernelGGL(fill_lut_kernel, dim3(1), dim3(256), 0, st, lut); }

@@ -64,12 +64,15 @@ class HotPath:
                                      "ranks sharing a device reduce through torch.distributed" % (
                                          world, torch.cuda.device_count(), tdist.get_backend(process_group)))
             self.comm = RcclComm(tdist.get_rank(process_group), world, group=process_group)
-        # layer-bucketed all-reduce that overlaps the backward: RCCL ranks only (gloo stages through the host)
+        # layer-bucketed all-reduce that overlaps the backward: RCCL ranks only (gloo stages through the host).
+        # OFF by default (DDRL_ALLREDUCE_OVERLAP=1 turns it on): it has never run with two real RCCL ranks, and what it can hide is
+        # one 13.5 MB all-reduce per 24 ms iteration; the flat reduction on the compute stream is the default until a multi-GPU
+        # run has shown bit-identity of the two.
         self._overlap = False
         self._comm_stream = self._comm_done = None
         self._buckets = []
         if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(process_group) > 1 \
-                and os.environ.get("DDRL_ALLREDUCE_OVERLAP", "1") != "0" \
+                and os.environ.get("DDRL_ALLREDUCE_OVERLAP", "0") == "1" \
                 and (self.comm is not None or tdist.get_backend(process_group) == "nccl"):
             self.enable_overlap()
 
@@ -200,8 +203,16 @@ class HotPath:
             check(self.lib.ddrl_grad_allreduce_overlapped(self.ctx, self.comm.h, c_void_p(cs.cuda_stream), _stream()))
             return
         import torch.distributed as tdist
+        # ordering against whatever the compute stream holds at this call; stale bucket events (no ppo_iter since the last
+        # reduction) make the communication stream wait for the compute stream up front (no race, no overlap)
+        fresh = c_int32()
+        check(self.lib.ddrl_grad_buckets_begin(self.ctx, c_void_p(cs.cuda_stream), _stream(), byref(fresh)))
+        last = len(self._buckets) - 1
         for b, ranges in enumerate(self._buckets):
-            check(self.lib.ddrl_grad_bucket_wait(self.ctx, b, c_void_p(cs.cuda_stream)))
+            if fresh.value:
+                check(self.lib.ddrl_grad_bucket_wait(self.ctx, b, c_void_p(cs.cuda_stream)))
+            if b == last:
+                check(self.lib.ddrl_grad_bucket_wait_last(self.ctx, c_void_p(cs.cuda_stream)))
             with torch.cuda.stream(cs):
                 for off, cnt in ranges:
                     tdist.all_reduce(self.grads[off:off + cnt], op=tdist.ReduceOp.SUM, group=self.process_group)

@@ -46,7 +46,9 @@ extern "C" {
 #define DDRL_ERR_TIMEOUT (-6)
 #define DDRL_ERR_NO_MEMORY (-7) /* host allocation of a handle failed */
 
-#define DDRL_ABI_VERSION 1
+/* 2 (round 4): ddrl_op_clip_rmsprop takes alpha as a double; ddrl_encoder_backward consumes dh (rescales its rows in place);
+ * ddrl_debug_buffer 4..7 hold per-sample NORMALISED gradients.  A host built against version 1 must be rebuilt. */
+#define DDRL_ABI_VERSION 2
 #define DDRL_STATS_FLOATS 8 /* tail of the grad arena, see ddrl_ppo_iter */
 
 typedef struct ddrl_ctx ddrl_ctx;
@@ -139,6 +141,14 @@ int32_t ddrl_last_features(ddrl_ctx* ctx, int32_t n, float* h_actor, float* h_cr
 int32_t ddrl_gae(const float* values, const float* rewards, const uint8_t* dones, int32_t T,
                  int32_t N, float gamma, float landa, float* adv, float* ret, void* stream);
 
+/* Status.update_reward_status (USTC_lab/agent/statistics.py:118-123) over the T steps of one rollout, on the device: per env
+ *   rewards_sum += r_t;  rewards_episode = rewards_episode * (1 - d_t) + rewards_sum * d_t;  rewards_sum *= (1 - d_t)
+ * in the reference's operation order.  rewards [T, N], dones uint8 [T, N]; rewards_sum / rewards_episode [N] are read and
+ * written (state across rollouts; zero them once); trace [T, N] (may be NULL) receives rewards_episode after every step;
+ * episodes_finished int32 [N] (may be NULL) is increased by the number of dones. */
+int32_t ddrl_episode_returns(const float* rewards, const uint8_t* dones, int32_t T, int32_t N, float* rewards_sum,
+                             float* rewards_episode, float* trace, int32_t* episodes_finished, void* stream);
+
 /* One iteration of the loss + backward half of PPO.learn (ppo.py:82-126, non-shared branch):
  * forward both encoders on B samples, dual-clip surrogate / value / entropy terms, backward
  * into the grad arena.  Gradients and loss sums are scaled by 1/B_global so that a SUM over
@@ -181,6 +191,13 @@ int32_t ddrl_grad_buckets_enable(ddrl_ctx* ctx);
 int32_t ddrl_grad_bucket_count(const ddrl_ctx* ctx, int32_t* n);
 int32_t ddrl_grad_bucket_info(const ddrl_ctx* ctx, int32_t bucket, int64_t* offsets2, int64_t* counts2, int32_t* n_ranges);
 int32_t ddrl_grad_bucket_wait(ddrl_ctx* ctx, int32_t bucket, void* stream);
+/* Ordering against the compute stream AT THE CALL (round 4).  ddrl_grad_buckets_begin records an event on `compute_stream`;
+ * *fresh = 1 when a ddrl_ppo_iter has recorded every bucket event since the previous reduction.  Otherwise (gradients from
+ * another producer, accumulation, a retried iteration) the bucket events are stale: `comm_stream` is made to wait for the
+ * call-time event at once and the host must NOT rely on ddrl_grad_bucket_wait.  ddrl_grad_bucket_wait_last makes `comm_stream`
+ * wait for the call-time event; hosts issue it in front of the last bucket.  ddrl_grad_allreduce_overlapped does both itself. */
+int32_t ddrl_grad_buckets_begin(ddrl_ctx* ctx, void* comm_stream, void* compute_stream, int32_t* fresh);
+int32_t ddrl_grad_bucket_wait_last(ddrl_ctx* ctx, void* comm_stream);
 int32_t ddrl_grad_allreduce_overlapped(ddrl_ctx* ctx, ddrl_comm* comm, void* comm_stream, void* compute_stream);
 int32_t ddrl_params_broadcast(ddrl_ctx* ctx, ddrl_comm* comm, int32_t root, void* stream);
 

@@ -213,6 +213,112 @@ def test_device_rollout_end_to_end_vs_oracle(net):
     assert torch.equal(ro.frames[0], ro.frames[T])
 
 
+def test_carry_over_keep_step_is_the_references_carry(net, golden):
+    """agent.py:286-292: the whole (T+1)-th step -- frame, action already sent to the env, old log-prob, value under the
+    weights of that moment, reward, done -- becomes step 0 of the next rollout, which then acts from step 1 on.
+    (a) GAE side through the POOL on F2 (two chained rollouts of the reference's own _accumulate_rewards): bit-exact;
+    (b) acting side: act(0) of the next rollout returns the kept action and evaluates nothing."""
+    from ddrl4nav_amd.agent import DeviceRollout
+    g = golden("f2_gae")
+    T, N = 256, 8
+    dev = "cuda"
+    ro = DeviceRollout(net, N, horizon=T, seed=5, track_returns=True)
+    vals, rew, dones = (torch.from_numpy(g[k]).to(dev) for k in ("values", "rewards", "dones"))
+    ro.values.copy_(vals[:T + 1])
+    for t in range(T + 1):               # rows 0..T: the reference stores T+1 steps before it scans (agent.py:272-276)
+        ro.record(t, rew[t], dones[t])
+    ro.finish()
+    assert np.array_equal(ro.adv.cpu().numpy(), g["adv1"]) and np.array_equal(ro.ret.cpu().numpy(), g["ret1"])
+    ro.carry_over(keep_step=True)
+    assert ro.t0 == 1
+    assert torch.equal(ro.values[0], vals[T]) and torch.equal(ro.rewards[0], rew[T]) and torch.equal(ro.dones[0], dones[T])
+    with pytest.raises(ValueError):
+        ro.record(0, rew[T], dones[T])   # slot 0 came with its reward and done
+    ro.values[1:].copy_(vals[T + 1:2 * T + 1])
+    for t in range(1, T + 1):
+        ro.record(t, rew[T + t], dones[T + t])
+    ro.finish()
+    assert np.array_equal(ro.adv.cpu().numpy(), g["adv2"]) and np.array_equal(ro.ret.cpu().numpy(), g["ret2"])
+    # every step entered the episode-return accumulator exactly once (rows 0..T-1 of both rollouts = fixture rows 0..2T-1)
+    tr, rsum = O.episode_returns(g["rewards"][:2 * T], g["dones"][:2 * T])
+    assert np.array_equal(ro.returns.rewards_episode.cpu().numpy(), tr[-1])
+    assert np.array_equal(ro.returns.rewards_sum.cpu().numpy(), rsum)
+
+    # (b) acting side on a short rollout
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+    N, T = 6, 4
+    rng = np.random.default_rng(8)
+    frames = torch.from_numpy(rng.integers(0, 256, size=(2 * T + 1, N, 4, 84, 84), dtype=np.uint8)).to(dev)
+    r = torch.from_numpy(rng.choice(np.array([-1, 0, 1], np.float32), size=(2 * T + 1, N)).astype(np.float32)).to(dev)
+    d = torch.from_numpy((rng.random((2 * T + 1, N)) < 0.3).astype(np.uint8)).to(dev)
+    ro = DeviceRollout(net, N, horizon=T, seed=9)
+    for t in range(T):
+        ro.put_frames(t, frames[t])
+        ro.act(t)
+        ro.record(t, r[t], d[t])
+    ro.put_frames(T, frames[T])
+    a_T = ro.bootstrap().clone()          # the action the host steps the env with
+    ro.record(T, r[T], d[T])
+    ro.finish()
+    kept = [x.clone() for x in (ro.frames[T], ro.values[T], ro._actions[T], ro._logps[T], ro._rewards[T], ro._dones[T])]
+    assert torch.equal(kept[2], a_T)
+    # weights move between the rollouts (an update happened): the kept step must NOT be re-evaluated
+    net.hot_path.params.mul_(1.001)
+    net.hot_path.params_changed()
+    ro.carry_over(keep_step=True)
+    assert torch.equal(ro.act(0), a_T)
+    now = (ro.frames[0], ro.values[0], ro.actions[0], ro.logps[0], ro.rewards[0], ro.dones[0])
+    for a, b in zip(kept, now):
+        assert torch.equal(a, b)
+    for t in range(ro.t0, T):
+        ro.put_frames(t, frames[T + t])
+        ro.act(t)
+        ro.record(t, r[T + t], d[T + t])
+    ro.put_frames(T, frames[2 * T])
+    ro.bootstrap()
+    ro.finish()
+    oadv, oret = O.gae(ro.values.cpu().numpy(), ro.rewards.cpu().numpy(), ro.dones.cpu().numpy())
+    assert np.array_equal(ro.adv.cpu().numpy(), oadv) and np.array_equal(ro.ret.cpu().numpy(), oret)
+    # default carry-over: the frame only, slot 0 is evaluated again under the current weights (DESIGN.md section 7)
+    v0 = ro.values[T].clone()
+    net.hot_path.params.mul_(1.001)
+    net.hot_path.params_changed()
+    ro.carry_over()
+    assert ro.t0 == 0
+    ro.act(0)
+    assert not torch.equal(ro.values[0], v0)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in make_weights(0).items()})
+
+
+def test_episode_returns_device_accumulator_golden_f6(golden):
+    """Status.update_reward_status (statistics.py:118-123) on the device, fed in chunks the way rollouts arrive: the trace and
+    the final running sums of the reference's own Status run (F6), bit for bit."""
+    from ddrl4nav_amd.agent import EpisodeReturns
+    g = golden("f6_returns")
+    r = torch.from_numpy(g["rewards"]).cuda()
+    d = torch.from_numpy(g["dones"].astype(np.uint8)).cuda()
+    Tn, Nn = r.shape
+    acc = EpisodeReturns(Nn, "cuda")
+    trace = torch.empty_like(r)
+    for lo, hi in ((0, 1), (1, 130), (130, 257), (257, Tn)):   # ragged chunks: the state carries across calls
+        acc.update(r[lo:hi].contiguous(), d[lo:hi].contiguous(), trace=trace[lo:hi])
+    assert np.array_equal(trace.cpu().numpy(), g["trace"])
+    assert np.array_equal(acc.rewards_sum.cpu().numpy(), g["final_sum"])
+    assert np.array_equal(acc.rewards_episode.cpu().numpy(), g["trace"][-1])
+    assert np.array_equal(acc.episodes_finished.cpu().numpy(), g["dones"].sum(0).astype(np.int32))
+    # non-integer rewards: against the oracle's restatement (same fp32 operation order)
+    rng = np.random.default_rng(66)
+    r2 = rng.normal(size=(300, 70)).astype(np.float32)
+    d2 = (rng.random((300, 70)) < 0.05).astype(np.uint8)
+    acc2 = EpisodeReturns(70, "cuda")
+    tr2 = torch.empty((300, 70), dtype=torch.float32, device="cuda")
+    acc2.update(torch.from_numpy(r2).cuda(), torch.from_numpy(d2).cuda(), trace=tr2)
+    otr, osum = O.episode_returns(r2, d2.astype(np.float32))
+    assert np.array_equal(tr2.cpu().numpy(), otr) and np.array_equal(acc2.rewards_sum.cpu().numpy(), osum)
+    with pytest.raises(ValueError):
+        acc.update(r[:, :2].contiguous(), d[:, :2].contiguous())
+
+
 def test_pinned_ring_feeds_pool():
     from ddrl4nav_amd.data import PinnedRing
     from ddrl4nav_amd._lib import DdrlError
