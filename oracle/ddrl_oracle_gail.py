@@ -2,8 +2,8 @@
 
 Plain PyTorch-CPU restatement of the reference's discriminator, its WGAN-style update and the PPO update with the
 extra GAIL critic; pinned against golden vectors produced by importing the reference itself
-(tests/golden/make_golden_gail.py -> f16_gail_classical.npz, f17_gail_atari.npz, f18_gae_two_rows.npz; checked in
-tests/test_oracle_golden.py).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this file.
+(tests/golden/make_golden_gail.py -> f16_gail_classical.npz, f17_gail_atari.npz, f18_gae_two_rows.npz;
+tests/golden/make_golden_gail_nav.py -> f22_gail_navped.npz: GAIL over a shared NavPedPreNet; checked in tests/test_oracle_golden.py).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this file.
 
 Reference sites restated (under /root/reference/USTC_lab):
   * nn/GAIL.py:19-71     Discriminator: mlp(GAN_D_MLP_LIST) on cat(pre(state), action)
@@ -46,7 +46,17 @@ class OracleDiscriminator(nn.Module):
 
     def forward(self, x):
         state, action = x
-        return self.mlp_layer(torch.cat((self.pre(state), action), dim=-1))
+        # Test hook (not part of the reference): ``sub_seq`` = one {site: ReLU output} dict per coming forward call of a NAV encoder
+        # (ddrl_oracle_nav._act): the discriminator step runs `pre` twice, on the policy batch and on the expert batch.
+        seq = getattr(self, "sub_seq", None)
+        if seq:
+            self.pre.sub = seq.pop(0)
+        try:
+            h = self.pre(state)
+        finally:
+            if seq is not None:
+                self.pre.sub = None
+        return self.mlp_layer(torch.cat((h, action), dim=-1))
 
 
 class OracleGAIL(nn.Module):

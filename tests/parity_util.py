@@ -258,9 +258,36 @@ def gail_oracle(name):
     g = _load(name)
     hidden = int(g["d_mlp_hidden"])
     spec = [(513, hidden, "relu"), (hidden, 1, None)]
+    if name == "f22_gail_navped":   # shared NavPedPreNet(1 + 3 channels) + CategoricalActor(5): states are a LIST of three arrays
+        return g, G.OracleGAIL(lambda: N.NavPedPreNet(4), 5, False, spec), [g["state0"], g["state1"], g["state2"]], 22
     if name == "f16_gail_classical":
         return g, G.OracleGAIL(lambda: N.MLPPreNet(4, 512), 2, False, spec), g["states"], 16
     return g, G.OracleGAIL(lambda: G.AtariPre(4), 6, False, spec), O.u8_lut()[_load("f3_loss")["frames"]], 17
+
+
+def gail_state_lists(g, states_np):
+    """(policy-batch states, expert-batch states) of a GAIL fixture as lists of arrays: F16 / F17 draw the expert batch from the
+    policy batch's own states (expert_index, reversed), F22 stores it."""
+    if isinstance(states_np, (list, tuple)):
+        return list(states_np), [g["expert_state%d" % i] for i in range(len(states_np))]
+    return [states_np], [states_np[g["expert_index"]][::-1].copy()]
+
+
+def relu_outputs_of(e, n):
+    """{site: ReLU output of the latest forward} of ONE operator-composed encoder (nn/generic.py): what oracle_nav._act substitutes
+    so that the float64 yardstick takes the kernels' ReLU / max-pool decisions."""
+    d = {}
+    for site in ("c1", "c2", "c3"):
+        if hasattr(e, site):
+            d["conv" + site[1]] = getattr(e, site).a[:n].detach().cpu().clone()
+    if hasattr(e, "cat"):       # the nav tails: fc0 writes its ReLU output into the cat buffer, fc1 into f1
+        d["fc0"] = e.cat[:n, e.extra:e.extra + 512].detach().cpu().clone()
+        d["fc1"] = e.f1[:n].detach().cpu().clone()
+        if e.extra:             # NavPreNet1D: fc_1d -> cat[:, 0:256]
+            d["fc_1d"] = e.cat[:n, :e.extra].detach().cpu().clone()
+    else:                       # MLPPreNet: h = relu(fc0)
+        d["fc0"] = e.h[:n].detach().cpu().clone()
+    return d
 
 
 _GTRAJ = {}
@@ -282,8 +309,9 @@ def gail_f64_trajectory(name, d_forced=None):
     net.load_weights(w)
     net.double()
     t = lambda k: torch.from_numpy(g[k]).double()
-    states = [torch.from_numpy(states_np).double()]
-    ex_states = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy()).double()]
+    st_np, ex_np = gail_state_lists(g, states_np)
+    states = [torch.from_numpy(a).double() for a in st_np]
+    ex_states = [torch.from_numpy(a).double() for a in ex_np]
     threads = torch.get_num_threads()
     torch.set_num_threads(min(8, max(1, os.cpu_count() or 1)))
     snaps, d_loss, losses = {}, [], []
@@ -324,8 +352,10 @@ class GailStepper:
         self.G, self.net, self.w = G, net, w
         self.p0 = {k: np.asarray(v, np.float64) for k, v in w.items()}
         t = lambda k: torch.from_numpy(g[k]).double()
-        self.states = [torch.from_numpy(states_np).double()]
-        self.ex_states = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy()).double()]
+        st_np, ex_np = gail_state_lists(g, states_np)
+        self.states = [torch.from_numpy(a).double() for a in st_np]
+        self.ex_states = [torch.from_numpy(a).double() for a in ex_np]
+        self.nav = isinstance(states_np, (list, tuple))   # nav encoders take {site: ReLU output} dicts, Atari ones sign triples
         self.batch = (t("actions"), t("old_logps"), t("advs"), t("rets"))
         self.expert_actions = t("expert_actions")
         self.g_optim, self.d_optim, self.d_sched = net.make_optims()
@@ -337,11 +367,15 @@ class GailStepper:
         pre, old = self.net.discriminator.pre, torch.get_num_threads()
         torch.set_num_threads(self._threads())
         try:
-            if forced_seq is not None:
+            if forced_seq is not None and self.nav:
+                self.net.discriminator.sub_seq = list(forced_seq)
+            elif forced_seq is not None:
                 pre.forced_seq, pre._forward_calls = forced_seq, 0
             item, _, _ = self.G.d_step(self.net, self.d_optim, self.d_sched, self.states, self.batch[0], self.ex_states, self.expert_actions)
         finally:
-            if forced_seq is not None:
+            if forced_seq is not None and self.nav:
+                self.net.discriminator.sub_seq = None
+            elif forced_seq is not None:
                 pre.forced_seq = pre.forced = None
             torch.set_num_threads(old)
         return item["Gail[D]Loss"]
@@ -350,11 +384,15 @@ class GailStepper:
         pre, old = self.net.generator.prenet, torch.get_num_threads()
         torch.set_num_threads(self._threads())
         try:
-            if forced is not None:
+            if forced is not None and self.nav:
+                pre.sub = forced
+            elif forced is not None:
                 pre.forced = forced
             ld, _, _ = self.G.g_step(self.net, self.g_optim, self.states, *self.batch)
         finally:
-            if forced is not None:
+            if forced is not None and self.nav:
+                pre.sub = None
+            elif forced is not None:
                 pre.forced = None
             torch.set_num_threads(old)
         return [ld[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")]

@@ -109,23 +109,9 @@ def test_generic_net_forward_loss_gradients_golden(golden, name):
 
 
 def _relu_outputs(net, n):
-    """[{site: ReLU output of the latest forward}] per encoder of a GenericPPO, in the oracle's encoder order: what
-    oracle_nav._act substitutes so that the float64 yardstick takes the kernels' ReLU / max-pool decisions."""
-    out = []
-    for e in net._encs:
-        d = {}
-        for site in ("c1", "c2", "c3"):
-            if hasattr(e, site):
-                d["conv" + site[1]] = getattr(e, site).a[:n].detach().cpu().clone()
-        if hasattr(e, "cat"):       # the nav tails: fc0 writes its ReLU output into the cat buffer, fc1 into f1
-            d["fc0"] = e.cat[:n, e.extra:e.extra + 512].detach().cpu().clone()
-            d["fc1"] = e.f1[:n].detach().cpu().clone()
-            if e.extra:             # NavPreNet1D: fc_1d -> cat[:, 0:256]
-                d["fc_1d"] = e.cat[:n, :e.extra].detach().cpu().clone()
-        else:                       # MLPPreNet: h = relu(fc0)
-            d["fc0"] = e.h[:n].detach().cpu().clone()
-        out.append(d)
-    return out
+    """[{site: ReLU output of the latest forward}] per encoder of a GenericPPO, in the oracle's encoder order."""
+    import parity_util as P
+    return [P.relu_outputs_of(e, n) for e in net._encs]
 
 
 @pytest.mark.parametrize("name", CASES)

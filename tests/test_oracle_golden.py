@@ -308,7 +308,10 @@ def _gail_case(name, golden):
     from oracle import ddrl_oracle_nav as N
     g = golden(name)
     hidden = int(g["d_mlp_hidden"])
-    if name == "f16_gail_classical":
+    if name == "f22_gail_navped":
+        net = G.OracleGAIL(lambda: N.NavPedPreNet(4), 5, False, [(513, hidden, "relu"), (hidden, 1, None)])
+        states_np, seed = [g["state0"], g["state1"], g["state2"]], 22
+    elif name == "f16_gail_classical":
         net = G.OracleGAIL(lambda: N.MLPPreNet(4, 512), 2, False, [(513, hidden, "relu"), (hidden, 1, None)])
         states_np, seed = g["states"], 16
     else:
@@ -317,10 +320,11 @@ def _gail_case(name, golden):
     return g, net, states_np, seed
 
 
-@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])
+@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari", "f22_gail_navped"])
 def test_gail_oracle_pinned_to_reference(golden, name):
     """Discriminator forward / WGAN step / StepLR and the PPO update with the extra GAIL critic, against the
-    reference's own GAIL.learn (tests/golden/make_golden_gail.py)."""
+    reference's own GAIL.learn (tests/golden/make_golden_gail.py; F22, a shared NavPedPreNet: make_golden_gail_nav.py)."""
+    import parity_util as P
     from ddrl4nav_amd.utils.recipe import hash_weights
     from oracle import ddrl_oracle_gail as G
     g, net, states_np, seed = _gail_case(name, golden)
@@ -329,8 +333,8 @@ def test_gail_oracle_pinned_to_reference(golden, name):
     w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
     net.load_weights(w)
     t = lambda k: torch.from_numpy(g[k])
-    states = [torch.from_numpy(states_np)]
-    ex_states = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy())]
+    st_np, ex_np = P.gail_state_lists(g, states_np)
+    states, ex_states = [torch.from_numpy(a) for a in st_np], [torch.from_numpy(a) for a in ex_np]
     with torch.no_grad():
         probs, logp, _, values = net(states, t("actions"))
         dr = net.d_reward(states, t("actions"))
@@ -381,7 +385,7 @@ def test_gae_two_value_rows_bit_exact(golden):
     assert np.array_equal(adv, g["adv"]) and np.array_equal(ret, g["ret"])
 
 
-@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])
+@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari", "f22_gail_navped"])
 def test_gail_oracle_float64_trajectory_pinned(name):
     """The float64 trajectory the GPU GAIL tests measure against == the reference's own float64 GAIL.learn."""
     import parity_util as P
