@@ -40,6 +40,9 @@ def _act(net, key, z):
     still flows into z.  Downstream max-pools then route by a_k, i.e. every ReLU / max-pool DECISION of the backward is the other
     implementation's (an activation within fp32 noise of a decision boundary comes out on either side depending on the summation
     order; one such flip moves every conv-weight gradient upstream of it by ~1e-3 of its size), the arithmetic stays the oracle's."""
+    rec = getattr(net, "record", None)
+    if rec is not None:          # test hook: the pre-activations of this forward, for the "decisions differ only within fp32 noise" checks
+        rec[key] = z.detach()
     sub = getattr(net, "sub", None)
     if sub is None or key not in sub:
         return F.relu(z)

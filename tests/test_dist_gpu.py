@@ -4,7 +4,8 @@ the F4 batch.  Asserted: every rank ends every iteration with bit-identical para
 sharded run obeys the SAME bounds against the reference's trajectory as the single-rank run (section 8e's
 "the F4 fixture split N ways must match the 1-GPU result within the stated tolerance"), for even, uneven
 (40/24), 4-way and ragged 5-way splits (the GPU boxes admit at most six processes on the card at once: five ranks + the
-test runner; more ranks than that are covered on the CPU by tests/test_surface_cpu.py).  The children are started as
+test runner); the 8-way split of BASELINE config 3 runs as eight contexts inside one process
+(test_f4_split_eight_ways_in_process), eight gloo ranks on the CPU in tests/test_surface_cpu.py.  The children are started as
 ordinary child processes (never exec'd over a process that has touched the GPU)."""
 import os
 import socket
@@ -76,6 +77,68 @@ def test_sharded_learn_matches_reference_trajectory(tmp_path, golden, tag, bound
         return next(rows)
 
     P.check_sequence("learn_f4_sharded", "default", step, lambda: r0["params_it%d" % state["it"]], ref, env)
+
+
+def test_f4_split_eight_ways_in_process(golden):
+    """SURVEY.md section 8e's own parity statement -- "the F4 fixture split 8 ways must match the 1-GPU result" (BASELINE config 3 = 8
+    ranks; reference: USTC_lab/server/backward.py:167 is a TODO) -- without eight processes (the GPU boxes admit six on a card):
+    eight contexts of 8 samples each in ONE process, every one scaling by 1 / B_global = 1 / 64; their gradient arenas + loss
+    tails are summed in rank order (what the SUM all-reduce hands every rank), written back to all eight, and every context runs
+    its own clip + Adam.  (1) the summed gradient equals the one-context full-batch gradient to 2e-6 max|g| per tensor;
+    (2) the eight replicas stay bit-identical over ten iterations; (3) the trajectory obeys the single-rank bounds against the
+    reference (losses inside the envelope, parameters inside the reference's own fp32 cloud)."""
+    import torch
+    import parity_util as P
+    from ddrl4nav_amd.engine import HotPath
+    from ddrl4nav_amd.utils.recipe import flatten, make_weights, param_specs
+    frames, actions, old_logps, advs, rets = P.mode_batch("default")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    W, B = 8, 64
+    per = B // W
+    ranks = []
+    for r in range(W):
+        h = HotPath(max_batch=per)
+        h.set_params(flatten(make_weights(0)))
+        sl = slice(r * per, (r + 1) * per)
+        ranks.append((h, (d(frames[sl]), d(actions[sl]), d(old_logps[sl]), d(advs[sl]), d(rets[sl]))))
+    full = HotPath(max_batch=B)
+    full.set_params(flatten(make_weights(0)))
+    full.ppo_iter(d(frames), d(actions), d(old_logps), d(advs), d(rets))
+    want = full.grads.clone()
+    full.close()
+    g4 = golden("f4_learn")
+    ref = g4["losses"]
+    env = P.mode_loss_envelope("default", ref, g4["losses_f64"], g4["losses_f32t8"])
+    state = {"it": 0}
+
+    def step():
+        state["it"] += 1
+        total = None
+        for h, args in ranks:
+            h.ppo_iter(*args, b_global=B)
+            total = h.grads.clone() if total is None else total + h.grads     # fixed order: rank 0 + rank 1 + ...
+        if state["it"] == 1:
+            off = 0
+            for name, shape, _ in param_specs():
+                n = int(np.prod(shape))
+                a, b = total[off:off + n], want[off:off + n]
+                assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), name
+                off += n
+            np.testing.assert_allclose(total[off:off + 3].cpu().numpy(), want[off:off + 3].cpu().numpy(), rtol=1e-5, atol=1e-7)
+        for h, _ in ranks:
+            h.grads.copy_(total)
+            h.clip_adam_step()
+        p0 = ranks[0][0].params
+        for h, _ in ranks[1:]:
+            assert torch.equal(h.params, p0)                                   # replicas: bit-identical
+        s = ranks[0][0].stats()
+        return [s["PpoTotalLoss"], s["ActorLoss"], s["VLoss"], s["EntLoss"]]
+
+    try:
+        P.check_sequence("learn_f4_sharded", "default", step, lambda: ranks[0][0].params.cpu().numpy(), ref, env)
+    finally:
+        for h, _ in ranks:
+            h.close()
 
 
 @pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])

@@ -1,5 +1,6 @@
 """GPU tests of the GAIL path (BASELINE config 5) against golden vectors produced by the
-reference's own GAIL / Discriminator / PPO objects (tests/golden/make_golden_gail.py: F16 classical, F17 Atari, F18 GAE)
+reference's own GAIL / Discriminator / PPO objects (tests/golden/make_golden_gail.py: F16 classical, F17 Atari, F18 GAE;
+make_golden_gail_nav.py: F22 = config 5's "nav env + discriminator", a shared NavPedPreNet under generator and discriminator)
 and the pinned oracle (oracle/ddrl_oracle_gail.py).  Everything goes through the drop-in surface:
 create_net(NETWORK_TYPE="gail") -> GAIL.forward / GAIL.learn -> the HIP operators behind include/ddrl.h."""
 import types
@@ -12,30 +13,41 @@ from ddrl4nav_amd.utils.recipe import hash_weights
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["f16_gail_classical", "f17_gail_atari"]
+CASES = ["f16_gail_classical", "f17_gail_atari", "f22_gail_navped"]
 
 
 def _net(name, golden, max_batch=256):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
     g = golden(name)
+    task = None
     if name == "f16_gail_classical":
         env = {"env_type": "gym", "env_name": "CartPole-v1", "env_num": 8, "discrete_action": True, "discrete_actions": [0, 1],
                "input_dim": 4}
-        states = g["states"]
+        states = [g["states"]]
         seed = 16
+    elif name == "f22_gail_navped":   # robot_nav with a pedestrian map (runner/utils.py:88-102) + the gail branch (:161-168)
+        env = {"env_type": "robot_nav", "env_name": "robot_nav", "env_num": 8, "discrete_action": True, "discrete_actions": list(range(5)),
+               "image_batch": 1, "ped_sim": {"total": 3}}
+        states = [g["state0"], g["state1"], g["state2"]]
+        seed, task = 22, "robot_nav"
     else:
         env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "int_frame_stack": 4, "discrete_action": True,
                "discrete_actions": list(range(6))}
-        states = golden("f3_loss")["frames"]      # uint8; the reference fixture saw float32(u8 / 255.0)
+        states = [golden("f3_loss")["frames"]]      # uint8; the reference fixture saw float32(u8 / 255.0)
         seed = 17
     cfg = BaseConfig(types.SimpleNamespace(task="gail", ip="127.0.0.1"), env)
+    if task:
+        cfg.TASK_TYPE = task
     cfg_nn = ConfigNN(env)
     cfg_nn.NETWORK_TYPE, cfg_nn.SHARE_CNN_NET = "gail", True
     hidden = int(g["d_mlp_hidden"])
     cfg.GAN_D_MLP_LIST = [(512 + cfg.ACTIONS_DIM, hidden, "relu"), (hidden, 1, None)]
-    ex_states = states[g["expert_index"]][::-1].copy()
-    expert = [(ex_states[None], g["expert_actions"])]       # the reference-shaped batch: states [1, n, ...]
+    if name == "f22_gail_navped":
+        expert = [([g["expert_state0"], g["expert_state1"], g["expert_state2"]], g["expert_actions"])]   # a LIST of components
+    else:
+        ex_states = states[0][g["expert_index"]][::-1].copy()
+        expert = [(ex_states[None], g["expert_actions"])]       # the reference-shaped batch: states [1, n, ...]
     net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=max_batch, expert_data=expert)
     assert [k for k, _ in net.named_parameters()] == list(g["names"])   # reference module tree / blob order
     w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
@@ -53,20 +65,20 @@ def test_gail_forward_two_critics_and_discriminator_reward(golden, name):
     g, net, states, _ = _net(name, golden)
     B = len(g["actions"])
     acts = torch.from_numpy(g["actions"])
-    (dist, logp), values = net([states], acts)
+    (dist, logp), values = net(states, acts)
     assert len(values) == 2 and values[0].shape == (B, 1) and values[1].shape == (B, 1)
     np.testing.assert_allclose(values[0].cpu().numpy()[:, 0], g["value0"], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(values[1].cpu().numpy()[:, 0], g["value1"], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=2e-5, atol=2e-6)
-    (probs, _), _ = net([states], None, True)
+    (probs, _), _ = net(states, None, True)
     np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=2e-5, atol=2e-6)
     # forward.py:159-165: D_rewards = net((batch_states, actions.reshape(n, action_dim)))[:, 0]
-    d = net(([states], acts.reshape(B, 1)))
+    d = net((states, acts.reshape(B, 1)))
     assert d.shape == (B, 1)
     np.testing.assert_allclose(d.cpu().numpy()[:, 0], g["d_reward"], rtol=2e-5, atol=2e-6)
     # micro-batched evaluation gives the same scores
     net.discriminator.cap, cap = 48, net.discriminator.cap
-    d2 = net(([states], acts.reshape(B, 1)))
+    d2 = net((states, acts.reshape(B, 1)))
     net.discriminator.cap = cap
     assert torch.equal(d, d2)
 
@@ -85,26 +97,39 @@ def _enc_signs(pre, n):
 
 
 def _d_decisions(net, name, g, states, w):
-    """Leaky-ReLU decisions of the discriminator's Atari encoder on the policy batch and on the expert batch (the two forwards of
-    one discriminator step), read from the kernel's activations; None for an MLP encoder.  Checked against the fp32 oracle's
-    pre-activations: at most 8 decisions per layer differ, all with |z| < 2e-5 (fp32 noise of zero)."""
+    """ReLU / leaky-ReLU / max-pool decisions of the discriminator's encoder on the policy batch and on the expert batch (the two
+    forwards of one discriminator step), read from the kernels' activations: sign triples for the Atari encoder, {site: ReLU
+    output} dicts for a nav encoder; None for an MLP encoder.  Checked against the fp32 oracle's pre-activations: at most 8
+    decisions per layer differ, all with |z| < 2e-5 (fp32 noise of zero)."""
     import parity_util as P
-    from oracle import ddrl_oracle as O
     D = net.discriminator
-    if not hasattr(D.pre, "_ctx"):
+    atari, nav = hasattr(D.pre, "_ctx"), hasattr(D.pre, "cat")
+    if not (atari or nav):
         return None
-    ex_states = states[g["expert_index"]][::-1].copy()
     acts = torch.from_numpy(g["actions"]).reshape(-1, 1)
     _, onet, states_np, _ = P.gail_oracle(name)
     onet.load_weights(w)
     enc = onet.discriminator.pre
+    st_np, ex_np = P.gail_state_lists(g, states_np)
+    _, ex_dev = P.gail_state_lists(g, states if nav else states[0])       # what the HIP path is fed (uint8 frames for Atari)
     seq = []
-    for st, st_np, a in ((states, states_np, acts), (ex_states, states_np[g["expert_index"]][::-1].copy(), torch.from_numpy(g["expert_actions"]))):
-        net(([st], a))                       # D forward with the step's weights: same kernels, same decisions as in learn()
-        signs = _enc_signs(D.pre, st.shape[0])
-        with torch.no_grad():
-            enc([torch.from_numpy(st_np)])
-        for k, (pos, z) in enumerate(zip(signs, enc.last_z)):
+    for st, st_o, a in ((states, st_np, acts), (ex_dev, ex_np, torch.from_numpy(g["expert_actions"]))):
+        net((st, a))                         # D forward with the step's weights: same kernels, same decisions as in learn()
+        n = st[0].shape[0]
+        if atari:
+            signs = _enc_signs(D.pre, n)
+            with torch.no_grad():
+                enc([torch.from_numpy(x) for x in st_o])
+            pairs = list(zip(signs, enc.last_z))
+        else:
+            signs = P.relu_outputs_of(D.pre, n)
+            enc.record = {}
+            with torch.no_grad():
+                enc([torch.from_numpy(x) for x in st_o])
+            pairs = [(signs[k].reshape(z.shape) > 0, z) for k, z in enc.record.items()]
+            enc.record = None
+            assert len(pairs) == 5   # conv1-3, fc0, fc1
+        for k, (pos, z) in enumerate(pairs):
             differ = pos != (z > 0)
             assert int(differ.sum()) <= 8, (k, int(differ.sum()))
             if differ.any():
@@ -123,7 +148,7 @@ def test_discriminator_gradient_vs_float64_oracle(golden, name):
     from ddrl4nav_amd.data import Experience
     g, net, states, w = _net(name, golden)
     forced = _d_decisions(net, name, g, states, w)
-    exp = Experience(states=[states], advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
+    exp = Experience(states=states, advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
     D = net.discriminator
     next(D.learn(exp))
     st = D.stats()
@@ -131,11 +156,13 @@ def test_discriminator_gradient_vs_float64_oracle(golden, name):
     onet.load_weights(w)
     onet.double()
     Dn = onet.discriminator
-    if forced is not None:
+    if forced is not None and isinstance(forced[0], dict):
+        Dn.sub_seq = list(forced)
+    elif forced is not None:
         Dn.pre.forced_seq = forced
     t = lambda k: torch.from_numpy(g[k]).double()
-    s = [torch.from_numpy(states_np).double()]
-    ex = [torch.from_numpy(states_np[g["expert_index"]][::-1].copy()).double()]
+    st_np, ex_np = P.gail_state_lists(g, states_np)
+    s, ex = [torch.from_numpy(a).double() for a in st_np], [torch.from_numpy(a).double() for a in ex_np]
     loss = torch.mean(Dn((s, t("actions").reshape(-1, 1)))) - torch.mean(Dn((ex, t("expert_actions"))))
     loss.backward()
     gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in Dn.parameters())))
@@ -166,9 +193,9 @@ def test_gail_learn_matches_reference(golden, name):
     # hundreds of conv weight-gradient elements by a few 1e-3, and the sign-like first RMSprop / Adam steps turn that into
     # flipped updates): _d_decisions checks that those decisions are within 2e-5 of the oracle's own.
     forced = _d_decisions(net, name, g, states, w)
-    atari = forced is not None
+    atari, nav = forced is not None and not isinstance(forced[0], dict), forced is not None and isinstance(forced[0], dict)
     ora = P.GailStepper(name)
-    exp = Experience(states=[states], advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
+    exp = Experience(states=states, advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
     tag = "gail_" + name[:3]
     env = P.loss_envelope(g["losses"], g["losses_f64"], g["losses_f32t8"], g["losses_perm"])
     B = len(g["actions"])
@@ -188,7 +215,8 @@ def test_gail_learn_matches_reference(golden, name):
         it = len(rows)
         assert update_time == it
         # the generator's shared prenet holds this iteration's activations: its decisions for the yardstick's iteration
-        l64 = np.asarray(ora.g_step(_enc_signs(net.generator.prenet, B) if atari else None))
+        l64 = np.asarray(ora.g_step(_enc_signs(net.generator.prenet, B) if atari else
+                                    P.relu_outputs_of(net.generator.prenet, B) if nav else None))
         row = g["losses"][it - 1] if it == 1 else l64     # iteration 1 (nothing stepped yet): the reference's stored value
         excess = np.abs(np.asarray(rows[-1]) - row) - (1e-5 * np.abs(row) + 2e-6)
         P.MARGINS.check(tag, "loss_env", max(0.0, float(np.max(excess / np.maximum(env[it - 1], 1e-12)))), "(iteration %d)" % it)
@@ -210,7 +238,7 @@ def test_discriminator_260_steps_cross_the_steplr_boundary(golden):
     import parity_util as P
     from ddrl4nav_amd.data import Experience
     g, net, states, _ = _net("f16_gail_classical", golden)
-    exp = Experience(states=[states], advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
+    exp = Experience(states=states, advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
     D = net.discriminator
     ref, ref64 = g["d_only_loss"], g["d_only_loss_f64"]
     env = np.maximum.accumulate(np.abs(ref - ref64)) + 1e-9

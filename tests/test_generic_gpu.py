@@ -256,6 +256,86 @@ def test_nav_config4_batch_properties():
         assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
 
 
+def test_nav_config4_at_size_512_envs_x_256_steps():
+    """BASELINE config 4 AT ITS SIZE (robot_nav, 512 envs, TIME_MAX 256: 131,072 samples, 4.1 GB of fp32 observations in the device
+    pool): StateRollout acting over all 256 steps + bootstrap + GAE, then net.learn on the whole rollout in micro-batches.
+    (1) acting at n = 512 against the nav ORACLE on one 512-env step (values, mu, log-prob of the drawn actions);
+    (2) the stored values / log-probs equal a fresh evaluation of the stored actions (a late and an early step);
+    (3) GAE over [256, 512] equals the oracle scan bit for bit;
+    (4) learner on the full batch: micro-batched in 32 chunks of 4,096 == in 16 chunks of 8,192 (loss terms and gradient direction);
+    (5) duplication: the first 65,536 samples twice == once; (6) position independence of the forward."""
+    from ddrl4nav_amd.agent import StateRollout
+    from ddrl4nav_amd.data import Experience
+    from oracle import ddrl_oracle as O
+    from oracle import ddrl_oracle_nav as N
+    NE, T = 512, 256
+    B = NE * T
+    net, w = _make("f13_nav1d_gauss", max_batch=4096)
+    shapes = [(1, 960), (5,), (3, 48, 48)]
+    gen = torch.Generator(device="cuda").manual_seed(4004)
+    ro = StateRollout(net, NE, shapes, horizon=T)
+    # observations of all 257 steps straight into the pool (the synthetic env costs nothing, as in bench.py)
+    for t0 in range(0, T + 1, 32):
+        t1 = min(T + 1, t0 + 32)
+        ro.states[0][t0:t1] = torch.rand((t1 - t0, NE) + shapes[0], device="cuda", generator=gen)
+        ro.states[1][t0:t1] = torch.randn((t1 - t0, NE) + shapes[1], device="cuda", generator=gen)
+        ro.states[2][t0:t1] = (torch.rand((t1 - t0, NE) + shapes[2], device="cuda", generator=gen) < 0.15).float()
+    rew = (torch.rand((T, NE), device="cuda", generator=gen) < 0.02).float() - (torch.rand((T, NE), device="cuda", generator=gen) < 0.02).float()
+    done = (torch.rand((T, NE), device="cuda", generator=gen) < 1 / 200).to(torch.uint8)
+    for t in range(T):
+        a = ro.act(t)
+        ro.record(t, rew[t], done[t])
+    assert a.shape == (NE, 2)
+    ro.bootstrap()
+    ro.finish()
+    assert bool(torch.isfinite(ro.values).all()) and bool(torch.isfinite(ro.logps).all())
+    # (1) one 512-env acting step against the oracle
+    t_chk = 131
+    onet = N.OracleNet(lambda: N.NavPreNet1D(3), 2, True, False)
+    onet.load_weights(w)
+    st = [p[t_chk].cpu() for p in ro.states]
+    with torch.no_grad():
+        mu, logp, _, ov = onet(st, ro.actions[t_chk].cpu())
+    np.testing.assert_allclose(ro.values[t_chk].cpu().numpy(), ov.numpy()[:, 0], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ro.logps[t_chk].cpu().numpy(), logp.numpy(), rtol=2e-5, atol=2e-5)
+    # (2) stored values / log-probs == a fresh evaluation of the stored actions
+    for t in (3, 250):
+        (_, lp), v = net([p[t] for p in ro.states], ro.actions[t])
+        assert torch.allclose(lp, ro.logps[t], rtol=1e-5, atol=1e-5) and torch.equal(v[0][:, 0], ro.values[t])
+    # (3) GAE
+    adv, ret = O.gae(ro.values.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy())
+    assert np.array_equal(ro.adv.cpu().numpy(), adv) and np.array_equal(ro.ret.cpu().numpy(), ret)
+    exp = ro.batch()
+    assert len(exp) == B and exp.states[2].shape == (B, 3, 48, 48) and exp.actions.shape == (B, 2)
+    # (6) position independence of the forward: the same 300 observations at two places of a 4,096-sample forward
+    big = [torch.cat([s[:300], s[5000:5000 + 3496], s[:300]]) for s in exp.states]
+    (d_big, _), v_big = net(big, None, True)
+    assert torch.equal(v_big[0][:300], v_big[0][-300:]) and torch.equal(d_big[:300], d_big[-300:])
+    # (4) micro-batching and (5) duplication, one iteration each from the same weights
+    runs = {}
+    half = B // 2
+    dup = lambda x: torch.cat([x[:half], x[:half]])
+    cases = (("32x4096", 4096, exp),
+             ("16x8192", 8192, exp),
+             ("half", 4096, Experience(states=[s[:half] for s in exp.states], advs=exp.advs[:half], actions=exp.actions[:half],
+                                       old_logps=exp.old_logps[:half], values=exp.values[:, :half])),
+             ("half_twice", 4096, Experience(states=[dup(s) for s in exp.states], advs=dup(exp.advs), actions=dup(exp.actions),
+                                             old_logps=dup(exp.old_logps), values=torch.cat([exp.values[:, :half]] * 2, dim=1))))
+    for tag, cap, e in cases:
+        n2, _ = (net, None) if cap == 4096 and tag == "32x4096" else _make("f13_nav1d_gauss", max_batch=cap)
+        n2.training_iter_time = 1
+        losses = [l for l, _, _ in n2.learn(e)][0]
+        gflat = n2.grads[:n2.n_params].clone()
+        runs[tag] = (losses, gflat / gflat.norm())     # clip_adam scales .grad in place by the clip coefficient: compare directions
+        assert all(np.isfinite(losses[k]) for k in ("ActorLoss", "VLoss", "EntLoss", "PpoTotalLoss"))
+    for a, b in (("32x4096", "16x8192"), ("half", "half_twice")):
+        la, ga = runs[a]
+        lb, gb = runs[b]
+        assert (ga - gb).abs().max().item() <= 2e-4 * ga.abs().max().item(), (a, b)
+        for k in ("ActorLoss", "VLoss", "EntLoss"):
+            assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(la[k])), (a, b, k)
+
+
 def test_state_rollout_loop_matches_manual_sequence(golden):
     """StateRollout (device-resident pool for list-of-tensor observations): acting, bootstrap, GAE and the
     learner batch equal the same steps done by hand; one learn() on its batch runs."""

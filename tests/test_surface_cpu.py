@@ -105,22 +105,23 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gloo_world2_gradient_allreduce_equals_full_batch():
-    """world_size 2 on CPU: shard the batch, scale by 1/B_global, SUM all-reduce the flat arena ->
-    the full-batch gradient and loss means (the N>1 path of bench.py / PPO.learn)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_world2_gradient_allreduce_equals_full_batch(world):
+    """world_size 2 and 8 (BASELINE config 3's rank count) on CPU: shard the batch, scale by 1/B_global, SUM all-reduce the flat
+    arena -> the full-batch gradient and loss means (the N>1 path of bench.py / PPO.learn)."""
     import torch.multiprocessing as mp
     from oracle import ddrl_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert outs[0][1] == 16 and np.array_equal(outs[0][2], outs[1][2])  # replicas agree bit for bit
+    assert outs[0][1] == 16 and all(np.array_equal(outs[0][2], o[2]) for o in outs[1:])  # replicas agree bit for bit
     g = np.load(os.path.join(GOLDEN, "f3_loss.npz"))
     torch.set_num_threads(1)
     net = O.OraclePPO()

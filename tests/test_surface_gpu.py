@@ -319,6 +319,136 @@ def test_episode_returns_device_accumulator_golden_f6(golden):
         acc.update(r[:, :2].contiguous(), d[:, :2].contiguous())
 
 
+def test_chained_rollout_gae_learn_config1_shape():
+    """BASELINE config 1's shape (8 envs, TIME_MAX 256, TRAINING_ITER_TIME 10) END TO END: 256 acting steps + bootstrap on the device
+    pool -> GAE -> ten PPO iterations on the 2,048 samples, against the oracle running the SAME chain on the same frames with the
+    actions the HIP sampler drew (forward.py:128-149 -> agent.py:124-140 -> ppo.py:77-146).
+    Acting and GAE: single-step tolerances.  The ten-iteration trajectory: deviation from the oracle's float64 chain as a ratio to
+    the spread of the oracle's own fp32 chains around it (in order, another batch order, two runs with every parameter perturbed
+    by <= 4 fp32 roundings before each forward -- what "another fp32 evaluation of the reference" looks like).  Fixed limits:
+    losses 2.0 x that envelope beyond the single-step tolerance, parameters 1.5 x (L2 / max / direction)."""
+    import parity_util as P
+    from ddrl4nav_amd.agent import DeviceRollout
+    from ddrl4nav_amd.runner import create_net
+    N, T, ITERS = 8, 256, 10
+    B = N * T
+    net = create_net(_configs(), max_batch=B)
+    w = make_weights(0)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    rng = np.random.default_rng(256)
+    frames = rng.integers(0, 256, size=(T + 1, N, 4, 84, 84), dtype=np.uint8)
+    frames[::5] = (frames[::5] // 64) * 64                      # some low-entropy frames
+    rewards = rng.choice(np.array([-1, 0, 1], np.float32), p=[0.05, 0.9, 0.05], size=(T, N)).astype(np.float32)
+    dones = (rng.random((T, N)) < 1 / 60).astype(np.uint8)
+    ro = DeviceRollout(net, N, horizon=T, seed=77, track_returns=True)
+    fr = torch.from_numpy(frames).cuda()
+    r_dev, d_dev = torch.from_numpy(rewards).cuda(), torch.from_numpy(dones).cuda()
+    for t in range(T):
+        ro.put_frames(t, fr[t])
+        ro.act(t)
+        ro.record(t, r_dev[t], d_dev[t])
+    ro.put_frames(T, fr[T])
+    ro.bootstrap()
+    ro.finish()
+    acts = ro.actions.cpu().numpy()
+    x_all = O.frames_to_f32(frames.reshape(-1, 4, 84, 84))
+    a_t = torch.from_numpy(acts.reshape(-1))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, max(1, (__import__("os").cpu_count() or 1))))
+
+    def chain(dtype, order=None, noise_seed=None):
+        """The reference's chain in `dtype`: values / log-probs of the given actions, GAE, ten learn iterations."""
+        onet = O.OraclePPO()
+        onet.load_weights(w)
+        onet.to(dtype)
+        gen = None if noise_seed is None else torch.Generator().manual_seed(noise_seed)
+
+        def perturb():
+            if gen is not None:
+                with torch.no_grad():
+                    for p in onet.parameters():
+                        p.mul_(1 + (torch.randint(0, 2, p.shape, generator=gen).to(p.dtype) * 2 - 1) * 4.0 * 2.0 ** -24)
+        perturb()
+        with torch.no_grad():
+            outs = [onet(x_all[i:i + 512].to(dtype)) for i in range(0, x_all.shape[0], 512)]
+        logits = torch.cat([o[2] for o in outs])
+        v = torch.cat([o[3] for o in outs])[:, 0].reshape(T + 1, N)
+        logp = O.categorical_log_prob(logits[:B], a_t.to(dtype))
+        if dtype == torch.float64:                                # agent.py:124-140 in float64 (the yardstick's own GAE)
+            vv, g, nv = v.numpy(), np.zeros(N), v.numpy()[T]
+            adv, ret = np.empty((T, N)), np.empty((T, N))
+            for t in reversed(range(T)):
+                k = 1.0 - dones[t]
+                g = g * k
+                g = np.float64(np.float32(0.99)) * 0.95 * g + (np.float64(np.float32(0.99)) * nv * k - vv[t] + rewards[t])
+                nv = vv[t]
+                ret[t], adv[t] = vv[t] + g, g
+        else:
+            adv, ret = O.gae(v.numpy(), rewards, dones)
+        idx = np.arange(B) if order is None else order
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1)[idx])).to(dtype)
+        xs = x_all[:B][idx].to(dtype)
+        rows, snaps = [], {}
+        learner = O.learn(onet, onet.make_optims(), xs, tt(acts), tt(logp.numpy()), tt(adv), tt(ret), iters=ITERS)
+        for it in range(1, ITERS + 1):
+            if it > 1:
+                perturb()
+            ld, _, _ = next(learner)
+            rows.append([ld[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
+            if it in (1, ITERS):
+                snaps[it] = {k: p.detach().double().numpy().copy() for k, p in onet.named_parameters()}
+        return {"v": v.double().numpy(), "logp": logp.double().numpy().reshape(T, N), "adv": np.asarray(adv, np.float64),
+                "ret": np.asarray(ret, np.float64), "losses": np.asarray(rows, np.float64), "params": snaps}
+
+    try:
+        c64 = chain(torch.float64)
+        variants = [chain(torch.float32), chain(torch.float32, order=np.random.default_rng(1).permutation(B)),
+                    chain(torch.float32, noise_seed=501), chain(torch.float32, noise_seed=502)]
+    finally:
+        torch.set_num_threads(threads)
+    c32 = variants[0]
+    # ---- acting + GAE: single-step tolerances against the reference-order fp32 chain ------------------------------------
+    np.testing.assert_allclose(ro.values.cpu().numpy(), c32["v"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ro.logps.cpu().numpy(), c32["logp"], rtol=1e-5, atol=1e-6)
+    oadv, oret = O.gae(ro.values.cpu().numpy(), rewards, dones)                 # same values in -> bit-exact scan
+    assert np.array_equal(ro.adv.cpu().numpy(), oadv) and np.array_equal(ro.ret.cpu().numpy(), oret)
+    np.testing.assert_allclose(ro.adv.cpu().numpy(), c32["adv"], rtol=1e-4, atol=3e-5)   # value noise x sum of (gamma landa)^k <= 17
+    tr, _ = O.episode_returns(rewards, dones)
+    assert np.array_equal(ro.returns.rewards_episode.cpu().numpy(), tr[-1])
+    # ---- ten PPO iterations on the pool's batch ---------------------------------------------------------------------------
+    net.hot_path.reset_optimizer()
+    env = P.loss_envelope(c64["losses"], *[v["losses"] for v in variants])
+    p0 = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    ref = {}
+    for it in (1, ITERS):
+        for k in p0:
+            a64 = c64["params"][it][k]
+            u64 = (a64 - p0[k]).ravel()
+            l2 = mx = omc = 0.0
+            for v in variants:
+                dd = (v["params"][it][k] - a64).ravel()
+                l2, mx = max(l2, float(np.sqrt(dd @ dd))), max(mx, float(np.abs(dd).max()))
+                uv = (v["params"][it][k] - p0[k]).ravel()
+                den = np.linalg.norm(uv) * np.linalg.norm(u64)
+                omc = max(omc, 1.0 - float(uv @ u64 / den) if den > 0 else 0.0)
+            kk = "it%d/%s" % (it, k)
+            ref["ref_l2/" + kk], ref["ref_max/" + kk], ref["ref_1mcos/" + kk], ref["upd_l2/" + kk] = l2, mx, omc, float(np.linalg.norm(u64))
+    seen = 0
+    for ld, update_time, last in net.learn(ro.batch()):
+        seen += 1
+        assert update_time == seen and last is True
+        got = np.array([ld[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
+        row = c64["losses"][seen - 1]
+        excess = np.abs(got - row) - (1e-5 * np.abs(row) + 2e-6)
+        P.MARGINS.check("chain_config1", "loss_env", max(0.0, float(np.max(excess / np.maximum(env[seen - 1], 1e-12)))), "(iteration %d)" % seen)
+        if seen in (1, ITERS):
+            gotp = P.split_flat(net.hot_path.params.cpu().numpy().astype(np.float64))
+            worst = P.deviation_ratios(gotp, c64["params"][seen], p0, ref, lambda n, it=seen: "it%d/%s" % (it, n), lambda n: n.split(".")[0])
+            for k, (v, pname) in worst.items():
+                P.MARGINS.check("chain_config1", "param_%s_it%d" % (k, seen), v, "(%s)" % pname)
+    assert seen == ITERS
+
+
 def test_pinned_ring_feeds_pool():
     from ddrl4nav_amd.data import PinnedRing
     from ddrl4nav_amd._lib import DdrlError
