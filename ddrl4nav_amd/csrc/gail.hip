@@ -103,8 +103,9 @@ __global__ __launch_bounds__(256) void value_head_reduce_kernel(const float* __r
     if (vloss_accum) vloss_accum[0] += (float)(s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5));
     return;
   }
-  float s = 0.0f;
-  for (int q = 0; q < nwg; ++q) s += part[(int64_t)q * VH_STRIDE + i];
+  double sd = 0.0;  // summed in double, rounded once
+  for (int q = 0; q < nwg; ++q) sd += (double)part[(int64_t)q * VH_STRIDE + i];
+  const float s = (float)sd;
   if (i < FEAT) {
     if (dw) dw[i] = s;
   } else if (db) {

@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void gauss_reduce_kernel(const float* __restri
     grads[L.n_params + k] = (float)r;
     return;
   }
-  float s = 0.0f;
-  for (int w = 0; w < nwg; ++w) s += hpart[(int64_t)w * hstride + i];
+  double sd = 0.0;  // summed in double, rounded once
+  for (int w = 0; w < nwg; ++w) sd += (double)hpart[(int64_t)w * hstride + i];
+  const float s = (float)sd;
   int64_t dst;
   if (i < D * FEAT) dst = L.actor_w + i;
   else if (i < o) dst = L.critic_w + (i - D * FEAT);

@@ -308,9 +308,9 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
                                                            int64_t count, float* __restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
-  float s = 0.0f;
-  for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * slab_stride + i];
-  dst[i] = s;
+  double s = 0.0;  // summed in double, rounded once (optim.hip reduce_partials_kernel)
+  for (int sp = 0; sp < nsplit; ++sp) s += (double)part[(int64_t)sp * slab_stride + i];
+  dst[i] = (float)s;
 }
 
 // Many slabs, few elements (thin weight gradients: hundreds of splits of a few hundred values): 16
@@ -318,19 +318,19 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 // 16 partial sums in group order -- still a fixed order, so still deterministic.
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ part, int nsplit, int64_t slab_stride,
                                                                 int64_t count, float* __restrict__ dst) {
-  __shared__ float red[16][17];
+  __shared__ double red[16][17];
   const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
-  float s = 0.0f;
+  double s = 0.0;
   if (i < count)
-    for (int sp = g; sp < nsplit; sp += 16) s += part[(int64_t)sp * slab_stride + i];
+    for (int sp = g; sp < nsplit; sp += 16) s += (double)part[(int64_t)sp * slab_stride + i];
   red[g][e] = s;
   __syncthreads();
   if (g == 0 && i < count) {
-    float t = 0.0f;
+    double t = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][e];
-    dst[i] = t;
+    dst[i] = (float)t;
   }
 }
 

@@ -544,14 +544,15 @@ __global__ __launch_bounds__(256) void heads_reduce_kernel(const float* __restri
   }
   // eight independent partial sums (workgroups w = q mod 8), combined in a fixed order: the 256 loads of a thread are in flight
   // eight at a time instead of one dependent add after the other (0.12 -> 0.03 ms)
-  float ps[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  // (summed in double and rounded once, as the split-K slabs in optim.hip)
+  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   int w = 0;
   for (; w + 8 <= nwg; w += 8) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ps[q] += hpart[(int64_t)(w + q) * hstride + i];
+    for (int q = 0; q < 8; ++q) ps[q] += (double)hpart[(int64_t)(w + q) * hstride + i];
   }
-  for (; w < nwg; ++w) ps[0] += hpart[(int64_t)w * hstride + i];
-  const float s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+  for (; w < nwg; ++w) ps[0] += (double)hpart[(int64_t)w * hstride + i];
+  const float s = (float)(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
   int64_t dst;
   if (i < A * FEAT) dst = L.actor_w + i;
   else if (i < (A + 1) * FEAT) dst = L.critic_w + (i - A * FEAT);

@@ -166,35 +166,37 @@ void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* 
 }
 
 // --------------------------------------------------------------------------------------------
-// grads[off_e + i] = sum_s part[s][e][i]   (fixed order)
+// grads[off_e + i] = sum_s part[s][e][i]   (fixed order).  The slabs are summed in DOUBLE and rounded once (round 4): up to 1,024
+// fp32 partial sums per element added one after the other in fp32 cost a few 1e-7 of the result, as much as the matrix pipe's own
+// fp32 accumulation inside a slab; in double this stage adds nothing (the kernels are HBM-bound: 20 us either way).
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nsplit, int64_t count,
                                                               float* __restrict__ grads, int64_t off0, int64_t off1) {
   const int e = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
-  float s = 0.0f;
-  for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)sp * 2 + e) * count + i];
-  grads[(e ? off1 : off0) + i] = s;
+  double s = 0.0;
+  for (int sp = 0; sp < nsplit; ++sp) s += (double)part[((int64_t)sp * 2 + e) * count + i];
+  grads[(e ? off1 : off0) + i] = (float)s;
 }
 // Many slabs of few elements (conv1: 1,024 slabs x 8,224 values): 16 lane groups walk the slabs in
 // parallel (group g takes slabs g, g+16, ...), one lane then adds the 16 partial sums in group order.
 __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ part, int nsplit, int64_t count,
                                                                    float* __restrict__ grads, int64_t off0, int64_t off1) {
-  __shared__ float red[16][17];
+  __shared__ double red[16][17];
   const int e = blockIdx.y;
   const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + el;
-  float s = 0.0f;
+  double s = 0.0;
   if (i < count)
-    for (int sp = g; sp < nsplit; sp += 16) s += part[((int64_t)sp * 2 + e) * count + i];
+    for (int sp = g; sp < nsplit; sp += 16) s += (double)part[((int64_t)sp * 2 + e) * count + i];
   red[g][el] = s;
   __syncthreads();
   if (g == 0 && i < count) {
-    float t = 0.0f;
+    double t = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][el];
-    grads[(e ? off1 : off0) + i] = t;
+    grads[(e ? off1 : off0) + i] = (float)t;
   }
 }
 void launch_reduce_partials(const float* part, int nsplit, int64_t count, int ne, float* grads, int64_t off0,

@@ -202,7 +202,7 @@ class HotPath:
         if self.comm is not None:
             check(self.lib.ddrl_grad_allreduce_overlapped(self.ctx, self.comm.h, c_void_p(cs.cuda_stream), _stream()))
             return
-        import torch.distributed as tdist
+        from .dist import allreduce_flat
         # ordering against whatever the compute stream holds at this call; stale bucket events (no ppo_iter since the last
         # reduction) make the communication stream wait for the compute stream up front (no race, no overlap)
         fresh = c_int32()
@@ -215,7 +215,8 @@ class HotPath:
                 check(self.lib.ddrl_grad_bucket_wait_last(self.ctx, c_void_p(cs.cuda_stream)))
             with torch.cuda.stream(cs):
                 for off, cnt in ranges:
-                    tdist.all_reduce(self.grads[off:off + cnt], op=tdist.ReduceOp.SUM, group=self.process_group)
+                    # RCCL ranks: in place on the device; ranks that share a GPU (gloo rehearsal): staged through the host per bucket
+                    allreduce_flat(self.grads[off:off + cnt], self.process_group)
         self._comm_done.record(cs)
         torch.cuda.current_stream().wait_event(self._comm_done)
 

@@ -52,10 +52,76 @@ def nccl_one_rank(outdir):
     dist.destroy_process_group()
 
 
+def bucket_ranks(outdir, bounds):
+    """N gloo ranks sharing the GPU: the layer-bucket path (bucket events, communication stream, ranges) with REAL partners --
+    every bucket's ranges are reduced host-staged on the communication stream -- against the flat reduction of the same
+    gradients: bit-identical arenas, ranges that tile the arena exactly once, and the stale-event rule (a second reduction
+    without a new ppo_iter must still see everything the compute stream wrote)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ddrl4nav_amd.dist import allreduce_flat, init_from_env
+    from ddrl4nav_amd.engine import HotPath
+    from ddrl4nav_amd.utils.recipe import flatten, make_weights
+    import parity_util as P
+    rank, world, _ = init_from_env()
+    frames, actions, old_logps, advs, rets = P.mode_batch("default")
+    lo, hi = bounds[rank], bounds[rank + 1]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).cuda()
+    args = (d(frames), d(actions), d(old_logps), d(advs), d(rets))
+    h = HotPath(max_batch=64)
+    h.set_params(flatten(make_weights(0)))
+    assert not h._overlap          # off by default (DDRL_ALLREDUCE_OVERLAP unset)
+    h.ppo_iter(*args, b_global=64)
+    local = h.grads.clone()
+    flat = allreduce_flat(local.clone())
+    h.enable_overlap()
+    covered = np.zeros(h.grads.numel(), np.int32)
+    for ranges in h.grad_buckets():
+        for off, cnt in ranges:
+            covered[off:off + cnt] += 1
+    assert (covered == 1).all()    # the buckets tile the arena + loss tail exactly once
+    h.ppo_iter(*args, b_global=64)  # records the bucket events
+    assert torch.equal(h.grads, local)
+    h.allreduce_grads()
+    torch.cuda.synchronize()
+    bucketed = h.grads.clone()
+    # stale events: new gradients written by "another producer" on the compute stream, no ppo_iter in between
+    h.grads.copy_(local * 2.0)
+    h.allreduce_grads()
+    torch.cuda.synchronize()
+    stale = h.grads.clone()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), flat=flat.cpu().numpy(), bucketed=bucketed.cpu().numpy(),
+             stale=stale.cpu().numpy(), n_buckets=len(h.grad_buckets()))
+    h.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def rccl_duplicate(outdir):
+    """DDRL_ALLREDUCE=rccl with two ranks on ONE device must be refused with an error, not reach ncclCommInitRank (which would
+    hang or abort on duplicate devices)."""
+    from ddrl4nav_amd import _lib
+    from ddrl4nav_amd.dist import init_from_env
+    from ddrl4nav_amd.engine import HotPath
+    rank, world, _ = init_from_env()
+    try:
+        HotPath(max_batch=8)
+    except _lib.DdrlError as e:
+        print("REFUSED:", e)
+        sys.exit(3)
+    sys.exit(0)
+
+
 def main():
     outdir, mode, bounds = sys.argv[1], sys.argv[2], [int(t) for t in sys.argv[3].split(",")]
     if mode == "nccl1":
         return nccl_one_rank(outdir)
+    if mode == "buckets":
+        return bucket_ranks(outdir, bounds)
+    if mode == "rccl_dup":
+        return rccl_duplicate(outdir)
     import numpy as np
     import torch
     import torch.distributed as dist

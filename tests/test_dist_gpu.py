@@ -218,3 +218,37 @@ def test_torch_nccl_bucketed_allreduce_one_rank(tmp_path):
     assert p.returncode == 0, p.stdout[-3000:]
     r = np.load(out / "rank0.npz")
     assert np.array_equal(r["params_0"], r["params_1"]) and float(r["loss_0"]) == float(r["loss_1"])
+
+
+def test_bucketed_allreduce_with_two_real_ranks_equals_flat(tmp_path):
+    """The layer-bucket reduction with a real partner (two gloo ranks on the one GPU, every bucket host-staged on the communication
+    stream behind its event): the same ranges, the same sums as the flat reduction, bit for bit on both ranks; a reduction without
+    a fresh ppo_iter (stale bucket events) is ordered behind the compute stream as a whole."""
+    ranks = _run_world(tmp_path, "buckets", [0, 40, 64], "buckets_w2")
+    for r in ranks:
+        assert int(r["n_buckets"]) == 5
+        assert np.array_equal(r["bucketed"], r["flat"])
+        assert np.array_equal(r["stale"][:-8], 2.0 * r["flat"][:-8])      # power of two: exact
+    assert np.array_equal(ranks[0]["flat"], ranks[1]["flat"])
+
+
+def test_rccl_allreduce_refuses_duplicate_devices(tmp_path):
+    """DDRL_ALLREDUCE=rccl with two ranks on one GPU: refused with DdrlError before any communicator is created (exit code 3 of
+    the worker, within seconds), never a hang inside ncclCommInitRank."""
+    out = tmp_path / "dup"
+    out.mkdir()
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DDRL_DIST_BACKEND="gloo", DDRL_ALLREDUCE="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(out), "rccl_dup", "0,32,64"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("DDRL_ALLREDUCE=rccl on duplicate devices hung instead of failing")
+        assert p.returncode == 3 and "needs one GPU per rank" in o, o[-2000:]

@@ -264,7 +264,7 @@ def test_discriminator_260_steps_cross_the_steplr_boundary(golden):
             assert np.abs(got - want).max() <= 1e-6, (k, np.abs(got - want).max())
             continue
         # RMSprop normalises by sqrt(E[g^2]): like Adam it amplifies summation-order noise on elements whose gradient is
-        # tiny; the limit (margins.json) is a fraction of the distance the tensor travelled in 260 steps
+        # tiny; the limit (parity_util.PARAM_LIMIT) is a fraction of the distance the tensor travelled in 260 steps
         P.MARGINS.check("gail_d_only", "param_end", float(np.abs(got - want).max() / moved), "(%s)" % k)
 
 

@@ -325,7 +325,8 @@ def test_chained_rollout_gae_learn_config1_shape():
     actions the HIP sampler drew (forward.py:128-149 -> agent.py:124-140 -> ppo.py:77-146).
     Acting and GAE: single-step tolerances.  The ten-iteration trajectory: deviation from the oracle's float64 chain as a ratio to
     the spread of the oracle's own fp32 chains around it (in order, another batch order, two runs with every parameter perturbed
-    by <= 4 fp32 roundings before each forward -- what "another fp32 evaluation of the reference" looks like).  Fixed limits:
+    by <= 4 fp32 roundings before each forward, and one on torch's native convolution backend instead of oneDNN -- what "another
+    fp32 evaluation of the reference" looks like: tests/parity_util.py BACKEND).  Fixed limits:
     losses 2.0 x that envelope beyond the single-step tolerance, parameters 1.5 x (L2 / max / direction)."""
     import parity_util as P
     from ddrl4nav_amd.agent import DeviceRollout
@@ -356,8 +357,12 @@ def test_chained_rollout_gae_learn_config1_shape():
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, max(1, (__import__("os").cpu_count() or 1))))
 
-    def chain(dtype, order=None, noise_seed=None):
+    def chain(dtype, order=None, noise_seed=None, native=False):
         """The reference's chain in `dtype`: values / log-probs of the given actions, GAE, ten learn iterations."""
+        with torch.backends.mkldnn.flags(enabled=not native):
+            return _chain(dtype, order, noise_seed)
+
+    def _chain(dtype, order, noise_seed):
         onet = O.OraclePPO()
         onet.load_weights(w)
         onet.to(dtype)
@@ -403,7 +408,7 @@ def test_chained_rollout_gae_learn_config1_shape():
     try:
         c64 = chain(torch.float64)
         variants = [chain(torch.float32), chain(torch.float32, order=np.random.default_rng(1).permutation(B)),
-                    chain(torch.float32, noise_seed=501), chain(torch.float32, noise_seed=502)]
+                    chain(torch.float32, noise_seed=501), chain(torch.float32, noise_seed=502), chain(torch.float32, native=True)]
     finally:
         torch.set_num_threads(threads)
     c32 = variants[0]

@@ -54,6 +54,8 @@ def main():
         grads[tag] = {k: p.grad.double().numpy().copy() for k, p in net.named_parameters()}
     _release_decisions(net32)
     got = _grad_views(hp)
+    KEEP = ("actor.actor_linear.weight", "critic.pre.conv2.weight", "actor.pre.conv3.weight", "critic.critic_linear.weight")
+    dump = {"ghip/" + k: got[k].copy() for k in KEEP}
     print("%-34s %10s %10s %8s | %10s %8s" % ("gradient vs float64", "rms hip", "rms fp32", "ratio", "max hip/|g|", "ratio"))
     for k, g64 in grads["f64"].items():
         eh = got[k].astype(np.float64) - g64
@@ -64,6 +66,11 @@ def main():
     hp.clip_adam_step()
     traj = P.f64_trajectory(mode)
     flat = hp.params.cpu().numpy()
+    gp = P.split_flat(flat, False)
+    dump.update(tail=hp.grads[hp.n_params:].cpu().numpy().copy(), **{"p1/" + k: gp[k].copy() for k in KEEP},
+                **{"g64/" + k: grads["f64"][k] for k in KEEP}, **{"g32/" + k: grads["f32"][k] for k in KEEP})
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "diag_%s.npz" % mode), **dump)
     gotp = P.split_flat(np.asarray(flat, np.float64), False)
     ref = P.spread(mode)
     floor = {}
