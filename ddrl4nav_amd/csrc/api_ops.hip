@@ -26,16 +26,24 @@ static bool direct_ok(const ConvGeom& g, const void* in_side, const void* out_si
   return (g.in_sn & 3) == 0 && (g.out_sn & 3) == 0 && aligned16(in_side) && aligned16(out_side);
 }
 
+// regions of a layer's packed buffer: 0-4 gather layouts + tables (gconv.hip), 5 / 6 the direct forward / data-gradient layouts
+// (dconv.hip f32 planes, or pconv.hip fp16 planes + header where a layer has them), 7 = per-sample plane scales of the LATEST
+// launch (pconv.hip; g.n floats -- the last region, so that no other offset depends on the batch size of a call)
 struct PackView {
-  int64_t off[7], total;
+  int64_t off[8], total;
 };
 static PackView pack_view(const ConvGeom& g) {
-  int64_t sz[7];
+  int64_t sz[8];
   conv_pack_sizes(g, sz);
   conv_direct_pack_sizes(g, sz + 5);  // specialised direct-convolution layouts (dconv.hip), 0 when absent
+  sz[7] = 0;
+  if (conv_has_planes(g)) {
+    sz[5] = sz[6] = conv_planes_pack_floats(g);
+    sz[7] = g.n;
+  }
   PackView v;
   int64_t o = 0;
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < 8; ++i) {
     v.off[i] = o;
     o += align_up(sz[i], 64);
   }
@@ -66,7 +74,9 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
   const PackView v = pack_view(g);
   launch_conv_pack(g, w, packed + v.off[0], (int2*)(packed + v.off[1]), packed + v.off[2], (int2*)(packed + v.off[3]),
                    (int*)(packed + v.off[4]), (hipStream_t)stream);
-  if (conv_has_direct(g) || conv_has_band_fwd(g))
+  if (conv_has_planes(g))
+    launch_conv_planes_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
+  else if (conv_has_direct(g) || conv_has_band_fwd(g))
     launch_conv_direct_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
   return op_check();
 }
@@ -85,7 +95,12 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  if ((conv_has_direct(g) || conv_has_band_fwd(g)) && direct_ok(g, in, out))
+  // the caller sized `packed` for its largest batch (ddrl_op_conv_pack_floats with that n): region 7 holds this launch's scales
+  if (conv_has_planes(g) && direct_ok(g, in, out))
+    launch_conv_planes_fwd(g, in, packed + v.off[5], const_cast<float*>(packed) + v.off[7], bias, act, out, (hipStream_t)stream);
+  else if (conv_has_planes(g))
+    return DDRL_ERR_INVALID_ARG;   // fp16-plane layers keep no f32 layout: strides / bases must allow 16-byte loads
+  else if ((conv_has_direct(g) || conv_has_band_fwd(g)) && direct_ok(g, in, out))
     launch_conv_direct_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
   else
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
@@ -96,7 +111,11 @@ int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float
   ConvGeom g;
   if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  if (conv_has_direct(g) && direct_ok(g, din, dz))
+  if (conv_has_planes(g) && direct_ok(g, din, dz))
+    launch_conv_planes_dgrad(g, dz, packed + v.off[6], const_cast<float*>(packed) + v.off[7], din, (hipStream_t)stream);
+  else if (conv_has_planes(g))
+    return DDRL_ERR_INVALID_ARG;
+  else if (conv_has_direct(g) && direct_ok(g, din, dz))
     launch_conv_direct_dgrad(g, dz, packed + v.off[6], din, (hipStream_t)stream);
   else
     launch_conv_dgrad(g, dz, packed + v.off[2], (const int2*)(packed + v.off[3]), din, (hipStream_t)stream);

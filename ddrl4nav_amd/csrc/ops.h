@@ -35,6 +35,15 @@ int conv_direct_wgrad_splits(const ConvGeom& g);  // 0 when there is no speciali
 void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db,
                               hipStream_t st);
 
+// pconv.hip: the same forward / data-gradient layers on the 16-bit matrix pipe (two scaled fp16 planes per operand, per-sample input
+// scales); `scales` = n floats of scratch
+bool conv_has_planes(const ConvGeom& g);
+int64_t conv_planes_pack_floats(const ConvGeom& g);  // floats of ONE region (forward or data gradient)
+void launch_conv_planes_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st);
+void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, int act, float* out,
+                            hipStream_t st);
+void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* scales, float* din, hipStream_t st);
+
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
 void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);

@@ -12,8 +12,9 @@ implementation of the same mathematics.  Against the oneDNN variants it scores u
 
 Stored per learner mode (default = F4 batch, shared = F10, smooth = F11, pong = F21, actions18 = F12), for the native backend at
 1 and 8 threads, exactly the keys of the other spread fixtures under a "<mode>/" prefix:
-    <mode>/ref_l2|ref_max|ref_1mcos/it<k>/<name>   largest deviation of the two runs from the float64 run (k = 1, 10)
-    <mode>/losses_variants [2, 10, 4]               their loss trajectories
+    <mode>/ref_l2|ref_max|ref_1mcos/it<k>/<name>   largest deviation of the runs from the float64 run (k = 1, 10)
+    <mode>/losses_variants [2 + 16, 10, 4]          their loss trajectories: native backend at 1 and 8 threads, then eight batch
+                                                    orders under oneDNN and under the native backend each (one thread)
 tests/parity_util.py merges them into a mode's spread with max() (as it does for the wide F4 fixture).
 -> tests/golden/f23_backend_spread.npz.   Usage: python tests/golden/make_golden_backend_spread.py
 """
@@ -27,6 +28,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 import make_golden_shared as S  # noqa: E402
+
+
+N_ORDERS = 8
 
 
 def _snap(net):
@@ -81,13 +85,15 @@ def main():
     for mode, build, weights, x, src, rets, reset, stored in modes:
         B = x.shape[0]
 
-        def run(dtype, threads, native):
+        def run(dtype, threads, native, perm=None):
             torch.set_num_threads(threads)
             net, cfg_nn = build(weights)
             net.to(dtype)
             reset(net, cfg_nn)
             net.update_time = 0
-            e = Experience(states=[x], advs=src["advs"], actions=src["actions"], old_logps=src["old_logps"], values=rets.reshape(1, B))
+            idx = np.arange(B) if perm is None else perm
+            e = Experience(states=[x[idx]], advs=src["advs"][idx], actions=src["actions"][idx], old_logps=src["old_logps"][idx],
+                           values=rets[idx].reshape(1, B))
             e.to_tensor(dtype=dtype, device="cpu")
             with torch.backends.mkldnn.flags(enabled=not native):
                 return _run(net, e)
@@ -96,6 +102,12 @@ def main():
         assert np.array_equal(l32, stored), (mode, np.abs(l32 - stored).max())     # the committed fixture IS the oneDNN run
         l64, s64 = run(torch.float64, 1, False)
         variants = [run(torch.float32, 1, True), run(torch.float32, 8, True)]
+        # ... and batch orders under BOTH backends (the wide-spread idea of make_golden_spread_wide.py: from the fourth iteration on
+        # two fp32 evaluations drift apart, and a handful of variants under-states how far): N_ORDERS orders x 2 backends
+        for seed in range(N_ORDERS):
+            perm = np.random.default_rng(2300 + seed).permutation(B)
+            variants.append(run(torch.float32, 1, False, perm))
+            variants.append(run(torch.float32, 1, True, perm))
         torch.set_num_threads(1)
         p0 = {k: np.asarray(v, np.float64) for k, v in weights.items()}
         out[mode + "/losses_variants"] = np.stack([l for l, _ in variants])
