@@ -593,6 +593,28 @@ def ingest_leg(net, ro, N, T, steps=2, host_memcpy=False):
                     "has them resident in HBM as the metric defines"}
 
 
+def nav_leg():
+    """BASELINE config 4's network (robot_nav: NavPreNet1D x2 + GaussionActor(2) + Critic, reference nn/nav_encoder.py:82-128) through
+    the operator-composed path (nn/generic.py, csrc/pconv.hip / dconv.hip / glinear.hip): one PPO iteration on B = 4,096 samples in
+    micro-batches of 1,024, per-operator HIP events.  A sub-record: it never touches the headline `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_nav
+    r = bench_nav.run(4096, 1024, 3)
+    ops = r["ops"]
+    dom = max(ops, key=lambda k: ops[k]["ms_per_iter"])
+    # the forward / data gradient of the heavy layers run on the 16-bit matrix pipe as three fp16 plane products (ceiling 2.5 PF / 3);
+    # the weight gradients and the small layers still on the f32-input MFMA (157.3 TFLOP/s)
+    planes = {k for k in ops if (k.startswith("conv5x5_64->128") or k.startswith("conv3x3_128->256")) and not k.endswith("wgrad")}
+    peak = (PEAK_BF16_MFMA_TFLOPS / 3) if dom in planes else PEAK_F32_MFMA_TFLOPS
+    return {"workload": r["workload"], "B": r["B"], "micro_batch": r["micro_batch"], "ppo_iter_ms": r["ms_per_ppo_iter_wall"],
+            "samples_per_s": r["samples_per_s"], "gemm_ops_ms_per_iter": r["gemm_ops_ms_per_iter"],
+            "algorithmic_tflops_over_gemm_ops": r["algorithmic_tflops_over_gemm_ops"],
+            "dominant_kernel": dom, "dominant_ms_per_iter": ops[dom]["ms_per_iter"], "dominant_tflops": ops[dom]["tflops"],
+            "dominant_pipe": "f16x3" if dom in planes else "f32-input MFMA", "dominant_peak_tflops": round(peak, 1),
+            "dominant_roofline_frac": round(ops[dom]["tflops"] / peak, 4),
+            "ops": {k: v for k, v in list(ops.items())[:10]}}
+
+
 def build_net(n_envs, horizon, iters, max_batch=None):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
@@ -700,6 +722,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-async", action="store_true", help="skip the asynchronous actor/learner leg")
     ap.add_argument("--no-ingest", action="store_true", help="skip the leg that feeds the frames through the pinned-host ring")
+    ap.add_argument("--no-nav", action="store_true", help="skip the robot_nav (BASELINE config 4 network) sub-record")
     ap.add_argument("--ingest-memcpy", action="store_true", help="ingest leg: the producer also copies 7.2 MB per step into the slot")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: the ranks share the devices round-robin and reduce over gloo "
@@ -942,6 +965,12 @@ def main():
                 out["with_ingest_serial"] = ingest_leg(net, ro, N, T, host_memcpy=args.ingest_memcpy)
             except Exception as e:
                 out["with_ingest_serial"] = {"error": repr(e)[:200]}
+        if world == 1 and not args.no_nav:
+            try:
+                out["nav"] = nav_leg()
+                out["config"].update(nav_ppo_iter_ms=out["nav"]["ppo_iter_ms"], nav_samples_per_s=out["nav"]["samples_per_s"])
+            except Exception as e:
+                out["nav"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

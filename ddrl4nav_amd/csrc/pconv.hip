@@ -22,6 +22,8 @@
 // convolution is the same computation on dz with flipped, transposed kernels and PAD' = KS - 1 - PAD (the pack kernel does the
 // flipping).  Geometry-dependent tile shapes (waves x column tiles per wave) are chosen so that NS samples' pixels fill the 32-wide
 // column tiles as well as the register budget allows (table at the bottom): 2 x 400 = 8 x 100 = 25 of 28 tiles, 576 = 4 x 144 = 18 of 18.
+#include <cstdlib>
+
 #include "engine2.h"
 #include "ops.h"
 
@@ -259,6 +261,8 @@ static PlanesId planes_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
   return kPNone;  // the three-plane build keeps the f32-input kernels of dconv.hip
 #else
+  static const bool off = [] { const char* e = getenv("DDRL_NAV_F32"); return e && e[0] == '1'; }();  // A/B switch: the f32-input kernels
+  if (off) return kPNone;
   if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w || g.pad_h != 1) return kPNone;
   const auto is = [&](int cin, int cout, int ks, int h) { return g.cin == cin && g.cout == cout && g.kh == ks && g.h == h; };
   if (is(64, 128, 5, 22)) return kPN1dC2;

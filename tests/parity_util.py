@@ -154,14 +154,32 @@ BACKEND = "f23_backend_spread"
 _SPREAD = {}
 
 
-def _backend(mode):
-    """{key without the mode prefix: value} of the native-backend fixture for a learner mode ({} when it has none)."""
-    path = os.path.join(GOLDEN, BACKEND + ".npz")
+NAV_BACKEND = "f24_nav_backend_spread"   # the same for the nav nets and GAIL over a nav encoder (make_golden_backend_spread_nav.py)
+
+
+def _backend(mode, fixture=BACKEND):
+    """{key without the mode prefix: value} of the native-backend fixture for a learner mode / fixture name ({} when it has none)."""
+    path = os.path.join(GOLDEN, fixture + ".npz")
     if not os.path.exists(path):
         return {}
     g = np.load(path)
     pre = mode + "/"
     return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+
+
+def with_backend(ref, name):
+    """A fixture's own spread keys (ref_l2 / ref_max / ref_1mcos ...) merged with the native-backend runs of `name` by max()."""
+    d = dict(ref.items())
+    for k, v in _backend(name, NAV_BACKEND).items():
+        if k.split("/")[0] in ("ref_l2", "ref_max", "ref_1mcos") and k in d:
+            d[k] = np.maximum(d[k], v)
+    return d
+
+
+def backend_losses(name):
+    """[loss trajectories of the native-backend runs] of a nav / GAIL fixture, for loss_envelope (may be empty)."""
+    b = _backend(name, NAV_BACKEND)
+    return [b["losses_variants"]] if "losses_variants" in b else []
 
 
 def spread(mode):
@@ -427,13 +445,13 @@ class GailStepper:
 
 def gail_deviation_from(name, tag, got, p64, p0):
     """deviation_ratios of `got` against a given float64 state (GailStepper.params()), in the currency of the fixture's spread."""
-    return deviation_ratios(got, p64, p0, _load(name), lambda n: "%s/%s" % (tag, n), lambda n: n.split(".")[0])
+    return deviation_ratios(got, p64, p0, with_backend(_load(name), name), lambda n: "%s/%s" % (tag, n), lambda n: n.split(".")[0])
 
 
 def gail_param_deviation(name, tag, got, d_forced=None):
     """deviation_ratios for a GAIL fixture: `got` = {param name: array}, tag in ("D1", "it1", "it10")."""
     traj = _GTRAJ.get((name, "forced")) if d_forced is not None and (name, "forced") in _GTRAJ else gail_f64_trajectory(name, d_forced)
-    return deviation_ratios(got, traj["params"][tag], traj["p0"], _load(name), lambda n: "%s/%s" % (tag, n),
+    return deviation_ratios(got, traj["params"][tag], traj["p0"], with_backend(_load(name), name), lambda n: "%s/%s" % (tag, n),
                             lambda n: n.split(".")[0])      # generator (Adam) | discriminator (RMSprop) | gail_critic (none)
 
 
@@ -515,8 +533,8 @@ def nav_param_deviation(name, it, got, p64=None, p0=None):
     if p64 is not None:
         shared = NAV_CASES[name][4]
         group = (lambda n: "all") if shared else (lambda n: n.split(".")[0])
-        return deviation_ratios(got, p64, p0, _load(name[:3] + "b_spread"), lambda n: "it%d/%s" % (it, n), group)
+        return deviation_ratios(got, p64, p0, with_backend(_load(name[:3] + "b_spread"), name), lambda n: "it%d/%s" % (it, n), group)
     traj = nav_f64_trajectory(name)
     shared = NAV_CASES[name][4]
     group = (lambda n: "all") if shared else (lambda n: n.split(".")[0])
-    return deviation_ratios(got, traj["params"][it], traj["p0"], _load(name[:3] + "b_spread"), lambda n: "it%d/%s" % (it, n), group)
+    return deviation_ratios(got, traj["params"][it], traj["p0"], with_backend(_load(name[:3] + "b_spread"), name), lambda n: "it%d/%s" % (it, n), group)

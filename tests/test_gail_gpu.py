@@ -197,7 +197,7 @@ def test_gail_learn_matches_reference(golden, name):
     ora = P.GailStepper(name)
     exp = Experience(states=states, advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"])
     tag = "gail_" + name[:3]
-    env = P.loss_envelope(g["losses"], g["losses_f64"], g["losses_f32t8"], g["losses_perm"])
+    env = P.loss_envelope(g["losses"], g["losses_f64"], g["losses_f32t8"], g["losses_perm"], *P.backend_losses(name))
     B = len(g["actions"])
     rows, seen_d = [], 0
     for loss_item, update_time, last in net.learn(exp):
@@ -205,7 +205,8 @@ def test_gail_learn_matches_reference(golden, name):
             seen_d += 1
             assert set(loss_item) == {"Gail[D]BackUpTime", "Gail[D]Loss"} and update_time == seen_d
             excess = abs(loss_item["Gail[D]Loss"] - g["d_loss"][0]) - (2e-5 * abs(g["d_loss"][0]) + 2e-7)
-            P.MARGINS.check(tag, "d_loss", max(0.0, excess / max(float(g["d_loss_spread"]), 1e-9)))
+            d_spread = max(float(g["d_loss_spread"]), float(P._backend(name, P.NAV_BACKEND).get("d_loss_spread", 0.0)))
+            P.MARGINS.check(tag, "d_loss", max(0.0, excess / max(d_spread, 1e-9)))
             ora.d_step(forced)
             worst = P.gail_deviation_from(name, "D1", _params(net), ora.params(), ora.p0)
             for k, (v, pname) in worst.items():

@@ -78,7 +78,8 @@ def test_generic_net_forward_loss_gradients_golden(golden, name):
         got = flat[off:off + n]
         off += n
         l2 = float(g["gl2/" + k])
-        np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), l2, rtol=1e-4, atol=1e-9, err_msg=k)
+        # (the norm carries the same decision sensitivity as the samples below: 5e-3 here, 2e-5 per tensor under aligned decisions)
+        np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), l2, rtol=5e-3, atol=1e-9, err_msg=k)
         scale = max(np.abs(got).max(), l2 / np.sqrt(n))
         d = np.abs(got[::max(1, n // 129)][:129] - g["gstride/" + k])
         # beside the reference's stored samples: a ReLU / max-pool decision within rounding of its boundary flips with the
@@ -128,7 +129,8 @@ def test_generic_net_learn_sequence_golden(golden, name):
     exp = Experience(states=_states(g), advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"],
                      values=g["rets"].reshape(1, -1))
     ref = g["losses"]
-    env = P.loss_envelope(ref, sp["losses_f64"], g["losses_f32t8"], sp["losses_perm"], *([sp["losses_noise"]] if "losses_noise" in sp.files else []))
+    env = P.loss_envelope(ref, sp["losses_f64"], g["losses_f32t8"], sp["losses_perm"], *([sp["losses_noise"]] if "losses_noise" in sp.files else []),
+                          *P.backend_losses(name))   # incl. the reference on torch's native convolution backend (parity_util.NAV_BACKEND)
     tag = "generic_" + name[:3]
     seen = 0
     # the float64 yardstick advances one iteration behind the kernels and takes THEIR ReLU / max-pool decisions (one flipped

@@ -21,10 +21,6 @@ from ddrl4nav_amd.config import BaseConfig, ConfigNN  # noqa: E402
 from ddrl4nav_amd.data import Experience  # noqa: E402
 from ddrl4nav_amd.runner import create_net  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-CAP = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-
 events = []
 
 
@@ -56,82 +52,101 @@ def lin_flop(l, *a, **k):
     return 2.0 * a[-1] * l.K * l.N
 
 
-ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
-ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
-ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
-ops.Linear.forward = timed(lin_name("fwd"), lin_flop, ops.Linear.forward)
-ops.Linear.dgrad = timed(lin_name("dgrad"), lin_flop, ops.Linear.dgrad)
-ops.Linear.wgrad = timed(lin_name("wgrad"), lin_flop, ops.Linear.wgrad)
 
-env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "discrete_action": False, "act_dim": 2,
-       "image_batch": 1, "ped_sim": {"total": 3}}
-cfg = BaseConfig(types.SimpleNamespace(task="bench", ip="127.0.0.1"), env)
-cfg.TASK_TYPE = "robot_nav"
-cfg_nn = ConfigNN(env)
-cfg_nn.TRAINING_ITER_TIME = ITERS
-net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=CAP)
-g = torch.Generator(device="cuda")
-g.manual_seed(4)
-states = [torch.rand((B, 1, 960), device="cuda", generator=g), torch.randn((B, 5), device="cuda", generator=g),
-          (torch.rand((B, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
-(dist, _), values = net([s[:CAP] for s in states])
-exp = Experience(states=states, advs=torch.randn(B, device="cuda", generator=g),
-                 actions=torch.randn((B, 2), device="cuda", generator=g), old_logps=torch.full((B,), -2.0, device="cuda"),
-                 values=torch.randn((1, B), device="cuda", generator=g))
-for _ in net.learn(exp):  # warm-up (also sizes every lazily created buffer)
-    pass
-events.clear()
-torch.cuda.synchronize()
-t0 = time.time()
-for _ in net.learn(exp):
-    pass
-torch.cuda.synchronize()
-wall = (time.time() - t0) / ITERS
-agg = defaultdict(lambda: [0.0, 0.0, 0])
-for name, flop, e0, e1 in events:
-    a = agg[name]
-    a[0] += e0.elapsed_time(e1)
-    a[1] += flop
-    a[2] += 1
-rows = {k: {"ms_per_iter": round(v[0] / ITERS, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "calls_per_iter": v[2] // ITERS}
-        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
-tot_ms = sum(v[0] for v in agg.values()) / ITERS
-tot_flop = sum(v[1] for v in agg.values()) / ITERS
-# ---- whole loop at the BASELINE config-4 shape: 512 envs, T steps of acting + bootstrap + GAE + one PPO update ----
-loop = None
-if len(sys.argv) > 4:
-    from ddrl4nav_amd.agent import StateRollout
-    N, T = 512, int(sys.argv[4])
-    ro = StateRollout(net, N, [(1, 960), (5,), (3, 48, 48)], horizon=T)
-    ro.states[0].copy_(torch.rand(ro.states[0].shape, device="cuda", generator=g))
-    ro.states[1].copy_(torch.randn(ro.states[1].shape, device="cuda", generator=g))
-    ro.states[2].copy_((torch.rand(ro.states[2].shape, device="cuda", generator=g) < 0.15).float())
-    u = torch.rand((T, N), device="cuda", generator=g)
-    ro.rewards.copy_(torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)))
-    ro.dones.copy_((torch.rand((T, N), device="cuda", generator=g) < 1.0 / 800).to(torch.uint8))
-
-    def one_loop():
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
-        for t in range(T):
-            ro.act(t)
-        ro.bootstrap()
-        ro.finish()
-        e1.record()
-        for _ in net.learn(ro.batch()):
-            pass
-        e2.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1), e1.elapsed_time(e2)
-
-    one_loop()
+def run(B=4096, CAP=1024, ITERS=3, T_loop=None):
+    """One measurement; returns the record as a dict (bench.py's `nav` sub-record calls this).  The per-operator timing wraps
+    ops.Conv / ops.Linear for the duration of the call only."""
+    saved = {(cls, k): getattr(cls, k) for cls in (ops.Conv, ops.Linear) for k in ("forward", "dgrad", "wgrad")}
     events.clear()
-    act_ms, upd_ms = one_loop()
-    loop = {"envs": N, "horizon": T, "ppo_iters": ITERS, "acting_plus_gae_ms": round(act_ms, 1), "update_ms": round(upd_ms, 1),
-            "env_steps_per_s": round(N * T / ((act_ms + upd_ms) * 1e-3), 1),
-            "acting_env_steps_per_s": round(N * (T + 1) / (act_ms * 1e-3), 1)}
-print(json.dumps({"workload": "robot_nav: NavPreNet1D x2 + GaussionActor(2), PPO iteration", "B": B, "micro_batch": CAP,
-                  "whole_loop": loop,
-                  "ms_per_ppo_iter_wall": round(wall * 1e3, 2), "gemm_ops_ms_per_iter": round(tot_ms, 2),
-                  "algorithmic_tflops_over_gemm_ops": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
-                  "samples_per_s": round(B / wall, 1), "ops": rows}))
+    try:
+        return _run(B, CAP, ITERS, T_loop)
+    finally:
+        for (cls, k), fn in saved.items():
+            setattr(cls, k, fn)
+
+
+def _run(B, CAP, ITERS, T_loop):
+    ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
+    ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
+    ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
+    ops.Linear.forward = timed(lin_name("fwd"), lin_flop, ops.Linear.forward)
+    ops.Linear.dgrad = timed(lin_name("dgrad"), lin_flop, ops.Linear.dgrad)
+    ops.Linear.wgrad = timed(lin_name("wgrad"), lin_flop, ops.Linear.wgrad)
+
+    env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "discrete_action": False, "act_dim": 2,
+           "image_batch": 1, "ped_sim": {"total": 3}}
+    cfg = BaseConfig(types.SimpleNamespace(task="bench", ip="127.0.0.1"), env)
+    cfg.TASK_TYPE = "robot_nav"
+    cfg_nn = ConfigNN(env)
+    cfg_nn.TRAINING_ITER_TIME = ITERS
+    net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=CAP)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    states = [torch.rand((B, 1, 960), device="cuda", generator=g), torch.randn((B, 5), device="cuda", generator=g),
+              (torch.rand((B, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
+    (dist, _), values = net([s[:CAP] for s in states])
+    exp = Experience(states=states, advs=torch.randn(B, device="cuda", generator=g),
+                     actions=torch.randn((B, 2), device="cuda", generator=g), old_logps=torch.full((B,), -2.0, device="cuda"),
+                     values=torch.randn((1, B), device="cuda", generator=g))
+    for _ in net.learn(exp):  # warm-up (also sizes every lazily created buffer)
+        pass
+    events.clear()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in net.learn(exp):
+        pass
+    torch.cuda.synchronize()
+    wall = (time.time() - t0) / ITERS
+    agg = defaultdict(lambda: [0.0, 0.0, 0])
+    for name, flop, e0, e1 in events:
+        a = agg[name]
+        a[0] += e0.elapsed_time(e1)
+        a[1] += flop
+        a[2] += 1
+    rows = {k: {"ms_per_iter": round(v[0] / ITERS, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "calls_per_iter": v[2] // ITERS}
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+    tot_ms = sum(v[0] for v in agg.values()) / ITERS
+    tot_flop = sum(v[1] for v in agg.values()) / ITERS
+    # ---- whole loop at the BASELINE config-4 shape: 512 envs, T steps of acting + bootstrap + GAE + one PPO update ----
+    loop = None
+    if T_loop is not None:
+        from ddrl4nav_amd.agent import StateRollout
+        N, T = 512, int(T_loop)
+        ro = StateRollout(net, N, [(1, 960), (5,), (3, 48, 48)], horizon=T)
+        ro.states[0].copy_(torch.rand(ro.states[0].shape, device="cuda", generator=g))
+        ro.states[1].copy_(torch.randn(ro.states[1].shape, device="cuda", generator=g))
+        ro.states[2].copy_((torch.rand(ro.states[2].shape, device="cuda", generator=g) < 0.15).float())
+        u = torch.rand((T, N), device="cuda", generator=g)
+        ro.rewards.copy_(torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)))
+        ro.dones.copy_((torch.rand((T, N), device="cuda", generator=g) < 1.0 / 800).to(torch.uint8))
+
+        def one_loop():
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            for t in range(T):
+                ro.act(t)
+            ro.bootstrap()
+            ro.finish()
+            e1.record()
+            for _ in net.learn(ro.batch()):
+                pass
+            e2.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1), e1.elapsed_time(e2)
+
+        one_loop()
+        events.clear()
+        act_ms, upd_ms = one_loop()
+        loop = {"envs": N, "horizon": T, "ppo_iters": ITERS, "acting_plus_gae_ms": round(act_ms, 1), "update_ms": round(upd_ms, 1),
+                "env_steps_per_s": round(N * T / ((act_ms + upd_ms) * 1e-3), 1),
+                "acting_env_steps_per_s": round(N * (T + 1) / (act_ms * 1e-3), 1)}
+    return ({"workload": "robot_nav: NavPreNet1D x2 + GaussionActor(2), PPO iteration", "B": B, "micro_batch": CAP,
+                      "whole_loop": loop,
+                      "ms_per_ppo_iter_wall": round(wall * 1e3, 2), "gemm_ops_ms_per_iter": round(tot_ms, 2),
+                      "algorithmic_tflops_over_gemm_ops": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
+                      "samples_per_s": round(B / wall, 1), "ops": rows})
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 1024,
+                         int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 else None)))
