@@ -86,7 +86,9 @@ int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
   if (!fill_geom(d, g) || !floats) return DDRL_ERR_INVALID_ARG;
   int splits = conv_wgrad_splits(g);
   if (conv_direct_wgrad_splits(g) > splits) splits = conv_direct_wgrad_splits(g);
-  *floats = (int64_t)splits * ((int64_t)g.cout * g.cin * g.kh * g.kw + g.cout);
+  if (conv_planes_wgrad_splits(g) > splits) splits = conv_planes_wgrad_splits(g);
+  // + the per-sample scales of the plane kernels (pconv.hip): 2 n floats behind the slabs
+  *floats = (int64_t)splits * ((int64_t)g.cout * g.cin * g.kh * g.kw + g.cout) + (conv_has_planes(g) ? 2 * (int64_t)g.n + 64 : 0);
   return DDRL_OK;
 }
 
@@ -128,7 +130,9 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
   if (!fill_geom(d, g) || !in || !dz || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if (g.oh * g.ow < 32) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  if (conv_has_direct_wgrad(g) && direct_ok(g, in, dz))
+  if (conv_has_planes(g) && direct_ok(g, in, dz))
+    launch_conv_planes_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
+  else if (conv_has_direct_wgrad(g) && direct_ok(g, in, dz))
     launch_conv_direct_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
   else
     launch_conv_wgrad(g, in, dz, (const int*)(packed + v.off[4]), ws, dw, db, (hipStream_t)stream);

@@ -43,6 +43,9 @@ void launch_conv_planes_pack(const ConvGeom& g, const float* w, float* wpf, floa
 void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, int act, float* out,
                             hipStream_t st);
 void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* scales, float* din, hipStream_t st);
+int conv_planes_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no plane kernels
+// part: conv_planes_wgrad_splits slabs of cout * cin * kh * kw + cout floats, then 2 n floats (per-sample scales of this launch)
+void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
 
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);

@@ -239,6 +239,242 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
   }
 }
 
+// ================================================================================================
+// Weight gradient of the same layers as plane products -- the design of the Atari conv3 / conv2 weight gradients (wgrad2.hip:
+// both blocks staged channel-innermost, MFMA fragments through the transposing LDS read ds_read_b64_tr_b16) over the compile-time
+// geometry:
+//   part[split][oc][ic][tap] = sum over the split's samples and output pixels of  dz[b][oc][pix] * in[b][ic][oy + ky - PAD][ox + kx - PAD]
+// GEMM rows = 64 oc per workgroup, columns = (tap, ic) of an ICW-wide block of input channels, reduction index kappa = output pixel
+// of the staged block: NB whole samples, or a BAND of BR output rows of one sample (the input band is BR + KS - 1 padded rows).
+// dz as [kappa][64 oc] (128-byte rows, half-swap swizzle), the input as [ic half][padded pixel][32 ic] (64-byte rows; cells
+// outside the image are written as zeros by the staging); a lane's 8 k-values are 8 consecutive kappa = rows kappa (dz) and rows
+// rho(kappa) + tap offset (input).  Waves: ICW = 64: (oc half, ic half) x all KK taps (3x3: 9 fragment tiles, as the Atari
+// kernels); ICW = 32: (oc half, tap half) x 13 / 12 taps (5x5).  Both operands get ONE power-of-two scale for the whole batch (the
+// largest of the per-sample maxima the pre-pass leaves): a sum over samples is accurate in the absolute sense, relative to its
+// largest contribution.  The bias gradient (sum of dz) rides along in fp32 from the staging registers (ic block 0 only).
+// ================================================================================================
+using s4w = __attribute__((ext_vector_type(4))) short;
+__device__ __forceinline__ frag8 tr_frag(const char* lds, int off_lo, int off_hi) {
+  typedef s4w __attribute__((address_space(3))) * lds_s4;
+  const s4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + off_lo));
+  const s4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + off_hi));
+  typedef __attribute__((ext_vector_type(8))) short s8w;
+  return __builtin_bit_cast(frag8, (s8w)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int CIN_, int COUT_, int KS_, int HIN_, int PAD_, int NB_, int BR_, int ICW_>
+struct WGeo {
+  static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, HIN = HIN_, PAD = PAD_, NB = NB_, BR = BR_, ICW = ICW_;
+  static constexpr int KK = KS * KS, OH = HIN + 2 * PAD - KS + 1, P = OH * OH, LP = HIN + 2 * PAD, RAW = HIN * HIN, KT = CIN * KK;
+  static constexpr int NBANDS = OH / BR, KAPPA = NB * BR * OH, NKG = (KAPPA + 15) / 16, AROWS = NKG * 16;
+  static constexpr int BRW = BR + KS - 1, BPX = NB * BRW * LP, NH = ICW / 32, BP = 64;
+  static constexpr int A_PLANE = AROWS * 128, B_HALF = BPX * BP, B_PLANE = NH * B_HALF, B_OFF = NPL * A_PLANE;
+  static constexpr int LDS_BYTES = NPL * (A_PLANE + B_PLANE);
+  static constexpr int NT = ICW == 64 ? KK : (KK + 1) / 2;                   // fragment tiles (taps) per wave
+  static constexpr int A_UNITS = KAPPA * 8, B_UNITS = BPX * (ICW / 8);       // (row, 8-channel group) staging units
+  static constexpr int NA = (A_UNITS + 255) / 256, NBU = (B_UNITS + 255) / 256;
+  static constexpr int64_t SLAB = (int64_t)COUT * KT + COUT;
+  static_assert(OH % BR == 0 && (NB == 1 || BR == OH), "bands of whole output rows of one sample, or whole samples");
+  static_assert(ICW == 32 || ICW == 64, "input-channel block");
+  static_assert(CIN % ICW == 0 && COUT % 64 == 0 && LDS_BYTES <= 160 * 1024, "blocks / LDS budget");
+  static_assert(KAPPA * 8 * 8 * 4 <= LDS_BYTES, "the bias reduction reuses the stage");
+};
+
+template <class K>
+__global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restrict__ in, int64_t in_sn, const float* __restrict__ dz, int64_t dz_sn,
+                                                           const float* __restrict__ sc_in, const float* __restrict__ sc_dz,
+                                                           float* __restrict__ part, int n, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char ldsw[];
+  __shared__ float s_min[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave >> 1, wx = wave & 1;
+  constexpr int NICB = K::CIN / K::ICW;
+  const int icb = blockIdx.x % NICB, split = blockIdx.x / NICB, oct = blockIdx.y;
+  // one scale per operand for the whole batch: the smallest of the per-sample scales (= the largest magnitude)
+  {
+    float ma = 3.0e38f, mb = 3.0e38f;
+    for (int i = tid; i < n; i += 256) {
+      ma = fminf(ma, sc_dz[i]);
+      mb = fminf(mb, sc_in[i]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      ma = fminf(ma, __shfl_xor(ma, off, 64));
+      mb = fminf(mb, __shfl_xor(mb, off, 64));
+    }
+    if (lane == 0) {
+      s_min[0][wave] = ma;
+      s_min[1][wave] = mb;
+    }
+  }
+  __syncthreads();
+  const float sd = fminf(fminf(s_min[0][0], s_min[0][1]), fminf(s_min[0][2], s_min[0][3]));
+  const float sa = fminf(fminf(s_min[1][0], s_min[1][1]), fminf(s_min[1][2], s_min[1][3]));
+  const float inv = 1.0f / (sd * sa);
+  const int nsg = (n + K::NB - 1) / K::NB, nst = nsg * K::NBANDS;
+  const int per = (nst + nsplit - 1) / nsplit;
+  const int st_begin = split * per, st_end = min(nst, st_begin + per);
+  // zero rows of the dz image (kappa >= KAPPA): written once
+  for (int i = tid; i < NPL * (K::AROWS - K::KAPPA) * 8; i += 256) {
+    const int pl = i / ((K::AROWS - K::KAPPA) * 8), r = i % ((K::AROWS - K::KAPPA) * 8);
+    *(u4v*)(ldsw + pl * K::A_PLANE + K::KAPPA * 128 + r * 16) = (u4v){0u, 0u, 0u, 0u};
+  }
+  // ---- staging maps
+  int64_t aoff[K::NA], boff[K::NBU];  // offsets inside a sample (floats), without the band shift
+  int awr[K::NA], bwr[K::NBU], asmp[K::NA], bsmp[K::NBU], bry[K::NBU];
+  unsigned bxok = 0u;                 // bit t: the unit's column is inside the image
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t) {
+    const int u = min(tid + 256 * t, K::A_UNITS - 1);
+    const int c8 = u / K::KAPPA, kap = u % K::KAPPA, bl = kap / (K::BR * K::OH), w = kap % (K::BR * K::OH);
+    asmp[t] = bl;
+    aoff[t] = (int64_t)(oct * 64 + c8 * 8) * K::P + w;                        // + band * BR * OH, + sample * dz_sn, + c * P
+    awr[t] = kap * 128 + ((c8 * 16) ^ (((kap >> 1) & 1) * 64));
+  }
+#pragma unroll
+  for (int t = 0; t < K::NBU; ++t) {
+    const int u = min(tid + 256 * t, K::B_UNITS - 1);
+    const int c8 = u / K::BPX, rho = u % K::BPX, bl = rho / (K::BRW * K::LP), r = rho % (K::BRW * K::LP);
+    const int ry = r / K::LP, rx = r % K::LP, ix = rx - K::PAD;
+    bsmp[t] = bl;
+    bry[t] = ry - K::PAD;                                                     // input row = band * BR + bry
+    if (ix >= 0 && ix < K::HIN) bxok |= 1u << t;
+    boff[t] = (int64_t)(icb * K::ICW + c8 * 8) * K::RAW + min(max(ix, 0), K::HIN - 1);  // + iy * HIN, + sample * in_sn, + c * RAW
+    bwr[t] = K::B_OFF + (c8 >> 2) * K::B_HALF + rho * K::BP + (c8 & 3) * 16;
+  }
+  // ---- fragment addresses (wgrad2.hip): 16-lane group g16: columns 16 (g16 & 1) .. +15 of the 32-channel fragment, k-values
+  // 8 (g16 >> 1) .. +7; inside the group lane 4 q + pp supplies row q (first read) / q + 4 (second), chunk pp
+  const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int sw = (q >> 1) & 1;
+  const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
+  const int b_lane = K::B_OFF + (K::ICW == 64 ? wx * K::B_HALF : 0) + (g16 & 1) * 32 + pp * 8;
+  int brow[K::NKG][2];
+#pragma unroll
+  for (int g = 0; g < K::NKG; ++g)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kap = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
+      const int bl = kap / (K::BR * K::OH), w = kap % (K::BR * K::OH);
+      brow[g][r] = kap < K::KAPPA ? ((bl * K::BRW + w / K::OH) * K::LP + w % K::OH) * K::BP : 0;  // padded kappa: any row (dz is zero there)
+    }
+  float ar[K::NA][8], br[K::NBU][8], bsum[K::NA][8];
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bsum[t][c] = 0.0f;
+  auto fetch = [&](int st) {
+    const int sg = st / K::NBANDS, band = st % K::NBANDS;
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      const float* src = dz + (int64_t)min(sg * K::NB + asmp[t], n - 1) * dz_sn + aoff[t] + band * (K::BR * K::OH);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ar[t][c] = src[(int64_t)c * K::P];
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      const int iy = min(max(band * K::BR + bry[t], 0), K::HIN - 1);
+      const float* src = in + (int64_t)min(sg * K::NB + bsmp[t], n - 1) * in_sn + boff[t] + iy * K::HIN;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) br[t][c] = src[(int64_t)c * K::RAW];
+    }
+  };
+  auto commit = [&](int st) {
+    const int sg = st / K::NBANDS, band = st % K::NBANDS;
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+        if (sg * K::NB + asmp[t] >= n) {  // missing sample of a ragged last stage: contributes zero
+#pragma unroll
+          for (int c = 0; c < 8; ++c) ar[t][c] = 0.0f;
+        }
+        unsigned pl[4][NPL];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
+        char* d = ldsw + awr[t];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::A_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      if (t + 1 < K::NBU || tid + 256 * t < K::B_UNITS) {
+        const int iy = band * K::BR + bry[t];
+        const bool ok = ((bxok >> t) & 1u) && iy >= 0 && iy < K::HIN && sg * K::NB + bsmp[t] < n;
+        unsigned pl[4][NPL];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_planes(ok ? br[t][2 * c] : 0.0f, ok ? br[t][2 * c + 1] : 0.0f, sa, pl[c]);
+        char* d = ldsw + bwr[t];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::B_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+      }
+    }
+  };
+  f32x16 acc[K::NT];
+#pragma unroll
+  for (int t = 0; t < K::NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  if (st_begin < st_end) {
+    fetch(st_begin);
+    commit(st_begin);
+    if (st_begin + 1 < st_end) fetch(st_begin + 1);
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st) {
+#pragma unroll
+      for (int g = 0; g < K::NKG; ++g) {
+        frag8 a[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) a[p] = tr_frag(ldsw, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        DDRL_PLANE_PRODUCTS;
+#pragma unroll
+        for (int t = 0; t < K::NT; ++t) {
+          const int tap = K::ICW == 64 ? t : wx * K::NT + t;   // ICW = 32: the wave's half of the taps (wx is wave-uniform)
+          if (K::ICW == 32 && tap >= K::KK) continue;
+          const int toff = ((tap / K::KS) * K::LP + tap % K::KS) * K::BP;
+          frag8 b[NPL];
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) b[p] = tr_frag(ldsw, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
+#pragma unroll
+          for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[PA[m]], b[PB[m]], acc[t]);
+        }
+      }
+      __syncthreads();  // every wave is done with the stage
+      if (st + 1 < st_end) {
+        commit(st + 1);
+        if (st + 2 < st_end) fetch(st + 2);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- epilogue: slab[oc][ic][tap] (torch layout), then the bias partial (ic block 0)
+  float* slab = part + (int64_t)split * K::SLAB;
+#pragma unroll
+  for (int t = 0; t < K::NT; ++t) {
+    const int tap = K::ICW == 64 ? t : wx * K::NT + t;
+    if (K::ICW == 32 && tap >= K::KK) continue;
+    const int ic = icb * K::ICW + (K::ICW == 64 ? wx * 32 : 0) + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(int64_t)(oct * 64 + wi * 32 + acc_row(r, hi)) * K::KT + ic * K::KK + tap] = acc[t][r] * inv;
+  }
+  if (icb != 0) return;  // block-uniform
+  __syncthreads();
+  float* red = (float*)ldsw;  // [unit][8]
+#pragma unroll
+  for (int t = 0; t < K::NA; ++t)
+    if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[(tid + 256 * t) * 8 + c] = bsum[t][c];
+    }
+  __syncthreads();
+  if (tid < 64) {  // oc = oct * 64 + tid: units (c8 = tid / 8) * KAPPA .. + KAPPA - 1, channel tid % 8
+    float sacc = 0.0f;
+    for (int k = 0; k < K::KAPPA; ++k) sacc += red[((tid >> 3) * K::KAPPA + k) * 8 + (tid & 7)];
+    slab[(int64_t)K::COUT * K::KT + oct * 64 + tid] = sacc;
+  }
+}
+
 }  // namespace pconv
 
 // ---- dispatch table (same layers as dconv.hip's forward / data-gradient instantiations) -------------------------------------------
@@ -326,6 +562,66 @@ void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* w
     case kPNavC3: run_planes<PNavC3D>(dz, g.out_sn, wpd, planes, scales, nullptr, 0, din, g.in_sn, g.n, st); break;
     default: break;
   }
+}
+
+
+// ---- weight gradients ----------------------------------------------------------------------------------------------------------------
+//                          CIN  COUT KS HIN PAD NB BR ICW
+using PN1dC2W = pconv::WGeo<64, 128, 5, 22, 1, 1, 4, 32>;    // bands of 4 output rows: 80 kappa = 5 k-groups; wave = (oc half, 13 / 12 taps)
+using PN1dC3W = pconv::WGeo<128, 256, 3, 10, 1, 2, 10, 64>;  // 2 whole samples: 200 kappa of 208
+using PNavC2W = pconv::WGeo<64, 128, 3, 24, 1, 1, 4, 64>;    // bands of 4 rows: 96 kappa = 6 k-groups
+using PNavC3W = pconv::WGeo<128, 256, 3, 12, 1, 1, 12, 64>;  // one whole sample: 144 kappa = 9 k-groups
+
+template <class K>
+static int wgrad_splits_of(int n) {
+  const int tiles = (K::CIN / K::ICW) * (K::COUT / 64);
+  const int nst = ((n + K::NB - 1) / K::NB) * K::NBANDS;
+  int s = (768 + tiles - 1) / tiles;            // about three workgroups per CU in flight, where LDS and registers allow them
+  const int cap = (nst + 7) / 8;                // at least eight stages per workgroup (prologue / epilogue / slab traffic)
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : s;
+}
+
+int conv_planes_wgrad_splits(const ConvGeom& g) {
+  switch (planes_id(g)) {
+    case kPN1dC2: return wgrad_splits_of<PN1dC2W>(g.n);
+    case kPN1dC3: return wgrad_splits_of<PN1dC3W>(g.n);
+    case kPNavC2: return wgrad_splits_of<PNavC2W>(g.n);
+    case kPNavC3: return wgrad_splits_of<PNavC3W>(g.n);
+    default: return 0;
+  }
+}
+
+template <class K>
+static void run_planes_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* scales, int S, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)pconv::wgrad_planes_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  float* sc_in = scales;
+  float* sc_dz = scales + g.n;
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dz, g.out_sn, K::COUT * K::P, sc_dz);
+  hipLaunchKernelGGL(pconv::wgrad_planes_kernel<K>, dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in, g.in_sn,
+                     dz, g.out_sn, sc_in, sc_dz, part, g.n, S);
+}
+
+// part: S slabs of COUT * KT + COUT floats, then 2 n floats of scratch for the per-sample scales
+void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st) {
+  const int S = conv_planes_wgrad_splits(g);
+  const int KT = g.cin * g.kh * g.kw;
+  const int64_t slab = (int64_t)g.cout * KT + g.cout;
+  float* scales = part + (int64_t)S * slab;
+  switch (planes_id(g)) {
+    case kPN1dC2: run_planes_wgrad<PN1dC2W>(g, in, dz, part, scales, S, st); break;
+    case kPN1dC3: run_planes_wgrad<PN1dC3W>(g, in, dz, part, scales, S, st); break;
+    case kPNavC2: run_planes_wgrad<PNavC2W>(g, in, dz, part, scales, S, st); break;
+    case kPNavC3: run_planes_wgrad<PNavC3W>(g, in, dz, part, scales, S, st); break;
+    default: return;
+  }
+  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
+  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
 }
 
 }  // namespace ddrl
