@@ -596,15 +596,16 @@ def ingest_leg(net, ro, N, T, steps=2, host_memcpy=False):
 def nav_leg():
     """BASELINE config 4's network (robot_nav: NavPreNet1D x2 + GaussionActor(2) + Critic, reference nn/nav_encoder.py:82-128) through
     the operator-composed path (nn/generic.py, csrc/pconv.hip / dconv.hip / glinear.hip): one PPO iteration on B = 4,096 samples in
-    micro-batches of 1,024, per-operator HIP events.  A sub-record: it never touches the headline `value`."""
+    ONE micro-batch (max_batch 4,096; in micro-batches of 1,024 the same iteration takes 40.7 instead of 34.9 ms:
+    profiles/r04_nav_ops*.json), per-operator HIP events.  A sub-record: it never touches the headline `value`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_nav
-    r = bench_nav.run(4096, 1024, 3)
+    r = bench_nav.run(4096, 4096, 3)
     ops = r["ops"]
     dom = max(ops, key=lambda k: ops[k]["ms_per_iter"])
-    # the forward / data gradient of the heavy layers run on the 16-bit matrix pipe as three fp16 plane products (ceiling 2.5 PF / 3);
-    # the weight gradients and the small layers still on the f32-input MFMA (157.3 TFLOP/s)
-    planes = {k for k in ops if (k.startswith("conv5x5_64->128") or k.startswith("conv3x3_128->256")) and not k.endswith("wgrad")}
+    # the heavy layers (forward, data and weight gradient) run on the 16-bit matrix pipe as three fp16 plane products (ceiling
+    # 2.5 PF / 3); the 7x7 first layer, the Conv1d pair and the dense layers still on the f32-input MFMA (157.3 TFLOP/s)
+    planes = {k for k in ops if k.startswith("conv5x5_64->128") or k.startswith("conv3x3_128->256")}
     peak = (PEAK_BF16_MFMA_TFLOPS / 3) if dom in planes else PEAK_F32_MFMA_TFLOPS
     return {"workload": r["workload"], "B": r["B"], "micro_batch": r["micro_batch"], "ppo_iter_ms": r["ms_per_ppo_iter_wall"],
             "samples_per_s": r["samples_per_s"], "gemm_ops_ms_per_iter": r["gemm_ops_ms_per_iter"],

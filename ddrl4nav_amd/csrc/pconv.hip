@@ -63,7 +63,12 @@ __global__ __launch_bounds__(256) void sample_scale_kernel(const float* __restri
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) scales[blockIdx.x] = plane_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  if (threadIdx.x == 0) {
+    // an all-zero sample (e.g. the gradient of a sample whose advantage is exactly 0) must not pin the BATCH scale of the weight
+    // gradients at 1 (they take the smallest of these): it gets the largest scale there is; 2^60 also bounds the products of two scales
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    scales[blockIdx.x] = mx > 0.0f ? fminf(plane_scale(mx), 0x1p60f) : 0x1p60f;
+  }
 }
 
 // ---- weights: largest magnitude, then the planes in the order the k index walks ----------------------------------------------

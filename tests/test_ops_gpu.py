@@ -47,6 +47,11 @@ def test_conv_forward_backward_vs_torch(shape):
     z = F.conv2d(x, wt, b, stride=s, padding=pad)
     out = F.relu(z)
     dz = torch.randn(z.shape, generator=g)
+    if n > 2:
+        # one sample without gradient (an advantage of exactly 0) and one 1e-4 below the rest: the per-sample / batch plane scales of
+        # the fp16-plane kernels (csrc/pconv.hip) must not be pinned by the empty sample, nor lose the small one
+        dz[1] = 0.0
+        dz[2] *= 1e-4
     z.backward(dz)
     conv = Conv(cin, h, w, cout, kh, kw, stride=s, pad=pad, max_n=n)
     assert (conv.oh, conv.ow) == tuple(z.shape[2:])
@@ -54,7 +59,11 @@ def test_conv_forward_backward_vs_torch(shape):
     xd, bd, dzd = x.detach().cuda(), b.detach().cuda(), dz.cuda()
     close(conv.forward(xd, bd, relu=True), out)
     close(conv.forward(xd, bd, relu=False), z)
-    close(conv.dgrad(dzd), x.grad)
+    din = conv.dgrad(dzd)
+    close(din, x.grad)
+    if n > 2:   # the small sample on its own scale: per-sample relative accuracy of the data gradient
+        close(din[2], x.grad[2])
+        assert float(din[1].abs().max()) == 0.0
     if conv.oh * conv.ow >= 32:
         dw = torch.full_like(wt.detach(), 7.0).cuda()
         db = torch.full((cout,), 7.0).cuda()
