@@ -303,12 +303,20 @@ def test_full_size_properties_B65536():
         big.ppo_iter(frames[sl], acts[sl], old[sl], adv[sl], ret[sl], b_global=B)
         acc += big.grads
     scale = full[:n].abs().max().item()
-    assert (acc[:n] - full[:n]).abs().max().item() <= 1e-4 * scale
+    # bound 2e-5 max|g| (the B = 64 twin above: 2e-6): three evaluations of 65,536-sample sums in different groupings; the achieved
+    # figure goes on record (gpurun_out/margins_measured.json, "full_size")
+    add_err = (acc[:n] - full[:n]).abs().max().item() / scale
+    assert add_err <= 2e-5, add_err
     np.testing.assert_allclose(acc[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-4, atol=1e-7)
     # (c): the duplicated batch has the same mean gradient as one copy
     big.ppo_iter(frames[:B // 2], acts[:B // 2], old[:B // 2], adv[:B // 2], ret[:B // 2])
     one = big.grads.clone()
-    assert (one[:n] - full[:n]).abs().max().item() <= 1e-4 * scale
+    dup_err = (one[:n] - full[:n]).abs().max().item() / scale
+    assert dup_err <= 2e-5, dup_err
+    import parity_util as P
+    P.MARGINS.measured.setdefault("full_size", {}).update(additivity_over_2e5=add_err / 2e-5, duplication_over_2e5=dup_err / 2e-5)
+    P.MARGINS._flush()
+    print("B = 65,536: additivity error %.2e max|g|, duplication %.2e" % (add_err, dup_err))
     np.testing.assert_allclose(one[n:n + 3].cpu().numpy(), full[n:n + 3].cpu().numpy(), rtol=1e-4, atol=1e-7)
     # (b): two copies of the same samples inside ONE forward come out bit-identical although they sit in different tiles / rows --
     # 2 x 150 samples run the fused acting kernel (csrc/act.hip) + the split dense layer, 2 x 300 the batch-tiled kernels

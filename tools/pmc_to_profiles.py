@@ -95,7 +95,7 @@ def main():
         for cand in (os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "box.txt"), os.path.join(sys.argv[1], "box.txt")):
             if os.path.exists(cand):
                 lines = [ln.strip() for ln in open(cand) if ln.strip() and not set(ln.strip()) <= set("=-")]
-                box = "; ".join(lines[:1] + [ln for ln in lines[1:] if "Card Series" in ln or "Card SKU" in ln][:2])[:160]
+                box = "; ".join(lines[:1] + [" ".join(ln.split()) for ln in lines[1:] if "Card Model" in ln or "Card SKU" in ln or "Unique ID" in ln][:3])[:200]
                 break
     traffic["box"] = box
     with open(tag + "_pmc_traffic.json", "w") as out:
