@@ -299,7 +299,12 @@ typedef struct ddrl_conv_desc {
 } ddrl_conv_desc;
 
 int32_t ddrl_op_conv_out_shape(const ddrl_conv_desc* d, int32_t* oh, int32_t* ow);
-/* Derived weight layouts + index tables of one layer (rebuilt whenever the weights change). */
+/* Derived weight layouts + index tables of one layer (rebuilt whenever the weights change).  `packed` is sized for d->n = the
+ * LARGEST batch any later call passes (ddrl_op_conv_pack_floats with that n): besides the layouts it holds scratch of the layer's
+ * latest launch -- the heavy nav layers (64->128 5x5 @22, 128->256 3x3 @10, 64->128 3x3 @24, 128->256 3x3 @12) run as fp16 plane
+ * products on the 16-bit matrix pipe (csrc/pconv.hip) and leave the per-sample plane scales of their input there, so
+ * ddrl_op_conv_forward / _dgrad WRITE into `packed` although they take it as const: one launch per layer object at a time.
+ * Those layers need 16-byte aligned tensors and sample strides that are multiples of 4 floats (DDRL_ERR_INVALID_ARG otherwise). */
 int32_t ddrl_op_conv_pack_floats(const ddrl_conv_desc* d, int64_t* floats);
 int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed, void* stream);
 /* out = act(conv2d(in, w) + bias); act: 0 none, 1 ReLU        (torch.nn.Conv2d / Conv1d + F.relu) */
