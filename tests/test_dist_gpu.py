@@ -252,3 +252,28 @@ def test_rccl_allreduce_refuses_duplicate_devices(tmp_path):
                 q.kill()
             raise AssertionError("DDRL_ALLREDUCE=rccl on duplicate devices hung instead of failing")
         assert p.returncode == 3 and "needs one GPU per rank" in o, o[-2000:]
+
+
+def test_bench_single_gpu_line_has_its_legs():
+    """`python bench.py` on one GPU at a small shape: the JSON line carries the headline, the overlapped ring-ingest leg
+    (`value_with_ingest`, no producer error), the serial ingest leg, the asynchronous leg, `roofline` with the HBM fraction keys and
+    the phase figures inside `config` -- none of the legs may degrade to an {"error": ...} record."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--envs", "32", "--horizon", "16",
+                          "--no-cpu-baseline", "--no-nav"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"].startswith("f32")
+    for leg in ("with_ingest", "with_ingest_serial", "async_actor_learner"):
+        assert "error" not in d[leg], (leg, d[leg])
+        assert d[leg]["value"] > 0
+    assert d["with_ingest"]["producer_error"] is None and d["with_ingest"]["steps"] >= 10
+    assert d["value_with_ingest"] == d["with_ingest"]["value"] and d["config"]["value_with_ingest"] == d["value_with_ingest"]
+    assert d["with_ingest"]["h2d_bytes_per_rollout"] == 32 * 4 * 84 * 84 * 17
+    for k in ("ppo_iter_ms", "ppo_update_ms", "acting_ms_per_rollout", "arithmetic"):
+        assert k in d["config"]
+    assert d["roofline"]["bound"] == "mfma" and "hbm_frac" in d["roofline"]
