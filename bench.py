@@ -482,9 +482,17 @@ def async_ingest_leg(net, config_nn, N, T, ITERS, dev, steps=10, host_memcpy=Fal
     # The acting side has its own HOST thread, as the reference's Forward server has its own process: popping 257 ring slots per
     # rollout paces the enqueueing thread to PCIe speed (a slot is reused only when its copy has left it), and the learner's ten
     # iterations must not queue up behind that (measured with one thread: 229.5k against 252k env-steps/s).
+    act_err = []
+
     def act_thread_fn(i):
-        torch.cuda.set_device(dev)
-        enqueue_rollout(i)
+        try:
+            torch.cuda.set_device(dev)
+            enqueue_rollout(i)
+        except BaseException as e:   # surfaced by the main thread after the join: never a silent half-enqueued rollout
+            act_err.append(e)
+            with taken:
+                taken_n[0] = 1 << 30
+                taken.notify_all()
 
     def start_rollout(i):
         t = threading.Thread(target=act_thread_fn, args=(i,), daemon=True)
@@ -495,6 +503,8 @@ def async_ingest_leg(net, config_nn, N, T, ITERS, dev, steps=10, host_memcpy=Fal
     t_act = start_rollout(1)
     learn_on(0)                        # warm-up step
     t_act.join()
+    if act_err:
+        raise act_err[0]
     torch.cuda.synchronize()
     spans = []
     t0 = time.perf_counter()
@@ -502,6 +512,8 @@ def async_ingest_leg(net, config_nn, N, T, ITERS, dev, steps=10, host_memcpy=Fal
         t_act = start_rollout(i + 1)   # rollout i+1: ring -> copy stream -> acting stream, on its own host thread
         learn_on(i)                    # ends with the update's one host synchronisation
         t_act.join()                   # everything of rollout i+1 is enqueued (its GPU work may still run: ev_acted orders it)
+        if act_err:
+            raise act_err[0]
         a, b = copy_span[i % 2]
         b.synchronize()
         spans.append(a.elapsed_time(b))

@@ -495,8 +495,12 @@ using PNavC2F = pconv::Geo<64, 128, 3, 24, 1, 1, 6, 3, 3>;    // 576 columns = 1
 using PNavC2D = pconv::Geo<128, 64, 3, 24, 1, 1, 6, 3, 3>;
 using PNavC3F = pconv::Geo<128, 256, 3, 12, 1, 4, 6, 3, 3>;   // 4 x 144 columns
 using PNavC3D = pconv::Geo<256, 128, 3, 12, 1, 4, 6, 3, 3>;
+// AtariPreNet's conv3 as an operator (64 -> 64 3x3 @9, no padding; the fused Atari path has its own kernels in conv2.hip): 5 samples =
+// 245 of 256 columns; data gradient: dz 7x7 with PAD' = 2 -> 9x9 = 81 columns per sample, 3 samples = 243 of 256
+using PAtC3F = pconv::Geo<64, 64, 3, 9, 0, 5, 4, 2, 9>;
+using PAtC3D = pconv::Geo<64, 64, 3, 7, 2, 3, 4, 2, 9>;
 
-enum PlanesId { kPNone = -1, kPN1dC2, kPN1dC3, kPNavC2, kPNavC3 };
+enum PlanesId { kPNone = -1, kPN1dC2, kPN1dC3, kPNavC2, kPNavC3, kPAtC3 };
 
 static PlanesId planes_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
@@ -504,8 +508,10 @@ static PlanesId planes_id(const ConvGeom& g) {
 #else
   static const bool off = [] { const char* e = getenv("DDRL_NAV_F32"); return e && e[0] == '1'; }();  // A/B switch: the f32-input kernels
   if (off) return kPNone;
-  if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w || g.pad_h != 1) return kPNone;
+  if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w) return kPNone;
   const auto is = [&](int cin, int cout, int ks, int h) { return g.cin == cin && g.cout == cout && g.kh == ks && g.h == h; };
+  if (g.pad_h == 0) return is(64, 64, 3, 9) ? kPAtC3 : kPNone;
+  if (g.pad_h != 1) return kPNone;
   if (is(64, 128, 5, 22)) return kPN1dC2;
   if (is(128, 256, 3, 10)) return kPN1dC3;
   if (is(64, 128, 3, 24)) return kPNavC2;
@@ -554,6 +560,7 @@ void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf
     case kPN1dC3: run_planes<PN1dC3F>(in, g.in_sn, wpf, planes, scales, bias, act, out, g.out_sn, g.n, st); break;
     case kPNavC2: run_planes<PNavC2F>(in, g.in_sn, wpf, planes, scales, bias, act, out, g.out_sn, g.n, st); break;
     case kPNavC3: run_planes<PNavC3F>(in, g.in_sn, wpf, planes, scales, bias, act, out, g.out_sn, g.n, st); break;
+    case kPAtC3: run_planes<PAtC3F>(in, g.in_sn, wpf, planes, scales, bias, act, out, g.out_sn, g.n, st); break;
     default: break;
   }
 }
@@ -565,6 +572,7 @@ void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* w
     case kPN1dC3: run_planes<PN1dC3D>(dz, g.out_sn, wpd, planes, scales, nullptr, 0, din, g.in_sn, g.n, st); break;
     case kPNavC2: run_planes<PNavC2D>(dz, g.out_sn, wpd, planes, scales, nullptr, 0, din, g.in_sn, g.n, st); break;
     case kPNavC3: run_planes<PNavC3D>(dz, g.out_sn, wpd, planes, scales, nullptr, 0, din, g.in_sn, g.n, st); break;
+    case kPAtC3: run_planes<PAtC3D>(dz, g.out_sn, wpd, planes, scales, nullptr, 0, din, g.in_sn, g.n, st); break;
     default: break;
   }
 }
@@ -576,6 +584,7 @@ using PN1dC2W = pconv::WGeo<64, 128, 5, 22, 1, 1, 4, 32>;    // bands of 4 outpu
 using PN1dC3W = pconv::WGeo<128, 256, 3, 10, 1, 2, 10, 64>;  // 2 whole samples: 200 kappa of 208
 using PNavC2W = pconv::WGeo<64, 128, 3, 24, 1, 1, 4, 64>;    // bands of 4 rows: 96 kappa = 6 k-groups
 using PNavC3W = pconv::WGeo<128, 256, 3, 12, 1, 1, 12, 64>;  // one whole sample: 144 kappa = 9 k-groups
+using PAtC3W = pconv::WGeo<64, 64, 3, 9, 0, 2, 7, 64>;       // AtariPreNet conv3 as an operator: 2 whole samples, 98 kappa of 112
 
 template <class K>
 static int wgrad_splits_of(int n) {
@@ -593,6 +602,7 @@ int conv_planes_wgrad_splits(const ConvGeom& g) {
     case kPN1dC3: return wgrad_splits_of<PN1dC3W>(g.n);
     case kPNavC2: return wgrad_splits_of<PNavC2W>(g.n);
     case kPNavC3: return wgrad_splits_of<PNavC3W>(g.n);
+    case kPAtC3: return wgrad_splits_of<PAtC3W>(g.n);
     default: return 0;
   }
 }
@@ -623,6 +633,7 @@ void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* d
     case kPN1dC3: run_planes_wgrad<PN1dC3W>(g, in, dz, part, scales, S, st); break;
     case kPNavC2: run_planes_wgrad<PNavC2W>(g, in, dz, part, scales, S, st); break;
     case kPNavC3: run_planes_wgrad<PNavC3W>(g, in, dz, part, scales, S, st); break;
+    case kPAtC3: run_planes_wgrad<PAtC3W>(g, in, dz, part, scales, S, st); break;
     default: return;
   }
   launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);

@@ -28,17 +28,16 @@ def _staged(s, device):
     """Pinned copy of the pageable tensor `s` and the slot whose event must be recorded after the H2D copy was enqueued."""
     dev = torch.device(device)
     key = (tuple(s.shape), s.dtype, dev.index if dev.index is not None else torch.cuda.current_device())
-    with _lock:
-        slot = _buffers.get(key)
-        if slot is None:
-            slot = [torch.empty(s.shape, dtype=s.dtype, pin_memory=True), None]
-            _buffers[key] = slot
-            while len(_buffers) > _MAX_BUFFERS:
-                old = _buffers.popitem(last=False)[1]
-                if old[1] is not None:
-                    old[1].synchronize()
-        else:
-            _buffers.move_to_end(key)
+    slot = _buffers.get(key)      # (the callers hold _lock from here until the H2D copy is enqueued and marked)
+    if slot is None:
+        slot = [torch.empty(s.shape, dtype=s.dtype, pin_memory=True), None]
+        _buffers[key] = slot
+        while len(_buffers) > _MAX_BUFFERS:
+            old = _buffers.popitem(last=False)[1]
+            if old[1] is not None:
+                old[1].synchronize()
+    else:
+        _buffers.move_to_end(key)
     if slot[1] is not None:
         slot[1].synchronize()  # the previous H2D copy out of this buffer has finished (normally long ago)
     slot[0].copy_(s)            # synchronous host memcpy: the caller's buffer is free again after this line
@@ -56,9 +55,10 @@ def to_device(x, device, dtype=None):
     t = torch.as_tensor(x)
     if async_ok(t) or t.numel() == 0:
         return t.to(device, non_blocking=True) if dtype is None else t.to(device, dtype, non_blocking=True)
-    slot = _staged(t, device)
-    out = slot[0].to(device, non_blocking=True)
-    _mark(slot)
+    with _lock:   # one user of a pinned buffer at a time: fill, enqueue the H2D copy, record its event
+        slot = _staged(t, device)
+        out = slot[0].to(device, non_blocking=True)
+        _mark(slot)
     return out if dtype is None else out.to(dtype)
 
 
@@ -70,7 +70,8 @@ def copy_into(dst, src):
         return dst
     if tuple(s.shape) != tuple(dst.shape):
         s = torch.broadcast_to(s, dst.shape)  # dst.copy_'s own broadcasting rule (raises on a mismatch)
-    slot = _staged(s, dst.device)
-    dst.copy_(slot[0], non_blocking=True)
-    _mark(slot)
+    with _lock:
+        slot = _staged(s, dst.device)
+        dst.copy_(slot[0], non_blocking=True)
+        _mark(slot)
     return dst

@@ -25,6 +25,7 @@ CONVS = [
     (4, 1, 48, 48, 64, 3, 3, 1, (1, 1)),     # NavPreNet.conv1
     (2, 64, 24, 24, 128, 3, 3, 1, (1, 1)),   # NavPreNet.conv2
     (3, 128, 12, 12, 256, 3, 3, 1, (1, 1)),  # NavPreNet.conv3
+    (7, 64, 9, 9, 64, 3, 3, 1, (0, 0)),      # AtariPreNet.conv3 as an operator (no padding)
     (6, 1, 1, 960, 32, 1, 5, 2, (0, 0)),     # conv1d1
     (6, 32, 1, 478, 32, 1, 3, 2, (0, 0)),    # conv1d2
     (1, 5, 9, 11, 70, 3, 2, 1, (2, 0)),      # odd everything, one sample
