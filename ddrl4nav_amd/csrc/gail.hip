@@ -103,9 +103,14 @@ __global__ __launch_bounds__(256) void value_head_reduce_kernel(const float* __r
     if (vloss_accum) vloss_accum[0] += (float)(s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5));
     return;
   }
-  double sd = 0.0;  // summed in double, rounded once
-  for (int q = 0; q < nwg; ++q) sd += (double)part[(int64_t)q * VH_STRIDE + i];
-  const float s = (float)sd;
+  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // summed in double, rounded once; eight loads in flight (heads_reduce_kernel)
+  int w = 0;
+  for (; w + 8 <= nwg; w += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ps[q] += (double)part[(int64_t)(w + q) * VH_STRIDE + i];
+  }
+  for (; w < nwg; ++w) ps[0] += (double)part[(int64_t)w * VH_STRIDE + i];
+  const float s = (float)(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
   if (i < FEAT) {
     if (dw) dw[i] = s;
   } else if (db) {

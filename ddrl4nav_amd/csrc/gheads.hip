@@ -249,9 +249,16 @@ __global__ __launch_bounds__(256) void gauss_reduce_kernel(const float* __restri
     grads[L.n_params + k] = (float)r;
     return;
   }
-  double sd = 0.0;  // summed in double, rounded once
-  for (int w = 0; w < nwg; ++w) sd += (double)hpart[(int64_t)w * hstride + i];
-  const float s = (float)sd;
+  // summed in double, rounded once; eight independent partial sums (workgroups w = q mod 8) combined in a fixed order, so that the
+  // 256 loads of a thread are in flight eight at a time instead of one dependent add after the other (heads.hip heads_reduce_kernel)
+  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int w = 0;
+  for (; w + 8 <= nwg; w += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ps[q] += (double)hpart[(int64_t)(w + q) * hstride + i];
+  }
+  for (; w < nwg; ++w) ps[0] += (double)hpart[(int64_t)w * hstride + i];
+  const float s = (float)(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
   int64_t dst;
   if (i < D * FEAT) dst = L.actor_w + i;
   else if (i < o) dst = L.critic_w + (i - D * FEAT);

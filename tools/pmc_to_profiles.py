@@ -25,6 +25,15 @@ SIMDS = 1024  # 256 CUs x 4
 
 
 def short(k):
+    # templates over a compile-time geometry (nav layers): keep the geometry in the name
+    m = re.search(r"ddrl::pconv::(\w+?)_kernel<ddrl::pconv::\w+<([\d, ]+)>", k)
+    if m:
+        g = [x.strip() for x in m.group(2).split(",")]
+        return "pconv_%s<%s>" % (m.group(1), "x".join(g[:5]))      # CIN x COUT x KS x HIN x PAD
+    m = re.search(r"engine2_kernel<ddrl::dconv::(\w+)<([\d, ]+)>", k)
+    if m:
+        g = [x.strip() for x in m.group(2).split(",")]
+        return "dconv_%s<%s>" % (m.group(1), "x".join(g[:5]))
     m = re.search(r"engine2_kernel<ddrl::(\w+?)(?:v2|2)?(?:<(\d)>)?\s*>", k)
     if m:
         return m.group(1) + ("" if not m.group(2) or m.group(2) == "2" else ".ne" + m.group(2))
