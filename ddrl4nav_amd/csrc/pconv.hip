@@ -483,14 +483,28 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
 }  // namespace pconv
 
 // ---- dispatch table (same layers as dconv.hip's forward / data-gradient instantiations) -------------------------------------------
-// Tile shapes.  A 5-wave workgroup would fit 25 column tiles exactly, but two of its waves share a SIMD and the compiler then has
-// 256 registers per wave for 160 accumulators + fragments + prefetch: four waves x 7 column tiles (224 accumulators of a 512-register
-// budget, 25 of 28 tiles used) instead.  The 18-tile geometries run 6 waves x 3 tiles (96 accumulators), two workgroups per CU.
+// Tile shapes.  The 18-tile geometries (576 = 4 x 144 columns) run 6 waves x 3 tiles (96 accumulators), two workgroups per CU; for the
+// 400- / 100-pixel layers see the A/B note below (a 5-wave workgroup would fit 25 column tiles exactly, but two of its waves share a
+// SIMD and the compiler then has 256 registers per wave for 160 accumulators + fragments + prefetch).
 //                        CIN  COUT KS HIN PAD NS WAVES TN TAPC
+// Same-box A/B (tools/ab_nav.py, profiles/README.md r04): whole samples filling the column tiles better (2 x 400 = 8 x 100 columns on
+// four waves x 7 tiles: 25 of 28 used, 224 accumulators, 94-111 KB of LDS -> ONE workgroup per CU) against one / four samples on
+// four waves x 4 tiles (400 of 512 columns, 128 accumulators, 57-62 KB -> TWO workgroups per CU): the second is faster although it
+// issues 14 % more matrix instructions (5x5 forward 4.29 -> 4.12 ms, 3x3 data gradient 1.81 -> 1.59 ms per 4,096 samples): at one
+// workgroup per CU nothing covers the barriers and commits of a k-block.  -DDDRL_PC_WIDE=1 selects the wide tiles.
+#ifndef DDRL_PC_WIDE
+#define DDRL_PC_WIDE 0
+#endif
+#if DDRL_PC_WIDE
 using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 2, 4, 7, 5>;    // 2 x 400 columns = 25 of 28 column tiles
-using PN1dC2D = pconv::Geo<128, 64, 5, 20, 3, 1, 4, 4, 5>;    // 484 of 512 columns
 using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, 8, 4, 7, 3>;   // 8 x 100 columns
 using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, 8, 4, 7, 3>;
+#else
+using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 1, 4, 4, 5>;    // 400 of 512 columns
+using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, 4, 4, 4, 3>;   // 4 x 100 of 512 columns
+using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, 4, 4, 4, 3>;
+#endif
+using PN1dC2D = pconv::Geo<128, 64, 5, 20, 3, 1, 4, 4, 5>;    // 484 of 512 columns
 using PNavC2F = pconv::Geo<64, 128, 3, 24, 1, 1, 6, 3, 3>;    // 576 columns = 18 column tiles
 using PNavC2D = pconv::Geo<128, 64, 3, 24, 1, 1, 6, 3, 3>;
 using PNavC3F = pconv::Geo<128, 256, 3, 12, 1, 4, 6, 3, 3>;   // 4 x 144 columns
