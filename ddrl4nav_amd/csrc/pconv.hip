@@ -594,6 +594,8 @@ void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* w
 
 // ---- weight gradients ----------------------------------------------------------------------------------------------------------------
 //                          CIN  COUT KS HIN PAD NB BR ICW
+// (5x5 A/B, round 4: three tap groups of 9 / 9 / 7 taps across workgroups with (oc half, ic half) waves -- 144 accumulators, two
+// workgroups per CU, the dz band staged three times -- measured 6.3 against 4.45 ms: not kept)
 using PN1dC2W = pconv::WGeo<64, 128, 5, 22, 1, 1, 4, 32>;    // bands of 4 output rows: 80 kappa = 5 k-groups; wave = (oc half, 13 / 12 taps)
 using PN1dC3W = pconv::WGeo<128, 256, 3, 10, 1, 2, 10, 64>;  // 2 whole samples: 200 kappa of 208
 using PNavC2W = pconv::WGeo<64, 128, 3, 24, 1, 1, 4, 64>;    // bands of 4 rows: 96 kappa = 6 k-groups
