@@ -109,6 +109,8 @@ SIGNATURES = {
     "ddrl_op_conv_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_maxpool2_forward": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_maxpool2_relu_backward": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_maxpool2_forward_idx": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_maxpool2_backward_idx": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_linear_pack_floats": (c_int32, [c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
     "ddrl_op_linear_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_linear_forward": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,

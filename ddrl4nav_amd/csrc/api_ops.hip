@@ -140,15 +140,29 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
 }
 
 int32_t ddrl_op_maxpool2_forward(const float* in, int64_t planes, int32_t h, int32_t w, float* out, void* stream) {
-  if (!in || !out || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return DDRL_ERR_INVALID_ARG;
+  if (!in || !out || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || ((uintptr_t)in & 7)) return DDRL_ERR_INVALID_ARG;
   launch_maxpool2_fwd(in, planes, h, w, out, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_maxpool2_relu_backward(const float* a, const float* dpool, int64_t planes, int32_t h, int32_t w, float* dz,
                                        void* stream) {
-  if (!a || !dpool || !dz || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return DDRL_ERR_INVALID_ARG;
+  if (!a || !dpool || !dz || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || (((uintptr_t)a | (uintptr_t)dz) & 7))
+    return DDRL_ERR_INVALID_ARG;
   launch_maxpool2_relu_bwd(a, dpool, planes, h, w, dz, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_maxpool2_forward_idx(const float* in, int64_t planes, int32_t h, int32_t w, float* out, uint8_t* code, void* stream) {
+  if (!in || !out || !code || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || ((uintptr_t)in & 7)) return DDRL_ERR_INVALID_ARG;
+  launch_maxpool2_fwd_idx(in, planes, h, w, out, code, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_maxpool2_backward_idx(const float* dpool, const uint8_t* code, int64_t planes, int32_t h, int32_t w, float* dz,
+                                      void* stream) {
+  if (!dpool || !code || !dz || planes < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || ((uintptr_t)dz & 15)) return DDRL_ERR_INVALID_ARG;
+  launch_maxpool2_bwd_idx(dpool, code, planes, h, w, dz, (hipStream_t)stream);
   return op_check();
 }
 

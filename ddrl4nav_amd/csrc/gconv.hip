@@ -335,39 +335,144 @@ __global__ __launch_bounds__(256) void conv_ptab_kernel(int ow, int P, int* __re
   if (i < P) ptab[i] = ((i / ow) << 16) | (i % ow);
 }
 
-// 2x2 / stride 2 max pool over [planes][H][W] (H, W even) -- F.max_pool2d(x, 2, stride=2)
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, int64_t total, int H, int W,
-                                                           float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int ow = W / 2, oh = H / 2;
-  const int x = (int)(i % ow), y = (int)((i / ow) % oh);
-  const int64_t pl = i / ((int64_t)ow * oh);
-  const float* s = in + (pl * H + 2 * y) * W + 2 * x;
-  out[i] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[W], s[W + 1]));
-}
+// 2x2 / stride 2 max pool over [planes][H][W] (H, W even) -- F.max_pool2d(x, 2, stride=2).
+// Rows 2y and 2y+1 of a plane are adjacent in memory and H is even, so the tensor is a flat list of ROW PAIRS of 2W floats, each
+// producing one output row of W/2 windows: window i sits in pair i / ow, and that one division (32-bit whenever the tensor allows) is
+// all the index arithmetic there is.  Every access is 8 bytes per lane (W even keeps them aligned), contiguous across the wave.
+template <typename IT>
+struct PoolAt {
+  IT i, in_off;
+  __device__ PoolAt(IT idx, int W) : i(idx) {
+    const IT ow = (IT)(W / 2), rp = idx / ow, x = idx - rp * ow;
+    in_off = rp * (IT)(2 * W) + 2 * x;
+  }
+};
 
-// dz[plane][y][x] = (a[y][x] is the FIRST maximum of its window, row-major scan as in PyTorch) and
-// a[y][x] > 0 (ReLU') ? dpool[window] : 0          a = relu(conv) at full resolution
-__global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dpool,
-                                                                int64_t total, int H, int W, float* __restrict__ dz) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per pooled element
-  if (i >= total) return;
-  const int ow = W / 2, oh = H / 2;
-  const int x = (int)(i % ow), y = (int)((i / ow) % oh);
-  const int64_t pl = i / ((int64_t)ow * oh);
-  const int64_t o = (pl * H + 2 * y) * W + 2 * x;
-  const float v0 = a[o], v1 = a[o + 1], v2 = a[o + W], v3 = a[o + W + 1];
+__device__ __forceinline__ int first_max(float v0, float v1, float v2, float v3, float& m) {  // PyTorch's scan order; ties keep the first
   int am = 0;
-  float m = v0;
+  m = v0;
   if (v1 > m) { m = v1; am = 1; }
   if (v2 > m) { m = v2; am = 2; }
   if (v3 > m) { m = v3; am = 3; }
+  return am;
+}
+
+template <typename IT>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, IT total, int W, float* __restrict__ out) {
+  const IT i = (IT)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const PoolAt<IT> at(i, W);
+  const float2 r0 = *(const float2*)(in + at.in_off), r1 = *(const float2*)(in + at.in_off + W);
+  out[i] = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y));
+}
+
+// The same pool, also leaving the DECISIONS its backward needs in one byte per window: bits 0-1 = position of the FIRST maximum
+// (row-major scan, as PyTorch routes the gradient), bit 2 = that maximum is positive (the ReLU in front of the pool lets the gradient
+// through).  The backward then reads dpool and this byte instead of the full-resolution activations: 1.31 instead of 2.25 tensor sizes.
+template <typename IT>
+__global__ __launch_bounds__(256) void maxpool2_fwd_idx_kernel(const float* __restrict__ in, IT total, int W, float* __restrict__ out,
+                                                               uint8_t* __restrict__ code) {
+  const IT i = (IT)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const PoolAt<IT> at(i, W);
+  const float2 r0 = *(const float2*)(in + at.in_off), r1 = *(const float2*)(in + at.in_off + W);
+  float m;
+  const int am = first_max(r0.x, r0.y, r1.x, r1.y, m);
+  out[i] = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y));  // the value exactly as maxpool2_fwd_kernel forms it
+  code[i] = (uint8_t)(am | (m > 0.0f ? 4 : 0));
+}
+
+// One thread per 16 bytes of dz (H*W is a multiple of 4, so the flat tensor is whole float4s): the kernel is bound by its 4-byte-per-
+// element WRITE, and 1 KiB contiguous per wave is what the write path wants (one thread per window stores two half-used 128-byte lines per
+// instruction and measured 2.7 TB/s).  W even makes elements (0,1) and (2,3) of a quad two whole window halves; the byte and the pooled
+// gradient of a window are read by the two threads that own its rows, the second time from cache.
+#ifndef DDRL_POOL_QUADS
+#define DDRL_POOL_QUADS 4
+#endif
+template <typename IT>
+__global__ __launch_bounds__(256) void maxpool2_bwd_idx_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ code, IT total4,
+                                                               int W, float* __restrict__ dz) {
+  const IT ow = (IT)(W / 2);
+  IT e[DDRL_POOL_QUADS];
+  int ca[DDRL_POOL_QUADS], cb[DDRL_POOL_QUADS], sa[DDRL_POOL_QUADS], sb[DDRL_POOL_QUADS];
+  float ga[DDRL_POOL_QUADS], gb[DDRL_POOL_QUADS];
+  bool live[DDRL_POOL_QUADS];
+  // every load of the thread's quads is issued before the first store: a wave's stores wait on its loads, and one quad per wave
+  // lifetime leaves too few bytes in flight to fill the write path
+#pragma unroll
+  for (int k = 0; k < DDRL_POOL_QUADS; ++k) {
+    IT q = ((IT)blockIdx.x * DDRL_POOL_QUADS + k) * 256 + threadIdx.x;
+    live[k] = q < total4;
+    q = live[k] ? q : total4 - 1;
+    e[k] = q * 4;
+    const IT row = e[k] / (IT)W, col = e[k] - row * (IT)W;
+    IT row2 = row, col2 = col + 2;
+    if (col2 >= (IT)W) { col2 = 0; row2 = row + 1; }
+    const IT wa = (row >> 1) * ow + (col >> 1), wb = (row2 >> 1) * ow + (col2 >> 1);
+    ca[k] = code[wa];
+    cb[k] = code[wb];
+    ga[k] = dpool[wa];
+    gb[k] = dpool[wb];
+    sa[k] = (int)(row & 1) * 2;  // which half of the window this row is
+    sb[k] = (int)(row2 & 1) * 2;
+  }
+#pragma unroll
+  for (int k = 0; k < DDRL_POOL_QUADS; ++k) {
+    const float xa = (ca[k] & 4) ? ga[k] : 0.0f, xb = (cb[k] & 4) ? gb[k] : 0.0f;
+    if (live[k])
+      *(float4*)(dz + e[k]) = make_float4((ca[k] & 3) == sa[k] ? xa : 0.0f, (ca[k] & 3) == sa[k] + 1 ? xa : 0.0f,
+                                          (cb[k] & 3) == sb[k] ? xb : 0.0f, (cb[k] & 3) == sb[k] + 1 ? xb : 0.0f);
+  }
+}
+
+// W a multiple of 4 (the usual case): one thread per PAIR of windows of a row pair -- one 2-byte and one 8-byte load (both aligned, since
+// an even number of windows per row keeps pair p at pooled offset 2p) for two 16-byte stores, a quarter of the loads per byte of the
+// kernel above.  The two stores of a wave land in the two rows of the same pairs, so together they cover whole lines.
+template <typename IT>
+__global__ __launch_bounds__(256) void maxpool2_bwd_idx_pairs_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ code,
+                                                                     IT pairs, int W, float* __restrict__ dz) {
+  const IT pw = (IT)(W / 4);
+  IT off[DDRL_POOL_QUADS];
+  unsigned c[DDRL_POOL_QUADS];
+  float2 g[DDRL_POOL_QUADS];
+  bool live[DDRL_POOL_QUADS];
+#pragma unroll
+  for (int k = 0; k < DDRL_POOL_QUADS; ++k) {
+    IT p = ((IT)blockIdx.x * DDRL_POOL_QUADS + k) * 256 + threadIdx.x;
+    live[k] = p < pairs;
+    p = live[k] ? p : pairs - 1;
+    const IT rp = p / pw, xp = p - rp * pw;
+    off[k] = rp * (IT)(2 * W) + 4 * xp;
+    c[k] = *(const uint16_t*)(code + 2 * p);
+    g[k] = *(const float2*)(dpool + 2 * p);
+  }
+#pragma unroll
+  for (int k = 0; k < DDRL_POOL_QUADS; ++k) {
+    const unsigned c0 = c[k] & 255u, c1 = c[k] >> 8;
+    const float x0 = (c0 & 4) ? g[k].x : 0.0f, x1 = (c1 & 4) ? g[k].y : 0.0f;
+    if (live[k]) {
+      *(float4*)(dz + off[k]) = make_float4((c0 & 3) == 0 ? x0 : 0.0f, (c0 & 3) == 1 ? x0 : 0.0f, (c1 & 3) == 0 ? x1 : 0.0f,
+                                            (c1 & 3) == 1 ? x1 : 0.0f);
+      *(float4*)(dz + off[k] + W) = make_float4((c0 & 3) == 2 ? x0 : 0.0f, (c0 & 3) == 3 ? x0 : 0.0f, (c1 & 3) == 2 ? x1 : 0.0f,
+                                                (c1 & 3) == 3 ? x1 : 0.0f);
+    }
+  }
+}
+
+// d(pre-activation of the conv) from d(pooled): gradient goes to the FIRST maximum of each 2x2 window (PyTorch's scan order) and only
+// where the ReLU in front of the pool was active (max > 0).  `a` = relu output (pre-pool), dz gets every element written.
+template <typename IT>
+__global__ __launch_bounds__(256) void maxpool2_relu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dpool, IT total,
+                                                                int W, float* __restrict__ dz) {
+  const IT i = (IT)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const PoolAt<IT> at(i, W);
+  const float2 r0 = *(const float2*)(a + at.in_off), r1 = *(const float2*)(a + at.in_off + W);
+  float m;
+  const int am = first_max(r0.x, r0.y, r1.x, r1.y, m);
   const float g = (m > 0.0f) ? dpool[i] : 0.0f;
-  dz[o] = am == 0 ? g : 0.0f;
-  dz[o + 1] = am == 1 ? g : 0.0f;
-  dz[o + W] = am == 2 ? g : 0.0f;
-  dz[o + W + 1] = am == 3 ? g : 0.0f;
+  *(float2*)(dz + at.in_off) = make_float2(am == 0 ? g : 0.0f, am == 1 ? g : 0.0f);
+  *(float2*)(dz + at.in_off + W) = make_float2(am == 2 ? g : 0.0f, am == 3 ? g : 0.0f);
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -520,15 +625,45 @@ void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, cons
   launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
 }
 
+// 32-bit index arithmetic whenever every float offset of the full-resolution tensor fits (the usual case: < 16 GiB)
+#define DDRL_POOL_LAUNCH(KERNEL, ...)                                                                               \
+  do {                                                                                                              \
+    const int64_t total = planes * (H / 2) * (W / 2);                                                               \
+    const dim3 grid((unsigned)((total + 255) / 256));                                                               \
+    if (total * 4 < ((int64_t)1 << 32) - 1024)                                                                      \
+      hipLaunchKernelGGL(KERNEL<uint32_t>, grid, dim3(256), 0, st, __VA_ARGS__);                                    \
+    else                                                                                                            \
+      hipLaunchKernelGGL(KERNEL<int64_t>, grid, dim3(256), 0, st, __VA_ARGS__);                                     \
+  } while (0)
+
 void launch_maxpool2_fwd(const float* in, int64_t planes, int H, int W, float* out, hipStream_t st) {
-  const int64_t total = planes * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, total, H, W, out);
+  DDRL_POOL_LAUNCH(maxpool2_fwd_kernel, in, total, W, out);
+}
+
+void launch_maxpool2_fwd_idx(const float* in, int64_t planes, int H, int W, float* out, uint8_t* code, hipStream_t st) {
+  DDRL_POOL_LAUNCH(maxpool2_fwd_idx_kernel, in, total, W, out, code);
+}
+
+void launch_maxpool2_bwd_idx(const float* dpool, const uint8_t* code, int64_t planes, int H, int W, float* dz, hipStream_t st) {
+  const int64_t total4 = planes * H * W / 4;  // H, W even
+  if (W % 4 == 0 && !(((uintptr_t)dpool & 7) | ((uintptr_t)code & 1))) {
+    const int64_t pairs = total4 / 2;
+    const dim3 pgrid((unsigned)((pairs + 256 * DDRL_POOL_QUADS - 1) / (256 * DDRL_POOL_QUADS)));
+    if (total4 * 4 < ((int64_t)1 << 32) - 1024)
+      hipLaunchKernelGGL(maxpool2_bwd_idx_pairs_kernel<uint32_t>, pgrid, dim3(256), 0, st, dpool, code, (uint32_t)pairs, W, dz);
+    else
+      hipLaunchKernelGGL(maxpool2_bwd_idx_pairs_kernel<int64_t>, pgrid, dim3(256), 0, st, dpool, code, pairs, W, dz);
+    return;
+  }
+  const dim3 grid((unsigned)((total4 + 256 * DDRL_POOL_QUADS - 1) / (256 * DDRL_POOL_QUADS)));
+  if (total4 * 4 < ((int64_t)1 << 32) - 1024)
+    hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<uint32_t>, grid, dim3(256), 0, st, dpool, code, (uint32_t)total4, W, dz);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<int64_t>, grid, dim3(256), 0, st, dpool, code, total4, W, dz);
 }
 
 void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes, int H, int W, float* dz, hipStream_t st) {
-  const int64_t total = planes * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, dpool, total, H, W,
-                     dz);
+  DDRL_POOL_LAUNCH(maxpool2_relu_bwd_kernel, a, dpool, total, W, dz);
 }
 
 }  // namespace ddrl

@@ -21,6 +21,8 @@ void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, cons
                        hipStream_t st);
 void launch_maxpool2_fwd(const float* in, int64_t planes, int H, int W, float* out, hipStream_t st);
 void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes, int H, int W, float* dz, hipStream_t st);
+void launch_maxpool2_fwd_idx(const float* in, int64_t planes, int H, int W, float* out, uint8_t* code, hipStream_t st);
+void launch_maxpool2_bwd_idx(const float* dpool, const uint8_t* code, int64_t planes, int H, int W, float* dz, hipStream_t st);
 
 // dconv.hip: compile-time-geometry direct convolutions for the heavy nav layers
 bool conv_has_direct(const ConvGeom& g);        // forward + data gradient

@@ -19,7 +19,7 @@ from ddrl4nav_amd import _lib
 from ddrl4nav_amd._lib import STATS_FLOATS, HeadsDesc, check
 from ddrl4nav_amd.data import Experience
 from ddrl4nav_amd.nn.base import Basenn, PreNet
-from ddrl4nav_amd.ops import Conv, Linear, maxpool2, maxpool2_relu_backward, _p, _st
+from ddrl4nav_amd.ops import Conv, Linear, maxpool2_idx, maxpool2_backward_idx, _p, _st
 from ddrl4nav_amd.utils.staging import to_device
 
 FEAT = 512
@@ -118,6 +118,8 @@ class _ConvPool:
         if pool:
             self.p = torch.empty((cap, module.out_channels, oh // 2, ow // 2), **f)
             self.dp = torch.empty_like(self.p)
+            # one decision byte per window (first maximum + ReLU sign): the backward reads it instead of the full-resolution `a`
+            self.code = torch.empty((cap, module.out_channels, oh // 2, ow // 2), dtype=torch.uint8, device=device)
         self.out_shape = (module.out_channels, oh // 2, ow // 2) if pool else (module.out_channels, oh, ow)
 
     def pack(self):
@@ -128,7 +130,7 @@ class _ConvPool:
         self.op.forward(x, self.m.bias.data, self.relu, out=self.a, n=n)
         if not self.pool:
             return self.a
-        maxpool2(self.a[:n], out=self.p)
+        maxpool2_idx(self.a[:n], out=self.p, code=self.code)
         return self.p
 
     def out_grad_buffer(self):
@@ -137,7 +139,7 @@ class _ConvPool:
 
     def backward(self, x, n, din=None):
         if self.pool:
-            maxpool2_relu_backward(self.a[:n], self.dp[:n], dz=self.dz)
+            maxpool2_backward_idx(self.dp[:n], self.code, self.a.shape[2], self.a.shape[3], dz=self.dz)
         self.op.wgrad(x, self.dz, self.m.weight.grad_view, self.m.bias.grad_view, n=n)
         if din is not None:
             self.op.dgrad(self.dz, din=din, n=n)

@@ -86,6 +86,25 @@ def maxpool2_relu_backward(a, dpool, dz=None):
     return dz
 
 
+def maxpool2_idx(x, out=None, code=None):
+    """max_pool2d(x, 2) that also leaves one decision byte per window for maxpool2_backward_idx (include/ddrl.h)."""
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    if code is None:
+        code = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=x.device)
+    check(_lib.load().ddrl_op_maxpool2_forward_idx(_p(_f32(x)), n * c, h, w, _p(out), _p(code), _st()))
+    return out, code
+
+
+def maxpool2_backward_idx(dpool, code, h, w, dz=None):
+    n, c = dpool.shape[:2]
+    if dz is None:
+        dz = torch.empty((n, c, h, w), dtype=torch.float32, device=dpool.device)
+    check(_lib.load().ddrl_op_maxpool2_backward_idx(_p(_f32(dpool)), _p(code), n * c, h, w, _p(dz), _st()))
+    return dz
+
+
 class Linear:
     """One nn.Linear(K, N) (+ReLU) layer; weight [N][K]."""
 

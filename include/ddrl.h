@@ -320,10 +320,19 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
 
 /* F.max_pool2d(x, 2, stride=2) over `planes` = n*c planes of h x w (both even), and its backward
  * fused with the ReLU that precedes it in the reference (`a` = relu(conv) at full resolution):
- * dz = dpool routed to the first maximum of each window (PyTorch scan order), zero where a <= 0. */
+ * dz = dpool routed to the first maximum of each window (PyTorch scan order), zero where a <= 0.
+ * The full-resolution pointers (in, a, dz) must be 8-byte aligned (INVALID_ARG otherwise). */
 int32_t ddrl_op_maxpool2_forward(const float* in, int64_t planes, int32_t h, int32_t w, float* out, void* stream);
 int32_t ddrl_op_maxpool2_relu_backward(const float* a, const float* dpool, int64_t planes, int32_t h, int32_t w,
                                        float* dz, void* stream);
+
+/* The same pair with the decisions kept in ONE BYTE per window (round 4): the forward also writes code[planes][h/2][w/2] (bits 0-1 =
+ * position of the first maximum in PyTorch's scan order, bit 2 = the maximum is positive, i.e. the ReLU in front of the pool lets the
+ * gradient through); the backward reads dpool and the code instead of the full-resolution activations (1.31 instead of 2.25 tensor
+ * sizes of HBM traffic) and writes the same dz as ddrl_op_maxpool2_relu_backward.  Same alignment rule for `in`; dz 16-byte aligned. */
+int32_t ddrl_op_maxpool2_forward_idx(const float* in, int64_t planes, int32_t h, int32_t w, float* out, uint8_t* code, void* stream);
+int32_t ddrl_op_maxpool2_backward_idx(const float* dpool, const uint8_t* code, int64_t planes, int32_t h, int32_t w, float* dz,
+                                      void* stream);
 
 /* nn.Linear(K, N) (+ReLU): out[b][:] = act(in[b][:K] W^T + bias).  Leading dimensions are
  * multiples of 4 floats (>= K rounded up to 4), pointers 16-byte aligned, N a multiple of 4;

@@ -96,7 +96,7 @@ def test_conv_strided_sample_layout():
 
 @pytest.mark.parametrize("planes_hw", [((3, 5), 44, 44), ((2, 7), 20, 20), ((1, 1), 2, 2), ((4, 3), 10, 6)])
 def test_maxpool_relu_pair_vs_torch(planes_hw):
-    from ddrl4nav_amd.ops import maxpool2, maxpool2_relu_backward
+    from ddrl4nav_amd.ops import maxpool2, maxpool2_relu_backward, maxpool2_idx, maxpool2_backward_idx
     (n, c), h, w = planes_hw
     g = torch.Generator().manual_seed(h * 100 + w)
     z = torch.randn(n, c, h, w, generator=g)
@@ -110,6 +110,11 @@ def test_maxpool_relu_pair_vs_torch(planes_hw):
     ad = a.detach().cuda()
     assert torch.equal(maxpool2(ad).cpu(), pooled.detach())
     assert torch.equal(maxpool2_relu_backward(ad, dpool.cuda()).cpu(), z.grad)
+    # the pair that keeps one decision byte per window instead of re-reading the activations
+    out, code = maxpool2_idx(ad)
+    assert torch.equal(out.cpu(), pooled.detach())
+    assert int(code.max()) < 8
+    assert torch.equal(maxpool2_backward_idx(dpool.cuda(), code, h, w).cpu(), z.grad)
 
 
 LINEARS = [(300, 7616, 256), (257, 6400, 512), (130, 773, 512), (64, 512, 512), (1, 512, 512), (33, 4, 128), (5, 37, 12)]
