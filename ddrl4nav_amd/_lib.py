@@ -116,7 +116,7 @@ SIGNATURES = {
     "ddrl_op_linear_forward": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
                                          c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_linear_dgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
-                                       c_int32, c_void_p]),
+                                       c_int32, c_void_p, c_void_p]),
     "ddrl_op_linear_ws_floats": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_int64)]),
     "ddrl_op_linear_wgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_int32, c_void_p]),

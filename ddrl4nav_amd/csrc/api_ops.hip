@@ -173,6 +173,10 @@ int32_t ddrl_op_linear_pack_floats(int32_t K, int32_t N, int64_t* wt_floats, int
   if (!lin_ok(1, K, N) || !wt_floats || !wn_floats) return DDRL_ERR_INVALID_ARG;
   *wt_floats = (int64_t)((K + 31) / 32 * 32) * N;
   *wn_floats = (int64_t)N * ((K + 3) / 4 * 4);
+  if (linear_has_planes(K, N)) {  // the fp16 plane layouts of plin.hip follow the f32 layouts (both regions start 16-byte aligned)
+    *wt_floats += linear_planes_fwd_floats(K, N);
+    *wn_floats += linear_planes_dgrad_floats(K, N);
+  }
   return DDRL_OK;
 }
 
@@ -191,16 +195,20 @@ int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, 
 }
 
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, void* stream) {
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, void* stream) {
   if (!lin_ok(n, K, N) || !dout || !wn || !din) return DDRL_ERR_INVALID_ARG;
   if ((ld_dout & 3) || ld_dout < N || ld_din < K || !aligned16(dout) || !aligned16(wn)) return DDRL_ERR_INVALID_ARG;
-  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, (hipStream_t)stream);
+  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, ws, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats) {
   if (!lin_ok(n, K, N) || !floats) return DDRL_ERR_INVALID_ARG;
-  const int64_t wg = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);   // non-decreasing in n
+  int64_t wg = (int64_t)linear_wgrad_splits(n, K, N) * ((int64_t)N * K + N);   // non-decreasing in n
+  if (linear_has_planes(K, N)) {  // plin.hip's split counts (non-decreasing in n as well)
+    const int64_t wp = (int64_t)linear_planes_wgrad_splits(n, K, N) * ((int64_t)N * K + N);
+    if (wp > wg) wg = wp;
+  }
   // split-K partials of the forward: splits(n') * n' * N floats for a launch of n' <= n samples.  FEWER samples take MORE splits
   // (the split count fills the chip), so the product is NOT largest at n' = n: with tn = ceil(N / 128) column tiles,
   // splits(n') <= min(cap_K, ceil(512 / (tn ceil(n' / 128)))) gives splits(n') n' <= min(cap_K n, 65536 / tn + n).  (Sizing by n alone
@@ -210,7 +218,8 @@ int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* float
   if (cap_k < 1) cap_k = 1;
   const int64_t by_k = cap_k * (int64_t)n, by_fill = 65536 / tn + (int64_t)n + 128;
   const int64_t fw = (by_k < by_fill ? by_k : by_fill) * N;
-  *floats = wg > fw ? wg : fw;
+  // + the per-row plane scales of plin.hip: n floats (rounded up to 64) in front of the forward's partials, 2 n behind the slabs
+  *floats = (wg > fw ? wg : fw) + 2 * (int64_t)n + 128;
   return DDRL_OK;
 }
 

@@ -367,7 +367,11 @@ void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, 
                      width);
 }
 
+static int64_t wt_f32_floats(int K, int N) { return (int64_t)((K + 31) / 32 * 32) * N; }
+static int64_t wn_f32_floats(int K, int N) { return (int64_t)N * ((K + 3) / 4 * 4); }
+
 void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st) {
+  if (linear_has_planes(K, N)) launch_linear_planes_pack(w, K, N, wt + wt_f32_floats(K, N), wn + wn_f32_floats(K, N), st);
   const int Kp32 = (K + 31) / 32 * 32, Kp4 = (K + 3) / 4 * 4;
   const int64_t total = (int64_t)N * (Kp32 > Kp4 ? Kp32 : Kp4);
   hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N, Kp32, Kp4, wt, wn);
@@ -396,8 +400,17 @@ int linear_fwd_splits(int n, int K, int N) {
   return s < 1 ? 1 : s;
 }
 
+void launch_linear_finish(const float* part, int nsplit, int n, int N, const float* bias, int act, float* out, int64_t ld_out, hipStream_t st) {
+  hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)(((int64_t)n * N + 255) / 256)), dim3(256), 0, st, part, nsplit, (int64_t)n, N,
+                     bias, act, out, ld_out);
+}
+
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
                        int K, int N, int act, float* part, hipStream_t st) {
+  if (part && linear_uses_planes(n, K, N)) {
+    launch_linear_planes_fwd(in, ld_in, wt + wt_f32_floats(K, N), bias, out, ld_out, n, K, N, act, part, st);
+    return;
+  }
   const int S = part ? linear_fwd_splits(n, K, N) : 1;
   glin::Fwd::Params p{in, ld_in, wt, bias, out, ld_out, n, K, N, act, S, part};
   launch_engine2<glin::Fwd>(dim3((N + 127) / 128, (n + 127) / 128, S), p, st);
@@ -407,7 +420,11 @@ void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const fl
 }
 
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                         float* din, int64_t ld_din, int n, int K, int N, hipStream_t st) {
+                         float* din, int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st) {
+  if (ws && linear_uses_planes(n, K, N)) {
+    launch_linear_planes_dgrad(dout, ld_dout, wn + wn_f32_floats(K, N), mask_src, ld_mask, din, ld_din, n, K, N, ws, st);
+    return;
+  }
   glin::Dgrad::Params p{dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, (K + 3) / 4 * 4};
   launch_engine2<glin::Dgrad>(dim3((K + 127) / 128, (n + 127) / 128, 1), p, st);
 }
@@ -423,6 +440,10 @@ int linear_wgrad_splits(int n, int K, int N) {
 
 void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
                          float* dw, float* db, hipStream_t st) {
+  if (linear_uses_planes(n, K, N)) {
+    launch_linear_planes_wgrad(in, ld_in, dout, ld_dout, part, n, K, N, dw, db, st);
+    return;
+  }
   const int S = linear_wgrad_splits(n, K, N);
   glin::Wgrad::Params p{dout, ld_dout, in, ld_in, part, n, K, N, S};
   launch_engine2<glin::Wgrad>(dim3((K + 127) / 128, (N + 127) / 128, S), p, st);

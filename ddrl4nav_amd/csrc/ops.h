@@ -58,10 +58,31 @@ int linear_fwd_splits(int n, int K, int N);
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
                        int K, int N, int act, float* part, hipStream_t st);
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                         float* din, int64_t ld_din, int n, int K, int N, hipStream_t st);
+                         float* din, int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st);
 int linear_wgrad_splits(int n, int K, int N);
 void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
                          float* dw, float* db, hipStream_t st);
+
+void launch_linear_finish(const float* part, int nsplit, int n, int N, const float* bias, int act, float* out, int64_t ld_out, hipStream_t st);
+
+// plin.hip: the same three operators on the 16-bit matrix pipe (two scaled fp16 planes per operand, per-row activation scales) for layers
+// of K >= 128, N >= 64 and launches of n >= 128 rows; packed plane regions follow the f32 layouts inside wt / wn
+bool linear_has_planes(int K, int N);
+bool linear_uses_planes(int n, int K, int N);
+int64_t linear_planes_fwd_floats(int K, int N);
+int64_t linear_planes_dgrad_floats(int K, int N);
+void launch_linear_planes_pack(const float* w, int K, int N, float* pf, float* pd, hipStream_t st);
+int linear_planes_fwd_splits(int n, int K, int N);
+// ws: n floats rounded up to 64 (row scales), then linear_planes_fwd_splits * n * N partials
+void launch_linear_planes_fwd(const float* in, int64_t ld_in, const float* pf, const float* bias, float* out, int64_t ld_out, int n, int K,
+                              int N, int act, float* ws, hipStream_t st);
+// ws: n floats
+void launch_linear_planes_dgrad(const float* dout, int64_t ld_dout, const float* pd, const float* mask_src, int64_t ld_mask, float* din,
+                                int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st);
+int linear_planes_wgrad_splits(int n, int K, int N);
+// part: linear_planes_wgrad_splits slabs of N * K + N floats, then 2 n floats
+void launch_linear_planes_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
+                                float* dw, float* db, hipStream_t st);
 
 // gheads.hip: Gaussian actor + critic heads; offsets into the caller's flat parameter arena
 struct GaussLayout {

@@ -129,8 +129,9 @@ class Linear:
         return out
 
     def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n):
+        assert n <= self.max_n
         check(self.lib.ddrl_op_linear_dgrad(_p(dout), ld_dout, _p(self.wn), _p(mask_src), ld_mask, _p(din), ld_din, n,
-                                            self.K, self.N, _st()))
+                                            self.K, self.N, _p(self.ws), _st()))
         return din
 
     def wgrad(self, x, ld_in, dout, ld_dout, dw, db, n):

@@ -345,9 +345,10 @@ int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, flo
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act,
                                float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, void* stream);
 /* din[b][k] = [mask_src[b][k] > 0 or mask_src == NULL] * sum_n dout[b][n] W[n][k]; mask_src is the
- * (ReLU) output of the layer that produced `in`. */
+ * (ReLU) output of the layer that produced `in`.  ws: the same scratch as the forward's (the 16-bit plane kernels of layers with
+ * K >= 128, N >= 64 keep their per-row scales there for launches of n >= 128 rows), or NULL for the f32-input kernels. */
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, void* stream);
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, void* stream);
 int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats);
 /* dw [N][K] = dout^T in, db [N] = column sums of dout (overwritten) */
 int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,

@@ -101,7 +101,11 @@ def test_operator_abi_host_side_queries():
     assert lib.ddrl_op_conv_out_shape(byref(bad), byref(oh), byref(ow)) == -1
     a, b = c_int64(), c_int64()
     _lib.check(lib.ddrl_op_linear_pack_floats(773, 512, byref(a), byref(b)))
-    assert a.value == 800 * 512 and b.value == 512 * 776
+    # the f32 layouts, followed by the 16-bit plane layouts of csrc/plin.hip (K >= 128, N >= 64): [column tile 128][k-groups of 16,
+    # an even number][2 planes][128][16] halves + a 64-float header
+    assert a.value == 800 * 512 + (4 * 50 * 4096 // 2 + 64) and b.value == 512 * 776 + (7 * 32 * 4096 // 2 + 64)
+    _lib.check(lib.ddrl_op_linear_pack_floats(37, 12, byref(a), byref(b)))       # a small layer keeps the f32 layouts only
+    assert a.value == 64 * 12 and b.value == 12 * 40
     assert lib.ddrl_op_linear_pack_floats(16, 6, byref(a), byref(b)) == -1  # N must be a multiple of 4
     _lib.check(lib.ddrl_op_linear_ws_floats(1024, 7616, 256, byref(f)))
     assert f.value >= 7616 * 256 + 256

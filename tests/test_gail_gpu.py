@@ -76,11 +76,15 @@ def test_gail_forward_two_critics_and_discriminator_reward(golden, name):
     d = net((states, acts.reshape(B, 1)))
     assert d.shape == (B, 1)
     np.testing.assert_allclose(d.cpu().numpy()[:, 0], g["d_reward"], rtol=2e-5, atol=2e-6)
-    # micro-batched evaluation gives the same scores
+    # micro-batched evaluation gives the same scores: to the bit while every launch takes the same kernels, to fp32 rounding when
+    # the 48-row launches fall below the 128 rows from which dense layers run on the 16-bit plane kernels (csrc/plin.hip)
     net.discriminator.cap, cap = 48, net.discriminator.cap
     d2 = net((states, acts.reshape(B, 1)))
     net.discriminator.cap = cap
-    assert torch.equal(d, d2)
+    if B < 128:
+        assert torch.equal(d, d2)
+    else:
+        np.testing.assert_allclose(d2.cpu().numpy(), d.cpu().numpy(), rtol=2e-6, atol=2e-7)
 
 
 def _enc_signs(pre, n):

@@ -117,7 +117,8 @@ def test_maxpool_relu_pair_vs_torch(planes_hw):
     assert torch.equal(maxpool2_backward_idx(dpool.cuda(), code, h, w).cpu(), z.grad)
 
 
-LINEARS = [(300, 7616, 256), (257, 6400, 512), (130, 773, 512), (64, 512, 512), (1, 512, 512), (33, 4, 128), (5, 37, 12)]
+LINEARS = [(300, 7616, 256), (257, 6400, 512), (130, 773, 512), (64, 512, 512), (1, 512, 512), (33, 4, 128), (5, 37, 12),
+           (1100, 1024, 192), (128, 128, 64)]  # several row tiles + split K; the smallest layer / launch of the 16-bit plane kernels
 
 
 @pytest.mark.parametrize("shape", LINEARS)
@@ -154,6 +155,41 @@ def test_linear_forward_backward_vs_torch(shape):
     lin.wgrad(xd, ld_in, dzd, N, dw, db, n)
     close(dw, wt.grad)
     close(db, b.grad)
+
+
+def test_linear_rows_of_very_different_magnitude_keep_their_precision():
+    """The plane kernels of the dense layers (csrc/plin.hip) scale every ROW of the activations / gradients by its own power of two:
+    a sample 1e-6 below the batch's largest keeps fp32 accuracy relative to ITSELF, an all-zero sample does not pin the batch scale
+    of the weight gradient."""
+    from ddrl4nav_amd.ops import Linear
+    n, K, N = 384, 1536, 256
+    g = torch.Generator().manual_seed(5)
+    mag = 10.0 ** (torch.rand(n, 1, generator=g, dtype=torch.float64) * 8.0 - 6.0)
+    mag[7] = 0.0
+    x = (torch.relu(torch.randn(n, K, generator=g, dtype=torch.float64)) * mag).float()
+    dz = (torch.randn(n, N, generator=g, dtype=torch.float64) * mag.flip(0)).float()
+    wt = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.zeros(N)
+    lin = Linear(K, N, max_n=n)
+    lin.pack(wt.cuda())
+    out = torch.empty(n, N).cuda()
+    lin.forward(x.cuda(), K, b.cuda(), False, out, N, n)
+    want = x.double() @ wt.double().t()
+    row = want.abs().amax(1, keepdim=True).clamp_min(1e-300)
+    assert float(((out.cpu().double() - want).abs() / row).max()) < 2e-6      # per row, not per batch
+    assert float(out[7].abs().max()) == 0.0
+    din = torch.empty(n, K).cuda()
+    lin.dgrad(dz.cuda(), N, None, 0, din, K, n)
+    want = dz.double() @ wt.double()
+    row = want.abs().amax(1, keepdim=True).clamp_min(1e-300)
+    assert float(((din.cpu().double() - want).abs() / row).max()) < 2e-6
+    dw, db = torch.empty(N, K).cuda(), torch.empty(N).cuda()
+    lin.wgrad(x.cuda(), K, dz.cuda(), N, dw, db, n)
+    want = dz.double().t() @ x.double()
+    ref32 = dz.t() @ x                                                       # torch fp32 on the CPU
+    err, err32 = (dw.cpu().double() - want).abs().max().item(), (ref32.double() - want).abs().max().item()
+    assert err <= 2.0 * err32 + 1e-30, (err, err32)
+    close(db, dz.double().sum(0).float())
 
 
 def test_ops_reject_bad_arguments():
