@@ -49,6 +49,15 @@ int conv_planes_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no pla
 // part: conv_planes_wgrad_splits slabs of cout * cin * kh * kw + cout floats, then 2 n floats (per-sample scales of this launch)
 void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
 
+// fconv.hip: the 3-channel 7x7 first layer of NavPreNet1D as fp16 plane products (forward + weight gradient; per-sample / per-stage
+// scales are found inside the kernels: no scratch)
+bool conv_has_first(const ConvGeom& g);
+int64_t conv_first_pack_floats(const ConvGeom& g);
+void launch_conv_first_pack(const ConvGeom& g, const float* w, float* region, hipStream_t st);
+void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, hipStream_t st);
+int conv_first_wgrad_splits(const ConvGeom& g);  // 0 when the layer is not this one
+void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
+
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
 void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);

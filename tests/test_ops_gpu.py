@@ -20,6 +20,7 @@ def close(got, want, tol=2e-5):
 # (n, cin, h, w, cout, kh, kw, stride, pad) -- the nav encoder layers plus ragged shapes
 CONVS = [
     (5, 3, 48, 48, 64, 7, 7, 1, (1, 1)),     # NavPreNet1D.conv1
+    (300, 3, 48, 48, 64, 7, 7, 1, (1, 1)),   # the same with more samples than persistent workgroups (csrc/fconv.hip walks them)
     (3, 64, 22, 22, 128, 5, 5, 1, (1, 1)),   # NavPreNet1D.conv2
     (7, 128, 10, 10, 256, 3, 3, 1, (1, 1)),  # NavPreNet1D.conv3
     (4, 1, 48, 48, 64, 3, 3, 1, (1, 1)),     # NavPreNet.conv1
@@ -42,6 +43,9 @@ def test_conv_forward_backward_vs_torch(shape):
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, kh, kw, generator=g) / (cin * kh * kw) ** 0.5
     b = torch.randn(cout, generator=g)
+    if n > 4:
+        x[3] *= 1e-5   # a faint and an empty input sample: per-sample input scales of the plane kernels
+        x[4] = 0.0
     x.requires_grad_(True)
     wt.requires_grad_(True)
     b.requires_grad_(True)
@@ -59,7 +63,10 @@ def test_conv_forward_backward_vs_torch(shape):
     conv.pack(wt.detach().cuda())
     xd, bd, dzd = x.detach().cuda(), b.detach().cuda(), dz.cuda()
     close(conv.forward(xd, bd, relu=True), out)
-    close(conv.forward(xd, bd, relu=False), z)
+    got = conv.forward(xd, bd, relu=False)
+    close(got, z)
+    if n > 4:   # the faint sample: bias + 1e-5-sized terms, right to the rounding of the fp32 sum (a batch-wide scale would lose the terms)
+        assert float((got[3].cpu() - z[3].detach()).abs().max()) <= 1e-6
     din = conv.dgrad(dzd)
     close(din, x.grad)
     if n > 2:   # the small sample on its own scale: per-sample relative accuracy of the data gradient
