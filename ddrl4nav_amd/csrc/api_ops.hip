@@ -120,6 +120,27 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
   return op_check();
 }
 
+int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d) {
+  ConvGeom g;
+  if (!fill_geom(d, g)) return 0;
+  return (conv_has_first(g) || (conv_has_planes(g) && conv_planes_has_pool(g))) ? 1 : 0;
+}
+
+int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
+                                  uint8_t* code, void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !in || !packed || !bias || !pooled || !code) return DDRL_ERR_INVALID_ARG;
+  if ((g.in_sn & 3) || !aligned16(in)) return DDRL_ERR_INVALID_ARG;
+  const PackView v = pack_view(g);
+  if (conv_has_first(g))
+    launch_conv_first_fwd_pool(g, in, packed + v.off[5], bias, pooled, code, (hipStream_t)stream);
+  else if (conv_has_planes(g) && conv_planes_has_pool(g))
+    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], const_cast<float*>(packed) + v.off[7], bias, pooled, code, (hipStream_t)stream);
+  else
+    return DDRL_ERR_UNSUPPORTED;  // the caller runs ddrl_op_conv_forward + ddrl_op_maxpool2_forward_idx
+  return op_check();
+}
+
 int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;

@@ -445,6 +445,11 @@ __device__ __forceinline__ void split_bf16x3(float x, float y, unsigned& p0, uns
 // the six plane products of a k-group under three bf16 planes per operand, smallest first: (a plane, b plane)
 #define DDRL_BF16X6_PRODUCTS constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0}
 
+// the value the neighbouring lane (lane ^ 1) holds: one DPP move (quad_perm [1, 0, 3, 2]), no LDS traffic
+__device__ __forceinline__ float lane_swap1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // ---- plane scheme of the kernels with TWO fp32 operands -----------------------------------------------------------

@@ -43,6 +43,9 @@ struct FGeo {
   static constexpr int W_BYTES = NKG * NPL * 64 * 32;        // [k-group][plane][oc 64][lane half 2][8 k] fp16
   // ---- forward
   static constexpr int FW_WAVES = 8, FW_TN = 4, FW_TILES = (P + 31) / 32, FW_PASSES = (FW_TILES + FW_WAVES * FW_TN - 1) / (FW_WAVES * FW_TN);
+  // pooled epilogue: the upper rows of the row pairs as one stream of OH / 2 x OH pixels, two stream tiles (x 2 rows) per wave and pass
+  static constexpr int OW2 = OH / 2, PW = OW2 * OW2, STREAM = OW2 * OH;
+  static constexpr int FWP_PASSES = ((STREAM + 31) / 32 + FW_WAVES * (FW_TN / 2) - 1) / (FW_WAVES * (FW_TN / 2));
   static constexpr int LPX_F = OH + 8;                       // columns a fragment may touch: ox + 7 + 1
   static constexpr int IMG_F_PLANE = LPY * LPX_F * 8, IMG_F = NPL * IMG_F_PLANE;
   static constexpr int F_IMG_OFF = W_BYTES, F_BIAS_OFF = F_IMG_OFF + 2 * IMG_F, F_RED_OFF = F_BIAS_OFF + 64 * 4;
@@ -115,10 +118,17 @@ __device__ __forceinline__ void commit_quad(char* img, int plane_bytes, const f4
   }
 }
 
-template <class K>
+// POOL: ReLU + max_pool2d(2) in the epilogue.  The column tiles of a wave then come in PAIRS over the same 32 consecutive pixels of
+// the upper and the lower row of a row pair (the pixels of all upper rows form one stream of OH / 2 x OH elements; OH is even, so
+// lanes 2 m and 2 m + 1 always hold the two columns of one pooling window): a window's four activations are two accumulators of a
+// lane and the same two of its neighbour (one DPP move each), and neighbouring lanes still read neighbouring pixels (lane = window
+// would double the stride of the fragment reads: two-way bank conflicts, measured).  `out` receives the pooled map
+// [oc][OH / 2][OH / 2], `code` one decision byte per window (gconv.hip maxpool2_fwd_idx_kernel: first maximum in PyTorch's scan
+// order + sign); the full-resolution activations are never written.
+template <class K, bool POOL>
 __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
                                                         const float* __restrict__ whdr, const float* __restrict__ bias, int act,
-                                                        float* __restrict__ out, int64_t out_sn, int n) {
+                                                        float* __restrict__ out, int64_t out_sn, uint8_t* __restrict__ code, int n) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_u(), l31 = lane & 31, hi = lane >> 5;
   float* lbias = (float*)(lds + K::F_BIAS_OFF);
@@ -180,11 +190,16 @@ __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict_
     const float inv = winv / sc_cur;
     float* obase = out + (int64_t)b * out_sn;
 #pragma unroll 1
-    for (int pass = 0; pass < K::FW_PASSES; ++pass) {
+    for (int pass = 0; pass < (POOL ? K::FWP_PASSES : K::FW_PASSES); ++pass) {
       int bB[K::FW_TN], pix[K::FW_TN];
 #pragma unroll
       for (int j = 0; j < K::FW_TN; ++j) {
-        pix[j] = ((pass * K::FW_WAVES + wave) * K::FW_TN + j) * 32 + l31;
+        if (POOL) {  // tiles (2 jj, 2 jj + 1) = stream elements q .. of the upper / lower rows
+          const int q = ((pass * K::FW_WAVES + wave) * (K::FW_TN / 2) + (j >> 1)) * 32 + l31;
+          pix[j] = q < K::STREAM ? (2 * (q / K::OH) + (j & 1)) * K::OH + q % K::OH : K::P;
+        } else {
+          pix[j] = ((pass * K::FW_WAVES + wave) * K::FW_TN + j) * 32 + l31;
+        }
         const int p = pix[j] < K::P ? pix[j] : 0;
         bB[j] = ((p / K::OH) * K::LPX_F + p % K::OH + 2 * hi) * 8;
       }
@@ -195,41 +210,89 @@ __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict_
         for (int j = 0; j < K::FW_TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      // one kernel row (two k-groups) per trip: the loop bounds how far ahead the scheduler pulls fragment reads (fully unrolled, the
+      // fourteen k-groups spilled 72 - 288 registers); the row offsets are wave-uniform adds, the kx half stays an immediate
+#pragma unroll 1
+      for (int ky = 0; ky < K::KS; ++ky) {
+        const char* wrow = lds + ky * (2 * NPL * 2048);
+        const char* irow = img + ky * (K::LPX_F * 8);
 #pragma unroll
-      for (int kg = 0; kg < K::NKG; ++kg) {
-        const int toff = ((kg >> 1) * K::LPX_F + 4 * (kg & 1)) * 8;
-        frag8 af[NPL][2], bf[NPL][K::FW_TN];
+        for (int h4 = 0; h4 < 2; ++h4) {
+          frag8 af[NPL][2], bf[NPL][K::FW_TN];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
+          for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(lds + aA[i] + (kg * NPL + p) * 2048);
+            for (int i = 0; i < 2; ++i) af[p][i] = *(const frag8*)(wrow + aA[i] + (h4 * NPL + p) * 2048);
 #pragma unroll
-          for (int j = 0; j < K::FW_TN; ++j) {
-            const char* s = img + p * K::IMG_F_PLANE + bB[j] + toff;  // 8-byte aligned: two 8-byte reads
-            const u2v lo = *(const u2v*)s, hh = *(const u2v*)(s + 8);
-            bf[p][j] = __builtin_bit_cast(frag8, (u4v){lo.x, lo.y, hh.x, hh.y});
+            for (int j = 0; j < K::FW_TN; ++j) {
+              const char* s = irow + p * K::IMG_F_PLANE + bB[j] + h4 * 32;  // 8-byte aligned: two 8-byte reads
+              const u2v lo = *(const u2v*)s, hh = *(const u2v*)(s + 8);
+              bf[p][j] = __builtin_bit_cast(frag8, (u4v){lo.x, lo.y, hh.x, hh.y});
+            }
           }
-        }
-        DDRL_PLANE_PRODUCTS;
+          DDRL_PLANE_PRODUCTS;
 #pragma unroll
-        for (int m = 0; m < NPROD; ++m)
+          for (int m = 0; m < NPROD; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < K::FW_TN; ++j) acc[i][j] = mfma_planes(af[PA[m]][i], bf[PB[m]][j], acc[i][j]);
+        }
+      }
+      if (POOL) {
+        uint8_t* cbase = code + (int64_t)b * (64 * K::PW);
+#pragma unroll
+        for (int jj = 0; jj < K::FW_TN / 2; ++jj) {
+          const int top = pix[2 * jj];                                             // this lane's pixel of the upper row
+          const int win = (top / K::OH / 2) * K::OW2 + (top % K::OH) / 2;
+          const bool writer = top < K::P && !(lane & 1);
+          // every lane takes part in the exchange; the even lanes then store under ONE predicate (a branch per store costs more than
+          // the stores: measured)
+          float pm[2][16];
+          int pc[2][16];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < K::FW_TN; ++j) acc[i][j] = mfma_planes(af[PA[m]][i], bf[PB[m]][j], acc[i][j]);
-      }
+            for (int r = 0; r < 16; ++r) {
+              const int oc = i * 32 + acc_row(r, hi);
+              const float v0 = fmaxf(__builtin_fmaf(acc[i][2 * jj][r], inv, lbias[oc]), 0.0f);
+              const float v2 = fmaxf(__builtin_fmaf(acc[i][2 * jj + 1][r], inv, lbias[oc]), 0.0f);
+              const float v1 = lane_swap1(v0), v3 = lane_swap1(v2);               // the window's right column, from the odd lane
+              float m = v0;
+              int am = 0;
+              if (v1 > m) { m = v1; am = 1; }
+              if (v2 > m) { m = v2; am = 2; }
+              if (v3 > m) { m = v3; am = 3; }
+              pm[i][r] = m;
+              pc[i][r] = am | (m > 0.0f ? 4 : 0);
+            }
+          if (writer) {
+            float* op = obase + 4 * hi * K::PW + win;
+            uint8_t* cp = cbase + 4 * hi * K::PW + win;
 #pragma unroll
-      for (int j = 0; j < K::FW_TN; ++j) {
-        if (pix[j] >= K::P) continue;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int oc = i * 32 + acc_row(r, hi);
-            float v = __builtin_fmaf(acc[i][j][r], inv, lbias[oc]);
-            if (act == 1) v = fmaxf(v, 0.0f);
-            obase[(int64_t)oc * K::P + pix[j]] = v;
+              for (int r = 0; r < 16; ++r) {
+                const int ro = (i * 32 + (r & 3) + 8 * (r >> 2)) * K::PW;
+                op[ro] = pm[i][r];
+                cp[ro] = (uint8_t)pc[i][r];
+              }
           }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < K::FW_TN; ++j) {
+          if (pix[j] >= K::P) continue;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int oc = i * 32 + acc_row(r, hi);
+              float v = __builtin_fmaf(acc[i][j][r], inv, lbias[oc]);
+              if (act == 1) v = fmaxf(v, 0.0f);
+              obase[(int64_t)oc * K::P + pix[j]] = v;
+            }
+        }
       }
     }
     // ---- the next sample: its maxima, then its planes into the other image (released by the barrier that ended the previous round)
@@ -445,12 +508,26 @@ void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* regi
   using K = FN1dC1;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
+    (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
     configured = true;
   }
   const int grid = g.n < 256 ? g.n : 256;  // one persistent workgroup per CU walks the samples
-  hipLaunchKernelGGL(fconv::first_fwd_kernel<K>, dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
-                     region + K::W_BYTES / 4, bias, act, out, g.out_sn, g.n);
+  hipLaunchKernelGGL((fconv::first_fwd_kernel<K, false>), dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
+                     region + K::W_BYTES / 4, bias, act, out, g.out_sn, (uint8_t*)nullptr, g.n);
+}
+
+// conv + ReLU + max_pool2d(2): pooled [n][64][OH / 2][OH / 2] (dense), code = one decision byte per window
+void launch_conv_first_fwd_pool(const ConvGeom& g, const float* in, const float* region, const float* bias, float* pooled, uint8_t* code,
+                                hipStream_t st) {
+  using K = FN1dC1;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
+    configured = true;
+  }
+  const int grid = g.n < 256 ? g.n : 256;
+  hipLaunchKernelGGL((fconv::first_fwd_kernel<K, true>), dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
+                     region + K::W_BYTES / 4, bias, 1, pooled, (int64_t)64 * K::PW, code, g.n);
 }
 
 int conv_first_wgrad_splits(const ConvGeom& g) {

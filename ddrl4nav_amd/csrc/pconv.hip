@@ -101,11 +101,17 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
   for (int p = 0; p < NPL; ++p) d[p * 1024] = pl[p];
 }
 
-template <class K>
+// POOL (forward of a layer that is followed by ReLU + max_pool2d(2); TN = 4): the column tiles of a wave come in PAIRS over the
+// same 32 consecutive pixels of the upper and the lower row of a row pair (the upper rows of the NS samples form one stream of
+// NS x OH / 2 x OH pixels; OH is even, so lanes 2 m and 2 m + 1 hold the two columns of one pooling window and neighbouring lanes
+// still read neighbouring pixels), the epilogue takes the window's maximum over two accumulators of the lane and the same two of its
+// neighbour (one DPP move each) and writes the pooled map [oc][OH / 2][OH / 2] + one decision byte per window (gconv.hip
+// maxpool2_fwd_idx_kernel); the full-resolution activations are never written.
+template <class K, bool POOL = false>
 __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
                                                                    const float* __restrict__ whdr, const float* __restrict__ scales,
                                                                    const float* __restrict__ bias, int act, float* __restrict__ out,
-                                                                   int64_t out_sn, int n) {
+                                                                   int64_t out_sn, uint8_t* __restrict__ code, int n) {
   extern __shared__ __attribute__((aligned(16))) char ldsp[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b0 = blockIdx.x * K::NS, rt = blockIdx.y;
@@ -130,12 +136,19 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
   int aA[2], bB[K::TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i) aA[i] = K::W_OFF + (i * 32 + l31) * 32 + hi * 16;
+  constexpr int OW2 = K::OH / 2, PW = OW2 * OW2, SPS = OW2 * K::OH;  // POOL: stream elements (upper-row pixels) per sample
 #pragma unroll
   for (int j = 0; j < K::TN; ++j) {
-    int c = wc * (32 * K::TN) + j * 32 + l31;
-    if (c >= K::COLS) c = 0;
-    const int s = c / K::P, pix = c % K::P;
-    bB[j] = (s * K::LPP + (pix / K::OH) * K::LP + pix % K::OH) * K::PIXB + hi * 16;
+    if (POOL) {  // tiles (2 jj, 2 jj + 1) = stream elements q .. of the upper / lower rows
+      const int q0 = (wc * (K::TN / 2) + (j >> 1)) * 32 + l31, q = q0 < K::NS * SPS ? q0 : 0;
+      const int s = q / SPS, e = q % SPS;
+      bB[j] = (s * K::LPP + (2 * (e / K::OH) + (j & 1)) * K::LP + e % K::OH) * K::PIXB + hi * 16;
+    } else {
+      int c = wc * (32 * K::TN) + j * 32 + l31;
+      if (c >= K::COLS) c = 0;
+      const int s = c / K::P, pix = c % K::P;
+      bB[j] = (s * K::LPP + (pix / K::OH) * K::LP + pix % K::OH) * K::PIXB + hi * 16;
+    }
   }
   float ir[K::NIJ][K::KOC];
   f4 wr[K::NWJ];
@@ -225,6 +238,48 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
   const float* lbias = (const float*)(ldsp + K::BIAS_OFF);
   const float* lsc = (const float*)(ldsp + K::SC_OFF);
   const float winv = 1.0f / whdr[1];
+  if constexpr (POOL) {
+    static_assert(K::TN % 2 == 0 && K::WAVES * (K::TN / 2) * 32 >= K::NS * SPS && K::OH % 2 == 0, "tile pairs over the stream of upper-row pixels");
+#pragma unroll
+    for (int jj = 0; jj < K::TN / 2; ++jj) {
+      const int q = (wc * (K::TN / 2) + jj) * 32 + l31;
+      const int s = q / SPS, e = q % SPS, wl = (e / K::OH) * OW2 + (e % K::OH) / 2;
+      const bool writer = q < K::NS * SPS && b0 + s < n && !(lane & 1);
+      const float inv = winv / lsc[min(s, K::NS - 1)];
+      // every lane takes part in the exchange; the even lanes then store under ONE predicate
+      float pm[2][16];
+      int pc[2][16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + acc_row(r, hi);
+          const float v0 = fmaxf(__builtin_fmaf(acc[i][2 * jj][r], inv, lbias[row]), 0.0f);
+          const float v2 = fmaxf(__builtin_fmaf(acc[i][2 * jj + 1][r], inv, lbias[row]), 0.0f);
+          const float v1 = lane_swap1(v0), v3 = lane_swap1(v2);  // the window's right column, from the odd lane
+          float m = v0;
+          int am = 0;
+          if (v1 > m) { m = v1; am = 1; }
+          if (v2 > m) { m = v2; am = 2; }
+          if (v3 > m) { m = v3; am = 3; }
+          pm[i][r] = m;
+          pc[i][r] = am | (m > 0.0f ? 4 : 0);
+        }
+      if (writer) {
+        float* op = out + (int64_t)(b0 + s) * out_sn + (int64_t)(rt * 64 + 4 * hi) * PW + wl;
+        uint8_t* cp = code + (int64_t)(b0 + s) * ((int64_t)K::COUT * PW) + (int64_t)(rt * 64 + 4 * hi) * PW + wl;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = (i * 32 + (r & 3) + 8 * (r >> 2)) * PW;
+            op[ro] = pm[i][r];
+            cp[ro] = (uint8_t)pc[i][r];
+          }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < K::TN; ++j) {
     const int c = wc * (32 * K::TN) + j * 32 + l31;
@@ -562,8 +617,42 @@ static void run_planes(const float* in, int64_t in_sn, const float* region, int6
     configured = true;
   }
   hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
-  hipLaunchKernelGGL(pconv::direct_planes_kernel<K>, dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
-                     in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, n);
+  hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
+                     in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, (uint8_t*)nullptr, n);
+}
+
+template <class K>
+static void run_planes_pool(const float* in, int64_t in_sn, const float* region, int64_t planes, float* scales, const float* bias, float* pooled,
+                            uint8_t* code, int n, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
+  hipLaunchKernelGGL((pconv::direct_planes_kernel<K, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
+                     in_sn, (const unsigned short*)region, region + planes, scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, n);
+}
+
+// conv + ReLU + max_pool2d(2) in one launch for the layers whose tiles allow it (four column tiles per wave)
+bool conv_planes_has_pool(const ConvGeom& g) {
+#if DDRL_PC_WIDE
+  return false;
+#else
+  return planes_id(g) == kPN1dC2 || planes_id(g) == kPN1dC3;
+#endif
+}
+
+void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, float* pooled, uint8_t* code,
+                                 hipStream_t st) {
+#if !DDRL_PC_WIDE
+  const int64_t planes = (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2;
+  switch (planes_id(g)) {
+    case kPN1dC2: run_planes_pool<PN1dC2F>(in, g.in_sn, wpf, planes, scales, bias, pooled, code, g.n, st); break;
+    case kPN1dC3: run_planes_pool<PN1dC3F>(in, g.in_sn, wpf, planes, scales, bias, pooled, code, g.n, st); break;
+    default: break;
+  }
+#endif
 }
 
 void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, int act, float* out,

@@ -12,6 +12,8 @@ The Atari encoder does not go through this file: it has its own fused kernels (n
 import time
 from ctypes import byref, c_int64, c_void_p
 
+import os
+
 import torch
 from torch import nn
 
@@ -112,8 +114,12 @@ class _ConvPool:
         self.op = Conv(module.in_channels, h, w, module.out_channels, kh, kw, stride=module.stride[0], pad=pad, max_n=cap,
                        device=device)
         oh, ow = self.op.oh, self.op.ow
+        self.oh, self.ow = oh, ow
         f = dict(dtype=torch.float32, device=device)
-        self.a = torch.empty((cap, module.out_channels, oh, ow), **f)       # relu(conv)
+        # layers whose kernels pool in their epilogue never write the full-resolution activations (ddrl_op_conv_forward_pool)
+        # (DDRL_POOL_UNFUSED=1: A/B switch, convolution and pool as two launches)
+        self.fused = bool(pool and relu and self.op.has_forward_pool() and os.environ.get("DDRL_POOL_UNFUSED") != "1")
+        self._a = None if self.fused else torch.empty((cap, module.out_channels, oh, ow), **f)   # relu(conv)
         self.dz = torch.empty((cap, module.out_channels, oh, ow), **f)      # d(loss)/d(pre-activation)
         if pool:
             self.p = torch.empty((cap, module.out_channels, oh // 2, ow // 2), **f)
@@ -126,11 +132,28 @@ class _ConvPool:
         w = self.m.weight.data
         self.op.pack(w if w.dim() == 4 else w.unsqueeze(2))
 
+    @property
+    def a(self):
+        """relu(conv) at full resolution.  A fused layer keeps only the pooled map and the decisions: what comes back then is zero
+        except at each window's first maximum, which holds the pooled value -- the same pooled map, the same max-pool routing and
+        the same ReLU mask under it as the activations the kernel had in its registers (what tests/parity_util.py substitutes into
+        the float64 yardstick)."""
+        if not self.fused:
+            return self._a
+        a = torch.zeros((self.p.shape[0], self.p.shape[1], self.oh, self.ow), dtype=torch.float32, device=self.p.device)
+        am = self.code & 3
+        for k in range(4):
+            a[:, :, (k >> 1)::2, (k & 1)::2] = torch.where(am == k, self.p, torch.zeros_like(self.p))
+        return a
+
     def forward(self, x, n):
-        self.op.forward(x, self.m.bias.data, self.relu, out=self.a, n=n)
+        if self.fused:
+            self.op.forward_pool(x, self.m.bias.data, self.p, self.code, n=n)
+            return self.p
+        self.op.forward(x, self.m.bias.data, self.relu, out=self._a, n=n)
         if not self.pool:
-            return self.a
-        maxpool2_idx(self.a[:n], out=self.p, code=self.code)
+            return self._a
+        maxpool2_idx(self._a[:n], out=self.p, code=self.code)
         return self.p
 
     def out_grad_buffer(self):
@@ -139,7 +162,7 @@ class _ConvPool:
 
     def backward(self, x, n, din=None):
         if self.pool:
-            maxpool2_backward_idx(self.dp[:n], self.code, self.a.shape[2], self.a.shape[3], dz=self.dz)
+            maxpool2_backward_idx(self.dp[:n], self.code, self.oh, self.ow, dz=self.dz)
         self.op.wgrad(x, self.dz, self.m.weight.grad_view, self.m.bias.grad_view, n=n)
         if din is not None:
             self.op.dgrad(self.dz, din=din, n=n)

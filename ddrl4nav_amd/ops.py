@@ -56,6 +56,17 @@ class Conv:
                                             1 if relu else 0, _p(out), _st()))
         return out
 
+    def has_forward_pool(self):
+        """True when the layer's kernels take ReLU + max_pool2d(2) into their epilogue (include/ddrl.h ddrl_op_conv_forward_pool)."""
+        return bool(self.lib.ddrl_op_conv_has_forward_pool(byref(self.desc(1))))
+
+    def forward_pool(self, x, bias, pooled, code, n=None):
+        """max_pool2d(relu(conv(x)), 2) in one launch: pooled [n][cout][oh/2][ow/2] + one decision byte per window."""
+        n = x.shape[0] if n is None else n
+        check(self.lib.ddrl_op_conv_forward_pool(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)), _p(pooled),
+                                                 _p(code), _st()))
+        return pooled
+
     def dgrad(self, dz, din=None, n=None):
         n = dz.shape[0] if n is None else n
         if din is None:

@@ -311,6 +311,14 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
 int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias,
                              int32_t act, float* out, void* stream);
 /* din = d(loss)/d(in) given dz = d(loss)/d(pre-activation output) */
+/* Conv2d + ReLU + max_pool2d(2) in ONE launch (round 4), for the layers whose kernels pool in their epilogue -- NavPreNet1D's three
+ * (3->64 7x7 @48, 64->128 5x5 @22, 128->256 3x3 @10): pooled [n][cout][oh/2][ow/2] (dense) and one decision byte per window as
+ * ddrl_op_maxpool2_forward_idx leaves it (ddrl_op_maxpool2_backward_idx turns d(pooled) + code into d(pre-activation)); the
+ * full-resolution activations are never written.  DDRL_ERR_UNSUPPORTED for every other layer: run ddrl_op_conv_forward and
+ * ddrl_op_maxpool2_forward_idx instead.  `in` 16-byte aligned, sample stride a multiple of 4 floats. */
+int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
+                                  uint8_t* code, void* stream);
+int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d);  /* 1 when ddrl_op_conv_forward_pool serves the layer, else 0 (host only) */
 int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream);
 /* dw [cout][cin][kh][kw], db [cout] (overwritten); `ws` = split-K scratch of ddrl_op_conv_ws_floats.
  * Requires oh*ow >= 32. */

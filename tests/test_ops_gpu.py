@@ -80,6 +80,48 @@ def test_conv_forward_backward_vs_torch(shape):
         close(db, b.grad)
 
 
+@pytest.mark.parametrize("shape", [(5, 3, 48, 64, 7, 1), (259, 3, 48, 64, 7, 1), (9, 64, 22, 128, 5, 1), (11, 128, 10, 256, 3, 1),
+                                   (4, 64, 24, 128, 3, 1)])
+def test_conv_relu_pool_in_one_launch_vs_torch(shape):
+    """ddrl_op_conv_forward_pool: max_pool2d(relu(conv(x)), 2) from the convolution's epilogue (csrc/fconv.hip, csrc/pconv.hip) --
+    pooled values to fp32 rounding, and the decision bytes route d(pooled) exactly as torch's autograd does wherever the window's
+    maximum is clear of fp32 noise."""
+    from ddrl4nav_amd.ops import Conv, maxpool2_backward_idx
+    n, cin, h, cout, ks, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, h, generator=g)
+    x[1] *= 1e-3
+    wt = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    conv = Conv(cin, h, h, cout, ks, ks, pad=(pad, pad), max_n=n)
+    conv.pack(wt.cuda())
+    if (cin, h) == (64, 24):          # NavPreNet.conv2: no pooling epilogue -> the caller composes the two operators
+        assert not conv.has_forward_pool()
+        return
+    assert conv.has_forward_pool()
+    z = F.conv2d(x.double(), wt.double(), b.double(), padding=pad).requires_grad_(True)
+    a = F.relu(z)
+    want = F.max_pool2d(a, 2, stride=2)
+    oh = conv.oh
+    pooled = torch.full((n, cout, oh // 2, oh // 2), -7.0).cuda()
+    code = torch.full((n, cout, oh // 2, oh // 2), 255, dtype=torch.uint8).cuda()
+    conv.forward_pool(x.cuda(), b.cuda(), pooled, code, n=n)
+    close(pooled, want.float())
+    close(pooled[1], want[1].float())                      # the faint sample on its own scale
+    assert int(code.max()) < 8
+    dpool = torch.randn(want.shape, generator=g)
+    want.backward(dpool.double())
+    dz = maxpool2_backward_idx(dpool.cuda(), code, oh, oh).cpu()
+    # windows whose two largest activations are closer than fp32 noise may route either way: compare where the decision is clear
+    top2 = F.unfold(a.detach().reshape(n * cout, 1, oh, oh), 2, stride=2).topk(2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]).abs() > 1e-5 * (1 + top2[:, 0].abs())) | (top2[:, 0] == 0)
+    clear &= (top2[:, 0] == 0) | (top2[:, 0] > 1e-5)
+    clear = clear.reshape(n, cout, oh // 2, oh // 2)
+    mask = clear.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    assert float(clear.double().mean()) > 0.99
+    assert torch.equal(dz[mask], z.grad.float()[mask])
+
+
 def test_conv_strided_sample_layout():
     """in_sn / out_sn: the layer reads and writes slices of wider per-sample records."""
     from ddrl4nav_amd import _lib
