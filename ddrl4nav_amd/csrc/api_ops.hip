@@ -141,6 +141,31 @@ int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, cons
   return op_check();
 }
 
+int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
+                                  void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !dpool || !code || !packed || !din) return DDRL_ERR_INVALID_ARG;
+  if ((g.in_sn & 3) || !aligned16(din) || !aligned16(dpool)) return DDRL_ERR_INVALID_ARG;
+  if (!(conv_has_planes(g) && conv_planes_has_pool(g))) return DDRL_ERR_UNSUPPORTED;
+  const PackView v = pack_view(g);
+  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], const_cast<float*>(packed) + v.off[7], din, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
+                                  float* ws, float* dw, float* db, void* stream) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !in || !dpool || !code || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
+  if ((g.in_sn & 3) || !aligned16(in) || !aligned16(dpool) || ((uintptr_t)code & 1)) return DDRL_ERR_INVALID_ARG;
+  if (conv_has_first(g))
+    launch_conv_first_wgrad_pooled(g, in, dpool, code, ws, dw, db, (hipStream_t)stream);
+  else if (conv_has_planes(g) && conv_planes_has_pool(g))
+    launch_conv_planes_wgrad_pooled(g, in, dpool, code, ws, dw, db, (hipStream_t)stream);
+  else
+    return DDRL_ERR_UNSUPPORTED;
+  return op_check();
+}
+
 int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;

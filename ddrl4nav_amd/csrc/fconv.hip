@@ -318,9 +318,13 @@ __device__ __forceinline__ frag8 tr_frag(const char* lds, int off_lo, int off_hi
   return __builtin_bit_cast(frag8, (s8w)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <class K>
+// UNPOOL: `dz` is d(pooled) [64][OH / 2][OH / 2] of the layer's ReLU + max_pool2d(2) and `ucode` its decision bytes; the staging
+// forms d(pre-activation) on the fly (the pooled gradient at the window's first maximum under the ReLU's sign, zero elsewhere), so
+// the 2 GB full-resolution gradient of a 4,096-sample batch is neither written nor read.
+template <class K, bool UNPOOL>
 __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(const float* __restrict__ in, int64_t in_sn, const float* __restrict__ dz,
-                                                             int64_t dz_sn, float* __restrict__ part, int n, int nsplit) {
+                                                             int64_t dz_sn, const uint8_t* __restrict__ ucode, float* __restrict__ part, int n,
+                                                             int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_u(), l31 = lane & 31, hi = lane >> 5;
   float* red = (float*)(lds + K::W_RED_OFF);  // [0..3] dz maxima of the waves, [4..7] image maxima
@@ -329,11 +333,16 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(const float* __rest
   const int st_begin = min(nst, split * per), st_end = min(nst, st_begin + per);
   for (int i = tid; i < K::W_RED_OFF / 16; i += 256) *(f4*)(lds + i * 16) = zero4();  // the padded pixels of the dz rows and the image borders stay zero
   // ---- staging maps
-  int doff[K::DZ_NJ], ddst[K::DZ_NJ];
+  int doff[K::DZ_NJ], ddst[K::DZ_NJ], dpos[K::DZ_NJ];
 #pragma unroll
   for (int j = 0; j < K::DZ_NJ; ++j) {
     const int u = tid + 256 * j, oc = u / (K::BR * (K::OH / 4)), rem = u % (K::BR * (K::OH / 4)), r = rem / (K::OH / 4), x4 = rem % (K::OH / 4);
-    doff[j] = oc * K::P + r * K::OH + x4 * 4;              // + oy0 * OH
+    if (UNPOOL) {  // two windows per quad: row pair r / 2 of the band, columns 2 x4, 2 x4 + 1
+      doff[j] = oc * K::PW + (r >> 1) * K::OW2 + x4 * 2;   // + (oy0 / 2) * OW2
+      dpos[j] = (r & 1) * 2;
+    } else {
+      doff[j] = oc * K::P + r * K::OH + x4 * 4;            // + oy0 * OH
+    }
     ddst[j] = (oc * K::DZP + r * K::PXR + x4 * 4) * 2;
   }
   const int iu = min(tid, K::IM_UNITS - 1), irow = iu / (K::HIN / 4), ix4 = iu % (K::HIN / 4);
@@ -345,17 +354,39 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(const float* __rest
   bool irow_ok = false;
   auto fetch = [&](int st) {
     const int b = st / K::NBANDS, oy0 = (st % K::NBANDS) * K::BR;
-    const float* dsrc = dz + (int64_t)b * dz_sn + oy0 * K::OH;
+    if (UNPOOL) {
+      const int64_t o = (int64_t)b * dz_sn + (oy0 / 2) * K::OW2;
 #pragma unroll
-    for (int j = 0; j < K::DZ_NJ; ++j) dr[j] = ld4(dsrc + doff[j]);
+      for (int j = 0; j < K::DZ_NJ; ++j) {
+        const f2 g = *(const f2*)(dz + o + doff[j]);                  // (OW2 and 2 x4 are even: 8-byte aligned)
+        const unsigned cc = *(const unsigned short*)(ucode + o + doff[j]);
+        dr[j] = (f4){g.x, g.y, __uint_as_float(cc), 0.0f};            // routed at commit, once the loads have landed
+      }
+    } else {
+      const float* dsrc = dz + (int64_t)b * dz_sn + oy0 * K::OH;
+#pragma unroll
+      for (int j = 0; j < K::DZ_NJ; ++j) dr[j] = ld4(dsrc + doff[j]);
+    }
     const int iy = oy0 - K::PAD + irow;
     irow_ok = iy >= 0 && iy < K::HIN;
     const float* isrc = in + (int64_t)b * in_sn + min(max(iy, 0), K::HIN - 1) * K::HIN + ix4 * 4;
 #pragma unroll
     for (int c = 0; c < K::CIN; ++c) ir[c] = ld4(isrc + c * K::RAW);
   };
+  auto route = [&]() {  // UNPOOL: (g0, g1, codes) -> the four gradients of the quad
+    if (UNPOOL) {
+#pragma unroll
+      for (int j = 0; j < K::DZ_NJ; ++j) {
+        const unsigned cc = __float_as_uint(dr[j].z), c0 = cc & 7u, c1 = (cc >> 8) & 7u;
+        const unsigned p0 = 4u | (unsigned)dpos[j];
+        const float g0 = dr[j].x, g1 = dr[j].y;
+        dr[j] = (f4){c0 == p0 ? g0 : 0.0f, c0 == p0 + 1 ? g0 : 0.0f, c1 == p0 ? g1 : 0.0f, c1 == p0 + 1 ? g1 : 0.0f};
+      }
+    }
+  };
   auto leave_amax = [&]() {
     float md = 0.0f, mi = 0.0f;
+    route();
 #pragma unroll
     for (int j = 0; j < K::DZ_NJ; ++j) md = fmaxf(md, amax4(dr[j]));
     if (irow_ok && tid < K::IM_UNITS) {
@@ -543,11 +574,28 @@ void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz
   using K = FN1dC1;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)fconv::first_wgrad_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, K::W_LDS);
+    (void)hipFuncSetAttribute((const void*)fconv::first_wgrad_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::W_LDS);
     configured = true;
   }
   const int S = conv_first_wgrad_splits(g);
-  hipLaunchKernelGGL(fconv::first_wgrad_kernel<K>, dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dz, g.out_sn, part, g.n, S);
+  hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, false>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dz, g.out_sn, (const uint8_t*)nullptr, part,
+                     g.n, S);
+  const int KT = g.cin * g.kh * g.kw;
+  launch_reduce_slabs(part, S, K::SLAB, (int64_t)g.cout * KT, dw, st);
+  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, K::SLAB, g.cout, db, st);
+}
+
+// the same from d(pooled) [n][64][OH / 2][OH / 2] + decision bytes
+void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
+                                    hipStream_t st) {
+  using K = FN1dC1;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)fconv::first_wgrad_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::W_LDS);
+    configured = true;
+  }
+  const int S = conv_first_wgrad_splits(g);
+  hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, true>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dpool, (int64_t)64 * K::PW, ucode, part, g.n, S);
   const int KT = g.cin * g.kh * g.kw;
   launch_reduce_slabs(part, S, K::SLAB, (int64_t)g.cout * KT, dw, st);
   launch_reduce_slabs(part + (int64_t)g.cout * KT, S, K::SLAB, g.cout, db, st);

@@ -48,6 +48,11 @@ void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* w
 bool conv_planes_has_pool(const ConvGeom& g);     // forward with ReLU + max_pool2d(2) in the epilogue
 void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, float* pooled, uint8_t* code,
                                  hipStream_t st);
+// gradients of such a layer from d(pooled) + decision bytes (scales / part as launch_conv_planes_dgrad / _wgrad)
+void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, float* din,
+                                     hipStream_t st);
+void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
+                                     hipStream_t st);
 int conv_planes_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no plane kernels
 // part: conv_planes_wgrad_splits slabs of cout * cin * kh * kw + cout floats, then 2 n floats (per-sample scales of this launch)
 void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
@@ -60,6 +65,8 @@ void launch_conv_first_pack(const ConvGeom& g, const float* w, float* region, hi
 void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, hipStream_t st);
 void launch_conv_first_fwd_pool(const ConvGeom& g, const float* in, const float* region, const float* bias, float* pooled, uint8_t* code,
                                 hipStream_t st);  // conv + ReLU + max_pool2d(2) in one launch
+void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
+                                    hipStream_t st);  // weight gradient from d(pooled) + decision bytes
 int conv_first_wgrad_splits(const ConvGeom& g);  // 0 when the layer is not this one
 void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
 

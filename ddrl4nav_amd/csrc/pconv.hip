@@ -107,11 +107,15 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
 // still read neighbouring pixels), the epilogue takes the window's maximum over two accumulators of the lane and the same two of its
 // neighbour (one DPP move each) and writes the pooled map [oc][OH / 2][OH / 2] + one decision byte per window (gconv.hip
 // maxpool2_fwd_idx_kernel); the full-resolution activations are never written.
-template <class K, bool POOL = false>
+// UNPOOL (data gradient of such a layer): `in` is d(pooled) [CIN][HIN / 2][HIN / 2] and `ucode` the layer's decision bytes; the
+// staging forms d(pre-activation) on the fly -- the pooled gradient at the window's first maximum under the ReLU's sign, zero
+// elsewhere (gconv.hip maxpool2_bwd_idx_kernel) -- so the full-resolution gradient is never written or read either.
+template <class K, bool POOL = false, bool UNPOOL = false>
 __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
                                                                    const float* __restrict__ whdr, const float* __restrict__ scales,
                                                                    const float* __restrict__ bias, int act, float* __restrict__ out,
-                                                                   int64_t out_sn, uint8_t* __restrict__ code, int n) {
+                                                                   int64_t out_sn, uint8_t* __restrict__ code,
+                                                                   const uint8_t* __restrict__ ucode, int n) {
   extern __shared__ __attribute__((aligned(16))) char ldsp[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b0 = blockIdx.x * K::NS, rt = blockIdx.y;
@@ -119,16 +123,26 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
   if (tid < 64) ((float*)(ldsp + K::BIAS_OFF))[tid] = bias != nullptr ? bias[rt * 64 + tid] : 0.0f;
   if (tid < K::NS) ((float*)(ldsp + K::SC_OFF))[tid] = scales[min(b0 + tid, n - 1)];
   // ---- staging maps.  unit u = tid + THREADS j: sample u / RAW, raw pixel u % RAW -> 16 loads of stride RAW (the k-block's channels)
+  constexpr int CST = UNPOOL ? K::RAW / 4 : K::RAW;  // channel stride of `in`
   const float* isrc[K::NIJ];
-  int idst[K::NIJ];
+  const uint8_t* usrc[K::NIJ];
+  int idst[K::NIJ], upos[K::NIJ];
   float isc[K::NIJ];
 #pragma unroll
   for (int j = 0; j < K::NIJ; ++j) {
     const int u = min(tid + K::THREADS * j, K::NIU - 1);
     const int s = u / K::RAW, px = u % K::RAW;
     const int b = min(b0 + s, n - 1);
-    isrc[j] = in + (int64_t)b * in_sn + px;  // + (16 cb + c) * RAW
-    idst[j] = (s * K::LPP + (px / K::HIN + K::PAD) * K::LP + px % K::HIN + K::PAD) * K::PIXB;
+    const int y = px / K::HIN, x = px % K::HIN;
+    if (UNPOOL) {
+      const int w = (y >> 1) * (K::HIN / 2) + (x >> 1);
+      isrc[j] = in + (int64_t)b * in_sn + w;  // + (16 cb + c) * RAW / 4
+      usrc[j] = ucode + (int64_t)b * ((int64_t)K::CIN * CST) + w;
+      upos[j] = (y & 1) * 2 + (x & 1);
+    } else {
+      isrc[j] = in + (int64_t)b * in_sn + px;  // + (16 cb + c) * RAW
+    }
+    idst[j] = (s * K::LPP + (y + K::PAD) * K::LP + x + K::PAD) * K::PIXB;
     isc[j] = scales[b];
   }
   const unsigned short* wsrc = wp + (int64_t)rt * ((int64_t)K::NCB * K::KK * NPL * 1024) + tid * 8;  // + kb * TAPC * NPL * 1024 + j * THREADS * 8
@@ -151,12 +165,16 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
     }
   }
   float ir[K::NIJ][K::KOC];
+  uint8_t ic[UNPOOL ? K::NIJ : 1][K::KOC];
   f4 wr[K::NWJ];
   auto fetch_img = [&](int cb) {
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j)
 #pragma unroll
-      for (int c = 0; c < K::KOC; ++c) ir[j][c] = isrc[j][(int64_t)(cb * K::KOC + c) * K::RAW];
+      for (int c = 0; c < K::KOC; ++c) {
+        ir[j][c] = isrc[j][(int64_t)(cb * K::KOC + c) * CST];
+        if (UNPOOL) ic[j][c] = usrc[j][(int64_t)(cb * K::KOC + c) * CST];
+      }
   };
   auto fetch_w = [&](int kb) {
 #pragma unroll
@@ -167,6 +185,10 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < K::NIJ; ++j) {
       if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
+        if (UNPOOL) {  // the window's gradient goes to its first maximum, under the ReLU's sign
+#pragma unroll
+          for (int c = 0; c < K::KOC; ++c) ir[j][c] = (ic[j][c] & 7) == (4 | upos[j]) ? ir[j][c] : 0.0f;
+        }
         unsigned pl[K::KOC / 2][NPL];
 #pragma unroll
         for (int c = 0; c < K::KOC / 2; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], isc[j], pl[c]);
@@ -340,10 +362,12 @@ struct WGeo {
   static_assert(KAPPA * 8 * 8 * 4 <= LDS_BYTES, "the bias reduction reuses the stage");
 };
 
-template <class K>
+// UNPOOL: `dz` is d(pooled) [COUT][OH / 2][OH / 2] of a layer that is followed by ReLU + max_pool2d(2) and `ucode` its decision
+// bytes; the staging forms d(pre-activation) on the fly (direct_planes_kernel's UNPOOL).
+template <class K, bool UNPOOL = false>
 __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restrict__ in, int64_t in_sn, const float* __restrict__ dz, int64_t dz_sn,
-                                                           const float* __restrict__ sc_in, const float* __restrict__ sc_dz,
-                                                           float* __restrict__ part, int n, int nsplit) {
+                                                           const uint8_t* __restrict__ ucode, const float* __restrict__ sc_in,
+                                                           const float* __restrict__ sc_dz, float* __restrict__ part, int n, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char ldsw[];
   __shared__ float s_min[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -381,14 +405,23 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
   }
   // ---- staging maps
   int64_t aoff[K::NA], boff[K::NBU];  // offsets inside a sample (floats), without the band shift
-  int awr[K::NA], bwr[K::NBU], asmp[K::NA], bsmp[K::NBU], bry[K::NBU];
+  int awr[K::NA], bwr[K::NBU], asmp[K::NA], bsmp[K::NBU], bry[K::NBU], apos[K::NA];
+  constexpr int ACS = UNPOOL ? K::P / 4 : K::P;                       // channel stride of `dz`
+  constexpr int ABAND = UNPOOL ? (K::BR / 2) * (K::OH / 2) : K::BR * K::OH;  // band shift inside a channel
   unsigned bxok = 0u;                 // bit t: the unit's column is inside the image
 #pragma unroll
   for (int t = 0; t < K::NA; ++t) {
     const int u = min(tid + 256 * t, K::A_UNITS - 1);
     const int c8 = u / K::KAPPA, kap = u % K::KAPPA, bl = kap / (K::BR * K::OH), w = kap % (K::BR * K::OH);
     asmp[t] = bl;
-    aoff[t] = (int64_t)(oct * 64 + c8 * 8) * K::P + w;                        // + band * BR * OH, + sample * dz_sn, + c * P
+    if (UNPOOL) {
+      static_assert(!UNPOOL || (K::BR % 2 == 0 && K::OH % 2 == 0), "bands of whole row pairs");
+      const int yl = w / K::OH, x = w % K::OH;
+      aoff[t] = (int64_t)(oct * 64 + c8 * 8) * ACS + (yl >> 1) * (K::OH / 2) + (x >> 1);  // + band * (BR / 2) * (OH / 2), + sample * dz_sn, + c * P / 4
+      apos[t] = (yl & 1) * 2 + (x & 1);
+    } else {
+      aoff[t] = (int64_t)(oct * 64 + c8 * 8) * K::P + w;                      // + band * BR * OH, + sample * dz_sn, + c * P
+    }
     awr[t] = kap * 128 + ((c8 * 16) ^ (((kap >> 1) & 1) * 64));
   }
 #pragma unroll
@@ -418,6 +451,7 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
       brow[g][r] = kap < K::KAPPA ? ((bl * K::BRW + w / K::OH) * K::LP + w % K::OH) * K::BP : 0;  // padded kappa: any row (dz is zero there)
     }
   float ar[K::NA][8], br[K::NBU][8], bsum[K::NA][8];
+  uint8_t ac[UNPOOL ? K::NA : 1][8];
 #pragma unroll
   for (int t = 0; t < K::NA; ++t)
 #pragma unroll
@@ -426,9 +460,12 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
     const int sg = st / K::NBANDS, band = st % K::NBANDS;
 #pragma unroll
     for (int t = 0; t < K::NA; ++t) {
-      const float* src = dz + (int64_t)min(sg * K::NB + asmp[t], n - 1) * dz_sn + aoff[t] + band * (K::BR * K::OH);
+      const int64_t o = (int64_t)min(sg * K::NB + asmp[t], n - 1) * dz_sn + aoff[t] + band * ABAND;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ar[t][c] = src[(int64_t)c * K::P];
+      for (int c = 0; c < 8; ++c) {
+        ar[t][c] = dz[o + (int64_t)c * ACS];
+        if (UNPOOL) ac[t][c] = ucode[o + (int64_t)c * ACS];
+      }
     }
 #pragma unroll
     for (int t = 0; t < K::NBU; ++t) {
@@ -446,6 +483,10 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
         if (sg * K::NB + asmp[t] >= n) {  // missing sample of a ragged last stage: contributes zero
 #pragma unroll
           for (int c = 0; c < 8; ++c) ar[t][c] = 0.0f;
+        }
+        if (UNPOOL) {  // the window's gradient goes to its first maximum, under the ReLU's sign
+#pragma unroll
+          for (int c = 0; c < 8; ++c) ar[t][c] = (ac[t][c] & 7) == (4 | apos[t]) ? ar[t][c] : 0.0f;
         }
         unsigned pl[4][NPL];
 #pragma unroll
@@ -618,7 +659,7 @@ static void run_planes(const float* in, int64_t in_sn, const float* region, int6
   }
   hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
-                     in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, (uint8_t*)nullptr, n);
+                     in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, (uint8_t*)nullptr, (const uint8_t*)nullptr, n);
 }
 
 template <class K>
@@ -631,7 +672,23 @@ static void run_planes_pool(const float* in, int64_t in_sn, const float* region,
   }
   hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
-                     in_sn, (const unsigned short*)region, region + planes, scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, n);
+                     in_sn, (const unsigned short*)region, region + planes, scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, (const uint8_t*)nullptr, n);
+}
+
+// data gradient straight from d(pooled) + decision bytes (K = the layer's data-gradient geometry: CIN = dz channels, HIN = dz size).
+// The per-sample scales come from d(pooled) itself: max |d(pooled)| bounds max |dz| (the routing only drops elements).
+template <class K>
+static void run_planes_unpool(const float* dpool, const uint8_t* ucode, const float* region, int64_t planes, float* scales, float* din, int64_t din_sn,
+                              int n, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  constexpr int64_t PSN = (int64_t)K::CIN * K::RAW / 4;
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales);
+  hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES,
+                     st, dpool, PSN, (const unsigned short*)region, region + planes, scales, (const float*)nullptr, 0, din, din_sn, (uint8_t*)nullptr, ucode, n);
 }
 
 // conv + ReLU + max_pool2d(2) in one launch for the layers whose tiles allow it (four column tiles per wave)
@@ -724,7 +781,54 @@ static void run_planes_wgrad(const ConvGeom& g, const float* in, const float* dz
   hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
   hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dz, g.out_sn, K::COUT * K::P, sc_dz);
   hipLaunchKernelGGL(pconv::wgrad_planes_kernel<K>, dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in, g.in_sn,
-                     dz, g.out_sn, sc_in, sc_dz, part, g.n, S);
+                     dz, g.out_sn, (const uint8_t*)nullptr, sc_in, sc_dz, part, g.n, S);
+}
+
+template <class K>
+static void run_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* scales, int S,
+                                    hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)pconv::wgrad_planes_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+    configured = true;
+  }
+  float* sc_in = scales;
+  float* sc_dz = scales + g.n;
+  constexpr int64_t PSN = (int64_t)K::COUT * K::P / 4;
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz);  // max |d(pooled)| bounds max |dz|
+  hipLaunchKernelGGL((pconv::wgrad_planes_kernel<K, true>), dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in,
+                     g.in_sn, dpool, PSN, ucode, sc_in, sc_dz, part, g.n, S);
+}
+
+// weight / data gradient of a pooled layer straight from d(pooled) + decision bytes (the layers of conv_planes_has_pool)
+void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
+                                     hipStream_t st) {
+#if !DDRL_PC_WIDE
+  const int S = conv_planes_wgrad_splits(g);
+  const int KT = g.cin * g.kh * g.kw;
+  const int64_t slab = (int64_t)g.cout * KT + g.cout;
+  float* scales = part + (int64_t)S * slab;
+  switch (planes_id(g)) {
+    case kPN1dC2: run_planes_wgrad_pooled<PN1dC2W>(g, in, dpool, ucode, part, scales, S, st); break;
+    case kPN1dC3: run_planes_wgrad_pooled<PN1dC3W>(g, in, dpool, ucode, part, scales, S, st); break;
+    default: return;
+  }
+  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
+  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
+#endif
+}
+
+void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, float* din,
+                                     hipStream_t st) {
+#if !DDRL_PC_WIDE
+  const int64_t planes = (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2;
+  switch (planes_id(g)) {
+    case kPN1dC2: run_planes_unpool<PN1dC2D>(dpool, ucode, wpd, planes, scales, din, g.in_sn, g.n, st); break;
+    case kPN1dC3: run_planes_unpool<PN1dC3D>(dpool, ucode, wpd, planes, scales, din, g.in_sn, g.n, st); break;
+    default: break;
+  }
+#endif
 }
 
 // part: S slabs of COUT * KT + COUT floats, then 2 n floats of scratch for the per-sample scales

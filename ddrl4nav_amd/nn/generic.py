@@ -120,7 +120,10 @@ class _ConvPool:
         # (DDRL_POOL_UNFUSED=1: A/B switch, convolution and pool as two launches)
         self.fused = bool(pool and relu and self.op.has_forward_pool() and os.environ.get("DDRL_POOL_UNFUSED") != "1")
         self._a = None if self.fused else torch.empty((cap, module.out_channels, oh, ow), **f)   # relu(conv)
-        self.dz = torch.empty((cap, module.out_channels, oh, ow), **f)      # d(loss)/d(pre-activation)
+        # ... and their backward reads d(pooled) + the decision bytes (ddrl_op_conv_*_pooled): no full-resolution gradient either
+        # (DDRL_POOL_BWD_UNFUSED=1: A/B switch, the pool's backward as its own launch)
+        self.fused_bwd = self.fused and os.environ.get("DDRL_POOL_BWD_UNFUSED") != "1"
+        self.dz = None if self.fused_bwd else torch.empty((cap, module.out_channels, oh, ow), **f)   # d(loss)/d(pre-activation)
         if pool:
             self.p = torch.empty((cap, module.out_channels, oh // 2, ow // 2), **f)
             self.dp = torch.empty_like(self.p)
@@ -161,6 +164,11 @@ class _ConvPool:
         return self.dp if self.pool else self.dz
 
     def backward(self, x, n, din=None):
+        if self.fused_bwd:
+            self.op.wgrad_pooled(x, self.dp, self.code, self.m.weight.grad_view, self.m.bias.grad_view, n=n)
+            if din is not None:
+                self.op.dgrad_pooled(self.dp, self.code, din=din, n=n)
+            return
         if self.pool:
             maxpool2_backward_idx(self.dp[:n], self.code, self.oh, self.ow, dz=self.dz)
         self.op.wgrad(x, self.dz, self.m.weight.grad_view, self.m.bias.grad_view, n=n)

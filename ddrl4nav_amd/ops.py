@@ -67,6 +67,19 @@ class Conv:
                                                  _p(code), _st()))
         return pooled
 
+    def dgrad_pooled(self, dpool, code, din=None, n=None):
+        """Data gradient of a forward_pool layer from d(pooled) + decision bytes (no full-resolution gradient in between)."""
+        n = dpool.shape[0] if n is None else n
+        if din is None:
+            din = torch.empty((n, self.cin, self.h, self.w), dtype=torch.float32, device=dpool.device)
+        check(self.lib.ddrl_op_conv_dgrad_pooled(byref(self.desc(n)), _p(_f32(dpool)), _p(code), _p(self.packed), _p(din), _st()))
+        return din
+
+    def wgrad_pooled(self, x, dpool, code, dw, db, n=None):
+        n = x.shape[0] if n is None else n
+        check(self.lib.ddrl_op_conv_wgrad_pooled(byref(self.desc(n)), _p(_f32(x)), _p(_f32(dpool)), _p(code), _p(self.packed),
+                                                 _p(self.ws), _p(dw), _p(db), _st()))
+
     def dgrad(self, dz, din=None, n=None):
         n = dz.shape[0] if n is None else n
         if din is None:

@@ -319,6 +319,14 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
                                   uint8_t* code, void* stream);
 int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d);  /* 1 when ddrl_op_conv_forward_pool serves the layer, else 0 (host only) */
+/* The backward of the same layers straight from d(pooled) [n][cout][oh/2][ow/2] and the decision bytes: the kernels form
+ * d(pre-activation) while they stage it (the pooled gradient at each window's first maximum under the ReLU's sign, zero elsewhere --
+ * what ddrl_op_maxpool2_backward_idx would write), so the full-resolution gradient is neither written nor read.  Same layers as
+ * ddrl_op_conv_forward_pool (the 3-channel first layer has no data gradient: DDRL_ERR_UNSUPPORTED); dpool 16-byte aligned, dense. */
+int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
+                                  void* stream);
+int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
+                                  float* ws, float* dw, float* db, void* stream);
 int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream);
 /* dw [cout][cin][kh][kw], db [cout] (overwritten); `ws` = split-K scratch of ddrl_op_conv_ws_floats.
  * Requires oh*ow >= 32. */

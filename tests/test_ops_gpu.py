@@ -120,6 +120,23 @@ def test_conv_relu_pool_in_one_launch_vs_torch(shape):
     mask = clear.repeat_interleave(2, 2).repeat_interleave(2, 3)
     assert float(clear.double().mean()) > 0.99
     assert torch.equal(dz[mask], z.grad.float()[mask])
+    # the backward straight from d(pooled) + decision bytes equals the backward from the unpooled gradient (same kernels, the
+    # gradient formed while it is staged): weight / bias gradient, and the data gradient where the layer has one
+    dzd = dz.cuda()
+    dw_a, db_a = torch.empty_like(wt).cuda(), torch.empty(cout).cuda()
+    dw_b, db_b = torch.empty_like(wt).cuda(), torch.empty(cout).cuda()
+    conv.wgrad(x.cuda(), dzd, dw_a, db_a)
+    conv.wgrad_pooled(x.cuda(), dpool.cuda(), code, dw_b, db_b)
+    close(dw_b, dw_a, tol=2e-6)
+    close(db_b, db_a, tol=2e-6)
+    want_dw = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dz.double(), padding=pad)
+    close(dw_b, want_dw.float())
+    if cin > 4:
+        din_a = conv.dgrad(dzd)
+        din_b = conv.dgrad_pooled(dpool.cuda(), code)
+        close(din_b, din_a, tol=2e-6)
+        close(din_b, torch.nn.grad.conv2d_input(x.shape, wt.double(), dz.double(), padding=pad).float())
+        close(din_b[1], torch.nn.grad.conv2d_input(x.shape, wt.double(), dz.double(), padding=pad)[1].float())
 
 
 def test_conv_strided_sample_layout():

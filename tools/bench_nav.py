@@ -57,6 +57,7 @@ def run(B=4096, CAP=1024, ITERS=3, T_loop=None):
     """One measurement; returns the record as a dict (bench.py's `nav` sub-record calls this).  The per-operator timing wraps
     ops.Conv / ops.Linear for the duration of the call only."""
     saved = {(cls, k): getattr(cls, k) for cls in (ops.Conv, ops.Linear) for k in ("forward", "dgrad", "wgrad")}
+    saved.update({(ops.Conv, k): getattr(ops.Conv, k) for k in ("forward_pool", "dgrad_pooled", "wgrad_pooled")})
     events.clear()
     try:
         return _run(B, CAP, ITERS, T_loop)
@@ -69,6 +70,10 @@ def _run(B, CAP, ITERS, T_loop):
     ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
     ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
     ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
+    # the pooled forms (conv + ReLU + max-pool in one launch; gradients from d(pooled) + decision bytes) under the same names
+    ops.Conv.forward_pool = timed(conv_name("fwd"), conv_flop, ops.Conv.forward_pool)
+    ops.Conv.dgrad_pooled = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad_pooled)
+    ops.Conv.wgrad_pooled = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad_pooled)
     ops.Linear.forward = timed(lin_name("fwd"), lin_flop, ops.Linear.forward)
     ops.Linear.dgrad = timed(lin_name("dgrad"), lin_flop, ops.Linear.dgrad)
     ops.Linear.wgrad = timed(lin_name("wgrad"), lin_flop, ops.Linear.wgrad)
