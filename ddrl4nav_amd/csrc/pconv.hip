@@ -123,27 +123,30 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
   if (tid < 64) ((float*)(ldsp + K::BIAS_OFF))[tid] = bias != nullptr ? bias[rt * 64 + tid] : 0.0f;
   if (tid < K::NS) ((float*)(ldsp + K::SC_OFF))[tid] = scales[min(b0 + tid, n - 1)];
   // ---- staging maps.  unit u = tid + THREADS j: sample u / RAW, raw pixel u % RAW -> 16 loads of stride RAW (the k-block's channels)
+  // UNPOOL: a unit is a pooling WINDOW (its four pixels share the 16 gradients and decision bytes of the k-block's channels)
   constexpr int CST = UNPOOL ? K::RAW / 4 : K::RAW;  // channel stride of `in`
-  const float* isrc[K::NIJ];
-  const uint8_t* usrc[K::NIJ];
-  int idst[K::NIJ], upos[K::NIJ];
-  float isc[K::NIJ];
+  constexpr int NIU = UNPOOL ? K::NS * K::RAW / 4 : K::NIU, NIJ = (NIU + K::THREADS - 1) / K::THREADS;
+  const float* isrc[NIJ];
+  const uint8_t* usrc[NIJ];
+  int idst[NIJ];
+  float isc[NIJ];
 #pragma unroll
-  for (int j = 0; j < K::NIJ; ++j) {
-    const int u = min(tid + K::THREADS * j, K::NIU - 1);
-    const int s = u / K::RAW, px = u % K::RAW;
-    const int b = min(b0 + s, n - 1);
-    const int y = px / K::HIN, x = px % K::HIN;
+  for (int j = 0; j < NIJ; ++j) {
+    const int u = min(tid + K::THREADS * j, NIU - 1);
     if (UNPOOL) {
-      const int w = (y >> 1) * (K::HIN / 2) + (x >> 1);
+      const int s = u / CST, w = u % CST, wy = w / (K::HIN / 2), wx = w % (K::HIN / 2);
+      const int b = min(b0 + s, n - 1);
       isrc[j] = in + (int64_t)b * in_sn + w;  // + (16 cb + c) * RAW / 4
       usrc[j] = ucode + (int64_t)b * ((int64_t)K::CIN * CST) + w;
-      upos[j] = (y & 1) * 2 + (x & 1);
+      idst[j] = (s * K::LPP + (2 * wy + K::PAD) * K::LP + 2 * wx + K::PAD) * K::PIXB;  // pixel (0, 0) of the window
+      isc[j] = scales[b];
     } else {
+      const int s = u / K::RAW, px = u % K::RAW;
+      const int b = min(b0 + s, n - 1);
       isrc[j] = in + (int64_t)b * in_sn + px;  // + (16 cb + c) * RAW
+      idst[j] = (s * K::LPP + (px / K::HIN + K::PAD) * K::LP + px % K::HIN + K::PAD) * K::PIXB;
+      isc[j] = scales[b];
     }
-    idst[j] = (s * K::LPP + (y + K::PAD) * K::LP + x + K::PAD) * K::PIXB;
-    isc[j] = scales[b];
   }
   const unsigned short* wsrc = wp + (int64_t)rt * ((int64_t)K::NCB * K::KK * NPL * 1024) + tid * 8;  // + kb * TAPC * NPL * 1024 + j * THREADS * 8
   // ---- operand bases
@@ -164,12 +167,12 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
       bB[j] = (s * K::LPP + (pix / K::OH) * K::LP + pix % K::OH) * K::PIXB + hi * 16;
     }
   }
-  float ir[K::NIJ][K::KOC];
-  uint8_t ic[UNPOOL ? K::NIJ : 1][K::KOC];
+  float ir[NIJ][K::KOC];
+  uint8_t ic[UNPOOL ? NIJ : 1][K::KOC];
   f4 wr[K::NWJ];
   auto fetch_img = [&](int cb) {
 #pragma unroll
-    for (int j = 0; j < K::NIJ; ++j)
+    for (int j = 0; j < NIJ; ++j)
 #pragma unroll
       for (int c = 0; c < K::KOC; ++c) {
         ir[j][c] = isrc[j][(int64_t)(cb * K::KOC + c) * CST];
@@ -181,22 +184,30 @@ __global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* 
     for (int j = 0; j < K::NWJ; ++j)
       if (j + 1 < K::NWJ || tid + K::THREADS * j < K::NWQ) wr[j] = *(const f4*)(wsrc + (int64_t)kb * (K::TAPC * NPL * 1024) + j * (K::THREADS * 8));
   };
+  auto commit_px = [&](char* d, const float (&v)[K::KOC], float sc) {  // one pixel: 16 channels -> 32 bytes per plane
+    unsigned pl[K::KOC / 2][NPL];
+#pragma unroll
+    for (int c = 0; c < K::KOC / 2; ++c) split_planes(v[2 * c], v[2 * c + 1], sc, pl[c]);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+      *(u4v*)(d + p * K::IMG_PLANE + 16) = (u4v){pl[4][p], pl[5][p], pl[6][p], pl[7][p]};
+    }
+  };
   auto commit_img = [&]() {
 #pragma unroll
-    for (int j = 0; j < K::NIJ; ++j) {
-      if (j + 1 < K::NIJ || tid + K::THREADS * j < K::NIU) {
-        if (UNPOOL) {  // the window's gradient goes to its first maximum, under the ReLU's sign
+    for (int j = 0; j < NIJ; ++j) {
+      if (j + 1 < NIJ || tid + K::THREADS * j < NIU) {
+        if (UNPOOL) {  // the window's gradient goes to its first maximum, under the ReLU's sign; the other three pixels get zeros
 #pragma unroll
-          for (int c = 0; c < K::KOC; ++c) ir[j][c] = (ic[j][c] & 7) == (4 | upos[j]) ? ir[j][c] : 0.0f;
-        }
-        unsigned pl[K::KOC / 2][NPL];
+          for (int pos = 0; pos < 4; ++pos) {
+            float v[K::KOC];
 #pragma unroll
-        for (int c = 0; c < K::KOC / 2; ++c) split_planes(ir[j][2 * c], ir[j][2 * c + 1], isc[j], pl[c]);
-        char* d = ldsp + idst[j];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-          *(u4v*)(d + p * K::IMG_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
-          *(u4v*)(d + p * K::IMG_PLANE + 16) = (u4v){pl[4][p], pl[5][p], pl[6][p], pl[7][p]};
+            for (int c = 0; c < K::KOC; ++c) v[c] = (ic[j][c] & 7) == (4 | pos) ? ir[j][c] : 0.0f;
+            commit_px(ldsp + idst[j] + ((pos >> 1) * K::LP + (pos & 1)) * K::PIXB, v, isc[j]);
+          }
+        } else {
+          commit_px(ldsp + idst[j], ir[j], isc[j]);
         }
       }
     }
@@ -403,26 +414,31 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
     const int pl = i / ((K::AROWS - K::KAPPA) * 8), r = i % ((K::AROWS - K::KAPPA) * 8);
     *(u4v*)(ldsw + pl * K::A_PLANE + K::KAPPA * 128 + r * 16) = (u4v){0u, 0u, 0u, 0u};
   }
-  // ---- staging maps
-  int64_t aoff[K::NA], boff[K::NBU];  // offsets inside a sample (floats), without the band shift
-  int awr[K::NA], bwr[K::NBU], asmp[K::NA], bsmp[K::NBU], bry[K::NBU], apos[K::NA];
+  // ---- staging maps.  UNPOOL: an A unit is (8 channels, one pooling WINDOW): its four pixels share the 8 gradients and decision bytes
   constexpr int ACS = UNPOOL ? K::P / 4 : K::P;                       // channel stride of `dz`
   constexpr int ABAND = UNPOOL ? (K::BR / 2) * (K::OH / 2) : K::BR * K::OH;  // band shift inside a channel
+  constexpr int A_UNITS = UNPOOL ? K::KAPPA * 2 : K::A_UNITS, NA = (A_UNITS + 255) / 256;
+  int64_t aoff[NA], boff[K::NBU];  // offsets inside a sample (floats), without the band shift
+  int awr[NA], awr1[UNPOOL ? NA : 1], bwr[K::NBU], asmp[NA], bsmp[K::NBU], bry[K::NBU];
   unsigned bxok = 0u;                 // bit t: the unit's column is inside the image
 #pragma unroll
-  for (int t = 0; t < K::NA; ++t) {
-    const int u = min(tid + 256 * t, K::A_UNITS - 1);
-    const int c8 = u / K::KAPPA, kap = u % K::KAPPA, bl = kap / (K::BR * K::OH), w = kap % (K::BR * K::OH);
-    asmp[t] = bl;
+  for (int t = 0; t < NA; ++t) {
+    const int u = min(tid + 256 * t, A_UNITS - 1);
     if (UNPOOL) {
       static_assert(!UNPOOL || (K::BR % 2 == 0 && K::OH % 2 == 0), "bands of whole row pairs");
-      const int yl = w / K::OH, x = w % K::OH;
-      aoff[t] = (int64_t)(oct * 64 + c8 * 8) * ACS + (yl >> 1) * (K::OH / 2) + (x >> 1);  // + band * (BR / 2) * (OH / 2), + sample * dz_sn, + c * P / 4
-      apos[t] = (yl & 1) * 2 + (x & 1);
+      constexpr int WPS = (K::BR / 2) * (K::OH / 2), NW = K::KAPPA / 4;  // windows per sample band / per stage
+      const int c8 = u / NW, win = u % NW, bl = win / WPS, wr = win % WPS, wy = wr / (K::OH / 2), wx = wr % (K::OH / 2);
+      asmp[t] = bl;
+      aoff[t] = (int64_t)(oct * 64 + c8 * 8) * ACS + wr;                      // + band * (BR / 2) * (OH / 2), + sample * dz_sn, + c * P / 4
+      const int k0 = bl * (K::BR * K::OH) + 2 * wy * K::OH + 2 * wx, k1 = k0 + K::OH;  // even: k and k + 1 share the swizzle
+      awr[t] = k0 * 128 + ((c8 * 16) ^ (((k0 >> 1) & 1) * 64));
+      awr1[t] = k1 * 128 + ((c8 * 16) ^ (((k1 >> 1) & 1) * 64));
     } else {
+      const int c8 = u / K::KAPPA, kap = u % K::KAPPA, bl = kap / (K::BR * K::OH), w = kap % (K::BR * K::OH);
+      asmp[t] = bl;
       aoff[t] = (int64_t)(oct * 64 + c8 * 8) * K::P + w;                      // + band * BR * OH, + sample * dz_sn, + c * P
+      awr[t] = kap * 128 + ((c8 * 16) ^ (((kap >> 1) & 1) * 64));
     }
-    awr[t] = kap * 128 + ((c8 * 16) ^ (((kap >> 1) & 1) * 64));
   }
 #pragma unroll
   for (int t = 0; t < K::NBU; ++t) {
@@ -450,16 +466,16 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
       const int bl = kap / (K::BR * K::OH), w = kap % (K::BR * K::OH);
       brow[g][r] = kap < K::KAPPA ? ((bl * K::BRW + w / K::OH) * K::LP + w % K::OH) * K::BP : 0;  // padded kappa: any row (dz is zero there)
     }
-  float ar[K::NA][8], br[K::NBU][8], bsum[K::NA][8];
-  uint8_t ac[UNPOOL ? K::NA : 1][8];
+  float ar[NA][8], br[K::NBU][8], bsum[NA][8];
+  uint8_t ac[UNPOOL ? NA : 1][8];
 #pragma unroll
-  for (int t = 0; t < K::NA; ++t)
+  for (int t = 0; t < NA; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) bsum[t][c] = 0.0f;
   auto fetch = [&](int st) {
     const int sg = st / K::NBANDS, band = st % K::NBANDS;
 #pragma unroll
-    for (int t = 0; t < K::NA; ++t) {
+    for (int t = 0; t < NA; ++t) {
       const int64_t o = (int64_t)min(sg * K::NB + asmp[t], n - 1) * dz_sn + aoff[t] + band * ABAND;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -478,24 +494,34 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
   auto commit = [&](int st) {
     const int sg = st / K::NBANDS, band = st % K::NBANDS;
 #pragma unroll
-    for (int t = 0; t < K::NA; ++t) {
-      if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+    for (int t = 0; t < NA; ++t) {
+      if (t + 1 < NA || tid + 256 * t < A_UNITS) {
         if (sg * K::NB + asmp[t] >= n) {  // missing sample of a ragged last stage: contributes zero
 #pragma unroll
           for (int c = 0; c < 8; ++c) ar[t][c] = 0.0f;
         }
-        if (UNPOOL) {  // the window's gradient goes to its first maximum, under the ReLU's sign
+        auto put = [&](char* d, const float (&v)[8]) {
+          unsigned pl[4][NPL];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) ar[t][c] = (ac[t][c] & 7) == (4 | apos[t]) ? ar[t][c] : 0.0f;
+          for (int c = 0; c < 4; ++c) split_planes(v[2 * c], v[2 * c + 1], sd, pl[c]);
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::A_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+        };
+        if (UNPOOL) {  // the window's gradient goes to its first maximum, under the ReLU's sign; the other three pixels get zeros
+#pragma unroll
+          for (int pos = 0; pos < 4; ++pos) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (ac[t][c] & 7) == (4 | pos) ? ar[t][c] : 0.0f;
+            put(ldsw + ((pos >> 1) ? awr1[t] : awr[t]) + (pos & 1) * 128, v);
+          }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) bsum[t][c] += (ac[t][c] & 4) ? ar[t][c] : 0.0f;
+        } else {
+          put(ldsw + awr[t], ar[t]);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
         }
-        unsigned pl[4][NPL];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sd, pl[c]);
-        char* d = ldsw + awr[t];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) *(u4v*)(d + p * K::A_PLANE) = (u4v){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) bsum[t][c] += ar[t][c];
       }
     }
 #pragma unroll
@@ -563,15 +589,16 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
   __syncthreads();
   float* red = (float*)ldsw;  // [unit][8]
 #pragma unroll
-  for (int t = 0; t < K::NA; ++t)
-    if (t + 1 < K::NA || tid + 256 * t < K::A_UNITS) {
+  for (int t = 0; t < NA; ++t)
+    if (t + 1 < NA || tid + 256 * t < A_UNITS) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) red[(tid + 256 * t) * 8 + c] = bsum[t][c];
     }
   __syncthreads();
-  if (tid < 64) {  // oc = oct * 64 + tid: units (c8 = tid / 8) * KAPPA .. + KAPPA - 1, channel tid % 8
+  if (tid < 64) {  // oc = oct * 64 + tid: units (c8 = tid / 8) * UPC .. + UPC - 1, channel tid % 8
+    constexpr int UPC = A_UNITS / 8;  // units per channel group: the stage's pixels, or its windows (UNPOOL)
     float sacc = 0.0f;
-    for (int k = 0; k < K::KAPPA; ++k) sacc += red[((tid >> 3) * K::KAPPA + k) * 8 + (tid & 7)];
+    for (int k = 0; k < UPC; ++k) sacc += red[((tid >> 3) * UPC + k) * 8 + (tid & 7)];
     slab[(int64_t)K::COUT * K::KT + oct * 64 + tid] = sacc;
   }
 }
