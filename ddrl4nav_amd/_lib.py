@@ -104,11 +104,13 @@ SIGNATURES = {
     "ddrl_op_conv_pack_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
     "ddrl_op_conv_pack": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_forward": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
-    "ddrl_op_conv_dgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_dgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_wgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p]),
+                                            c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_plane_scales": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_conv_pooled_uses_scales": (c_int32, [POINTER(ConvDesc)]),
     "ddrl_op_conv_has_forward_pool": (c_int32, [POINTER(ConvDesc)]),
-    "ddrl_op_conv_forward_pool": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_forward_pool": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_dgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_ws_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
     "ddrl_op_conv_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -126,8 +126,20 @@ int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d) {
   return (conv_has_first(g) || (conv_has_planes(g) && conv_planes_has_pool(g))) ? 1 : 0;
 }
 
+int32_t ddrl_op_plane_scales(const float* x, int64_t sn, int32_t elems, int32_t n, float* scales, void* stream) {
+  if (!x || !scales || n < 1 || elems < 4 || (elems & 3) || (sn & 3) || sn < elems || !aligned16(x)) return DDRL_ERR_INVALID_ARG;
+  launch_plane_scales(x, sn, elems, n, scales, (hipStream_t)stream);
+  return op_check();
+}
+
+int32_t ddrl_op_conv_pooled_uses_scales(const ddrl_conv_desc* d) {
+  ConvGeom g;
+  if (!fill_geom(d, g)) return 0;
+  return (!conv_has_first(g) && conv_has_planes(g) && conv_planes_has_pool(g)) ? 1 : 0;
+}
+
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
-                                  uint8_t* code, void* stream) {
+                                  uint8_t* code, const float* in_scales, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !pooled || !code) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(in)) return DDRL_ERR_INVALID_ARG;
@@ -135,32 +147,32 @@ int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, cons
   if (conv_has_first(g))
     launch_conv_first_fwd_pool(g, in, packed + v.off[5], bias, pooled, code, (hipStream_t)stream);
   else if (conv_has_planes(g) && conv_planes_has_pool(g))
-    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], const_cast<float*>(packed) + v.off[7], bias, pooled, code, (hipStream_t)stream);
+    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], const_cast<float*>(packed) + v.off[7], in_scales, bias, pooled, code, (hipStream_t)stream);
   else
     return DDRL_ERR_UNSUPPORTED;  // the caller runs ddrl_op_conv_forward + ddrl_op_maxpool2_forward_idx
   return op_check();
 }
 
 int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
-                                  void* stream) {
+                                  const float* dpool_scales, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !dpool || !code || !packed || !din) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(din) || !aligned16(dpool)) return DDRL_ERR_INVALID_ARG;
   if (!(conv_has_planes(g) && conv_planes_has_pool(g))) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], const_cast<float*>(packed) + v.off[7], din, (hipStream_t)stream);
+  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], const_cast<float*>(packed) + v.off[7], dpool_scales, din, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
-                                  float* ws, float* dw, float* db, void* stream) {
+                                  float* ws, float* dw, float* db, const float* in_scales, const float* dpool_scales, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !dpool || !code || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(in) || !aligned16(dpool) || ((uintptr_t)code & 1)) return DDRL_ERR_INVALID_ARG;
   if (conv_has_first(g))
     launch_conv_first_wgrad_pooled(g, in, dpool, code, ws, dw, db, (hipStream_t)stream);
   else if (conv_has_planes(g) && conv_planes_has_pool(g))
-    launch_conv_planes_wgrad_pooled(g, in, dpool, code, ws, dw, db, (hipStream_t)stream);
+    launch_conv_planes_wgrad_pooled(g, in, dpool, code, in_scales, dpool_scales, ws, dw, db, (hipStream_t)stream);
   else
     return DDRL_ERR_UNSUPPORTED;
   return op_check();

@@ -46,13 +46,15 @@ void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf
                             hipStream_t st);
 void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* scales, float* din, hipStream_t st);
 bool conv_planes_has_pool(const ConvGeom& g);     // forward with ReLU + max_pool2d(2) in the epilogue
-void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, float* pooled, uint8_t* code,
-                                 hipStream_t st);
+// `given*`: per-sample plane scales the caller already holds (launch_plane_scales), or nullptr for a pre-pass into the scratch
+void launch_plane_scales(const float* x, int64_t sn, int elems, int n, float* scales, hipStream_t st);
+void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* given, const float* bias,
+                                 float* pooled, uint8_t* code, hipStream_t st);
 // gradients of such a layer from d(pooled) + decision bytes (scales / part as launch_conv_planes_dgrad / _wgrad)
-void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, float* din,
-                                     hipStream_t st);
-void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
-                                     hipStream_t st);
+void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, const float* given,
+                                     float* din, hipStream_t st);
+void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, const float* given_in,
+                                     const float* given_dp, float* part, float* dw, float* db, hipStream_t st);
 int conv_planes_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no plane kernels
 // part: conv_planes_wgrad_splits slabs of cout * cin * kh * kw + cout floats, then 2 n floats (per-sample scales of this launch)
 void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);

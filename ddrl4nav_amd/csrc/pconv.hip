@@ -659,6 +659,11 @@ static PlanesId planes_id(const ConvGeom& g) {
 
 bool conv_has_planes(const ConvGeom& g) { return planes_id(g) != kPNone; }
 
+// per-sample power-of-two plane scales of x[n][elems] (sample stride sn): what the plane kernels compute in their pre-pass
+void launch_plane_scales(const float* x, int64_t sn, int elems, int n, float* scales, hipStream_t st) {
+  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, x, sn, elems, scales);
+}
+
 // floats of ONE packed region (forward or data gradient): the planes (2 bytes x 2 planes per weight = 4 bytes) + a 64-float header
 int64_t conv_planes_pack_floats(const ConvGeom& g) { return (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2 + 64; }
 
@@ -690,32 +695,32 @@ static void run_planes(const float* in, int64_t in_sn, const float* region, int6
 }
 
 template <class K>
-static void run_planes_pool(const float* in, int64_t in_sn, const float* region, int64_t planes, float* scales, const float* bias, float* pooled,
-                            uint8_t* code, int n, hipStream_t st) {
+static void run_planes_pool(const float* in, int64_t in_sn, const float* region, int64_t planes, float* scales, const float* given, const float* bias,
+                            float* pooled, uint8_t* code, int n, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
+  if (!given) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
-                     in_sn, (const unsigned short*)region, region + planes, scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, (const uint8_t*)nullptr, n);
+                     in_sn, (const unsigned short*)region, region + planes, given ? given : scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, (const uint8_t*)nullptr, n);
 }
 
 // data gradient straight from d(pooled) + decision bytes (K = the layer's data-gradient geometry: CIN = dz channels, HIN = dz size).
 // The per-sample scales come from d(pooled) itself: max |d(pooled)| bounds max |dz| (the routing only drops elements).
 template <class K>
-static void run_planes_unpool(const float* dpool, const uint8_t* ucode, const float* region, int64_t planes, float* scales, float* din, int64_t din_sn,
-                              int n, hipStream_t st) {
+static void run_planes_unpool(const float* dpool, const uint8_t* ucode, const float* region, int64_t planes, float* scales, const float* given,
+                              float* din, int64_t din_sn, int n, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
   constexpr int64_t PSN = (int64_t)K::CIN * K::RAW / 4;
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales);
+  if (!given) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES,
-                     st, dpool, PSN, (const unsigned short*)region, region + planes, scales, (const float*)nullptr, 0, din, din_sn, (uint8_t*)nullptr, ucode, n);
+                     st, dpool, PSN, (const unsigned short*)region, region + planes, given ? given : scales, (const float*)nullptr, 0, din, din_sn, (uint8_t*)nullptr, ucode, n);
 }
 
 // conv + ReLU + max_pool2d(2) in one launch for the layers whose tiles allow it (four column tiles per wave)
@@ -727,13 +732,13 @@ bool conv_planes_has_pool(const ConvGeom& g) {
 #endif
 }
 
-void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* bias, float* pooled, uint8_t* code,
-                                 hipStream_t st) {
+void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* given, const float* bias,
+                                 float* pooled, uint8_t* code, hipStream_t st) {
 #if !DDRL_PC_WIDE
   const int64_t planes = (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2;
   switch (planes_id(g)) {
-    case kPN1dC2: run_planes_pool<PN1dC2F>(in, g.in_sn, wpf, planes, scales, bias, pooled, code, g.n, st); break;
-    case kPN1dC3: run_planes_pool<PN1dC3F>(in, g.in_sn, wpf, planes, scales, bias, pooled, code, g.n, st); break;
+    case kPN1dC2: run_planes_pool<PN1dC2F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
+    case kPN1dC3: run_planes_pool<PN1dC3F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
     default: break;
   }
 #endif
@@ -812,8 +817,8 @@ static void run_planes_wgrad(const ConvGeom& g, const float* in, const float* dz
 }
 
 template <class K>
-static void run_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* scales, int S,
-                                    hipStream_t st) {
+static void run_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* scales,
+                                    const float* given_in, const float* given_dp, int S, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)pconv::wgrad_planes_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
@@ -822,23 +827,23 @@ static void run_planes_wgrad_pooled(const ConvGeom& g, const float* in, const fl
   float* sc_in = scales;
   float* sc_dz = scales + g.n;
   constexpr int64_t PSN = (int64_t)K::COUT * K::P / 4;
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz);  // max |d(pooled)| bounds max |dz|
+  if (!given_in) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
+  if (!given_dp) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz);  // max |d(pooled)| bounds max |dz|
   hipLaunchKernelGGL((pconv::wgrad_planes_kernel<K, true>), dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in,
-                     g.in_sn, dpool, PSN, ucode, sc_in, sc_dz, part, g.n, S);
+                     g.in_sn, dpool, PSN, ucode, given_in ? given_in : sc_in, given_dp ? given_dp : sc_dz, part, g.n, S);
 }
 
 // weight / data gradient of a pooled layer straight from d(pooled) + decision bytes (the layers of conv_planes_has_pool)
-void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
-                                     hipStream_t st) {
+void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, const float* given_in,
+                                     const float* given_dp, float* part, float* dw, float* db, hipStream_t st) {
 #if !DDRL_PC_WIDE
   const int S = conv_planes_wgrad_splits(g);
   const int KT = g.cin * g.kh * g.kw;
   const int64_t slab = (int64_t)g.cout * KT + g.cout;
   float* scales = part + (int64_t)S * slab;
   switch (planes_id(g)) {
-    case kPN1dC2: run_planes_wgrad_pooled<PN1dC2W>(g, in, dpool, ucode, part, scales, S, st); break;
-    case kPN1dC3: run_planes_wgrad_pooled<PN1dC3W>(g, in, dpool, ucode, part, scales, S, st); break;
+    case kPN1dC2: run_planes_wgrad_pooled<PN1dC2W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
+    case kPN1dC3: run_planes_wgrad_pooled<PN1dC3W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
     default: return;
   }
   launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
@@ -846,13 +851,13 @@ void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const f
 #endif
 }
 
-void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, float* din,
-                                     hipStream_t st) {
+void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, const float* given,
+                                     float* din, hipStream_t st) {
 #if !DDRL_PC_WIDE
   const int64_t planes = (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2;
   switch (planes_id(g)) {
-    case kPN1dC2: run_planes_unpool<PN1dC2D>(dpool, ucode, wpd, planes, scales, din, g.in_sn, g.n, st); break;
-    case kPN1dC3: run_planes_unpool<PN1dC3D>(dpool, ucode, wpd, planes, scales, din, g.in_sn, g.n, st); break;
+    case kPN1dC2: run_planes_unpool<PN1dC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
+    case kPN1dC3: run_planes_unpool<PN1dC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
     default: break;
   }
 #endif

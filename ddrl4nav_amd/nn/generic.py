@@ -21,7 +21,7 @@ from ddrl4nav_amd import _lib
 from ddrl4nav_amd._lib import STATS_FLOATS, HeadsDesc, check
 from ddrl4nav_amd.data import Experience
 from ddrl4nav_amd.nn.base import Basenn, PreNet
-from ddrl4nav_amd.ops import Conv, Linear, maxpool2_idx, maxpool2_backward_idx, _p, _st
+from ddrl4nav_amd.ops import Conv, Linear, maxpool2_idx, maxpool2_backward_idx, plane_scales, _p, _st
 from ddrl4nav_amd.utils.staging import to_device
 
 FEAT = 512
@@ -123,6 +123,12 @@ class _ConvPool:
         # ... and their backward reads d(pooled) + the decision bytes (ddrl_op_conv_*_pooled): no full-resolution gradient either
         # (DDRL_POOL_BWD_UNFUSED=1: A/B switch, the pool's backward as its own launch)
         self.fused_bwd = self.fused and os.environ.get("DDRL_POOL_BWD_UNFUSED") != "1"
+        # per-sample plane scales of the layer's input and of d(pooled), computed once per pass and shared by the operators that read
+        # the same tensor (forward + weight gradient; data + weight gradient)
+        self.in_sc = self.dp_sc = None
+        if self.fused and self.op.pooled_uses_scales() and os.environ.get("DDRL_SCALES_PER_OP") != "1":
+            self.in_sc = torch.empty((cap,), **f)
+            self.dp_sc = torch.empty((cap,), **f)
         self.dz = None if self.fused_bwd else torch.empty((cap, module.out_channels, oh, ow), **f)   # d(loss)/d(pre-activation)
         if pool:
             self.p = torch.empty((cap, module.out_channels, oh // 2, ow // 2), **f)
@@ -151,7 +157,9 @@ class _ConvPool:
 
     def forward(self, x, n):
         if self.fused:
-            self.op.forward_pool(x, self.m.bias.data, self.p, self.code, n=n)
+            if self.in_sc is not None:
+                plane_scales(x, n, self.in_sc)
+            self.op.forward_pool(x, self.m.bias.data, self.p, self.code, n=n, in_scales=self.in_sc)
             return self.p
         self.op.forward(x, self.m.bias.data, self.relu, out=self._a, n=n)
         if not self.pool:
@@ -165,9 +173,12 @@ class _ConvPool:
 
     def backward(self, x, n, din=None):
         if self.fused_bwd:
-            self.op.wgrad_pooled(x, self.dp, self.code, self.m.weight.grad_view, self.m.bias.grad_view, n=n)
+            if self.dp_sc is not None:
+                plane_scales(self.dp, n, self.dp_sc)
+            self.op.wgrad_pooled(x, self.dp, self.code, self.m.weight.grad_view, self.m.bias.grad_view, n=n, in_scales=self.in_sc,
+                                 dpool_scales=self.dp_sc)
             if din is not None:
-                self.op.dgrad_pooled(self.dp, self.code, din=din, n=n)
+                self.op.dgrad_pooled(self.dp, self.code, din=din, n=n, dpool_scales=self.dp_sc)
             return
         if self.pool:
             maxpool2_backward_idx(self.dp[:n], self.code, self.oh, self.ow, dz=self.dz)

@@ -60,25 +60,30 @@ class Conv:
         """True when the layer's kernels take ReLU + max_pool2d(2) into their epilogue (include/ddrl.h ddrl_op_conv_forward_pool)."""
         return bool(self.lib.ddrl_op_conv_has_forward_pool(byref(self.desc(1))))
 
-    def forward_pool(self, x, bias, pooled, code, n=None):
+    def pooled_uses_scales(self):
+        """True when the pooled operators of this layer read per-sample plane scales (plane_scales below)."""
+        return bool(self.lib.ddrl_op_conv_pooled_uses_scales(byref(self.desc(1))))
+
+    def forward_pool(self, x, bias, pooled, code, n=None, in_scales=None):
         """max_pool2d(relu(conv(x)), 2) in one launch: pooled [n][cout][oh/2][ow/2] + one decision byte per window."""
         n = x.shape[0] if n is None else n
         check(self.lib.ddrl_op_conv_forward_pool(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)), _p(pooled),
-                                                 _p(code), _st()))
+                                                 _p(code), _p(in_scales), _st()))
         return pooled
 
-    def dgrad_pooled(self, dpool, code, din=None, n=None):
+    def dgrad_pooled(self, dpool, code, din=None, n=None, dpool_scales=None):
         """Data gradient of a forward_pool layer from d(pooled) + decision bytes (no full-resolution gradient in between)."""
         n = dpool.shape[0] if n is None else n
         if din is None:
             din = torch.empty((n, self.cin, self.h, self.w), dtype=torch.float32, device=dpool.device)
-        check(self.lib.ddrl_op_conv_dgrad_pooled(byref(self.desc(n)), _p(_f32(dpool)), _p(code), _p(self.packed), _p(din), _st()))
+        check(self.lib.ddrl_op_conv_dgrad_pooled(byref(self.desc(n)), _p(_f32(dpool)), _p(code), _p(self.packed), _p(din),
+                                                 _p(dpool_scales), _st()))
         return din
 
-    def wgrad_pooled(self, x, dpool, code, dw, db, n=None):
+    def wgrad_pooled(self, x, dpool, code, dw, db, n=None, in_scales=None, dpool_scales=None):
         n = x.shape[0] if n is None else n
         check(self.lib.ddrl_op_conv_wgrad_pooled(byref(self.desc(n)), _p(_f32(x)), _p(_f32(dpool)), _p(code), _p(self.packed),
-                                                 _p(self.ws), _p(dw), _p(db), _st()))
+                                                 _p(self.ws), _p(dw), _p(db), _p(in_scales), _p(dpool_scales), _st()))
 
     def dgrad(self, dz, din=None, n=None):
         n = dz.shape[0] if n is None else n
@@ -92,6 +97,13 @@ class Conv:
         assert n <= self.max_n, "batch larger than the split-K scratch was sized for"
         check(self.lib.ddrl_op_conv_wgrad(byref(self.desc(n)), _p(_f32(x)), _p(_f32(dz)), _p(self.packed), _p(self.ws),
                                           _p(dw), _p(db), _st()))
+
+
+def plane_scales(x, n, out):
+    """Per-sample power-of-two plane scales of x[:n] (dense samples) for the *_pool / *_pooled operators (include/ddrl.h)."""
+    elems = x[0].numel()
+    check(_lib.load().ddrl_op_plane_scales(_p(_f32(x)), elems, elems, n, _p(out), _st()))
+    return out
 
 
 def maxpool2(x, out=None):

@@ -317,16 +317,24 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
  * full-resolution activations are never written.  DDRL_ERR_UNSUPPORTED for every other layer: run ddrl_op_conv_forward and
  * ddrl_op_maxpool2_forward_idx instead.  `in` 16-byte aligned, sample stride a multiple of 4 floats. */
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
-                                  uint8_t* code, void* stream);
+                                  uint8_t* code, const float* in_scales, void* stream);
+/* The fp16-plane kernels scale every sample by a power of two taken from its largest magnitude, found in a pre-pass over the tensor.
+ * A caller that runs several operators on the SAME tensor (the forward and the weight gradient both read the layer's input; the data
+ * and the weight gradient both read d(pooled)) computes the scales once with ddrl_op_plane_scales(x [n] samples of `elems` floats at
+ * stride sn -> scales[n]) and hands them to the *_pool / *_pooled operators as in_scales / dpool_scales; NULL = the operator runs
+ * its own pre-pass.  The scales of d(pooled) are taken from d(pooled) itself (its largest magnitude bounds the routed gradient's).
+ * ddrl_op_conv_pooled_uses_scales: 1 for the layers that read them (the 3-channel first layer finds its scales inside its kernels). */
+int32_t ddrl_op_plane_scales(const float* x, int64_t sn, int32_t elems, int32_t n, float* scales, void* stream);
+int32_t ddrl_op_conv_pooled_uses_scales(const ddrl_conv_desc* d);
 int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d);  /* 1 when ddrl_op_conv_forward_pool serves the layer, else 0 (host only) */
 /* The backward of the same layers straight from d(pooled) [n][cout][oh/2][ow/2] and the decision bytes: the kernels form
  * d(pre-activation) while they stage it (the pooled gradient at each window's first maximum under the ReLU's sign, zero elsewhere --
  * what ddrl_op_maxpool2_backward_idx would write), so the full-resolution gradient is neither written nor read.  Same layers as
  * ddrl_op_conv_forward_pool (the 3-channel first layer has no data gradient: DDRL_ERR_UNSUPPORTED); dpool 16-byte aligned, dense. */
 int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
-                                  void* stream);
+                                  const float* dpool_scales, void* stream);
 int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
-                                  float* ws, float* dw, float* db, void* stream);
+                                  float* ws, float* dw, float* db, const float* in_scales, const float* dpool_scales, void* stream);
 int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream);
 /* dw [cout][cin][kh][kw], db [cout] (overwritten); `ws` = split-K scratch of ddrl_op_conv_ws_floats.
  * Requires oh*ow >= 32. */

@@ -106,6 +106,14 @@ def test_conv_relu_pool_in_one_launch_vs_torch(shape):
     pooled = torch.full((n, cout, oh // 2, oh // 2), -7.0).cuda()
     code = torch.full((n, cout, oh // 2, oh // 2), 255, dtype=torch.uint8).cuda()
     conv.forward_pool(x.cuda(), b.cuda(), pooled, code, n=n)
+    if conv.pooled_uses_scales():   # the caller's per-sample scales (shared by forward and weight gradient) = the operator's own pre-pass
+        from ddrl4nav_amd.ops import plane_scales
+        sc = plane_scales(x.cuda(), n, torch.empty(n).cuda())
+        p2, c2 = torch.empty_like(pooled), torch.empty_like(code)
+        conv.forward_pool(x.cuda(), b.cuda(), p2, c2, n=n, in_scales=sc)
+        assert torch.equal(p2, pooled) and torch.equal(c2, code)
+    else:
+        assert cin == 3
     close(pooled, want.float())
     close(pooled[1], want[1].float())                      # the faint sample on its own scale
     assert int(code.max()) < 8
