@@ -29,11 +29,23 @@ def short(k):
     m = re.search(r"ddrl::pconv::(\w+?)_kernel<ddrl::pconv::\w+<([\d, ]+)>", k)
     if m:
         g = [x.strip() for x in m.group(2).split(",")]
-        return "pconv_%s<%s>" % (m.group(1), "x".join(g[:5]))      # CIN x COUT x KS x HIN x PAD
+        tail = k[m.end():m.end() + 16]
+        flag = ".pool" if tail.startswith(", true, false") else (".unpool" if (tail.startswith(", false, true") or tail.startswith(", true>")) else "")
+        return "pconv_%s<%s>%s" % (m.group(1), "x".join(g[:5]), flag)      # CIN x COUT x KS x HIN x PAD
+    m = re.search(r"ddrl::fconv::(\w+?)_kernel<ddrl::fconv::\w+<([\d, ]+)>, (\w+)>", k)
+    if m:
+        flag = "" if m.group(3) != "true" else (".unpool" if "wgrad" in m.group(1) else ".pool")
+        return "fconv_%s<%s>%s" % (m.group(1), "x".join(x.strip() for x in m.group(2).split(",")), flag)
+    m = re.search(r"ddrl::plin::(\w+?)_kernel(?:<(\d)>)?", k)
+    if m:
+        return "plin_" + m.group(1) + ("" if m.group(2) is None else {"0": ".fwd", "1": ".dgrad"}[m.group(2)])
     m = re.search(r"engine2_kernel<ddrl::dconv::(\w+)<([\d, ]+)>", k)
     if m:
         g = [x.strip() for x in m.group(2).split(",")]
         return "dconv_%s<%s>" % (m.group(1), "x".join(g[:5]))
+    m = re.search(r"engine2_kernel<ddrl::(gconv|glin)::(\w+)(?:<(\w+)>)?", k)
+    if m:
+        return "%s_%s%s" % (m.group(1), m.group(2), "" if m.group(3) is None else "." + m.group(3))
     m = re.search(r"engine2_kernel<ddrl::(\w+?)(?:v2|2)?(?:<(\d)>)?\s*>", k)
     if m:
         return m.group(1) + ("" if not m.group(2) or m.group(2) == "2" else ".ne" + m.group(2))
@@ -54,7 +66,7 @@ def main():
                 continue
             # acting-size launches of the forward kernels (small grids) are kept apart from the
             # training-size ones; every other kernel only runs in training (or is size-independent)
-            big = ("fwd" not in name.lower() and name != "heads_act") or name == "conv_fwd1_resident" or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000  # (the resident conv1 kernel: one workgroup per CU, training launches only)
+            big = ("fwd" not in name.lower() and name != "heads_act") or name == "conv_fwd1_resident" or name.startswith(("fconv_", "plin_")) or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000  # (the resident conv1 kernel: one workgroup per CU, training launches only)
             key = name + ("" if big else ":acting")
             c = agg[key][row["Counter_Name"]]
             c[0] += float(row["Counter_Value"])
