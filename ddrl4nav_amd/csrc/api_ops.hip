@@ -41,6 +41,7 @@ static PackView pack_view(const ConvGeom& g) {
     sz[5] = sz[6] = conv_planes_pack_floats(g);
     sz[7] = g.n;
   }
+  if (conv_has_c1d(g)) sz[5] = sz[6] = conv_c1d_pack_floats(g);  // c1d.hip: transposed weights for the scalar cache
   if (conv_has_first(g)) {  // fconv.hip: forward weight planes only (a first layer has no data gradient)
     sz[5] = conv_first_pack_floats(g);
     sz[6] = 0;
@@ -78,7 +79,9 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
   const PackView v = pack_view(g);
   launch_conv_pack(g, w, packed + v.off[0], (int2*)(packed + v.off[1]), packed + v.off[2], (int2*)(packed + v.off[3]),
                    (int*)(packed + v.off[4]), (hipStream_t)stream);
-  if (conv_has_first(g))
+  if (conv_has_c1d(g))
+    launch_conv_c1d_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
+  else if (conv_has_first(g))
     launch_conv_first_pack(g, w, packed + v.off[5], (hipStream_t)stream);
   else if (conv_has_planes(g))
     launch_conv_planes_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
@@ -94,6 +97,7 @@ int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
   if (conv_direct_wgrad_splits(g) > splits) splits = conv_direct_wgrad_splits(g);
   if (conv_planes_wgrad_splits(g) > splits) splits = conv_planes_wgrad_splits(g);
   if (conv_first_wgrad_splits(g) > splits) splits = conv_first_wgrad_splits(g);
+  if (conv_c1d_wgrad_splits(g) > splits) splits = conv_c1d_wgrad_splits(g);
   // + the per-sample scales of the plane kernels (pconv.hip): 2 n floats behind the slabs
   *floats = (int64_t)splits * ((int64_t)g.cout * g.cin * g.kh * g.kw + g.cout) + (conv_has_planes(g) ? 2 * (int64_t)g.n + 64 : 0);
   return DDRL_OK;
@@ -105,7 +109,9 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
   if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
   // the caller sized `packed` for its largest batch (ddrl_op_conv_pack_floats with that n): region 7 holds this launch's scales
-  if (conv_has_first(g) && direct_ok(g, in, out))
+  if (conv_has_c1d(g))
+    launch_conv_c1d_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
+  else if (conv_has_first(g) && direct_ok(g, in, out))
     launch_conv_first_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
   else if (conv_has_first(g))
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
@@ -182,7 +188,9 @@ int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float
   ConvGeom g;
   if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  if (conv_has_planes(g) && direct_ok(g, din, dz))
+  if (conv_has_c1d_backward(g))
+    launch_conv_c1d_dgrad(g, dz, packed + v.off[6], din, (hipStream_t)stream);
+  else if (conv_has_planes(g) && direct_ok(g, din, dz))
     launch_conv_planes_dgrad(g, dz, packed + v.off[6], const_cast<float*>(packed) + v.off[7], din, (hipStream_t)stream);
   else if (conv_has_planes(g))
     return DDRL_ERR_INVALID_ARG;
@@ -199,7 +207,9 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
   if (!fill_geom(d, g) || !in || !dz || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if (g.oh * g.ow < 32) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  if (conv_has_first(g) && direct_ok(g, in, dz))
+  if (conv_has_c1d_backward(g))
+    launch_conv_c1d_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
+  else if (conv_has_first(g) && direct_ok(g, in, dz))
     launch_conv_first_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
   else if (conv_has_planes(g) && direct_ok(g, in, dz))
     launch_conv_planes_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);

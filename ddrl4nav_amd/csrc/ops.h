@@ -72,6 +72,16 @@ void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const fl
 int conv_first_wgrad_splits(const ConvGeom& g);  // 0 when the layer is not this one
 void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
 
+// c1d.hip: the two stride-2 Conv1d layers of NavPreNet1D's laser branch as fp32 vector kernels (weights through the scalar cache)
+bool conv_has_c1d(const ConvGeom& g);           // forward
+bool conv_has_c1d_backward(const ConvGeom& g);  // data + weight gradient (the 32 -> 32 layer)
+int64_t conv_c1d_pack_floats(const ConvGeom& g);  // floats of EACH of the two regions
+void launch_conv_c1d_pack(const ConvGeom& g, const float* w, float* wt, float* wd, hipStream_t st);
+void launch_conv_c1d_fwd(const ConvGeom& g, const float* in, const float* wt, const float* bias, int act, float* out, hipStream_t st);
+void launch_conv_c1d_dgrad(const ConvGeom& g, const float* dz, const float* wd, float* din, hipStream_t st);
+int conv_c1d_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no such kernel
+void launch_conv_c1d_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
+
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
 void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);

@@ -29,6 +29,8 @@ CONVS = [
     (7, 64, 9, 9, 64, 3, 3, 1, (0, 0)),      # AtariPreNet.conv3 as an operator (no padding)
     (6, 1, 1, 960, 32, 1, 5, 2, (0, 0)),     # conv1d1
     (6, 32, 1, 478, 32, 1, 3, 2, (0, 0)),    # conv1d2
+    (133, 32, 1, 478, 32, 1, 3, 2, (0, 0)),  # conv1d2, enough samples for several slabs of its weight gradient (csrc/c1d.hip)
+    (5, 32, 1, 101, 32, 1, 3, 2, (0, 0)),    # the same kernels on an odd width
     (1, 5, 9, 11, 70, 3, 2, 1, (2, 0)),      # odd everything, one sample
     (9, 4, 20, 20, 32, 4, 4, 2, (0, 0)),     # stride 2 square
     (2, 3, 16, 16, 8, 8, 8, 4, (0, 0)),      # stride 4
