@@ -211,8 +211,7 @@ void launch_conv_c1d_wgrad(const ConvGeom& g, const float* in, const float* dz, 
   constexpr int TILES = (32 / c1d::WG_OC) * (32 / c1d::WG_C);
   hipLaunchKernelGGL((c1d::wgrad32_kernel<32, 32>), dim3(S, TILES), dim3(256), 0, st, in, g.in_sn, dz, g.out_sn, part, g.w, g.ow, g.n, S);
   const int64_t slab = (int64_t)32 * 32 * 3 + 32;
-  launch_reduce_slabs(part, S, slab, (int64_t)32 * 32 * 3, dw, st);
-  launch_reduce_slabs(part + (int64_t)32 * 32 * 3, S, slab, 32, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)32 * 32 * 3, dw, 32, db, st);
 }
 
 }  // namespace ddrl

@@ -562,8 +562,7 @@ void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* d
   }
   const int KT = g.cin * g.kh * g.kw;
   const int64_t slab = (int64_t)g.cout * KT + g.cout;
-  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
-  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)g.cout * KT, dw, g.cout, db, st);
 }
 
 }  // namespace ddrl

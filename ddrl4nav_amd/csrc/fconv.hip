@@ -581,8 +581,7 @@ void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz
   hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, false>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dz, g.out_sn, (const uint8_t*)nullptr, part,
                      g.n, S);
   const int KT = g.cin * g.kh * g.kw;
-  launch_reduce_slabs(part, S, K::SLAB, (int64_t)g.cout * KT, dw, st);
-  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, K::SLAB, g.cout, db, st);
+  launch_reduce_slabs2(part, S, K::SLAB, (int64_t)g.cout * KT, dw, g.cout, db, st);
 }
 
 // the same from d(pooled) [n][64][OH / 2][OH / 2] + decision bytes
@@ -597,8 +596,7 @@ void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const fl
   const int S = conv_first_wgrad_splits(g);
   hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, true>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dpool, (int64_t)64 * K::PW, ucode, part, g.n, S);
   const int KT = g.cin * g.kh * g.kw;
-  launch_reduce_slabs(part, S, K::SLAB, (int64_t)g.cout * KT, dw, st);
-  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, K::SLAB, g.cout, db, st);
+  launch_reduce_slabs2(part, S, K::SLAB, (int64_t)g.cout * KT, dw, g.cout, db, st);
 }
 
 }  // namespace ddrl

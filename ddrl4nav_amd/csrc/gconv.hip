@@ -612,8 +612,7 @@ void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, cons
       default: hipLaunchKernelGGL(thin_wgrad_kernel<6>, dim3(W), dim3(256), 0, st, g, in, dz, part); break;
     }
     const int64_t slab = (int64_t)g.cout * KT + g.cout;
-    launch_reduce_slabs(part, W, slab, (int64_t)g.cout * KT, dw, st);
-    launch_reduce_slabs(part + (int64_t)g.cout * KT, W, slab, g.cout, db, st);
+    launch_reduce_slabs2(part, W, slab, (int64_t)g.cout * KT, dw, g.cout, db, st);
     return;
   }
   const int KT = g.cin * g.kh * g.kw;
@@ -621,8 +620,7 @@ void launch_conv_wgrad(const ConvGeom& g, const float* in, const float* dz, cons
   gconv::Wgrad::Params p{g, in, dz, ptab, part, KT, S};
   launch_engine2<gconv::Wgrad>(dim3((KT + 255) / 256, (g.cout + 63) / 64, S), p, st);
   const int64_t slab = (int64_t)g.cout * KT + g.cout;
-  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
-  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)g.cout * KT, dw, g.cout, db, st);
 }
 
 // 32-bit index arithmetic whenever every float offset of the full-resolution tensor fits (the usual case: < 16 GiB)

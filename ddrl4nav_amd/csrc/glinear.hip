@@ -304,20 +304,23 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restric
 }
 
 // dst[i] = sum_s part[s * slab_stride + i]   (fixed order)
+// (two destinations: a slab is [weight gradient | bias gradient]; element i < c0 goes to dst0[i], the rest to dst1[i - c0] -- one launch
+// instead of two, the same per-element sums)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nsplit, int64_t slab_stride,
-                                                           int64_t count, float* __restrict__ dst) {
+                                                           int64_t count, float* __restrict__ dst0, int64_t c0, float* __restrict__ dst1) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
   double s = 0.0;  // summed in double, rounded once (optim.hip reduce_partials_kernel)
   for (int sp = 0; sp < nsplit; ++sp) s += (double)part[(int64_t)sp * slab_stride + i];
-  dst[i] = (float)s;
+  if (i < c0) dst0[i] = (float)s;
+  else dst1[i - c0] = (float)s;
 }
 
 // Many slabs, few elements (thin weight gradients: hundreds of splits of a few hundred values): 16
 // lane groups walk the slabs in parallel (group g takes slabs g, g+16, ...), then one lane adds the
 // 16 partial sums in group order -- still a fixed order, so still deterministic.
 __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ part, int nsplit, int64_t slab_stride,
-                                                                int64_t count, float* __restrict__ dst) {
+                                                                int64_t count, float* __restrict__ dst0, int64_t c0, float* __restrict__ dst1) {
   __shared__ double red[16][17];
   const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
@@ -330,18 +333,25 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
     double t = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][e];
-    dst[i] = (float)t;
+    if (i < c0) dst0[i] = (float)t;
+    else dst1[i - c0] = (float)t;
   }
 }
 
-void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st) {
+// dst0[0 .. c0) and dst1[0 .. c1) = the slabs' first c0 + c1 elements summed over the slabs
+void launch_reduce_slabs2(const float* part, int nsplit, int64_t slab_stride, int64_t c0, float* dst0, int64_t c1, float* dst1, hipStream_t st) {
+  const int64_t count = c0 + c1;
   if (count <= 0) return;
   if (nsplit >= 64 && count < 65536)
     hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, st, part, nsplit,
-                       slab_stride, count, dst);
+                       slab_stride, count, dst0, c0, dst1);
   else
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, part, nsplit,
-                       slab_stride, count, dst);
+                       slab_stride, count, dst0, c0, dst1);
+}
+
+void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st) {
+  launch_reduce_slabs2(part, nsplit, slab_stride, count, dst, 0, nullptr, st);
 }
 
 __global__ __launch_bounds__(256) void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
@@ -448,8 +458,7 @@ void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int6
   glin::Wgrad::Params p{dout, ld_dout, in, ld_in, part, n, K, N, S};
   launch_engine2<glin::Wgrad>(dim3((K + 127) / 128, (N + 127) / 128, S), p, st);
   const int64_t slab = (int64_t)N * K + N;
-  launch_reduce_slabs(part, S, slab, (int64_t)N * K, dw, st);
-  launch_reduce_slabs(part + (int64_t)N * K, S, slab, N, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)N * K, dw, N, db, st);
 }
 
 }  // namespace ddrl

@@ -84,6 +84,7 @@ void launch_conv_c1d_wgrad(const ConvGeom& g, const float* in, const float* dz, 
 
 // glinear.hip
 void launch_reduce_slabs(const float* part, int nsplit, int64_t slab_stride, int64_t count, float* dst, hipStream_t st);
+void launch_reduce_slabs2(const float* part, int nsplit, int64_t slab_stride, int64_t c0, float* dst0, int64_t c1, float* dst1, hipStream_t st);
 void launch_relu_mask(float* d, int64_t ld_d, const float* act, int64_t ld_act, int64_t n, int width, hipStream_t st);
 void launch_accumulate(float* dst, const float* src, int64_t count, hipStream_t st);
 void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st);

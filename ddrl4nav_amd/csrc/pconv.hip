@@ -72,10 +72,12 @@ __global__ __launch_bounds__(256) void sample_scale_kernel(const float* __restri
 }
 
 // ---- weights: largest magnitude, then the planes in the order the k index walks ----------------------------------------------
-__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ w, int64_t count, float* __restrict__ slot) {
+// (the forward and the data-gradient region take the same scale: one pass over the weights leaves it in both headers)
+__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ w, int64_t count, float* __restrict__ slot, float* __restrict__ slot2) {
   float m = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
   amax_update(m, slot);
+  amax_update(m, slot2);
 }
 // dst[row tile][cb][tap][plane][row 64][lane half 2][8 channels] (16-bit); hdr[0] = largest |w| (in), hdr[1] = scale (out).
 // dgrad = 0: rows = cout, channels = cin, taps as they are.  dgrad = 1: rows = cin, channels = cout, taps flipped.
@@ -672,11 +674,13 @@ void launch_conv_planes_pack(const ConvGeom& g, const float* w, float* wpf, floa
   const int64_t total = (int64_t)g.cout * g.cin * kk;
   const int64_t planes = total * NPL / 2;
   const unsigned blocks = (unsigned)((total + 255) / 256);
+  (void)hipMemsetAsync(wpf + planes, 0, 64 * sizeof(float), st);
+  (void)hipMemsetAsync(wpd + planes, 0, 64 * sizeof(float), st);
+  const unsigned ablocks = (unsigned)((total + 4095) / 4096 < 512 ? (total + 4095) / 4096 : 512);  // ~16 elements per thread
+  hipLaunchKernelGGL(pconv::weight_amax_kernel, dim3(ablocks), dim3(256), 0, st, w, total, wpf + planes, wpd + planes);
   for (int dg = 0; dg < 2; ++dg) {
     float* region = dg ? wpd : wpf;
     float* hdr = region + planes;
-    (void)hipMemsetAsync(hdr, 0, 64 * sizeof(float), st);
-    hipLaunchKernelGGL(pconv::weight_amax_kernel, dim3(64), dim3(256), 0, st, w, total, hdr);
     hipLaunchKernelGGL(pconv::pack_planes_kernel, dim3(blocks), dim3(256), 0, st, w, g.cin, g.cout, kk, dg, (unsigned short*)region, hdr);
   }
 }
@@ -846,8 +850,7 @@ void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const f
     case kPN1dC3: run_planes_wgrad_pooled<PN1dC3W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
     default: return;
   }
-  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
-  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)g.cout * KT, dw, g.cout, db, st);
 #endif
 }
 
@@ -877,8 +880,7 @@ void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* d
     case kPAtC3: run_planes_wgrad<PAtC3W>(g, in, dz, part, scales, S, st); break;
     default: return;
   }
-  launch_reduce_slabs(part, S, slab, (int64_t)g.cout * KT, dw, st);
-  launch_reduce_slabs(part + (int64_t)g.cout * KT, S, slab, g.cout, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)g.cout * KT, dw, g.cout, db, st);
 }
 
 }  // namespace ddrl

@@ -51,10 +51,12 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
   if (lane == 0) scales[row] = m > 0.0f ? fminf(plane_scale(m), 0x1p60f) : 0x1p60f;
 }
 
-__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ w, int64_t count, float* __restrict__ slot) {
+// (both packed regions of a layer take the same scale: one pass over the weights leaves it in both headers)
+__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ w, int64_t count, float* __restrict__ slot, float* __restrict__ slot2) {
   float m = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
   amax_update(m, slot);
+  amax_update(m, slot2);
 }
 
 // dst[column tile][k-group][plane][column 128][lane half 2][8 k] (16-bit), zero beyond the matrix; hdr[0] = largest |w| (in), hdr[1] = scale.
@@ -405,13 +407,19 @@ int64_t linear_planes_fwd_floats(int K, int N) { return (int64_t)((N + 127) / 12
 int64_t linear_planes_dgrad_floats(int K, int N) { return (int64_t)((K + 127) / 128) * kgs_of(N) * (NPL * 2048) / 2 + 64; }
 
 void launch_linear_planes_pack(const float* w, int K, int N, float* pf, float* pd, hipStream_t st) {
+  float* hdrs[2];
+  for (int t = 0; t < 2; ++t) {
+    const int cols = t ? K : N, kgs = kgs_of(t ? N : K);
+    hdrs[t] = (t ? pd : pf) + (int64_t)((cols + 127) / 128) * kgs * (NPL * 2048) / 2;
+    (void)hipMemsetAsync(hdrs[t], 0, 64 * sizeof(float), st);
+  }
+  const int64_t count = (int64_t)K * N;
+  const unsigned ablocks = (unsigned)((count + 4095) / 4096 < 512 ? (count + 4095) / 4096 : 512);  // ~16 elements per thread, up to two workgroups per CU
+  hipLaunchKernelGGL(plin::weight_amax_kernel, dim3(ablocks), dim3(256), 0, st, w, count, hdrs[0], hdrs[1]);
   for (int t = 0; t < 2; ++t) {
     float* region = t ? pd : pf;
     const int cols = t ? K : N, kgs = kgs_of(t ? N : K);
-    const int64_t planes = (int64_t)((cols + 127) / 128) * kgs * (NPL * 2048) / 2;
-    float* hdr = region + planes;
-    (void)hipMemsetAsync(hdr, 0, 64 * sizeof(float), st);
-    hipLaunchKernelGGL(plin::weight_amax_kernel, dim3(64), dim3(256), 0, st, w, (int64_t)K * N, hdr);
+    float* hdr = hdrs[t];
     const int64_t total = (int64_t)((cols + 127) / 128) * kgs * 2048;
     hipLaunchKernelGGL(plin::pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N, t, kgs, (unsigned short*)region, hdr);
   }
@@ -485,8 +493,7 @@ void launch_linear_planes_wgrad(const float* in, int64_t ld_in, const float* dou
   row_scales(dout, ld_dout, N, n, sc_d, st);
   plin::TnParams p{dout, ld_dout, in, ld_in, sc_d, sc_i, part, n, K, N, S};
   hipLaunchKernelGGL(plin::tn_planes_kernel, dim3((K + 127) / 128, (N + 127) / 128, S), dim3(256), plin::LDS_TN, st, p);
-  launch_reduce_slabs(part, S, slab, (int64_t)N * K, dw, st);
-  launch_reduce_slabs(part + (int64_t)N * K, S, slab, N, db, st);
+  launch_reduce_slabs2(part, S, slab, (int64_t)N * K, dw, N, db, st);
 }
 
 }  // namespace ddrl
