@@ -548,9 +548,42 @@ class GenericPPO(Basenn):
             return [torch.as_tensor(s)[lo:hi] for s in states]
         return [to_device(torch.as_tensor(s)[lo:hi], self.device, torch.float32) for s in states]
 
+    def _side(self):
+        """The second encoder's stream: actor and critic encoders are independent networks with their own buffers and their own slices
+        of the gradient arena, so the critic's runs beside the actor's (its small, latency-bound launches -- dense layers, the laser
+        branch, slab reductions -- fill what the other's leave idle).  DDRL_ENC_STREAMS=0: one stream (A/B switch)."""
+        if self.share_cnn_net or os.environ.get("DDRL_ENC_STREAMS") == "0":
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        return self._side_stream
+
     def _features(self, st, n):
-        hs = [e.forward_dev(st, n) for e in self._encs]
-        return (hs[0], hs[0]) if self.share_cnn_net else (hs[0], hs[1])
+        side = self._side()
+        if side is None:
+            hs = [e.forward_dev(st, n) for e in self._encs]
+            return (hs[0], hs[0]) if self.share_cnn_net else (hs[0], hs[1])
+        cur = torch.cuda.current_stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            hc = self._encs[1].forward_dev(st, n)
+        ha = self._encs[0].forward_dev(st, n)
+        cur.wait_stream(side)
+        return ha, hc
+
+    def _backward_both(self, dha, dhc, n):
+        side = self._side()
+        if side is None:
+            self._encs[0].backward_dev(dha, n)
+            if not self.share_cnn_net:
+                self._encs[1].backward_dev(dhc, n)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._encs[1].backward_dev(dhc, n)
+        self._encs[0].backward_dev(dha, n)
+        cur.wait_stream(side)
 
     def forward(self, states, act=None, play_mode=False):
         states = states if isinstance(states, (list, tuple)) else [states]
@@ -652,9 +685,7 @@ class GenericPPO(Basenn):
             check(self.lib.ddrl_op_value_head_loss(byref(self._cfg), 1, _p(crit.critic_linear.weight.data),
                                                    _p(crit.critic_linear.bias.data), _p(hc), FEAT, n, _p(xr), b_global, _p(dha),
                                                    FEAT, _p(None), _p(None), _p(self.gtmp[self.n_params + 1:]), _p(ws), _st()))
-        self._encs[0].backward_dev(dha, n)
-        if not self.share_cnn_net:
-            self._encs[1].backward_dev(dhc, n)
+        self._backward_both(dha, dhc, n)
 
     def learn(self, data: Experience):
         states = data.states if isinstance(data.states, (list, tuple)) else [data.states]
