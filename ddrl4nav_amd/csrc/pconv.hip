@@ -634,6 +634,10 @@ using PNavC2F = pconv::Geo<64, 128, 3, 24, 1, 1, 6, 3, 3>;    // 576 columns = 1
 using PNavC2D = pconv::Geo<128, 64, 3, 24, 1, 1, 6, 3, 3>;
 using PNavC3F = pconv::Geo<128, 256, 3, 12, 1, 4, 6, 3, 3>;   // 4 x 144 columns
 using PNavC3D = pconv::Geo<256, 128, 3, 12, 1, 4, 6, 3, 3>;
+// the same forwards with ReLU + max-pool in the epilogue: tile PAIRS over the 288-pixel stream of upper rows (9 stream tiles) need an even
+// number of column tiles per wave: five waves x (2 pairs) = 10 stream tiles, 128 accumulators (six waves x 3 tiles cannot pair up)
+using PNavC2FP = pconv::Geo<64, 128, 3, 24, 1, 1, 5, 4, 3>;
+using PNavC3FP = pconv::Geo<128, 256, 3, 12, 1, 4, 5, 4, 3>;
 // AtariPreNet's conv3 as an operator (64 -> 64 3x3 @9, no padding; the fused Atari path has its own kernels in conv2.hip): 5 samples =
 // 245 of 256 columns; data gradient: dz 7x7 with PAD' = 2 -> 9x9 = 81 columns per sample, 3 samples = 243 of 256
 using PAtC3F = pconv::Geo<64, 64, 3, 9, 0, 5, 4, 2, 9>;
@@ -732,7 +736,8 @@ bool conv_planes_has_pool(const ConvGeom& g) {
 #if DDRL_PC_WIDE
   return false;
 #else
-  return planes_id(g) == kPN1dC2 || planes_id(g) == kPN1dC3;
+  const PlanesId id = planes_id(g);
+  return id == kPN1dC2 || id == kPN1dC3 || id == kPNavC2 || id == kPNavC3;
 #endif
 }
 
@@ -743,6 +748,8 @@ void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float
   switch (planes_id(g)) {
     case kPN1dC2: run_planes_pool<PN1dC2F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
     case kPN1dC3: run_planes_pool<PN1dC3F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
+    case kPNavC2: run_planes_pool<PNavC2FP>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
+    case kPNavC3: run_planes_pool<PNavC3FP>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
     default: break;
   }
 #endif
@@ -848,6 +855,8 @@ void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const f
   switch (planes_id(g)) {
     case kPN1dC2: run_planes_wgrad_pooled<PN1dC2W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
     case kPN1dC3: run_planes_wgrad_pooled<PN1dC3W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
+    case kPNavC2: run_planes_wgrad_pooled<PNavC2W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
+    case kPNavC3: run_planes_wgrad_pooled<PNavC3W>(g, in, dpool, ucode, part, scales, given_in, given_dp, S, st); break;
     default: return;
   }
   launch_reduce_slabs2(part, S, slab, (int64_t)g.cout * KT, dw, g.cout, db, st);
@@ -861,6 +870,8 @@ void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, cons
   switch (planes_id(g)) {
     case kPN1dC2: run_planes_unpool<PN1dC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
     case kPN1dC3: run_planes_unpool<PN1dC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
+    case kPNavC2: run_planes_unpool<PNavC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
+    case kPNavC3: run_planes_unpool<PNavC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
     default: break;
   }
 #endif

@@ -53,20 +53,20 @@ def lin_flop(l, *a, **k):
 
 
 
-def run(B=4096, CAP=1024, ITERS=3, T_loop=None):
+def run(B=4096, CAP=1024, ITERS=3, T_loop=None, encoder="nav1d"):
     """One measurement; returns the record as a dict (bench.py's `nav` sub-record calls this).  The per-operator timing wraps
     ops.Conv / ops.Linear for the duration of the call only."""
     saved = {(cls, k): getattr(cls, k) for cls in (ops.Conv, ops.Linear) for k in ("forward", "dgrad", "wgrad")}
     saved.update({(ops.Conv, k): getattr(ops.Conv, k) for k in ("forward_pool", "dgrad_pooled", "wgrad_pooled")})
     events.clear()
     try:
-        return _run(B, CAP, ITERS, T_loop)
+        return _run(B, CAP, ITERS, T_loop, encoder)
     finally:
         for (cls, k), fn in saved.items():
             setattr(cls, k, fn)
 
 
-def _run(B, CAP, ITERS, T_loop):
+def _run(B, CAP, ITERS, T_loop, encoder):
     ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
     ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
     ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
@@ -84,11 +84,17 @@ def _run(B, CAP, ITERS, T_loop):
     cfg.TASK_TYPE = "robot_nav"
     cfg_nn = ConfigNN(env)
     cfg_nn.TRAINING_ITER_TIME = ITERS
+    # encoder = "navped": ONE shared NavPedPreNet(4) (runner/utils.py:98-102, SHARE_CNN_NET; the encoder of the GAIL nav configuration)
+    cfg_nn.SHARE_CNN_NET = encoder == "navped"
     net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=CAP)
     g = torch.Generator(device="cuda")
     g.manual_seed(4)
-    states = [torch.rand((B, 1, 960), device="cuda", generator=g), torch.randn((B, 5), device="cuda", generator=g),
-              (torch.rand((B, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
+    if encoder == "navped":
+        states = [torch.rand((B, 1, 48, 48), device="cuda", generator=g), torch.randn((B, 9), device="cuda", generator=g),
+                  (torch.rand((B, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
+    else:
+        states = [torch.rand((B, 1, 960), device="cuda", generator=g), torch.randn((B, 5), device="cuda", generator=g),
+                  (torch.rand((B, 3, 48, 48), device="cuda", generator=g) < 0.15).float()]
     (dist, _), values = net([s[:CAP] for s in states])
     exp = Experience(states=states, advs=torch.randn(B, device="cuda", generator=g),
                      actions=torch.randn((B, 2), device="cuda", generator=g), old_logps=torch.full((B,), -2.0, device="cuda"),
@@ -145,7 +151,8 @@ def _run(B, CAP, ITERS, T_loop):
         loop = {"envs": N, "horizon": T, "ppo_iters": ITERS, "acting_plus_gae_ms": round(act_ms, 1), "update_ms": round(upd_ms, 1),
                 "env_steps_per_s": round(N * T / ((act_ms + upd_ms) * 1e-3), 1),
                 "acting_env_steps_per_s": round(N * (T + 1) / (act_ms * 1e-3), 1)}
-    return ({"workload": "robot_nav: NavPreNet1D x2 + GaussionActor(2), PPO iteration", "B": B, "micro_batch": CAP,
+    return ({"workload": ("robot_nav: shared NavPedPreNet(4) + GaussionActor(2), PPO iteration" if encoder == "navped" else
+                          "robot_nav: NavPreNet1D x2 + GaussionActor(2), PPO iteration"), "B": B, "micro_batch": CAP,
                       "whole_loop": loop,
                       "ms_per_ppo_iter_wall": round(wall * 1e3, 2), "gemm_ops_ms_per_iter": round(tot_ms, 2),
                       "algorithmic_tflops_over_gemm_ops": round(tot_flop / (tot_ms * 1e-3) / 1e12, 2),
@@ -154,4 +161,5 @@ def _run(B, CAP, ITERS, T_loop):
 
 if __name__ == "__main__":
     print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 1024,
-                         int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 else None)))
+                         int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None,
+                         sys.argv[5] if len(sys.argv) > 5 else "nav1d")))
