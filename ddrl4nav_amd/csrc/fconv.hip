@@ -39,7 +39,8 @@ template <int CIN_, int KS_, int HIN_, int PAD_>
 struct FGeo {
   static constexpr int CIN = CIN_, COUT = 64, KS = KS_, HIN = HIN_, PAD = PAD_, KK = KS * KS;
   static constexpr int OH = HIN + 2 * PAD - KS + 1, P = OH * OH, RAW = HIN * HIN, LPY = HIN + 2 * PAD;
-  static constexpr int NKG = 2 * KS;                         // k-groups: (ky, kx half)
+  static constexpr int KXH = (KS + 3) / 4;                   // halves of the 8 kx slots that carry weights (7 taps: 2, 3 taps: 1)
+  static constexpr int NKG = KXH * KS;                       // k-groups: (ky, kx half)
   static constexpr int W_BYTES = NKG * NPL * 64 * 32;        // [k-group][plane][oc 64][lane half 2][8 k] fp16
   // ---- forward
   static constexpr int FW_WAVES = 8, FW_TN = 4, FW_TILES = (P + 31) / 32, FW_PASSES = (FW_TILES + FW_WAVES * FW_TN - 1) / (FW_WAVES * FW_TN);
@@ -70,17 +71,17 @@ __global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restric
   amax_update(m, slot);
 }
 
-// dst[k-group = 2 ky + kx / 4][plane][oc 64][lane half][8 k]: k = 8 half + 4 t + c  <->  kx = 4 (k-group & 1) + 2 half + t; hdr[0] =
+// dst[k-group = KXH ky + kx / 4][plane][oc 64][lane half][8 k]: k = 8 half + 4 t + c  <->  kx = 4 (k-group % KXH) + 2 half + t; hdr[0] =
 // largest |w| (in), hdr[1] = scale (out)
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int cin, int ks, unsigned short* __restrict__ dst,
                                                    float* __restrict__ hdr) {
-  const int total = 2 * ks * 1024;
+  const int kxh = (ks + 3) / 4, total = kxh * ks * 1024;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const float scale = plane_scale(hdr[0]);
   if (i == 0) hdr[1] = scale;
   if (i >= total) return;
   const int e = i & 7, hf = (i >> 3) & 1, oc = (i >> 4) & 63, kg = i >> 10;
-  const int ky = kg >> 1, kx = 4 * (kg & 1) + 2 * hf + (e >> 2), c = e & 3;
+  const int ky = kg / kxh, kx = 4 * (kg % kxh) + 2 * hf + (e >> 2), c = e & 3;
   const float v = (kx < ks && c < cin) ? w[((oc * cin + c) * ks + ky) * ks + kx] : 0.0f;
   unsigned short pl[NPL];
   planes_of(v, scale, pl);
@@ -214,10 +215,10 @@ __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict_
       // fourteen k-groups spilled 72 - 288 registers); the row offsets are wave-uniform adds, the kx half stays an immediate
 #pragma unroll 1
       for (int ky = 0; ky < K::KS; ++ky) {
-        const char* wrow = lds + ky * (2 * NPL * 2048);
+        const char* wrow = lds + ky * (K::KXH * NPL * 2048);
         const char* irow = img + ky * (K::LPX_F * 8);
 #pragma unroll
-        for (int h4 = 0; h4 < 2; ++h4) {
+        for (int h4 = 0; h4 < K::KXH; ++h4) {
           frag8 af[NPL][2], bf[NPL][K::FW_TN];
 #pragma unroll
           for (int p = 0; p < NPL; ++p) {
@@ -423,8 +424,9 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < 2; ++i) aA[i] = ((i * 32 + l31) * K::DZP + 8 * hi) * 2;
   const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  const int ky0 = 2 * wave;  // this wave's kernel rows: ky0, ky0 + 1 (the last wave has one)
-  const bool two = ky0 + 1 < K::KS;
+  constexpr int KYW = (K::KS + 3) / 4;  // kernel rows per wave (7 taps: 2, the last wave has one; 3 taps: 1, the last wave idles)
+  const int ky0 = KYW * wave;
+  const bool two = KYW == 2 && ky0 + 1 < K::KS;
   const int bL = K::W_IMG_OFF + (ky0 * K::LPX_W + 8 * (g16 >> 1) + q + 4 * (g16 & 1) + pp) * 8;
   f32x16 acc[2][2];
 #pragma unroll
@@ -509,94 +511,109 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(const float* __rest
 }  // namespace fconv
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
-using FN1dC1 = fconv::FGeo<3, 7, 48, 1>;
+using FN1dC1 = fconv::FGeo<3, 7, 48, 1>;   // NavPreNet1D.conv1
+using FNavC1 = fconv::FGeo<1, 3, 48, 1>;   // NavPreNet.conv1 (image_batch = 1): 3 k-groups, 9 of their 48 k carry weights
+using FPedC1 = fconv::FGeo<4, 3, 48, 1>;   // NavPedPreNet.conv1 (image + 3 pedestrian maps): 36 of 48
 
-bool conv_has_first(const ConvGeom& g) {
+enum FirstId { kFNone = 0, kFN1d, kFNav, kFPed };
+
+static FirstId first_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
-  return false;
+  return kFNone;
 #else
   // A/B switches: DDRL_NAV_F32=1 puts every nav operator on its f32-input kernels, DDRL_FIRST_F32=1 this layer only
   static const bool off = [] {
     const char *a = getenv("DDRL_NAV_F32"), *b = getenv("DDRL_FIRST_F32");
     return (a && a[0] == '1') || (b && b[0] == '1');
   }();
-  if (off) return false;
-  return g.stride == 1 && g.h == 48 && g.w == 48 && g.kh == 7 && g.kw == 7 && g.pad_h == 1 && g.pad_w == 1 && g.cin == 3 && g.cout == 64;
+  if (off || g.stride != 1 || g.h != 48 || g.w != 48 || g.kh != g.kw || g.pad_h != 1 || g.pad_w != 1 || g.cout != 64) return kFNone;
+  if (g.kh == 7 && g.cin == 3) return kFN1d;
+  if (g.kh == 3 && g.cin == 1) return kFNav;
+  if (g.kh == 3 && g.cin == 4) return kFPed;
+  return kFNone;
 #endif
 }
 
-// floats of the packed region: the forward's weight planes + a 64-float header
-int64_t conv_first_pack_floats(const ConvGeom&) { return FN1dC1::W_BYTES / 4 + 64; }
+bool conv_has_first(const ConvGeom& g) { return first_id(g) != kFNone; }
 
-void launch_conv_first_pack(const ConvGeom& g, const float* w, float* region, hipStream_t st) {
-  float* hdr = region + FN1dC1::W_BYTES / 4;
-  (void)hipMemsetAsync(hdr, 0, 64 * sizeof(float), st);
-  hipLaunchKernelGGL(fconv::weight_amax_kernel, dim3(8), dim3(256), 0, st, w, (int64_t)g.cout * g.cin * g.kh * g.kw, hdr);
-  hipLaunchKernelGGL(fconv::pack_kernel, dim3((2 * g.kh * 1024 + 255) / 256), dim3(256), 0, st, w, g.cin, g.kh, (unsigned short*)region, hdr);
+// dispatch over the compile-time geometries
+#define DDRL_FIRST_DISPATCH(g, CALL)        \
+  switch (first_id(g)) {                    \
+    case kFN1d: { using K = FN1dC1; CALL; } break; \
+    case kFNav: { using K = FNavC1; CALL; } break; \
+    case kFPed: { using K = FPedC1; CALL; } break; \
+    default: break;                         \
+  }
+
+// floats of the packed region: the forward's weight planes + a 64-float header
+int64_t conv_first_pack_floats(const ConvGeom& g) {
+  int64_t f = 0;
+  DDRL_FIRST_DISPATCH(g, f = K::W_BYTES / 4 + 64);
+  return f;
 }
 
-void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, hipStream_t st) {
-  using K = FN1dC1;
+void launch_conv_first_pack(const ConvGeom& g, const float* w, float* region, hipStream_t st) {
+  float* hdr = region + conv_first_pack_floats(g) - 64;
+  (void)hipMemsetAsync(hdr, 0, 64 * sizeof(float), st);
+  hipLaunchKernelGGL(fconv::weight_amax_kernel, dim3(8), dim3(256), 0, st, w, (int64_t)g.cout * g.cin * g.kh * g.kw, hdr);
+  hipLaunchKernelGGL(fconv::pack_kernel, dim3((((g.kh + 3) / 4) * g.kh * 1024 + 255) / 256), dim3(256), 0, st, w, g.cin, g.kh, (unsigned short*)region, hdr);
+}
+
+template <class K, bool POOL>
+static void run_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, int64_t out_sn, uint8_t* code,
+                          hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
+    (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
     configured = true;
   }
   const int grid = g.n < 256 ? g.n : 256;  // one persistent workgroup per CU walks the samples
-  hipLaunchKernelGGL((fconv::first_fwd_kernel<K, false>), dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
-                     region + K::W_BYTES / 4, bias, act, out, g.out_sn, (uint8_t*)nullptr, g.n);
+  hipLaunchKernelGGL((fconv::first_fwd_kernel<K, POOL>), dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
+                     region + K::W_BYTES / 4, bias, act, out, out_sn, code, g.n);
+}
+
+void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, hipStream_t st) {
+  DDRL_FIRST_DISPATCH(g, (run_first_fwd<K, false>(g, in, region, bias, act, out, g.out_sn, nullptr, st)));
 }
 
 // conv + ReLU + max_pool2d(2): pooled [n][64][OH / 2][OH / 2] (dense), code = one decision byte per window
 void launch_conv_first_fwd_pool(const ConvGeom& g, const float* in, const float* region, const float* bias, float* pooled, uint8_t* code,
                                 hipStream_t st) {
-  using K = FN1dC1;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
-    configured = true;
-  }
-  const int grid = g.n < 256 ? g.n : 256;
-  hipLaunchKernelGGL((fconv::first_fwd_kernel<K, true>), dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
-                     region + K::W_BYTES / 4, bias, 1, pooled, (int64_t)64 * K::PW, code, g.n);
+  DDRL_FIRST_DISPATCH(g, (run_first_fwd<K, true>(g, in, region, bias, 1, pooled, (int64_t)64 * K::PW, code, st)));
 }
 
 int conv_first_wgrad_splits(const ConvGeom& g) {
-  if (!conv_has_first(g)) return 0;
-  const int nst = g.n * FN1dC1::NBANDS;
-  int s = 512;                      // two workgroups per CU
-  const int cap = (nst + 10) / 11;  // at least a sample's worth of bands per workgroup
+  int nbands = 0;
+  DDRL_FIRST_DISPATCH(g, nbands = K::NBANDS);
+  if (nbands == 0) return 0;
+  const int nst = g.n * nbands;
+  int s = 512;                                  // two workgroups per CU
+  const int cap = (nst + nbands - 1) / nbands;  // at least a sample's worth of bands per workgroup
   if (s > cap) s = cap;
   return s < 1 ? 1 : s;
 }
 
-void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st) {
-  using K = FN1dC1;
+template <class K, bool UNPOOL>
+static void run_first_wgrad(const ConvGeom& g, const float* in, const float* dz, int64_t dz_sn, const uint8_t* ucode, float* part, float* dw, float* db,
+                            hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)fconv::first_wgrad_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::W_LDS);
+    (void)hipFuncSetAttribute((const void*)fconv::first_wgrad_kernel<K, UNPOOL>, hipFuncAttributeMaxDynamicSharedMemorySize, K::W_LDS);
     configured = true;
   }
   const int S = conv_first_wgrad_splits(g);
-  hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, false>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dz, g.out_sn, (const uint8_t*)nullptr, part,
-                     g.n, S);
-  const int KT = g.cin * g.kh * g.kw;
-  launch_reduce_slabs2(part, S, K::SLAB, (int64_t)g.cout * KT, dw, g.cout, db, st);
+  hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, UNPOOL>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dz, dz_sn, ucode, part, g.n, S);
+  launch_reduce_slabs2(part, S, K::SLAB, (int64_t)64 * K::CIN * K::KK, dw, 64, db, st);
+}
+
+void launch_conv_first_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st) {
+  DDRL_FIRST_DISPATCH(g, (run_first_wgrad<K, false>(g, in, dz, g.out_sn, nullptr, part, dw, db, st)));
 }
 
 // the same from d(pooled) [n][64][OH / 2][OH / 2] + decision bytes
 void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
                                     hipStream_t st) {
-  using K = FN1dC1;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)fconv::first_wgrad_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::W_LDS);
-    configured = true;
-  }
-  const int S = conv_first_wgrad_splits(g);
-  hipLaunchKernelGGL((fconv::first_wgrad_kernel<K, true>), dim3(S), dim3(256), K::W_LDS, st, in, g.in_sn, dpool, (int64_t)64 * K::PW, ucode, part, g.n, S);
-  const int KT = g.cin * g.kh * g.kw;
-  launch_reduce_slabs2(part, S, K::SLAB, (int64_t)g.cout * KT, dw, g.cout, db, st);
+  DDRL_FIRST_DISPATCH(g, (run_first_wgrad<K, true>(g, in, dpool, (int64_t)64 * K::PW, ucode, part, dw, db, st)));
 }
 
 }  // namespace ddrl

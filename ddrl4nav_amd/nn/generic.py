@@ -147,12 +147,16 @@ class _ConvPool:
         except at each window's first maximum, which holds the pooled value -- the same pooled map, the same max-pool routing and
         the same ReLU mask under it as the activations the kernel had in its registers (what tests/parity_util.py substitutes into
         the float64 yardstick)."""
+        return self.relu_output(self.p.shape[0] if self.fused else self._a.shape[0])
+
+    def relu_output(self, n):
+        """`a` of the first n samples (the surrogate of a fused layer is built for those n only)."""
         if not self.fused:
-            return self._a
-        a = torch.zeros((self.p.shape[0], self.p.shape[1], self.oh, self.ow), dtype=torch.float32, device=self.p.device)
-        am = self.code & 3
+            return self._a[:n]
+        p, am = self.p[:n], self.code[:n] & 3
+        a = torch.zeros((n, p.shape[1], self.oh, self.ow), dtype=torch.float32, device=p.device)
         for k in range(4):
-            a[:, :, (k >> 1)::2, (k & 1)::2] = torch.where(am == k, self.p, torch.zeros_like(self.p))
+            a[:, :, (k >> 1)::2, (k & 1)::2] = torch.where(am == k, p, torch.zeros_like(p))
         return a
 
     def forward(self, x, n):

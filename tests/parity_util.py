@@ -321,7 +321,7 @@ def relu_outputs_of(e, n):
     d = {}
     for site in ("c1", "c2", "c3"):
         if hasattr(e, site):
-            d["conv" + site[1]] = getattr(e, site).a[:n].detach().cpu().clone()
+            d["conv" + site[1]] = getattr(e, site).relu_output(n).detach().cpu().clone()
     if hasattr(e, "cat"):       # the nav tails: fc0 writes its ReLU output into the cat buffer, fc1 into f1
         d["fc0"] = e.cat[:n, e.extra:e.extra + 512].detach().cpu().clone()
         d["fc1"] = e.f1[:n].detach().cpu().clone()

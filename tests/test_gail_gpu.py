@@ -138,9 +138,9 @@ def _d_decisions(net, name, g, states, w):
             if not atari and fused[k]:
                 # a layer that pools in its epilogue keeps ONE decision per window (which element is the first maximum, and whether
                 # it is positive): compare those with the oracle's relu + max-pool decisions on the same window
-                import torch.nn.functional as F
-                zw = F.unfold(torch.relu(z).reshape(-1, 1, *z.shape[2:]), 2, stride=2)      # [planes, 4, windows]
-                pw = F.unfold(pos.float().reshape(-1, 1, *z.shape[2:]), 2, stride=2)
+                H, W = z.shape[2:]
+                win = lambda t: t.reshape(-1, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3).reshape(-1, 4, (H // 2) * (W // 2))
+                zw, pw = win(torch.relu(z)), win(pos.float())                               # [planes, 4 (scan order), windows]
                 pos_o, pos_k = zw.amax(1) > 0, pw.amax(1) > 0
                 am_o, am_k = zw.argmax(1), pw.argmax(1)
                 differ = (pos_o != pos_k) | (pos_o & pos_k & (am_o != am_k))

@@ -24,6 +24,7 @@ CONVS = [
     (3, 64, 22, 22, 128, 5, 5, 1, (1, 1)),   # NavPreNet1D.conv2
     (7, 128, 10, 10, 256, 3, 3, 1, (1, 1)),  # NavPreNet1D.conv3
     (4, 1, 48, 48, 64, 3, 3, 1, (1, 1)),     # NavPreNet.conv1
+    (261, 4, 48, 48, 64, 3, 3, 1, (1, 1)),   # NavPedPreNet.conv1 (image + 3 pedestrian maps), more samples than persistent workgroups
     (2, 64, 24, 24, 128, 3, 3, 1, (1, 1)),   # NavPreNet.conv2
     (3, 128, 12, 12, 256, 3, 3, 1, (1, 1)),  # NavPreNet.conv3
     (7, 64, 9, 9, 64, 3, 3, 1, (0, 0)),      # AtariPreNet.conv3 as an operator (no padding)
@@ -83,7 +84,8 @@ def test_conv_forward_backward_vs_torch(shape):
 
 
 @pytest.mark.parametrize("shape", [(5, 3, 48, 64, 7, 1), (259, 3, 48, 64, 7, 1), (9, 64, 22, 128, 5, 1), (11, 128, 10, 256, 3, 1),
-                                   (4, 64, 24, 128, 3, 1), (6, 128, 12, 256, 3, 1), (3, 64, 9, 64, 3, 0)])
+                                   (4, 64, 24, 128, 3, 1), (6, 128, 12, 256, 3, 1), (3, 64, 9, 64, 3, 0), (5, 1, 48, 64, 3, 1),
+                                   (7, 4, 48, 64, 3, 1)])
 def test_conv_relu_pool_in_one_launch_vs_torch(shape):
     """ddrl_op_conv_forward_pool: max_pool2d(relu(conv(x)), 2) from the convolution's epilogue (csrc/fconv.hip, csrc/pconv.hip) --
     pooled values to fp32 rounding, and the decision bytes route d(pooled) exactly as torch's autograd does wherever the window's
@@ -115,7 +117,7 @@ def test_conv_relu_pool_in_one_launch_vs_torch(shape):
         conv.forward_pool(x.cuda(), b.cuda(), p2, c2, n=n, in_scales=sc)
         assert torch.equal(p2, pooled) and torch.equal(c2, code)
     else:
-        assert cin == 3
+        assert cin <= 4       # the few-channel first layers find their scales inside their kernels (csrc/fconv.hip)
     close(pooled, want.float())
     close(pooled[1], want[1].float())                      # the faint sample on its own scale
     assert int(code.max()) < 8
