@@ -607,21 +607,34 @@ def ingest_leg(net, ro, N, T, steps=2, host_memcpy=False):
 
 def nav_leg():
     """BASELINE config 4's network (robot_nav: NavPreNet1D x2 + GaussionActor(2) + Critic, reference nn/nav_encoder.py:82-128) through
-    the operator-composed path (nn/generic.py, csrc/pconv.hip / dconv.hip / glinear.hip): one PPO iteration on B = 4,096 samples in
-    ONE micro-batch (max_batch 4,096; in micro-batches of 1,024 the same iteration takes 40.7 instead of 34.9 ms:
-    profiles/r04_nav_ops*.json), per-operator HIP events.  A sub-record: it never touches the headline `value`."""
+    the operator-composed path (nn/generic.py; csrc/pconv.hip, fconv.hip, plin.hip, c1d.hip): one PPO iteration on B = 4,096 samples in
+    ONE micro-batch, per-operator HIP events (the two encoders run on two streams: the operator times overlap and sum to more than the
+    iteration).  `shared_navped_ppo_iter_ms`: the same for the shared NavPedPreNet(4) net of the GAIL nav configuration (config 5's
+    encoder).  A sub-record: it never touches the headline `value`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_nav
     r = bench_nav.run(4096, 4096, 3)
-    ops = r["ops"]
+    ped = bench_nav.run(4096, 4096, 3, None, "navped")
+    # per-operator times from a one-stream run (with the critic's encoder beside the actor's the operators' events overlap)
+    prev = os.environ.get("DDRL_ENC_STREAMS")
+    os.environ["DDRL_ENC_STREAMS"] = "0"
+    try:
+        r1 = bench_nav.run(4096, 4096, 3)
+    finally:
+        if prev is None:
+            os.environ.pop("DDRL_ENC_STREAMS", None)
+        else:
+            os.environ["DDRL_ENC_STREAMS"] = prev
+    ops = r1["ops"]
     dom = max(ops, key=lambda k: ops[k]["ms_per_iter"])
-    # the heavy layers (forward, data and weight gradient) run on the 16-bit matrix pipe as three fp16 plane products (ceiling
-    # 2.5 PF / 3); the 7x7 first layer, the Conv1d pair and the dense layers still on the f32-input MFMA (157.3 TFLOP/s)
-    planes = {k for k in ops if k.startswith("conv5x5_64->128") or k.startswith("conv3x3_128->256")}
+    # conv and dense layers run on the 16-bit matrix pipe as three fp16 plane products (ceiling 2.5 PF / 3); the Conv1d pair of the laser
+    # branch as fp32 vector kernels
+    planes = {k for k in ops if k.startswith("conv") and not k.startswith("conv1x")} | {k for k in ops if k.startswith("linear")}
     peak = (PEAK_BF16_MFMA_TFLOPS / 3) if dom in planes else PEAK_F32_MFMA_TFLOPS
     return {"workload": r["workload"], "B": r["B"], "micro_batch": r["micro_batch"], "ppo_iter_ms": r["ms_per_ppo_iter_wall"],
-            "samples_per_s": r["samples_per_s"], "gemm_ops_ms_per_iter": r["gemm_ops_ms_per_iter"],
-            "algorithmic_tflops_over_gemm_ops": r["algorithmic_tflops_over_gemm_ops"],
+            "samples_per_s": r["samples_per_s"], "ppo_iter_ms_one_stream": r1["ms_per_ppo_iter_wall"],
+            "shared_navped_ppo_iter_ms": ped["ms_per_ppo_iter_wall"], "gemm_ops_ms_per_iter": r1["gemm_ops_ms_per_iter"],
+            "algorithmic_tflops_over_gemm_ops": r1["algorithmic_tflops_over_gemm_ops"],
             "dominant_kernel": dom, "dominant_ms_per_iter": ops[dom]["ms_per_iter"], "dominant_tflops": ops[dom]["tflops"],
             "dominant_pipe": "f16x3" if dom in planes else "f32-input MFMA", "dominant_peak_tflops": round(peak, 1),
             "dominant_roofline_frac": round(ops[dom]["tflops"] / peak, 4),
@@ -983,7 +996,8 @@ def main():
         if world == 1 and not args.no_nav:
             try:
                 out["nav"] = nav_leg()
-                out["config"].update(nav_ppo_iter_ms=out["nav"]["ppo_iter_ms"], nav_samples_per_s=out["nav"]["samples_per_s"])
+                out["config"].update(nav_ppo_iter_ms=out["nav"]["ppo_iter_ms"], nav_samples_per_s=out["nav"]["samples_per_s"],
+                                     nav_shared_navped_ppo_iter_ms=out["nav"]["shared_navped_ppo_iter_ms"])
             except Exception as e:
                 out["nav"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:

@@ -36,6 +36,9 @@ def short(k):
     if m:
         flag = "" if m.group(3) != "true" else (".unpool" if "wgrad" in m.group(1) else ".pool")
         return "fconv_%s<%s>%s" % (m.group(1), "x".join(x.strip() for x in m.group(2).split(",")), flag)
+    m = re.search(r"ddrl::c1d::(\w+?)_kernel(?:<([\d, ]+)>)?", k)
+    if m:
+        return "c1d_" + m.group(1) + ("" if m.group(2) is None else "<%s>" % "x".join(x.strip() for x in m.group(2).split(",")))
     m = re.search(r"ddrl::plin::(\w+?)_kernel(?:<(\d)>)?", k)
     if m:
         return "plin_" + m.group(1) + ("" if m.group(2) is None else {"0": ".fwd", "1": ".dgrad"}[m.group(2)])
@@ -66,7 +69,7 @@ def main():
                 continue
             # acting-size launches of the forward kernels (small grids) are kept apart from the
             # training-size ones; every other kernel only runs in training (or is size-independent)
-            big = ("fwd" not in name.lower() and name != "heads_act") or name == "conv_fwd1_resident" or name.startswith(("fconv_", "plin_")) or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000  # (the resident conv1 kernel: one workgroup per CU, training launches only)
+            big = ("fwd" not in name.lower() and name != "heads_act") or name == "conv_fwd1_resident" or name.startswith(("fconv_", "plin_", "c1d_")) or int(row.get("Grid_Size", 0) or 0) >= 256 * 2000  # (the resident conv1 kernel: one workgroup per CU, training launches only)
             key = name + ("" if big else ":acting")
             c = agg[key][row["Counter_Name"]]
             c[0] += float(row["Counter_Value"])
