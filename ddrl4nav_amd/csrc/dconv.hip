@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void direct_pack_kernel(const float* __restric
   wp[i] = flip ? w[((int64_t)ch * cin + rr) * kk + (kk - 1 - tap)] : w[((int64_t)rr * cin + ch) * kk + tap];
 }
 
+// (Since round 4 this layer runs on fconv.hip's fp16-plane kernels; what follows is the f32-input form kept for DDRL_NAV_F32=1 / DDRL_FIRST_F32=1.)
 // Forward for layers with few input channels (NavPreNet1D.conv1: 3 -> 64, 7x7, 48 -> 44), where the
 // channel-pair MFMA k of `Direct` does not apply: the two k indices of an MFMA are the taps (kx, kx+1)
 // of one kernel row (KS is padded to an even width with a zero weight), one k-block per input channel.

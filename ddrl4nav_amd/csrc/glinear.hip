@@ -3,6 +3,9 @@
 // sizes and leading dimensions.  These serve the encoders outside the Atari fast path
 // (reference USTC_lab/nn/nav_encoder.py:21-24,103-106, USTC_lab/nn/mlp_encoder.py:18 and the
 // `mlp` helper USTC_lab/nn/utils.py:10-20); the 3136->512 Atari layer keeps its own kernels (fc2.hip).
+// Since round 4 layers of K >= 128, N >= 64 in launches of >= 128 rows run as fp16 plane products instead (plin.hip; the launchers at
+// the bottom dispatch): these kernels remain for small layers, small launches (acting with a few environments: split-K fills the chip
+// from one row tile) and as the A/B reference (DDRL_LIN_F32=1).
 //
 // Layout contract (checked by the C ABI): every leading dimension is a multiple of 4 floats and
 // every base pointer 16-byte aligned, so that all staging loads are aligned f4 loads;

@@ -102,8 +102,9 @@ def dense_layer(module, relu, cap, device):
 
 
 class _ConvPool:
-    """Conv2d + ReLU + max_pool2d(2) (nav_encoder.py:27-31): keeps the full-resolution ReLU output
-    for the pool / ReLU backward."""
+    """Conv2d + ReLU + max_pool2d(2) (nav_encoder.py:27-31).  Layers whose kernels pool in their epilogue (`fused`: the conv layers of the
+    three nav encoders) keep the pooled map and one decision byte per window and run their backward from d(pooled); every other layer keeps
+    the full-resolution ReLU output and d(pre-activation) around the stand-alone pool operators."""
 
     def __init__(self, module, h, w, cap, device, pool=True, relu=True):
         self.m, self.pool, self.relu = module, pool, relu
