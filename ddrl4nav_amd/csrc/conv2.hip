@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256) void conv_fwd1_planes_kernel(const uint8_t* __
 // run the same phases), the next tile's frame bytes are in flight while the present one feeds the matrix pipe.
 // ------------------------------------------------------------------------------------------------
 #ifndef DDRL_F1_RESIDENT
+#ifdef DDRL_PLANES_BF16
+#define DDRL_F1_RESIDENT 0  // three planes per operand: the resident weights (96 KB) and two image groups exceed the LDS
+#else
 #define DDRL_F1_RESIDENT 1
+#endif
 #endif
 template <int NE>
 struct Fwd1R {
@@ -224,7 +228,7 @@ struct Fwd1R {
   static constexpr int W_BYTES = 4 * A_BYTES, IMG_OFF = W_BYTES, GROUP_IMG = 4 * IMG_BYTES;   // per group: four stacked frames
   static constexpr int BIAS_OFF = IMG_OFF + 2 * GROUP_IMG;
   static constexpr size_t LDS_BYTES = BIAS_OFF + ROWS * 4;
-  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+  static_assert(!DDRL_F1_RESIDENT || LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
 template <int NE>

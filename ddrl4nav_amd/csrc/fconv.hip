@@ -27,6 +27,19 @@
 #include "engine2.h"
 #include "ops.h"
 
+#ifdef DDRL_PLANES_BF16
+// The three-plane build (bf16x6) keeps the f32-input kernels for this layer (LDS budgets).  Every query answers "no", nothing launches.
+namespace ddrl {
+bool conv_has_first(const ConvGeom&) { return false; }
+int64_t conv_first_pack_floats(const ConvGeom&) { return 0; }
+int conv_first_wgrad_splits(const ConvGeom&) { return 0; }
+void launch_conv_first_pack(const ConvGeom&, const float*, float*, hipStream_t) {}
+void launch_conv_first_fwd(const ConvGeom&, const float*, const float*, const float*, int, float*, hipStream_t) {}
+void launch_conv_first_fwd_pool(const ConvGeom&, const float*, const float*, const float*, float*, uint8_t*, hipStream_t) {}
+void launch_conv_first_wgrad(const ConvGeom&, const float*, const float*, float*, float*, float*, hipStream_t) {}
+void launch_conv_first_wgrad_pooled(const ConvGeom&, const float*, const float*, const uint8_t*, float*, float*, float*, hipStream_t) {}
+}  // namespace ddrl
+#else
 namespace ddrl {
 
 namespace fconv {
@@ -617,3 +630,4 @@ void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const fl
 }
 
 }  // namespace ddrl
+#endif  // DDRL_PLANES_BF16

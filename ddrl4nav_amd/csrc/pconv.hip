@@ -27,6 +27,25 @@
 #include "engine2.h"
 #include "ops.h"
 
+#ifdef DDRL_PLANES_BF16
+// The three-plane build (bf16x6) keeps the f32-input kernels of dconv.hip for these layers: three planes per operand do not fit the LDS
+// budgets of the tiles below.  Every query answers "no", nothing launches.
+namespace ddrl {
+bool conv_has_planes(const ConvGeom&) { return false; }
+bool conv_planes_has_pool(const ConvGeom&) { return false; }
+int64_t conv_planes_pack_floats(const ConvGeom&) { return 0; }
+int conv_planes_wgrad_splits(const ConvGeom&) { return 0; }
+void launch_plane_scales(const float*, int64_t, int, int, float*, hipStream_t) {}
+void launch_conv_planes_pack(const ConvGeom&, const float*, float*, float*, hipStream_t) {}
+void launch_conv_planes_fwd(const ConvGeom&, const float*, const float*, float*, const float*, int, float*, hipStream_t) {}
+void launch_conv_planes_dgrad(const ConvGeom&, const float*, const float*, float*, float*, hipStream_t) {}
+void launch_conv_planes_wgrad(const ConvGeom&, const float*, const float*, float*, float*, float*, hipStream_t) {}
+void launch_conv_planes_fwd_pool(const ConvGeom&, const float*, const float*, float*, const float*, const float*, float*, uint8_t*, hipStream_t) {}
+void launch_conv_planes_dgrad_pooled(const ConvGeom&, const float*, const uint8_t*, const float*, float*, const float*, float*, hipStream_t) {}
+void launch_conv_planes_wgrad_pooled(const ConvGeom&, const float*, const float*, const uint8_t*, const float*, const float*, float*, float*, float*,
+                                     hipStream_t) {}
+}  // namespace ddrl
+#else
 namespace ddrl {
 
 namespace pconv {
@@ -895,3 +914,4 @@ void launch_conv_planes_wgrad(const ConvGeom& g, const float* in, const float* d
 }
 
 }  // namespace ddrl
+#endif  // DDRL_PLANES_BF16
