@@ -81,10 +81,15 @@ __global__ __launch_bounds__(256) void dgrad32_kernel(const float* __restrict__ 
   }
   float* dst = din + (int64_t)b * din_sn + 2 * m;
   const bool has_odd = 2 * m + 1 < W;
+  if (has_odd && !((W | din_sn) & 1) && !((uintptr_t)din & 7)) {  // (even, odd) as one 8-byte store: full lines per wave instead of every other dword
 #pragma unroll
-  for (int c = 0; c < CIN; ++c) {
-    dst[(int64_t)c * W] = ev[c];
-    if (has_odd) dst[(int64_t)c * W + 1] = od[c];
+    for (int c = 0; c < CIN; ++c) *(float2*)(dst + (int64_t)c * W) = make_float2(ev[c], od[c]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      dst[(int64_t)c * W] = ev[c];
+      if (has_odd) dst[(int64_t)c * W + 1] = od[c];
+    }
   }
 }
 
