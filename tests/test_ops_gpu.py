@@ -308,6 +308,54 @@ def test_conv_full_batch_size_vs_torch_gpu(shape):
     close(db, b.grad, tol=2e-4)
 
 
+@pytest.mark.parametrize("shape", [(512, 3, 48, 64, 7), (512, 64, 22, 128, 5), (512, 128, 10, 256, 3), (512, 4, 48, 64, 3), (512, 64, 24, 128, 3)])
+def test_pooled_conv_block_full_batch_size_vs_torch_gpu(shape):
+    """The same at n = 512 for the blocks that pool in their epilogue: conv + ReLU + max-pool in one launch and the backward from
+    d(pooled), against torch's GPU autograd through F.max_pool2d(F.relu(conv)) (fp32, MIOpen).  Pooled values agree to fp32
+    rounding; the per-window routing agrees except where the window's two largest activations lie within fp32 noise of each other
+    (either implementation may take either: a few windows in 10^7, each of which moves a weight-gradient element by ~1e-3 of its
+    size -- so the gradients are compared under torch's OWN routing, which separates the arithmetic from those coin flips)."""
+    from ddrl4nav_amd.ops import Conv, plane_scales, maxpool2_backward_idx
+    n, cin, h, cout, ks = shape
+    g = torch.Generator(device="cuda").manual_seed(n + cin + h)
+    x = torch.randn(n, cin, h, h, device="cuda", generator=g).requires_grad_(True)
+    wt = (torch.randn(cout, cin, ks, ks, device="cuda", generator=g) / (cin * ks * ks) ** 0.5).requires_grad_(True)
+    b = (0.1 * torch.randn(cout, device="cuda", generator=g)).requires_grad_(True)
+    z = F.conv2d(x, wt, b, padding=1)
+    z.retain_grad()
+    pooled_ref = F.max_pool2d(F.relu(z), 2, stride=2)
+    dpool = torch.randn(pooled_ref.shape, device="cuda", generator=g)
+    pooled_ref.backward(dpool)
+    conv = Conv(cin, h, h, cout, ks, ks, pad=(1, 1), max_n=n)
+    conv.pack(wt.detach())
+    assert conv.has_forward_pool()
+    pooled, code = torch.empty_like(pooled_ref), torch.empty(pooled_ref.shape, dtype=torch.uint8, device="cuda")
+    sc = plane_scales(x.detach(), n, torch.empty(n, device="cuda")) if conv.pooled_uses_scales() else None
+    conv.forward_pool(x.detach(), b.detach(), pooled, code, n=n, in_scales=sc)
+    close(pooled, pooled_ref, tol=5e-5)
+    oh = conv.oh
+    dz_k = maxpool2_backward_idx(dpool, code, oh, oh)
+    differ = (dz_k != z.grad).reshape(n, cout, oh // 2, 2, oh // 2, 2).any(5).any(3)          # windows routed differently
+    assert float(differ.float().mean()) < 2e-5, float(differ.float().mean())
+    if differ.any():   # ... only where the decision was a coin flip: the two candidates (or the maximum and zero) within fp32 noise
+        a = F.relu(z.detach()).reshape(n, cout, oh // 2, 2, oh // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, cout, oh // 2, oh // 2, 4)
+        top2 = a[differ].topk(2, dim=1).values
+        assert float(((top2[:, 0] - top2[:, 1]).abs().minimum(top2[:, 0])).max()) < 2e-5
+    # gradients under torch's routing: overwrite the decision bytes of the few coin-flip windows with torch's choice
+    zg = z.grad.reshape(n, cout, oh // 2, 2, oh // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, cout, oh // 2, oh // 2, 4)
+    t_am = (zg != 0).float().argmax(4).to(torch.uint8)
+    t_pos = (zg != 0).any(4) | (dpool == 0)
+    code_t = torch.where(differ, t_am | (t_pos.to(torch.uint8) * 4), code)
+    rel = lambda got, want: float((got.double() - want.double()).norm() / want.double().norm())
+    dw, db = torch.empty_like(wt.detach()), torch.empty_like(b.detach())
+    conv.wgrad_pooled(x.detach(), dpool, code_t, dw, db, n=n, in_scales=sc)
+    assert rel(db, b.grad) < 2e-5, rel(db, b.grad)
+    assert rel(dw, wt.grad) < 2e-5, rel(dw, wt.grad)
+    if cin > 4:
+        din = conv.dgrad_pooled(dpool, code_t, n=n)
+        assert rel(din, x.grad) < 2e-5, rel(din, x.grad)
+
+
 @pytest.mark.parametrize("order", ["critic_below_actor", "critic_above_actor"])
 def test_heads_take_the_two_feature_buffers_at_any_relative_address(order):
     """ddrl_op_heads_act / ddrl_op_heads_loss receive the actor's and the critic's feature (and gradient) buffers as two
