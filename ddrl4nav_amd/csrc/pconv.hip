@@ -645,8 +645,11 @@ using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, 8, 4, 7, 3>;   // 8 x 100 columns
 using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, 8, 4, 7, 3>;
 #else
 using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 1, 4, 4, 5>;    // 400 of 512 columns
-using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, 4, 4, 4, 3>;   // 4 x 100 of 512 columns
-using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, 4, 4, 4, 3>;
+#ifndef DDRL_PC3_NS
+#define DDRL_PC3_NS 5  // samples per workgroup of the 3x3 @10 layer: 5 x 100 = 500 of 512 columns (4: 400 of 512)
+#endif
+using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, DDRL_PC3_NS, 4, 4, 3>;
+using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, DDRL_PC3_NS, 4, 4, 3>;
 #endif
 using PN1dC2D = pconv::Geo<128, 64, 5, 20, 3, 1, 4, 4, 5>;    // 484 of 512 columns
 using PNavC2F = pconv::Geo<64, 128, 3, 24, 1, 1, 6, 3, 3>;    // 576 columns = 18 column tiles
