@@ -636,6 +636,8 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
 // four waves x 4 tiles (400 of 512 columns, 128 accumulators, 57-62 KB -> TWO workgroups per CU): the second is faster although it
 // issues 14 % more matrix instructions (5x5 forward 4.29 -> 4.12 ms, 3x3 data gradient 1.81 -> 1.59 ms per 4,096 samples): at one
 // workgroup per CU nothing covers the barriers and commits of a k-block.  -DDDRL_PC_WIDE=1 selects the wide tiles.
+// Later in the round, still at two workgroups per CU: the 3x3 @10 layer with FIVE samples per workgroup (500 of 512 columns, 59 KB; nav
+// iteration 23.39 -> 23.05 ms) and the 5x5 forward on seven waves x one tile pair (400 of 448 columns; 4.04 -> 3.70 ms).
 #ifndef DDRL_PC_WIDE
 #define DDRL_PC_WIDE 0
 #endif
@@ -644,7 +646,14 @@ using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 2, 4, 7, 5>;    // 2 x 400 columns
 using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, 8, 4, 7, 3>;   // 8 x 100 columns
 using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, 8, 4, 7, 3>;
 #else
+#ifndef DDRL_PC2_W7
+#define DDRL_PC2_W7 1  // same-box A/B: 5x5 forward 4.04 -> 3.70 ms per 4,096 samples (12.5 % fewer matrix instructions, a third more fragment reads each)
+#endif
+#if DDRL_PC2_W7
+using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 1, 7, 2, 5>;    // 400 of 448 columns, seven waves x one tile pair
+#else
 using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 1, 4, 4, 5>;    // 400 of 512 columns
+#endif
 #ifndef DDRL_PC3_NS
 #define DDRL_PC3_NS 5  // samples per workgroup of the 3x3 @10 layer: 5 x 100 = 500 of 512 columns (4: 400 of 512)
 #endif
