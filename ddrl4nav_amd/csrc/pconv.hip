@@ -131,8 +131,11 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
 // UNPOOL (data gradient of such a layer): `in` is d(pooled) [CIN][HIN / 2][HIN / 2] and `ucode` the layer's decision bytes; the
 // staging forms d(pre-activation) on the fly -- the pooled gradient at the window's first maximum under the ReLU's sign, zero
 // elsewhere (gconv.hip maxpool2_bwd_idx_kernel) -- so the full-resolution gradient is never written or read either.
+#ifndef DDRL_PC_OCC2
+#define DDRL_PC_OCC2 1  // four-wave geometries: ask for two waves per SIMD (<= 256 registers), i.e. two RESIDENT workgroups per CU
+#endif
 template <class K, bool POOL = false, bool UNPOOL = false>
-__global__ __launch_bounds__(K::THREADS) void direct_planes_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
+__global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2 : 1) void direct_planes_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
                                                                    const float* __restrict__ whdr, const float* __restrict__ scales,
                                                                    const float* __restrict__ bias, int act, float* __restrict__ out,
                                                                    int64_t out_sn, uint8_t* __restrict__ code,
@@ -636,8 +639,11 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
 // four waves x 4 tiles (400 of 512 columns, 128 accumulators, 57-62 KB -> TWO workgroups per CU): the second is faster although it
 // issues 14 % more matrix instructions (5x5 forward 4.29 -> 4.12 ms, 3x3 data gradient 1.81 -> 1.59 ms per 4,096 samples): at one
 // workgroup per CU nothing covers the barriers and commits of a k-block.  -DDDRL_PC_WIDE=1 selects the wide tiles.
-// Later in the round, still at two workgroups per CU: the 3x3 @10 layer with FIVE samples per workgroup (500 of 512 columns, 59 KB; nav
-// iteration 23.39 -> 23.05 ms) and the 5x5 forward on seven waves x one tile pair (400 of 448 columns; 4.04 -> 3.70 ms).
+// Later in the round: the 3x3 @10 layer with FIVE samples per workgroup (500 of 512 columns, 59 KB; nav iteration 23.39 -> 23.05 ms).
+// Then the register count: the four-wave kernels compiled to 320-370 registers, so that in spite of their LDS footprint only ONE
+// workgroup per CU was ever resident.  With the allocator asked for two waves per SIMD (launch bounds; 234-256 registers, no spills but
+// 38 in the 5x5 data gradient) two really are: nav iteration 22.71 -> 21.89 ms.  Under it the 5x5 forward on four waves x two tile pairs
+// (3.41 ms) beats the seven-wave form that had won before (3.54; 4.04 -> 3.70 against the one-resident-workgroup four-wave form).
 #ifndef DDRL_PC_WIDE
 #define DDRL_PC_WIDE 0
 #endif
@@ -647,7 +653,7 @@ using PN1dC3F = pconv::Geo<128, 256, 3, 10, 1, 8, 4, 7, 3>;   // 8 x 100 columns
 using PN1dC3D = pconv::Geo<256, 128, 3, 10, 1, 8, 4, 7, 3>;
 #else
 #ifndef DDRL_PC2_W7
-#define DDRL_PC2_W7 1  // same-box A/B: 5x5 forward 4.04 -> 3.70 ms per 4,096 samples (12.5 % fewer matrix instructions, a third more fragment reads each)
+#define DDRL_PC2_W7 0  // 1: seven waves x one tile pair (400 of 448 columns); see the A/B notes below
 #endif
 #if DDRL_PC2_W7
 using PN1dC2F = pconv::Geo<64, 128, 5, 22, 1, 1, 7, 2, 5>;    // 400 of 448 columns, seven waves x one tile pair
