@@ -120,13 +120,15 @@ SIGNATURES = {
     "ddrl_op_maxpool2_backward_idx": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_linear_pack_floats": (c_int32, [c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
     "ddrl_op_linear_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_linear_uses_planes": (c_int32, [c_int32, c_int32, c_int32]),
+    "ddrl_op_row_scales": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_linear_forward": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
-                                         c_int32, c_int32, c_void_p, c_void_p]),
+                                         c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_linear_dgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
-                                       c_int32, c_void_p, c_void_p]),
+                                       c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_linear_ws_floats": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_int64)]),
     "ddrl_op_linear_wgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
-                                       c_int32, c_void_p]),
+                                       c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_heads_ws_floats": (c_int32, [POINTER(HeadsDesc), c_int32, POINTER(c_int64)]),
     "ddrl_op_heads_act": (c_int32, [POINTER(HeadsDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_uint64, c_uint64,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

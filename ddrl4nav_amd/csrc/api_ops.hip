@@ -267,19 +267,28 @@ int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, flo
   return op_check();
 }
 
+int32_t ddrl_op_linear_uses_planes(int32_t n, int32_t K, int32_t N) { return lin_ok(n, K, N) && linear_uses_planes(n, K, N) ? 1 : 0; }
+
+int32_t ddrl_op_row_scales(const float* x, int64_t ld, int32_t width, int32_t n, float* scales, void* stream) {
+  if (!x || !scales || n < 1 || width < 1 || (ld & 3) || ld < (width + 3) / 4 * 4 || !aligned16(x)) return DDRL_ERR_INVALID_ARG;
+  launch_row_scales(x, ld, width, n, scales, (hipStream_t)stream);
+  return op_check();
+}
+
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act, float* out,
-                               int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, void* stream) {
+                               int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, const float* in_scales, void* stream) {
   if (!lin_ok(n, K, N) || !in || !wt || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   if ((ld_in & 3) || ld_in < (K + 3) / 4 * 4 || ld_out < N || !aligned16(in) || !aligned16(wt)) return DDRL_ERR_INVALID_ARG;
-  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, ws, (hipStream_t)stream);
+  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, ws, in_scales, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, void* stream) {
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, const float* dout_scales,
+                             void* stream) {
   if (!lin_ok(n, K, N) || !dout || !wn || !din) return DDRL_ERR_INVALID_ARG;
   if ((ld_dout & 3) || ld_dout < N || ld_din < K || !aligned16(dout) || !aligned16(wn)) return DDRL_ERR_INVALID_ARG;
-  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, ws, (hipStream_t)stream);
+  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, ws, dout_scales, (hipStream_t)stream);
   return op_check();
 }
 
@@ -305,11 +314,11 @@ int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* float
 }
 
 int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
-                             float* db, int32_t n, int32_t K, int32_t N, void* stream) {
+                             float* db, int32_t n, int32_t K, int32_t N, const float* in_scales, const float* dout_scales, void* stream) {
   if (!lin_ok(n, K, N) || !in || !dout || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if ((ld_in & 3) || (ld_dout & 3) || ld_in < (K + 3) / 4 * 4 || ld_dout < N || !aligned16(in) || !aligned16(dout))
     return DDRL_ERR_INVALID_ARG;
-  launch_linear_wgrad(in, ld_in, dout, ld_dout, ws, n, K, N, dw, db, (hipStream_t)stream);
+  launch_linear_wgrad(in, ld_in, dout, ld_dout, ws, n, K, N, dw, db, in_scales, dout_scales, (hipStream_t)stream);
   return op_check();
 }
 

@@ -419,9 +419,9 @@ void launch_linear_finish(const float* part, int nsplit, int n, int N, const flo
 }
 
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
-                       int K, int N, int act, float* part, hipStream_t st) {
+                       int K, int N, int act, float* part, const float* in_scales, hipStream_t st) {
   if (part && linear_uses_planes(n, K, N)) {
-    launch_linear_planes_fwd(in, ld_in, wt + wt_f32_floats(K, N), bias, out, ld_out, n, K, N, act, part, st);
+    launch_linear_planes_fwd(in, ld_in, wt + wt_f32_floats(K, N), bias, out, ld_out, n, K, N, act, part, in_scales, st);
     return;
   }
   const int S = part ? linear_fwd_splits(n, K, N) : 1;
@@ -433,9 +433,9 @@ void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const fl
 }
 
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                         float* din, int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st) {
+                         float* din, int64_t ld_din, int n, int K, int N, float* ws, const float* dout_scales, hipStream_t st) {
   if (ws && linear_uses_planes(n, K, N)) {
-    launch_linear_planes_dgrad(dout, ld_dout, wn + wn_f32_floats(K, N), mask_src, ld_mask, din, ld_din, n, K, N, ws, st);
+    launch_linear_planes_dgrad(dout, ld_dout, wn + wn_f32_floats(K, N), mask_src, ld_mask, din, ld_din, n, K, N, ws, dout_scales, st);
     return;
   }
   glin::Dgrad::Params p{dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, (K + 3) / 4 * 4};
@@ -452,9 +452,9 @@ int linear_wgrad_splits(int n, int K, int N) {
 }
 
 void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
-                         float* dw, float* db, hipStream_t st) {
+                         float* dw, float* db, const float* in_scales, const float* dout_scales, hipStream_t st) {
   if (linear_uses_planes(n, K, N)) {
-    launch_linear_planes_wgrad(in, ld_in, dout, ld_dout, part, n, K, N, dw, db, st);
+    launch_linear_planes_wgrad(in, ld_in, dout, ld_dout, part, n, K, N, dw, db, in_scales, dout_scales, st);
     return;
   }
   const int S = linear_wgrad_splits(n, K, N);

@@ -90,12 +90,12 @@ void launch_accumulate(float* dst, const float* src, int64_t count, hipStream_t 
 void launch_linear_pack(const float* w, int K, int N, float* wt, float* wn, hipStream_t st);
 int linear_fwd_splits(int n, int K, int N);
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
-                       int K, int N, int act, float* part, hipStream_t st);
+                       int K, int N, int act, float* part, const float* in_scales, hipStream_t st);
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                         float* din, int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st);
+                         float* din, int64_t ld_din, int n, int K, int N, float* ws, const float* dout_scales, hipStream_t st);
 int linear_wgrad_splits(int n, int K, int N);
 void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
-                         float* dw, float* db, hipStream_t st);
+                         float* dw, float* db, const float* in_scales, const float* dout_scales, hipStream_t st);
 
 void launch_linear_finish(const float* part, int nsplit, int n, int N, const float* bias, int act, float* out, int64_t ld_out, hipStream_t st);
 
@@ -108,15 +108,17 @@ int64_t linear_planes_dgrad_floats(int K, int N);
 void launch_linear_planes_pack(const float* w, int K, int N, float* pf, float* pd, hipStream_t st);
 int linear_planes_fwd_splits(int n, int K, int N);
 // ws: n floats rounded up to 64 (row scales), then linear_planes_fwd_splits * n * N partials
+void launch_row_scales(const float* x, int64_t ld, int width, int n, float* scales, hipStream_t st);
+// given*: per-row scales the caller already holds for that tensor (launch_row_scales), or nullptr for a pre-pass into the scratch
 void launch_linear_planes_fwd(const float* in, int64_t ld_in, const float* pf, const float* bias, float* out, int64_t ld_out, int n, int K,
-                              int N, int act, float* ws, hipStream_t st);
+                              int N, int act, float* ws, const float* given, hipStream_t st);
 // ws: n floats
 void launch_linear_planes_dgrad(const float* dout, int64_t ld_dout, const float* pd, const float* mask_src, int64_t ld_mask, float* din,
-                                int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st);
+                                int64_t ld_din, int n, int K, int N, float* ws, const float* given, hipStream_t st);
 int linear_planes_wgrad_splits(int n, int K, int N);
 // part: linear_planes_wgrad_splits slabs of N * K + N floats, then 2 n floats
 void launch_linear_planes_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
-                                float* dw, float* db, hipStream_t st);
+                                float* dw, float* db, const float* given_in, const float* given_dout, hipStream_t st);
 
 // gheads.hip: Gaussian actor + critic heads; offsets into the caller's flat parameter arena
 struct GaussLayout {

@@ -448,24 +448,27 @@ int linear_planes_fwd_splits(int n, int K, int N) {
 }
 
 // ws: n floats (row scales, rounded up to 64), then the split-K partials
+void launch_row_scales(const float* x, int64_t ld, int width, int n, float* scales, hipStream_t st) { row_scales(x, ld, width, n, scales, st); }
+
+// given*: per-row scales the caller already holds (launch_row_scales on the same tensor), or nullptr for a pre-pass into the scratch
 void launch_linear_planes_fwd(const float* in, int64_t ld_in, const float* pf, const float* bias, float* out, int64_t ld_out, int n, int K,
-                              int N, int act, float* ws, hipStream_t st) {
+                              int N, int act, float* ws, const float* given, hipStream_t st) {
   const int kgs = kgs_of(K);
   const int64_t planes = (int64_t)((N + 127) / 128) * kgs * (NPL * 2048) / 2;
   const int S = linear_planes_fwd_splits(n, K, N);
   float* part = ws + (n + 63) / 64 * 64;
-  row_scales(in, ld_in, K, n, ws, st);
-  plin::NtParams p{in, ld_in, ws, (const unsigned short*)pf, pf + planes, n, N, kgs, bias, act, S, part, nullptr, 0, out, ld_out};
+  if (!given) row_scales(in, ld_in, K, n, ws, st);
+  plin::NtParams p{in, ld_in, given ? given : ws, (const unsigned short*)pf, pf + planes, n, N, kgs, bias, act, S, part, nullptr, 0, out, ld_out};
   run_nt<0>(p, dim3((N + 127) / 128, (n + 127) / 128, S), st);
   if (S > 1) launch_linear_finish(part, S, n, N, bias, act, out, ld_out, st);
 }
 
 void launch_linear_planes_dgrad(const float* dout, int64_t ld_dout, const float* pd, const float* mask_src, int64_t ld_mask, float* din,
-                                int64_t ld_din, int n, int K, int N, float* ws, hipStream_t st) {
+                                int64_t ld_din, int n, int K, int N, float* ws, const float* given, hipStream_t st) {
   const int kgs = kgs_of(N);
   const int64_t planes = (int64_t)((K + 127) / 128) * kgs * (NPL * 2048) / 2;
-  row_scales(dout, ld_dout, N, n, ws, st);
-  plin::NtParams p{dout, ld_dout, ws, (const unsigned short*)pd, pd + planes, n, K, kgs, nullptr, 0, 1, nullptr, mask_src, ld_mask, din, ld_din};
+  if (!given) row_scales(dout, ld_dout, N, n, ws, st);
+  plin::NtParams p{dout, ld_dout, given ? given : ws, (const unsigned short*)pd, pd + planes, n, K, kgs, nullptr, 0, 1, nullptr, mask_src, ld_mask, din, ld_din};
   run_nt<1>(p, dim3((K + 127) / 128, (n + 127) / 128, 1), st);
 }
 
@@ -479,7 +482,7 @@ int linear_planes_wgrad_splits(int n, int K, int N) {
 
 // part: S slabs of N * K + N floats, then 2 n floats for the row scales
 void launch_linear_planes_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
-                                float* dw, float* db, hipStream_t st) {
+                                float* dw, float* db, const float* given_in, const float* given_dout, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)plin::tn_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, plin::LDS_TN);
@@ -489,9 +492,9 @@ void launch_linear_planes_wgrad(const float* in, int64_t ld_in, const float* dou
   const int64_t slab = (int64_t)N * K + N;
   float* sc_i = part + (int64_t)S * slab;
   float* sc_d = sc_i + n;
-  row_scales(in, ld_in, K, n, sc_i, st);
-  row_scales(dout, ld_dout, N, n, sc_d, st);
-  plin::TnParams p{dout, ld_dout, in, ld_in, sc_d, sc_i, part, n, K, N, S};
+  if (!given_in) row_scales(in, ld_in, K, n, sc_i, st);
+  if (!given_dout) row_scales(dout, ld_dout, N, n, sc_d, st);
+  plin::TnParams p{dout, ld_dout, in, ld_in, given_dout ? given_dout : sc_d, given_in ? given_in : sc_i, part, n, K, N, S};
   hipLaunchKernelGGL(plin::tn_planes_kernel, dim3((K + 127) / 128, (N + 127) / 128, S), dim3(256), plin::LDS_TN, st, p);
   launch_reduce_slabs2(part, S, slab, (int64_t)N * K, dw, N, db, st);
 }

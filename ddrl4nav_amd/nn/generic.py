@@ -51,18 +51,39 @@ class _Dense:
         self.m, self.relu = module, relu
         self.K, self.N = module.in_features, module.out_features
         self.op = Linear(self.K, self.N, max_n=cap, device=device)
+        self._scale_buffers(cap, device)
+
+    def _scale_buffers(self, cap, device):
+        # per-row plane scales of the layer's input and of d(output), computed once per pass and shared by the operators that read the
+        # same tensor (forward + weight gradient; data + weight gradient); DDRL_SCALES_PER_OP=1: every operator runs its own pre-pass
+        share = self.op.uses_planes(cap) and os.environ.get("DDRL_SCALES_PER_OP") != "1"
+        self.in_sc = torch.empty((cap,), dtype=torch.float32, device=device) if share else None
+        self.dout_sc = torch.empty((cap,), dtype=torch.float32, device=device) if share else None
+
+    def _in_scales(self, x, ld_in, n):
+        if self.in_sc is None or not self.op.uses_planes(n):
+            return None
+        return self.op.row_scales(x, ld_in, self.K, n, self.in_sc)
+
+    def _dout_scales(self, dout, ld_dout, n):
+        if self.dout_sc is None or not self.op.uses_planes(n):
+            return None
+        return self.op.row_scales(dout, ld_dout, self.N, n, self.dout_sc)
 
     def pack(self):
         self.op.pack(self.m.weight.data)
 
     def forward(self, x, ld_in, out, ld_out, n):
-        return self.op.forward(x, ld_in, self.m.bias.data, self.relu, out, ld_out, n)
+        self._fwd_sc = self._in_scales(x, ld_in, n)     # kept for the weight gradient of the same pass
+        return self.op.forward(x, ld_in, self.m.bias.data, self.relu, out, ld_out, n, in_scales=self._fwd_sc)
 
     def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0):
         """dout = gradient w.r.t. this layer's PRE-activation output (the consumer applied the ReLU mask)."""
-        self.op.wgrad(x, ld_in, dout, ld_dout, self.m.weight.grad_view, self.m.bias.grad_view, n)
+        ds = self._dout_scales(dout, ld_dout, n)
+        self.op.wgrad(x, ld_in, dout, ld_dout, self.m.weight.grad_view, self.m.bias.grad_view, n, in_scales=getattr(self, "_fwd_sc", None),
+                      dout_scales=ds)
         if din is not None:
-            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n)
+            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_scales=ds)
 
 
 class _PaddedDense(_Dense):
@@ -76,6 +97,7 @@ class _PaddedDense(_Dense):
         self.K, self.N_real = module.in_features, module.out_features
         self.N = _pad4(self.N_real)
         self.op = Linear(self.K, self.N, max_n=cap, device=device)
+        self._scale_buffers(cap, device)
         f = dict(dtype=torch.float32, device=device)
         self.wpad, self.bpad = torch.zeros((self.N, self.K), **f), torch.zeros(self.N, **f)
         self.dwpad, self.dbpad = torch.zeros((self.N, self.K), **f), torch.zeros(self.N, **f)
@@ -86,15 +108,17 @@ class _PaddedDense(_Dense):
         self.op.pack(self.wpad)
 
     def forward(self, x, ld_in, out, ld_out, n):
-        return self.op.forward(x, ld_in, self.bpad, self.relu, out, ld_out, n)
+        self._fwd_sc = self._in_scales(x, ld_in, n)
+        return self.op.forward(x, ld_in, self.bpad, self.relu, out, ld_out, n, in_scales=self._fwd_sc)
 
     def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0):
-        self.op.wgrad(x, ld_in, dout, ld_dout, self.dwpad, self.dbpad, n)
+        ds = self._dout_scales(dout, ld_dout, n)
+        self.op.wgrad(x, ld_in, dout, ld_dout, self.dwpad, self.dbpad, n, in_scales=getattr(self, "_fwd_sc", None), dout_scales=ds)
         self.m.weight.grad_view.copy_(self.dwpad[:self.N_real])
         # bias gradient = column sums of dout, correctly rounded (see csrc/gail.hip:colsum_kernel)
         check(_lib.load().ddrl_op_colsum(_p(dout), ld_dout, n, self.N_real, _p(self.m.bias.grad_view), _st()))
         if din is not None:
-            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n)
+            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_scales=ds)
 
 
 def dense_layer(module, relu, cap, device):

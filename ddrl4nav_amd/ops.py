@@ -158,19 +158,28 @@ class Linear:
     def pack(self, weight):
         check(self.lib.ddrl_op_linear_pack(_p(_f32(weight)), self.K, self.N, _p(self.wt), _p(self.wn), _st()))
 
-    def forward(self, x, ld_in, bias, relu, out, ld_out, n):
-        assert n <= self.max_n
-        check(self.lib.ddrl_op_linear_forward(_p(x), ld_in, _p(self.wt), _p(_f32(bias)), 1 if relu else 0, _p(out), ld_out,
-                                              n, self.K, self.N, _p(self.ws), _st()))
+    def uses_planes(self, n):
+        """True when a launch of n rows runs on the fp16 plane kernels (and therefore reads per-row scales)."""
+        return bool(self.lib.ddrl_op_linear_uses_planes(n, self.K, self.N))
+
+    def row_scales(self, x, ld, width, n, out):
+        """Per-row plane scales of x[:n] (one pass; hand them to the operators that read the same tensor)."""
+        check(self.lib.ddrl_op_row_scales(_p(x), ld, width, n, _p(out), _st()))
         return out
 
-    def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n):
+    def forward(self, x, ld_in, bias, relu, out, ld_out, n, in_scales=None):
+        assert n <= self.max_n
+        check(self.lib.ddrl_op_linear_forward(_p(x), ld_in, _p(self.wt), _p(_f32(bias)), 1 if relu else 0, _p(out), ld_out,
+                                              n, self.K, self.N, _p(self.ws), _p(in_scales), _st()))
+        return out
+
+    def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_scales=None):
         assert n <= self.max_n
         check(self.lib.ddrl_op_linear_dgrad(_p(dout), ld_dout, _p(self.wn), _p(mask_src), ld_mask, _p(din), ld_din, n,
-                                            self.K, self.N, _p(self.ws), _st()))
+                                            self.K, self.N, _p(self.ws), _p(dout_scales), _st()))
         return din
 
-    def wgrad(self, x, ld_in, dout, ld_dout, dw, db, n):
+    def wgrad(self, x, ld_in, dout, ld_dout, dw, db, n, in_scales=None, dout_scales=None):
         assert n <= self.max_n
         check(self.lib.ddrl_op_linear_wgrad(_p(x), ld_in, _p(dout), ld_dout, _p(self.ws), _p(dw), _p(db), n, self.K,
-                                            self.N, _st()))
+                                            self.N, _p(in_scales), _p(dout_scales), _st()))

@@ -365,18 +365,27 @@ int32_t ddrl_op_maxpool2_backward_idx(const float* dpool, const uint8_t* code, i
 int32_t ddrl_op_linear_pack_floats(int32_t K, int32_t N, int64_t* wt_floats, int64_t* wn_floats);
 int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, float* wn, void* stream);
 /* ws: scratch of ddrl_op_linear_ws_floats(n, K, N) floats (lets small n x N problems split K over
- * workgroups), or NULL for a single pass. */
+ * workgroups), or NULL for a single pass.
+ * in_scales / dout_scales (the last argument before `stream` of the three operators): layers of K >= 128, N >= 64 in launches of
+ * n >= 128 rows (ddrl_op_linear_uses_planes: 1) run as fp16 plane products and scale every ROW of `in` / `dout` by a power of two found
+ * in a pre-pass over that tensor.  The forward and the weight gradient read the same `in`, the data and the weight gradient the same
+ * `dout`: a caller computes the scales once per tensor with ddrl_op_row_scales(x [n][ld], width -> scales[n]) and passes them; NULL =
+ * the operator runs its own pre-pass. */
+int32_t ddrl_op_linear_uses_planes(int32_t n, int32_t K, int32_t N);
+int32_t ddrl_op_row_scales(const float* x, int64_t ld, int32_t width, int32_t n, float* scales, void* stream);
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act,
-                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, void* stream);
+                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, const float* in_scales,
+                               void* stream);
 /* din[b][k] = [mask_src[b][k] > 0 or mask_src == NULL] * sum_n dout[b][n] W[n][k]; mask_src is the
  * (ReLU) output of the layer that produced `in`.  ws: the same scratch as the forward's (the 16-bit plane kernels of layers with
  * K >= 128, N >= 64 keep their per-row scales there for launches of n >= 128 rows), or NULL for the f32-input kernels. */
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, void* stream);
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, const float* dout_scales,
+                             void* stream);
 int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats);
 /* dw [N][K] = dout^T in, db [N] = column sums of dout (overwritten) */
 int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
-                             float* db, int32_t n, int32_t K, int32_t N, void* stream);
+                             float* db, int32_t n, int32_t K, int32_t N, const float* in_scales, const float* dout_scales, void* stream);
 
 /* Actor / critic heads on 512-wide encoder features (AC_INPUT_DIM, config_nn.py:23) with the PPO
  * loss block and its backward, for nets assembled from the operators above.  `continuous` selects
