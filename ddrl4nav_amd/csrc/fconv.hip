@@ -1,7 +1,10 @@
 // First layer of the nav encoders -- a handful of input channels under a wide kernel -- on the 16-bit matrix pipe, fp32-accurate
 // (round 4; engine2.h "f16x3": two scaled fp16 planes per operand, three products per k-group on v_mfma_f32_32x32x16_f16):
-//   NavPreNet1D  conv1  3 -> 64  7x7 @48, padding 1      (reference USTC_lab/nn/nav_encoder.py:96)
-// replacing dconv.hip's f32-input band kernels (90 TFLOP/s) for the forward and the weight gradient (a first layer has no data gradient).
+//   NavPreNet1D   conv1  3 -> 64  7x7 @48, padding 1      (reference USTC_lab/nn/nav_encoder.py:96)
+//   NavPreNet     conv1  1 -> 64  3x3 @48, padding 1      (nav_encoder.py:18; image_batch = 1)
+//   NavPedPreNet  conv1  4 -> 64  3x3 @48, padding 1      (nav_encoder.py:56; image + three pedestrian maps)
+// replacing dconv.hip's f32-input band kernels (90 TFLOP/s) / the gather kernels for the forward and the weight gradient (a first layer
+// has no data gradient).  The text below describes the 7x7 layer; the 3x3 layers use the same template with one kx half (3 k-groups).
 //
 // With three channels a k-group cannot be "one tap x 16 channels" (pconv.hip).  Both kernels keep the input as a zero-bordered image with
 // the channels innermost and padded to four, [row][column][4 channels] fp16 = 8 bytes per pixel and plane, and order the reduction index as
