@@ -2,6 +2,8 @@
 plain PyTorch fp32 CPU operator it replaces (the operators of the reference's nav / MLP encoders,
 USTC_lab/nn/nav_encoder.py, mlp_encoder.py).  Tolerance: |d| <= 2e-5 * max|want| (+1e-6) --
 same products, different fp32 summation order."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -90,6 +92,8 @@ def test_conv_relu_pool_in_one_launch_vs_torch(shape):
     """ddrl_op_conv_forward_pool: max_pool2d(relu(conv(x)), 2) from the convolution's epilogue (csrc/fconv.hip, csrc/pconv.hip) --
     pooled values to fp32 rounding, and the decision bytes route d(pooled) exactly as torch's autograd does wherever the window's
     maximum is clear of fp32 noise."""
+    if os.environ.get("DDRL_NAV_F32") == "1" or os.environ.get("DDRL_FIRST_F32") == "1":
+        pytest.skip("the A/B switches put these layers on kernels without a pooling epilogue")
     from ddrl4nav_amd.ops import Conv, maxpool2_backward_idx
     n, cin, h, cout, ks, pad = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -315,6 +319,8 @@ def test_pooled_conv_block_full_batch_size_vs_torch_gpu(shape):
     rounding; the per-window routing agrees except where the window's two largest activations lie within fp32 noise of each other
     (either implementation may take either: a few windows in 10^7, each of which moves a weight-gradient element by ~1e-3 of its
     size -- so the gradients are compared under torch's OWN routing, which separates the arithmetic from those coin flips)."""
+    if os.environ.get("DDRL_NAV_F32") == "1" or os.environ.get("DDRL_FIRST_F32") == "1":
+        pytest.skip("the A/B switches put these layers on kernels without a pooling epilogue")
     from ddrl4nav_amd.ops import Conv, plane_scales, maxpool2_backward_idx
     n, cin, h, cout, ks = shape
     g = torch.Generator(device="cuda").manual_seed(n + cin + h)
