@@ -47,6 +47,14 @@ PIPE = {"ConvFwd1": ("f16x2", 2), "ConvWgrad1": ("f16x2", 2), "ConvFwd2": ("f16x
 EXECUTED_OVER_ALGORITHMIC = {"ConvDgrad3": 81.0 / 49.0, "ConvDgrad2": 1.23, "ConvFwd3": 1.11, "ConvWgrad3": 112.0 / 98.0,
                              "ConvWgrad2": 96.0 / 81.0, "ConvWgrad1": 48.0 / 40.0}
 PEAK_HBM_GBPS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# algorithmic HBM bytes per training launch of the GEMM kernels, both encoders (what a launch must read and
+# write once -- fp32 activations / gradients, u8 frames; weights and masks are noise), f(B samples)
+ALG_BYTES = {
+    "ConvFwd1": lambda B: B * (28224 + 2 * 51200), "ConvFwd2": lambda B: B * 2 * (51200 + 20736), "ConvFwd3": lambda B: B * 2 * (20736 + 12544),
+    "FcFwd": lambda B: B * 2 * (12544 + 2048), "FcDgrad": lambda B: B * 2 * (2048 + 12544), "FcWgrad": lambda B: B * 2 * (2048 + 12544),
+    "ConvDgrad3": lambda B: B * 2 * (12544 + 20736), "ConvDgrad2": lambda B: B * 2 * (20736 + 51200),
+    "ConvWgrad3": lambda B: B * 2 * (12544 + 20736), "ConvWgrad2": lambda B: B * 2 * (20736 + 51200), "ConvWgrad1": lambda B: B * (28224 + 2 * 51200),
+}
 # algorithmic HBM bytes per launch of the HBM-bound kernels, f(N envs, B samples, P params)
 HBM_BYTES = {
     "heads_loss": lambda N, B, P: B * (2 * 2 * 512 * 4 + 72),       # read h, write dh (both heads) + loss operands
@@ -235,32 +243,59 @@ def torch_rocm_baseline(net, x, acts, old, adv, ret):
                       "B=8192 x4 (4 .item() syncs per iteration as in the reference)"}
 
 
+_PMC_DOCS = {}
+# names in the PMC summaries follow the device functions (tools/pmc_to_profiles.py), bench names the launch sites
+_PMC_ALIAS = {"ConvFwd1": ("conv_fwd1_resident", "conv_fwd1_planes"), "ConvWgrad1": ("conv_wgrad1_planes",),
+              "ConvFwd2": ("conv_fwd2_planes",), "ConvFwd3": ("conv_fwd3_planes",), "FcFwd": ("fc_fwd_planes",),
+              "FcDgrad": ("fc_dgrad_planes",), "FcWgrad": ("fc_wgrad_planes",), "ConvDgrad3": ("conv_dgrad3_planes", "conv_dgrad3_exact"),
+              "ConvDgrad2": ("conv_dgrad2_both",), "ConvWgrad3": ("conv_wgrad3_planes",), "ConvWgrad2": ("conv_wgrad2_planes",)}
+
+
+def _pmc_files(family):
+    """Committed PMC summaries of one profile FAMILY, newest last: "atari" = profiles/r<round>_v<version>_pmc_traffic.json (the Pong
+    training kernels, tools/prof_round.sh), "nav" = profiles/r<round>_nav<version>_pmc_traffic.json (tools/prof_nav.sh).  The two
+    families share kernel names (clip_adam, sqnorm) at different sizes, so a lookup never crosses them; ordering is by the
+    integers (round, version) of the name ("v9" sorts after "v15" as text)."""
+    import glob
+    import re
+    pat = re.compile(r"^r(\d+)_%s(\d*)_pmc_traffic\.json$" % ("v" if family == "atari" else "nav"))
+    out = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")):
+        m = pat.match(os.path.basename(f))
+        if m:
+            out.append(((int(m.group(1)), int(m.group(2) or 0)), f))
+    return [f for _, f in sorted(out)]
+
+
+def _pmc_lookup(kernel, family="atari"):
+    """(document, kernel entry, file name) from the NEWEST committed PMC summary of `family` THAT CONTAINS `kernel` -- never the
+    newest file by name alone (round 4: a nav profile sorted after the Pong one and every Pong lookup came back empty)."""
+    names = (kernel,) + _PMC_ALIAS.get(kernel, ())
+    for f in reversed(_pmc_files(family)):
+        try:
+            doc = _PMC_DOCS.get(f)
+            if doc is None:
+                doc = _PMC_DOCS[f] = json.load(open(f))
+            for nm in names:
+                if nm in doc.get("kernels", {}):
+                    return doc, doc["kernels"][nm], os.path.basename(f)
+        except Exception:
+            continue
+    return None, None, None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per training launch of `kernel` from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate passes, tools/prof_pmc.sh -> profiles/*_pmc_traffic.json);
     null when no profile of this build is committed.  bench.py itself never runs the profiler."""
-    import glob
-    import re
-    # newest profile = highest (round, version) in the file name r<round>_v<version>_... ("v9" sorts after "v15" as text)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
-    if not files:
+    doc, k, src = _pmc_lookup(kernel)
+    if k is None:
         return None
-    # names in the PMC summaries follow the device functions (tools/pmc_to_profiles.py), bench names the launch sites
-    alias = {"ConvFwd1": "conv_fwd1_planes", "ConvWgrad1": "conv_wgrad1_planes", "ConvFwd2": "conv_fwd2_planes",
-             "ConvFwd3": "conv_fwd3_planes", "FcFwd": "fc_fwd_planes", "FcDgrad": "fc_dgrad_planes", "FcWgrad": "fc_wgrad_planes",
-             "ConvDgrad3": "conv_dgrad3_planes", "ConvDgrad2": "conv_dgrad2_both", "ConvWgrad3": "conv_wgrad3_planes",
-             "ConvWgrad2": "conv_wgrad2_planes"}
     try:
-        doc = json.load(open(files[-1]))
-        ks = doc["kernels"]
-        k = ks.get(kernel) or (ks.get("conv_fwd1_resident") if kernel == "ConvFwd1" else None) or ks.get(alias.get(kernel, ""))
-        if k is None:
-            return None
         out = {"hbm_bytes_per_launch": k["hbm_bytes"], "fetch_bytes": k["fetch_bytes"], "write_bytes": k["write_bytes"],
                # gfx950: FETCH_SIZE tallies wide (16 B / lane) streaming reads at half their bytes (MI355X_MICROARCH.md)
                "hbm_bytes_per_launch_corrected": k.get("hbm_bytes_corrected", 2.0 * k["fetch_bytes"] + k["write_bytes"]),
-               "mfma_busy_frac": k["mfma_busy_frac"], "clock_ghz": k["clock_ghz"], "source": os.path.basename(files[-1]),
+               "mfma_busy_frac": k["mfma_busy_frac"], "clock_ghz": k["clock_ghz"], "source": src,
                # NOT this run: the committed rocprofv3 --pmc passes of the named build on the named box (bench.py never profiles)
                "measured_on": {"build": doc.get("build", ""), "box": doc.get("box", ""), "batch": doc.get("batch", 65536)}}
         if "mfma_insts" in k and kernel in MAC and kernel in PIPE:
@@ -305,9 +340,7 @@ def mix_model(kernel, measured_ms):
         if not mixes or not t:
             return None
         rate, c_valu, c_byte, _ = cost_model.fit(mixes[-1])
-        doc = json.load(open(os.path.join(ROOT, "profiles", t["source"])))["kernels"]
-        alias = {v: k for k, v in cost_model.NAMES.items()}
-        k = doc.get("conv_fwd1_resident") if kernel == "ConvFwd1" and "conv_fwd1_resident" in doc else doc[alias[kernel]]
+        _, k, _ = _pmc_lookup(kernel)
         by = k["write_bytes"] + 2.0 * k["fetch_bytes"]  # FETCH_SIZE counts 16-byte-per-lane streams at half their bytes on gfx950
         ms = lambda eq: eq * cost_model.FLOP_PER_MFMA / (rate * 1e12) * 1e3
         parts = [ms(k["mfma_insts"]), ms(c_valu * (k["valu_insts"] - k["mfma_insts"])), ms(c_byte * by)]  # SQ_INSTS_VALU includes the MFMAs
@@ -605,7 +638,7 @@ def ingest_leg(net, ro, N, T, steps=2, host_memcpy=False):
                     "has them resident in HBM as the metric defines"}
 
 
-def nav_leg():
+def nav_leg(whole_loop=True):
     """BASELINE config 4's network (robot_nav: NavPreNet1D x2 + GaussionActor(2) + Critic, reference nn/nav_encoder.py:82-128) through
     the operator-composed path (nn/generic.py; csrc/pconv.hip, fconv.hip, plin.hip, c1d.hip): one PPO iteration on B = 4,096 samples in
     ONE micro-batch, per-operator HIP events (the two encoders run on two streams: the operator times overlap and sum to more than the
@@ -613,7 +646,9 @@ def nav_leg():
     encoder).  A sub-record: it never touches the headline `value`."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_nav
-    r = bench_nav.run(4096, 4096, 3)
+    # the first run also times ONE whole actor-learner loop at config 4's own size: 512 envs x T = 256 steps of acting + bootstrap +
+    # GAE, then 10 PPO iterations over the 131,072 samples in micro-batches of 4,096 (about 8 s; one loop after a one-iteration warm-up)
+    r = bench_nav.run(4096, 4096, 3, 256 if whole_loop else None, "nav1d", 10)
     ped = bench_nav.run(4096, 4096, 3, None, "navped")
     # per-operator times from a one-stream run (with the critic's encoder beside the actor's the operators' events overlap)
     prev = os.environ.get("DDRL_ENC_STREAMS")
@@ -638,7 +673,44 @@ def nav_leg():
             "dominant_kernel": dom, "dominant_ms_per_iter": ops[dom]["ms_per_iter"], "dominant_tflops": ops[dom]["tflops"],
             "dominant_pipe": "f16x3" if dom in planes else "f32-input MFMA", "dominant_peak_tflops": round(peak, 1),
             "dominant_roofline_frac": round(ops[dom]["tflops"] / peak, 4),
+            # the same figure under the key the headline's `roofline` uses, and the dominant kernel's PMC traffic from the newest committed
+            # NAV profile (profiles/r<round>_nav<version>_pmc_traffic.json: a family of its own, bench.py:_pmc_files)
+            "roofline_frac": round(ops[dom]["tflops"] / peak, 4), "roofline_traffic": nav_traffic(dom, r["micro_batch"]),
+            "whole_loop": r.get("whole_loop"),
             "ops": {k: v for k, v in list(ops.items())[:10]}}
+
+
+def nav_traffic(op_name, micro_batch):
+    """Corrected HBM bytes per launch of the device kernel behind the operator `op_name` (tools/bench_nav.py names, e.g.
+    conv5x5_64->128_fwd) from the newest committed nav PMC summary; None when the profile has no such kernel."""
+    import re
+    m = re.match(r"conv(\d+)x(\d+)_(\d+)->(\d+)_(fwd|dgrad|wgrad)$", op_name)
+    files = _pmc_files("nav")
+    if not m or not files:
+        return None
+    kh, _, cin, cout, kind = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5)
+    try:
+        doc = json.load(open(files[-1]))
+        for name, k in doc["kernels"].items():
+            # template arguments (csrc/pconv.hip, fconv.hip): pconv_*<CIN x COUT x KS x HIN x PAD> of the convolution the kernel RUNS (a data
+            # gradient runs the transposed convolution: CIN = the layer's cout); fconv_first_*<CIN x KS x HIN x PAD>
+            t = re.match(r"(pconv_direct_planes|pconv_wgrad_planes)<(\d+)x(\d+)x(\d+)x", name)
+            f = re.match(r"(fconv_first_fwd|fconv_first_wgrad)<(\d+)x(\d+)x", name)
+            if t:
+                fam, a, b, ks = t.group(1), int(t.group(2)), int(t.group(3)), int(t.group(4))
+                ok = ks == kh and ((kind == "wgrad") == (fam == "pconv_wgrad_planes")) and \
+                    ((a, b) == ((cout, cin) if kind == "dgrad" else (cin, cout)))
+            elif f:
+                ok = int(f.group(2)) == cin and int(f.group(3)) == kh and kind == ("fwd" if f.group(1).endswith("fwd") else "wgrad")
+            else:
+                continue
+            if ok:
+                return {"kernel": name, "hbm_bytes_per_launch_corrected": k.get("hbm_bytes_corrected", 2.0 * k["fetch_bytes"] + k["write_bytes"]),
+                        "mfma_busy_frac": k.get("mfma_busy_frac"), "clock_ghz": k.get("clock_ghz"), "source": os.path.basename(files[-1]),
+                        "measured_on": {"build": doc.get("build", ""), "box": doc.get("box", ""), "batch": doc.get("batch")}}
+    except Exception:
+        pass
+    return None
 
 
 def build_net(n_envs, horizon, iters, max_batch=None):
@@ -749,6 +821,7 @@ def main():
     ap.add_argument("--no-async", action="store_true", help="skip the asynchronous actor/learner leg")
     ap.add_argument("--no-ingest", action="store_true", help="skip the leg that feeds the frames through the pinned-host ring")
     ap.add_argument("--no-nav", action="store_true", help="skip the robot_nav (BASELINE config 4 network) sub-record")
+    ap.add_argument("--no-nav-loop", action="store_true", help="nav sub-record without the whole loop at config 4's size (about 10 s)")
     ap.add_argument("--ingest-memcpy", action="store_true", help="ingest leg: the producer also copies 7.2 MB per step into the slot")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: the ranks share the devices round-robin and reduce over gloo "
@@ -827,8 +900,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ms = []                         # per-step wall time: one_step(True) ends with a device synchronisation
     for _ in range(args.steps):
+        ts = time.perf_counter()
         one_step(True)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -894,19 +970,23 @@ def main():
             d = gemm[dom]
             pipe, products = PIPE.get(dom, ("f32", None))
             peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
+            td = pmc_traffic(dom)
+            # the committed PMC passes ran at their own batch (65,536); a run at another B scales the per-launch bytes linearly
+            tscale = (B / float(td["measured_on"]["batch"])) if td else 1.0
+            tbytes = td["hbm_bytes_per_launch_corrected"] * tscale if td else None
             roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
                         # HBM bytes per launch from the PMC passes WITH the guide's gfx950 correction (FETCH_SIZE counts wide streaming
                         # reads at half their bytes: 2 x FETCH_SIZE + WRITE_SIZE); the uncorrected sum is in traffic_detail
-                        "traffic": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch_corrected"),
-                        "traffic_detail": pmc_traffic(dom),
-                        "mix_model": mix_model(dom, d["ms_avg"]),
+                        "traffic": tbytes, "traffic_scaled_by_batch": round(tscale, 6),
+                        "traffic_detail": td,
+                        "mix_model": mix_model(dom, d["ms_avg"] / tscale),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
                         # the HBM side of the same kernel (north_star asks for the HBM fraction): corrected PMC bytes per launch /
                         # this run's launch time / 8 TB/s
-                        "hbm_bytes_per_launch_corrected": (pmc_traffic(dom) or {}).get("hbm_bytes_per_launch_corrected"),
-                        "hbm_frac": (round((pmc_traffic(dom) or {})["hbm_bytes_per_launch_corrected"] / (d["ms_avg"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
-                                     if pmc_traffic(dom) else None),
+                        "hbm_bytes_per_launch_corrected": tbytes,
+                        "hbm_frac": round(tbytes / (d["ms_avg"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if td else None,
+                        "algorithmic_bytes_per_launch": ALG_BYTES[dom](B) if dom in ALG_BYTES else None,
                         "algorithmic_flop_per_launch": d["flop_per_launch"], "pipe": pipe,
                         "executed_over_algorithmic": executed_over_algorithmic(dom),
                         "note": "dominant training kernel (largest accumulated time).  achieved = ALGORITHMIC fp32 FLOP (2*2*MAC per "
@@ -922,6 +1002,7 @@ def main():
         upd_ms = phase["update_ms"] / steps
         it_bytes = iteration_traffic()
         if roofline is not None and it_bytes:
+            it_bytes *= roofline["traffic_scaled_by_batch"]
             roofline["iteration_hbm_bytes_corrected"] = round(it_bytes)
             roofline["iteration_hbm_frac"] = round(it_bytes / (upd_ms / ITERS * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
             roofline["iteration_algorithmic_bytes"] = 28296 * B     # frames re-read + loss operands per sample
@@ -930,6 +1011,10 @@ def main():
             "metric": "env-steps/sec (whole node) + PPO update ms, Pong 256 envs at 1/2/4/8 GPUs",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            # median + p95 over the timed steps (rank 0's own steps; `value` stays total work / total time)
+            "step_ms": {"median": round(float(np.median(step_ms)), 3), "p95": round(float(np.percentile(step_ms, 95)), 3),
+                        "min": round(float(np.min(step_ms)), 3), "max": round(float(np.max(step_ms)), 3), "n": len(step_ms)},
+            "value_at_median_step": round(world * N * T / (float(np.median(step_ms)) * 1e-3), 1),
             "vs_baseline": None, "dtype": "f32 (f16x3 MFMA planes, fp32 accumulate)",
             "arithmetic": "f16x3 split-plane MFMA (f16x2 where the pixels are exact), fp32 accumulate, per-sample power-of-two scales in the backward",
             "data": "synthetic",
@@ -995,9 +1080,11 @@ def main():
                 out["with_ingest_serial"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_nav:
             try:
-                out["nav"] = nav_leg()
+                out["nav"] = nav_leg(whole_loop=not args.no_nav_loop)
                 out["config"].update(nav_ppo_iter_ms=out["nav"]["ppo_iter_ms"], nav_samples_per_s=out["nav"]["samples_per_s"],
-                                     nav_shared_navped_ppo_iter_ms=out["nav"]["shared_navped_ppo_iter_ms"])
+                                     nav_shared_navped_ppo_iter_ms=out["nav"]["shared_navped_ppo_iter_ms"],
+                                     nav_roofline_frac=out["nav"]["roofline_frac"],
+                                     nav_whole_loop_env_steps_per_s=(out["nav"]["whole_loop"] or {}).get("env_steps_per_s"))
             except Exception as e:
                 out["nav"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:

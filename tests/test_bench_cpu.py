@@ -1,0 +1,42 @@
+"""bench.py's host-side bookkeeping that needs no GPU: the lookup of the committed PMC summaries (profiles/*_pmc_traffic.json).
+Round 4's driver line carried null `roofline.traffic` / `hbm_frac` because the newest file BY NAME was a nav profile."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_every_training_kernel_resolves_in_the_newest_pong_profile():
+    srcs = set()
+    for k in bench.TRAIN_KERNELS + ("heads_loss", "clip_adam"):
+        t = bench.pmc_traffic(k)
+        assert t is not None, k
+        assert t["hbm_bytes_per_launch_corrected"] > 0 and t["fetch_bytes"] > 0
+        assert "nav" not in t["source"]
+        srcs.add(t["source"])
+    assert len(srcs) == 1, srcs      # one profile serves the whole iteration
+    newest = os.path.basename(bench._pmc_files("atari")[-1])
+    assert srcs == {newest}
+    it = bench.iteration_traffic()
+    assert it and it > 28296 * 65536           # never below the algorithmic bytes of an iteration
+    for k in bench.TRAIN_KERNELS:
+        assert bench.pmc_traffic(k)["executed_over_algorithmic"] >= 0.99, k
+
+
+def test_families_do_not_cross(tmp_path, monkeypatch):
+    """A nav profile that sorts after the Pong one must not shadow it, and shared kernel names (clip_adam) stay per family."""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    ent = {"hbm_bytes": 3.0, "fetch_bytes": 1.0, "write_bytes": 1.0, "mfma_busy_frac": 0.5, "clock_ghz": 2.0}
+    (prof / "r07_v2_pmc_traffic.json").write_text(json.dumps({"batch": 65536, "kernels": {"conv_dgrad2_both": ent, "clip_adam": dict(ent, hbm_bytes=7.0)}}))
+    (prof / "r07_v10_pmc_traffic.json").write_text(json.dumps({"batch": 65536, "kernels": {"clip_adam": dict(ent, hbm_bytes=9.0)}}))
+    (prof / "r07_nav9_pmc_traffic.json").write_text(json.dumps({"batch": 4096, "kernels": {"clip_adam": dict(ent, hbm_bytes=11.0)}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "_PMC_DOCS", {})
+    assert bench.pmc_traffic("ConvDgrad2")["source"] == "r07_v2_pmc_traffic.json"      # newest file that HAS the kernel
+    assert bench.pmc_traffic("clip_adam")["hbm_bytes_per_launch"] == 9.0               # v10 after v2 (integers, not text)
+    assert bench._pmc_lookup("clip_adam", "nav")[1]["hbm_bytes"] == 11.0
+    assert bench.pmc_traffic("ConvWgrad2") is None

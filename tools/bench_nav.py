@@ -3,8 +3,9 @@
 GaussionActor(2) + Critic): PPO iterations on synthetic inputs, per-operator HIP-event times and
 algorithmic TFLOP/s.  Not the headline bench (bench.py is); prints one JSON line.
 
-Usage: python tools/bench_nav.py [B] [micro_batch] [iters] [T]
-(T given: also one whole actor-learner loop at 512 envs x T steps, BASELINE config 4 shape)"""
+Usage: python tools/bench_nav.py [B] [micro_batch] [iters] [T] [encoder] [loop_iters]
+(T given: also one whole actor-learner loop at 512 envs x T steps with loop_iters PPO iterations, BASELINE config 4 shape:
+T = 256, loop_iters = 10)"""
 import json
 import sys
 import time
@@ -53,20 +54,20 @@ def lin_flop(l, *a, **k):
 
 
 
-def run(B=4096, CAP=1024, ITERS=3, T_loop=None, encoder="nav1d"):
+def run(B=4096, CAP=1024, ITERS=3, T_loop=None, encoder="nav1d", loop_iters=None):
     """One measurement; returns the record as a dict (bench.py's `nav` sub-record calls this).  The per-operator timing wraps
     ops.Conv / ops.Linear for the duration of the call only."""
     saved = {(cls, k): getattr(cls, k) for cls in (ops.Conv, ops.Linear) for k in ("forward", "dgrad", "wgrad")}
     saved.update({(ops.Conv, k): getattr(ops.Conv, k) for k in ("forward_pool", "dgrad_pooled", "wgrad_pooled")})
     events.clear()
     try:
-        return _run(B, CAP, ITERS, T_loop, encoder)
+        return _run(B, CAP, ITERS, T_loop, encoder, loop_iters)
     finally:
         for (cls, k), fn in saved.items():
             setattr(cls, k, fn)
 
 
-def _run(B, CAP, ITERS, T_loop, encoder):
+def _run(B, CAP, ITERS, T_loop, encoder, loop_iters=None):
     ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
     ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
     ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
@@ -131,10 +132,11 @@ def _run(B, CAP, ITERS, T_loop, encoder):
         ro.rewards.copy_(torch.where(u < 0.01, -1.0, torch.where(u > 0.99, 1.0, 0.0)))
         ro.dones.copy_((torch.rand((T, N), device="cuda", generator=g) < 1.0 / 800).to(torch.uint8))
 
-        def one_loop():
+        def one_loop(t_act, iters):
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            net.training_iter_time = iters
             e0.record()
-            for t in range(T):
+            for t in range(t_act):
                 ro.act(t)
             ro.bootstrap()
             ro.finish()
@@ -145,10 +147,14 @@ def _run(B, CAP, ITERS, T_loop, encoder):
             torch.cuda.synchronize()
             return e0.elapsed_time(e1), e1.elapsed_time(e2)
 
-        one_loop()
+        L_IT = int(loop_iters) if loop_iters else ITERS
+        one_loop(T, 1)              # warm-up: the whole rollout, one PPO iteration over the whole batch (every buffer sized)
         events.clear()
-        act_ms, upd_ms = one_loop()
-        loop = {"envs": N, "horizon": T, "ppo_iters": ITERS, "acting_plus_gae_ms": round(act_ms, 1), "update_ms": round(upd_ms, 1),
+        act_ms, upd_ms = one_loop(T, L_IT)
+        net.training_iter_time = ITERS
+        loop = {"envs": N, "horizon": T, "ppo_iters": L_IT, "samples": N * T, "micro_batch": CAP,
+                "acting_plus_gae_ms": round(act_ms, 1), "update_ms": round(upd_ms, 1),
+                "ppo_iter_ms": round(upd_ms / L_IT, 2), "ppo_iter_ms_per_4096_samples": round(upd_ms / L_IT * 4096 / (N * T), 3),
                 "env_steps_per_s": round(N * T / ((act_ms + upd_ms) * 1e-3), 1),
                 "acting_env_steps_per_s": round(N * (T + 1) / (act_ms * 1e-3), 1)}
     return ({"workload": ("robot_nav: shared NavPedPreNet(4) + GaussionActor(2), PPO iteration" if encoder == "navped" else
@@ -162,4 +168,4 @@ def _run(B, CAP, ITERS, T_loop, encoder):
 if __name__ == "__main__":
     print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 1024,
                          int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None,
-                         sys.argv[5] if len(sys.argv) > 5 else "nav1d")))
+                         sys.argv[5] if len(sys.argv) > 5 else "nav1d", int(sys.argv[6]) if len(sys.argv) > 6 else None)))
