@@ -713,6 +713,14 @@ def nav_traffic(op_name, micro_batch):
     return None
 
 
+def _rccl_version():
+    """RCCL's version as torch reports it ("nccl" IS RCCL on ROCm); None when the build has none."""
+    try:
+        return ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        return None
+
+
 def build_net(n_envs, horizon, iters, max_batch=None):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
@@ -918,6 +926,20 @@ def main():
         per_rank = [float(t.item()) for t in allr]
         elapsed = max(per_rank)
     stats = hp.stats()
+    # N > 1: the run proves its own replicas.  Every rank's parameters after the timed updates as a 64-bit checksum (the fp32 bit
+    # patterns summed as integers) and its step count, gathered on all ranks: clip + Adam run on every rank from the SAME reduced
+    # gradient, so the replicas must be bit-identical (the reference has no multi-GPU path to compare with,
+    # server/backward.py:167).  A collective that dropped or re-ordered a contribution on one rank shows up here.
+    replicas = None
+    if world > 1:
+        on_dev = dist.get_backend() == "nccl"
+        mine = torch.stack([hp.params.view(torch.int32).to(torch.int64).sum(), torch.tensor(hp.step, dtype=torch.int64, device=dev)])
+        mine = mine if on_dev else mine.cpu()
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        sums, stepsr = [int(t[0].item()) for t in allc], [int(t[1].item()) for t in allc]
+        replicas = {"identical": len(set(sums)) == 1 and len(set(stepsr)) == 1, "param_checksums": ["%016x" % (c & (2 ** 64 - 1)) for c in sums],
+                    "optimizer_steps": stepsr}
     ar_ms = hp.allreduce_ms() if world > 1 else []
     hp.time_allreduce(False)
     prof = hp.profile_read()
@@ -1041,10 +1063,12 @@ def main():
                 "bytes": int(hp.grads.numel() * 4), "calls": len(ar_ms), "ms_avg": round(float(np.mean(ar_ms)), 4),
                 "ms_p50": round(float(np.median(ar_ms)), 4), "ms_max": round(float(np.max(ar_ms)), 4),
                 "ms_per_update": round(float(np.sum(ar_ms)) / steps, 3), "backend": dist.get_backend(),
+                "rccl_version": _rccl_version(), "path": ("ddrl_comm (C ABI, csrc/comm.cpp)" if hp.comm is not None else "torch.distributed"),
                 # overlapped = layer buckets reduced on a second stream under the rest of the backward: the span above is then the
                 # EXPOSED part (what the compute stream waited for before clip + Adam)
                 "overlapped_with_backward": bool(hp._overlap), "exposed_ms_per_iteration": round(float(np.mean(ar_ms)), 4),
                 "algbw_gbps": round(hp.grads.numel() * 4 / (float(np.median(ar_ms)) * 1e-3) / 1e9, 2)},
+            "replicas_identical": None if replicas is None else replicas["identical"], "replicas": replicas,
             "last_losses": dict(stats, **{k: v for k, v in last.items() if k != "PpoBackUpTime"}),
             "roofline": roofline, "kernels": kernels,
             "dtype_note": "fp32 operands, fp32 accumulation, fp32-accurate results everywhere.  Every GEMM kernel of a training launch "

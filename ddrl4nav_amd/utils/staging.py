@@ -44,10 +44,16 @@ def _staged(s, device):
     return slot
 
 
-def _mark(slot):
-    if slot[1] is None:
-        slot[1] = torch.cuda.Event()
-    slot[1].record()  # current stream: the H2D copy enqueued just before
+def _mark(slot, device):
+    """Record the slot's event on the DESTINATION device's current stream -- the stream the H2D copy was enqueued on.  (The
+    calling thread's current device may be another one when one process drives several GPUs: an event recorded there would not
+    cover the copy, and the next fill of the pinned buffer could overwrite it under the DMA.)"""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(idx))
 
 
 def to_device(x, device, dtype=None):
@@ -58,7 +64,7 @@ def to_device(x, device, dtype=None):
     with _lock:   # one user of a pinned buffer at a time: fill, enqueue the H2D copy, record its event
         slot = _staged(t, device)
         out = slot[0].to(device, non_blocking=True)
-        _mark(slot)
+        _mark(slot, device)
     return out if dtype is None else out.to(dtype)
 
 
@@ -73,5 +79,5 @@ def copy_into(dst, src):
     with _lock:
         slot = _staged(s, dst.device)
         dst.copy_(slot[0], non_blocking=True)
-        _mark(slot)
+        _mark(slot, dst.device)
     return dst

@@ -179,14 +179,21 @@ def gail_rank(outdir, name, bounds, rank, world):
     from ddrl4nav_amd.runner import create_net
     from ddrl4nav_amd.utils.recipe import hash_weights
     g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    task = None
     if name == "f16_gail_classical":
         env = {"env_type": "gym", "env_name": "CartPole-v1", "env_num": 8, "discrete_action": True, "discrete_actions": [0, 1], "input_dim": 4}
         states, seed = g["states"], 16
+    elif name == "f22_gail_navped":   # config 5's own encoder: robot_nav with a pedestrian map -> shared NavPedPreNet(1 + 3) (runner/utils.py:88-102)
+        env = {"env_type": "robot_nav", "env_name": "robot_nav", "env_num": 8, "discrete_action": True, "discrete_actions": list(range(5)),
+               "image_batch": 1, "ped_sim": {"total": 3}}
+        states, seed, task = [g["state0"], g["state1"], g["state2"]], 22, "robot_nav"
     else:
         env = {"env_type": "gym", "env_name": "PongNoFrameskip-v4", "env_num": 8, "int_frame_stack": 4, "discrete_action": True,
                "discrete_actions": list(range(6))}
         states, seed = np.load(os.path.join(HERE, "golden", "f3_loss.npz"))["frames"], 17
     cfg = BaseConfig(types.SimpleNamespace(task="gail", ip="127.0.0.1"), env)
+    if task:
+        cfg.TASK_TYPE = task
     cfg_nn = ConfigNN(env)
     cfg_nn.NETWORK_TYPE, cfg_nn.SHARE_CNN_NET = "gail", True
     hidden = int(g["d_mlp_hidden"])
@@ -195,12 +202,17 @@ def gail_rank(outdir, name, bounds, rank, world):
     B, E = len(g["actions"]), len(g["expert_actions"])
     lo, hi = bounds[rank] * B // bounds[-1], bounds[rank + 1] * B // bounds[-1]
     elo, ehi = bounds[rank] * E // bounds[-1], bounds[rank + 1] * E // bounds[-1]
-    ex_states = states[g["expert_index"]][::-1].copy()
-    expert = [(ex_states[elo:ehi][None], g["expert_actions"][elo:ehi])]
+    if isinstance(states, list):     # F22 stores its expert batch (a LIST of state components)
+        expert = [([g["expert_state%d" % i][elo:ehi] for i in range(3)], g["expert_actions"][elo:ehi])]
+        shard = [s[lo:hi] for s in states]
+    else:
+        ex_states = states[g["expert_index"]][::-1].copy()
+        expert = [(ex_states[elo:ehi][None], g["expert_actions"][elo:ehi])]
+        shard = [states[lo:hi]]
     net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=256, expert_data=expert)
     w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)
     net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()}, strict=False)
-    exp = Experience(states=[states[lo:hi]], advs=g["advs"][lo:hi], actions=g["actions"][lo:hi], old_logps=g["old_logps"][lo:hi],
+    exp = Experience(states=shard, advs=g["advs"][lo:hi], actions=g["actions"][lo:hi], old_logps=g["old_logps"][lo:hi],
                      values=g["rets"][:, lo:hi])
     d_loss, losses, keep, digests = [], [], {}, {}
     for item, ut, last in net.learn(exp):

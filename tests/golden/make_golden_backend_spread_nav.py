@@ -44,11 +44,11 @@ def _spread(out, prefix, p0, s64, variants, tags):
             out["%s/ref_1mcos/%s" % (prefix, kk)] = np.float64(omc)
 
 
-def ppo_nets(out):
+def ppo_nets(out, makers=None, names=("f13_nav1d_gauss", "f14_navped_shared")):
     from ddrl4nav_amd.utils.recipe import hash_weights
     from USTC_lab.data import Experience
-    makers = NS.builders()
-    for name in ("f13_nav1d_gauss", "f14_navped_shared"):
+    makers = NS.builders() if makers is None else makers
+    for name in names:
         g = np.load(os.path.join(HERE, name + ".npz"))
         net, reopt, seed = makers[name]()
         weights = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)

@@ -74,9 +74,15 @@ def main():
     from make_golden import _install_stubs
     _install_stubs()
     sys.path.insert(0, NV.REF)
+    spread_for(builders())
+
+
+def spread_for(makers):
+    """The spread fixtures <fNN>b_spread.npz of {fixture name: builder -> (net, reopt, recipe seed)} (make_golden_navpre.py
+    calls this for F25)."""
     from ddrl4nav_amd.utils.recipe import hash_weights
     from USTC_lab.data import Experience
-    for name, make in builders().items():
+    for name, make in makers.items():
         g = np.load(os.path.join(HERE, name + ".npz"))
         net, reopt, seed = make()
         weights = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], seed)

@@ -154,17 +154,21 @@ BACKEND = "f23_backend_spread"
 _SPREAD = {}
 
 
-NAV_BACKEND = "f24_nav_backend_spread"   # the same for the nav nets and GAIL over a nav encoder (make_golden_backend_spread_nav.py)
+# the same for the nav nets and GAIL over a nav encoder (make_golden_backend_spread_nav.py; F25's own file: make_golden_navpre.py)
+NAV_BACKEND = ("f24_nav_backend_spread", "f25c_backend_spread")
 
 
 def _backend(mode, fixture=BACKEND):
-    """{key without the mode prefix: value} of the native-backend fixture for a learner mode / fixture name ({} when it has none)."""
-    path = os.path.join(GOLDEN, fixture + ".npz")
-    if not os.path.exists(path):
-        return {}
-    g = np.load(path)
-    pre = mode + "/"
-    return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+    """{key without the mode prefix: value} of the native-backend fixture(s) for a learner mode / fixture name ({} when none holds it)."""
+    out = {}
+    for fx in ((fixture,) if isinstance(fixture, str) else fixture):
+        path = os.path.join(GOLDEN, fx + ".npz")
+        if not os.path.exists(path):
+            continue
+        g = np.load(path)
+        pre = mode + "/"
+        out.update({k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
+    return out
 
 
 def with_backend(ref, name):
@@ -332,6 +336,32 @@ def relu_outputs_of(e, n):
     return d
 
 
+def decision_digest(record):
+    """Decision digests and margins of one nav-encoder forward from its recorded PRE-activations ({site: z}: oracle_nav._act's
+    `record` hook, or a kernel path's own values), as tests/golden/make_golden_navpre.py stores them for F26:
+      conv<k>_positive [n]  windows whose maximum is positive       conv<k>_argsum [n]  sum over those of the winner's index (scan order)
+      fc<k>_positive [n]    positive pre-activations
+    margin [n, sites]: the smallest distance of a decision from a tie (|max| of a window, or the gap between its two largest
+    entries when the maximum is positive; |z| for a dense ReLU), relative to the site's largest |z| over the batch."""
+    dig, margins = {}, []
+    for site in ("conv1", "conv2", "conv3"):
+        z = record[site].double()
+        n, c, h, w = z.shape
+        win = z.view(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+        top2 = win.topk(2, dim=-1)
+        mx, gap = top2.values[..., 0], top2.values[..., 0] - top2.values[..., 1]
+        risk = torch.minimum(mx.abs(), torch.where(mx > 0, gap, torch.full_like(gap, 1e9)))
+        margins.append((risk / z.abs().amax()).reshape(n, -1).amin(1))
+        pos = mx > 0
+        dig[site + "_positive"] = pos.reshape(n, -1).sum(1).numpy().astype(np.int64)
+        dig[site + "_argsum"] = (top2.indices[..., 0] * pos).reshape(n, -1).sum(1).numpy().astype(np.int64)
+    for site in ("fc0", "fc1"):
+        z = record[site].double()
+        margins.append((z.abs() / z.abs().amax()).amin(1))
+        dig[site + "_positive"] = (z > 0).sum(1).numpy().astype(np.int64)
+    return dig, torch.stack(margins, 1).numpy()
+
+
 _GTRAJ = {}
 
 
@@ -457,7 +487,9 @@ def gail_param_deviation(name, tag, got, d_forced=None):
 
 # ---- non-Atari nets (fixtures f13 / f14 / f15, oracle/ddrl_oracle_nav.py) ---------------------------------------------
 NAV_CASES = {"f13_nav1d_gauss": ("NavPreNet1D", 3, 2, True, False, 13), "f14_navped_shared": ("NavPedPreNet", 4, 5, False, True, 14),
-             "f15_mlp_classical": ("MLPPreNet", None, 2, False, False, 15)}
+             "f15_mlp_classical": ("MLPPreNet", None, 2, False, False, 15),
+             # the image-only shared encoder (runner/utils.py:104) and its no-tie batch (tests/golden/make_golden_navpre.py)
+             "f25_navpre_shared": ("NavPreNet", 1, 5, False, True, 25), "f26_navpre_unaligned": ("NavPreNet", 1, 5, False, True, 25)}
 _NTRAJ = {}
 
 

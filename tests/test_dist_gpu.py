@@ -141,14 +141,15 @@ def test_f4_split_eight_ways_in_process(golden):
             h.close()
 
 
-@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari"])
+@pytest.mark.parametrize("name", ["f16_gail_classical", "f17_gail_atari", "f22_gail_navped"])
 def test_data_parallel_gail_discriminator_and_generator(tmp_path, golden, name):
     """BASELINE config 5 (GAIL on several GPUs): two ranks, each with its shard (40 / 24) of the policy batch and of the expert
     batch.  The discriminator's WGAN means run over the UNION of the shards and its flat gradient + loss are all-reduced before
     the clip (reference semantics of GAIL.py:73-94 on the whole batch), then the generator's PPO iterations as for any net:
     D and G replicas bit-identical after the D step and after ten PPO iterations; the D loss equals the one-rank value; for
     the MLP fixture the D-step parameters obey the same bounds against the reference as the one-rank run (the Atari fixture's
-    bounds need the kernel's leaky-ReLU decisions, tests/test_gail_gpu.py)."""
+    bounds need the kernel's leaky-ReLU decisions, tests/test_gail_gpu.py).  f22_gail_navped = config 5's own encoder (shared
+    NavPedPreNet(4) under generator and discriminator, from the reference's GAIL.learn: tests/golden/make_golden_gail_nav.py)."""
     import parity_util as P
     ranks = _run_world(tmp_path, "gail:" + name, [0, 40, 64], "gail_w2_" + name[:3])
     r0, r1 = ranks
@@ -203,6 +204,13 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["launcher"] == "self" and len(d["elapsed_s_per_rank"]) == 2
     assert d["allreduce"]["calls"] == 10 and d["allreduce"]["backend"] in ("gloo", "nccl")
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # the N > 1 line proves its own replicas: identical parameter checksums and step counts on every rank,
+    # the collective's version / bandwidth / exposed time next to them
+    assert d["replicas_identical"] is True and len(set(d["replicas"]["param_checksums"])) == 1
+    assert d["replicas"]["optimizer_steps"] == [20, 20]          # (1 warm-up + 1 timed) x 10 iterations on both ranks
+    for k in ("algbw_gbps", "exposed_ms_per_iteration", "rccl_version", "path", "overlapped_with_backward"):
+        assert k in d["allreduce"], k
+    assert d["allreduce"]["algbw_gbps"] > 0
 
 
 def test_torch_nccl_bucketed_allreduce_one_rank(tmp_path):

@@ -370,3 +370,81 @@ def test_gail_config5_full_size_properties(golden):
     gs = g_full[:G.n_params].abs().max().item()
     assert (acc[:G.n_params] - g_full[:G.n_params]).abs().max().item() <= 1e-4 * gs
     np.testing.assert_allclose(acc[G.n_params:].cpu().numpy(), g_full[G.n_params:].cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_gail_config5_full_size_properties_on_the_nav_encoder(golden):
+    """BASELINE config 5 on ITS OWN encoder at size: GAIL over the shared NavPedPreNet(1 + 3 channels) (runner/utils.py:98-102,161-168;
+    reference arithmetic GAIL.py:73-94), 32,768 samples in micro-batches of 4,096 -- the properties of
+    test_gail_config5_full_size_properties, on the nav kernels (csrc/fconv.hip, pconv.hip, plin.hip):
+    (a) data-parallel additivity of the discriminator step over two uneven shards that divide by the TOTAL sizes (what the all-reduce
+        of nn/gail.py sums), gradient and loss;
+    (b) duplicating policy and expert batch leaves the discriminator's mean gradient and loss unchanged;
+    (c) the generator's PPO gradient with the GAIL critic over 8 micro-batches equals the sum over two uneven shards of it.
+    Tolerance 1e-4 of the largest gradient element: sums over 32,768 samples in different association orders (fp32)."""
+    g, net, _, _ = _net("f22_gail_navped", golden, max_batch=4096)
+    D = net.discriminator
+    B = 32768
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(522)
+    half = lambda t: torch.cat([t, t]).contiguous()
+    img = half((torch.rand((B // 2, 1, 48, 48), device="cuda", generator=gen) < 0.3).float())
+    vec = half(torch.randn((B // 2, 9), device="cuda", generator=gen))
+    ped = half((torch.rand((B // 2, 3, 48, 48), device="cuda", generator=gen) < 0.1).float())
+    states = [img, vec, ped]
+    ex_states = [s.flip(0).contiguous() for s in states]
+    acts = half(torch.randint(0, 5, (B // 2,), device="cuda", generator=gen).float())
+    ex_acts = half(torch.randint(0, 5, (B // 2,), device="cuda", generator=gen).float()).reshape(B, 1)
+    n = D.n_params
+    D._ensure_packed()
+    cut_of = lambda ts, sl: [t[sl] for t in ts]
+
+    def d_grad(pol, pol_a, ex, ex_a, n_pol, n_ex):
+        D._pass(pol, pol_a, +1.0, True, n_total=n_pol)
+        D._pass(ex, ex_a, -1.0, False, n_total=n_ex)
+        return D.grads[:n].clone(), float(D._loss.item())
+
+    full, loss_full = d_grad(states, acts, ex_states, ex_acts, B, B)
+    scale = full.abs().max().item()
+    assert scale > 0
+    cut = 20000                      # 4 full micro-batches + a ragged one | 3 full + a ragged one
+    acc, loss_acc = torch.zeros_like(full), 0.0
+    for sl in (slice(0, cut), slice(cut, B)):
+        gsh, lsh = d_grad(cut_of(states, sl), acts[sl], cut_of(ex_states, sl), ex_acts[sl], B, B)
+        acc += gsh
+        loss_acc += lsh
+    assert (acc - full).abs().max().item() <= 1e-4 * scale
+    np.testing.assert_allclose(loss_acc, loss_full, rtol=1e-4, atol=1e-7)
+    h = slice(0, B // 2)
+    one, loss_one = d_grad(cut_of(states, h), acts[h], cut_of(ex_states, slice(B // 2, B)), ex_acts[B // 2:], B // 2, B // 2)   # (b)
+    assert (one - full).abs().max().item() <= 1e-4 * scale
+    np.testing.assert_allclose(loss_one, loss_full, rtol=1e-4, atol=1e-7)
+    # (c) generator with the GAIL critic: gradient of the whole batch (8 micro-batches, accumulated by learn's rule) = sum of two shards'
+    G = net.generator
+    old = half(torch.full((B // 2,), -1.6, device="cuda") + 0.2 * torch.randn(B // 2, device="cuda", generator=gen))
+    adv = half(torch.randn(B // 2, device="cuda", generator=gen))
+    rets = torch.stack([half(torch.randn(B // 2, device="cuda", generator=gen)) for _ in range(2)])
+    G._ensure_packed()
+
+    def g_grad(sl):
+        tot = torch.zeros(G.n_params + 3, device="cuda")
+        lo0, hi0 = sl.start, sl.stop
+        for lo in range(lo0, hi0, G.cap):
+            hi = min(hi0, lo + G.cap)
+            G._iter_chunk([t[lo:hi] for t in states], hi - lo, acts[lo:hi], old[lo:hi], adv[lo:hi], rets[0, lo:hi].contiguous(), B,
+                          [rets[1, lo:hi].contiguous()])
+            tot += G.gtmp[:G.n_params + 3]
+        return tot
+
+    g_full = g_grad(slice(0, B))
+    acc = g_grad(slice(0, cut)) + g_grad(slice(cut, B))
+    gs = g_full[:G.n_params].abs().max().item()
+    assert gs > 0 and (acc[:G.n_params] - g_full[:G.n_params]).abs().max().item() <= 1e-4 * gs
+    np.testing.assert_allclose(acc[G.n_params:].cpu().numpy(), g_full[G.n_params:].cpu().numpy(), rtol=1e-4, atol=1e-7)
+    # duplicated batch: the first half alone (means over B / 2) gives the same mean gradient
+    acc2 = torch.zeros_like(g_full)
+    for lo in range(0, B // 2, G.cap):
+        hi = lo + G.cap
+        G._iter_chunk([t[lo:hi] for t in states], hi - lo, acts[lo:hi], old[lo:hi], adv[lo:hi], rets[0, lo:hi].contiguous(), B // 2,
+                      [rets[1, lo:hi].contiguous()])
+        acc2 += G.gtmp[:G.n_params + 3]
+    assert (acc2[:G.n_params] - g_full[:G.n_params]).abs().max().item() <= 1e-4 * gs

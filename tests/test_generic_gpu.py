@@ -33,6 +33,11 @@ def _make(name, max_batch=64):
         c = _configs({"discrete_action": True, "discrete_actions": list(range(5)), "image_batch": 1, "ped_sim": {"total": 3}},
                      shared=True)
         seed = 14
+    elif name in ("f25_navpre_shared", "f26_navpre_unaligned"):
+        # no pedestrian map: create_net picks the image-only NavPreNet(image_batch) as the shared encoder (runner/utils.py:104)
+        c = _configs({"discrete_action": True, "discrete_actions": list(range(5)), "image_batch": 1, "ped_sim": {"total": 0}},
+                     shared=True)
+        seed = 25
     else:
         c = _configs({"discrete_action": True, "discrete_actions": [0, 1], "input_dim": 4}, task="classical")
         seed = 15
@@ -47,7 +52,7 @@ def _states(g):
     return [g["state%d" % i] for i in range(n)]
 
 
-CASES = ["f13_nav1d_gauss", "f14_navped_shared", "f15_mlp_classical"]
+CASES = ["f13_nav1d_gauss", "f14_navped_shared", "f15_mlp_classical", "f25_navpre_shared"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -107,6 +112,59 @@ def test_generic_net_forward_loss_gradients_golden(golden, name):
         worst[k] = float(np.abs(got - want).max()) / scale
         assert worst[k] <= 2e-5, (k, worst[k])
     print(name, "gradient vs float64 under the kernels' decisions, worst tensor: %.2e" % max(worst.values()))
+
+
+def test_navpre_gradient_unaligned(golden):
+    """The one nav gradient check with NO transfer of decisions.  F26 = the shared NavPreNet(1) on 32 samples
+    selected (by the reference in float64, tests/golden/make_golden_navpre.py) so that every ReLU / max-pool decision of the forward
+    is at least 8.6e-6 of its site's largest pre-activation away from a tie.  The kernels' pre-activations are accurate to ~1e-7 of
+    that scale, so they must take the reference's decisions ON THEIR OWN: asserted through the decision digests (per sample and
+    site: how many windows / units are active, and which window entry won), then the FULL gradient of every tensor is held to
+    2e-5 max|g| against the float64 oracle running with ITS OWN decisions (pinned to the reference on this batch by
+    test_oracle_golden.py::test_f26_...) and against the reference's stored fp32 gradient."""
+    import parity_util as P
+    from ddrl4nav_amd.nn.generic import NavPreNet
+    g = golden("f26_navpre_unaligned")
+    net, w = _make("f26_navpre_unaligned", max_batch=64)
+    assert type(net.prenet) is NavPreNet and net.prenet.image_channel == 1
+    assert [k for k, _ in net.named_parameters()] == list(g["names"])
+    states, B = [g["state0"], g["state1"]], len(g["advs"])
+    (dist, logp), values = net(states, torch.from_numpy(g["actions"]))
+    np.testing.assert_allclose(values[0].cpu().numpy()[:, 0], g["value"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=2e-5, atol=2e-5)
+    dev = lambda k: torch.from_numpy(g[k]).cuda()
+    net._ensure_packed()
+    net._iter_chunk(net._stage(states, 0, B), B, dev("actions"), dev("old_logps"), dev("advs"), dev("rets"), B)
+    np.testing.assert_allclose(net.gtmp[net.n_params:net.n_params + 3].cpu().numpy(), g["loss4"][1:], rtol=2e-5, atol=2e-6)
+    # ---- the kernels' own decisions, as digests: identical to the reference's
+    e = net.prenet
+    for site, blk in (("conv1", e.c1), ("conv2", e.c2), ("conv3", e.c3)):
+        a = blk.relu_output(B).cpu()
+        n, c, h, wd = a.shape
+        win = a.view(n, c, h // 2, 2, wd // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, wd // 2, 4)
+        mx, arg = win.max(dim=-1)
+        pos = mx > 0
+        assert np.array_equal(pos.reshape(n, -1).sum(1).numpy(), g["digest/%s_positive" % site]), site
+        assert np.array_equal((arg * pos).reshape(n, -1).sum(1).numpy(), g["digest/%s_argsum" % site]), site
+    assert np.array_equal((e.cat[:B, e.extra:e.extra + 512] > 0).sum(1).cpu().numpy(), g["digest/fc0_positive"])
+    assert np.array_equal((e.f1[:B] > 0).sum(1).cpu().numpy(), g["digest/fc1_positive"])
+    # ---- the full gradient: float64 oracle with its OWN decisions (no `sub`), and the reference's stored fp32 gradient
+    flat = net.gtmp[:net.n_params].cpu().numpy().astype(np.float64)
+    ora = P.NavStepper("f26_navpre_unaligned")
+    total, _, _, _ = ora.N.losses(ora.net, ora.states, *ora.args)
+    total.backward()
+    off, worst = 0, {}
+    for k, p in ora.net.named_parameters():
+        n = p.numel()
+        want, got = p.grad.numpy().ravel(), flat[off:off + n]
+        off += n
+        scale = float(np.abs(want).max())
+        worst[k] = float(np.abs(got - want).max()) / scale
+        assert worst[k] <= 2e-5, (k, worst[k])
+        ref = g["gfull/" + k] if "gfull/" + k in g.files else g["gstride/" + k]
+        sub = got if "gfull/" + k in g.files else got[::max(1, n // 4097)][:4097]
+        assert np.abs(sub - ref).max() <= 2e-5 * float(g["gmax/" + k]), (k, "vs the reference's fp32 gradient")
+    print("F26 un-aligned gradient vs float64, worst tensor: %.2e (%s)" % (max(worst.values()), max(worst, key=worst.get)))
 
 
 def _relu_outputs(net, n):

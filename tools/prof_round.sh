@@ -9,7 +9,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 python3 bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-async --no-ingest > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" ); echo "kernel-trace rc=$?"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-async --no-ingest --no-nav > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" ); echo "kernel-trace rc=$?"
 find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 bash tools/prof_pmc.sh "gpurun_out/$TAG/pmc"; echo "pmc rc=$?"
 hostname > "$OUT/box.txt"; rocm-smi --showproductname --showuniqueid 2>/dev/null | grep -E "Card Model|Card SKU|Unique ID" | head -6 >> "$OUT/box.txt"
