@@ -651,15 +651,7 @@ def nav_leg(whole_loop=True):
     r = bench_nav.run(4096, 4096, 3, 256 if whole_loop else None, "nav1d", 10)
     ped = bench_nav.run(4096, 4096, 3, None, "navped")
     # per-operator times from a one-stream run (with the critic's encoder beside the actor's the operators' events overlap)
-    prev = os.environ.get("DDRL_ENC_STREAMS")
-    os.environ["DDRL_ENC_STREAMS"] = "0"
-    try:
-        r1 = bench_nav.run(4096, 4096, 3)
-    finally:
-        if prev is None:
-            os.environ.pop("DDRL_ENC_STREAMS", None)
-        else:
-            os.environ["DDRL_ENC_STREAMS"] = prev
+    r1 = bench_nav.run(4096, 4096, 3, encoder_streams=False)
     ops = r1["ops"]
     dom = max(ops, key=lambda k: ops[k]["ms_per_iter"])
     # conv and dense layers run on the 16-bit matrix pipe as three fp16 plane products (ceiling 2.5 PF / 3); the Conv1d pair of the laser

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libddrl_hip.so")
 
 STATS_FLOATS = 8
-ABI_VERSION = 2  # include/ddrl.h DDRL_ABI_VERSION this binding was written against
+ABI_VERSION = 3  # include/ddrl.h DDRL_ABI_VERSION this binding was written against
 
 
 class DdrlError(RuntimeError):
@@ -103,15 +103,16 @@ SIGNATURES = {
     "ddrl_op_conv_out_shape": (c_int32, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "ddrl_op_conv_pack_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
     "ddrl_op_conv_pack": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
-    "ddrl_op_conv_forward": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
-    "ddrl_op_conv_dgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_forward": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_scratch_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
+    "ddrl_op_conv_dgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_wgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "ddrl_op_plane_scales": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_conv_pooled_uses_scales": (c_int32, [POINTER(ConvDesc)]),
     "ddrl_op_conv_has_forward_pool": (c_int32, [POINTER(ConvDesc)]),
-    "ddrl_op_conv_forward_pool": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ddrl_op_conv_dgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_forward_pool": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_dgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_ws_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
     "ddrl_op_conv_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_maxpool2_forward": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),

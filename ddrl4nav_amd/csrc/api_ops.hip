@@ -26,21 +26,17 @@ static bool direct_ok(const ConvGeom& g, const void* in_side, const void* out_si
   return (g.in_sn & 3) == 0 && (g.out_sn & 3) == 0 && aligned16(in_side) && aligned16(out_side);
 }
 
-// regions of a layer's packed buffer: 0-4 gather layouts + tables (gconv.hip), 5 / 6 the direct forward / data-gradient layouts
-// (dconv.hip f32 planes, or pconv.hip fp16 planes + header where a layer has them), 7 = per-sample plane scales of the LATEST
-// launch (pconv.hip; g.n floats -- the last region, so that no other offset depends on the batch size of a call)
+// regions of a layer's packed buffer: 0-4 gather layouts + tables (gconv.hip), 5 / 6 the specialised forward / data-gradient layouts
+// of the layers that have them (pconv.hip / fconv.hip fp16 planes + header, c1d.hip transposed weights).  Read-only after ddrl_op_conv_pack;
+// nothing in it depends on the batch size of a call (the per-sample scales of a launch live in the caller's scales_scratch).
 struct PackView {
-  int64_t off[8], total;
+  int64_t off[7], total;
 };
 static PackView pack_view(const ConvGeom& g) {
-  int64_t sz[8];
+  int64_t sz[7];
   conv_pack_sizes(g, sz);
-  conv_direct_pack_sizes(g, sz + 5);  // specialised direct-convolution layouts (dconv.hip), 0 when absent
-  sz[7] = 0;
-  if (conv_has_planes(g)) {
-    sz[5] = sz[6] = conv_planes_pack_floats(g);
-    sz[7] = g.n;
-  }
+  sz[5] = sz[6] = 0;
+  if (conv_has_planes(g)) sz[5] = sz[6] = conv_planes_pack_floats(g);
   if (conv_has_c1d(g)) sz[5] = sz[6] = conv_c1d_pack_floats(g);  // c1d.hip: transposed weights for the scalar cache
   if (conv_has_first(g)) {  // fconv.hip: forward weight planes only (a first layer has no data gradient)
     sz[5] = conv_first_pack_floats(g);
@@ -48,7 +44,7 @@ static PackView pack_view(const ConvGeom& g) {
   }
   PackView v;
   int64_t o = 0;
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 7; ++i) {
     v.off[i] = o;
     o += align_up(sz[i], 64);
   }
@@ -85,16 +81,20 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
     launch_conv_first_pack(g, w, packed + v.off[5], (hipStream_t)stream);
   else if (conv_has_planes(g))
     launch_conv_planes_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
-  else if (conv_has_direct(g) || conv_has_band_fwd(g))
-    launch_conv_direct_pack(g, w, packed + v.off[5], packed + v.off[6], (hipStream_t)stream);
   return op_check();
+}
+
+int32_t ddrl_op_conv_scratch_floats(const ddrl_conv_desc* d, int64_t* floats) {
+  ConvGeom g;
+  if (!fill_geom(d, g) || !floats) return DDRL_ERR_INVALID_ARG;
+  *floats = conv_has_planes(g) ? (int64_t)g.n : 0;
+  return DDRL_OK;
 }
 
 int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
   ConvGeom g;
   if (!fill_geom(d, g) || !floats) return DDRL_ERR_INVALID_ARG;
   int splits = conv_wgrad_splits(g);
-  if (conv_direct_wgrad_splits(g) > splits) splits = conv_direct_wgrad_splits(g);
   if (conv_planes_wgrad_splits(g) > splits) splits = conv_planes_wgrad_splits(g);
   if (conv_first_wgrad_splits(g) > splits) splits = conv_first_wgrad_splits(g);
   if (conv_c1d_wgrad_splits(g) > splits) splits = conv_c1d_wgrad_splits(g);
@@ -104,11 +104,11 @@ int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
 }
 
 int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, int32_t act,
-                             float* out, void* stream) {
+                             float* out, float* scales_scratch, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
-  // the caller sized `packed` for its largest batch (ddrl_op_conv_pack_floats with that n): region 7 holds this launch's scales
+  if (conv_has_planes(g) && direct_ok(g, in, out) && !scales_scratch) return DDRL_ERR_INVALID_ARG;  // g.n floats (ddrl_op_conv_scratch_floats)
   if (conv_has_c1d(g))
     launch_conv_c1d_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
   else if (conv_has_first(g) && direct_ok(g, in, out))
@@ -116,12 +116,8 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
   else if (conv_has_first(g))
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
   else if (conv_has_planes(g) && direct_ok(g, in, out))
-    launch_conv_planes_fwd(g, in, packed + v.off[5], const_cast<float*>(packed) + v.off[7], bias, act, out, (hipStream_t)stream);
-  else if (conv_has_planes(g))
-    return DDRL_ERR_INVALID_ARG;   // fp16-plane layers keep no f32 layout: strides / bases must allow 16-byte loads
-  else if ((conv_has_direct(g) || conv_has_band_fwd(g)) && direct_ok(g, in, out))
-    launch_conv_direct_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
-  else
+    launch_conv_planes_fwd(g, in, packed + v.off[5], scales_scratch, bias, act, out, (hipStream_t)stream);
+  else   // any geometry, any stride / alignment (also the plane layers' when a strided view rules out their 16-byte loads)
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
   return op_check();
 }
@@ -145,28 +141,29 @@ int32_t ddrl_op_conv_pooled_uses_scales(const ddrl_conv_desc* d) {
 }
 
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
-                                  uint8_t* code, const float* in_scales, void* stream) {
+                                  uint8_t* code, const float* in_scales, float* scales_scratch, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !pooled || !code) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(in)) return DDRL_ERR_INVALID_ARG;
+  if (!conv_has_first(g) && conv_has_planes(g) && !in_scales && !scales_scratch) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
   if (conv_has_first(g))
     launch_conv_first_fwd_pool(g, in, packed + v.off[5], bias, pooled, code, (hipStream_t)stream);
   else if (conv_has_planes(g) && conv_planes_has_pool(g))
-    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], const_cast<float*>(packed) + v.off[7], in_scales, bias, pooled, code, (hipStream_t)stream);
+    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], scales_scratch, in_scales, bias, pooled, code, (hipStream_t)stream);
   else
     return DDRL_ERR_UNSUPPORTED;  // the caller runs ddrl_op_conv_forward + ddrl_op_maxpool2_forward_idx
   return op_check();
 }
 
 int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
-                                  const float* dpool_scales, void* stream) {
+                                  const float* dpool_scales, float* scales_scratch, void* stream) {
   ConvGeom g;
-  if (!fill_geom(d, g) || !dpool || !code || !packed || !din) return DDRL_ERR_INVALID_ARG;
+  if (!fill_geom(d, g) || !dpool || !code || !packed || !din || (!dpool_scales && !scales_scratch)) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(din) || !aligned16(dpool)) return DDRL_ERR_INVALID_ARG;
   if (!(conv_has_planes(g) && conv_planes_has_pool(g))) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], const_cast<float*>(packed) + v.off[7], dpool_scales, din, (hipStream_t)stream);
+  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], scales_scratch, dpool_scales, din, (hipStream_t)stream);
   return op_check();
 }
 
@@ -184,18 +181,15 @@ int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, cons
   return op_check();
 }
 
-int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream) {
+int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, float* scales_scratch, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !dz || !packed || !din) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
+  if (conv_has_planes(g) && direct_ok(g, din, dz) && !conv_has_c1d_backward(g) && !scales_scratch) return DDRL_ERR_INVALID_ARG;
   if (conv_has_c1d_backward(g))
     launch_conv_c1d_dgrad(g, dz, packed + v.off[6], din, (hipStream_t)stream);
   else if (conv_has_planes(g) && direct_ok(g, din, dz))
-    launch_conv_planes_dgrad(g, dz, packed + v.off[6], const_cast<float*>(packed) + v.off[7], din, (hipStream_t)stream);
-  else if (conv_has_planes(g))
-    return DDRL_ERR_INVALID_ARG;
-  else if (conv_has_direct(g) && direct_ok(g, din, dz))
-    launch_conv_direct_dgrad(g, dz, packed + v.off[6], din, (hipStream_t)stream);
+    launch_conv_planes_dgrad(g, dz, packed + v.off[6], scales_scratch, din, (hipStream_t)stream);
   else
     launch_conv_dgrad(g, dz, packed + v.off[2], (const int2*)(packed + v.off[3]), din, (hipStream_t)stream);
   return op_check();
@@ -213,8 +207,6 @@ int32_t ddrl_op_conv_wgrad(const ddrl_conv_desc* d, const float* in, const float
     launch_conv_first_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
   else if (conv_has_planes(g) && direct_ok(g, in, dz))
     launch_conv_planes_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
-  else if (conv_has_direct_wgrad(g) && direct_ok(g, in, dz))
-    launch_conv_direct_wgrad(g, in, dz, ws, dw, db, (hipStream_t)stream);
   else
     launch_conv_wgrad(g, in, dz, (const int*)(packed + v.off[4]), ws, dw, db, (hipStream_t)stream);
   return op_check();

@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256) void wgrad32_kernel(const float* __restrict__ 
 enum C1dId { kC1None = 0, kC1First, kC1Second };
 
 static C1dId c1d_id(const ConvGeom& g) {
-  static const bool off = [] { const char* e = getenv("DDRL_C1D_GATHER"); return e && e[0] == '1'; }();  // A/B switch: the gather kernels
-  if (off || g.h != 1 || g.kh != 1 || g.stride != 2 || g.pad_h != 0 || g.pad_w != 0 || g.cout != 32) return kC1None;
+  if (g.h != 1 || g.kh != 1 || g.stride != 2 || g.pad_h != 0 || g.pad_w != 0 || g.cout != 32) return kC1None;
   if (g.cin == 1 && g.kw == 5) return kC1First;
   if (g.cin == 32 && g.kw == 3) return kC1Second;
   return kC1None;

@@ -537,12 +537,7 @@ static FirstId first_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
   return kFNone;
 #else
-  // A/B switches: DDRL_NAV_F32=1 puts every nav operator on its f32-input kernels, DDRL_FIRST_F32=1 this layer only
-  static const bool off = [] {
-    const char *a = getenv("DDRL_NAV_F32"), *b = getenv("DDRL_FIRST_F32");
-    return (a && a[0] == '1') || (b && b[0] == '1');
-  }();
-  if (off || g.stride != 1 || g.h != 48 || g.w != 48 || g.kh != g.kw || g.pad_h != 1 || g.pad_w != 1 || g.cout != 64) return kFNone;
+  if (g.stride != 1 || g.h != 48 || g.w != 48 || g.kh != g.kw || g.pad_h != 1 || g.pad_w != 1 || g.cout != 64) return kFNone;
   if (g.kh == 7 && g.cin == 3) return kFN1d;
   if (g.kh == 3 && g.cin == 1) return kFNav;
   if (g.kh == 3 && g.cin == 4) return kFPed;

@@ -5,7 +5,7 @@
 // `mlp` helper USTC_lab/nn/utils.py:10-20); the 3136->512 Atari layer keeps its own kernels (fc2.hip).
 // Since round 4 layers of K >= 128, N >= 64 in launches of >= 128 rows run as fp16 plane products instead (plin.hip; the launchers at
 // the bottom dispatch): these kernels remain for small layers, small launches (acting with a few environments: split-K fills the chip
-// from one row tile) and as the A/B reference (DDRL_LIN_F32=1).
+// from one row tile).
 //
 // Layout contract (checked by the C ABI): every leading dimension is a multiple of 4 floats and
 // every base pointer 16-byte aligned, so that all staging loads are aligned f4 loads;

@@ -24,20 +24,7 @@ void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes
 void launch_maxpool2_fwd_idx(const float* in, int64_t planes, int H, int W, float* out, uint8_t* code, hipStream_t st);
 void launch_maxpool2_bwd_idx(const float* dpool, const uint8_t* code, int64_t planes, int H, int W, float* dz, hipStream_t st);
 
-// dconv.hip: compile-time-geometry direct convolutions for the heavy nav layers
-bool conv_has_direct(const ConvGeom& g);        // forward + data gradient
-bool conv_has_direct_wgrad(const ConvGeom& g);  // weight gradient
-bool conv_has_band_fwd(const ConvGeom& g);      // forward only (few input channels)
-void conv_direct_pack_sizes(const ConvGeom& g, int64_t out[2]);
-void launch_conv_direct_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st);
-void launch_conv_direct_fwd(const ConvGeom& g, const float* in, const float* wpf, const float* bias, int act, float* out,
-                            hipStream_t st);
-void launch_conv_direct_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* din, hipStream_t st);
-int conv_direct_wgrad_splits(const ConvGeom& g);  // 0 when there is no specialisation
-void launch_conv_direct_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db,
-                              hipStream_t st);
-
-// pconv.hip: the same forward / data-gradient layers on the 16-bit matrix pipe (two scaled fp16 planes per operand, per-sample input
+// pconv.hip: forward / data gradient / weight gradient of the heavy nav layers on the 16-bit matrix pipe (two scaled fp16 planes per operand, per-sample input
 // scales); `scales` = n floats of scratch
 bool conv_has_planes(const ConvGeom& g);
 int64_t conv_planes_pack_floats(const ConvGeom& g);  // floats of ONE region (forward or data gradient)

@@ -686,8 +686,6 @@ static PlanesId planes_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
   return kPNone;  // the three-plane build keeps the f32-input kernels of dconv.hip
 #else
-  static const bool off = [] { const char* e = getenv("DDRL_NAV_F32"); return e && e[0] == '1'; }();  // A/B switch: the f32-input kernels
-  if (off) return kPNone;
   if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w) return kPNone;
   const auto is = [&](int cin, int cout, int ks, int h) { return g.cin == cin && g.cout == cout && g.kh == ks && g.h == h; };
   if (g.pad_h == 0) return is(64, 64, 3, 9) ? kPAtC3 : kPNone;

@@ -387,12 +387,7 @@ static bool planes_off() {
 #ifdef DDRL_PLANES_BF16
   return true;
 #else
-  // A/B switches: DDRL_NAV_F32=1 puts every nav operator on its f32-input kernels, DDRL_LIN_F32=1 the dense layers only
-  static const bool off = [] {
-    const char *a = getenv("DDRL_NAV_F32"), *b = getenv("DDRL_LIN_F32");
-    return (a && a[0] == '1') || (b && b[0] == '1');
-  }();
-  return off;
+  return false;
 #endif
 }
 

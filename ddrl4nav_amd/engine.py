@@ -53,7 +53,10 @@ class HotPath:
         self.comm = None        # dist.RcclComm: the C-ABI all-reduce (ddrl_grad_allreduce) instead of torch.distributed
         import os
         import torch.distributed as tdist
-        if os.environ.get("DDRL_ALLREDUCE") == "rccl" and tdist.is_available() and tdist.is_initialized() \
+        # DDRL_ALLREDUCE = comma-separated options of the gradient all-reduce: "rccl" (the C-ABI communicator instead of
+        # torch.distributed), "overlap" (layer buckets on a second stream under the backward)
+        ar_opts = {o.strip() for o in os.environ.get("DDRL_ALLREDUCE", "").split(",") if o.strip()}
+        if "rccl" in ar_opts and tdist.is_available() and tdist.is_initialized() \
                 and tdist.get_world_size(process_group) > 1:
             from .dist import RcclComm
             world = tdist.get_world_size(process_group)
@@ -65,14 +68,14 @@ class HotPath:
                                          world, torch.cuda.device_count(), tdist.get_backend(process_group)))
             self.comm = RcclComm(tdist.get_rank(process_group), world, group=process_group)
         # layer-bucketed all-reduce that overlaps the backward: RCCL ranks only (gloo stages through the host).
-        # OFF by default (DDRL_ALLREDUCE_OVERLAP=1 turns it on): it has never run with two real RCCL ranks, and what it can hide is
+        # OFF by default (DDRL_ALLREDUCE=overlap, or "rccl,overlap", turns it on): it has never run with two real RCCL ranks, and what it can hide is
         # one 13.5 MB all-reduce per 24 ms iteration; the flat reduction on the compute stream is the default until a multi-GPU
         # run has shown bit-identity of the two.
         self._overlap = False
         self._comm_stream = self._comm_done = None
         self._buckets = []
         if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size(process_group) > 1 \
-                and os.environ.get("DDRL_ALLREDUCE_OVERLAP", "0") == "1" \
+                and "overlap" in ar_opts \
                 and (self.comm is not None or tdist.get_backend(process_group) == "nccl"):
             self.enable_overlap()
 

@@ -12,8 +12,6 @@ The Atari encoder does not go through this file: it has its own fused kernels (n
 import time
 from ctypes import byref, c_int64, c_void_p
 
-import os
-
 import torch
 from torch import nn
 
@@ -55,8 +53,8 @@ class _Dense:
 
     def _scale_buffers(self, cap, device):
         # per-row plane scales of the layer's input and of d(output), computed once per pass and shared by the operators that read the
-        # same tensor (forward + weight gradient; data + weight gradient); DDRL_SCALES_PER_OP=1: every operator runs its own pre-pass
-        share = self.op.uses_planes(cap) and os.environ.get("DDRL_SCALES_PER_OP") != "1"
+        # same tensor (forward + weight gradient; data + weight gradient)
+        share = self.op.uses_planes(cap)
         self.in_sc = torch.empty((cap,), dtype=torch.float32, device=device) if share else None
         self.dout_sc = torch.empty((cap,), dtype=torch.float32, device=device) if share else None
 
@@ -142,16 +140,14 @@ class _ConvPool:
         self.oh, self.ow = oh, ow
         f = dict(dtype=torch.float32, device=device)
         # layers whose kernels pool in their epilogue never write the full-resolution activations (ddrl_op_conv_forward_pool)
-        # (DDRL_POOL_UNFUSED=1: A/B switch, convolution and pool as two launches)
-        self.fused = bool(pool and relu and self.op.has_forward_pool() and os.environ.get("DDRL_POOL_UNFUSED") != "1")
+        self.fused = bool(pool and relu and self.op.has_forward_pool())
         self._a = None if self.fused else torch.empty((cap, module.out_channels, oh, ow), **f)   # relu(conv)
         # ... and their backward reads d(pooled) + the decision bytes (ddrl_op_conv_*_pooled): no full-resolution gradient either
-        # (DDRL_POOL_BWD_UNFUSED=1: A/B switch, the pool's backward as its own launch)
-        self.fused_bwd = self.fused and os.environ.get("DDRL_POOL_BWD_UNFUSED") != "1"
+        self.fused_bwd = self.fused
         # per-sample plane scales of the layer's input and of d(pooled), computed once per pass and shared by the operators that read
         # the same tensor (forward + weight gradient; data + weight gradient)
         self.in_sc = self.dp_sc = None
-        if self.fused and self.op.pooled_uses_scales() and os.environ.get("DDRL_SCALES_PER_OP") != "1":
+        if self.fused and self.op.pooled_uses_scales():
             self.in_sc = torch.empty((cap,), **f)
             self.dp_sc = torch.empty((cap,), **f)
         self.dz = None if self.fused_bwd else torch.empty((cap, module.out_channels, oh, ow), **f)   # d(loss)/d(pre-activation)
@@ -495,6 +491,7 @@ class GenericPPO(Basenn):
         self._build_heads()
         self._dirty = True
         self._step = 0
+        self.encoder_streams = True     # actor and critic encoders on two HIP streams (_side)
 
     # ---- flat arenas (reference named_parameters() order) ------------------------------------------
     def _bind_arena(self):
@@ -580,8 +577,8 @@ class GenericPPO(Basenn):
     def _side(self):
         """The second encoder's stream: actor and critic encoders are independent networks with their own buffers and their own slices
         of the gradient arena, so the critic's runs beside the actor's (its small, latency-bound launches -- dense layers, the laser
-        branch, slab reductions -- fill what the other's leave idle).  DDRL_ENC_STREAMS=0: one stream (A/B switch)."""
-        if self.share_cnn_net or os.environ.get("DDRL_ENC_STREAMS") == "0":
+        branch, slab reductions -- fill what the other's leave idle).  `net.encoder_streams = False`: one stream (per-operator timing)."""
+        if self.share_cnn_net or not self.encoder_streams:
             return None
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.device)

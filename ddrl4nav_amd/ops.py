@@ -33,13 +33,17 @@ class Conv:
         self.stride, self.pad = stride, tuple(pad)
         self.device = torch.device(device)
         d = self.desc(max_n)
-        oh, ow, pf, wf = c_int32(), c_int32(), c_int64(), c_int64()
+        oh, ow, pf, wf, sf = c_int32(), c_int32(), c_int64(), c_int64(), c_int64()
         check(self.lib.ddrl_op_conv_out_shape(byref(d), byref(oh), byref(ow)))
         check(self.lib.ddrl_op_conv_pack_floats(byref(d), byref(pf)))
         check(self.lib.ddrl_op_conv_ws_floats(byref(d), byref(wf)))
+        check(self.lib.ddrl_op_conv_scratch_floats(byref(d), byref(sf)))
         self.oh, self.ow, self.max_n = oh.value, ow.value, max_n
-        self.packed = torch.zeros(pf.value, dtype=torch.float32, device=self.device)
+        self.packed = torch.zeros(pf.value, dtype=torch.float32, device=self.device)   # read-only after pack()
         self.ws = torch.empty(wf.value, dtype=torch.float32, device=self.device)
+        # per-sample plane scales of a launch that is not handed its scales (fp16-plane layers; max_n floats): one launch per layer
+        # object at a time, like `ws`
+        self.scratch = torch.empty(sf.value, dtype=torch.float32, device=self.device) if sf.value else None
 
     def desc(self, n, in_sn=0, out_sn=0):
         return ConvDesc(n, self.cin, self.h, self.w, self.cout, self.kh, self.kw, self.stride, self.pad[0], self.pad[1],
@@ -50,10 +54,11 @@ class Conv:
 
     def forward(self, x, bias, relu, out=None, n=None):
         n = x.shape[0] if n is None else n
+        assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         if out is None:
             out = torch.empty((n, self.cout, self.oh, self.ow), dtype=torch.float32, device=x.device)
         check(self.lib.ddrl_op_conv_forward(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)),
-                                            1 if relu else 0, _p(out), _st()))
+                                            1 if relu else 0, _p(out), _p(self.scratch), _st()))
         return out
 
     def has_forward_pool(self):
@@ -67,29 +72,33 @@ class Conv:
     def forward_pool(self, x, bias, pooled, code, n=None, in_scales=None):
         """max_pool2d(relu(conv(x)), 2) in one launch: pooled [n][cout][oh/2][ow/2] + one decision byte per window."""
         n = x.shape[0] if n is None else n
+        assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         check(self.lib.ddrl_op_conv_forward_pool(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)), _p(pooled),
-                                                 _p(code), _p(in_scales), _st()))
+                                                 _p(code), _p(in_scales), _p(self.scratch), _st()))
         return pooled
 
     def dgrad_pooled(self, dpool, code, din=None, n=None, dpool_scales=None):
         """Data gradient of a forward_pool layer from d(pooled) + decision bytes (no full-resolution gradient in between)."""
         n = dpool.shape[0] if n is None else n
+        assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         if din is None:
             din = torch.empty((n, self.cin, self.h, self.w), dtype=torch.float32, device=dpool.device)
         check(self.lib.ddrl_op_conv_dgrad_pooled(byref(self.desc(n)), _p(_f32(dpool)), _p(code), _p(self.packed), _p(din),
-                                                 _p(dpool_scales), _st()))
+                                                 _p(dpool_scales), _p(self.scratch), _st()))
         return din
 
     def wgrad_pooled(self, x, dpool, code, dw, db, n=None, in_scales=None, dpool_scales=None):
         n = x.shape[0] if n is None else n
+        assert n <= self.max_n, "batch larger than the split-K scratch was sized for"
         check(self.lib.ddrl_op_conv_wgrad_pooled(byref(self.desc(n)), _p(_f32(x)), _p(_f32(dpool)), _p(code), _p(self.packed),
                                                  _p(self.ws), _p(dw), _p(db), _p(in_scales), _p(dpool_scales), _st()))
 
     def dgrad(self, dz, din=None, n=None):
         n = dz.shape[0] if n is None else n
+        assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         if din is None:
             din = torch.empty((n, self.cin, self.h, self.w), dtype=torch.float32, device=dz.device)
-        check(self.lib.ddrl_op_conv_dgrad(byref(self.desc(n)), _p(_f32(dz)), _p(self.packed), _p(din), _st()))
+        check(self.lib.ddrl_op_conv_dgrad(byref(self.desc(n)), _p(_f32(dz)), _p(self.packed), _p(din), _p(self.scratch), _st()))
         return din
 
     def wgrad(self, x, dz, dw, db, n=None):

@@ -48,7 +48,7 @@ extern "C" {
 
 /* 2 (round 4): ddrl_op_clip_rmsprop takes alpha as a double; ddrl_encoder_backward consumes dh (rescales its rows in place);
  * ddrl_debug_buffer 4..7 hold per-sample NORMALISED gradients.  A host built against version 1 must be rebuilt. */
-#define DDRL_ABI_VERSION 2
+#define DDRL_ABI_VERSION 3
 #define DDRL_STATS_FLOATS 8 /* tail of the grad arena, see ddrl_ppo_iter */
 
 typedef struct ddrl_ctx ddrl_ctx;
@@ -299,17 +299,20 @@ typedef struct ddrl_conv_desc {
 } ddrl_conv_desc;
 
 int32_t ddrl_op_conv_out_shape(const ddrl_conv_desc* d, int32_t* oh, int32_t* ow);
-/* Derived weight layouts + index tables of one layer (rebuilt whenever the weights change).  `packed` is sized for d->n = the
- * LARGEST batch any later call passes (ddrl_op_conv_pack_floats with that n): besides the layouts it holds scratch of the layer's
- * latest launch -- the heavy nav layers (64->128 5x5 @22, 128->256 3x3 @10, 64->128 3x3 @24, 128->256 3x3 @12) run as fp16 plane
- * products on the 16-bit matrix pipe (csrc/pconv.hip) and leave the per-sample plane scales of their input there, so
- * ddrl_op_conv_forward / _dgrad WRITE into `packed` although they take it as const: one launch per layer object at a time.
- * Those layers need 16-byte aligned tensors and sample strides that are multiples of 4 floats (DDRL_ERR_INVALID_ARG otherwise). */
+/* Derived weight layouts + index tables of one layer (rebuilt whenever the weights change; the size does not depend on d->n).
+ * `packed` is READ-ONLY for every later call (ABI 3; ABI 2 kept per-launch scratch inside it).  The heavy nav layers (64->128 5x5 @22,
+ * 128->256 3x3 @10, 64->128 3x3 @24, 128->256 3x3 @12) run as fp16 plane products on the 16-bit matrix pipe (csrc/pconv.hip) and need
+ * one float of scratch per sample for the per-sample plane scales of a launch that is not handed its scales: `scales_scratch` of
+ * ddrl_op_conv_forward / _dgrad / _forward_pool / _dgrad_pooled, ddrl_op_conv_scratch_floats(d) floats for a launch of d->n samples
+ * (0 for layers that need none: NULL is accepted then, and whenever in_scales / dpool_scales are given).  One launch per scratch buffer
+ * at a time.  The plane kernels need 16-byte aligned tensors and sample strides that are multiples of 4 floats; other views of the same
+ * layers run on the generic gather kernels (csrc/gconv.hip, f32-input MFMA) like every geometry without a specialised kernel. */
 int32_t ddrl_op_conv_pack_floats(const ddrl_conv_desc* d, int64_t* floats);
 int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed, void* stream);
+int32_t ddrl_op_conv_scratch_floats(const ddrl_conv_desc* d, int64_t* floats);
 /* out = act(conv2d(in, w) + bias); act: 0 none, 1 ReLU        (torch.nn.Conv2d / Conv1d + F.relu) */
 int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias,
-                             int32_t act, float* out, void* stream);
+                             int32_t act, float* out, float* scales_scratch, void* stream);
 /* din = d(loss)/d(in) given dz = d(loss)/d(pre-activation output) */
 /* Conv2d + ReLU + max_pool2d(2) in ONE launch (round 4), for the layers whose kernels pool in their epilogue -- NavPreNet1D's three
  * (3->64 7x7 @48, 64->128 5x5 @22, 128->256 3x3 @10): pooled [n][cout][oh/2][ow/2] (dense) and one decision byte per window as
@@ -317,7 +320,7 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
  * full-resolution activations are never written.  DDRL_ERR_UNSUPPORTED for every other layer: run ddrl_op_conv_forward and
  * ddrl_op_maxpool2_forward_idx instead.  `in` 16-byte aligned, sample stride a multiple of 4 floats. */
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
-                                  uint8_t* code, const float* in_scales, void* stream);
+                                  uint8_t* code, const float* in_scales, float* scales_scratch, void* stream);
 /* The fp16-plane kernels scale every sample by a power of two taken from its largest magnitude, found in a pre-pass over the tensor.
  * A caller that runs several operators on the SAME tensor (the forward and the weight gradient both read the layer's input; the data
  * and the weight gradient both read d(pooled)) computes the scales once with ddrl_op_plane_scales(x [n] samples of `elems` floats at
@@ -332,10 +335,10 @@ int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d);  /* 1 when ddrl_
  * what ddrl_op_maxpool2_backward_idx would write), so the full-resolution gradient is neither written nor read.  Same layers as
  * ddrl_op_conv_forward_pool (the 3-channel first layer has no data gradient: DDRL_ERR_UNSUPPORTED); dpool 16-byte aligned, dense. */
 int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
-                                  const float* dpool_scales, void* stream);
+                                  const float* dpool_scales, float* scales_scratch, void* stream);
 int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
                                   float* ws, float* dw, float* db, const float* in_scales, const float* dpool_scales, void* stream);
-int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, void* stream);
+int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, float* scales_scratch, void* stream);
 /* dw [cout][cin][kh][kw], db [cout] (overwritten); `ws` = split-K scratch of ddrl_op_conv_ws_floats.
  * Requires oh*ow >= 32. */
 int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats);

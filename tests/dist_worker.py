@@ -72,7 +72,7 @@ def bucket_ranks(outdir, bounds):
     args = (d(frames), d(actions), d(old_logps), d(advs), d(rets))
     h = HotPath(max_batch=64)
     h.set_params(flatten(make_weights(0)))
-    assert not h._overlap          # off by default (DDRL_ALLREDUCE_OVERLAP unset)
+    assert not h._overlap          # off by default (DDRL_ALLREDUCE has no "overlap" option)
     h.ppo_iter(*args, b_global=64)
     local = h.grads.clone()
     flat = allreduce_flat(local.clone())

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_load_and_host_only_calls():
     lib = _lib.load()
-    assert lib.ddrl_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.ddrl_abi_version() == _lib.ABI_VERSION == 3
     assert lib.ddrl_status_string(-3) == b"workspace too small"
     cfg = _lib.default_config(max_batch=64)
     assert (cfg.n_actions, cfg.in_channels) == (6, 4)

@@ -316,9 +316,9 @@ def test_nav_config4_batch_properties():
         assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
 
 
-def test_nav_two_encoder_streams_and_switches_are_bit_identical(monkeypatch):
-    """The robot_nav learner with the critic's encoder on its own stream equals the one-stream run bit for bit (independent buffers
-    and gradient slices, no atomics between them); so do shared per-sample scales against per-operator pre-passes."""
+def test_nav_two_encoder_streams_are_bit_identical():
+    """The robot_nav learner with the critic's encoder on its own stream equals the one-stream run (`net.encoder_streams = False`)
+    bit for bit: independent buffers and gradient slices, no atomics between them."""
     from ddrl4nav_amd.data import Experience
     B = 384
     g = torch.Generator(device="cuda").manual_seed(77)
@@ -327,19 +327,16 @@ def test_nav_two_encoder_streams_and_switches_are_bit_identical(monkeypatch):
     exp = Experience(states=states, advs=torch.randn(B, device="cuda", generator=g), actions=torch.randn((B, 2), device="cuda", generator=g),
                      old_logps=torch.full((B,), -2.0, device="cuda"), values=torch.randn((1, B), device="cuda", generator=g))
     outs = []
-    for env in ({}, {"DDRL_ENC_STREAMS": "0"}, {"DDRL_SCALES_PER_OP": "1"}):
-        for k in ("DDRL_ENC_STREAMS", "DDRL_SCALES_PER_OP"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for two in (True, False):
         net, _ = _make("f13_nav1d_gauss", max_batch=256)       # two micro-batches: the streams join before the accumulation
+        net.encoder_streams = two
         net.training_iter_time = 3
         losses = [l for l, _, _ in net.learn(exp)]
+        assert (net._side() is not None) == two
         outs.append((net.params.clone(), losses))
-    for other in outs[1:]:
-        assert torch.equal(outs[0][0], other[0])
-        for la, lb in zip(outs[0][1], other[1]):
-            assert all(la[k] == lb[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss"))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for la, lb in zip(outs[0][1], outs[1][1]):
+        assert all(la[k] == lb[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss"))
 
 
 def test_nav_config4_at_size_512_envs_x_256_steps():

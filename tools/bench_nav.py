@@ -54,20 +54,20 @@ def lin_flop(l, *a, **k):
 
 
 
-def run(B=4096, CAP=1024, ITERS=3, T_loop=None, encoder="nav1d", loop_iters=None):
+def run(B=4096, CAP=1024, ITERS=3, T_loop=None, encoder="nav1d", loop_iters=None, encoder_streams=True):
     """One measurement; returns the record as a dict (bench.py's `nav` sub-record calls this).  The per-operator timing wraps
     ops.Conv / ops.Linear for the duration of the call only."""
     saved = {(cls, k): getattr(cls, k) for cls in (ops.Conv, ops.Linear) for k in ("forward", "dgrad", "wgrad")}
     saved.update({(ops.Conv, k): getattr(ops.Conv, k) for k in ("forward_pool", "dgrad_pooled", "wgrad_pooled")})
     events.clear()
     try:
-        return _run(B, CAP, ITERS, T_loop, encoder, loop_iters)
+        return _run(B, CAP, ITERS, T_loop, encoder, loop_iters, encoder_streams)
     finally:
         for (cls, k), fn in saved.items():
             setattr(cls, k, fn)
 
 
-def _run(B, CAP, ITERS, T_loop, encoder, loop_iters=None):
+def _run(B, CAP, ITERS, T_loop, encoder, loop_iters=None, encoder_streams=True):
     ops.Conv.forward = timed(conv_name("fwd"), conv_flop, ops.Conv.forward)
     ops.Conv.dgrad = timed(conv_name("dgrad"), conv_flop, ops.Conv.dgrad)
     ops.Conv.wgrad = timed(conv_name("wgrad"), conv_flop, ops.Conv.wgrad)
@@ -88,6 +88,7 @@ def _run(B, CAP, ITERS, T_loop, encoder, loop_iters=None):
     # encoder = "navped": ONE shared NavPedPreNet(4) (runner/utils.py:98-102, SHARE_CNN_NET; the encoder of the GAIL nav configuration)
     cfg_nn.SHARE_CNN_NET = encoder == "navped"
     net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=CAP)
+    net.encoder_streams = bool(encoder_streams)   # False: one stream, so that the per-operator events do not overlap
     g = torch.Generator(device="cuda")
     g.manual_seed(4)
     if encoder == "navped":
