@@ -103,15 +103,15 @@ SIGNATURES = {
     "ddrl_op_conv_out_shape": (c_int32, [POINTER(ConvDesc), POINTER(c_int32), POINTER(c_int32)]),
     "ddrl_op_conv_pack_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
     "ddrl_op_conv_pack": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
-    "ddrl_op_conv_forward": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_forward": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_scratch_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
-    "ddrl_op_conv_dgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_dgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_wgrad_pooled": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
-    "ddrl_op_plane_scales": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_sample_amax": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ddrl_op_conv_pooled_uses_scales": (c_int32, [POINTER(ConvDesc)]),
     "ddrl_op_conv_has_forward_pool": (c_int32, [POINTER(ConvDesc)]),
-    "ddrl_op_conv_forward_pool": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddrl_op_conv_forward_pool": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_dgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_conv_ws_floats": (c_int32, [POINTER(ConvDesc), POINTER(c_int64)]),
     "ddrl_op_conv_wgrad": (c_int32, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -122,11 +122,11 @@ SIGNATURES = {
     "ddrl_op_linear_pack_floats": (c_int32, [c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]),
     "ddrl_op_linear_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_linear_uses_planes": (c_int32, [c_int32, c_int32, c_int32]),
-    "ddrl_op_row_scales": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ddrl_op_row_amax": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "ddrl_op_linear_forward": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32,
                                          c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "ddrl_op_linear_dgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
-                                       c_int32, c_void_p, c_void_p, c_void_p]),
+                                       c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "ddrl_op_linear_ws_floats": (c_int32, [c_int32, c_int32, c_int32, POINTER(c_int64)]),
     "ddrl_op_linear_wgrad": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_int32, c_void_p, c_void_p, c_void_p]),

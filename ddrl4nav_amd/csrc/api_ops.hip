@@ -104,13 +104,18 @@ int32_t ddrl_op_conv_ws_floats(const ddrl_conv_desc* d, int64_t* floats) {
 }
 
 int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, int32_t act,
-                             float* out, float* scales_scratch, void* stream) {
+                             float* out, float* scales_scratch, float* out_amax, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
   if (conv_has_planes(g) && direct_ok(g, in, out) && !scales_scratch) return DDRL_ERR_INVALID_ARG;  // g.n floats (ddrl_op_conv_scratch_floats)
+  if (out_amax && !conv_has_c1d(g)) {
+    // every other kernel family: the magnitudes come from a pass over the output just written (needs 16-byte loads of whole samples)
+    const int64_t elems = (int64_t)g.cout * g.oh * g.ow;
+    if ((elems & 3) || (g.out_sn & 3) || !aligned16(out)) return DDRL_ERR_INVALID_ARG;
+  }
   if (conv_has_c1d(g))
-    launch_conv_c1d_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
+    launch_conv_c1d_fwd(g, in, packed + v.off[5], bias, act, out, out_amax, (hipStream_t)stream);
   else if (conv_has_first(g) && direct_ok(g, in, out))
     launch_conv_first_fwd(g, in, packed + v.off[5], bias, act, out, (hipStream_t)stream);
   else if (conv_has_first(g))
@@ -119,6 +124,7 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
     launch_conv_planes_fwd(g, in, packed + v.off[5], scales_scratch, bias, act, out, (hipStream_t)stream);
   else   // any geometry, any stride / alignment (also the plane layers' when a strided view rules out their 16-byte loads)
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
+  if (out_amax && !conv_has_c1d(g)) launch_sample_amax(out, g.out_sn, g.cout * g.oh * g.ow, g.n, out_amax, (hipStream_t)stream);
   return op_check();
 }
 
@@ -128,9 +134,9 @@ int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d) {
   return (conv_has_first(g) || (conv_has_planes(g) && conv_planes_has_pool(g))) ? 1 : 0;
 }
 
-int32_t ddrl_op_plane_scales(const float* x, int64_t sn, int32_t elems, int32_t n, float* scales, void* stream) {
-  if (!x || !scales || n < 1 || elems < 4 || (elems & 3) || (sn & 3) || sn < elems || !aligned16(x)) return DDRL_ERR_INVALID_ARG;
-  launch_plane_scales(x, sn, elems, n, scales, (hipStream_t)stream);
+int32_t ddrl_op_sample_amax(const float* x, int64_t sn, int32_t elems, int32_t n, float* amax, void* stream) {
+  if (!x || !amax || n < 1 || elems < 4 || (elems & 3) || (sn & 3) || sn < elems || !aligned16(x)) return DDRL_ERR_INVALID_ARG;
+  launch_sample_amax(x, sn, elems, n, amax, (hipStream_t)stream);
   return op_check();
 }
 
@@ -141,41 +147,41 @@ int32_t ddrl_op_conv_pooled_uses_scales(const ddrl_conv_desc* d) {
 }
 
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
-                                  uint8_t* code, const float* in_scales, float* scales_scratch, void* stream) {
+                                  uint8_t* code, const float* in_amax, float* scales_scratch, float* out_amax, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !packed || !bias || !pooled || !code) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(in)) return DDRL_ERR_INVALID_ARG;
-  if (!conv_has_first(g) && conv_has_planes(g) && !in_scales && !scales_scratch) return DDRL_ERR_INVALID_ARG;
+  if (!conv_has_first(g) && conv_has_planes(g) && !in_amax && !scales_scratch) return DDRL_ERR_INVALID_ARG;
   const PackView v = pack_view(g);
   if (conv_has_first(g))
-    launch_conv_first_fwd_pool(g, in, packed + v.off[5], bias, pooled, code, (hipStream_t)stream);
+    launch_conv_first_fwd_pool(g, in, packed + v.off[5], bias, pooled, code, out_amax, (hipStream_t)stream);
   else if (conv_has_planes(g) && conv_planes_has_pool(g))
-    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], scales_scratch, in_scales, bias, pooled, code, (hipStream_t)stream);
+    launch_conv_planes_fwd_pool(g, in, packed + v.off[5], scales_scratch, in_amax, bias, pooled, code, out_amax, (hipStream_t)stream);
   else
     return DDRL_ERR_UNSUPPORTED;  // the caller runs ddrl_op_conv_forward + ddrl_op_maxpool2_forward_idx
   return op_check();
 }
 
 int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
-                                  const float* dpool_scales, float* scales_scratch, void* stream) {
+                                  const float* dpool_amax, float* scales_scratch, float* din_amax, void* stream) {
   ConvGeom g;
-  if (!fill_geom(d, g) || !dpool || !code || !packed || !din || (!dpool_scales && !scales_scratch)) return DDRL_ERR_INVALID_ARG;
+  if (!fill_geom(d, g) || !dpool || !code || !packed || !din || (!dpool_amax && !scales_scratch)) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(din) || !aligned16(dpool)) return DDRL_ERR_INVALID_ARG;
   if (!(conv_has_planes(g) && conv_planes_has_pool(g))) return DDRL_ERR_UNSUPPORTED;
   const PackView v = pack_view(g);
-  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], scales_scratch, dpool_scales, din, (hipStream_t)stream);
+  launch_conv_planes_dgrad_pooled(g, dpool, code, packed + v.off[6], scales_scratch, dpool_amax, din, din_amax, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
-                                  float* ws, float* dw, float* db, const float* in_scales, const float* dpool_scales, void* stream) {
+                                  float* ws, float* dw, float* db, const float* in_amax, const float* dpool_amax, void* stream) {
   ConvGeom g;
   if (!fill_geom(d, g) || !in || !dpool || !code || !packed || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if ((g.in_sn & 3) || !aligned16(in) || !aligned16(dpool) || ((uintptr_t)code & 1)) return DDRL_ERR_INVALID_ARG;
   if (conv_has_first(g))
     launch_conv_first_wgrad_pooled(g, in, dpool, code, ws, dw, db, (hipStream_t)stream);
   else if (conv_has_planes(g) && conv_planes_has_pool(g))
-    launch_conv_planes_wgrad_pooled(g, in, dpool, code, in_scales, dpool_scales, ws, dw, db, (hipStream_t)stream);
+    launch_conv_planes_wgrad_pooled(g, in, dpool, code, in_amax, dpool_amax, ws, dw, db, (hipStream_t)stream);
   else
     return DDRL_ERR_UNSUPPORTED;
   return op_check();
@@ -261,26 +267,30 @@ int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, flo
 
 int32_t ddrl_op_linear_uses_planes(int32_t n, int32_t K, int32_t N) { return lin_ok(n, K, N) && linear_uses_planes(n, K, N) ? 1 : 0; }
 
-int32_t ddrl_op_row_scales(const float* x, int64_t ld, int32_t width, int32_t n, float* scales, void* stream) {
-  if (!x || !scales || n < 1 || width < 1 || (ld & 3) || ld < (width + 3) / 4 * 4 || !aligned16(x)) return DDRL_ERR_INVALID_ARG;
-  launch_row_scales(x, ld, width, n, scales, (hipStream_t)stream);
+int32_t ddrl_op_row_amax(const float* x, int64_t ld, int32_t width, int32_t n, float* amax, int32_t accumulate, void* stream) {
+  if (!x || !amax || n < 1 || width < 1 || (ld & 3) || ld < (width + 3) / 4 * 4 || !aligned16(x)) return DDRL_ERR_INVALID_ARG;
+  launch_row_amax(x, ld, width, n, amax, accumulate ? 1 : 0, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act, float* out,
-                               int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, const float* in_scales, void* stream) {
+                               int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, const float* in_amax, void* stream) {
   if (!lin_ok(n, K, N) || !in || !wt || !bias || !out || act < 0 || act > 1) return DDRL_ERR_INVALID_ARG;
   if ((ld_in & 3) || ld_in < (K + 3) / 4 * 4 || ld_out < N || !aligned16(in) || !aligned16(wt)) return DDRL_ERR_INVALID_ARG;
-  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, ws, in_scales, (hipStream_t)stream);
+  launch_linear_fwd(in, ld_in, wt, bias, out, ld_out, n, K, N, act, ws, in_amax, (hipStream_t)stream);
   return op_check();
 }
 
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, const float* dout_scales,
-                             void* stream) {
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, const float* dout_amax,
+                             float* din_amax, int32_t amax_lo, int32_t amax_hi, void* stream) {
   if (!lin_ok(n, K, N) || !dout || !wn || !din) return DDRL_ERR_INVALID_ARG;
   if ((ld_dout & 3) || ld_dout < N || ld_din < K || !aligned16(dout) || !aligned16(wn)) return DDRL_ERR_INVALID_ARG;
-  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, ws, dout_scales, (hipStream_t)stream);
+  if (din_amax) {
+    if (amax_hi <= 0) amax_hi = K;   // default: every column
+    if (amax_lo < 0 || amax_lo >= amax_hi || amax_hi > K || (amax_lo & 3) || (ld_din & 3) || !aligned16(din)) return DDRL_ERR_INVALID_ARG;
+  }
+  launch_linear_dgrad(dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, ws, dout_amax, din_amax, amax_lo, amax_hi, (hipStream_t)stream);
   return op_check();
 }
 
@@ -306,11 +316,11 @@ int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* float
 }
 
 int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
-                             float* db, int32_t n, int32_t K, int32_t N, const float* in_scales, const float* dout_scales, void* stream) {
+                             float* db, int32_t n, int32_t K, int32_t N, const float* in_amax, const float* dout_amax, void* stream) {
   if (!lin_ok(n, K, N) || !in || !dout || !ws || !dw || !db) return DDRL_ERR_INVALID_ARG;
   if ((ld_in & 3) || (ld_dout & 3) || ld_in < (K + 3) / 4 * 4 || ld_dout < N || !aligned16(in) || !aligned16(dout))
     return DDRL_ERR_INVALID_ARG;
-  launch_linear_wgrad(in, ld_in, dout, ld_dout, ws, n, K, N, dw, db, in_scales, dout_scales, (hipStream_t)stream);
+  launch_linear_wgrad(in, ld_in, dout, ld_dout, ws, n, K, N, dw, db, in_amax, dout_amax, (hipStream_t)stream);
   return op_check();
 }
 

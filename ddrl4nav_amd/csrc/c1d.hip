@@ -12,6 +12,7 @@
 // the lanes once per wave and leaves slabs (fixed order: deterministic).  fp32 throughout, one fused multiply-add per term.
 #include <cstdlib>
 
+#include "engine2.h"
 #include "kernels.h"
 #include "ops.h"
 
@@ -32,9 +33,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 // out[b][oc][x] = act(bias[oc] + sum_{c, k} w[oc][c][k] in[b][c][S x + k]);  grid (ceil(OW / 256), n)
 template <int CIN, int COUT, int KW, int S>
 __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ in, int64_t in_sn, const float* __restrict__ wt,
-                                                  const float* __restrict__ bias, int act, float* __restrict__ out, int64_t out_sn, int W, int OW) {
-  const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (x >= OW) return;
+                                                  const float* __restrict__ bias, int act, float* __restrict__ out, int64_t out_sn, int W, int OW,
+                                                  float* __restrict__ out_amax) {
+  const int x0 = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const bool ok = x0 < OW;
+  const int x = ok ? x0 : OW - 1;   // lanes past the row compute a duplicate and store nothing (every lane reaches the wave reduction)
   const float* src = in + (int64_t)b * in_sn + S * x;
   float acc[COUT];
 #pragma unroll
@@ -50,10 +53,18 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ in, 
       for (int oc = 0; oc < COUT; ++oc) acc[oc] = __builtin_fmaf(wt[(c * KW + k) * COUT + oc], a[k], acc[oc]);
   }
   float* dst = out + (int64_t)b * out_sn + x;
+  float lm = 0.0f;
 #pragma unroll
   for (int oc = 0; oc < COUT; ++oc) {
-    const float v = acc[oc] + bias[oc];
-    dst[(int64_t)oc * OW] = act == 1 ? fmaxf(v, 0.0f) : v;
+    float v = acc[oc] + bias[oc];
+    if (act == 1) v = fmaxf(v, 0.0f);
+    if (ok) dst[(int64_t)oc * OW] = v;
+    lm = fmaxf(lm, fabsf(v));
+  }
+  if (out_amax != nullptr) {   // the sample's largest |output| for the dense layer that reads the flattened rows (engine2.h amax_raise)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lm = fmaxf(lm, __shfl_xor(lm, off, 64));
+    if ((threadIdx.x & 63) == 0) amax_raise(lm, out_amax + b);
   }
 }
 
@@ -188,12 +199,12 @@ void launch_conv_c1d_pack(const ConvGeom& g, const float* w, float* wt, float* w
   hipLaunchKernelGGL(c1d::pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, g.cin, g.cout, g.kw, wt, wd);
 }
 
-void launch_conv_c1d_fwd(const ConvGeom& g, const float* in, const float* wt, const float* bias, int act, float* out, hipStream_t st) {
+void launch_conv_c1d_fwd(const ConvGeom& g, const float* in, const float* wt, const float* bias, int act, float* out, float* out_amax, hipStream_t st) {
   const dim3 grid((g.ow + 255) / 256, g.n);
   if (c1d_id(g) == kC1First)
-    hipLaunchKernelGGL((c1d::fwd_kernel<1, 32, 5, 2>), grid, dim3(256), 0, st, in, g.in_sn, wt, bias, act, out, g.out_sn, g.w, g.ow);
+    hipLaunchKernelGGL((c1d::fwd_kernel<1, 32, 5, 2>), grid, dim3(256), 0, st, in, g.in_sn, wt, bias, act, out, g.out_sn, g.w, g.ow, out_amax);
   else
-    hipLaunchKernelGGL((c1d::fwd_kernel<32, 32, 3, 2>), grid, dim3(256), 0, st, in, g.in_sn, wt, bias, act, out, g.out_sn, g.w, g.ow);
+    hipLaunchKernelGGL((c1d::fwd_kernel<32, 32, 3, 2>), grid, dim3(256), 0, st, in, g.in_sn, wt, bias, act, out, g.out_sn, g.w, g.ow, out_amax);
 }
 
 void launch_conv_c1d_dgrad(const ConvGeom& g, const float* dz, const float* wd, float* din, hipStream_t st) {

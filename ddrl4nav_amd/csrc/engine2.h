@@ -584,4 +584,17 @@ __device__ __forceinline__ void amax_update(float m, float* slot) {
   }
 }
 
+// ---- per-sample plane scales of the operator kernels (pconv.hip, plin.hip) ----------------------------------------------------
+// What travels between operators is a sample's LARGEST MAGNITUDE (any upper bound works): a producer's epilogue raises it with
+// amax_raise (non-negative floats order like unsigned integers: a maximum is deterministic whatever the order of the atomics), the
+// consumer turns it into the power-of-two scale of the sample's fp16 planes.  An all-zero sample (the gradient of a sample whose advantage
+// is exactly 0) gets the largest scale there is -- it must not pin the batch scale of a weight gradient --; 2^60 also bounds the
+// products of two scales.
+__device__ __forceinline__ float scale_of_amax(float m) { return m > 0.0f ? fminf(plane_scale(m), 0x1p60f) : 0x1p60f; }
+__device__ __forceinline__ void amax_raise(float m, float* slot) {  // one lane; m >= 0; the slot never decreases
+  const unsigned bits = __float_as_uint(m);
+  if (bits > __hip_atomic_load((unsigned*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)slot, bits);
+}
+__device__ __forceinline__ void lds_amax_raise(float m, float* lds_slot) { atomicMax((unsigned*)lds_slot, __float_as_uint(m)); }
+
 }  // namespace ddrl

@@ -38,7 +38,7 @@ int64_t conv_first_pack_floats(const ConvGeom&) { return 0; }
 int conv_first_wgrad_splits(const ConvGeom&) { return 0; }
 void launch_conv_first_pack(const ConvGeom&, const float*, float*, hipStream_t) {}
 void launch_conv_first_fwd(const ConvGeom&, const float*, const float*, const float*, int, float*, hipStream_t) {}
-void launch_conv_first_fwd_pool(const ConvGeom&, const float*, const float*, const float*, float*, uint8_t*, hipStream_t) {}
+void launch_conv_first_fwd_pool(const ConvGeom&, const float*, const float*, const float*, float*, uint8_t*, float*, hipStream_t) {}
 void launch_conv_first_wgrad(const ConvGeom&, const float*, const float*, float*, float*, float*, hipStream_t) {}
 void launch_conv_first_wgrad_pooled(const ConvGeom&, const float*, const float*, const uint8_t*, float*, float*, float*, hipStream_t) {}
 }  // namespace ddrl
@@ -66,7 +66,7 @@ struct FGeo {
   static constexpr int LPX_F = OH + 8;                       // columns a fragment may touch: ox + 7 + 1
   static constexpr int IMG_F_PLANE = LPY * LPX_F * 8, IMG_F = NPL * IMG_F_PLANE;
   static constexpr int F_IMG_OFF = W_BYTES, F_BIAS_OFF = F_IMG_OFF + 2 * IMG_F, F_RED_OFF = F_BIAS_OFF + 64 * 4;
-  static constexpr int F_LDS = F_RED_OFF + 64;
+  static constexpr int F_OMAX_OFF = F_RED_OFF + 64, F_LDS = F_OMAX_OFF + 32;   // + the eight waves' largest pooled value of a sample
   static constexpr int F_UNITS = HIN * (HIN / 4), F_NJ = (F_UNITS + 511) / 512;   // (row, 4 pixels) staging units
   // ---- weight gradient
   static constexpr int BR = 4, NBANDS = OH / BR, RUNS = (OH + 15) / 16, PXR = RUNS * 16, BRPX = BR * PXR;
@@ -145,11 +145,13 @@ __device__ __forceinline__ void commit_quad(char* img, int plane_bytes, const f4
 template <class K, bool POOL>
 __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
                                                         const float* __restrict__ whdr, const float* __restrict__ bias, int act,
-                                                        float* __restrict__ out, int64_t out_sn, uint8_t* __restrict__ code, int n) {
+                                                        float* __restrict__ out, int64_t out_sn, uint8_t* __restrict__ code,
+                                                        float* __restrict__ out_amax, int n) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_u(), l31 = lane & 31, hi = lane >> 5;
   float* lbias = (float*)(lds + K::F_BIAS_OFF);
   float* red = (float*)(lds + K::F_RED_OFF);  // [2][8]
+  float* omax = (float*)(lds + K::F_OMAX_OFF);  // [8]: POOL with out_amax -- the sample's largest pooled value (= largest magnitude: >= 0)
   for (int i = tid; i < 2 * K::IMG_F / 16; i += 512) *(f4*)(lds + K::F_IMG_OFF + i * 16) = zero4();  // borders and the fourth channel stay zero
   for (int i = tid; i < K::W_BYTES / 16; i += 512) *(f4*)(lds + i * 16) = *(const f4*)((const char*)wp + i * 16);
   if (tid < 64) lbias[tid] = bias[tid];
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict_
     const char* img = lds + K::F_IMG_OFF + (it & 1) * K::IMG_F;
     const float inv = winv / sc_cur;
     float* obase = out + (int64_t)b * out_sn;
+    float omx = 0.0f;
 #pragma unroll 1
     for (int pass = 0; pass < (POOL ? K::FWP_PASSES : K::FW_PASSES); ++pass) {
       int bB[K::FW_TN], pix[K::FW_TN];
@@ -284,6 +287,12 @@ __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict_
               pc[i][r] = am | (m > 0.0f ? 4 : 0);
             }
           if (writer) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) omx = fmaxf(omx, pm[i][r]);
+          }
+          if (writer) {
             float* op = obase + 4 * hi * K::PW + win;
             uint8_t* cp = cbase + 4 * hi * K::PW + win;
 #pragma unroll
@@ -315,7 +324,13 @@ __global__ __launch_bounds__(512) void first_fwd_kernel(const float* __restrict_
     // ---- the next sample: its maxima, then its planes into the other image (released by the barrier that ended the previous round)
     const bool more = bn < n;
     if (more) leave_amax(red + 8 * ((it + 1) & 1));
+    if (POOL && out_amax != nullptr) {   // this workgroup owns the whole sample: its eight waves' maxima meet behind the barrier below
+      omx = wave_max(omx);
+      if (lane == 0) omax[wave] = omx;
+    }
     __syncthreads();
+    if (POOL && out_amax != nullptr && tid == 0)
+      amax_raise(fmaxf(fmaxf(fmaxf(omax[0], omax[1]), fmaxf(omax[2], omax[3])), fmaxf(fmaxf(omax[4], omax[5]), fmaxf(omax[6], omax[7]))), out_amax + b);
     if (more) {
       sc_cur = scale_from(red + 8 * ((it + 1) & 1), 8);
       commit(lds + K::F_IMG_OFF + ((it + 1) & 1) * K::IMG_F, sc_cur);
@@ -572,7 +587,7 @@ void launch_conv_first_pack(const ConvGeom& g, const float* w, float* region, hi
 
 template <class K, bool POOL>
 static void run_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, int64_t out_sn, uint8_t* code,
-                          hipStream_t st) {
+                          float* out_amax, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)fconv::first_fwd_kernel<K, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, K::F_LDS);
@@ -580,17 +595,17 @@ static void run_first_fwd(const ConvGeom& g, const float* in, const float* regio
   }
   const int grid = g.n < 256 ? g.n : 256;  // one persistent workgroup per CU walks the samples
   hipLaunchKernelGGL((fconv::first_fwd_kernel<K, POOL>), dim3(grid), dim3(512), K::F_LDS, st, in, g.in_sn, (const unsigned short*)region,
-                     region + K::W_BYTES / 4, bias, act, out, out_sn, code, g.n);
+                     region + K::W_BYTES / 4, bias, act, out, out_sn, code, out_amax, g.n);
 }
 
 void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, hipStream_t st) {
-  DDRL_FIRST_DISPATCH(g, (run_first_fwd<K, false>(g, in, region, bias, act, out, g.out_sn, nullptr, st)));
+  DDRL_FIRST_DISPATCH(g, (run_first_fwd<K, false>(g, in, region, bias, act, out, g.out_sn, nullptr, nullptr, st)));
 }
 
 // conv + ReLU + max_pool2d(2): pooled [n][64][OH / 2][OH / 2] (dense), code = one decision byte per window
 void launch_conv_first_fwd_pool(const ConvGeom& g, const float* in, const float* region, const float* bias, float* pooled, uint8_t* code,
-                                hipStream_t st) {
-  DDRL_FIRST_DISPATCH(g, (run_first_fwd<K, true>(g, in, region, bias, 1, pooled, (int64_t)64 * K::PW, code, st)));
+                                float* out_amax, hipStream_t st) {
+  DDRL_FIRST_DISPATCH(g, (run_first_fwd<K, true>(g, in, region, bias, 1, pooled, (int64_t)64 * K::PW, code, out_amax, st)));
 }
 
 int conv_first_wgrad_splits(const ConvGeom& g) {

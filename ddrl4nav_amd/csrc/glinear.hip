@@ -433,13 +433,18 @@ void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const fl
 }
 
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                         float* din, int64_t ld_din, int n, int K, int N, float* ws, const float* dout_scales, hipStream_t st) {
+                         float* din, int64_t ld_din, int n, int K, int N, float* ws, const float* dout_scales, float* din_amax, int amax_lo,
+                         int amax_hi, hipStream_t st) {
   if (ws && linear_uses_planes(n, K, N)) {
-    launch_linear_planes_dgrad(dout, ld_dout, wn + wn_f32_floats(K, N), mask_src, ld_mask, din, ld_din, n, K, N, ws, dout_scales, st);
+    launch_linear_planes_dgrad(dout, ld_dout, wn + wn_f32_floats(K, N), mask_src, ld_mask, din, ld_din, n, K, N, ws, dout_scales, din_amax,
+                               amax_lo, amax_hi, st);
     return;
   }
   glin::Dgrad::Params p{dout, ld_dout, wn, mask_src, ld_mask, din, ld_din, n, K, N, (K + 3) / 4 * 4};
   launch_engine2<glin::Dgrad>(dim3((K + 127) / 128, (n + 127) / 128, 1), p, st);
+  // small launches (fewer than 128 rows) and small layers: the magnitudes come from a pass over the rows just written (api_ops.hip
+  // checked that the column range allows 16-byte loads)
+  if (din_amax != nullptr) launch_row_amax(din + amax_lo, ld_din, amax_hi - amax_lo, n, din_amax, 1, st);
 }
 
 int linear_wgrad_splits(int n, int K, int N) {

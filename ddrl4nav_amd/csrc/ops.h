@@ -24,8 +24,10 @@ void launch_maxpool2_relu_bwd(const float* a, const float* dpool, int64_t planes
 void launch_maxpool2_fwd_idx(const float* in, int64_t planes, int H, int W, float* out, uint8_t* code, hipStream_t st);
 void launch_maxpool2_bwd_idx(const float* dpool, const uint8_t* code, int64_t planes, int H, int W, float* dz, hipStream_t st);
 
-// pconv.hip: forward / data gradient / weight gradient of the heavy nav layers on the 16-bit matrix pipe (two scaled fp16 planes per operand, per-sample input
-// scales); `scales` = n floats of scratch
+// pconv.hip: forward / data gradient / weight gradient of the heavy nav layers on the 16-bit matrix pipe (two scaled fp16 planes per operand, per-sample
+// input scales from the samples' largest magnitudes: engine2.h scale_of_amax); `scales` = n floats of scratch for a pre-pass over the
+// input; `given*` = the magnitudes the caller already holds (a producer's out_amax, or launch_sample_amax), nullptr = run the pre-pass;
+// `out_amax` (may be null) = n floats the epilogue RAISES to the largest |output| of every sample (zeroed by the caller)
 bool conv_has_planes(const ConvGeom& g);
 int64_t conv_planes_pack_floats(const ConvGeom& g);  // floats of ONE region (forward or data gradient)
 void launch_conv_planes_pack(const ConvGeom& g, const float* w, float* wpf, float* wpd, hipStream_t st);
@@ -33,13 +35,12 @@ void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf
                             hipStream_t st);
 void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* scales, float* din, hipStream_t st);
 bool conv_planes_has_pool(const ConvGeom& g);     // forward with ReLU + max_pool2d(2) in the epilogue
-// `given*`: per-sample plane scales the caller already holds (launch_plane_scales), or nullptr for a pre-pass into the scratch
-void launch_plane_scales(const float* x, int64_t sn, int elems, int n, float* scales, hipStream_t st);
+void launch_sample_amax(const float* x, int64_t sn, int elems, int n, float* amax, hipStream_t st);   // the pre-pass: amax[b] = max |x[b][:]|
 void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* given, const float* bias,
-                                 float* pooled, uint8_t* code, hipStream_t st);
+                                 float* pooled, uint8_t* code, float* out_amax, hipStream_t st);
 // gradients of such a layer from d(pooled) + decision bytes (scales / part as launch_conv_planes_dgrad / _wgrad)
 void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, const float* given,
-                                     float* din, hipStream_t st);
+                                     float* din, float* out_amax, hipStream_t st);
 void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, const float* given_in,
                                      const float* given_dp, float* part, float* dw, float* db, hipStream_t st);
 int conv_planes_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no plane kernels
@@ -53,7 +54,7 @@ int64_t conv_first_pack_floats(const ConvGeom& g);
 void launch_conv_first_pack(const ConvGeom& g, const float* w, float* region, hipStream_t st);
 void launch_conv_first_fwd(const ConvGeom& g, const float* in, const float* region, const float* bias, int act, float* out, hipStream_t st);
 void launch_conv_first_fwd_pool(const ConvGeom& g, const float* in, const float* region, const float* bias, float* pooled, uint8_t* code,
-                                hipStream_t st);  // conv + ReLU + max_pool2d(2) in one launch
+                                float* out_amax, hipStream_t st);  // conv + ReLU + max_pool2d(2) in one launch; out_amax as pconv.hip's
 void launch_conv_first_wgrad_pooled(const ConvGeom& g, const float* in, const float* dpool, const uint8_t* ucode, float* part, float* dw, float* db,
                                     hipStream_t st);  // weight gradient from d(pooled) + decision bytes
 int conv_first_wgrad_splits(const ConvGeom& g);  // 0 when the layer is not this one
@@ -64,7 +65,7 @@ bool conv_has_c1d(const ConvGeom& g);           // forward
 bool conv_has_c1d_backward(const ConvGeom& g);  // data + weight gradient (the 32 -> 32 layer)
 int64_t conv_c1d_pack_floats(const ConvGeom& g);  // floats of EACH of the two regions
 void launch_conv_c1d_pack(const ConvGeom& g, const float* w, float* wt, float* wd, hipStream_t st);
-void launch_conv_c1d_fwd(const ConvGeom& g, const float* in, const float* wt, const float* bias, int act, float* out, hipStream_t st);
+void launch_conv_c1d_fwd(const ConvGeom& g, const float* in, const float* wt, const float* bias, int act, float* out, float* out_amax, hipStream_t st);
 void launch_conv_c1d_dgrad(const ConvGeom& g, const float* dz, const float* wd, float* din, hipStream_t st);
 int conv_c1d_wgrad_splits(const ConvGeom& g);  // 0 when the layer has no such kernel
 void launch_conv_c1d_wgrad(const ConvGeom& g, const float* in, const float* dz, float* part, float* dw, float* db, hipStream_t st);
@@ -79,7 +80,8 @@ int linear_fwd_splits(int n, int K, int N);
 void launch_linear_fwd(const float* in, int64_t ld_in, const float* wt, const float* bias, float* out, int64_t ld_out, int n,
                        int K, int N, int act, float* part, const float* in_scales, hipStream_t st);
 void launch_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                         float* din, int64_t ld_din, int n, int K, int N, float* ws, const float* dout_scales, hipStream_t st);
+                         float* din, int64_t ld_din, int n, int K, int N, float* ws, const float* dout_scales, float* din_amax, int amax_lo,
+                         int amax_hi, hipStream_t st);
 int linear_wgrad_splits(int n, int K, int N);
 void launch_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,
                          float* dw, float* db, const float* in_scales, const float* dout_scales, hipStream_t st);
@@ -94,14 +96,16 @@ int64_t linear_planes_fwd_floats(int K, int N);
 int64_t linear_planes_dgrad_floats(int K, int N);
 void launch_linear_planes_pack(const float* w, int K, int N, float* pf, float* pd, hipStream_t st);
 int linear_planes_fwd_splits(int n, int K, int N);
-// ws: n floats rounded up to 64 (row scales), then linear_planes_fwd_splits * n * N partials
-void launch_row_scales(const float* x, int64_t ld, int width, int n, float* scales, hipStream_t st);
-// given*: per-row scales the caller already holds for that tensor (launch_row_scales), or nullptr for a pre-pass into the scratch
+// ws: n floats rounded up to 64 (row magnitudes of a pre-pass), then linear_planes_fwd_splits * n * N partials
+void launch_row_amax(const float* x, int64_t ld, int width, int n, float* amax, int accumulate, hipStream_t st);   // amax[b] = (max with) max |x[b][:width]|
+// given*: per-row magnitudes the caller already holds for that tensor (a producer's out_amax, launch_row_amax), or nullptr for a pre-pass into the scratch
 void launch_linear_planes_fwd(const float* in, int64_t ld_in, const float* pf, const float* bias, float* out, int64_t ld_out, int n, int K,
                               int N, int act, float* ws, const float* given, hipStream_t st);
 // ws: n floats
+// din_amax (may be null): n floats RAISED to the largest |din| of every row over the columns [amax_lo, amax_hi) (zeroed by the caller)
 void launch_linear_planes_dgrad(const float* dout, int64_t ld_dout, const float* pd, const float* mask_src, int64_t ld_mask, float* din,
-                                int64_t ld_din, int n, int K, int N, float* ws, const float* given, hipStream_t st);
+                                int64_t ld_din, int n, int K, int N, float* ws, const float* given, float* din_amax, int amax_lo, int amax_hi,
+                                hipStream_t st);
 int linear_planes_wgrad_splits(int n, int K, int N);
 // part: linear_planes_wgrad_splits slabs of N * K + N floats, then 2 n floats
 void launch_linear_planes_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* part, int n, int K, int N,

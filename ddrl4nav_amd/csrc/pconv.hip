@@ -9,10 +9,12 @@
 //
 // Plane scheme (engine2.h "f16x3"): every fp32 operand as two scaled fp16 planes, x S = h0 + h1 to 22 bits, three products per
 // k-group on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  The weights arrive pre-split from the pack kernel below with ONE
-// power-of-two scale per layer; the input is split while it is staged with ONE power-of-two scale PER SAMPLE (its largest
-// magnitude, left by sample_scale_kernel in a pre-pass over the input: 2 % of the convolution's time), so that a sample whose
-// activations or gradients are orders of magnitude below the batch's largest keeps its 22 bits; the epilogue multiplies every
-// output column by 1 / (S_sample S_w).
+// power-of-two scale per layer; the input is split while it is staged with ONE power-of-two scale PER SAMPLE, taken from the sample's
+// largest magnitude (engine2.h scale_of_amax), so that a sample whose activations or gradients are orders of magnitude below the
+// batch's largest keeps its 22 bits; the epilogue multiplies every output column by 1 / (S_sample S_w).  The magnitudes come from
+// the PRODUCER of the tensor: the pooling epilogue / the data gradient below leave the largest magnitude of every sample they write
+// in `out_amax` (round 5; the pre-passes over the tensors -- sample_amax_kernel, 1-2 GB of reads per PPO iteration of the nav net --
+// cost 2.5 of its 21 ms, profiles/README.md r05); a tensor that arrives from elsewhere takes the pre-pass.
 //
 // rows = 64 output channels per workgroup (MFMA A operand = weight planes), columns = the output pixels of NS WHOLE samples
 // (B operand), k-block = 16 input channels, one MFMA k-group = ONE tap x 16 channels: the input block is staged
@@ -35,13 +37,13 @@ bool conv_has_planes(const ConvGeom&) { return false; }
 bool conv_planes_has_pool(const ConvGeom&) { return false; }
 int64_t conv_planes_pack_floats(const ConvGeom&) { return 0; }
 int conv_planes_wgrad_splits(const ConvGeom&) { return 0; }
-void launch_plane_scales(const float*, int64_t, int, int, float*, hipStream_t) {}
+void launch_sample_amax(const float*, int64_t, int, int, float*, hipStream_t) {}
 void launch_conv_planes_pack(const ConvGeom&, const float*, float*, float*, hipStream_t) {}
 void launch_conv_planes_fwd(const ConvGeom&, const float*, const float*, float*, const float*, int, float*, hipStream_t) {}
 void launch_conv_planes_dgrad(const ConvGeom&, const float*, const float*, float*, float*, hipStream_t) {}
 void launch_conv_planes_wgrad(const ConvGeom&, const float*, const float*, float*, float*, float*, hipStream_t) {}
-void launch_conv_planes_fwd_pool(const ConvGeom&, const float*, const float*, float*, const float*, const float*, float*, uint8_t*, hipStream_t) {}
-void launch_conv_planes_dgrad_pooled(const ConvGeom&, const float*, const uint8_t*, const float*, float*, const float*, float*, hipStream_t) {}
+void launch_conv_planes_fwd_pool(const ConvGeom&, const float*, const float*, float*, const float*, const float*, float*, uint8_t*, float*, hipStream_t) {}
+void launch_conv_planes_dgrad_pooled(const ConvGeom&, const float*, const uint8_t*, const float*, float*, const float*, float*, float*, hipStream_t) {}
 void launch_conv_planes_wgrad_pooled(const ConvGeom&, const float*, const float*, const uint8_t*, const float*, const float*, float*, float*, float*,
                                      hipStream_t) {}
 }  // namespace ddrl
@@ -59,8 +61,8 @@ struct Geo {
   static constexpr int OH = HIN + 2 * PAD - KS + 1, P = OH * OH, LP = HIN + 2 * PAD, LPP = LP * LP, RAW = HIN * HIN;
   static constexpr int COLS = NS * P, PIXB = 2 * KOC;                      // bytes per pixel and plane
   static constexpr int IMG_PLANE = NS * LPP * PIXB, W_OFF = NPL * IMG_PLANE, W_BYTES = TAPC * NPL * 64 * 32;
-  static constexpr int BIAS_OFF = W_OFF + W_BYTES, SC_OFF = BIAS_OFF + 64 * 4;
-  static constexpr size_t LDS_BYTES = SC_OFF + ((NS * 4 + 15) / 16) * 16;
+  static constexpr int BIAS_OFF = W_OFF + W_BYTES, SC_OFF = BIAS_OFF + 64 * 4, OMAX_OFF = SC_OFF + ((NS * 4 + 15) / 16) * 16;
+  static constexpr size_t LDS_BYTES = OMAX_OFF + ((NS * 4 + 15) / 16) * 16;   // + the largest |output| of every sample of the tile
   static constexpr int NIU = NS * RAW, NIJ = (NIU + THREADS - 1) / THREADS;   // pixel units (16 channels each) per tile / thread
   static constexpr int NWQ = W_BYTES / 16, NWJ = (NWQ + THREADS - 1) / THREADS;
   static_assert(CIN % KOC == 0 && COUT % 64 == 0 && KK % TAPC == 0, "channel blocks of 16, row tiles of 64, whole tap chunks");
@@ -69,8 +71,8 @@ struct Geo {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-// Largest magnitude of every sample -> the power-of-two scale of its fp16 planes.  One workgroup per sample.
-__global__ __launch_bounds__(256) void sample_scale_kernel(const float* __restrict__ in, int64_t in_sn, int elems, float* __restrict__ scales) {
+// Largest magnitude of every sample (the pre-pass for tensors whose producer does not leave it).  One workgroup per sample.
+__global__ __launch_bounds__(256) void sample_amax_kernel(const float* __restrict__ in, int64_t in_sn, int elems, float* __restrict__ amax) {
   __shared__ float red[4];
   const float* src = in + (int64_t)blockIdx.x * in_sn;
   float m = 0.0f;
@@ -82,12 +84,7 @@ __global__ __launch_bounds__(256) void sample_scale_kernel(const float* __restri
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    // an all-zero sample (e.g. the gradient of a sample whose advantage is exactly 0) must not pin the BATCH scale of the weight
-    // gradients at 1 (they take the smallest of these): it gets the largest scale there is; 2^60 also bounds the products of two scales
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    scales[blockIdx.x] = mx > 0.0f ? fminf(plane_scale(mx), 0x1p60f) : 0x1p60f;
-  }
+  if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // ---- weights: largest magnitude, then the planes in the order the k index walks ----------------------------------------------
@@ -136,16 +133,19 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
 #endif
 template <class K, bool POOL = false, bool UNPOOL = false>
 __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2 : 1) void direct_planes_kernel(const float* __restrict__ in, int64_t in_sn, const unsigned short* __restrict__ wp,
-                                                                   const float* __restrict__ whdr, const float* __restrict__ scales,
+                                                                   const float* __restrict__ whdr, const float* __restrict__ amax,
                                                                    const float* __restrict__ bias, int act, float* __restrict__ out,
                                                                    int64_t out_sn, uint8_t* __restrict__ code,
-                                                                   const uint8_t* __restrict__ ucode, int n) {
+                                                                   const uint8_t* __restrict__ ucode, float* __restrict__ out_amax, int n) {
   extern __shared__ __attribute__((aligned(16))) char ldsp[];
   const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b0 = blockIdx.x * K::NS, rt = blockIdx.y;
   for (int i = tid; i < K::W_OFF / 16; i += K::THREADS) *(f4*)(ldsp + i * 16) = zero4();  // images incl. their zero borders
   if (tid < 64) ((float*)(ldsp + K::BIAS_OFF))[tid] = bias != nullptr ? bias[rt * 64 + tid] : 0.0f;
-  if (tid < K::NS) ((float*)(ldsp + K::SC_OFF))[tid] = scales[min(b0 + tid, n - 1)];
+  if (tid < K::NS) {
+    ((float*)(ldsp + K::SC_OFF))[tid] = scale_of_amax(amax[min(b0 + tid, n - 1)]);
+    ((float*)(ldsp + K::OMAX_OFF))[tid] = 0.0f;
+  }
   // ---- staging maps.  unit u = tid + THREADS j: sample u / RAW, raw pixel u % RAW -> 16 loads of stride RAW (the k-block's channels)
   // UNPOOL: a unit is a pooling WINDOW (its four pixels share the 16 gradients and decision bytes of the k-block's channels)
   constexpr int CST = UNPOOL ? K::RAW / 4 : K::RAW;  // channel stride of `in`
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
       isrc[j] = in + (int64_t)b * in_sn + w;  // + (16 cb + c) * RAW / 4
       usrc[j] = ucode + (int64_t)b * ((int64_t)K::CIN * CST) + w;
       idst[j] = (s * K::LPP + (2 * wy + K::PAD) * K::LP + 2 * wx + K::PAD) * K::PIXB;  // pixel (0, 0) of the window
-      isc[j] = scales[b];
+      isc[j] = scale_of_amax(amax[b]);
     } else {
       const int s = u / K::RAW, px = u % K::RAW;
       const int b = min(b0 + s, n - 1);
       isrc[j] = in + (int64_t)b * in_sn + px;  // + (16 cb + c) * RAW
       idst[j] = (s * K::LPP + (px / K::HIN + K::PAD) * K::LP + px % K::HIN + K::PAD) * K::PIXB;
-      isc[j] = scales[b];
+      isc[j] = scale_of_amax(amax[b]);
     }
   }
   const unsigned short* wsrc = wp + (int64_t)rt * ((int64_t)K::NCB * K::KK * NPL * 1024) + tid * 8;  // + kb * TAPC * NPL * 1024 + j * THREADS * 8
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
   // ---- epilogue: un-scale per column (sample), bias, ReLU
   const float* lbias = (const float*)(ldsp + K::BIAS_OFF);
   const float* lsc = (const float*)(ldsp + K::SC_OFF);
+  float* omax = (float*)(ldsp + K::OMAX_OFF);   // zeroed at the start; the barriers of the k loop lie in between
   const float winv = 1.0f / whdr[1];
   if constexpr (POOL) {
     static_assert(K::TN % 2 == 0 && K::WAVES * (K::TN / 2) * 32 >= K::NS * SPS && K::OH % 2 == 0, "tile pairs over the stream of upper-row pixels");
@@ -322,6 +323,14 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
           pm[i][r] = m;
           pc[i][r] = am | (m > 0.0f ? 4 : 0);
         }
+      if (out_amax != nullptr && writer) {   // the pooled values are >= 0: their largest is the sample's largest magnitude
+        float lm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lm = fmaxf(lm, pm[i][r]);
+        lds_amax_raise(lm, omax + s);
+      }
       if (writer) {
         float* op = out + (int64_t)(b0 + s) * out_sn + (int64_t)(rt * 64 + 4 * hi) * PW + wl;
         uint8_t* cp = code + (int64_t)(b0 + s) * ((int64_t)K::COUT * PW) + (int64_t)(rt * 64 + 4 * hi) * PW + wl;
@@ -335,6 +344,10 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
           }
       }
     }
+    if (out_amax != nullptr) {   // wave-uniform
+      __syncthreads();
+      if (tid < K::NS && b0 + tid < n) amax_raise(omax[tid], out_amax + b0 + tid);   // COUT / 64 row tiles raise the same slot
+    }
     return;
   }
 #pragma unroll
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
     if (c >= K::COLS || b0 + s >= n) continue;
     const float inv = winv / lsc[s];
     float* op = out + (int64_t)(b0 + s) * out_sn + (int64_t)(rt * 64) * K::P + pix;
+    float lm = 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -352,7 +366,13 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
         float v = __builtin_fmaf(acc[i][j][r], inv, lbias[row]);
         if (act == 1) v = fmaxf(v, 0.0f);
         op[(int64_t)row * K::P] = v;
+        lm = fmaxf(lm, fabsf(v));
       }
+    if (out_amax != nullptr) lds_amax_raise(lm, omax + s);
+  }
+  if (out_amax != nullptr) {   // wave-uniform
+    __syncthreads();
+    if (tid < K::NS && b0 + tid < n) amax_raise(omax[tid], out_amax + b0 + tid);
   }
 }
 
@@ -409,17 +429,17 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
   const int wi = wave >> 1, wx = wave & 1;
   constexpr int NICB = K::CIN / K::ICW;
   const int icb = blockIdx.x % NICB, split = blockIdx.x / NICB, oct = blockIdx.y;
-  // one scale per operand for the whole batch: the smallest of the per-sample scales (= the largest magnitude)
+  // one scale per operand for the whole batch, from the largest of the per-sample magnitudes (sc_dz / sc_in hold magnitudes)
   {
-    float ma = 3.0e38f, mb = 3.0e38f;
+    float ma = 0.0f, mb = 0.0f;
     for (int i = tid; i < n; i += 256) {
-      ma = fminf(ma, sc_dz[i]);
-      mb = fminf(mb, sc_in[i]);
+      ma = fmaxf(ma, sc_dz[i]);
+      mb = fmaxf(mb, sc_in[i]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      ma = fminf(ma, __shfl_xor(ma, off, 64));
-      mb = fminf(mb, __shfl_xor(mb, off, 64));
+      ma = fmaxf(ma, __shfl_xor(ma, off, 64));
+      mb = fmaxf(mb, __shfl_xor(mb, off, 64));
     }
     if (lane == 0) {
       s_min[0][wave] = ma;
@@ -427,8 +447,8 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
     }
   }
   __syncthreads();
-  const float sd = fminf(fminf(s_min[0][0], s_min[0][1]), fminf(s_min[0][2], s_min[0][3]));
-  const float sa = fminf(fminf(s_min[1][0], s_min[1][1]), fminf(s_min[1][2], s_min[1][3]));
+  const float sd = scale_of_amax(fmaxf(fmaxf(s_min[0][0], s_min[0][1]), fmaxf(s_min[0][2], s_min[0][3])));
+  const float sa = scale_of_amax(fmaxf(fmaxf(s_min[1][0], s_min[1][1]), fmaxf(s_min[1][2], s_min[1][3])));
   const float inv = 1.0f / (sd * sa);
   const int nsg = (n + K::NB - 1) / K::NB, nst = nsg * K::NBANDS;
   const int per = (nst + nsplit - 1) / nsplit;
@@ -701,8 +721,8 @@ static PlanesId planes_id(const ConvGeom& g) {
 bool conv_has_planes(const ConvGeom& g) { return planes_id(g) != kPNone; }
 
 // per-sample power-of-two plane scales of x[n][elems] (sample stride sn): what the plane kernels compute in their pre-pass
-void launch_plane_scales(const float* x, int64_t sn, int elems, int n, float* scales, hipStream_t st) {
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, x, sn, elems, scales);
+void launch_sample_amax(const float* x, int64_t sn, int elems, int n, float* scales, hipStream_t st) {
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, x, sn, elems, scales);
 }
 
 // floats of ONE packed region (forward or data gradient): the planes (2 bytes x 2 planes per weight = 4 bytes) + a 64-float header
@@ -726,44 +746,44 @@ void launch_conv_planes_pack(const ConvGeom& g, const float* w, float* wpf, floa
 
 template <class K>
 static void run_planes(const float* in, int64_t in_sn, const float* region, int64_t planes, float* scales, const float* bias, int act,
-                       float* out, int64_t out_sn, int n, hipStream_t st) {
+                       float* out, int64_t out_sn, int n, hipStream_t st, float* out_amax = nullptr) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
-                     in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, (uint8_t*)nullptr, (const uint8_t*)nullptr, n);
+                     in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, (uint8_t*)nullptr, (const uint8_t*)nullptr, out_amax, n);
 }
 
 template <class K>
 static void run_planes_pool(const float* in, int64_t in_sn, const float* region, int64_t planes, float* scales, const float* given, const float* bias,
-                            float* pooled, uint8_t* code, int n, hipStream_t st) {
+                            float* pooled, uint8_t* code, float* out_amax, int n, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  if (!given) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
+  if (!given) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
-                     in_sn, (const unsigned short*)region, region + planes, given ? given : scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, (const uint8_t*)nullptr, n);
+                     in_sn, (const unsigned short*)region, region + planes, given ? given : scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, (const uint8_t*)nullptr, out_amax, n);
 }
 
 // data gradient straight from d(pooled) + decision bytes (K = the layer's data-gradient geometry: CIN = dz channels, HIN = dz size).
 // The per-sample scales come from d(pooled) itself: max |d(pooled)| bounds max |dz| (the routing only drops elements).
 template <class K>
 static void run_planes_unpool(const float* dpool, const uint8_t* ucode, const float* region, int64_t planes, float* scales, const float* given,
-                              float* din, int64_t din_sn, int n, hipStream_t st) {
+                              float* din, int64_t din_sn, float* out_amax, int n, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
   constexpr int64_t PSN = (int64_t)K::CIN * K::RAW / 4;
-  if (!given) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales);
+  if (!given) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES,
-                     st, dpool, PSN, (const unsigned short*)region, region + planes, given ? given : scales, (const float*)nullptr, 0, din, din_sn, (uint8_t*)nullptr, ucode, n);
+                     st, dpool, PSN, (const unsigned short*)region, region + planes, given ? given : scales, (const float*)nullptr, 0, din, din_sn, (uint8_t*)nullptr, ucode, out_amax, n);
 }
 
 // conv + ReLU + max_pool2d(2) in one launch for the layers whose tiles allow it (four column tiles per wave)
@@ -777,14 +797,14 @@ bool conv_planes_has_pool(const ConvGeom& g) {
 }
 
 void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* given, const float* bias,
-                                 float* pooled, uint8_t* code, hipStream_t st) {
+                                 float* pooled, uint8_t* code, float* out_amax, hipStream_t st) {
 #if !DDRL_PC_WIDE
   const int64_t planes = (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2;
   switch (planes_id(g)) {
-    case kPN1dC2: run_planes_pool<PN1dC2F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
-    case kPN1dC3: run_planes_pool<PN1dC3F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
-    case kPNavC2: run_planes_pool<PNavC2FP>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
-    case kPNavC3: run_planes_pool<PNavC3FP>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, g.n, st); break;
+    case kPN1dC2: run_planes_pool<PN1dC2F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, out_amax, g.n, st); break;
+    case kPN1dC3: run_planes_pool<PN1dC3F>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, out_amax, g.n, st); break;
+    case kPNavC2: run_planes_pool<PNavC2FP>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, out_amax, g.n, st); break;
+    case kPNavC3: run_planes_pool<PNavC3FP>(in, g.in_sn, wpf, planes, scales, given, bias, pooled, code, out_amax, g.n, st); break;
     default: break;
   }
 #endif
@@ -856,8 +876,8 @@ static void run_planes_wgrad(const ConvGeom& g, const float* in, const float* dz
   }
   float* sc_in = scales;
   float* sc_dz = scales + g.n;
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
-  hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dz, g.out_sn, K::COUT * K::P, sc_dz);
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dz, g.out_sn, K::COUT * K::P, sc_dz);
   hipLaunchKernelGGL(pconv::wgrad_planes_kernel<K>, dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in, g.in_sn,
                      dz, g.out_sn, (const uint8_t*)nullptr, sc_in, sc_dz, part, g.n, S);
 }
@@ -873,8 +893,8 @@ static void run_planes_wgrad_pooled(const ConvGeom& g, const float* in, const fl
   float* sc_in = scales;
   float* sc_dz = scales + g.n;
   constexpr int64_t PSN = (int64_t)K::COUT * K::P / 4;
-  if (!given_in) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
-  if (!given_dp) hipLaunchKernelGGL(pconv::sample_scale_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz);  // max |d(pooled)| bounds max |dz|
+  if (!given_in) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
+  if (!given_dp) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz);  // max |d(pooled)| bounds max |dz|
   hipLaunchKernelGGL((pconv::wgrad_planes_kernel<K, true>), dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in,
                      g.in_sn, dpool, PSN, ucode, given_in ? given_in : sc_in, given_dp ? given_dp : sc_dz, part, g.n, S);
 }
@@ -899,14 +919,14 @@ void launch_conv_planes_wgrad_pooled(const ConvGeom& g, const float* in, const f
 }
 
 void launch_conv_planes_dgrad_pooled(const ConvGeom& g, const float* dpool, const uint8_t* ucode, const float* wpd, float* scales, const float* given,
-                                     float* din, hipStream_t st) {
+                                     float* din, float* out_amax, hipStream_t st) {
 #if !DDRL_PC_WIDE
   const int64_t planes = (int64_t)g.cout * g.cin * g.kh * g.kw * NPL / 2;
   switch (planes_id(g)) {
-    case kPN1dC2: run_planes_unpool<PN1dC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
-    case kPN1dC3: run_planes_unpool<PN1dC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
-    case kPNavC2: run_planes_unpool<PNavC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
-    case kPNavC3: run_planes_unpool<PNavC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, g.n, st); break;
+    case kPN1dC2: run_planes_unpool<PN1dC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, out_amax, g.n, st); break;
+    case kPN1dC3: run_planes_unpool<PN1dC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, out_amax, g.n, st); break;
+    case kPNavC2: run_planes_unpool<PNavC2D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, out_amax, g.n, st); break;
+    case kPNavC3: run_planes_unpool<PNavC3D>(dpool, ucode, wpd, planes, scales, given, din, g.in_sn, out_amax, g.n, st); break;
     default: break;
   }
 #endif

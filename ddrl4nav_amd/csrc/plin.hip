@@ -10,8 +10,10 @@
 //
 // The first two are ONE kernel (nt_planes_kernel): the weights arrive pre-split from the pack kernel in fragment order with one
 // power-of-two scale per layer ([column tile 128][k-group][plane][column][lane half][8 k] -- a k-block is 16 KB contiguous, copied as
-// it is), the activations are split while they are staged with one power-of-two scale PER ROW (per sample: row_scale_kernel leaves
-// them in a pre-pass), so a sample whose activations or gradients are orders of magnitude below the batch's largest keeps its 22
+// it is), the activations are split while they are staged with one power-of-two scale PER ROW (per sample), taken from the row's
+// largest magnitude (engine2.h scale_of_amax) -- left by the tensor's producer where it has one (the pooling epilogue of pconv.hip for
+// the flattened conv output, the data gradient below for its own output: `out_amax`), by the pre-pass row_amax_kernel otherwise --,
+// so a sample whose activations or gradients are orders of magnitude below the batch's largest keeps its 22
 // bits; the epilogue multiplies every output row by 1 / (S_row S_w).  The weight gradient stages both operands row-major as they
 // lie in memory ([sample][column], 256-byte rows, 32-byte blocks XOR-swizzled by the row) and forms its fragments with the
 // transposing LDS read (ds_read_b64_tr_b16), both operands under ONE scale for the batch (the largest of the row maxima): a sum over
@@ -32,11 +34,12 @@ using u2v = __attribute__((ext_vector_type(2))) unsigned;
 using s4w = __attribute__((ext_vector_type(4))) short;
 
 constexpr int STAGE = 32768, A_BYTES = 16384;          // bytes per stage: activation planes, then weight planes
-constexpr int LDS_NT = 2 * STAGE + 128 * 4;            // + the tile's row scales
+constexpr int LDS_NT = 2 * STAGE + 2 * 128 * 4;        // + the tile's row scales, + the largest |output| of every row of the tile
 constexpr int LDS_TN = 2 * STAGE;
 
-// Largest magnitude of every row -> the power-of-two scale of its fp16 planes.  One wave per row.
-__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ x, int64_t ld, int width4, int n, float* __restrict__ scales) {
+// Largest magnitude of every row (the pre-pass for tensors whose producer does not leave it).  One wave per row.  accumulate: raise
+// the slot instead of overwriting it (a row assembled from several producers: torch.cat).
+__global__ __launch_bounds__(256) void row_amax_kernel(const float* __restrict__ x, int64_t ld, int width4, int n, float* __restrict__ amax, int accumulate) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n) return;
   const float* src = x + (int64_t)row * ld;
@@ -47,8 +50,10 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  // an all-zero row must not pin the batch scale of the weight gradient (the smallest of these): it gets the largest scale there is
-  if (lane == 0) scales[row] = m > 0.0f ? fminf(plane_scale(m), 0x1p60f) : 0x1p60f;
+  if (lane == 0) {
+    if (accumulate) amax_raise(m, amax + row);
+    else amax[row] = m;
+  }
 }
 
 // (both packed regions of a layer take the same scale: one pass over the weights leaves it in both headers)
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 struct NtParams {
   const float* a;               // activations [n][lda]
   int64_t lda;
-  const float* scales;          // per row
+  const float* scales;          // per row: its largest magnitude
   const unsigned short* bp;     // packed weight planes
   const float* whdr;            // [1] = weight scale
   int n, cols, kgs;             // rows, output columns, k-groups of the packed planes (even)
@@ -98,6 +103,9 @@ struct NtParams {
   int64_t ldm;
   float* out;
   int64_t ldo;
+  // data gradient: the largest |out| of every row over the columns [amax_lo, amax_hi) is raised into out_amax[row] (may be null)
+  float* out_amax;
+  int amax_lo, amax_hi;
 };
 
 template <int DGRAD>
@@ -110,7 +118,11 @@ __global__ __launch_bounds__(256, 2) void nt_planes_kernel(NtParams P) {
   const int per = (nkb + P.nsplit - 1) / P.nsplit;
   const int kb_begin = min(nkb, split * per), kb_end = min(nkb, kb_begin + per);
   float* lsc = (float*)(lds + 2 * STAGE);
-  if (tid < 128) lsc[tid] = P.scales[min(b0 + tid, P.n - 1)];
+  float* omax = lsc + 128;
+  if (tid < 128) {
+    lsc[tid] = scale_of_amax(P.scales[min(b0 + tid, P.n - 1)]);
+    omax[tid] = 0.0f;
+  }
   // ---- staging maps: quad (row = tid / 8 + 32 j, k = 4 (tid % 8) ..) of the 128 x 32 activation block
   const int k4 = tid & 7, rr = tid >> 3;
   const float* asrc[4];
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void nt_planes_kernel(NtParams P) {
   for (int j = 0; j < 4; ++j) {
     const int row = min(b0 + rr + 32 * j, P.n - 1);
     asrc[j] = P.a + (int64_t)row * P.lda;
-    asc[j] = P.scales[row];
+    asc[j] = scale_of_amax(P.scales[row]);
   }
   const int awr = ((k4 >> 2) * (NPL * 128) + rr) * 32 + ((k4 >> 1) & 1) * 16 + (k4 & 1) * 8;  // + plane * 4096, + 32 j rows = 1024 j
   const unsigned short* bsrc = P.bp + (int64_t)blockIdx.x * P.kgs * (NPL * 2048) + tid * 8;     // + kb * 8192 + j * 2048 (shorts)
@@ -192,6 +204,9 @@ __global__ __launch_bounds__(256, 2) void nt_planes_kernel(NtParams P) {
   }
   // ---- epilogue: un-scale per row, then bias + ReLU (forward) / the producing layer's ReLU mask (data gradient)
   const float winv = 1.0f / P.whdr[1];
+  float rmax[32];   // data gradient with out_amax: this lane's largest |output| of each of its 32 rows (index 16 i + r)
+#pragma unroll
+  for (int k = 0; k < 32; ++k) rmax[k] = 0.0f;
   float rinv[2][16];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void nt_planes_kernel(NtParams P) {
         if (DGRAD) {
           if (P.mask != nullptr && !(P.mask[(int64_t)b * P.ldm + col] > 0.0f)) v = 0.0f;
           P.out[(int64_t)b * P.ldo + col] = v;
+          if (col >= P.amax_lo && col < P.amax_hi) rmax[16 * i + r] = fmaxf(rmax[16 * i + r], fabsf(v));
         } else if (P.nsplit > 1) {
           P.part[((int64_t)split * P.n + b) * P.cols + col] = v;
         } else {
@@ -220,6 +236,27 @@ __global__ __launch_bounds__(256, 2) void nt_planes_kernel(NtParams P) {
           P.out[(int64_t)b * P.ldo + col] = v;
         }
       }
+  }
+  if (DGRAD && P.out_amax != nullptr) {   // block-uniform
+    // row maxima over the 32 lanes of a half in 31 exchanges: at stage `mask` a lane keeps the half of its values whose index bit equals
+    // its own lane bit and takes the partner's candidates for them, so after five stages lane l31 holds the maximum of row index l31
+    // (rows of lanes past the batch hold zeros: they raise nothing)
+    int cnt = 32;
+#pragma unroll
+    for (int mask = 16; mask >= 1; mask >>= 1) {
+      cnt >>= 1;
+      const bool upper = (l31 & mask) != 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < cnt) {
+          const float send = upper ? rmax[k] : rmax[k + cnt], keep = upper ? rmax[k + cnt] : rmax[k];
+          rmax[k] = fmaxf(keep, __shfl_xor(send, mask, 64));
+        }
+      }
+    }
+    lds_amax_raise(rmax[0], omax + wr * 64 + (l31 >> 4) * 32 + acc_row(l31 & 15, hi));   // the two column halves (wc) meet here
+    __syncthreads();
+    if (tid < 128 && b0 + tid < P.n) amax_raise(omax[tid], P.out_amax + b0 + tid);
   }
 }
 
@@ -251,16 +288,16 @@ __global__ __launch_bounds__(256, 2) void tn_planes_kernel(TnParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wi = wave >> 1, wx = wave & 1;
   const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, split = blockIdx.z;
-  {
-    float ma = 3.0e38f, mb = 3.0e38f;
+  {   // one scale per operand for the whole batch, from the largest of the row magnitudes (sc_d / sc_i hold magnitudes)
+    float ma = 0.0f, mb = 0.0f;
     for (int i = tid; i < P.n; i += 256) {
-      ma = fminf(ma, P.sc_d[i]);
-      mb = fminf(mb, P.sc_i[i]);
+      ma = fmaxf(ma, P.sc_d[i]);
+      mb = fmaxf(mb, P.sc_i[i]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      ma = fminf(ma, __shfl_xor(ma, off, 64));
-      mb = fminf(mb, __shfl_xor(mb, off, 64));
+      ma = fmaxf(ma, __shfl_xor(ma, off, 64));
+      mb = fmaxf(mb, __shfl_xor(mb, off, 64));
     }
     if (lane == 0) {
       s_min[0][wave] = ma;
@@ -268,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void tn_planes_kernel(TnParams P) {
     }
   }
   __syncthreads();
-  const float sd = fminf(fminf(s_min[0][0], s_min[0][1]), fminf(s_min[0][2], s_min[0][3]));
-  const float sa = fminf(fminf(s_min[1][0], s_min[1][1]), fminf(s_min[1][2], s_min[1][3]));
+  const float sd = scale_of_amax(fmaxf(fmaxf(s_min[0][0], s_min[0][1]), fmaxf(s_min[0][2], s_min[0][3])));
+  const float sa = scale_of_amax(fmaxf(fmaxf(s_min[1][0], s_min[1][1]), fmaxf(s_min[1][2], s_min[1][3])));
   const float inv = 1.0f / (sd * sa);
   const int nst = (P.n + 31) / 32;
   const int per = (nst + P.nsplit - 1) / P.nsplit;
@@ -430,8 +467,8 @@ static void run_nt(const plin::NtParams& p, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL(plin::nt_planes_kernel<DGRAD>, grid, dim3(256), plin::LDS_NT, st, p);
 }
 
-static void row_scales(const float* x, int64_t ld, int width, int n, float* scales, hipStream_t st) {
-  hipLaunchKernelGGL(plin::row_scale_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, ld, (width + 3) / 4 * 4, n, scales);
+static void row_scales(const float* x, int64_t ld, int width, int n, float* amax, hipStream_t st, int accumulate = 0) {
+  hipLaunchKernelGGL(plin::row_amax_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, ld, (width + 3) / 4 * 4, n, amax, accumulate);
 }
 
 int linear_planes_fwd_splits(int n, int K, int N) {
@@ -443,7 +480,7 @@ int linear_planes_fwd_splits(int n, int K, int N) {
 }
 
 // ws: n floats (row scales, rounded up to 64), then the split-K partials
-void launch_row_scales(const float* x, int64_t ld, int width, int n, float* scales, hipStream_t st) { row_scales(x, ld, width, n, scales, st); }
+void launch_row_amax(const float* x, int64_t ld, int width, int n, float* amax, int accumulate, hipStream_t st) { row_scales(x, ld, width, n, amax, st, accumulate); }
 
 // given*: per-row scales the caller already holds (launch_row_scales on the same tensor), or nullptr for a pre-pass into the scratch
 void launch_linear_planes_fwd(const float* in, int64_t ld_in, const float* pf, const float* bias, float* out, int64_t ld_out, int n, int K,
@@ -453,17 +490,19 @@ void launch_linear_planes_fwd(const float* in, int64_t ld_in, const float* pf, c
   const int S = linear_planes_fwd_splits(n, K, N);
   float* part = ws + (n + 63) / 64 * 64;
   if (!given) row_scales(in, ld_in, K, n, ws, st);
-  plin::NtParams p{in, ld_in, given ? given : ws, (const unsigned short*)pf, pf + planes, n, N, kgs, bias, act, S, part, nullptr, 0, out, ld_out};
+  plin::NtParams p{in, ld_in, given ? given : ws, (const unsigned short*)pf, pf + planes, n, N, kgs, bias, act, S, part, nullptr, 0, out, ld_out, nullptr, 0, 0};
   run_nt<0>(p, dim3((N + 127) / 128, (n + 127) / 128, S), st);
   if (S > 1) launch_linear_finish(part, S, n, N, bias, act, out, ld_out, st);
 }
 
 void launch_linear_planes_dgrad(const float* dout, int64_t ld_dout, const float* pd, const float* mask_src, int64_t ld_mask, float* din,
-                                int64_t ld_din, int n, int K, int N, float* ws, const float* given, hipStream_t st) {
+                                int64_t ld_din, int n, int K, int N, float* ws, const float* given, float* din_amax, int amax_lo, int amax_hi,
+                                hipStream_t st) {
   const int kgs = kgs_of(N);
   const int64_t planes = (int64_t)((K + 127) / 128) * kgs * (NPL * 2048) / 2;
   if (!given) row_scales(dout, ld_dout, N, n, ws, st);
-  plin::NtParams p{dout, ld_dout, given ? given : ws, (const unsigned short*)pd, pd + planes, n, K, kgs, nullptr, 0, 1, nullptr, mask_src, ld_mask, din, ld_din};
+  plin::NtParams p{dout, ld_dout, given ? given : ws, (const unsigned short*)pd, pd + planes, n, K, kgs, nullptr, 0, 1, nullptr, mask_src, ld_mask, din, ld_din,
+                   din_amax, amax_lo, amax_hi};
   run_nt<1>(p, dim3((K + 127) / 128, (n + 127) / 128, 1), st);
 }
 

@@ -19,10 +19,11 @@ from ddrl4nav_amd import _lib
 from ddrl4nav_amd._lib import STATS_FLOATS, HeadsDesc, check
 from ddrl4nav_amd.data import Experience
 from ddrl4nav_amd.nn.base import Basenn, PreNet
-from ddrl4nav_amd.ops import Conv, Linear, maxpool2_idx, maxpool2_backward_idx, plane_scales, _p, _st
+from ddrl4nav_amd.ops import Conv, Linear, maxpool2_idx, maxpool2_backward_idx, sample_amax, _p, _st
 from ddrl4nav_amd.utils.staging import to_device
 
 FEAT = 512
+PRODUCER_AMAX = True   # per-sample magnitudes travel from a tensor's producer to its consumer (include/ddrl.h); False: pre-passes (A/B)
 
 
 def _pad4(k):
@@ -52,36 +53,39 @@ class _Dense:
         self._scale_buffers(cap, device)
 
     def _scale_buffers(self, cap, device):
-        # per-row plane scales of the layer's input and of d(output), computed once per pass and shared by the operators that read the
-        # same tensor (forward + weight gradient; data + weight gradient)
+        # per-row magnitudes of the layer's input and of d(output) (include/ddrl.h "per-sample magnitudes"): found once per pass and
+        # shared by the operators that read the same tensor (forward + weight gradient; data + weight gradient).  A caller that knows
+        # the tensor's producer hands the producer's `out_amax` in instead (in_amax / dout_amax below) and the pre-pass is skipped.
         share = self.op.uses_planes(cap)
         self.in_sc = torch.empty((cap,), dtype=torch.float32, device=device) if share else None
         self.dout_sc = torch.empty((cap,), dtype=torch.float32, device=device) if share else None
 
-    def _in_scales(self, x, ld_in, n):
+    def _in_amax(self, x, ld_in, n, given=None):
         if self.in_sc is None or not self.op.uses_planes(n):
             return None
-        return self.op.row_scales(x, ld_in, self.K, n, self.in_sc)
+        return given if given is not None else self.op.row_amax(x, ld_in, self.K, n, self.in_sc)
 
-    def _dout_scales(self, dout, ld_dout, n):
+    def _dout_amax(self, dout, ld_dout, n, given=None):
         if self.dout_sc is None or not self.op.uses_planes(n):
             return None
-        return self.op.row_scales(dout, ld_dout, self.N, n, self.dout_sc)
+        return given if given is not None else self.op.row_amax(dout, ld_dout, self.N, n, self.dout_sc)
 
     def pack(self):
         self.op.pack(self.m.weight.data)
 
-    def forward(self, x, ld_in, out, ld_out, n):
-        self._fwd_sc = self._in_scales(x, ld_in, n)     # kept for the weight gradient of the same pass
-        return self.op.forward(x, ld_in, self.m.bias.data, self.relu, out, ld_out, n, in_scales=self._fwd_sc)
+    def forward(self, x, ld_in, out, ld_out, n, in_amax=None):
+        self._fwd_sc = self._in_amax(x, ld_in, n, in_amax)     # kept for the weight gradient of the same pass
+        return self.op.forward(x, ld_in, self.m.bias.data, self.relu, out, ld_out, n, in_amax=self._fwd_sc)
 
-    def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0):
-        """dout = gradient w.r.t. this layer's PRE-activation output (the consumer applied the ReLU mask)."""
-        ds = self._dout_scales(dout, ld_dout, n)
-        self.op.wgrad(x, ld_in, dout, ld_dout, self.m.weight.grad_view, self.m.bias.grad_view, n, in_scales=getattr(self, "_fwd_sc", None),
-                      dout_scales=ds)
+    def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0, dout_amax=None, din_amax=None,
+                 amax_cols=None):
+        """dout = gradient w.r.t. this layer's PRE-activation output (the consumer applied the ReLU mask).  din_amax (zeroed by the
+        caller): raised to every row's largest |din| over the columns amax_cols -- what the layer below will ask for."""
+        ds = self._dout_amax(dout, ld_dout, n, dout_amax)
+        self.op.wgrad(x, ld_in, dout, ld_dout, self.m.weight.grad_view, self.m.bias.grad_view, n, in_amax=getattr(self, "_fwd_sc", None),
+                      dout_amax=ds)
         if din is not None:
-            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_scales=ds)
+            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_amax=ds, din_amax=din_amax, amax_cols=amax_cols)
 
 
 class _PaddedDense(_Dense):
@@ -105,18 +109,19 @@ class _PaddedDense(_Dense):
         self.bpad[:self.N_real].copy_(self.m.bias.data)
         self.op.pack(self.wpad)
 
-    def forward(self, x, ld_in, out, ld_out, n):
-        self._fwd_sc = self._in_scales(x, ld_in, n)
-        return self.op.forward(x, ld_in, self.bpad, self.relu, out, ld_out, n, in_scales=self._fwd_sc)
+    def forward(self, x, ld_in, out, ld_out, n, in_amax=None):
+        self._fwd_sc = self._in_amax(x, ld_in, n, in_amax)
+        return self.op.forward(x, ld_in, self.bpad, self.relu, out, ld_out, n, in_amax=self._fwd_sc)
 
-    def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0):
-        ds = self._dout_scales(dout, ld_dout, n)
-        self.op.wgrad(x, ld_in, dout, ld_dout, self.dwpad, self.dbpad, n, in_scales=getattr(self, "_fwd_sc", None), dout_scales=ds)
+    def backward(self, x, ld_in, dout, ld_dout, n, din=None, ld_din=0, mask_src=None, ld_mask=0, dout_amax=None, din_amax=None,
+                 amax_cols=None):
+        ds = self._dout_amax(dout, ld_dout, n, dout_amax)
+        self.op.wgrad(x, ld_in, dout, ld_dout, self.dwpad, self.dbpad, n, in_amax=getattr(self, "_fwd_sc", None), dout_amax=ds)
         self.m.weight.grad_view.copy_(self.dwpad[:self.N_real])
         # bias gradient = column sums of dout, correctly rounded (see csrc/gail.hip:colsum_kernel)
         check(_lib.load().ddrl_op_colsum(_p(dout), ld_dout, n, self.N_real, _p(self.m.bias.grad_view), _st()))
         if din is not None:
-            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_scales=ds)
+            self.op.dgrad(dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_amax=ds, din_amax=din_amax, amax_cols=amax_cols)
 
 
 def dense_layer(module, relu, cap, device):
@@ -144,8 +149,9 @@ class _ConvPool:
         self._a = None if self.fused else torch.empty((cap, module.out_channels, oh, ow), **f)   # relu(conv)
         # ... and their backward reads d(pooled) + the decision bytes (ddrl_op_conv_*_pooled): no full-resolution gradient either
         self.fused_bwd = self.fused
-        # per-sample plane scales of the layer's input and of d(pooled), computed once per pass and shared by the operators that read
-        # the same tensor (forward + weight gradient; data + weight gradient)
+        # per-sample magnitudes of the layer's input and of d(pooled) (include/ddrl.h): taken from the tensors' producers where the
+        # encoder hands them in (in_amax / dp_amax below), else found by a pre-pass into these buffers; one array per tensor serves the
+        # operators that read it (forward + weight gradient; data + weight gradient)
         self.in_sc = self.dp_sc = None
         if self.fused and self.op.pooled_uses_scales():
             self.in_sc = torch.empty((cap,), **f)
@@ -180,13 +186,16 @@ class _ConvPool:
             a[:, :, (k >> 1)::2, (k & 1)::2] = torch.where(am == k, p, torch.zeros_like(p))
         return a
 
-    def forward(self, x, n):
+    def forward(self, x, n, in_amax=None, out_amax=None):
+        """in_amax: the samples' largest |x| as x's producer left them (None: pre-pass); out_amax (zeroed by the caller): raised to the
+        samples' largest |output| for the layer that reads this one's output."""
         if self.fused:
+            self._in_amax = None
             if self.in_sc is not None:
-                plane_scales(x, n, self.in_sc)
-            self.op.forward_pool(x, self.m.bias.data, self.p, self.code, n=n, in_scales=self.in_sc)
+                self._in_amax = in_amax if in_amax is not None else sample_amax(x, n, self.in_sc)
+            self.op.forward_pool(x, self.m.bias.data, self.p, self.code, n=n, in_amax=self._in_amax, out_amax=out_amax)
             return self.p
-        self.op.forward(x, self.m.bias.data, self.relu, out=self._a, n=n)
+        self.op.forward(x, self.m.bias.data, self.relu, out=self._a, n=n, out_amax=None if self.pool else out_amax)
         if not self.pool:
             return self._a
         maxpool2_idx(self._a[:n], out=self.p, code=self.code)
@@ -196,14 +205,17 @@ class _ConvPool:
         """Where the consumer writes d(loss)/d(output of this block)."""
         return self.dp if self.pool else self.dz
 
-    def backward(self, x, n, din=None):
+    def backward(self, x, n, din=None, dp_amax=None, din_amax=None):
+        """dp_amax: the samples' largest |d(pooled)| as its producer left them (None: pre-pass); din_amax (zeroed by the caller): raised
+        to the samples' largest |din|."""
         if self.fused_bwd:
+            dpm = None
             if self.dp_sc is not None:
-                plane_scales(self.dp, n, self.dp_sc)
-            self.op.wgrad_pooled(x, self.dp, self.code, self.m.weight.grad_view, self.m.bias.grad_view, n=n, in_scales=self.in_sc,
-                                 dpool_scales=self.dp_sc)
+                dpm = dp_amax if dp_amax is not None else sample_amax(self.dp, n, self.dp_sc)
+            self.op.wgrad_pooled(x, self.dp, self.code, self.m.weight.grad_view, self.m.bias.grad_view, n=n,
+                                 in_amax=getattr(self, "_in_amax", None), dpool_amax=dpm)
             if din is not None:
-                self.op.dgrad_pooled(self.dp, self.code, din=din, n=n, dpool_scales=self.dp_sc)
+                self.op.dgrad_pooled(self.dp, self.code, din=din, n=n, dpool_amax=dpm, din_amax=din_amax)
             return
         if self.pool:
             maxpool2_backward_idx(self.dp[:n], self.code, self.oh, self.ow, dz=self.dz)
@@ -272,20 +284,33 @@ class _NavBase(GenericPreNet):
         self.h = self._f(cap, 512)
         self.flat_dim = flat_dim
 
-    def _tail_forward(self, flat, vec, n):
+    def _links(self, *rows):
+        """The arena rows handed from producers to consumers; PRODUCER_AMAX = False (tools/ab_nav_amax.py, same-box A/B) hands out
+        None instead, i.e. every consumer runs its own pre-pass as in round 4."""
+        return rows if PRODUCER_AMAX else (None,) * len(rows)
+
+    def _amax_arena(self, cap, device, n_fwd, n_bwd):
+        """Per-sample magnitudes that travel from a tensor's producer to its consumer (include/ddrl.h): one row per tensor, zeroed at
+        the start of a pass (one fill per pass and encoder), raised by the producers' epilogues."""
+        self._amax_f = torch.zeros((n_fwd, cap), dtype=torch.float32, device=device)
+        self._amax_b = torch.zeros((n_bwd, cap), dtype=torch.float32, device=device)
+
+    def _tail_forward(self, flat, vec, n, flat_amax=None):
         # torch.cat((x, state[1]), dim=1): fc0 writes its slice of the cat buffer directly
-        self.d0.forward(flat, self.flat_dim, self.cat[:, self.extra:], self.ld_cat, n)
+        self.d0.forward(flat, self.flat_dim, self.cat[:, self.extra:], self.ld_cat, n, in_amax=flat_amax)
         self.cat[:n, self.extra + 512:self.cat_k].copy_(vec.reshape(n, -1))
         self.d1.forward(self.cat, self.ld_cat, self.f1, 512, n)
         self.d2.forward(self.f1, 512, self.h, 512, n)
         return self.h
 
-    def _tail_backward(self, dh, flat, dflat, n):
+    def _tail_backward(self, dh, flat, dflat, n, dflat_amax=None):
         self.d2.backward(self.f1, 512, dh, 512, n, din=self.df1, ld_din=512, mask_src=self.f1, ld_mask=512)
         # the first extra+512 columns of cat are ReLU outputs: mask with the cat values themselves
         self.d1.backward(self.cat, self.ld_cat, self.df1, 512, n, din=self.dcat, ld_din=self.ld_cat, mask_src=self.cat,
                          ld_mask=self.ld_cat)
-        self.d0.backward(flat, self.flat_dim, self.dcat[:, self.extra:], self.ld_cat, n, din=dflat, ld_din=self.flat_dim)
+        # d(flat) = d(pooled) of the last conv block: its data gradient leaves the samples' magnitudes for that block's backward
+        self.d0.backward(flat, self.flat_dim, self.dcat[:, self.extra:], self.ld_cat, n, din=dflat, ld_din=self.flat_dim,
+                         din_amax=dflat_amax)
 
 
 class NavPreNet(_NavBase):
@@ -309,6 +334,7 @@ class NavPreNet(_NavBase):
         self.c2 = _ConvPool(self.conv2, 24, 24, cap, device)
         self.c3 = _ConvPool(self.conv3, 12, 12, cap, device)
         self._build_tail(cap, device, 256 * 6 * 6, 9)
+        self._amax_arena(cap, device, 3, 2)
         self._blocks = [self.c1, self.c2, self.c3, self.d0, self.d1, self.d2]
 
     def _image(self, states, n):
@@ -316,15 +342,19 @@ class NavPreNet(_NavBase):
 
     def forward_dev(self, states, n):
         self.img = self._image(states, n)
-        p1 = self.c1.forward(self.img, n)
-        p2 = self.c2.forward(p1, n)
-        p3 = self.c3.forward(p2, n)
-        return self._tail_forward(p3, states[1], n)
+        self._amax_f.zero_()
+        A = self._links(*self._amax_f)
+        p1 = self.c1.forward(self.img, n, out_amax=A[0])                 # every block leaves the magnitudes the next one scales by
+        p2 = self.c2.forward(p1, n, in_amax=A[0], out_amax=A[1])
+        p3 = self.c3.forward(p2, n, in_amax=A[1], out_amax=A[2])
+        return self._tail_forward(p3, states[1], n, flat_amax=A[2])
 
     def backward_dev(self, dh, n):
-        self._tail_backward(dh, self.c3.p, self.c3.dp, n)
-        self.c3.backward(self.c2.p, n, din=self.c2.dp)
-        self.c2.backward(self.c1.p, n, din=self.c1.dp)
+        self._amax_b.zero_()
+        G = self._links(*self._amax_b)
+        self._tail_backward(dh, self.c3.p, self.c3.dp, n, dflat_amax=G[0])
+        self.c3.backward(self.c2.p, n, din=self.c2.dp, dp_amax=G[0], din_amax=G[1])
+        self.c2.backward(self.c1.p, n, din=self.c1.dp, dp_amax=G[1])
         self.c1.backward(self.img, n)
 
 
@@ -367,24 +397,29 @@ class NavPreNet1D(_NavBase):
         self.l1.m, self.l2.m = self.conv1d1, self.conv1d2
         self.d1d = _Dense(self.fc_1d[0], True, cap, device)
         self._build_tail(cap, device, 6400, 5, extra=256)
+        self._amax_arena(cap, device, 4, 2)
         self.dl2 = self._f(cap, 7616)
         self._blocks = [self.c1, self.c2, self.c3, self.l1, self.l2, self.d1d, self.d0, self.d1, self.d2]
 
     def forward_dev(self, states, n):
         self.laser = states[0].reshape(n, 1, 1, 960).contiguous()
         self.img = states[2].reshape(n, self.image_channel, 48, 48).contiguous()
+        self._amax_f.zero_()
+        A = self._links(*self._amax_f)
         a1 = self.l1.forward(self.laser, n)
-        a2 = self.l2.forward(a1, n)
-        self.d1d.forward(a2, 7616, self.cat, self.ld_cat, n)  # encoded laser -> cat[:, 0:256]
-        p1 = self.c1.forward(self.img, n)
-        p2 = self.c2.forward(p1, n)
-        p3 = self.c3.forward(p2, n)
-        return self._tail_forward(p3, states[1], n)
+        a2 = self.l2.forward(a1, n, out_amax=A[3])
+        self.d1d.forward(a2, 7616, self.cat, self.ld_cat, n, in_amax=A[3])  # encoded laser -> cat[:, 0:256]
+        p1 = self.c1.forward(self.img, n, out_amax=A[0])                 # every block leaves the magnitudes the next one scales by
+        p2 = self.c2.forward(p1, n, in_amax=A[0], out_amax=A[1])
+        p3 = self.c3.forward(p2, n, in_amax=A[1], out_amax=A[2])
+        return self._tail_forward(p3, states[1], n, flat_amax=A[2])
 
     def backward_dev(self, dh, n):
-        self._tail_backward(dh, self.c3.p, self.c3.dp, n)
-        self.c3.backward(self.c2.p, n, din=self.c2.dp)
-        self.c2.backward(self.c1.p, n, din=self.c1.dp)
+        self._amax_b.zero_()
+        G = self._links(*self._amax_b)
+        self._tail_backward(dh, self.c3.p, self.c3.dp, n, dflat_amax=G[0])
+        self.c3.backward(self.c2.p, n, din=self.c2.dp, dp_amax=G[0], din_amax=G[1])
+        self.c2.backward(self.c1.p, n, din=self.c1.dp, dp_amax=G[1])
         self.c1.backward(self.img, n)
         # laser branch: dcat[:, 0:256] already carries the ReLU mask of fc_1d (applied by fc1's dgrad)
         self.d1d.backward(self.l2.a, 7616, self.dcat, self.ld_cat, n, din=self.l2.dz, ld_din=7616)

@@ -52,13 +52,15 @@ class Conv:
     def pack(self, weight):
         check(self.lib.ddrl_op_conv_pack(byref(self.desc(1)), _p(_f32(weight)), _p(self.packed), _st()))
 
-    def forward(self, x, bias, relu, out=None, n=None):
+    def forward(self, x, bias, relu, out=None, n=None, out_amax=None):
+        """out_amax (optional, [n] floats zeroed by the caller): raised to every sample's largest |output| (include/ddrl.h,
+        "per-sample magnitudes")."""
         n = x.shape[0] if n is None else n
         assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         if out is None:
             out = torch.empty((n, self.cout, self.oh, self.ow), dtype=torch.float32, device=x.device)
         check(self.lib.ddrl_op_conv_forward(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)),
-                                            1 if relu else 0, _p(out), _p(self.scratch), _st()))
+                                            1 if relu else 0, _p(out), _p(self.scratch), _p(out_amax), _st()))
         return out
 
     def has_forward_pool(self):
@@ -66,32 +68,35 @@ class Conv:
         return bool(self.lib.ddrl_op_conv_has_forward_pool(byref(self.desc(1))))
 
     def pooled_uses_scales(self):
-        """True when the pooled operators of this layer read per-sample plane scales (plane_scales below)."""
+        """True when the pooled operators of this layer read per-sample magnitudes (in_amax / dpool_amax; sample_amax below)."""
         return bool(self.lib.ddrl_op_conv_pooled_uses_scales(byref(self.desc(1))))
 
-    def forward_pool(self, x, bias, pooled, code, n=None, in_scales=None):
-        """max_pool2d(relu(conv(x)), 2) in one launch: pooled [n][cout][oh/2][ow/2] + one decision byte per window."""
+    def forward_pool(self, x, bias, pooled, code, n=None, in_amax=None, out_amax=None):
+        """max_pool2d(relu(conv(x)), 2) in one launch: pooled [n][cout][oh/2][ow/2] + one decision byte per window.
+        in_amax: the samples' largest |x| (from x's producer or sample_amax; None = own pre-pass); out_amax: raised to the samples'
+        largest pooled value (zeroed by the caller)."""
         n = x.shape[0] if n is None else n
         assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         check(self.lib.ddrl_op_conv_forward_pool(byref(self.desc(n)), _p(_f32(x)), _p(self.packed), _p(_f32(bias)), _p(pooled),
-                                                 _p(code), _p(in_scales), _p(self.scratch), _st()))
+                                                 _p(code), _p(in_amax), _p(self.scratch), _p(out_amax), _st()))
         return pooled
 
-    def dgrad_pooled(self, dpool, code, din=None, n=None, dpool_scales=None):
-        """Data gradient of a forward_pool layer from d(pooled) + decision bytes (no full-resolution gradient in between)."""
+    def dgrad_pooled(self, dpool, code, din=None, n=None, dpool_amax=None, din_amax=None):
+        """Data gradient of a forward_pool layer from d(pooled) + decision bytes (no full-resolution gradient in between).
+        din_amax: raised to the samples' largest |din| (zeroed by the caller)."""
         n = dpool.shape[0] if n is None else n
         assert n <= self.max_n, "batch larger than the layer's scratch was sized for"
         if din is None:
             din = torch.empty((n, self.cin, self.h, self.w), dtype=torch.float32, device=dpool.device)
         check(self.lib.ddrl_op_conv_dgrad_pooled(byref(self.desc(n)), _p(_f32(dpool)), _p(code), _p(self.packed), _p(din),
-                                                 _p(dpool_scales), _p(self.scratch), _st()))
+                                                 _p(dpool_amax), _p(self.scratch), _p(din_amax), _st()))
         return din
 
-    def wgrad_pooled(self, x, dpool, code, dw, db, n=None, in_scales=None, dpool_scales=None):
+    def wgrad_pooled(self, x, dpool, code, dw, db, n=None, in_amax=None, dpool_amax=None):
         n = x.shape[0] if n is None else n
         assert n <= self.max_n, "batch larger than the split-K scratch was sized for"
         check(self.lib.ddrl_op_conv_wgrad_pooled(byref(self.desc(n)), _p(_f32(x)), _p(_f32(dpool)), _p(code), _p(self.packed),
-                                                 _p(self.ws), _p(dw), _p(db), _p(in_scales), _p(dpool_scales), _st()))
+                                                 _p(self.ws), _p(dw), _p(db), _p(in_amax), _p(dpool_amax), _st()))
 
     def dgrad(self, dz, din=None, n=None):
         n = dz.shape[0] if n is None else n
@@ -108,10 +113,10 @@ class Conv:
                                           _p(dw), _p(db), _st()))
 
 
-def plane_scales(x, n, out):
-    """Per-sample power-of-two plane scales of x[:n] (dense samples) for the *_pool / *_pooled operators (include/ddrl.h)."""
+def sample_amax(x, n, out):
+    """Largest magnitude of every sample of x[:n] (dense samples): the pre-pass for tensors whose producer leaves none (include/ddrl.h)."""
     elems = x[0].numel()
-    check(_lib.load().ddrl_op_plane_scales(_p(_f32(x)), elems, elems, n, _p(out), _st()))
+    check(_lib.load().ddrl_op_sample_amax(_p(_f32(x)), elems, elems, n, _p(out), _st()))
     return out
 
 
@@ -171,24 +176,27 @@ class Linear:
         """True when a launch of n rows runs on the fp16 plane kernels (and therefore reads per-row scales)."""
         return bool(self.lib.ddrl_op_linear_uses_planes(n, self.K, self.N))
 
-    def row_scales(self, x, ld, width, n, out):
-        """Per-row plane scales of x[:n] (one pass; hand them to the operators that read the same tensor)."""
-        check(self.lib.ddrl_op_row_scales(_p(x), ld, width, n, _p(out), _st()))
+    def row_amax(self, x, ld, width, n, out, accumulate=False):
+        """Largest magnitude of every row of x[:n] (one pass; hand it to the operators that read the same tensor)."""
+        check(self.lib.ddrl_op_row_amax(_p(x), ld, width, n, _p(out), 1 if accumulate else 0, _st()))
         return out
 
-    def forward(self, x, ld_in, bias, relu, out, ld_out, n, in_scales=None):
+    def forward(self, x, ld_in, bias, relu, out, ld_out, n, in_amax=None):
         assert n <= self.max_n
         check(self.lib.ddrl_op_linear_forward(_p(x), ld_in, _p(self.wt), _p(_f32(bias)), 1 if relu else 0, _p(out), ld_out,
-                                              n, self.K, self.N, _p(self.ws), _p(in_scales), _st()))
+                                              n, self.K, self.N, _p(self.ws), _p(in_amax), _st()))
         return out
 
-    def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_scales=None):
+    def dgrad(self, dout, ld_dout, mask_src, ld_mask, din, ld_din, n, dout_amax=None, din_amax=None, amax_cols=None):
+        """din_amax ([n] floats zeroed by the caller): raised to every row's largest |din| over the columns amax_cols = (lo, hi)
+        (default: all K)."""
         assert n <= self.max_n
+        lo, hi = amax_cols if amax_cols is not None else (0, 0)
         check(self.lib.ddrl_op_linear_dgrad(_p(dout), ld_dout, _p(self.wn), _p(mask_src), ld_mask, _p(din), ld_din, n,
-                                            self.K, self.N, _p(self.ws), _p(dout_scales), _st()))
+                                            self.K, self.N, _p(self.ws), _p(dout_amax), _p(din_amax), lo, hi, _st()))
         return din
 
-    def wgrad(self, x, ld_in, dout, ld_dout, dw, db, n, in_scales=None, dout_scales=None):
+    def wgrad(self, x, ld_in, dout, ld_dout, dw, db, n, in_amax=None, dout_amax=None):
         assert n <= self.max_n
         check(self.lib.ddrl_op_linear_wgrad(_p(x), ld_in, _p(dout), ld_dout, _p(self.ws), _p(dw), _p(db), n, self.K,
-                                            self.N, _p(in_scales), _p(dout_scales), _st()))
+                                            self.N, _p(in_amax), _p(dout_amax), _st()))

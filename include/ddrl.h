@@ -304,7 +304,7 @@ int32_t ddrl_op_conv_out_shape(const ddrl_conv_desc* d, int32_t* oh, int32_t* ow
  * 128->256 3x3 @10, 64->128 3x3 @24, 128->256 3x3 @12) run as fp16 plane products on the 16-bit matrix pipe (csrc/pconv.hip) and need
  * one float of scratch per sample for the per-sample plane scales of a launch that is not handed its scales: `scales_scratch` of
  * ddrl_op_conv_forward / _dgrad / _forward_pool / _dgrad_pooled, ddrl_op_conv_scratch_floats(d) floats for a launch of d->n samples
- * (0 for layers that need none: NULL is accepted then, and whenever in_scales / dpool_scales are given).  One launch per scratch buffer
+ * (0 for layers that need none: NULL is accepted then, and whenever in_amax / dpool_amax are given).  One launch per scratch buffer
  * at a time.  The plane kernels need 16-byte aligned tensors and sample strides that are multiples of 4 floats; other views of the same
  * layers run on the generic gather kernels (csrc/gconv.hip, f32-input MFMA) like every geometry without a specialised kernel. */
 int32_t ddrl_op_conv_pack_floats(const ddrl_conv_desc* d, int64_t* floats);
@@ -312,7 +312,7 @@ int32_t ddrl_op_conv_pack(const ddrl_conv_desc* d, const float* w, float* packed
 int32_t ddrl_op_conv_scratch_floats(const ddrl_conv_desc* d, int64_t* floats);
 /* out = act(conv2d(in, w) + bias); act: 0 none, 1 ReLU        (torch.nn.Conv2d / Conv1d + F.relu) */
 int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias,
-                             int32_t act, float* out, float* scales_scratch, void* stream);
+                             int32_t act, float* out, float* scales_scratch, float* out_amax, void* stream);
 /* din = d(loss)/d(in) given dz = d(loss)/d(pre-activation output) */
 /* Conv2d + ReLU + max_pool2d(2) in ONE launch (round 4), for the layers whose kernels pool in their epilogue -- NavPreNet1D's three
  * (3->64 7x7 @48, 64->128 5x5 @22, 128->256 3x3 @10): pooled [n][cout][oh/2][ow/2] (dense) and one decision byte per window as
@@ -320,14 +320,20 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
  * full-resolution activations are never written.  DDRL_ERR_UNSUPPORTED for every other layer: run ddrl_op_conv_forward and
  * ddrl_op_maxpool2_forward_idx instead.  `in` 16-byte aligned, sample stride a multiple of 4 floats. */
 int32_t ddrl_op_conv_forward_pool(const ddrl_conv_desc* d, const float* in, const float* packed, const float* bias, float* pooled,
-                                  uint8_t* code, const float* in_scales, float* scales_scratch, void* stream);
-/* The fp16-plane kernels scale every sample by a power of two taken from its largest magnitude, found in a pre-pass over the tensor.
- * A caller that runs several operators on the SAME tensor (the forward and the weight gradient both read the layer's input; the data
- * and the weight gradient both read d(pooled)) computes the scales once with ddrl_op_plane_scales(x [n] samples of `elems` floats at
- * stride sn -> scales[n]) and hands them to the *_pool / *_pooled operators as in_scales / dpool_scales; NULL = the operator runs
- * its own pre-pass.  The scales of d(pooled) are taken from d(pooled) itself (its largest magnitude bounds the routed gradient's).
- * ddrl_op_conv_pooled_uses_scales: 1 for the layers that read them (the 3-channel first layer finds its scales inside its kernels). */
-int32_t ddrl_op_plane_scales(const float* x, int64_t sn, int32_t elems, int32_t n, float* scales, void* stream);
+                                  uint8_t* code, const float* in_amax, float* scales_scratch, float* out_amax, void* stream);
+/* PER-SAMPLE MAGNITUDES (`*_amax`, ABI 3).  The fp16-plane kernels scale every sample (dense layers: every row) by a power of two taken
+ * from its largest magnitude.  What travels between operators is that magnitude itself -- n floats, amax[b] >= max |x[b][:]| (any upper
+ * bound is valid; the tighter, the more bits the sample keeps) --, and it comes from the PRODUCER of the tensor wherever there is one:
+ *   out_amax / din_amax (outputs, may be NULL): the operator RAISES amax[b] to the largest |value| it writes for sample b (an atomic
+ *     maximum on the bit pattern: deterministic, and several operators may raise the same array -- the row tiles of one launch, or
+ *     the layers that fill the slices of a torch.cat buffer).  The CALLER zeroes the array before the first producer runs.
+ *   in_amax / dpool_amax / dout_amax (inputs, may be NULL): the magnitudes of the tensor the operator reads; NULL = the operator runs
+ *     its own pre-pass over the tensor (a full read of it: ~12 % of a robot_nav PPO iteration when every operator did that).
+ * ddrl_op_sample_amax (x: n samples of `elems` floats at stride sn) and ddrl_op_row_amax (x [n][ld], `width` columns; accumulate != 0:
+ * raise instead of overwrite) are the stand-alone pre-passes for tensors that arrive from elsewhere.  The magnitudes of d(pooled) bound
+ * those of the routed gradient.  ddrl_op_conv_pooled_uses_scales: 1 for the layers that read in_amax / dpool_amax (the first layer of a
+ * nav encoder finds its scales inside its kernels). */
+int32_t ddrl_op_sample_amax(const float* x, int64_t sn, int32_t elems, int32_t n, float* amax, void* stream);
 int32_t ddrl_op_conv_pooled_uses_scales(const ddrl_conv_desc* d);
 int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d);  /* 1 when ddrl_op_conv_forward_pool serves the layer, else 0 (host only) */
 /* The backward of the same layers straight from d(pooled) [n][cout][oh/2][ow/2] and the decision bytes: the kernels form
@@ -335,9 +341,9 @@ int32_t ddrl_op_conv_has_forward_pool(const ddrl_conv_desc* d);  /* 1 when ddrl_
  * what ddrl_op_maxpool2_backward_idx would write), so the full-resolution gradient is neither written nor read.  Same layers as
  * ddrl_op_conv_forward_pool (the 3-channel first layer has no data gradient: DDRL_ERR_UNSUPPORTED); dpool 16-byte aligned, dense. */
 int32_t ddrl_op_conv_dgrad_pooled(const ddrl_conv_desc* d, const float* dpool, const uint8_t* code, const float* packed, float* din,
-                                  const float* dpool_scales, float* scales_scratch, void* stream);
+                                  const float* dpool_amax, float* scales_scratch, float* din_amax, void* stream);
 int32_t ddrl_op_conv_wgrad_pooled(const ddrl_conv_desc* d, const float* in, const float* dpool, const uint8_t* code, const float* packed,
-                                  float* ws, float* dw, float* db, const float* in_scales, const float* dpool_scales, void* stream);
+                                  float* ws, float* dw, float* db, const float* in_amax, const float* dpool_amax, void* stream);
 int32_t ddrl_op_conv_dgrad(const ddrl_conv_desc* d, const float* dz, const float* packed, float* din, float* scales_scratch, void* stream);
 /* dw [cout][cin][kh][kw], db [cout] (overwritten); `ws` = split-K scratch of ddrl_op_conv_ws_floats.
  * Requires oh*ow >= 32. */
@@ -369,26 +375,27 @@ int32_t ddrl_op_linear_pack_floats(int32_t K, int32_t N, int64_t* wt_floats, int
 int32_t ddrl_op_linear_pack(const float* w, int32_t K, int32_t N, float* wt, float* wn, void* stream);
 /* ws: scratch of ddrl_op_linear_ws_floats(n, K, N) floats (lets small n x N problems split K over
  * workgroups), or NULL for a single pass.
- * in_scales / dout_scales (the last argument before `stream` of the three operators): layers of K >= 128, N >= 64 in launches of
- * n >= 128 rows (ddrl_op_linear_uses_planes: 1) run as fp16 plane products and scale every ROW of `in` / `dout` by a power of two found
- * in a pre-pass over that tensor.  The forward and the weight gradient read the same `in`, the data and the weight gradient the same
- * `dout`: a caller computes the scales once per tensor with ddrl_op_row_scales(x [n][ld], width -> scales[n]) and passes them; NULL =
- * the operator runs its own pre-pass. */
+ * in_amax / dout_amax: layers of K >= 128, N >= 64 in launches of n >= 128 rows (ddrl_op_linear_uses_planes: 1) run as fp16 plane
+ * products and scale every ROW of `in` / `dout` by a power of two from the row's largest magnitude ("per-sample magnitudes" above: from
+ * the tensor's producer, from ddrl_op_row_amax, or NULL = the operator's own pre-pass).  The forward and the weight gradient read the
+ * same `in`, the data and the weight gradient the same `dout`: one array per tensor serves both. */
 int32_t ddrl_op_linear_uses_planes(int32_t n, int32_t K, int32_t N);
-int32_t ddrl_op_row_scales(const float* x, int64_t ld, int32_t width, int32_t n, float* scales, void* stream);
+int32_t ddrl_op_row_amax(const float* x, int64_t ld, int32_t width, int32_t n, float* amax, int32_t accumulate, void* stream);
 int32_t ddrl_op_linear_forward(const float* in, int64_t ld_in, const float* wt, const float* bias, int32_t act,
-                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, const float* in_scales,
+                               float* out, int64_t ld_out, int32_t n, int32_t K, int32_t N, float* ws, const float* in_amax,
                                void* stream);
 /* din[b][k] = [mask_src[b][k] > 0 or mask_src == NULL] * sum_n dout[b][n] W[n][k]; mask_src is the
  * (ReLU) output of the layer that produced `in`.  ws: the same scratch as the forward's (the 16-bit plane kernels of layers with
- * K >= 128, N >= 64 keep their per-row scales there for launches of n >= 128 rows), or NULL for the f32-input kernels. */
+ * K >= 128, N >= 64 keep their per-row scales there for launches of n >= 128 rows), or NULL for the f32-input kernels.
+ * din_amax (may be NULL): raised to the largest |din[b][k]| over the columns amax_lo <= k < amax_hi (amax_hi <= 0: all K columns;
+ * amax_lo a multiple of 4) -- a slice when the consumer reads a slice of din (the layers behind a torch.cat). */
 int32_t ddrl_op_linear_dgrad(const float* dout, int64_t ld_dout, const float* wn, const float* mask_src, int64_t ld_mask,
-                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, const float* dout_scales,
-                             void* stream);
+                             float* din, int64_t ld_din, int32_t n, int32_t K, int32_t N, float* ws, const float* dout_amax,
+                             float* din_amax, int32_t amax_lo, int32_t amax_hi, void* stream);
 int32_t ddrl_op_linear_ws_floats(int32_t n, int32_t K, int32_t N, int64_t* floats);
 /* dw [N][K] = dout^T in, db [N] = column sums of dout (overwritten) */
 int32_t ddrl_op_linear_wgrad(const float* in, int64_t ld_in, const float* dout, int64_t ld_dout, float* ws, float* dw,
-                             float* db, int32_t n, int32_t K, int32_t N, const float* in_scales, const float* dout_scales, void* stream);
+                             float* db, int32_t n, int32_t K, int32_t N, const float* in_amax, const float* dout_amax, void* stream);
 
 /* Actor / critic heads on 512-wide encoder features (AC_INPUT_DIM, config_nn.py:23) with the PPO
  * loss block and its backward, for nets assembled from the operators above.  `continuous` selects

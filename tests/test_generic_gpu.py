@@ -215,6 +215,27 @@ def test_generic_net_learn_sequence_golden(golden, name):
     assert seen == 10
 
 
+@pytest.mark.parametrize("name", ["f15_mlp_classical", "f13_nav1d_gauss"])
+def test_generic_deferred_loss_readback_yields_the_same_values(golden, name):
+    """config_nn.DEFERRED_LOSS_READBACK on the operator-composed PPO (nn/generic.py:learn): all iterations enqueued, every iteration's
+    loss terms copied to its own pinned row, ONE synchronisation, then the same items -- keys, values, update_time -- and the same
+    parameters as the per-iteration protocol of the reference (ppo.py:131-146), bit for bit."""
+    from ddrl4nav_amd.data import Experience
+    g = golden(name)
+    runs = []
+    for deferred in (False, True):
+        net, _ = _make(name, max_batch=48)      # two micro-batches (one of them ragged) per iteration
+        net.deferred_stats = deferred
+        exp = Experience(states=_states(g), advs=g["advs"], actions=g["actions"], old_logps=g["old_logps"], values=g["rets"].reshape(1, -1))
+        items = [(dict(l), ut, last) for l, ut, last in net.learn(exp)]
+        runs.append((items, net.params.clone()))
+    (a, pa), (b, pb) = runs
+    assert len(a) == len(b) == 10 and torch.equal(pa, pb)
+    for (la, ua, fa), (lb, ub, fb) in zip(a, b):
+        assert ua == ub and fa is fb is True and set(la) == set(lb)
+        assert all(la[k] == lb[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss"))
+
+
 def test_micro_batching_matches_one_shot(golden):
     """max_batch smaller than B: gradients are accumulated over micro-batches (ddrl_op_accumulate)."""
     from ddrl4nav_amd.data import Experience
@@ -314,6 +335,47 @@ def test_nav_config4_batch_properties():
     for k in ("ActorLoss", "VLoss", "EntLoss"):
         assert abs(losses[0][k] - losses[1][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
         assert abs(losses[0][k] - losses[2][k]) <= 1e-5 * max(1.0, abs(losses[0][k]))
+
+
+@pytest.mark.parametrize("name", ["f13_nav1d_gauss", "f14_navped_shared"])
+def test_producer_magnitudes_equal_the_prepass_bit_for_bit(golden, name):
+    """Round 5: the per-sample magnitudes behind the fp16 plane scales come from the PRODUCER of a tensor (pooling epilogues of
+    fconv.hip / pconv.hip, the data gradients of pconv.hip / plin.hip, the laser branch's Conv1d) instead of a pre-pass over the
+    tensor in front of every consumer (include/ddrl.h "per-sample magnitudes").  Both are the exact maximum of the same values, so
+    three PPO iterations leave the same parameters and losses bit for bit (nn/generic.py PRODUCER_AMAX = False restores the
+    pre-passes: tools/ab_nav_amax.py)."""
+    from ddrl4nav_amd.data import Experience
+    from ddrl4nav_amd.nn import generic
+    g = golden(name)
+    B = 256
+    gen = torch.Generator(device="cuda").manual_seed(91)
+    if name == "f13_nav1d_gauss":
+        states = [torch.rand((B, 1, 960), device="cuda", generator=gen), torch.randn((B, 5), device="cuda", generator=gen),
+                  (torch.rand((B, 3, 48, 48), device="cuda", generator=gen) < 0.15).float()]
+        actions = torch.randn((B, 2), device="cuda", generator=gen)
+    else:
+        states = [(torch.rand((B, 1, 48, 48), device="cuda", generator=gen) < 0.3).float(), torch.randn((B, 9), device="cuda", generator=gen),
+                  (torch.rand((B, 3, 48, 48), device="cuda", generator=gen) < 0.1).float()]
+        actions = torch.randint(0, 5, (B,), device="cuda", generator=gen).float()
+    states[0][7] *= 1e-4                 # a sample whose magnitudes are decades below the batch's: its scale must follow it in both forms
+    adv = torch.randn(B, device="cuda", generator=gen)
+    adv[3] = 0.0                         # an all-zero gradient row: the largest scale, in both forms
+    exp = Experience(states=states, advs=adv, actions=actions, old_logps=torch.full((B,), -2.0, device="cuda"),
+                     values=torch.randn((1, B), device="cuda", generator=gen))
+    outs = []
+    try:
+        for flag in (True, False):
+            generic.PRODUCER_AMAX = flag
+            net, _ = _make(name, max_batch=160)       # two micro-batches, the second one ragged
+            net.training_iter_time = 3
+            losses = [l for l, _, _ in net.learn(exp)]
+            assert all(np.isfinite(l["PpoTotalLoss"]) for l in losses)
+            outs.append((net.params.clone(), losses))
+    finally:
+        generic.PRODUCER_AMAX = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    for la, lb in zip(outs[0][1], outs[1][1]):
+        assert all(la[k] == lb[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss"))
 
 
 def test_nav_two_encoder_streams_are_bit_identical():

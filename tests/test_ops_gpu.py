@@ -113,10 +113,10 @@ def test_conv_relu_pool_in_one_launch_vs_torch(shape):
     code = torch.full((n, cout, oh // 2, oh // 2), 255, dtype=torch.uint8).cuda()
     conv.forward_pool(x.cuda(), b.cuda(), pooled, code, n=n)
     if conv.pooled_uses_scales():   # the caller's per-sample scales (shared by forward and weight gradient) = the operator's own pre-pass
-        from ddrl4nav_amd.ops import plane_scales
-        sc = plane_scales(x.cuda(), n, torch.empty(n).cuda())
+        from ddrl4nav_amd.ops import sample_amax
+        sc = sample_amax(x.cuda(), n, torch.empty(n).cuda())
         p2, c2 = torch.empty_like(pooled), torch.empty_like(code)
-        conv.forward_pool(x.cuda(), b.cuda(), p2, c2, n=n, in_scales=sc)
+        conv.forward_pool(x.cuda(), b.cuda(), p2, c2, n=n, in_amax=sc)
         assert torch.equal(p2, pooled) and torch.equal(c2, code)
     else:
         assert cin <= 4       # the few-channel first layers find their scales inside their kernels (csrc/fconv.hip)
@@ -168,7 +168,7 @@ def test_conv_strided_sample_layout():
     out = torch.zeros(n, cout * h * w + 6).cuda()
     d = conv.desc(n, in_sn=x.shape[1], out_sn=out.shape[1])
     xd, bd = x.cuda(), b.cuda()  # keep the device copies alive across the asynchronous launch
-    _lib.check(_lib.load().ddrl_op_conv_forward(byref(d), _p(xd), _p(conv.packed), _p(bd), 0, _p(out), _p(conv.scratch), _st()))
+    _lib.check(_lib.load().ddrl_op_conv_forward(byref(d), _p(xd), _p(conv.packed), _p(bd), 0, _p(out), _p(conv.scratch), _p(None), _st()))
     want = F.conv2d(x[:, :cin * h * w].reshape(n, cin, h, w), wt, b, padding=1)
     close(out[:, :cout * h * w].reshape(n, cout, h, w), want)
     assert float(out[:, cout * h * w:].abs().max()) == 0.0
@@ -317,7 +317,7 @@ def test_pooled_conv_block_full_batch_size_vs_torch_gpu(shape):
     rounding; the per-window routing agrees except where the window's two largest activations lie within fp32 noise of each other
     (either implementation may take either: a few windows in 10^7, each of which moves a weight-gradient element by ~1e-3 of its
     size -- so the gradients are compared under torch's OWN routing, which separates the arithmetic from those coin flips)."""
-    from ddrl4nav_amd.ops import Conv, plane_scales, maxpool2_backward_idx
+    from ddrl4nav_amd.ops import Conv, sample_amax, maxpool2_backward_idx
     n, cin, h, cout, ks = shape
     g = torch.Generator(device="cuda").manual_seed(n + cin + h)
     x = torch.randn(n, cin, h, h, device="cuda", generator=g).requires_grad_(True)
@@ -332,8 +332,8 @@ def test_pooled_conv_block_full_batch_size_vs_torch_gpu(shape):
     conv.pack(wt.detach())
     assert conv.has_forward_pool()
     pooled, code = torch.empty_like(pooled_ref), torch.empty(pooled_ref.shape, dtype=torch.uint8, device="cuda")
-    sc = plane_scales(x.detach(), n, torch.empty(n, device="cuda")) if conv.pooled_uses_scales() else None
-    conv.forward_pool(x.detach(), b.detach(), pooled, code, n=n, in_scales=sc)
+    sc = sample_amax(x.detach(), n, torch.empty(n, device="cuda")) if conv.pooled_uses_scales() else None
+    conv.forward_pool(x.detach(), b.detach(), pooled, code, n=n, in_amax=sc)
     close(pooled, pooled_ref, tol=5e-5)
     oh = conv.oh
     dz_k = maxpool2_backward_idx(dpool, code, oh, oh)
@@ -350,7 +350,7 @@ def test_pooled_conv_block_full_batch_size_vs_torch_gpu(shape):
     code_t = torch.where(differ, t_am | (t_pos.to(torch.uint8) * 4), code)
     rel = lambda got, want: float((got.double() - want.double()).norm() / want.double().norm())
     dw, db = torch.empty_like(wt.detach()), torch.empty_like(b.detach())
-    conv.wgrad_pooled(x.detach(), dpool, code_t, dw, db, n=n, in_scales=sc)
+    conv.wgrad_pooled(x.detach(), dpool, code_t, dw, db, n=n, in_amax=sc)
     assert rel(db, b.grad) < 2e-5, rel(db, b.grad)
     assert rel(dw, wt.grad) < 2e-5, rel(dw, wt.grad)
     if cin > 4:

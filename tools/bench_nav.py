@@ -3,7 +3,7 @@
 GaussionActor(2) + Critic): PPO iterations on synthetic inputs, per-operator HIP-event times and
 algorithmic TFLOP/s.  Not the headline bench (bench.py is); prints one JSON line.
 
-Usage: python tools/bench_nav.py [B] [micro_batch] [iters] [T] [encoder] [loop_iters]
+Usage: python tools/bench_nav.py [B] [micro_batch] [iters] [T] [encoder] [loop_iters] [one-stream]
 (T given: also one whole actor-learner loop at 512 envs x T steps with loop_iters PPO iterations, BASELINE config 4 shape:
 T = 256, loop_iters = 10)"""
 import json
@@ -89,6 +89,7 @@ def _run(B, CAP, ITERS, T_loop, encoder, loop_iters=None, encoder_streams=True):
     cfg_nn.SHARE_CNN_NET = encoder == "navped"
     net = create_net({"config": cfg, "config_nn": cfg_nn, "config_env": env}, max_batch=CAP)
     net.encoder_streams = bool(encoder_streams)   # False: one stream, so that the per-operator events do not overlap
+    net.deferred_stats = os.environ.get("NAV_SYNC_EVERY_ITER") != "1"   # one host sync per update, as bench.py's headline (nn/generic.py:learn)
     g = torch.Generator(device="cuda")
     g.manual_seed(4)
     if encoder == "navped":
@@ -169,4 +170,5 @@ def _run(B, CAP, ITERS, T_loop, encoder, loop_iters=None, encoder_streams=True):
 if __name__ == "__main__":
     print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, int(sys.argv[2]) if len(sys.argv) > 2 else 1024,
                          int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None,
-                         sys.argv[5] if len(sys.argv) > 5 else "nav1d", int(sys.argv[6]) if len(sys.argv) > 6 else None)))
+                         sys.argv[5] if len(sys.argv) > 5 else "nav1d", int(sys.argv[6]) if len(sys.argv) > 6 and sys.argv[6] != "-" else None,
+                         encoder_streams=not (len(sys.argv) > 7 and sys.argv[7] == "one-stream"))))
