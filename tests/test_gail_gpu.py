@@ -230,6 +230,7 @@ def test_gail_learn_matches_reference(golden, name):
             worst = P.gail_deviation_from(name, "D1", _params(net), ora.params(), ora.p0)
             for k, (v, pname) in worst.items():
                 P.MARGINS.check(tag, "D1_param_" + k, v, "(%s)" % pname)
+            P.MARGINS.record_onednn_only(tag, worst, "D1_param_%s")
             continue
         rows.append([loss_item[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")])
         it = len(rows)
@@ -244,6 +245,7 @@ def test_gail_learn_matches_reference(golden, name):
             worst = P.gail_deviation_from(name, "it%d" % it, _params(net), ora.params(), ora.p0)
             for k, (v, pname) in worst.items():
                 P.MARGINS.check(tag, "param_%s_it%d" % (k, it), v, "(%s)" % pname)
+            P.MARGINS.record_onednn_only(tag, worst, "param_%%s_it%d" % it)
     assert seen_d == 1 and len(rows) == 10
     got = _params(net)
     for k in got:   # in no optimiser (ppo.py:39,61-62): the GAIL critic has not moved

@@ -212,6 +212,7 @@ def test_generic_net_learn_sequence_golden(golden, name):
                                           p64=ora.params(), p0=ora.p0)
             for k, (v, pname) in worst.items():
                 P.MARGINS.check(tag, "param_%s_it%d" % (k, seen), v, "(%s)" % pname)
+            P.MARGINS.record_onednn_only(tag, worst, "param_%%s_it%d" % seen)
     assert seen == 10
 
 

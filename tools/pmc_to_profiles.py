@@ -112,8 +112,20 @@ def main():
         if "SQ_INSTS_VALU" in a:
             e["valu_insts"] = a["SQ_INSTS_VALU"]
         traffic["kernels"][k] = e
-    traffic["batch"] = int(os.environ.get("DDRL_PROFILE_BATCH", "65536"))  # tools/profile_iter.py's B (training launches)
-    traffic["build"] = os.environ.get("DDRL_PROFILE_BUILD", "")            # git revision / note of the profiled build
+    # batch of the profiled launches and the profiled build: meta.json written by tools/prof_round.sh / prof_nav.sh next to the pmc
+    # directory (or inside it), else the environment; a summary without them is refused (round 4 committed one with batch 65,536 for a
+    # 4,096-sample run and an empty build)
+    meta = {}
+    for cand in (os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "meta.json"), os.path.join(sys.argv[1], "meta.json")):
+        if os.path.exists(cand):
+            meta = json.load(open(cand))
+            break
+    batch = os.environ.get("DDRL_PROFILE_BATCH") or meta.get("batch")
+    build = os.environ.get("DDRL_PROFILE_BUILD") or meta.get("build")
+    if not batch or not build or str(build).startswith("unknown"):
+        sys.exit("pmc_to_profiles.py: no batch / build for this profile (meta.json or DDRL_PROFILE_BATCH / DDRL_PROFILE_BUILD)")
+    traffic["batch"] = int(batch)
+    traffic["build"] = str(build)
     box = os.environ.get("DDRL_PROFILE_BOX", "")                            # host the passes ran on
     if not box:  # tools/prof_round.sh leaves hostname + product name next to the pmc directory
         for cand in (os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "box.txt"), os.path.join(sys.argv[1], "box.txt")):
