@@ -393,6 +393,8 @@ __global__ __launch_bounds__(K::THREADS, (DDRL_PC_OCC2 && K::THREADS <= 256) ? 2
 #ifndef DDRL_PW_KO
 #define DDRL_PW_KO 0  // wgrad_planes_kernel timing knock-outs (1: staging only, 2: matrix work only; tools/build_variant.sh)
 #endif
+// (Round 5 also measured the taps of a stage as a software-pipelined sequence -- fragments of tap t + 1 requested before the MFMAs of
+// tap t, pinned with sched_group_barrier --: no gain, and one pinned region over a whole stage took hipcc 11 minutes; profiles/README.md.)
 using s4w = __attribute__((ext_vector_type(4))) short;
 __device__ __forceinline__ frag8 tr_frag(const char* lds, int off_lo, int off_hi) {
   typedef s4w __attribute__((address_space(3))) * lds_s4;
@@ -597,52 +599,22 @@ __global__ __launch_bounds__(256) void wgrad_planes_kernel(const float* __restri
     __syncthreads();
     for (int st = st_begin; st < st_end; ++st) {
 #if DDRL_PW_KO != 1   // timing-only knock-out 1: no fragment reads, no matrix instructions (results are WRONG)
-      // The (k-group, tap) steps of a stage as ONE software-pipelined sequence: the fragments of step i + 1 are requested before the three
-      // MFMAs of step i are issued, and the machine scheduler is told to keep that order (sched_group_barrier: 0x100 = LDS read, 0x008 =
-      // MFMA).  Left to itself it sinks every transposing read next to its use -- "4 reads, wait, MFMA, wait, 2 MFMAs" per tap --, and
-      // with ONE wave per SIMD (208 accumulators) nothing else covers the LDS latency: the matrix pipe sat at 0.46 busy at 2.17 GHz
-      // (profiles/r05_nav1_pmc_traffic.json; knock-outs in profiles/README.md r05).  A wave whose tap group has a tap less than its
-      // partner's (ICW = 32: 12 of 13) runs the last one on tap KK - 1 again into an accumulator nobody stores: no branch in the sequence.
-      {
-        auto tap_of = [&](int t) { const int tap = K::ICW == 64 ? t : wx * K::NT + t; return tap < K::KK ? tap : K::KK - 1; };
-        auto load_a = [&](int g, frag8 (&a)[NPL]) {
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) a[p] = tr_frag(ldsw, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
-        };
-        auto load_b = [&](int g, int t, frag8 (&b)[NPL]) {
-          const int tap = tap_of(t);
+      for (int g = 0; g < K::NKG; ++g) {
+        frag8 a[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) a[p] = tr_frag(ldsw, a_lane + p * K::A_PLANE + g * 2048, a_lane + p * K::A_PLANE + g * 2048 + 512);
+        DDRL_PLANE_PRODUCTS;
+#pragma unroll
+        for (int t = 0; t < K::NT; ++t) {
+          const int tap = K::ICW == 64 ? t : wx * K::NT + t;   // ICW = 32: the wave's half of the taps (wx is wave-uniform)
+          if (K::ICW == 32 && tap >= K::KK) continue;
           const int toff = ((tap / K::KS) * K::LP + tap % K::KS) * K::BP;
+          frag8 b[NPL];
 #pragma unroll
           for (int p = 0; p < NPL; ++p) b[p] = tr_frag(ldsw, b_lane + p * K::B_PLANE + brow[g][0] + toff, b_lane + p * K::B_PLANE + brow[g][1] + toff);
-        };
-        DDRL_PLANE_PRODUCTS;
-        frag8 a[NPL], b[NPL];
-        load_a(0, a);
-        load_b(0, 0, b);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);   // the first step's own reads: the groups below then pair (reads of step i + 1, MFMAs of step i)
 #pragma unroll
-        for (int g = 0; g < K::NKG; ++g) {
-#pragma unroll
-          for (int t = 0; t < K::NT; ++t) {
-            const bool last = g + 1 == K::NKG && t + 1 == K::NT, next_g = t + 1 == K::NT;
-            frag8 an[NPL], bn[NPL];
-            if (!last) {
-              load_b(next_g ? g + 1 : g, next_g ? 0 : t + 1, bn);
-              if (next_g) load_a(g + 1, an);
-            }
-#pragma unroll
-            for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[PA[m]], b[PB[m]], acc[t]);
-            if (!last) {
-#pragma unroll
-              for (int p = 0; p < NPL; ++p) {
-                b[p] = bn[p];
-                if (next_g) a[p] = an[p];
-              }
-              if (next_g) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);
-              else __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
-          }
+          for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[PA[m]], b[PB[m]], acc[t]);
         }
       }
 #endif
