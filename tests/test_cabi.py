@@ -116,3 +116,23 @@ def test_operator_abi_host_side_queries():
     assert lib.ddrl_op_heads_ws_floats(byref(h), 256, byref(f)) == -1
     _lib.check(lib.ddrl_op_clip_adam_ws_bytes(byref(f)))
     assert f.value == 1024 * 8
+
+
+def test_clean_build_stays_within_its_time_budget(tmp_path):
+    """Every HIP source compiles from scratch in well under five minutes (hipcc cross-compiles gfx950 without a GPU): the driver's
+    build() check and a fresh checkout depend on it.  (Round 5: a scheduling experiment -- one sched_group_barrier-pinned region over
+    a whole stage of pconv.hip's weight gradient -- compiled correctly but took hipcc 11 minutes for that one file.)"""
+    import shutil
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = tmp_path / "ddrl4nav_amd" / "csrc"
+    dst.parent.mkdir(parents=True)
+    shutil.copytree(os.path.join(root, "ddrl4nav_amd", "csrc"), dst, ignore=shutil.ignore_patterns("*.o", "*.so", ".pytest_cache", "_scratch*"))
+    (tmp_path / "include").mkdir()
+    shutil.copy(os.path.join(root, "include", "ddrl.h"), tmp_path / "include" / "ddrl.h")
+    t0 = time.time()
+    r = subprocess.run(["make", "-C", str(dst), "-j", str(min(8, os.cpu_count() or 1))], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (dst / "libddrl_hip.so").exists()
+    print("clean build: %.0f s" % (time.time() - t0))
