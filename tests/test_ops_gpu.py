@@ -423,3 +423,83 @@ def test_linear_launch_smaller_than_capacity_takes_more_splits():
         lin.forward(x.cuda(), K, b.cuda(), True, out, N, n)
         close(out, torch.relu(x @ W.T + b))
     assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
+
+
+# ---- per-sample magnitudes left by the producers (include/ddrl.h "per-sample magnitudes", round 5) ------------------------------------
+@pytest.mark.parametrize("shape", [(37, 3, 48, 64, 7), (9, 64, 22, 128, 5), (11, 128, 10, 256, 3), (7, 1, 48, 64, 3), (6, 64, 24, 128, 3), (5, 128, 12, 256, 3)])
+def test_pooled_forward_and_data_gradient_leave_exact_sample_magnitudes(shape):
+    """ddrl_op_conv_forward_pool(out_amax) / ddrl_op_conv_dgrad_pooled(din_amax): the arrays hold EXACTLY max |value written| per sample
+    (the operators raise a zeroed array with an atomic maximum; several row tiles meet in one slot), a sample decades below the rest
+    keeps its own magnitude, an all-zero gradient sample stays at 0, and a pre-raised slot is never lowered."""
+    from ddrl4nav_amd.ops import Conv, sample_amax
+    n, cin, h, cout, ks = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, h, device="cuda", generator=g)
+    x[1] *= 1e-4
+    wt = torch.randn(cout, cin, ks, ks, device="cuda", generator=g) / (cin * ks * ks) ** 0.5
+    b = 0.1 * torch.randn(cout, device="cuda", generator=g)
+    conv = Conv(cin, h, h, cout, ks, ks, pad=(1, 1), max_n=n)
+    conv.pack(wt)
+    assert conv.has_forward_pool()
+    oh = conv.oh
+    pooled = torch.empty((n, cout, oh // 2, oh // 2), device="cuda")
+    code = torch.empty((n, cout, oh // 2, oh // 2), dtype=torch.uint8, device="cuda")
+    out_amax = torch.zeros(n, device="cuda")
+    out_amax[2] = 1e30                                       # never lowered
+    in_amax = sample_amax(x, n, torch.empty(n, device="cuda")) if conv.pooled_uses_scales() else None
+    assert in_amax is None or torch.equal(in_amax, x.abs().amax(dim=(1, 2, 3)))
+    conv.forward_pool(x, b, pooled, code, n=n, in_amax=in_amax, out_amax=out_amax)
+    want = pooled.amax(dim=(1, 2, 3))
+    want[2] = 1e30
+    assert torch.equal(out_amax, want)
+    if cin > 4:                                              # first layers have no data gradient
+        dpool = torch.randn(pooled.shape, device="cuda", generator=g)
+        dpool[3] = 0.0
+        dpool[1] *= 1e-6
+        din = torch.empty((n, cin, h, h), device="cuda")
+        din_amax = torch.zeros(n, device="cuda")
+        conv.dgrad_pooled(dpool, code, din=din, n=n, din_amax=din_amax)
+        assert torch.equal(din_amax, din.abs().amax(dim=(1, 2, 3))) and float(din_amax[3]) == 0.0 and float(din_amax[1]) > 0.0
+
+
+@pytest.mark.parametrize("n", [300, 40])       # the fp16 plane kernels (n >= 128 rows) and the f32-input kernels below that
+def test_linear_data_gradient_leaves_row_magnitudes_of_a_column_slice(n):
+    """ddrl_op_linear_dgrad(din_amax, amax_lo, amax_hi): exact row maxima of |din| over the slice a consumer behind a torch.cat reads
+    (NavPreNet1D: fc1's data gradient feeds fc_1d through columns 0..255 and fc0 through 256..767), whole rows by default; masked
+    elements count as the zeros they are written as."""
+    from ddrl4nav_amd.ops import Linear
+    K, N, ld = 773, 512, 776
+    g = torch.Generator(device="cuda").manual_seed(n)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    dout = torch.randn(n, N, device="cuda", generator=g)
+    dout[5] *= 1e-5
+    dout[6] = 0.0
+    mask = torch.randn(n, ld, device="cuda", generator=g)
+    lin = Linear(K, N, max_n=n)
+    lin.pack(w)
+    for cols in (None, (0, 256), (256, 768)):
+        din = torch.zeros(n, ld, device="cuda")
+        amax = torch.zeros(n, device="cuda")
+        lin.dgrad(dout, N, mask, ld, din, ld, n, din_amax=amax, amax_cols=cols)
+        lo, hi = cols if cols is not None else (0, K)
+        assert torch.equal(amax, din[:, lo:hi].abs().amax(dim=1)), cols
+        assert float(amax[6]) == 0.0
+    close(din[:, :K], (dout @ w) * (mask[:, :K] > 0))
+
+
+def test_conv1d_forward_leaves_sample_magnitudes():
+    """The laser branch's second Conv1d (csrc/c1d.hip) leaves max |output| per sample for the dense layer that reads its rows; other
+    geometries take a pass over the output they just wrote (same values)."""
+    from ddrl4nav_amd.ops import Conv
+    for (n, cin, w_, cout, kw, stride) in ((133, 32, 478, 32, 3, 2), (5, 4, 64, 8, 4, 2)):
+        g = torch.Generator(device="cuda").manual_seed(n)
+        x = torch.randn(n, cin, 1, w_, device="cuda", generator=g)
+        x[2] *= 1e-3
+        wt = torch.randn(cout, cin, 1, kw, device="cuda", generator=g) / (cin * kw) ** 0.5
+        b = 0.1 * torch.randn(cout, device="cuda", generator=g)
+        conv = Conv(cin, 1, w_, cout, 1, kw, stride=stride, max_n=n)
+        conv.pack(wt)
+        amax = torch.zeros(n, device="cuda")
+        out = conv.forward(x, b, False, n=n, out_amax=amax)
+        assert torch.equal(amax, out.abs().amax(dim=(1, 2, 3)))
+        close(out, F.conv2d(x, wt, b, stride=(1, stride)))
