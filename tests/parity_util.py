@@ -388,6 +388,10 @@ def decision_digest(record):
     margin [n, sites]: the smallest distance of a decision from a tie (|max| of a window, or the gap between its two largest
     entries when the maximum is positive; |z| for a dense ReLU), relative to the site's largest |z| over the batch."""
     dig, margins = {}, []
+    if "fc_1d" in record:       # NavPreNet1D: the laser branch's dense layer comes first (tests/golden/make_golden_navpre.py)
+        z = record["fc_1d"].double()
+        margins.append((z.abs() / z.abs().amax()).amin(1))
+        dig["fc_1d_positive"] = (z > 0).sum(1).numpy().astype(np.int64)
     for site in ("conv1", "conv2", "conv3"):
         z = record[site].double()
         n, c, h, w = z.shape
@@ -533,7 +537,8 @@ def gail_param_deviation(name, tag, got, d_forced=None):
 NAV_CASES = {"f13_nav1d_gauss": ("NavPreNet1D", 3, 2, True, False, 13), "f14_navped_shared": ("NavPedPreNet", 4, 5, False, True, 14),
              "f15_mlp_classical": ("MLPPreNet", None, 2, False, False, 15),
              # the image-only shared encoder (runner/utils.py:104) and its no-tie batch (tests/golden/make_golden_navpre.py)
-             "f25_navpre_shared": ("NavPreNet", 1, 5, False, True, 25), "f26_navpre_unaligned": ("NavPreNet", 1, 5, False, True, 25)}
+             "f25_navpre_shared": ("NavPreNet", 1, 5, False, True, 25), "f26_navpre_unaligned": ("NavPreNet", 1, 5, False, True, 25),
+             "f27_nav1d_unaligned": ("NavPreNet1D", 3, 2, True, False, 27)}
 _NTRAJ = {}
 
 
