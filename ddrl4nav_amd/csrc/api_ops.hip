@@ -124,7 +124,7 @@ int32_t ddrl_op_conv_forward(const ddrl_conv_desc* d, const float* in, const flo
     launch_conv_planes_fwd(g, in, packed + v.off[5], scales_scratch, bias, act, out, (hipStream_t)stream);
   else   // any geometry, any stride / alignment (also the plane layers' when a strided view rules out their 16-byte loads)
     launch_conv_fwd(g, in, packed + v.off[0], (const int2*)(packed + v.off[1]), bias, act, out, (hipStream_t)stream);
-  if (out_amax && !conv_has_c1d(g)) launch_sample_amax(out, g.out_sn, g.cout * g.oh * g.ow, g.n, out_amax, (hipStream_t)stream);
+  if (out_amax && !conv_has_c1d(g)) launch_sample_amax(out, g.out_sn, g.cout * g.oh * g.ow, g.n, out_amax, (hipStream_t)stream, 1);
   return op_check();
 }
 

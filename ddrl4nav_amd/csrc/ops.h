@@ -35,7 +35,7 @@ void launch_conv_planes_fwd(const ConvGeom& g, const float* in, const float* wpf
                             hipStream_t st);
 void launch_conv_planes_dgrad(const ConvGeom& g, const float* dz, const float* wpd, float* scales, float* din, hipStream_t st);
 bool conv_planes_has_pool(const ConvGeom& g);     // forward with ReLU + max_pool2d(2) in the epilogue
-void launch_sample_amax(const float* x, int64_t sn, int elems, int n, float* amax, hipStream_t st);   // the pre-pass: amax[b] = max |x[b][:]|
+void launch_sample_amax(const float* x, int64_t sn, int elems, int n, float* amax, hipStream_t st, int accumulate = 0);   // amax[b] = (max with) max |x[b][:]|
 void launch_conv_planes_fwd_pool(const ConvGeom& g, const float* in, const float* wpf, float* scales, const float* given, const float* bias,
                                  float* pooled, uint8_t* code, float* out_amax, hipStream_t st);
 // gradients of such a layer from d(pooled) + decision bytes (scales / part as launch_conv_planes_dgrad / _wgrad)

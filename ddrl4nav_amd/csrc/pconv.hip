@@ -37,7 +37,7 @@ bool conv_has_planes(const ConvGeom&) { return false; }
 bool conv_planes_has_pool(const ConvGeom&) { return false; }
 int64_t conv_planes_pack_floats(const ConvGeom&) { return 0; }
 int conv_planes_wgrad_splits(const ConvGeom&) { return 0; }
-void launch_sample_amax(const float*, int64_t, int, int, float*, hipStream_t) {}
+void launch_sample_amax(const float*, int64_t, int, int, float*, hipStream_t, int) {}
 void launch_conv_planes_pack(const ConvGeom&, const float*, float*, float*, hipStream_t) {}
 void launch_conv_planes_fwd(const ConvGeom&, const float*, const float*, float*, const float*, int, float*, hipStream_t) {}
 void launch_conv_planes_dgrad(const ConvGeom&, const float*, const float*, float*, float*, hipStream_t) {}
@@ -72,7 +72,8 @@ struct Geo {
 };
 
 // Largest magnitude of every sample (the pre-pass for tensors whose producer does not leave it).  One workgroup per sample.
-__global__ __launch_bounds__(256) void sample_amax_kernel(const float* __restrict__ in, int64_t in_sn, int elems, float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void sample_amax_kernel(const float* __restrict__ in, int64_t in_sn, int elems, float* __restrict__ amax,
+                                                          int accumulate = 0) {
   __shared__ float red[4];
   const float* src = in + (int64_t)blockIdx.x * in_sn;
   float m = 0.0f;
@@ -84,7 +85,11 @@ __global__ __launch_bounds__(256) void sample_amax_kernel(const float* __restric
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (accumulate) amax_raise(m, amax + blockIdx.x);   // an `out_amax` filled by a pass over the output: raised, like the epilogues do
+    else amax[blockIdx.x] = m;
+  }
 }
 
 // ---- weights: largest magnitude, then the planes in the order the k index walks ----------------------------------------------
@@ -730,8 +735,8 @@ static PlanesId planes_id(const ConvGeom& g) {
 bool conv_has_planes(const ConvGeom& g) { return planes_id(g) != kPNone; }
 
 // per-sample power-of-two plane scales of x[n][elems] (sample stride sn): what the plane kernels compute in their pre-pass
-void launch_sample_amax(const float* x, int64_t sn, int elems, int n, float* scales, hipStream_t st) {
-  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, x, sn, elems, scales);
+void launch_sample_amax(const float* x, int64_t sn, int elems, int n, float* amax, hipStream_t st, int accumulate) {
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, x, sn, elems, amax, accumulate);
 }
 
 // floats of ONE packed region (forward or data gradient): the planes (2 bytes x 2 planes per weight = 4 bytes) + a 64-float header
@@ -761,7 +766,7 @@ static void run_planes(const float* in, int64_t in_sn, const float* region, int6
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales, 0);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
                      in_sn, (const unsigned short*)region, region + planes, scales, bias, act, out, out_sn, (uint8_t*)nullptr, (const uint8_t*)nullptr, out_amax, n);
 }
@@ -774,7 +779,7 @@ static void run_planes_pool(const float* in, int64_t in_sn, const float* region,
     (void)hipFuncSetAttribute((const void*)pconv::direct_planes_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
     configured = true;
   }
-  if (!given) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales);
+  if (!given) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, in, in_sn, K::CIN * K::RAW, scales, 0);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES, st, in,
                      in_sn, (const unsigned short*)region, region + planes, given ? given : scales, bias, 1, pooled, (int64_t)K::COUT * (K::P / 4), code, (const uint8_t*)nullptr, out_amax, n);
 }
@@ -790,7 +795,7 @@ static void run_planes_unpool(const float* dpool, const uint8_t* ucode, const fl
     configured = true;
   }
   constexpr int64_t PSN = (int64_t)K::CIN * K::RAW / 4;
-  if (!given) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales);
+  if (!given) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)n), dim3(256), 0, st, dpool, PSN, (int)PSN, scales, 0);
   hipLaunchKernelGGL((pconv::direct_planes_kernel<K, false, true>), dim3((unsigned)((n + K::NS - 1) / K::NS), K::COUT / 64, 1), dim3(K::THREADS), K::LDS_BYTES,
                      st, dpool, PSN, (const unsigned short*)region, region + planes, given ? given : scales, (const float*)nullptr, 0, din, din_sn, (uint8_t*)nullptr, ucode, out_amax, n);
 }
@@ -885,8 +890,8 @@ static void run_planes_wgrad(const ConvGeom& g, const float* in, const float* dz
   }
   float* sc_in = scales;
   float* sc_dz = scales + g.n;
-  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
-  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dz, g.out_sn, K::COUT * K::P, sc_dz);
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in, 0);
+  hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dz, g.out_sn, K::COUT * K::P, sc_dz, 0);
   hipLaunchKernelGGL(pconv::wgrad_planes_kernel<K>, dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in, g.in_sn,
                      dz, g.out_sn, (const uint8_t*)nullptr, sc_in, sc_dz, part, g.n, S);
 }
@@ -902,8 +907,8 @@ static void run_planes_wgrad_pooled(const ConvGeom& g, const float* in, const fl
   float* sc_in = scales;
   float* sc_dz = scales + g.n;
   constexpr int64_t PSN = (int64_t)K::COUT * K::P / 4;
-  if (!given_in) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in);
-  if (!given_dp) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz);  // max |d(pooled)| bounds max |dz|
+  if (!given_in) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, in, g.in_sn, K::CIN * K::RAW, sc_in, 0);
+  if (!given_dp) hipLaunchKernelGGL(pconv::sample_amax_kernel, dim3((unsigned)g.n), dim3(256), 0, st, dpool, PSN, (int)PSN, sc_dz, 0);  // max |d(pooled)| bounds max |dz|
   hipLaunchKernelGGL((pconv::wgrad_planes_kernel<K, true>), dim3((unsigned)((K::CIN / K::ICW) * S), K::COUT / 64, 1), dim3(256), K::LDS_BYTES, st, in,
                      g.in_sn, dpool, PSN, ucode, given_in ? given_in : sc_in, given_dp ? given_dp : sc_dz, part, g.n, S);
 }
