@@ -213,6 +213,28 @@ def test_bench_launches_its_own_ranks():
     assert d["allreduce"]["algbw_gbps"] > 0
 
 
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """The driver's own form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`.  On this one-GPU box the two ranks share the device and reduce over gloo
+    (DDRL_DIST_BACKEND=gloo); rank 0 prints ONE line with n_gpus = 2, the launcher named, identical replicas, K timed steps."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DDRL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--envs", "32", "--horizon", "16", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["launcher"] == "torchrun" and d["steps"] == 2 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2" and len(d["elapsed_s_per_rank"]) == 2
+    assert d["replicas_identical"] is True and d["replicas"]["optimizer_steps"] == [30, 30]
+    assert d["value"] == pytest.approx(2 * 32 * 16 * 2 / max(d["elapsed_s_per_rank"]), rel=1e-3)      # whole-job units / slowest rank's time
+    assert d["allreduce"]["calls"] == 20 and d["step_ms"]["n"] == 2
+
+
 def test_torch_nccl_bucketed_allreduce_one_rank(tmp_path):
     """What RCCL ranks run by default at N > 1 (torch.distributed nccl backend, layer buckets reduced on a communication stream behind
     the backward's events, the compute stream waiting for the last one) on this one-GPU box: a one-rank nccl group in a fresh
