@@ -193,7 +193,30 @@ def load():
         raise DdrlError("libddrl_hip.so ABI version %d, this binding needs %d: rebuild with `make -C ddrl4nav_amd/csrc`"
                         % (got, ABI_VERSION))
     _lib = lib
+    _warn_removed_switches()
     return lib
+
+
+# environment switches of earlier rounds that no longer do anything: a launch script that still sets one keeps running,
+# so say once what replaced it instead of ignoring it silently
+REMOVED_SWITCHES = {
+    "DDRL_ALLREDUCE_OVERLAP": "use DDRL_ALLREDUCE=overlap (or rccl,overlap)",
+    "DDRL_ENC_STREAMS": "set net.encoder_streams = False on the GenericPPO instance",
+    "DDRL_NAV_F32": "the f32-input direct-convolution family was removed",
+    "DDRL_FIRST_F32": "the f32-input direct-convolution family was removed",
+    "DDRL_LIN_F32": "the f32-input dense kernels are chosen by shape only",
+    "DDRL_POOL_UNFUSED": "pooling is fused wherever the layer has a plane kernel",
+    "DDRL_POOL_BWD_UNFUSED": "pooling is fused wherever the layer has a plane kernel",
+    "DDRL_SCALES_PER_OP": "set encoder.producer_amax = False (nn/generic.py PRODUCER_AMAX) for the pre-pass arrangement",
+    "DDRL_C1D_GATHER": "the laser branch always runs csrc/c1d.hip",
+}
+
+
+def _warn_removed_switches():
+    import warnings
+    for k, hint in REMOVED_SWITCHES.items():
+        if k in os.environ:
+            warnings.warn("%s is set but was removed and has no effect: %s" % (k, hint), RuntimeWarning, stacklevel=3)
 
 
 def check(status):

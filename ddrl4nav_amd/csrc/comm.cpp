@@ -4,8 +4,10 @@
 //
 // librccl is resolved at run time (dlopen): libddrl_hip.so carries no link dependency on it, a single-GPU host without RCCL
 // still loads the library, and inside a PyTorch process the RCCL that torch already loaded is the one that gets used.
+//
+// Pure host code (no HIP header: the stream crosses this file as the opaque pointer it is), so that `make asan` can build it with
+// g++ -fsanitize=address,undefined next to easybytes.cpp.
 #include <dlfcn.h>
-#include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstring>
@@ -21,6 +23,7 @@ struct nccl_unique_id {
   char internal[128];
 };
 typedef void* nccl_comm_t;
+typedef void* hipStream_t;  // ihipStream_t* in the HIP headers: opaque here
 typedef int (*fn_get_unique_id)(nccl_unique_id*);
 typedef int (*fn_comm_init_rank)(nccl_comm_t*, int, nccl_unique_id, int);
 typedef int (*fn_comm_destroy)(nccl_comm_t);

@@ -65,10 +65,11 @@ int32_t ddrl_eb_array_bytes(int32_t dtype, int32_t ndim, const int64_t* dims, in
   int64_t count = 1;
   for (int i = 0; i < ndim; ++i) {
     if (dims[i] < 0 || dims[i] > 0xFFFFFFFFll) return DDRL_ERR_INVALID_ARG;
+    // the wire format stores count as uint32: test BEFORE multiplying (two 32-bit factors can pass INT64_MAX)
+    if (dims[i] != 0 && count > 0xFFFFFFFFll / dims[i]) return DDRL_ERR_INVALID_ARG;
     count *= dims[i];
   }
-  if (count > 0xFFFFFFFFll) return DDRL_ERR_INVALID_ARG;  // the wire format stores count as uint32
-  *nbytes = 2 + 8 + 4 * (int64_t)ndim + count * isz;
+  *nbytes = 2 + 8 + 4 * (int64_t)ndim + count * isz;  // count <= 2^32 - 1, isz <= 8: no wrap
   return DDRL_OK;
 }
 
@@ -80,7 +81,7 @@ int32_t ddrl_eb_encode_array(int32_t dtype, int32_t ndim, const int64_t* dims, c
   if (!out || !written || (!data && need > 10 + 4 * ndim)) return DDRL_ERR_INVALID_ARG;
   if (need > cap) return DDRL_ERR_WORKSPACE;
   int64_t count = 1;
-  for (int i = 0; i < ndim; ++i) count *= dims[i];
+  for (int i = 0; i < ndim; ++i) count *= dims[i];  // bounded by ddrl_eb_array_bytes above
   put16(out, (uint16_t)dtype);
   put32(out + 2, (uint32_t)count);
   put32(out + 6, (uint32_t)ndim);
@@ -108,8 +109,10 @@ int32_t ddrl_eb_scan(const uint8_t* buf, int64_t len, ddrl_eb_array* out, int32_
     std::memset(&a, 0, sizeof(a));
     for (int d = 0; d < ndim; ++d) {
       a.dims[d] = be32(buf + i + 10 + 4 * d);
+      // count is a uint32 on the wire.  The test comes BEFORE the product: prod and the dim are both < 2^32, so prod * dim can reach
+      // 1.8e19 > INT64_MAX (signed overflow, undefined) if multiplied first
+      if (a.dims[d] != 0 && prod > 0xFFFFFFFFll / a.dims[d]) return DDRL_ERR_INVALID_ARG;
       prod *= a.dims[d];
-      if (prod > 0xFFFFFFFFll) return DDRL_ERR_INVALID_ARG;  // count is a uint32 on the wire; also keeps prod from wrapping
     }
     if (prod != count) return DDRL_ERR_INVALID_ARG;
     a.dtype = dtype;

@@ -550,7 +550,7 @@ enum FirstId { kFNone = 0, kFN1d, kFNav, kFPed };
 
 static FirstId first_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
-  return kFNone;
+  return kFNone;  // diagnostic three-plane build: first layers on the generic gather kernels (gconv.hip) as well
 #else
   if (g.stride != 1 || g.h != 48 || g.w != 48 || g.kh != g.kw || g.pad_h != 1 || g.pad_w != 1 || g.cout != 64) return kFNone;
   if (g.kh == 7 && g.cin == 3) return kFN1d;

@@ -718,7 +718,9 @@ enum PlanesId { kPNone = -1, kPN1dC2, kPN1dC3, kPNavC2, kPNavC3, kPAtC3 };
 
 static PlanesId planes_id(const ConvGeom& g) {
 #ifdef DDRL_PLANES_BF16
-  return kPNone;  // the three-plane build keeps the f32-input kernels of dconv.hip
+  // the three-plane diagnostic build (accuracy attribution only, never the shipped library) has no specialised plane kernels: every
+  // nav layer then runs on the generic gather kernels of gconv.hip (f32 inputs, three bf16 planes: several times slower)
+  return kPNone;
 #else
   if (g.stride != 1 || g.h != g.w || g.kh != g.kw || g.pad_h != g.pad_w) return kPNone;
   const auto is = [&](int cin, int cout, int ks, int h) { return g.cin == cin && g.cout == cout && g.kh == ks && g.h == h; };

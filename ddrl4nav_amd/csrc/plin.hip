@@ -38,15 +38,17 @@ constexpr int LDS_NT = 2 * STAGE + 2 * 128 * 4;        // + the tile's row scale
 constexpr int LDS_TN = 2 * STAGE;
 
 // Largest magnitude of every row (the pre-pass for tensors whose producer does not leave it).  One wave per row.  accumulate: raise
-// the slot instead of overwriting it (a row assembled from several producers: torch.cat).
-__global__ __launch_bounds__(256) void row_amax_kernel(const float* __restrict__ x, int64_t ld, int width4, int n, float* __restrict__ amax, int accumulate) {
+// the slot instead of overwriting it (a row assembled from several producers: torch.cat).  Loads are 16 bytes wide (rows are padded to
+// a multiple of four floats); columns >= width of the last load are the row's padding or a neighbour's columns and are masked out.
+__global__ __launch_bounds__(256) void row_amax_kernel(const float* __restrict__ x, int64_t ld, int width, int n, float* __restrict__ amax, int accumulate) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n) return;
   const float* src = x + (int64_t)row * ld;
   float m = 0.0f;
-  for (int i = lane * 4; i < width4; i += 256) {
+  for (int i = lane * 4; i < width; i += 256) {
     const f4 v = ld4(src + i);
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const float y = i + 1 < width ? fabsf(v.y) : 0.0f, z = i + 2 < width ? fabsf(v.z) : 0.0f, w = i + 3 < width ? fabsf(v.w) : 0.0f;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), y)), fmaxf(z, w));
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -468,7 +470,7 @@ static void run_nt(const plin::NtParams& p, dim3 grid, hipStream_t st) {
 }
 
 static void row_scales(const float* x, int64_t ld, int width, int n, float* amax, hipStream_t st, int accumulate = 0) {
-  hipLaunchKernelGGL(plin::row_amax_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, ld, (width + 3) / 4 * 4, n, amax, accumulate);
+  hipLaunchKernelGGL(plin::row_amax_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, ld, width, n, amax, accumulate);
 }
 
 int linear_planes_fwd_splits(int n, int K, int N) {

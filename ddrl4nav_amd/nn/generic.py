@@ -23,7 +23,10 @@ from ddrl4nav_amd.ops import Conv, Linear, maxpool2_idx, maxpool2_backward_idx, 
 from ddrl4nav_amd.utils.staging import to_device
 
 FEAT = 512
-PRODUCER_AMAX = True   # per-sample magnitudes travel from a tensor's producer to its consumer (include/ddrl.h); False: pre-passes (A/B)
+# per-sample magnitudes travel from a tensor's producer to its consumer (include/ddrl.h); False: a pre-pass in front of every consumer.
+# Default for encoders BUILT from here on: each encoder keeps its own `producer_amax` (like GenericPPO.encoder_streams), so flipping
+# this mid-training does not reach live nets.
+PRODUCER_AMAX = True
 
 
 def _pad4(k):
@@ -195,7 +198,9 @@ class _ConvPool:
                 self._in_amax = in_amax if in_amax is not None else sample_amax(x, n, self.in_sc)
             self.op.forward_pool(x, self.m.bias.data, self.p, self.code, n=n, in_amax=self._in_amax, out_amax=out_amax)
             return self.p
-        self.op.forward(x, self.m.bias.data, self.relu, out=self._a, n=n, out_amax=None if self.pool else out_amax)
+        # a pooled block's consumer reads the pooled map: every pooled value is one of `a`'s, so max|a| bounds it (equal under ReLU on
+        # even maps); the row must be raised here too, the next block trusts it (conv1 with a non-specialised cin runs this path)
+        self.op.forward(x, self.m.bias.data, self.relu, out=self._a, n=n, out_amax=out_amax)
         if not self.pool:
             return self._a
         maxpool2_idx(self._a[:n], out=self.p, code=self.code)
@@ -285,15 +290,16 @@ class _NavBase(GenericPreNet):
         self.flat_dim = flat_dim
 
     def _links(self, *rows):
-        """The arena rows handed from producers to consumers; PRODUCER_AMAX = False (tools/ab_nav_amax.py, same-box A/B) hands out
+        """The arena rows handed from producers to consumers; producer_amax = False (tools/ab_nav_amax.py, same-box A/B) hands out
         None instead, i.e. every consumer runs its own pre-pass as in round 4."""
-        return rows if PRODUCER_AMAX else (None,) * len(rows)
+        return rows if self.producer_amax else (None,) * len(rows)
 
     def _amax_arena(self, cap, device, n_fwd, n_bwd):
         """Per-sample magnitudes that travel from a tensor's producer to its consumer (include/ddrl.h): one row per tensor, zeroed at
         the start of a pass (one fill per pass and encoder), raised by the producers' epilogues."""
         self._amax_f = torch.zeros((n_fwd, cap), dtype=torch.float32, device=device)
         self._amax_b = torch.zeros((n_bwd, cap), dtype=torch.float32, device=device)
+        self.producer_amax = bool(PRODUCER_AMAX)
 
     def _tail_forward(self, flat, vec, n, flat_amax=None):
         # torch.cat((x, state[1]), dim=1): fc0 writes its slice of the cat buffer directly

@@ -14,11 +14,66 @@ batch and per yielded iteration is kept, with the same config constants:
   * the train lock key is cleared after every batch (backward.py:212-213);
   * ``TEST`` skips training (backward.py:188).
 ``pipe`` is anything with ``set / incr / execute`` (a redis pipeline, or an in-process stand-in when Forward and Backward
-are co-located); ``log`` receives ``(key, value, update_time)``."""
+are co-located); ``log`` receives ``(key, value, update_time)``.
+
+The learner's side of the Redis drop-in, upstream of ``consume`` (round 6): ``decode_train_blob`` is the body of
+``BackwardGetDataThread.get_train_data`` (backward.py:145-151) after the BRPOP -- one ``encode_backward_data`` blob (the >= 128-sample
+pieces ``TrainingProcess.run`` pushes, agent/multiqueue.py:83-105) -> ``(Experience, dict_logger)``; ``BackwardQueue.get(batch_size)``
+is backward.py:48-62 -- pop items until >= ``TRAINING_MIN_BATCH`` samples, ``Experience.batch_data`` them, average the logger dicts
+(``batch_logger``, backward.py:30-39); ``BackwardTrainer.train_from_queue`` is one turn of the trainer's while-loop (backward.py:184-187)."""
+import queue
 import time
 from collections import defaultdict
+from typing import Dict, List, Tuple
 
+import numpy as np
 import torch
+
+from ddrl4nav_amd.data.experience import Experience
+
+
+def batch_logger(p: List[Dict]) -> Dict:
+    """Key-wise mean of the env-statistics dicts that arrived with the gathered blobs (backward.py:30-39; keys of the first)."""
+    if len(p) == 0:
+        return {}
+    return {key: float(np.mean([j[key] for j in p])) for key in p[0]}
+
+
+def decode_train_blob(easy_bytes, batch_bytes) -> Tuple[Experience, Dict]:
+    """backward.py:148-149: states arrays + [advs, actions, old_logps, values] + the marshalled logger dict of one blob."""
+    list_np_states, list_np_other4, dict_logger = easy_bytes.decode_backward_data(batch_bytes)
+    return Experience(list_np_states, *list_np_other4), dict_logger
+
+
+class BackwardQueue:
+    """backward.py:42-65.  The reference's MultiQueue is a multiprocessing queue between its getter and trainer THREADS of one process
+    (manager/trainer_manager.py:19-41); a thread-safe ``queue.Queue`` serves the same two threads here."""
+
+    def __init__(self, maxsize=0):
+        self.q = queue.Queue(maxsize)
+
+    def get(self, batch_size, *args) -> Tuple[Experience, Dict]:
+        """Blocks (``*args`` = ``queue.Queue.get``'s block / timeout; a timeout raises ``queue.Empty``) until the gathered pieces hold at
+        least ``batch_size`` samples: never fewer, possibly more (whole pieces only), in arrival order."""
+        cur_size = 0
+        list_exp: List[Experience] = []
+        list_dict: List[dict] = []
+        while cur_size < batch_size:
+            data, dict_logger = self.q.get(*args)
+            assert isinstance(data, Experience)
+            assert isinstance(dict_logger, dict)
+            cur_size += len(data)
+            list_exp.append(data)
+            if len(dict_logger):
+                list_dict.append(dict_logger)
+        return Experience.batch_data(list_exp), batch_logger(list_dict)
+
+    def put(self, data: Tuple[Experience, Dict], *args) -> None:
+        self.q.put(data, *args)
+
+    def put_blob(self, easy_bytes, batch_bytes, *args) -> None:
+        """get_train_data (backward.py:145-151) without the BRPOP / lock SET around it."""
+        self.put(decode_train_blob(easy_bytes, batch_bytes), *args)
 
 
 class BackwardTrainer:
@@ -38,6 +93,7 @@ class BackwardTrainer:
         self.test = getattr(config, "TEST", False)
         self.device = net.device
         self.tensortype = config_nn.MODULE_TENSOR_DTYPE
+        self.min_batch_size = config_nn.TRAINING_MIN_BATCH
         self.data_len = 0
         self.published = self.saved = 0
         self._loss = defaultdict(list)
@@ -53,6 +109,11 @@ class BackwardTrainer:
             self.net.load_state_dict(torch.load(self.load_checkpoint_path, map_location=self.device))
         self._publish()
         self._started = True
+
+    def train_from_queue(self, training_data_queue, *args):
+        """One turn of the while-loop (backward.py:184-187): gather >= TRAINING_MIN_BATCH samples from the queue, then ``consume``."""
+        train_data, dict_logger = training_data_queue.get(self.min_batch_size, *args)
+        return self.consume(train_data, dict_logger)
 
     def consume(self, train_data, dict_logger=None):
         """One pass of the while-loop body; returns the (shifted) update_time of the last iteration."""

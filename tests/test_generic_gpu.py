@@ -393,6 +393,63 @@ def test_producer_magnitudes_equal_the_prepass_bit_for_bit(golden, name):
         assert all(la[k] == lb[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss"))
 
 
+@pytest.mark.parametrize("ped", [0, 3])
+def test_stacked_image_batch_takes_the_unfused_first_layer(ped):
+    """`image_batch` = 2 gives conv1 an input-channel count no specialised first-layer kernel takes (fconv.hip: 1 or 4
+    channels for 3x3, 3 for 7x7), so the first block runs conv + stand-alone pool -- and must still leave the per-sample magnitudes the
+    fused second block scales its fp16 planes by (a zero row means scale 2^60 and Inf / NaN planes).  NavPreNet(2) (runner/utils.py:104)
+    and NavPedPreNet(5) (:100): forward and one learn() against the CPU oracle, and bit-identical to the pre-pass arrangement."""
+    from ddrl4nav_amd.data import Experience
+    from ddrl4nav_amd.nn import generic
+    from ddrl4nav_amd.runner import create_net
+    from oracle import ddrl_oracle_nav as N
+    env = {"discrete_action": True, "discrete_actions": list(range(5)), "image_batch": 2, "ped_sim": {"total": ped}}
+    B = 96
+    rng = np.random.default_rng(60 + ped)
+    states = [(rng.random((B, 2, 48, 48)) < 0.3).astype(np.float32), rng.normal(size=(B, 9)).astype(np.float32)]
+    if ped:
+        states.append((rng.random((B, 3, 48, 48)) < 0.1).astype(np.float32))
+    states[0][5] *= 1e-4                 # one sample decades below the others: its scale must follow it
+    acts = rng.integers(0, 5, B).astype(np.float32)
+    adv, ret = rng.normal(size=B).astype(np.float32), rng.normal(size=B).astype(np.float32)
+    old = np.full(B, -1.7, np.float32)
+    outs = []
+    try:
+        for flag in (True, False):
+            generic.PRODUCER_AMAX = flag
+            net = create_net(_configs(env, shared=True), max_batch=64)     # two micro-batches, the second one ragged
+            enc = net.prenet
+            assert type(enc).__name__ == ("NavPedPreNet" if ped else "NavPreNet") and enc.image_channel == (5 if ped else 2)
+            assert enc.producer_amax is flag and not enc.c1.fused and enc.c2.fused
+            w = hash_weights([(k, tuple(p.shape)) for k, p in net.named_parameters()], 61)
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+            (dist, logp), values = net([torch.from_numpy(s) for s in states], torch.from_numpy(acts))
+            fwd = (values[0].cpu().numpy()[:, 0].copy(), logp.cpu().numpy().copy())
+            exp = Experience(states=[torch.from_numpy(s).cuda() for s in states], advs=torch.from_numpy(adv).cuda(),
+                             actions=torch.from_numpy(acts).cuda(), old_logps=torch.from_numpy(old).cuda(),
+                             values=torch.from_numpy(ret[None]).cuda())
+            net.training_iter_time = 2
+            losses = [l for l, _, _ in net.learn(exp)]
+            outs.append((net.params.clone(), losses, fwd, w))
+    finally:
+        generic.PRODUCER_AMAX = True
+    assert torch.equal(outs[0][0], outs[1][0]) and bool(torch.isfinite(outs[0][0]).all())
+    for la, lb in zip(outs[0][1], outs[1][1]):
+        assert all(la[k] == lb[k] for k in ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss"))
+    ora = N.OracleNet((lambda: N.NavPedPreNet(5)) if ped else (lambda: N.NavPreNet(2)), 5, False, True)
+    ora.load_weights(outs[0][3])
+    t = [torch.from_numpy(s) for s in states]
+    with torch.no_grad():
+        _, ologp, _, ov = ora(t, torch.from_numpy(acts))
+    np.testing.assert_allclose(outs[0][2][0], ov.numpy()[:, 0], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(outs[0][2][1], ologp.numpy(), rtol=2e-5, atol=2e-5)
+    ol = [l for l, _, _ in N.learn(ora, ora.make_optims(), t, torch.from_numpy(acts), torch.from_numpy(old), torch.from_numpy(adv),
+                                   torch.from_numpy(ret), iters=2)]
+    for got, want in zip(outs[0][1], ol):
+        for k in ("ActorLoss", "VLoss", "EntLoss", "PpoTotalLoss"):
+            np.testing.assert_allclose(got[k], want[k], rtol=2e-4, atol=2e-5, err_msg=k)
+
+
 def test_nav_two_encoder_streams_are_bit_identical():
     """The robot_nav learner with the critic's encoder on its own stream equals the one-stream run (`net.encoder_streams = False`)
     bit for bit: independent buffers and gradient slices, no atomics between them."""

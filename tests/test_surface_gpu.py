@@ -735,6 +735,79 @@ def test_backward_trainer_publish_save_and_checkpoint_offsets(net, golden, tmp_p
     net.load_state_dict(w0)
 
 
+def test_learner_side_redis_chain_blobs_gather_learn_equals_the_direct_path():
+    """The learner's side of the Redis drop-in END TO END: what reference env workers push --
+    ``encode_backward_data`` blobs of >= 128 samples each (agent/multiqueue.py:83-105) whose frames are FLOAT64 ``u8 / 255.0``
+    (warputils.py:300) -- through ``decode_backward_data`` (C codec) -> ``BackwardQueue.get(TRAINING_MIN_BATCH)`` (backward.py:48-62: eight
+    ragged pieces = 1,152 samples, the ninth stays queued) -> ``BackwardTrainer.consume`` (``to_tensor`` float64 -> float32 -> device,
+    backward.py:185) -> ``net.learn``: the ten yielded loss dicts and the final parameters are BIT-IDENTICAL to handing the same 1,152
+    samples to ``learn`` as uint8 frames, and follow the CPU oracle's fp32 ``learn`` on them (first iteration at the single-step
+    tolerance, the trajectory at 1e-3: its pinned bounds are F4 / F21's, which the direct path carries)."""
+    from ddrl4nav_amd.data import EasyBytes, Experience
+    from ddrl4nav_amd.runner import create_net
+    from ddrl4nav_amd.server import BackwardQueue, BackwardTrainer
+    c = _configs()
+    cfg, cfg_nn = c["config"], c["config_nn"]
+    assert cfg_nn.TRAINING_MIN_BATCH == 1024 and cfg_nn.TRAINING_ITER_TIME == 10
+    cfg.LOG_LOSS_FREQUENCY, cfg.SAVE_MODELS = 1, False
+    sizes = [128, 150, 131, 160, 129, 144, 128, 182, 133]                 # the first eight hold 1,152 >= 1,024; seven hold 970
+    B = sum(sizes[:8])
+    rng = np.random.default_rng(64)
+    frames = rng.integers(0, 256, size=(sum(sizes), 4, 84, 84), dtype=np.uint8)
+    frames[::3] = (frames[::3] // 32) * 32
+    n_all = frames.shape[0]
+    acts = rng.integers(0, 6, n_all).astype(np.float32)
+    old = (np.log(1 / 6) + 0.05 * rng.normal(size=n_all)).astype(np.float32)
+    advs, rets = rng.normal(size=n_all).astype(np.float32), rng.normal(size=n_all).astype(np.float32)
+    w = make_weights(0)
+    n = create_net(c, max_batch=B)
+    keys = ("PpoTotalLoss", "ActorLoss", "VLoss", "EntLoss")
+
+    def fresh():
+        n.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+        n.hot_path.reset_optimizer()
+        n.update_time = 0
+
+    # (a) the direct path: the same 1,152 samples as uint8 frames
+    fresh()
+    direct = [l for l, _, _ in n.learn(Experience(states=[frames[:B]], advs=advs[:B], actions=acts[:B], old_logps=old[:B],
+                                                  values=rets[None, :B]))]
+    p_direct = n.hot_path.params.clone()
+    # (b) the chain: blobs -> decode -> gather -> consume -> learn
+    fresh()
+    eb, q = EasyBytes("127.0.0.1"), BackwardQueue()
+    at = 0
+    for i, m in enumerate(sizes):
+        sl = slice(at, at + m)
+        at += m
+        xrapv = [[frames[sl] / 255.0], advs[sl], acts[sl], old[sl], rets[None, sl]]
+        assert xrapv[0][0].dtype == np.float64
+        q.put_blob(eb, eb.encode_backward_data(xrapv, {"RewardEpisode": float(i)}))
+    logged = []
+    tr = BackwardTrainer(n, cfg, cfg_nn, pipe=None, log=lambda k, v, t: logged.append((k, v, t)))
+    assert tr.train_from_queue(q) == 10 and tr.data_len == B and q.q.qsize() == 1
+    chain = [{k: v for k, v, t in logged if t == it and k in keys} for it in range(1, 11)]
+    assert ("RewardEpisode", {"mean": 3.5}, B) in logged                 # batch_logger over the eight gathered dicts, at data_len
+    for a, b in zip(direct, chain):
+        assert all(a[k] == b[k] for k in keys), (a, b)
+    assert torch.equal(n.hot_path.params, p_direct)
+    # (c) the oracle's learn on the same samples
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, max(1, (__import__("os").cpu_count() or 1))))
+    try:
+        onet = O.OraclePPO()
+        onet.load_weights(w)
+        t = torch.from_numpy
+        ora = [l for l, _, _ in O.learn(onet, onet.make_optims(), O.frames_to_f32(frames[:B]), t(acts[:B]), t(old[:B]), t(advs[:B]),
+                                        t(rets[:B]), iters=10)]
+    finally:
+        torch.set_num_threads(threads)
+    for it, (got, want) in enumerate(zip(chain, ora)):
+        for k in keys:
+            np.testing.assert_allclose(got[k], want[k], rtol=1e-5 if it == 0 else 1e-3, atol=1e-6 if it == 0 else 1e-5, err_msg="%s it%d" % (k, it))
+    n.hot_path.close()
+
+
 def test_deferred_loss_readback_yields_the_same_values(golden):
     """net.deferred_stats = True (bench.py, DEFERRED_LOSS_READBACK): all iterations enqueued, one host sync, then the yields --
     bit-identical loss dicts and parameters to the per-iteration protocol."""

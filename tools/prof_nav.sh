@@ -6,7 +6,10 @@ TAG=${1:-rXX_nav}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
-echo "{\"batch\": 4096, \"build\": \"${DDRL_PROFILE_BUILD:-unknown} ($TAG)\"}" > "$OUT/meta.json"
+# the build the summaries are stamped with (tools/pmc_to_profiles.py refuses "unknown"): fail before the passes, not after them
+BUILD=${DDRL_PROFILE_BUILD:-$(git rev-parse --short HEAD 2>/dev/null || true)}
+if [ -z "$BUILD" ]; then echo "set DDRL_PROFILE_BUILD=<git short hash> (the GPU box has no .git)" >&2; exit 2; fi
+echo "{\"batch\": 4096, \"build\": \"$BUILD ($TAG)\"}" > "$OUT/meta.json"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$REPO/tools/bench_nav.py" 4096 4096 2 > "$OUT/nav_under_rocprof.json" 2> "$OUT/kt.err"; echo "kernel-trace rc=$?"
 find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;

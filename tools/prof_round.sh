@@ -8,8 +8,11 @@ TAG=${1:-rXX}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
+# the build the summaries are stamped with (tools/pmc_to_profiles.py refuses "unknown"): fail before the passes, not after them
+BUILD=${DDRL_PROFILE_BUILD:-$(git rev-parse --short HEAD 2>/dev/null || true)}
+if [ -z "$BUILD" ]; then echo "set DDRL_PROFILE_BUILD=<git short hash> (the GPU box has no .git)" >&2; exit 2; fi
 # what the summaries must carry (tools/pmc_to_profiles.py): the profiled build and the batch of the PMC passes (tools/profile_iter.py: 65,536)
-echo "{\"batch\": 65536, \"build\": \"${DDRL_PROFILE_BUILD:-unknown} ($TAG)\"}" > "$OUT/meta.json"
+echo "{\"batch\": 65536, \"build\": \"$BUILD ($TAG)\"}" > "$OUT/meta.json"
 python3 bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-async --no-ingest --no-nav > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" ); echo "kernel-trace rc=$?"
 find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
