@@ -10,6 +10,8 @@
 //
 // Reference: autograd weight/bias gradients of conv1..conv3 (atari_encoder.py:16-18 through
 // actor_loss.backward(); v_loss.backward(), ppo.py:122-123).
+#include <type_traits>
+
 #include "engine2.h"
 
 namespace ddrl {
@@ -459,6 +461,249 @@ __global__ __launch_bounds__(256) void conv_wgrad2_planes_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same weight gradient as a two-buffer software pipeline (round 6; -DDDRL_W2_PIPE=0: the one-stage kernel above).
+// conv_wgrad2_planes_kernel runs ONE wave per SIMD (128 accumulators, 111 KB of LDS) and alternates "multiply the stage" with "split
+// + commit the next stage": nothing covers the commit (its counters: matrix pipe busy 0.41, 3.1 vector instructions per MFMA, all of
+// them outside the matrix phase).  Here a sample is cut into two HALF-STAGES of three k-groups -- output rows y 0..4 (45 pixels, a1
+// rows 0..11) and y 5..8 (36 pixels, a1 rows 10..19) -- each with its own LDS buffer (12 + 46 KB and 12 + 38 KB: 106.5 KB together,
+// LESS than the one stage, which held all 20 rows at once).  While the waves multiply one buffer they split and commit the next
+// half-stage into the other and request the one after it, one staging unit per pair of tap blocks, so the vector work sits in the
+// shadow of the wave's own MFMAs and there is ONE barrier per half-stage.  Rows 10 and 11 are staged twice (+10 % of the a1 reads);
+// 48 staging registers instead of 80.  Results: the same products in another grouping of the reduction index (bias sums bit-identical).
+// ------------------------------------------------------------------------------------------------
+#ifndef DDRL_W2_PIN
+#define DDRL_W2_PIN 4  // vector instructions pinned into each gap between the MFMAs of a tap block (0: the compiler's own order)
+#endif
+#ifndef DDRL_W2_SPLIT
+#define DDRL_W2_SPLIT split_planes  // the four-instruction v_fma_mix form (engine2.h); split_planes_c = the plain one, which the compiler packs
+                                    // into v_pk_mul / v_pk_fma beside the MFMAs: 2.65 against 2.58 ms, profiles/r06_w2pipe_ab_bench.txt
+#endif
+#ifndef DDRL_W2_PIPE
+#ifdef DDRL_PLANES_BF16
+#define DDRL_W2_PIPE 0  // three planes per operand: the two buffers exceed the LDS
+#else
+#define DDRL_W2_PIPE 1
+#endif
+#endif
+struct Wgrad2P {
+  static constexpr int BP = DDRL_W2_BPITCH, NKG = 3, AROWS = NKG * 16;
+  static constexpr int KAP0 = 45, KAP1 = 36;                  // output pixels of the halves: y 0..4 / y 5..8
+  static constexpr int ROW1 = 10;                             // first a1 row of half 1
+  static constexpr int PX0 = 12 * 20, PX1 = 10 * 20;          // a1 pixels staged per half: rows 0..11 / 10..19
+  static constexpr int A_PLANE = AROWS * 128, B_PLANE0 = PX0 * BP, B_PLANE1 = PX1 * BP;
+  static constexpr int A0 = 0, B0 = A0 + NPL * A_PLANE, A1 = B0 + NPL * B_PLANE0, B1 = A1 + NPL * A_PLANE;
+  static constexpr int LDS_BYTES = B1 + NPL * B_PLANE1;
+  static constexpr int AU0 = KAP0 * 8, AU1 = KAP1 * 8, BU0 = PX0 * 4, BU1 = PX1 * 4;  // staging units (row, 8-channel group) per half
+  static constexpr int NA = 2, NBU = 4;                       // per thread and half
+  static_assert(AU0 <= 256 * NA && AU1 <= 256 * NA && BU0 <= 256 * NBU && BU1 <= 256 * NBU, "units per thread");
+  static_assert(!DDRL_W2_PIPE || LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(648 * 8 * 4 <= LDS_BYTES, "the bias reduction reuses the buffers");
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad2_pipe_kernel(const float* __restrict__ a1, int64_t a1_es, const float* __restrict__ dz2,
+                                                               int64_t dz_es, const float* __restrict__ amax, const float* __restrict__ gsc,
+                                                               int64_t gsc_es, float* __restrict__ part, int n, int nsplit, int ne) {
+  using K = Wgrad2P;
+  extern __shared__ __attribute__((aligned(16))) char ldsp[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int e = blockIdx.x % ne, split = blockIdx.x / ne;
+  const float sd = WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ2, e)]) / amax[amax_idx(AMAX_GMAX, e)], sa = plane_scale(amax[amax_idx(AMAX_A1, e)]),
+              inv = 1.0f / (sd * sa);
+  const float* gs = gsc + e * gsc_es;
+  const int per = (n + nsplit - 1) / nsplit;
+  const int st_begin = split * per, st_end = min(n, st_begin + per);
+  // zero rows of the dz2 images (local kappa >= 45 / 36): written once, never touched by a commit
+  for (int i = tid; i < NPL * (3 + 12) * 8; i += 256) {
+    const int pl = i / (15 * 8), r = i % (15 * 8), row = r >> 3, qd = r & 7;
+    const int off = row < 3 ? K::A0 + (K::KAP0 + row) * 128 : K::A1 + (K::KAP1 + row - 3) * 128;
+    *(u4w*)(ldsp + off + pl * K::A_PLANE + qd * 16) = (u4w){0u, 0u, 0u, 0u};
+  }
+  // ---- staging maps, per half h and unit t (see conv_wgrad2_planes_kernel); a unit index past the half's count repeats the last unit
+  // (the same bytes to the same address) and contributes nothing to the bias sums
+  const float* dzb = dz2 + e * dz_es;
+  const float* a1b = a1 + e * a1_es;
+  int aoff[2][K::NA], awr[2][K::NA], boff[2][K::NBU], bwr[2][K::NBU], ared[2][K::NA];
+  float alive[2][K::NA];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int kaph = h ? K::KAP1 : K::KAP0, kap0 = h ? K::KAP0 : 0, au = h ? K::AU1 : K::AU0;
+    const int pxh = h ? K::PX1 : K::PX0, bu = h ? K::BU1 : K::BU0, abase = h ? K::A1 : K::A0, bbase = h ? K::B1 : K::B0;
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      const int u = tid + 256 * t, uc = min(u, au - 1), c8 = uc / kaph, kl = uc % kaph;
+      alive[h][t] = u < au ? 1.0f : 0.0f;
+      aoff[h][t] = (c8 * 8) * 81 + kap0 + kl;                                      // + sample * 5184, + c * 81
+      awr[h][t] = abase + kl * 128 + ((c8 * 16) ^ (((kl >> 1) & 1) * 64));
+      ared[h][t] = u < au ? (c8 * 81 + kap0 + kl) * 8 : -1;                        // slot of the unit's bias sums in the final reduction
+    }
+#pragma unroll
+    for (int t = 0; t < K::NBU; ++t) {
+      const int u = tid + 256 * t, uc = min(u, bu - 1), c8 = uc / pxh, pos = uc % pxh;
+      boff[h][t] = (c8 * 8) * 400 + (h ? K::ROW1 * 20 : 0) + pos;                  // + sample * 12800, + c * 400
+      bwr[h][t] = bbase + pos * K::BP + c8 * 16;
+    }
+  }
+  const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int sw = (q >> 1) & 1;
+  int a_lane[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_lane[i] = (8 * (g16 >> 1) + q) * 128 + (((i ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
+  const int b_lane = wave * (20 * K::BP) + (g16 & 1) * 32 + pp * 8;
+  // a1 row (2 y') 20 + 2 x of the lane's local kappa = 9 y' + x: the same formula for both halves (half 1 starts at y = 5 = a1 row 10, its
+  // buffer's first row); padded kappa read row 0 (dz2 is zero there, but the operand must be a finite number: a row that was staged)
+  int brow[2][K::NKG][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < K::NKG; ++g)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int kl = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
+        brow[h][g][r] = kl < (h ? K::KAP1 : K::KAP0) ? ((kl / 9) * 40 + (kl % 9) * 2) * K::BP : 0;
+      }
+  float ar[K::NA][8], br[K::NBU][8], bsum[2][K::NA][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bsum[h][t][c] = 0.0f;
+  // staging unit j of a half: 0 .. NBU - 1 = a1 units, NBU .. NBU + NA - 1 = dz2 units
+  constexpr int NU = K::NBU + K::NA;
+  auto fetch_unit = [&](int h, int j, int s) __attribute__((always_inline)) {
+    if (j < K::NBU) {
+      const float* src = a1b + (int64_t)s * 12800 + boff[h][j];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) br[j][c] = src[c * 400];
+    } else {
+      const float* src = dzb + (int64_t)s * 5184 + aoff[h][j - K::NBU];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ar[j - K::NBU][c] = src[c * 81];
+    }
+  };
+  auto commit_unit = [&](int h, int j, float g) __attribute__((always_inline)) {  // g = the sample's g_s (0: a stage past the split's end)
+    unsigned pl[4][NPL];
+    if (j < K::NBU) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) DDRL_W2_SPLIT(br[j][2 * c], br[j][2 * c + 1], sa, pl[c]);
+      char* d = ldsp + bwr[h][j];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * (h ? K::B_PLANE1 : K::B_PLANE0)) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+    } else {
+      const int t = j - K::NBU;
+      const float sdt = sd * g, gb = g * alive[h][t];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) DDRL_W2_SPLIT(ar[t][2 * c], ar[t][2 * c + 1], sdt, pl[c]);
+      char* d = ldsp + awr[h][t];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * K::A_PLANE) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bsum[h][t][c] += ar[t][c] * gb;
+    }
+  };
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  // one phase: multiply buffer H (12 tap blocks of 6 MFMAs) while half 1 - H of sample `sc` is committed into the other buffer and half
+  // H of sample `sf` requested into the registers that held it: one unit per pair of tap blocks
+  auto phase = [&](auto hc, float gc, int sf) __attribute__((always_inline)) {
+    constexpr int H = decltype(hc)::value;
+    const char* ab = ldsp + (H ? K::A1 : K::A0);
+    const char* bb = ldsp + (H ? K::B1 : K::B0) + b_lane;
+    constexpr int BPL = H ? K::B_PLANE1 : K::B_PLANE0;
+    DDRL_PLANE_PRODUCTS;
+    auto read_a = [&](int g, frag8 (&a)[2][NPL]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) a[i][p] = tr_frag3(ab, a_lane[i] + p * K::A_PLANE + g * 2048, a_lane[i] + p * K::A_PLANE + g * 2048 + 512);
+    };
+    auto read_b = [&](int blk, frag8 (&b)[NPL]) __attribute__((always_inline)) {
+      const int g = blk >> 2, t = blk & 3;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) b[p] = tr_frag3(bb, p * BPL + brow[H][g][0] + t * K::BP, p * BPL + brow[H][g][1] + t * K::BP);
+    };
+    // fragments one tap block ahead (the scheduling fence at the end of a block keeps the reads of the next one from being hoisted by
+    // the compiler, so they are requested here, in front of the block's MFMAs)
+    frag8 a[2][2][NPL], b[2][NPL];
+    read_a(0, a[0]);
+    read_b(0, b[0]);
+#pragma unroll
+    for (int blk = 0; blk < 4 * K::NKG; ++blk) {
+      const int g = blk >> 2, t = blk & 3, j = blk >> 1;
+      if (blk + 1 < 4 * K::NKG) {
+        read_b(blk + 1, b[(blk + 1) & 1]);
+        if (((blk + 1) & 3) == 0) read_a(g + 1, a[(g + 1) & 1]);
+      }
+#pragma unroll
+      for (int m = 0; m < NPROD; ++m)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[4 * i + t] = mfma_planes(a[g & 1][i][PA[m]], b[blk & 1][PB[m]], acc[4 * i + t]);
+      if (j < NU) {
+        if ((blk & 1) == 0) commit_unit(1 - H, j, gc);
+        else fetch_unit(H, j, sf);
+      }
+#if DDRL_W2_PIN
+      // the block's order: fragment reads first, then its vector work spread over the gaps between the six MFMAs, LDS stores last
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int k = 0; k < 2 * NPROD; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, DDRL_W2_PIN, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 2 * NPL, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  };
+  if (st_begin < st_end) {
+    float g0 = ld_gs(gs, st_begin);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) fetch_unit(0, j, st_begin);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) commit_unit(0, j, g0);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) fetch_unit(1, j, st_begin);
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st) {
+      const bool more = st + 1 < st_end;
+      const int sn = more ? st + 1 : st;             // past the end: re-read the last sample (valid memory), committed with g = 0, never multiplied
+      const float g1 = more ? ld_gs(gs, sn) : 0.0f;
+      phase(std::integral_constant<int, 0>{}, g0, sn);
+      __syncthreads();
+      phase(std::integral_constant<int, 1>{}, g1, sn);
+      __syncthreads();
+      g0 = g1;
+    }
+  }
+  // ---- epilogue: slab[oc][ic][ky][kx] (torch layout of conv2.weight), then the bias partial
+  float* slab = part + ((int64_t)split * 2 + e) * Wgrad2B::SLAB;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[((t / 4) * 32 + acc_row(r, hi)) * 512 + l31 * 16 + wave * 4 + t % 4] = acc[t][r] * inv;
+  __syncthreads();
+  float* red = (float*)ldsp;  // [c8 * 81 + kappa][8]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t)
+      if (ared[h][t] >= 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[ared[h][t] + c] = bsum[h][t][c];
+      }
+  __syncthreads();
+  if (tid < 64) {
+    float sacc = 0.0f;
+    for (int k = 0; k < 81; ++k) sacc += red[((tid >> 3) * 81 + k) * 8 + (tid & 7)];
+    slab[64 * 512 + tid] = sacc;
+  }
+}
+
 void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
@@ -472,8 +717,18 @@ void launch_conv_wgrad2_2(const EncCall& c, float* grads, hipStream_t st) {
       configured = true;
     }
     ProfRange pr(c.prof, "ConvWgrad2", st);
+#if DDRL_W2_PIPE
+    static bool configured_p = false;
+    if (!configured_p) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad2_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad2P::LDS_BYTES);
+      configured_p = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad2_pipe_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad2P::LDS_BYTES, st, w.a1, MB * 12800, w.dz2, MB * 5184,
+                       w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
+#else
     hipLaunchKernelGGL(conv_wgrad2_planes_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad2B::LDS_BYTES, st, w.a1, MB * 12800, w.dz2, MB * 5184,
                        w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
+#endif
   }
   ProfRange pr(c.prof, "reduce_partials", st);
   launch_reduce_partials(w.wpart, S, Wgrad2B::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c2w, L.enc_base[1] + L.enc.c2w, st);
