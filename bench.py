@@ -163,17 +163,20 @@ def cpu_baseline():
         sweep[k] = {"threads": k, "forward_n256": f, "ppo_iter_B1024": _timed(lambda: next(gen), 1, 3, 4.0)}
     cands = {**sweep, k_all: full, 1: one}
     best = min(cands, key=lambda k: per_env_step(cands[k]))
-    out = {"value": round(1.0 / per_env_step(cands[best]), 2), "unit": "env-steps/s", "cores": best, "kind": "port",
+    # the headline of the CPU baseline is k = ALL PHYSICAL HOST CORES (k = 1 beside it); the fastest thread count of
+    # the sweep is a sub-key (torch's CPU convolutions do not scale to a 128-core host at these batch sizes)
+    out = {"value": round(1.0 / per_env_step(full), 2), "unit": "env-steps/s", "cores": k_all, "kind": "port",
            "sample": "oracle (torch-CPU fp32 restatement of PPO.forward / learn / GAE, pinned to the reference by tests/golden) on "
                      "synthetic inputs (rng 1234): value = 1 / (forward n=256 per sample + 10 x PPO iteration B=1024 per sample) at "
-                     "the fastest thread count of {1, 8, 16, 32, 64, all physical cores} = %d; k_all / k_1 are the legs "
-                     "BASELINE.md section 3 prescribes; every figure is a median over `reps` repetitions" % best,
+                     "k = all %d physical host cores (SURVEY.md section 8d; k = 1 in value_at_one_core); best_of_sweep = the fastest "
+                     "thread count of {1, 8, 16, 32, 64, all} = %d; every figure is a median over `reps` repetitions" % (k_all, best),
            "cpu_model": model, "host_logical_cpus": logical, "host_physical_cores": physical,
-           "torch_threads_used": best, "value_at_all_physical_cores": round(1.0 / per_env_step(full), 2),
+           "best_of_sweep": {"value": round(1.0 / per_env_step(cands[best]), 2), "threads": best},
+           "torch_threads_used": k_all, "value_at_all_physical_cores": round(1.0 / per_env_step(full), 2),
            "value_at_one_core": round(1.0 / per_env_step(one), 2), "k_all": full, "k_1": one,
            "k_sweep": {str(k): {"forward_n256_ms": v["forward_n256"]["median_ms"], "ppo_iter_B1024_ms": v["ppo_iter_B1024"]["median_ms"],
                                 "env_steps_per_s": round(1.0 / per_env_step(v), 2)} for k, v in sweep.items()}}
-    torch.set_num_threads(best)
+    torch.set_num_threads(min(best, 16))
     out["same_gpu_torch"] = torch_rocm_baseline_child()
     return out
 
@@ -248,7 +251,54 @@ _PMC_DOCS = {}
 _PMC_ALIAS = {"ConvFwd1": ("conv_fwd1_resident", "conv_fwd1_planes"), "ConvWgrad1": ("conv_wgrad1_planes",),
               "ConvFwd2": ("conv_fwd2_planes",), "ConvFwd3": ("conv_fwd3_planes",), "FcFwd": ("fc_fwd_planes",),
               "FcDgrad": ("fc_dgrad_planes",), "FcWgrad": ("fc_wgrad_planes",), "ConvDgrad3": ("conv_dgrad3_planes", "conv_dgrad3_exact"),
-              "ConvDgrad2": ("conv_dgrad2_both",), "ConvWgrad3": ("conv_wgrad3_planes",), "ConvWgrad2": ("conv_wgrad2_planes",)}
+              "ConvDgrad2": ("conv_dgrad2_both",), "ConvWgrad3": ("conv_wgrad3_planes",), "ConvWgrad2": ("conv_wgrad2_pipe", "conv_wgrad2_planes")}
+# the source file every profiled kernel lives in (ddrl4nav_amd/csrc): what `traffic_stale` is judged by
+_KERNEL_SOURCE = {"ConvFwd1": "conv2.hip", "ConvFwd2": "conv2.hip", "ConvFwd3": "conv2.hip", "ConvDgrad3": "conv2.hip", "ConvDgrad2": "conv2.hip",
+                  "ConvWgrad1": "wgrad2.hip", "ConvWgrad2": "wgrad2.hip", "ConvWgrad3": "wgrad2.hip", "FcFwd": "fc2.hip", "FcDgrad": "fc2.hip",
+                  "FcWgrad": "fc2.hip", "heads_loss": "heads.hip", "clip_adam": "optim.hip", "sqnorm": "optim.hip", "reduce_partials": "optim.hip"}
+
+
+def _source_of(kernel):
+    if kernel in _KERNEL_SOURCE:
+        return _KERNEL_SOURCE[kernel]
+    for pre, f in (("pconv_", "pconv.hip"), ("fconv_", "fconv.hip"), ("plin_", "plin.hip"), ("c1d_", "c1d.hip"), ("gconv_", "gconv.hip"),
+                   ("glin_", "glinear.hip")):
+        if kernel.startswith(pre):
+            return f
+    return None
+
+
+def evidence_age(doc, kernel):
+    """Dates a committed PMC summary against the source the bench is RUNNING: {"traffic_build": the summary's build,
+    "traffic_source_file": the kernel's .hip, "traffic_stale": True / False / None}.  Stale = the kernel's source file differs from the
+    one the summary was taken on: by the SHA-1 the summary carries (tools/pmc_to_profiles.py `sources`, round 6 on), else -- older
+    summaries -- by git: the last commit that touched the file is not an ancestor of the summary's build.  None: undecidable here (an
+    old summary on a box without .git)."""
+    import hashlib
+    import subprocess
+    src = _source_of(kernel)
+    out = {"traffic_build": (doc or {}).get("build", ""), "traffic_source_file": src, "traffic_stale": None}
+    if not doc or not src:
+        return out
+    path = os.path.join(ROOT, "ddrl4nav_amd", "csrc", src)
+    try:
+        if "sources" in doc:
+            now = hashlib.sha1(open(path, "rb").read()).hexdigest()
+            out["traffic_stale"] = doc["sources"].get(src) != now
+            return out
+        build = str(doc.get("build", "")).split()[0]
+        if build and os.path.isdir(os.path.join(ROOT, ".git")):
+            last = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%H", "--", os.path.relpath(path, ROOT)], capture_output=True,
+                                  text=True, timeout=20).stdout.strip()
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", os.path.relpath(path, ROOT)], capture_output=True,
+                                   text=True, timeout=20).stdout.strip()
+            if last:
+                anc = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", last, build], capture_output=True, timeout=20)
+                out["traffic_stale"] = bool(dirty) or anc.returncode != 0
+                out["traffic_source_last_commit"] = last[:7]
+    except Exception:
+        pass
+    return out
 
 
 def _pmc_files(family):
@@ -298,6 +348,7 @@ def pmc_traffic(kernel):
                "mfma_busy_frac": k["mfma_busy_frac"], "clock_ghz": k["clock_ghz"], "source": src,
                # NOT this run: the committed rocprofv3 --pmc passes of the named build on the named box (bench.py never profiles)
                "measured_on": {"build": doc.get("build", ""), "box": doc.get("box", ""), "batch": doc.get("batch", 65536)}}
+        out.update(evidence_age(doc, kernel))
         if "mfma_insts" in k and kernel in MAC and kernel in PIPE:
             # executed / algorithmic matrix work from SQ_INSTS_MFMA: one v_mfma_f32_32x32x16_f16 = 16,384 MAC per wave
             alg = MAC[kernel] * doc.get("batch", 65536) * 2 * PIPE[kernel][1] / 16384.0
@@ -697,9 +748,11 @@ def nav_traffic(op_name, micro_batch):
             else:
                 continue
             if ok:
-                return {"kernel": name, "hbm_bytes_per_launch_corrected": k.get("hbm_bytes_corrected", 2.0 * k["fetch_bytes"] + k["write_bytes"]),
-                        "mfma_busy_frac": k.get("mfma_busy_frac"), "clock_ghz": k.get("clock_ghz"), "source": os.path.basename(files[-1]),
-                        "measured_on": {"build": doc.get("build", ""), "box": doc.get("box", ""), "batch": doc.get("batch")}}
+                out = {"kernel": name, "hbm_bytes_per_launch_corrected": k.get("hbm_bytes_corrected", 2.0 * k["fetch_bytes"] + k["write_bytes"]),
+                       "mfma_busy_frac": k.get("mfma_busy_frac"), "clock_ghz": k.get("clock_ghz"), "source": os.path.basename(files[-1]),
+                       "measured_on": {"build": doc.get("build", ""), "box": doc.get("box", ""), "batch": doc.get("batch")}}
+                out.update(evidence_age(doc, name))
+                return out
     except Exception:
         pass
     return None
@@ -993,6 +1046,9 @@ def main():
                         # HBM bytes per launch from the PMC passes WITH the guide's gfx950 correction (FETCH_SIZE counts wide streaming
                         # reads at half their bytes: 2 x FETCH_SIZE + WRITE_SIZE); the uncorrected sum is in traffic_detail
                         "traffic": tbytes, "traffic_scaled_by_batch": round(tscale, 6),
+                        # traffic is NOT measured by this run (bench.py never profiles): it is the newest committed PMC summary that holds
+                        # the kernel, dated here -- its build, and whether the kernel's source file has changed since (evidence_age)
+                        "traffic_build": td["traffic_build"] if td else None, "traffic_stale": td["traffic_stale"] if td else None,
                         "traffic_detail": td,
                         "mix_model": mix_model(dom, d["ms_avg"] / tscale),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],

@@ -40,3 +40,42 @@ def test_families_do_not_cross(tmp_path, monkeypatch):
     assert bench.pmc_traffic("clip_adam")["hbm_bytes_per_launch"] == 9.0               # v10 after v2 (integers, not text)
     assert bench._pmc_lookup("clip_adam", "nav")[1]["hbm_bytes"] == 11.0
     assert bench.pmc_traffic("ConvWgrad2") is None
+
+
+def test_traffic_evidence_is_dated_against_the_running_source(tmp_path, monkeypatch):
+    """`roofline.traffic` is a committed PMC summary, not a measurement of the run that prints it -- so the line says
+    which build the summary is of and whether the kernel's source file has changed since (bench.evidence_age).  Summaries written from
+    round 6 on carry the SHA-1 of every csrc file (tools/pmc_to_profiles.py `sources`): the comparison needs no .git (GPU boxes have
+    none).  Older summaries fall back to git ancestry of the last commit that touched the file, or None where that is undecidable."""
+    import hashlib
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    ent = {"hbm_bytes": 5.0, "fetch_bytes": 2.0, "write_bytes": 3.0, "mfma_busy_frac": 0.5, "clock_ghz": 1.8}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = lambda f: hashlib.sha1(open(os.path.join(root, "ddrl4nav_amd", "csrc", f), "rb").read()).hexdigest()
+    doc = {"batch": 65536, "build": "abc1234 (r09_v1)", "kernels": {"conv_dgrad2_both": ent, "conv_wgrad2_pipe": ent},
+           "sources": {"conv2.hip": sha("conv2.hip"), "wgrad2.hip": "0" * 40}}
+    (prof / "r09_v1_pmc_traffic.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "ddrl4nav_amd").mkdir()
+    os.symlink(os.path.join(root, "ddrl4nav_amd", "csrc"), tmp_path / "ddrl4nav_amd" / "csrc")
+    bench._PMC_DOCS.clear()
+    fresh, stale = bench.pmc_traffic("ConvDgrad2"), bench.pmc_traffic("ConvWgrad2")
+    assert fresh["traffic_stale"] is False and fresh["traffic_build"] == "abc1234 (r09_v1)" and fresh["traffic_source_file"] == "conv2.hip"
+    assert stale["traffic_stale"] is True and stale["traffic_source_file"] == "wgrad2.hip"      # the pipe kernel resolves through its alias
+    # a summary without hashes and no .git beside it: undecidable, said so
+    del doc["sources"]
+    (prof / "r09_v1_pmc_traffic.json").write_text(json.dumps(doc))
+    bench._PMC_DOCS.clear()
+    assert bench.pmc_traffic("ConvDgrad2")["traffic_stale"] is None
+    bench._PMC_DOCS.clear()
+
+
+def test_committed_summaries_date_themselves():
+    """On the real tree every kernel of the headline family answers the staleness question with True or False (this container has .git;
+    round-6 summaries carry hashes), never silently."""
+    bench._PMC_DOCS.clear()
+    for k in bench.TRAIN_KERNELS:
+        t = bench.pmc_traffic(k)
+        assert t is not None and t["traffic_build"] and t["traffic_source_file"], k
+        assert t["traffic_stale"] in (True, False) or not os.path.isdir(os.path.join(bench.ROOT, ".git")), k

@@ -312,6 +312,10 @@ def test_bench_single_gpu_line_has_its_legs():
     for k in ("traffic", "hbm_frac", "iteration_hbm_frac", "iteration_hbm_bytes_corrected"):
         assert isinstance(r[k], (int, float)) and r[k] > 0, (k, r.get(k))
     assert r["traffic_detail"]["source"].endswith("_pmc_traffic.json") and "nav" not in r["traffic_detail"]["source"]
+    # ... and the line dates that evidence (round 6): the summary's build, and whether the kernel's source has changed since.  A summary
+    # with source hashes decides it anywhere; the hash-less ones of earlier rounds cannot be decided on a box without .git (None)
+    assert r["traffic_build"] and r["traffic_build"] == r["traffic_detail"]["measured_on"]["build"]
+    assert r["traffic_stale"] in (True, False, None) and r["traffic_detail"]["traffic_source_file"].endswith(".hip")
     assert isinstance(r["mix_model"], dict) and "error" not in r["mix_model"] and r["mix_model"]["model_ms"] > 0
     sm = d["step_ms"]
     assert sm["n"] == 2 and 0 < sm["min"] <= sm["median"] <= sm["p95"] <= sm["max"]

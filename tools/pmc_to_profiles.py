@@ -134,6 +134,13 @@ def main():
                 box = "; ".join(lines[:1] + [" ".join(ln.split()) for ln in lines[1:] if "Card Model" in ln or "Card SKU" in ln or "Unique ID" in ln][:3])[:200]
                 break
     traffic["box"] = box
+    # what the summary is evidence OF: the SHA-1 of every kernel source file as it stands when the summary is written (the tree the
+    # profiled library was built from).  bench.py compares them with the files it runs on and marks a kernel's traffic stale when its
+    # source has changed since (there is no .git on a GPU box, so the hashes travel inside the summary).
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ddrl4nav_amd", "csrc")
+    traffic["sources"] = {os.path.basename(f): hashlib.sha1(open(f, "rb").read()).hexdigest()
+                          for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))}
     with open(tag + "_pmc_traffic.json", "w") as out:
         json.dump(traffic, out, indent=1, sort_keys=True)
     print("wrote", tag + "_pmc_per_kernel.csv", tag + "_pmc_traffic.json", "(%d kernels)" % len(agg))
