@@ -766,6 +766,141 @@ def _rccl_version():
         return None
 
 
+def preflight_static():
+    """What a rank can say about the node WITHOUT any collective and without initialising a device context beyond counting: visible
+    devices and the environment that selects them, the peer-access matrix (hipDeviceCanAccessPeer through torch), the RCCL torch links
+    and the one csrc/comm.cpp resolves (ddrl_comm_info), the environment switches that steer either."""
+    import ctypes
+    out = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+           "world": int(os.environ.get("WORLD_SIZE", "1")), "host": os.uname().nodename,
+           "env": {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                              "NCCL_DEBUG", "NCCL_ALGO", "NCCL_PROTO", "NCCL_P2P_DISABLE", "RCCL_MSCCL_ENABLE", "DDRL_ALLREDUCE",
+                                              "DDRL_DIST_BACKEND", "MASTER_ADDR", "MASTER_PORT") if k in os.environ},
+           "torch": torch.__version__, "torch_rccl_version": _rccl_version()}
+    try:
+        n = torch.cuda.device_count()
+        out["device_count"] = n
+        out["devices"] = [torch.cuda.get_device_name(i) or "(name string empty)" for i in range(n)]
+        out["peer_access"] = [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
+    except Exception as e:
+        out["device_error"] = repr(e)[:200]
+    try:
+        from ddrl4nav_amd import _lib
+        buf, ver = ctypes.create_string_buffer(1024), ctypes.c_int32()
+        st = _lib.load().ddrl_comm_info(buf, 1024, ctypes.byref(ver))
+        out["ddrl_comm_rccl"] = {"status": int(st), "path": buf.value.decode(errors="replace"), "version_code": int(ver.value)}
+    except Exception as e:
+        out["ddrl_comm_rccl"] = {"error": repr(e)[:200]}
+    return out
+
+
+def preflight_main(args):
+    """`bench.py --gpus N --preflight` (under torchrun, or self-launched like the bench): per rank (1) preflight_static() to stderr BEFORE
+    anything collective, (2) the process group with NCCL_DEBUG=INFO into a per-rank file, from which RCCL's choice of algorithm /
+    protocol / channels for the gradient all-reduce is quoted, (3) ONE checked and timed SUM all-reduce of the 13,487,420-byte gradient
+    arena through torch.distributed and (4) the same through the C-ABI communicator (ddrl_comm_*, csrc/comm.cpp), each compared
+    with the analytic sum.  With one rank every step still runs (a one-rank RCCL communicator); ranks that share a device
+    (--share-gpu, gloo) skip the RCCL steps and say so.  Rank 0 prints ONE JSON line; exit code 1 when a check fails.
+    Reference: the multi-GPU path USTC_lab/server/backward.py:167 leaves as a TODO."""
+    import tempfile
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    static = preflight_static()
+    sys.stderr.write("preflight rank %d static: %s\n" % (rank, json.dumps(static)))
+    sys.stderr.flush()
+    logdir = tempfile.mkdtemp(prefix="ddrl_preflight_")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,ENV,TUNING,COLL")
+    os.environ["NCCL_DEBUG_FILE"] = os.path.join(logdir, "rccl_rank%d.log" % rank)
+    shared = os.environ.get("DDRL_DIST_BACKEND") == "gloo"
+    res = {"static": static, "shared_device": shared}
+    n_floats = 3371847 + 8                       # the gradient arena + its loss tail: what every PPO iteration reduces
+    ok = True
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pattern = (torch.arange(n_floats, device=dev, dtype=torch.float32) % 251) * 0.5 - 31.0      # exact in fp32, sums of <= 8 ranks exact too
+    want = pattern * (world * (world + 1) / 2.0)
+
+    def timed(fn, reps=5):
+        buf = pattern * float(rank + 1)
+        fn(buf)                                    # first call: connection set-up
+        torch.cuda.synchronize()
+        good = bool(torch.equal(buf, want))
+        ts = []
+        for _ in range(reps):
+            buf = pattern * float(rank + 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(buf)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            good = good and bool(torch.equal(buf, want))
+        ms = float(np.median(ts))
+        return {"matches_analytic_sum": good, "median_ms": round(ms, 4), "first_to_last_ms": [round(t, 4) for t in ts],
+                "algbw_gbps": round(n_floats * 4 / (ms * 1e-3) / 1e9, 2), "bytes": n_floats * 4}
+
+    # ---- torch.distributed: "nccl" IS RCCL on ROCm (one rank too: a one-rank communicator still goes through RCCL's init)
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            backend = "gloo" if shared else "nccl"
+            kw = {"device_id": dev} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        res["torch_backend"] = dist.get_backend()
+        if shared:
+            from ddrl4nav_amd.dist import allreduce_flat
+            res["torch_distributed"] = dict(timed(lambda b: allreduce_flat(b)), path="gloo through the host (ranks share a device)")
+        else:
+            res["torch_distributed"] = dict(timed(lambda b: dist.all_reduce(b, op=dist.ReduceOp.SUM)), path="nccl (RCCL)")
+        ok = ok and res["torch_distributed"]["matches_analytic_sum"]
+    except Exception as e:
+        res["torch_distributed"] = {"error": repr(e)[:300]}
+        ok = False
+    # ---- the C-ABI communicator
+    try:
+        if shared or world > torch.cuda.device_count():
+            res["ddrl_comm"] = {"skipped": "ranks share a device: ncclCommInitRank would fail or hang on duplicate devices"}
+        else:
+            from ddrl4nav_amd.dist import RcclComm
+            comm = RcclComm(rank, world)
+            res["ddrl_comm"] = dict(timed(lambda b: comm.allreduce(b)), path="ddrl_comm_* (csrc/comm.cpp, dlopen'ed librccl)")
+            comm.close()
+            ok = ok and res["ddrl_comm"]["matches_analytic_sum"]
+    except Exception as e:
+        res["ddrl_comm"] = {"error": repr(e)[:300]}
+        ok = False
+    # ---- what RCCL said it chose (NCCL_DEBUG=INFO): the tuning / channel / transport lines of this rank
+    try:
+        lines = open(os.environ["NCCL_DEBUG_FILE"], errors="replace").read().splitlines()
+        keys = ("Algo", "algo", "Proto", "proto", "Channel", "channel", "via", "P2P", "SHM", "NET/", "comm 0x", "nranks", "Trees", "Ring ", "XGMI", "version")
+        pick = [ln[-220:] for ln in lines if any(k in ln for k in keys)]
+        res["rccl_debug"] = {"file_lines": len(lines), "quoted": pick[:40] + (["... %d more" % (len(pick) - 40)] if len(pick) > 40 else [])}
+    except Exception as e:
+        res["rccl_debug"] = {"error": repr(e)[:200]}
+    res["ok"] = ok
+    sys.stderr.write("preflight rank %d result: %s\n" % (rank, json.dumps({k: v for k, v in res.items() if k != "static"})[:4000]))
+    sys.stderr.flush()
+    allres = [res]
+    if world > 1 and dist.is_initialized():
+        try:
+            allres = [None] * world
+            dist.all_gather_object(allres, res)
+        except Exception as e:
+            allres = [res, {"gather_error": repr(e)[:200]}]
+    if rank == 0:
+        print(json.dumps({"preflight": True, "n_gpus": world, "ok": all(bool(r and r.get("ok")) for r in allres if isinstance(r, dict) and "ok" in r),
+                          "ranks": allres}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def build_net(n_envs, horizon, iters, max_batch=None):
     from ddrl4nav_amd.config import BaseConfig, ConfigNN
     from ddrl4nav_amd.runner import create_net
@@ -849,6 +984,9 @@ def self_launch(args):
             break
         sys.stderr.write("bench.py: rendezvous port %d was taken, retrying with a new one\n" % port)
     line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if line and '"preflight": true' in line[-1]:   # diagnostics: the line is the product, also (above all) when a check failed
+        print(line[-1])
+        return 0 if not any(codes) and json.loads(line[-1]).get("ok") else 1
     if any(codes) or not line:
         sys.stderr.write("bench.py: rank exit codes %s, %d JSON line(s) from rank 0\n" % (codes, len(line)))
         return 1
@@ -876,6 +1014,10 @@ def main():
     ap.add_argument("--no-nav", action="store_true", help="skip the robot_nav (BASELINE config 4 network) sub-record")
     ap.add_argument("--no-nav-loop", action="store_true", help="nav sub-record without the whole loop at config 4's size (about 10 s)")
     ap.add_argument("--ingest-memcpy", action="store_true", help="ingest leg: the producer also copies 7.2 MB per step into the slot")
+    ap.add_argument("--preflight", action="store_true",
+                    help="first-contact diagnostics of a multi-GPU node instead of the bench: devices, peer-access matrix, the RCCL this "
+                         "process and csrc/comm.cpp resolve, RCCL's chosen algorithm / protocol for the 13.5 MB gradient all-reduce, one "
+                         "timed + checked all-reduce through torch.distributed AND through ddrl_comm; prints one JSON line")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: the ranks share the devices round-robin and reduce over gloo "
                          "(DDRL_DIST_BACKEND=gloo); never a measurement of scaling")
@@ -886,6 +1028,13 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s\n" % (args.gpus, os.environ["WORLD_SIZE"]))
         return 2
 
+    if args.preflight:
+        return preflight_main(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the cheap half of --preflight on EVERY N > 1 run, on stderr, BEFORE the first collective: if the rendezvous or the first
+        # all-reduce hangs on a node nobody has run on yet, what this rank saw is already on record
+        sys.stderr.write("bench.py rank %s pre-collective: %s\n" % (os.environ.get("RANK", "?"), json.dumps(preflight_static())))
+        sys.stderr.flush()
     from ddrl4nav_amd.dist import broadcast_params, init_from_env
     rank, world, local_rank = init_from_env()
     if world == 1:

@@ -141,6 +141,7 @@ SIGNATURES = {
     "ddrl_op_relu_mask": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "ddrl_op_accumulate": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ddrl_comm_unique_id": (c_int32, [c_void_p]),
+    "ddrl_comm_info": (c_int32, [c_void_p, c_int64, POINTER(c_int32)]),
     "ddrl_comm_create": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_void_p)]),
     "ddrl_comm_destroy": (c_int32, [c_void_p]),
     "ddrl_allreduce_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),

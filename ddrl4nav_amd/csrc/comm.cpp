@@ -29,6 +29,7 @@ typedef int (*fn_comm_init_rank)(nccl_comm_t*, int, nccl_unique_id, int);
 typedef int (*fn_comm_destroy)(nccl_comm_t);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
 typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_get_version)(int*);
 
 struct Rccl {
   void* handle = nullptr;
@@ -37,6 +38,7 @@ struct Rccl {
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_reduce all_reduce = nullptr;
   fn_broadcast broadcast = nullptr;
+  fn_get_version get_version = nullptr;
   bool ok = false;
 };
 
@@ -56,6 +58,7 @@ Rccl& rccl() {
     r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
     r.all_reduce = (fn_all_reduce)dlsym(r.handle, "ncclAllReduce");
     r.broadcast = (fn_broadcast)dlsym(r.handle, "ncclBroadcast");
+    r.get_version = (fn_get_version)dlsym(r.handle, "ncclGetVersion");
     r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce && r.broadcast;
   });
   return r;
@@ -69,6 +72,27 @@ struct ddrl_comm {
 };
 
 extern "C" {
+
+// First-contact diagnostics (bench.py --preflight): WHICH librccl this library resolved (the file the ncclAllReduce symbol lives in: inside
+// a PyTorch process that is torch's bundled copy, not /opt/rocm's) and its version code (ncclGetVersion: major * 10000 + minor * 100 +
+// patch).  No communicator and no GPU needed.  DDRL_ERR_UNSUPPORTED when no librccl could be loaded.
+int32_t ddrl_comm_info(char* path_out, int64_t cap, int32_t* version_out) {
+  if ((cap > 0 && !path_out) || cap < 0) return DDRL_ERR_INVALID_ARG;
+  if (cap > 0) path_out[0] = 0;
+  if (version_out) *version_out = 0;
+  Rccl& r = rccl();
+  if (!r.ok) return DDRL_ERR_UNSUPPORTED;
+  Dl_info info;
+  if (cap > 0 && dladdr((void*)r.all_reduce, &info) != 0 && info.dli_fname) {
+    std::strncpy(path_out, info.dli_fname, (size_t)cap - 1);
+    path_out[cap - 1] = 0;
+  }
+  if (version_out && r.get_version) {
+    int v = 0;
+    if (r.get_version(&v) == 0) *version_out = (int32_t)v;
+  }
+  return DDRL_OK;
+}
 
 int32_t ddrl_comm_unique_id(uint8_t* out128) {
   if (!out128) return DDRL_ERR_INVALID_ARG;

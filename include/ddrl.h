@@ -175,6 +175,9 @@ int32_t ddrl_clip_adam_step(ddrl_ctx* ctx, void* stream);
  *                           sees the global norm (ppo.py:126) and the replicas stay in step.
  * All calls are asynchronous on `stream`. */
 int32_t ddrl_comm_unique_id(uint8_t* out128);
+/* Which librccl the library resolved (file path of the ncclAllReduce symbol, NUL-terminated into path_out[cap]) and its version code
+ * (ncclGetVersion); diagnostics only (bench.py --preflight), no communicator or GPU needed.  Added in round 6 (additive: ABI 3). */
+int32_t ddrl_comm_info(char* path_out, int64_t cap, int32_t* version_out);
 int32_t ddrl_comm_create(const uint8_t* id128, int32_t rank, int32_t world, ddrl_comm** out);
 int32_t ddrl_comm_destroy(ddrl_comm* comm);
 int32_t ddrl_allreduce_f32(ddrl_comm* comm, float* buf, int64_t count, void* stream);

