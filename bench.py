@@ -804,14 +804,18 @@ def preflight_main(args):
     Reference: the multi-GPU path USTC_lab/server/backward.py:167 leaves as a TODO."""
     import tempfile
     import torch.distributed as dist
+    t_start = time.perf_counter()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    static = preflight_static()
-    sys.stderr.write("preflight rank %d static: %s\n" % (rank, json.dumps(static)))
-    sys.stderr.flush()
+    # RCCL reads its debug switches ONCE, the first time anything in the process makes it log: set them before the first call into it
+    # (preflight_static asks it for its version).  The GPU boxes export NCCL_DEBUG=VERSION: raised to INFO for this run.
     logdir = tempfile.mkdtemp(prefix="ddrl_preflight_")
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        os.environ["NCCL_DEBUG"] = "INFO"
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,ENV,TUNING,COLL")
     os.environ["NCCL_DEBUG_FILE"] = os.path.join(logdir, "rccl_rank%d.log" % rank)
+    static = preflight_static()
+    sys.stderr.write("preflight rank %d static (t = %.1f s): %s\n" % (rank, time.perf_counter() - t_start, json.dumps(static)))
+    sys.stderr.flush()
     shared = os.environ.get("DDRL_DIST_BACKEND") == "gloo"
     res = {"static": static, "shared_device": shared}
     n_floats = 3371847 + 8                       # the gradient arena + its loss tail: what every PPO iteration reduces
@@ -884,6 +888,7 @@ def preflight_main(args):
     except Exception as e:
         res["rccl_debug"] = {"error": repr(e)[:200]}
     res["ok"] = ok
+    res["seconds"] = round(time.perf_counter() - t_start, 1)
     sys.stderr.write("preflight rank %d result: %s\n" % (rank, json.dumps({k: v for k, v in res.items() if k != "static"})[:4000]))
     sys.stderr.flush()
     allres = [res]
