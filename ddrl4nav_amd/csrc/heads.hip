@@ -250,6 +250,10 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
 // WLDS (A > 8): the actor-head weight / bias gradient slots of hpart are written by
 // head_wgrad_kernel from dlogits instead (288 accumulator + weight registers do not fit a lane).
 constexpr int LOSS_WAVES = 4;  // waves per workgroup of heads_loss: one per SIMD, see the sample loop
+#ifndef DDRL_LOSS_NS
+#define DDRL_LOSS_NS 4      // samples per wave and turn (a power of two): the scalar chain of the loss block runs once per NS samples
+#endif
+constexpr int LOSS_NS = DDRL_LOSS_NS;
 template <int MAXA, bool WLDS>
 __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
@@ -313,46 +317,75 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
   // v_loss.backward() only -- no theta_v, no entropy gradient.
   const bool shared = (L.NE == 1);
   const int ec = L.NE - 1;
-  // one wave per SIMD (284 registers: the 8 x 8 + 8 gradient accumulators, the head weights and a sample's working set; with two
-  // waves per SIMD 53 of them lived in scratch and every sample paid their round trips): the NEXT sample's operands are requested
-  // before this one's arithmetic, so the wave never waits for memory inside a sample
-  float ha[8], hc[8], s_act = 0.0f, s_adv = 0.0f, s_olp = 0.0f, s_ret = 0.0f;
-  auto request = [&](int b, float (&xa)[8], float (&xc)[8], float& a_, float& ad_, float& ol_, float& rt_) {
-    load8(h + (int64_t)b * FEAT + lane * 8, xa);
-    load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, xc);
-    a_ = actions[b], ad_ = advs[b], ol_ = old_logps[b], rt_ = rets[b];
-  };
-  if (gw < n) request(gw, ha, hc, s_act, s_adv, s_olp, s_ret);
-  for (int b = gw; b < n; b += nw) {
-    float na[8], nc[8], n_act = 0.0f, n_adv = 0.0f, n_olp = 0.0f, n_ret = 0.0f;
-    if (b + nw < n) request(b + nw, na, nc, n_act, n_adv, n_olp, n_ret);
-    float z[MAXA];
+  // One wave per SIMD (the 8 x 8 + 8 gradient accumulators, the head weights and the working set do not fit two).  A wave takes NS samples
+  // per turn (round 6; one per turn before: 1,046 vector instructions per sample, most of them the softmax / log / divide chain that
+  // all 64 lanes executed on the same wave-uniform numbers).  Three phases per turn:
+  //   A  per sample: the A + 1 dot products (8 features per lane + a wave reduction), results in every lane, as before;
+  //   B  ONCE for the NS samples: lane l works on sample l mod NS -- softmax, Categorical bookkeeping, surrogate, value loss, entropy
+  //      and d(loss)/d(logits, value) -- so the transcendental chain is paid once per NS samples;
+  //   C  per sample: its dlogits / dvalue are read back from lane i (v_readlane: wave-uniform again) and the head layers' backward,
+  //      the per-sample normalisation of dh and the stores run as before.
+  // Sample i of the NEXT turn is requested into the registers of this turn's sample i as soon as phase C is done with them (no second
+  // register set: with one the kernel needed 394 registers, 138 of them accumulation registers used as a spill area): the request has
+  // the rest of phase C, phase B and i samples of phase A to arrive.
+  constexpr int NS = LOSS_NS;
+  const int ls = lane & (NS - 1);                   // the sample of the turn this lane works on in phase B
+  float ha[NS][8], hc[NS][8];
+  auto request = [&](int b0, float (&xa)[NS][8], float (&xc)[NS][8]) {
 #pragma unroll
-    for (int j = 0; j < MAXA; ++j) {
-      float s = 0.0f, w[8];
-      R.row(j, lane, w);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s = __builtin_fmaf(ha[i], w[i], s);
-      z[j] = wave_sum(s) + R.ba[j];
+    for (int i = 0; i < NS; ++i) {
+      const int b = min(b0 + i, n - 1);               // past the end: re-read the last sample, masked below
+      load8(h + (int64_t)b * FEAT + lane * 8, xa[i]);
+      load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, xc[i]);
     }
-    float sv = 0.0f;
+  };
+  auto bcast = [&](float x, int i) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x), i)); };
+  if (gw * NS < n) request(gw * NS, ha, hc);
+  for (int b0 = gw * NS; b0 < n; b0 += nw * NS) {
+    // the lane's own sample of phase B: its four scalars come straight from memory (contiguous over the NS lanes)
+    const int bl = min(b0 + ls, n - 1);
+    const bool live = b0 + ls < n && lane < NS;       // this lane's phase-B results count (lanes >= NS repeat lanes < NS)
+    const float s_act = actions[bl], s_adv = advs[bl], s_olp = old_logps[bl], s_ret = rets[bl];
+    // ---- phase A (a lane keeps only the results of ITS sample of phase B: no [NS][A + 1] array of logits in registers)
+    float zl[MAXA], v = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sv = __builtin_fmaf(hc[i], R.wc[i], sv);
-    const float v = wave_sum(sv) + R.bc;
+    for (int j = 0; j < MAXA; ++j) zl[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) {
+        float s = 0.0f, w[8];
+        R.row(j, lane, w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = __builtin_fmaf(ha[i][k], w[k], s);
+        const float zj = wave_sum(s) + R.ba[j];
+        zl[j] = (ls == i) ? zj : zl[j];
+      }
+      float sv = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sv = __builtin_fmaf(hc[i][k], R.wc[k], sv);
+      const float vi = wave_sum(sv) + R.bc;
+      v = (ls == i) ? vi : v;
+    }
+    // ---- phase B: this lane's sample
     Dist<MAXA> d;
-    softmax_categorical(z, A, d);
+    softmax_categorical(zl, A, d);
     const int a = (int)s_act;
     const float adv = s_adv;
     const float logp = pick(d.lc, a);
     const SurrogateTerm sg = ppo_surrogate(logp, s_olp, adv, cfg, inv_b);
-    s_actor += (double)sg.term;
     const float err = s_ret - v;
-    const float gv_unit = value_loss_element(err, cfg, s_v);  // d(v_loss element)/d(v) before the 1/B
+    double v_el = 0.0;
+    const float gv_unit = value_loss_element(err, cfg, v_el);  // d(v_loss element)/d(v) before the 1/B
     float ent = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXA; ++j)
       if (j < A) ent += d.lc[j] * d.q[j];
-    s_ent += (double)(-ent);
+    if (live) {
+      s_actor += (double)sg.term;
+      s_v += v_el;
+      s_ent += (double)(-ent);
+    }
 
     const float g_logp = sg.g_logp;
     // ---- log(clamp(q_a)) , q = p / sum(p) , softmax ----
@@ -382,59 +415,78 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
 #pragma unroll
     for (int j = 0; j < MAXA; ++j)
       if (j < A) dot += gp[j] * d.p[j];
-    float gz[MAXA];
+    float gzl[MAXA];
 #pragma unroll
-    for (int j = 0; j < MAXA; ++j) gz[j] = (j < A) ? (gp[j] - dot) * d.p[j] : 0.0f;
-    const float gv = shared ? gv_unit * inv_b * cfg.v_loss_theta : gv_unit * inv_b;
+    for (int j = 0; j < MAXA; ++j) gzl[j] = (j < A) ? (gp[j] - dot) * d.p[j] : 0.0f;
+    const float gvl = shared ? gv_unit * inv_b * cfg.v_loss_theta : gv_unit * inv_b;
 
-    // ---- head layers backward ----
-    float da[8], dc[8];
+    // ---- phase C: head layers backward, sample by sample
 #pragma unroll
-    for (int i = 0; i < 8; ++i) da[i] = 0.0f;
+    for (int i = 0; i < NS; ++i) {
+      const int b = b0 + i;
+      if (b >= n) break;  // wave-uniform
+      float gz[MAXA];
 #pragma unroll
-    for (int j = 0; j < MAXA; ++j) {  // per element the same j-ordered fma chain as sum_j gz[j] * Wa[j][i]
-      float w[8];
-      R.row(j, lane, w);
+      for (int j = 0; j < MAXA; ++j) gz[j] = bcast(gzl[j], i);
+      const float gv = bcast(gvl, i);
+      float da[8], dc[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) da[i] = __builtin_fmaf(gz[j], w[i], da[i]);
-    }
+      for (int k = 0; k < 8; ++k) da[k] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      dc[i] = gv * R.wc[i];
-      gwc[i] = __builtin_fmaf(gv, hc[i], gwc[i]);
-    }
-    if constexpr (!WLDS) {
+      for (int j = 0; j < MAXA; ++j) {  // per element the same j-ordered fma chain as sum_j gz[j] * Wa[j][k]
+        float w[8];
+        R.row(j, lane, w);
 #pragma unroll
-      for (int j = 0; j < MAXA; ++j) {
-        gba[j] += gz[j];
+        for (int k = 0; k < 8; ++k) da[k] = __builtin_fmaf(gz[j], w[k], da[k]);
+      }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gwa[j][i] = __builtin_fmaf(gz[j], ha[i], gwa[j][i]);
+      for (int k = 0; k < 8; ++k) {
+        dc[k] = gv * R.wc[k];
+        gwc[k] = __builtin_fmaf(gv, hc[i][k], gwc[k]);
+      }
+      if constexpr (!WLDS) {
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) {
+          gba[j] += gz[j];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gwa[j][k] = __builtin_fmaf(gz[j], ha[i][k], gwa[j][k]);
+        }
+      }
+      gbc += gv;
+      if (shared) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) da[k] += dc[k];
+        if (gsc != nullptr) normalise(da, wave_absmax(da), 0, b);
+        store8(dh + (int64_t)b * FEAT + lane * 8, da);
+      } else {
+        if (gsc != nullptr) {
+          normalise(da, wave_absmax(da), 0, b);
+          // the critic's row is gv * w_c: its largest magnitude is |gv| x the (loop-invariant) largest |w_c| -- exactly, since rounding
+          // a product is monotone in the factor -- so only the actor's row needs a reduction
+          normalise(dc, fabsf(gv) * wc_absmax, 1, b);
+        }
+        store8(dh + (int64_t)b * FEAT + lane * 8, da);
+        store8(dh + dh_es + (int64_t)b * FEAT + lane * 8, dc);
+      }
+      if (lane < A) dlogits[(int64_t)b * A + lane] = pick(gz, lane);
+      if (lane == 0) dvalue[b] = gv;
+      {  // the next turn's sample i (past the end: the last sample again, never used)
+        const int bn = min(b + nw * NS, n - 1);
+        load8(h + (int64_t)bn * FEAT + lane * 8, ha[i]);
+        load8(h + ec * h_es + (int64_t)bn * FEAT + lane * 8, hc[i]);
       }
     }
-    gbc += gv;
-    if (shared) {
+  }
+  // the loss sums live in lanes 0 .. NS - 1 (one sample each per turn): added in lane order into lane 0
+  {
+    double ta = 0.0, tv = 0.0, te = 0.0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) da[i] += dc[i];
-      if (gsc != nullptr) normalise(da, wave_absmax(da), 0, b);
-      store8(dh + (int64_t)b * FEAT + lane * 8, da);
-    } else {
-      if (gsc != nullptr) {
-        normalise(da, wave_absmax(da), 0, b);
-        // the critic's row is gv * w_c: its largest magnitude is |gv| x the (loop-invariant) largest |w_c| -- exactly, since rounding
-        // a product is monotone in the factor -- so only the actor's row needs a reduction
-        normalise(dc, fabsf(gv) * wc_absmax, 1, b);
-      }
-      store8(dh + (int64_t)b * FEAT + lane * 8, da);
-      store8(dh + dh_es + (int64_t)b * FEAT + lane * 8, dc);
+    for (int i = 0; i < NS; ++i) {
+      ta += __shfl(s_actor, i, 64);
+      tv += __shfl(s_v, i, 64);
+      te += __shfl(s_ent, i, 64);
     }
-    if (lane < A) dlogits[(int64_t)b * A + lane] = pick(gz, lane);
-    if (lane == 0) dvalue[b] = gv;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      ha[i] = na[i];
-      hc[i] = nc[i];
-    }
-    s_act = n_act, s_adv = n_adv, s_olp = n_olp, s_ret = n_ret;
+    s_actor = ta, s_v = tv, s_ent = te;
   }
 
   if (gsc != nullptr && lane == 0) {  // AMAX_GMAX / AMAX_DH: one look (and rarely an atomic) per wave and encoder
@@ -625,7 +677,8 @@ void launch_heads_loss(const HeadsCall& c, const float* actions, const float* ol
                        const float* rets, float inv_b, float* grads, hipStream_t st) {
   const int64_t hs = hpart_stride(c.L->A);
   const bool large = c.L->A > MAXA_SMALL;
-  auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : heads_loss_kernel<MAXA_SMALL, false>;
+  // A <= 6 (Pong's six actions): two rows fewer of weights, gradient accumulators and per-sample logits in registers than the A <= 8 form
+  auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : (c.L->A <= 6 ? heads_loss_kernel<6, false> : heads_loss_kernel<MAXA_SMALL, false>);
   hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(LOSS_WAVES * 64), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT, c.params,
                      *c.L, *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh,
                      c.dh_es != HeadsCall::ES_UNSET ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs,

@@ -24,6 +24,16 @@ __device__ __forceinline__ float ld_gs(const float* gs, int idx) {
   return gs[idx];
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N - 1 (a `#pragma unroll` over 27-36 tap blocks with lambdas in the body
+// is not always honoured, and an index that stays a run-time value puts the fragment / staging arrays into scratch)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 struct WgradSplit {
   int pair_begin, pair_end;
   __device__ __forceinline__ void set(int n, int nsplit, int split) {
@@ -253,21 +263,291 @@ __global__ __launch_bounds__(256) void conv_wgrad3_planes_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same weight gradient as a two-buffer software pipeline (round 6, the form of conv_wgrad2_pipe_kernel below; -DDDRL_W3_PIPE=0:
+// the one-stage kernel above).  A turn = two samples = 98 reduction indices, cut into two HALF-STAGES with an LDS buffer each:
+//   half 0: sample 0, pixels 0..47  (3 k-groups, exact)          its a2 image: sample 0 (81 pixels)
+//   half 1: sample 0, pixel 48 + sample 1, pixels 0..48 (50 of 64) its a2 image: rows 6..8 of sample 0 (27 pixels) + sample 1 (81)
+// 76 KB together (the one stage: 103 KB).  While the waves multiply one buffer they split + commit the other half-stage and request
+// the one after it, one staging unit per few tap blocks; ONE barrier per half-stage.  Rows 6..8 of sample 0 are staged twice.
+// ------------------------------------------------------------------------------------------------
+#ifndef DDRL_W3_PIPE
+#ifdef DDRL_PLANES_BF16
+#define DDRL_W3_PIPE 0
+#else
+#define DDRL_W3_PIPE 1
+#endif
+#endif
+#ifndef DDRL_W3_PIN
+#define DDRL_W3_PIN 4
+#endif
+#ifndef DDRL_W3_WPE
+#define DDRL_W3_WPE 1   // waves per SIMD the registers are cut for: 2 = two workgroups per CU (the two buffers leave room for them)
+#endif
+struct Wgrad3P {
+  static constexpr int BP = DDRL_W3_BPITCH;
+  static constexpr int KAP0 = 48, KAP1 = 50, NKG0 = 3, NKG1 = 4;   // reduction indices / k-groups of the halves
+  static constexpr int PX0 = 81, PX1 = 27 + 81;                     // a2 pixels staged per half
+  static constexpr int A_PLANE0 = NKG0 * 16 * 128, A_PLANE1 = NKG1 * 16 * 128;
+  static constexpr int B_HALF0 = PX0 * BP, B_HALF1 = PX1 * BP, B_PLANE0 = 2 * B_HALF0, B_PLANE1 = 2 * B_HALF1;
+  static constexpr int A0 = 0, B0 = A0 + NPL * A_PLANE0, A1 = B0 + NPL * B_PLANE0, B1 = A1 + NPL * A_PLANE1;
+  static constexpr int LDS_BYTES = B1 + NPL * B_PLANE1;
+  static constexpr int AU0 = KAP0 * 8, AU1 = KAP1 * 8, BU0 = PX0 * 8, BU1 = PX1 * 8;   // staging units per half
+  static constexpr int NA = 2, NB0 = 3, NB1 = 4;                    // per thread
+  static_assert(AU0 <= 256 * NA && AU1 <= 256 * NA && BU0 <= 256 * NB0 && BU1 <= 256 * NB1 && NB0 + 1 == NB1, "units per thread");
+  static_assert(!DDRL_W3_PIPE || LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(98 * 8 * 8 * 4 <= LDS_BYTES, "the bias reduction reuses the buffers");
+  static constexpr int WG_PER_CU = (DDRL_W3_WPE >= 2 && LDS_BYTES <= 80 * 1024) ? 2 : 1;
+};
+
+__global__ __launch_bounds__(256, DDRL_W3_WPE) void conv_wgrad3_pipe_kernel(const float* __restrict__ a2, int64_t a2_es, const float* __restrict__ dz3,
+                                                                          int64_t dz_es, const float* __restrict__ amax, const float* __restrict__ gsc,
+                                                                          int64_t gsc_es, float* __restrict__ part, int n, int nsplit, int ne) {
+  using K = Wgrad3P;
+  extern __shared__ __attribute__((aligned(16))) char ldsq[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int e = blockIdx.x % ne, split = blockIdx.x / ne;
+  const float sd = WGRAD_HEADROOM * plane_scale(amax[amax_idx(AMAX_DZ3, e)]) / amax[amax_idx(AMAX_GMAX, e)], sa = plane_scale(amax[amax_idx(AMAX_A2, e)]),
+              inv = 1.0f / (sd * sa);
+  const float* gs = gsc + e * gsc_es;
+  const int nst = (n + 1) / 2;                           // turns = sample pairs
+  const int per = (nst + nsplit - 1) / nsplit;
+  const int st_begin = split * per, st_end = min(nst, st_begin + per);
+  // zero rows of half 1's dz3 image (local kappa >= 50): written once, never touched by a commit
+  for (int i = tid; i < NPL * (K::NKG1 * 16 - K::KAP1) * 8; i += 256) {
+    const int pl = i / ((K::NKG1 * 16 - K::KAP1) * 8), r = i % ((K::NKG1 * 16 - K::KAP1) * 8);
+    *(u4w*)(ldsq + K::A1 + pl * K::A_PLANE1 + K::KAP1 * 128 + r * 16) = (u4w){0u, 0u, 0u, 0u};
+  }
+  // ---- staging maps per half h and unit t (offsets relative to the turn's FIRST sample; a unit past the half's count repeats the last
+  // one and contributes nothing to the bias sums)
+  const float* dzb = dz3 + e * dz_es;
+  const float* a2b = a2 + e * a2_es;
+  int aoff[2][K::NA], awr[2][K::NA], ared[2][K::NA], boff[2][K::NB1], bwr[2][K::NB1];
+  float alive[2][K::NA];
+  unsigned a_s1 = 0u, b_s1 = 0u;                        // bit (h * 4 + t): the unit reads the turn's SECOND sample
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int kaph = h ? K::KAP1 : K::KAP0, au = h ? K::AU1 : K::AU0, pxh = h ? K::PX1 : K::PX0, bu = h ? K::BU1 : K::BU0;
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t) {
+      const int u = tid + 256 * t, uc = min(u, au - 1), c8 = uc / kaph, kl = uc % kaph;
+      const int second = h && kl > 0, px = h ? (kl > 0 ? kl - 1 : 48) : kl;   // half 1: local 0 = sample 0's last pixel, then sample 1
+      alive[h][t] = u < au ? 1.0f : 0.0f;
+      a_s1 |= (unsigned)second << (h * 4 + t);
+      aoff[h][t] = second * FLAT + (c8 * 8) * 49 + px;                                       // + sample0 * FLAT, + c * 49
+      awr[h][t] = (h ? K::A1 : K::A0) + kl * 128 + ((c8 * 16) ^ (((kl >> 1) & 1) * 64));
+      ared[h][t] = u < au ? (c8 * 98 + second * 49 + px) * 8 : -1;                            // slot of the unit's bias sums in the final reduction
+    }
+#pragma unroll
+    for (int t = 0; t < K::NB1; ++t) {
+      const int u = tid + 256 * t, uc = min(u, bu - 1), c8 = uc / pxh, lp = uc % pxh;
+      const int second = h && lp >= 27, pos = h ? (lp >= 27 ? lp - 27 : 54 + lp) : lp;       // half 1: rows 6..8 of sample 0, then sample 1
+      b_s1 |= (unsigned)second << (h * 4 + t);
+      boff[h][t] = second * 5184 + (c8 * 8) * 81 + pos;                                       // + sample0 * 5184, + c * 81
+      bwr[h][t] = (h ? K::B1 : K::B0) + (c8 >> 2) * (h ? K::B_HALF1 : K::B_HALF0) + lp * K::BP + (c8 & 3) * 16;
+    }
+  }
+  const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int sw = (q >> 1) & 1;
+  const int a_lane = (8 * (g16 >> 1) + q) * 128 + (((wi ^ sw) * 64) + (g16 & 1) * 32 + pp * 8);
+  const int b_lane = (g16 & 1) * 32 + pp * 8;
+  int brow0[K::NKG0][2], brow1[K::NKG1][2];  // a2 row of this lane's local kappa (tap 0); padded kappa read row 0 (dz3 is zero there)
+#pragma unroll
+  for (int g = 0; g < K::NKG1; ++g)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int kl = 16 * g + 8 * (g16 >> 1) + q + 4 * r;
+      if (g < K::NKG0) brow0[g][r] = ((kl / 7) * 9 + kl % 7) * K::BP;                      // sample 0, pixel kl
+      const int px = kl - 1;
+      brow1[g][r] = kl == 0 ? 6 * K::BP : (kl < K::KAP1 ? (27 + (px / 7) * 9 + px % 7) * K::BP : 0);
+    }
+  float ar[K::NA][8], br[K::NB1][8], bsum[2][K::NA][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bsum[h][t][c] = 0.0f;
+  // register SLOT j of a half: 0 .. 3 = a2 units (br[j]; half 0 has three, its slot 3 is empty), 4 / 5 = the two dz3 units (ar[j - 4]).
+  // A slot is requested for the next half-stage right after the one it held has been committed, so the slots -- not the unit counts --
+  // pair the two lists.  s0 = the turn; its second sample is clamped to the batch's last one when the batch is odd (valid memory; its
+  // dz3 is committed with g = 0)
+  auto fetch_unit = [&](int h, int j, int s0) __attribute__((always_inline)) {
+    const int nb = K::NB1;
+    if (j < nb) {
+      const int second = (int)((b_s1 >> (h * 4 + j)) & 1u);
+      const int64_t base = (int64_t)(second && 2 * s0 + 1 >= n ? 2 * s0 * 5184 + boff[h][j] - 5184 : 2 * s0 * 5184 + boff[h][j]);
+      const float* src = a2b + base;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) br[j][c] = src[c * 81];
+    } else {
+      const int t = j - nb;
+      const int second = (int)((a_s1 >> (h * 4 + t)) & 1u);
+      const int64_t base = (int64_t)(second && 2 * s0 + 1 >= n ? 2 * s0 * FLAT + aoff[h][t] - FLAT : 2 * s0 * FLAT + aoff[h][t]);
+      const float* src = dzb + base;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ar[t][c] = src[c * 49];
+    }
+  };
+  auto commit_unit = [&](int h, int j, float g0, float g1) __attribute__((always_inline)) {  // g = the samples' g_s (0: absent sample)
+    const int nb = K::NB1;
+    unsigned pl[4][NPL];
+    if (j < nb) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split_planes(br[j][2 * c], br[j][2 * c + 1], sa, pl[c]);
+      char* d = ldsq + bwr[h][j];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * (h ? K::B_PLANE1 : K::B_PLANE0)) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+    } else {
+      const int t = j - nb;
+      const float g = ((a_s1 >> (h * 4 + t)) & 1u) ? g1 : g0, sdt = sd * g, gb = g * alive[h][t];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split_planes(ar[t][2 * c], ar[t][2 * c + 1], sdt, pl[c]);
+      char* d = ldsq + awr[h][t];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) *(u4w*)(d + p * (h ? K::A_PLANE1 : K::A_PLANE0)) = (u4w){pl[0][p], pl[1][p], pl[2][p], pl[3][p]};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bsum[h][t][c] += ar[t][c] * gb;
+    }
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  // one phase: multiply buffer H (NKG x 9 tap blocks of NPROD MFMAs) while half 1 - H (of the turn `sc` scales belong to) is committed
+  // into the other buffer and half H of turn `sf` requested into the registers that held it
+  auto phase = [&](auto hc, float g0, float g1, int sf) __attribute__((always_inline)) {
+    constexpr int H = decltype(hc)::value;
+    constexpr int NKG = H ? K::NKG1 : K::NKG0, NBLK = NKG * 9;
+    constexpr int APL = H ? K::A_PLANE1 : K::A_PLANE0, BPL = H ? K::B_PLANE1 : K::B_PLANE0;
+    constexpr int NSLOT = K::NB1 + K::NA, NOPS = 2 * NSLOT, STEP = NBLK / NOPS;   // commit slot 0, request slot 0, commit slot 1, ...
+    const char* ab = ldsq + (H ? K::A1 : K::A0) + a_lane;
+    const char* bb = ldsq + (H ? K::B1 : K::B0) + wj * (H ? K::B_HALF1 : K::B_HALF0) + b_lane;
+    DDRL_PLANE_PRODUCTS;
+    auto read_a = [&](int g, frag8 (&a)[NPL]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) a[p] = tr_frag3(ab, p * APL + g * 2048, p * APL + g * 2048 + 512);
+    };
+    auto read_b = [&](int blk, frag8 (&b)[NPL]) __attribute__((always_inline)) {
+      const int g = blk / 9, t = blk % 9, toff = ((t / 3) * 9 + t % 3) * K::BP;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        b[p] = tr_frag3(bb, p * BPL + (H ? brow1[g][0] : brow0[g < K::NKG0 ? g : 0][0]) + toff, p * BPL + (H ? brow1[g][1] : brow0[g < K::NKG0 ? g : 0][1]) + toff);
+    };
+    frag8 a[2][NPL], b[2][NPL];
+    read_a(0, a[0]);
+    read_b(0, b[0]);
+    static_for<0, NBLK>([&](auto blk_c) __attribute__((always_inline)) {
+      constexpr int blk = decltype(blk_c)::value;
+      constexpr int g = blk / 9, t = blk % 9;
+      if constexpr (blk + 1 < NBLK) {
+        read_b(blk + 1, b[(blk + 1) & 1]);
+        if constexpr ((blk + 1) % 9 == 0) read_a(g + 1, a[(g + 1) & 1]);
+      }
+#pragma unroll
+      for (int m = 0; m < NPROD; ++m) acc[t] = mfma_planes(a[g & 1][PA[m]], b[blk & 1][PB[m]], acc[t]);
+      if constexpr (blk % STEP == STEP - 1 && blk / STEP < NOPS) {
+        constexpr int op = blk / STEP, slot = op >> 1, hh = (op & 1) ? H : 1 - H;   // even: commit the other half's unit, odd: request this half's
+        constexpr bool exists = slot != K::NB0 || hh == 1 || K::NB0 == K::NB1;      // half 0 has no a2 unit in slot 3
+        if constexpr (exists) {
+          if constexpr ((op & 1) == 0) commit_unit(hh, slot, g0, g1);
+          else fetch_unit(hh, slot, sf);
+        }
+      }
+#if DDRL_W3_PIN
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int k = 0; k < NPROD; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2 * DDRL_W3_PIN, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 2 * NPL, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+  };
+  if (st_begin < st_end) {
+    auto gs_of = [&](int st, float& g0, float& g1) {
+      g0 = ld_gs(gs, min(2 * st, n - 1));
+      g1 = 2 * st + 1 < n ? ld_gs(gs, 2 * st + 1) : 0.0f;
+    };
+    float g0, g1;
+    gs_of(st_begin, g0, g1);
+#pragma unroll
+    for (int j = 0; j < K::NB1 + K::NA; ++j)
+      if (j != K::NB0) fetch_unit(0, j, st_begin);
+#pragma unroll
+    for (int j = 0; j < K::NB1 + K::NA; ++j)
+      if (j != K::NB0) commit_unit(0, j, g0, g1);
+#pragma unroll
+    for (int j = 0; j < K::NB1 + K::NA; ++j) fetch_unit(1, j, st_begin);
+    __syncthreads();
+    for (int st = st_begin; st < st_end; ++st) {
+      const bool more = st + 1 < st_end;
+      const int sn = more ? st + 1 : st;               // past the end: re-read the last turn (valid memory), committed with g = 0, never multiplied
+      float n0 = 0.0f, n1 = 0.0f;
+      if (more) gs_of(sn, n0, n1);
+      phase(std::integral_constant<int, 0>{}, g0, g1, sn);   // multiply half 0 of turn st, commit half 1 of turn st, request half 0 of turn sn
+      __syncthreads();
+      phase(std::integral_constant<int, 1>{}, n0, n1, sn);   // multiply half 1 of turn st, commit half 0 of turn sn, request half 1 of turn sn
+      __syncthreads();
+      g0 = n0, g1 = n1;
+    }
+  }
+  // ---- epilogue: slab[oc][ic][tap] (torch layout of conv3.weight), then the bias partial
+  float* slab = part + ((int64_t)split * 2 + e) * Wgrad3B::SLAB;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(wi * 32 + acc_row(r, hi)) * 576 + (wj * 32 + l31) * 9 + t] = acc[t][r] * inv;
+  __syncthreads();
+  float* red = (float*)ldsq;  // [c8 * 98 + kappa][8]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < K::NA; ++t)
+      if (ared[h][t] >= 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[ared[h][t] + c] = bsum[h][t][c];
+      }
+  __syncthreads();
+  if (tid < 64) {
+    float sacc = 0.0f;
+    for (int k = 0; k < 98; ++k) sacc += red[((tid >> 3) * 98 + k) * 8 + (tid & 7)];
+    slab[64 * 576 + tid] = sacc;
+  }
+}
+
 void launch_conv_wgrad3_2(const EncCall& c, float* grads, hipStream_t st) {
   const Workspace& w = *c.ws;
   const int64_t MB = c.max_batch;
   const ParamLayout& L = *c.L;
-  const int want = 256 * Wgrad3B::WG_PER_CU / L.NE;  // as many workgroups as fit the chip at once
+#if DDRL_W3_PIPE
+  const int want = 256 * Wgrad3P::WG_PER_CU / L.NE;  // as many workgroups as fit the chip at once
+#else
+  const int want = 256 * Wgrad3B::WG_PER_CU / L.NE;
+#endif
   const int S = c.splits->c3 < want ? c.splits->c3 : want;
   {
     static bool configured = false;
     if (!configured) {
       (void)hipFuncSetAttribute((const void*)conv_wgrad3_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad3B::LDS_BYTES);
+#if DDRL_W3_PIPE
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wgrad3P::LDS_BYTES);
+#endif
       configured = true;
     }
     ProfRange pr(c.prof, "ConvWgrad3", st);
+#if DDRL_W3_PIPE
+    hipLaunchKernelGGL(conv_wgrad3_pipe_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad3P::LDS_BYTES, st, w.a2, MB * 5184, w.dz3, MB * FLAT,
+                       w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
+#else
     hipLaunchKernelGGL(conv_wgrad3_planes_kernel, dim3((unsigned)(L.NE * S)), dim3(256), Wgrad3B::LDS_BYTES, st, w.a2, MB * 5184, w.dz3, MB * FLAT,
                        w.amax, w.gsc, MB, w.wpart, c.n, S, L.NE);
+#endif
   }
   ProfRange pr(c.prof, "reduce_partials", st);
   launch_reduce_partials(w.wpart, S, Wgrad3B::SLAB, L.NE, grads, L.enc_base[0] + L.enc.c3w, L.enc_base[1] + L.enc.c3w, st);

@@ -16,6 +16,6 @@ hp.profile(True)
 for _ in range(3): hp.ppo_iter(fr,a,old,adv,ret)
 torch.cuda.synchronize()
 p=hp.profile_read()
-print(sys.argv[1], " ".join("%s %.2f"%(k.replace("Conv",""), v[0]/3) for k,v in sorted(p.items()) if v[0]/3>0.3))
+print(sys.argv[1], " ".join("%s %.2f"%(k.replace("Conv",""), v[0]/3) for k,v in sorted(p.items()) if v[0]/3>0.1))
 gr=hp.grads[:hp.n_params].double()
 print(sys.argv[1], "grad |sum| %.9e  L2 %.9e  finite %s" % (float(gr.abs().sum()), float(gr.norm()), bool(torch.isfinite(gr).all())))

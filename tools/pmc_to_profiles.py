@@ -138,7 +138,8 @@ def main():
     # profiled library was built from).  bench.py compares them with the files it runs on and marks a kernel's traffic stale when its
     # source has changed since (there is no .git on a GPU box, so the hashes travel inside the summary).
     import hashlib
-    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ddrl4nav_amd", "csrc")
+    # (DDRL_PROFILE_SRC: the csrc directory of the profiled build when the working tree has moved on since the passes ran)
+    csrc = os.environ.get("DDRL_PROFILE_SRC") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ddrl4nav_amd", "csrc")
     traffic["sources"] = {os.path.basename(f): hashlib.sha1(open(f, "rb").read()).hexdigest()
                           for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))}
     with open(tag + "_pmc_traffic.json", "w") as out:

@@ -13,20 +13,10 @@ BUILD=${DDRL_PROFILE_BUILD:-$(git rev-parse --short HEAD 2>/dev/null || true)}
 if [ -z "$BUILD" ]; then echo "set DDRL_PROFILE_BUILD=<git short hash> (the GPU box has no .git)" >&2; exit 2; fi
 # what the summaries must carry (tools/pmc_to_profiles.py): the profiled build and the batch of the PMC passes (tools/profile_iter.py: 65,536)
 echo "{\"batch\": 65536, \"build\": \"$BUILD ($TAG)\"}" > "$OUT/meta.json"
-# socket power / shader clock / junction temperature every ~50 ms WHILE the bench line is measured (the node that draws the most power):
-# the headline runs at the socket's power cap, and this trace is the evidence
-( NODES=$(ls -d /sys/class/drm/card*/device/hwmon/hwmon* 2>/dev/null)
-  echo "hwmon nodes: $(echo $NODES | wc -w)  power1_cap_uW=$(cat $(echo $NODES | cut -d' ' -f1)/power1_cap 2>/dev/null)"
-  i=0
-  while [ ! -e "$OUT/.bench_done" ] && [ $i -lt 6000 ]; do
-    i=$((i + 1)); best=0; line=""
-    for H in $NODES; do
-      p=$(cat $H/power1_input 2>/dev/null || echo 0)
-      if [ "$p" -gt "$best" ]; then best=$p; line="power_uW=$p sclk_Hz=$(cat $H/freq1_input 2>/dev/null) tj_mC=$(cat $H/temp2_input 2>/dev/null) node=$(basename $H)"; fi
-    done
-    echo "$i t_ms=$(($(date +%s%N) / 1000000)) $line"
-    sleep 0.03
-  done ) > "$OUT/hwmon_power_clock.txt" 2>/dev/null &
+# socket power / shader clock / junction temperature of every hwmon node every ~25 ms WHILE the bench line is measured: the headline runs
+# at the socket's power cap, and this trace is the evidence; tools/hwmon_trace.py --summary picks this GPU's node
+rm -f "$OUT/.bench_done"
+python3 tools/hwmon_trace.py "$OUT/hwmon_all_nodes.txt" "$OUT/.bench_done" &
 SAMPLER=$!
 python3 bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 touch "$OUT/.bench_done"; wait $SAMPLER 2>/dev/null; rm -f "$OUT/.bench_done"
@@ -34,4 +24,6 @@ touch "$OUT/.bench_done"; wait $SAMPLER 2>/dev/null; rm -f "$OUT/.bench_done"
 find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 bash tools/prof_pmc.sh "gpurun_out/$TAG/pmc"; echo "pmc rc=$?"
 hostname > "$OUT/box.txt"; rocm-smi --showproductname --showuniqueid 2>/dev/null | grep -E "Card Model|Card SKU|Unique ID" | head -6 >> "$OUT/box.txt"
+PCI=$(rocm-smi --showbus 2>/dev/null | grep -oE "[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9]" | head -1); echo "pci $PCI" >> "$OUT/box.txt"
+python3 tools/hwmon_trace.py --summary "$OUT/hwmon_all_nodes.txt" "$PCI" > "$OUT/hwmon_summary.json" 2>&1; cat "$OUT/hwmon_summary.json" | head -30
 ls "$OUT" "$OUT/pmc" | head -40
