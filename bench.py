@@ -251,7 +251,8 @@ _PMC_DOCS = {}
 _PMC_ALIAS = {"ConvFwd1": ("conv_fwd1_resident", "conv_fwd1_planes"), "ConvWgrad1": ("conv_wgrad1_planes",),
               "ConvFwd2": ("conv_fwd2_planes",), "ConvFwd3": ("conv_fwd3_planes",), "FcFwd": ("fc_fwd_planes",),
               "FcDgrad": ("fc_dgrad_planes",), "FcWgrad": ("fc_wgrad_planes",), "ConvDgrad3": ("conv_dgrad3_planes", "conv_dgrad3_exact"),
-              "ConvDgrad2": ("conv_dgrad2_both",), "ConvWgrad3": ("conv_wgrad3_planes",), "ConvWgrad2": ("conv_wgrad2_pipe", "conv_wgrad2_planes")}
+              "ConvDgrad2": ("conv_dgrad2_both",), "ConvWgrad3": ("conv_wgrad3_pipe", "conv_wgrad3_planes"),
+              "ConvWgrad2": ("conv_wgrad2_pipe", "conv_wgrad2_planes")}
 # the source file every profiled kernel lives in (ddrl4nav_amd/csrc): what `traffic_stale` is judged by
 _KERNEL_SOURCE = {"ConvFwd1": "conv2.hip", "ConvFwd2": "conv2.hip", "ConvFwd3": "conv2.hip", "ConvDgrad3": "conv2.hip", "ConvDgrad2": "conv2.hip",
                   "ConvWgrad1": "wgrad2.hip", "ConvWgrad2": "wgrad2.hip", "ConvWgrad3": "wgrad2.hip", "FcFwd": "fc2.hip", "FcDgrad": "fc2.hip",
