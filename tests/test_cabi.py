@@ -136,3 +136,20 @@ def test_clean_build_stays_within_its_time_budget(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert (dst / "libddrl_hip.so").exists()
     print("clean build: %.0f s" % (time.time() - t0))
+
+
+def test_removed_environment_switches_are_reported_once():
+    """a launch script that still sets a switch removed in round 5 (DDRL_ALLREDUCE_OVERLAP, DDRL_ENC_STREAMS, ...) must not be
+    ignored silently: loading the library warns once per variable and names the replacement (ddrl4nav_amd/_lib.py:REMOVED_SWITCHES)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import warnings; warnings.simplefilter('always'); from ddrl4nav_amd import _lib; _lib.load(); _lib.load()"
+    env = dict(os.environ, DDRL_ALLREDUCE_OVERLAP="1", DDRL_ENC_STREAMS="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("DDRL_ALLREDUCE_OVERLAP is set but was removed") == 1 and "DDRL_ALLREDUCE=overlap" in r.stderr
+    assert r.stderr.count("DDRL_ENC_STREAMS is set but was removed") == 1 and "encoder_streams" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env={k: v for k, v in os.environ.items() if not k.startswith("DDRL_")},
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "was removed" not in r.stderr
