@@ -51,21 +51,27 @@ class BackwardQueue:
 
     def __init__(self, maxsize=0):
         self.q = queue.Queue(maxsize)
+        self._partial = ([], [], 0)      # pieces a timed-out get() had already taken off the queue
 
     def get(self, batch_size, *args) -> Tuple[Experience, Dict]:
         """Blocks (``*args`` = ``queue.Queue.get``'s block / timeout; a timeout raises ``queue.Empty``) until the gathered pieces hold at
-        least ``batch_size`` samples: never fewer, possibly more (whole pieces only), in arrival order."""
-        cur_size = 0
-        list_exp: List[Experience] = []
-        list_dict: List[dict] = []
-        while cur_size < batch_size:
-            data, dict_logger = self.q.get(*args)
-            assert isinstance(data, Experience)
-            assert isinstance(dict_logger, dict)
-            cur_size += len(data)
-            list_exp.append(data)
-            if len(dict_logger):
-                list_dict.append(dict_logger)
+        least ``batch_size`` samples: never fewer, possibly more (whole pieces only), in arrival order.  One deviation from the
+        reference, whose gather list is a local of ``get`` (backward.py:50-52) and dies with an exception: pieces already taken when a
+        timeout strikes are kept and head the next call's batch -- no sample is ever dropped."""
+        list_exp, list_dict, cur_size = self._partial
+        self._partial = ([], [], 0)
+        try:
+            while cur_size < batch_size:
+                data, dict_logger = self.q.get(*args)
+                assert isinstance(data, Experience)
+                assert isinstance(dict_logger, dict)
+                cur_size += len(data)
+                list_exp.append(data)
+                if len(dict_logger):
+                    list_dict.append(dict_logger)
+        except queue.Empty:
+            self._partial = (list_exp, list_dict, cur_size)
+            raise
         return Experience.batch_data(list_exp), batch_logger(list_dict)
 
     def put(self, data: Tuple[Experience, Dict], *args) -> None:

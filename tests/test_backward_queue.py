@@ -49,6 +49,14 @@ def test_get_gathers_whole_pieces_until_the_minimum_batch():
     assert q.q.qsize() == 2                                              # pieces 9 and 10 wait for the next batch
     with pytest.raises(queue.Empty):                                     # ... which is not complete yet
         q.get(1024, True, 0.05)
+    # the two pieces the timed-out call had taken are not lost (the reference's local gather list would be): they head the next batch
+    assert q.q.qsize() == 0
+    more = [_piece(rng, n) for n in (300, 300, 200)]
+    for e, _ in more:
+        q.put((e, {}))
+    exp2, lg2 = q.get(1024)
+    assert len(exp2) == 128 + 140 + 800 and lg2 == {"RewardEpisode": 8.0, "Len": 16.0}     # piece 10's dict was empty (9 % 3 == 0), piece 9's is the only one
+    np.testing.assert_array_equal(exp2.advs[:268], np.concatenate([pieces[8][0].advs, pieces[9][0].advs]))
 
 
 def test_decode_train_blob_roundtrips_u8_and_float64_frames():
