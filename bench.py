@@ -361,6 +361,29 @@ def pmc_traffic(kernel):
         return None
 
 
+def power_evidence():
+    """The newest committed hwmon summary of a bench run (tools/hwmon_trace.py via tools/prof_round.sh): socket power cap, what the
+    bench GPU drew during the PPO updates and the shader clock it held there -- NOT measured by this run (an unprivileged bench
+    process does not sample sysfs beside itself); None without one."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_v*_hwmon_summary.json")):
+        m = re.match(r"^r(\d+)_v(\d+)_hwmon_summary\.json$", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), int(m.group(2))) > best[0]):
+            best = ((int(m.group(1)), int(m.group(2))), f)
+    if best is None:
+        return None
+    try:
+        d = json.load(open(best[1]))
+        c = d["at_cap"]
+        return {"cap_W": d["power_cap_W"], "update_power_W": c["longest_run"]["power_W_mean"], "update_sclk_GHz": c["longest_run"]["sclk_GHz_mean"],
+                "idle_sclk_GHz": d["idle_sclk_GHz_max"], "seconds_at_cap": c["seconds"], "source": os.path.basename(best[1]),
+                "note": "the PPO update runs at the socket's power cap: kernel time follows issued work (energy), DESIGN.md section 3.1"}
+    except Exception:
+        return None
+
+
 TRAIN_KERNELS = ("ConvFwd1", "ConvFwd2", "ConvFwd3", "FcFwd", "FcDgrad", "FcWgrad", "ConvDgrad3", "ConvDgrad2", "ConvWgrad3",
                  "ConvWgrad2", "ConvWgrad1")
 
@@ -1205,6 +1228,8 @@ def main():
                         # the kernel, dated here -- its build, and whether the kernel's source file has changed since (evidence_age)
                         "traffic_build": td["traffic_build"] if td else None, "traffic_stale": td["traffic_stale"] if td else None,
                         "traffic_detail": td,
+                        # what actually binds the update: the socket's power cap (committed hwmon trace of a bench run)
+                        "power": power_evidence(),
                         "mix_model": mix_model(dom, d["ms_avg"] / tscale),
                         "avg_launch_ms": d["ms_avg"], "launches": d["calls"],
                         # the HBM side of the same kernel (north_star asks for the HBM fraction): corrected PMC bytes per launch /

@@ -90,3 +90,10 @@ def test_preflight_static_needs_no_gpu_and_names_the_rccl_in_use():
     assert r["status"] == 0 and r["path"].endswith(".so") or ".so." in r["path"], r
     assert r["version_code"] > 20000, r                      # ncclGetVersion: major * 10000 + minor * 100 + patch
     assert len(st.get("peer_access", [])) == st["device_count"]
+
+
+def test_power_evidence_resolves_from_the_committed_hwmon_summary():
+    """Round 6: the bench line names what binds the update -- the socket's power cap -- from the newest committed hwmon summary."""
+    p = bench.power_evidence()
+    assert p is not None and p["source"].endswith("_hwmon_summary.json")
+    assert p["cap_W"] >= 1000 and 0.9 * p["cap_W"] <= p["update_power_W"] <= p["cap_W"] and 1.0 < p["update_sclk_GHz"] < p["idle_sclk_GHz"]
