@@ -56,7 +56,10 @@ class DeviceRollout:
         copy_into(self.frames[t], frames)
 
     def put_frames_from_ring(self, t, ring):
-        """hipMemcpyAsync from the pinned ring on the copy stream; the compute stream waits on it."""
+        """hipMemcpyAsync from the pinned ring on the copy stream; the compute stream waits on it -- and the copy waits for the compute
+        stream first: whatever was enqueued there on slot t (the pool's zero fill, the previous update still reading the frames) must
+        be through before the DMA overwrites it."""
+        self.copy_stream.wait_stream(torch.cuda.current_stream())
         ring.pop_to(self.frames[t], stream=self.copy_stream)
         torch.cuda.current_stream().wait_stream(self.copy_stream)
 
@@ -145,7 +148,9 @@ class StateRollout:
             copy_into(pool[t], torch.as_tensor(s).reshape(pool[t].shape))
 
     def put_state_from_ring(self, t, index, ring):
-        """Component `index` of slot t from a pinned ring (raw fp32 bytes), on the copy stream."""
+        """Component `index` of slot t from a pinned ring (raw fp32 bytes), on the copy stream (ordered both ways against the compute
+        stream, as put_frames_from_ring)."""
+        self.copy_stream.wait_stream(torch.cuda.current_stream())
         ring.pop_to(self.states[index][t], stream=self.copy_stream)
         torch.cuda.current_stream().wait_stream(self.copy_stream)
 

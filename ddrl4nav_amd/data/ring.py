@@ -31,7 +31,10 @@ class PinnedRing:
         check(self.lib.ddrl_ring_commit(self.h))
 
     def pop_to(self, dst, stream=None, timeout_ms=1000):
-        """hipMemcpyAsync the oldest committed slot into the device tensor `dst`."""
+        """hipMemcpyAsync the oldest committed slot into the device tensor `dst` on `stream` (default: the current one).  With a stream of
+        the caller's own the ordering against other streams is the caller's too: work already enqueued elsewhere on `dst` (its
+        allocation's fill, a kernel still reading it) must be ordered in front of the copy (`stream.wait_stream(...)`), and consumers
+        behind it -- what agent/rollout.py:put_frames_from_ring does."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream()
         nbytes = dst.numel() * dst.element_size()

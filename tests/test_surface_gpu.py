@@ -463,6 +463,9 @@ def test_pinned_ring_feeds_pool():
     dst = torch.zeros((5, 8, 4, 84, 84), dtype=torch.uint8, device="cuda")
     sent = []
     copy_stream = torch.cuda.Stream()
+    # the zero fill of `dst` runs on the CURRENT stream: order it in front of the copies (data/ring.py: with a stream of its own the
+    # caller orders; without this line the fill can land after a copy -- seen once in round 6 as an all-zero slot)
+    copy_stream.wait_stream(torch.cuda.current_stream())
     for i in range(5):  # more messages than slots: exercises recycling
         buf = ring.acquire(timeout_ms=2000)
         data = rng.integers(0, 256, size=slot, dtype=np.uint8)
@@ -587,6 +590,7 @@ def test_pinned_ring_producer_consumer_threads():
     t = threading.Thread(target=producer)
     t.start()
     stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())   # dst's zero fill (current stream) in front of the copies
     for i in range(n_msgs):
         ring.pop_to(dst[i], stream=stream, timeout_ms=5000)
     t.join(timeout=30)
