@@ -95,22 +95,17 @@ __global__ __launch_bounds__(VH_WAVES * 64) void value_head_loss_kernel(const fl
 __global__ __launch_bounds__(256) void value_head_reduce_kernel(const float* __restrict__ part, int nwg, ddrl_config cfg,
                                                                 float inv_b, float* __restrict__ dw, float* __restrict__ db,
                                                                 float* __restrict__ vloss_accum) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= FEAT + 2) return;
-  if (i == FEAT + 1) {
-    double s = 0.0;
-    for (int q = 0; q < nwg; ++q) s += (double)part[(int64_t)q * VH_STRIDE + i];
-    if (vloss_accum) vloss_accum[0] += (float)(s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5));
+  __shared__ double sh[8][RED_OUT];
+  if (blockIdx.x == gridDim.x - 1) {  // the loss sum, by one wave
+    if (threadIdx.x >= 64) return;
+    const double s = wave_sum_partials(part, VH_STRIDE, nwg, FEAT + 1);
+    if (threadIdx.x == 0 && vloss_accum) vloss_accum[0] += (float)(s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5));
     return;
   }
-  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // summed in double, rounded once; eight loads in flight (heads_reduce_kernel)
-  int w = 0;
-  for (; w + 8 <= nwg; w += 8) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) ps[q] += (double)part[(int64_t)(w + q) * VH_STRIDE + i];
-  }
-  for (; w < nwg; ++w) ps[0] += (double)part[(int64_t)w * VH_STRIDE + i];
-  const float s = (float)(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
+  // summed in double, rounded once, in the fixed order of ppo_math.h sum_partials8
+  const int i = blockIdx.x * RED_OUT + (threadIdx.x & (RED_OUT - 1));
+  const float s = sum_partials8(part, VH_STRIDE, nwg, min(i, FEAT), sh);
+  if (threadIdx.x >= RED_OUT || i > FEAT) return;
   if (i < FEAT) {
     if (dw) dw[i] = s;
   } else if (db) {
@@ -131,7 +126,7 @@ void launch_value_head_loss(const ddrl_config& cfg, bool shared, const float* w,
   const float gscale = shared ? inv_b * cfg.v_loss_theta : inv_b;
   hipLaunchKernelGGL(value_head_loss_kernel, dim3(VH_WG), dim3(VH_WAVES * 64), 0, st, w, b, h, ld_h, n, rets, cfg, gscale, dh,
                      ld_dh, part);
-  hipLaunchKernelGGL(value_head_reduce_kernel, dim3((FEAT + 2 + 255) / 256), dim3(256), 0, st, part, VH_WG, cfg, inv_b, dw, db,
+  hipLaunchKernelGGL(value_head_reduce_kernel, dim3((FEAT + 1 + RED_OUT - 1) / RED_OUT + 1), dim3(256), 0, st, part, VH_WG, cfg, inv_b, dw, db,
                      vloss_accum);
 }
 

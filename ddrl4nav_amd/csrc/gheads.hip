@@ -233,32 +233,25 @@ __global__ __launch_bounds__(256) void gauss_loss_kernel(
 __global__ __launch_bounds__(256) void gauss_reduce_kernel(const float* __restrict__ hpart, int64_t hstride, int nwg,
                                                            GaussLayout L, ddrl_config cfg, float inv_b,
                                                            float* __restrict__ grads) {
+  __shared__ double sh[8][RED_OUT];
   const int D = L.D;
   const int o = (D + 1) * FEAT;
-  const int total = o + 2 * D + 1 + 3;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  if (i >= o + 2 * D + 1) {
-    double s = 0.0;
-    for (int w = 0; w < nwg; ++w) s += (double)hpart[(int64_t)w * hstride + i];
-    const int k = i - (o + 2 * D + 1);
+  const int nsum = o + 2 * D + 1;
+  if (blockIdx.x == gridDim.x - 1) {  // the three loss sums, one wave each
+    const int k = threadIdx.x >> 6;
+    if (k >= 3) return;
+    const double s = wave_sum_partials(hpart, hstride, nwg, nsum + k);
     double r;
     if (k == 0) r = -s * (double)inv_b;
     else if (k == 1) r = s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5);
     else r = s * (double)inv_b;
-    grads[L.n_params + k] = (float)r;
+    if ((threadIdx.x & 63) == 0) grads[L.n_params + k] = (float)r;
     return;
   }
-  // summed in double, rounded once; eight independent partial sums (workgroups w = q mod 8) combined in a fixed order, so that the
-  // 256 loads of a thread are in flight eight at a time instead of one dependent add after the other (heads.hip heads_reduce_kernel)
-  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int w = 0;
-  for (; w + 8 <= nwg; w += 8) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) ps[q] += (double)hpart[(int64_t)(w + q) * hstride + i];
-  }
-  for (; w < nwg; ++w) ps[0] += (double)hpart[(int64_t)w * hstride + i];
-  const float s = (float)(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
+  // summed in double, rounded once, in the fixed order of ppo_math.h sum_partials8 (the arithmetic of the one-thread-per-element form)
+  const int i = blockIdx.x * RED_OUT + (threadIdx.x & (RED_OUT - 1));
+  const float s = sum_partials8(hpart, hstride, nwg, min(i, nsum - 1), sh);
+  if (threadIdx.x >= RED_OUT || i >= nsum) return;
   int64_t dst;
   if (i < D * FEAT) dst = L.actor_w + i;
   else if (i < o) dst = L.critic_w + (i - D * FEAT);
@@ -286,8 +279,8 @@ void launch_gauss_loss(const GaussLayout& L, const ddrl_config& cfg, const float
   const int64_t hs = gauss_hpart_stride(L.D);
   hipLaunchKernelGGL(gauss_loss_kernel, dim3(HEAD_WG), dim3(256), 0, st, h_actor, h_critic, params, L, cfg, n, actions,
                      old_logps, advs, rets, inv_b, dh_actor, dh_critic, dmu, dvalue, hpart, hs);
-  const int total = (L.D + 1) * FEAT + 2 * L.D + 1 + 3;
-  hipLaunchKernelGGL(gauss_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, hpart, hs, HEAD_WG, L, cfg, inv_b,
+  const int nsum = (L.D + 1) * FEAT + 2 * L.D + 1;  // gradient elements; + one workgroup for the three loss sums
+  hipLaunchKernelGGL(gauss_reduce_kernel, dim3((nsum + RED_OUT - 1) / RED_OUT + 1), dim3(256), 0, st, hpart, hs, HEAD_WG, L, cfg, inv_b,
                      grads);
 }
 

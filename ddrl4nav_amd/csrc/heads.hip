@@ -249,13 +249,18 @@ __global__ __launch_bounds__(256) void heads_act_kernel(float* __restrict__ h, i
 // --------------------------------------------------------------------------------------------
 // WLDS (A > 8): the actor-head weight / bias gradient slots of hpart are written by
 // head_wgrad_kernel from dlogits instead (288 accumulator + weight registers do not fit a lane).
-constexpr int LOSS_WAVES = 4;  // waves per workgroup of heads_loss: one per SIMD, see the sample loop
+constexpr int LOSS_WAVES = 4;      // waves per workgroup of heads_loss: one per SIMD (register-resident head weights, A = 7 .. 8 and A > 8)
+#ifndef DDRL_LOSS_WAVES6
+#define DDRL_LOSS_WAVES6 8         // A <= 6 (Pong): the weight rows live in LDS, 245 registers -> two waves per SIMD (round 6)
+#endif
+constexpr int LOSS_WAVES6 = DDRL_LOSS_WAVES6;
 #ifndef DDRL_LOSS_NS
 #define DDRL_LOSS_NS 4      // samples per wave and turn (a power of two): the scalar chain of the loss block runs once per NS samples
 #endif
 constexpr int LOSS_NS = DDRL_LOSS_NS;
-template <int MAXA, bool WLDS>
-__global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
+// GREG: the actor head's weight / bias gradient is accumulated in registers (else: head_wgrad_kernel, A > 8)
+template <int MAXA, bool WLDS, bool GREG = !WLDS, int WAVES = LOSS_WAVES>
+__global__ __launch_bounds__(WAVES * 64) void heads_loss_kernel(
     const float* __restrict__ h, int64_t h_es, const float* __restrict__ params, ParamLayout L, ddrl_config cfg, int n,
     const float* __restrict__ actions, const float* __restrict__ old_logps, const float* __restrict__ advs,
     const float* __restrict__ rets, float inv_b, float* __restrict__ dh, int64_t dh_es, float* __restrict__ dlogits,
@@ -263,12 +268,12 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     float* __restrict__ amax) {
   __shared__ float red[(MAXA + 1) * FEAT + 2 * MAXA + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw = blockIdx.x * LOSS_WAVES + wave;
-  const int nw = gridDim.x * LOSS_WAVES;
+  const int gw = blockIdx.x * WAVES + wave;
+  const int nw = gridDim.x * WAVES;
   const int A = L.A;
   HeadRegs<MAXA, WLDS> R;
   load_head_weights(R, params, L, lane, red);  // LDS weights alias the reduction buffer (used after the loop)
-  constexpr int GA = WLDS ? 1 : MAXA;
+  constexpr int GA = GREG ? MAXA : 1;
   float gwa[GA][8], gwc[8], gba[GA], gbc = 0.0f;
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
@@ -285,8 +290,7 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
   float wc_absmax = 0.0f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) wc_absmax = fmaxf(wc_absmax, fabsf(R.wc[i]));
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) wc_absmax = fmaxf(wc_absmax, __shfl_xor(wc_absmax, off, 64));
+  wc_absmax = wave_max(wc_absmax);
   // (exponent arithmetic on the bit pattern: frexpf / ldexpf are library calls, and this runs once per sample and encoder)
   auto scale_of = [&](float m, float& g, float& gi) {
     int ex = GSC_EXP_MIN;
@@ -307,9 +311,7 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     float m = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(d[i]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    return m;
+    return wave_max(m);
   };
   // shared prenet (ppo.py:110-117): one backward of total_loss = actor_loss + theta_v * v_loss
   // - theta_e * entropy, so the value gradient carries theta_v, the entropy has a gradient, and
@@ -317,19 +319,26 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
   // v_loss.backward() only -- no theta_v, no entropy gradient.
   const bool shared = (L.NE == 1);
   const int ec = L.NE - 1;
-  // One wave per SIMD (the 8 x 8 + 8 gradient accumulators, the head weights and the working set do not fit two).  A wave takes NS samples
-  // per turn (round 6; one per turn before: 1,046 vector instructions per sample, most of them the softmax / log / divide chain that
-  // all 64 lanes executed on the same wave-uniform numbers).  Three phases per turn:
-  //   A  per sample: the A + 1 dot products (8 features per lane + a wave reduction), results in every lane, as before;
-  //   B  ONCE for the NS samples: lane l works on sample l mod NS -- softmax, Categorical bookkeeping, surrogate, value loss, entropy
-  //      and d(loss)/d(logits, value) -- so the transcendental chain is paid once per NS samples;
-  //   C  per sample: its dlogits / dvalue are read back from lane i (v_readlane: wave-uniform again) and the head layers' backward,
-  //      the per-sample normalisation of dh and the stores run as before.
-  // Sample i of the NEXT turn is requested into the registers of this turn's sample i as soon as phase C is done with them (no second
-  // register set: with one the kernel needed 394 registers, 138 of them accumulation registers used as a spill area): the request has
-  // the rest of phase C, phase B and i samples of phase A to arrive.
+  // A wave takes NS samples per turn (round 6; one per turn before: 1,046 vector instructions per sample, most of them the softmax /
+  // log / divide chain that all 64 lanes executed on the same wave-uniform numbers).  Phases of a turn:
+  //   A  the NS x (A + 1) dot products: 8 features per lane, then wave reductions (TR below: all of them together);
+  //   B  ONCE for the NS samples: one lane per sample -- softmax, Categorical bookkeeping, surrogate, value loss, entropy and
+  //      d(loss)/d(logits, value) -- so the transcendental chain is paid once per NS samples;
+  //   C  per sample: its dlogits / dvalue are read back from its lane (v_readlane: wave-uniform again); C1 = the weight-gradient sums and
+  //      the request of the next turn's sample into the same registers, C2 = d(features), their per-sample normalisation, the stores.
+  // Registers: 8 x (A + 1) gradient accumulators, NS x 16 features, the head weights.  With the weights in registers that is one wave per
+  // SIMD (A = 7, 8); the A <= 6 form reads the weight rows from LDS (60 ds_read_b128 per turn) and runs two (245 registers).
+  // No second register set for the next turn: the kernel would need 394 registers, 138 of them accumulation registers used as spill area.
   constexpr int NS = LOSS_NS;
-  const int ls = lane & (NS - 1);                   // the sample of the turn this lane works on in phase B
+  // TR: the NS x (A + 1) dot products of a turn are reduced TOGETHER (ppo_math.h, transposing reduction: 32 values in 32 exchanges
+  // instead of 28 butterflies of 6); sample i's totals then sit in ROW i' = 2 (i & 1) + (i >> 1) of the wave (16 lanes), value j at lane
+  // 8 (j & 1) + 4 (j >> 1 & 1) + 2 (j >> 2) of the row, and the row's first lane -- the one that works on the sample in phase B -- collects
+  // them with seven DPP row shifts for all four samples at once.
+  constexpr bool TR = (NS == 4) && (MAXA + 1 <= 8);
+  const int ls = TR ? ((lane >> 5) | ((lane >> 3) & 2)) : (lane & (NS - 1));  // the sample of the turn this lane works on in phase B
+  const bool owner = TR ? (lane & 15) == 0 : lane < NS;
+  auto owner_lane = [](int i) { return TR ? 32 * (i & 1) + 16 * (i >> 1) : i; };
+  const bool bit3 = lane & 8, bit2 = lane & 4, bit1 = lane & 2;
   float ha[NS][8], hc[NS][8];
   auto request = [&](int b0, float (&xa)[NS][8], float (&xc)[NS][8]) {
 #pragma unroll
@@ -339,33 +348,72 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
       load8(h + ec * h_es + (int64_t)b * FEAT + lane * 8, xc[i]);
     }
   };
-  auto bcast = [&](float x, int i) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x), i)); };
+  auto bcast = [&](float x, int i) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x), owner_lane(i))); };
   if (gw * NS < n) request(gw * NS, ha, hc);
   for (int b0 = gw * NS; b0 < n; b0 += nw * NS) {
     // the lane's own sample of phase B: its four scalars come straight from memory (contiguous over the NS lanes)
     const int bl = min(b0 + ls, n - 1);
-    const bool live = b0 + ls < n && lane < NS;       // this lane's phase-B results count (lanes >= NS repeat lanes < NS)
+    const bool live = b0 + ls < n && owner;           // this lane's phase-B results count (the other lanes repeat them or work on junk)
     const float s_act = actions[bl], s_adv = advs[bl], s_olp = old_logps[bl], s_ret = rets[bl];
     // ---- phase A (a lane keeps only the results of ITS sample of phase B: no [NS][A + 1] array of logits in registers)
     float zl[MAXA], v = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) zl[j] = 0.0f;
+    if constexpr (TR) {
+      // value index = i + 4 j (j = MAXA: the critic's dot product; j > MAXA: padding): level 32 pairs samples (0, 1) / (2, 3) of one j
+      float zz[8];  // after level 16: one register per j, row i' = sample i
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
+      for (int j = 0; j < 8; ++j) {
+        if (j > MAXA) { zz[j] = 0.0f; continue; }
+        float w[8];
+        if (j < MAXA) R.row(j, lane, w);
+        float y[2];
 #pragma unroll
-      for (int j = 0; j < MAXA; ++j) {
-        float s = 0.0f, w[8];
-        R.row(j, lane, w);
+        for (int i1 = 0; i1 < 2; ++i1) {
+          float s[2] = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s = __builtin_fmaf(ha[i][k], w[k], s);
-        const float zj = wave_sum(s) + R.ba[j];
-        zl[j] = (ls == i) ? zj : zl[j];
+          for (int i0 = 0; i0 < 2; ++i0)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              s[i0] = j < MAXA ? __builtin_fmaf(ha[2 * i1 + i0][k], w[k], s[i0]) : __builtin_fmaf(hc[2 * i1 + i0][k], R.wc[k], s[i0]);
+          y[i1] = swap_add32(s[0], s[1]);
+        }
+        zz[j] = swap_add16(y[0], y[1]);
       }
-      float sv = 0.0f;
+      float w4[4], w2[2];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sv = __builtin_fmaf(hc[i][k], R.wc[k], sv);
-      const float vi = wave_sum(sv) + R.bc;
-      v = (ls == i) ? vi : v;
+      for (int q = 0; q < 4; ++q) w4[q] = fold_add8(zz[2 * q], zz[2 * q + 1], bit3);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) w2[q] = fold_add4(w4[2 * q], w4[2 * q + 1], bit2);
+      float tot = fold_add2(w2[0], w2[1], bit1);
+      tot += dpp_lane<0xB1>(tot, tot);
+      // the row's first lane collects its sample's values: row_shl:n reads lane + n of the row
+      float g[8];
+      g[0] = tot;
+      g[1] = dpp_lane<0x108>(tot, tot), g[2] = dpp_lane<0x104>(tot, tot), g[3] = dpp_lane<0x10C>(tot, tot);
+      g[4] = dpp_lane<0x102>(tot, tot), g[5] = dpp_lane<0x10A>(tot, tot), g[6] = dpp_lane<0x106>(tot, tot);
+      g[7] = dpp_lane<0x10E>(tot, tot);
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) zl[j] = g[j] + R.ba[j];
+      v = g[MAXA] + R.bc;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) {
+          float s = 0.0f, w[8];
+          R.row(j, lane, w);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s = __builtin_fmaf(ha[i][k], w[k], s);
+          const float zj = wave_sum(s) + R.ba[j];
+          zl[j] = (ls == i) ? zj : zl[j];
+        }
+        float sv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sv = __builtin_fmaf(hc[i][k], R.wc[k], sv);
+        const float vi = wave_sum(sv) + R.bc;
+        v = (ls == i) ? vi : v;
+      }
     }
     // ---- phase B: this lane's sample
     Dist<MAXA> d;
@@ -420,7 +468,35 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     for (int j = 0; j < MAXA; ++j) gzl[j] = (j < A) ? (gp[j] - dot) * d.p[j] : 0.0f;
     const float gvl = shared ? gv_unit * inv_b * cfg.v_loss_theta : gv_unit * inv_b;
 
-    // ---- phase C: head layers backward, sample by sample
+    // ---- phase C: head layers backward, sample by sample.  C1 takes what needs the features (the weight-gradient sums) and
+    // requests the next turn's sample into the registers it has just finished with; C2 (d(features), their normalisation, the stores)
+    // needs only weights and the sample's dlogits / dvalue, so the requests have all of C2 to arrive before the next phase A -- which,
+    // reducing the four samples together, wants all four at its start.
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int b = b0 + i;
+      if (b >= n) break;  // wave-uniform
+      float gz[MAXA];
+#pragma unroll
+      for (int j = 0; j < MAXA; ++j) gz[j] = bcast(gzl[j], i);
+      const float gv = bcast(gvl, i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gwc[k] = __builtin_fmaf(gv, hc[i][k], gwc[k]);
+      if constexpr (GREG) {
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) {
+          gba[j] += gz[j];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gwa[j][k] = __builtin_fmaf(gz[j], ha[i][k], gwa[j][k]);
+        }
+      }
+      gbc += gv;
+      {  // the next turn's sample i (past the end: the last sample again, never used)
+        const int bn = min(b + nw * NS, n - 1);
+        load8(h + (int64_t)bn * FEAT + lane * 8, ha[i]);
+        load8(h + ec * h_es + (int64_t)bn * FEAT + lane * 8, hc[i]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int b = b0 + i;
@@ -440,19 +516,7 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
         for (int k = 0; k < 8; ++k) da[k] = __builtin_fmaf(gz[j], w[k], da[k]);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        dc[k] = gv * R.wc[k];
-        gwc[k] = __builtin_fmaf(gv, hc[i][k], gwc[k]);
-      }
-      if constexpr (!WLDS) {
-#pragma unroll
-        for (int j = 0; j < MAXA; ++j) {
-          gba[j] += gz[j];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) gwa[j][k] = __builtin_fmaf(gz[j], ha[i][k], gwa[j][k]);
-        }
-      }
-      gbc += gv;
+      for (int k = 0; k < 8; ++k) dc[k] = gv * R.wc[k];
       if (shared) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) da[k] += dc[k];
@@ -470,21 +534,16 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
       }
       if (lane < A) dlogits[(int64_t)b * A + lane] = pick(gz, lane);
       if (lane == 0) dvalue[b] = gv;
-      {  // the next turn's sample i (past the end: the last sample again, never used)
-        const int bn = min(b + nw * NS, n - 1);
-        load8(h + (int64_t)bn * FEAT + lane * 8, ha[i]);
-        load8(h + ec * h_es + (int64_t)bn * FEAT + lane * 8, hc[i]);
-      }
     }
   }
-  // the loss sums live in lanes 0 .. NS - 1 (one sample each per turn): added in lane order into lane 0
+  // the loss sums live in the NS owner lanes (one sample each per turn): added in sample order into lane 0
   {
     double ta = 0.0, tv = 0.0, te = 0.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      ta += __shfl(s_actor, i, 64);
-      tv += __shfl(s_v, i, 64);
-      te += __shfl(s_ent, i, 64);
+      ta += __shfl(s_actor, owner_lane(i), 64);
+      tv += __shfl(s_v, owner_lane(i), 64);
+      te += __shfl(s_ent, owner_lane(i), 64);
     }
     s_actor = ta, s_v = tv, s_ent = te;
   }
@@ -503,10 +562,10 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
   // ---- workgroup reduction, waves accumulate in turn (fixed order) -> hpart[blockIdx.x] ----
   constexpr int SCAL = (MAXA + 1) * FEAT;
   if constexpr (WLDS) __syncthreads();  // every wave is done with the LDS weights aliased by `red`
-  for (int w = 0; w < LOSS_WAVES; ++w) {
+  for (int w = 0; w < WAVES; ++w) {
     if (wave == w) {
       const bool first = (w == 0);
-      if constexpr (!WLDS) {
+      if constexpr (GREG) {
 #pragma unroll
         for (int j = 0; j < MAXA; ++j)
 #pragma unroll
@@ -521,7 +580,7 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
         red[idx] = first ? gwc[i] : red[idx] + gwc[i];
       }
       if (lane == 0) {
-        if constexpr (!WLDS) {
+        if constexpr (GREG) {
 #pragma unroll
           for (int j = 0; j < MAXA; ++j) red[SCAL + j] = first ? gba[j] : red[SCAL + j] + gba[j];
         }
@@ -534,11 +593,11 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void heads_loss_kernel(
     __syncthreads();
   }
   float* out = hpart + (int64_t)blockIdx.x * hstride;
-  if constexpr (!WLDS) {
-    for (int i = threadIdx.x; i < A * FEAT; i += LOSS_WAVES * 64) out[i] = red[i];
+  if constexpr (GREG) {
+    for (int i = threadIdx.x; i < A * FEAT; i += WAVES * 64) out[i] = red[i];
     if (threadIdx.x < A) out[(A + 1) * FEAT + threadIdx.x] = red[SCAL + threadIdx.x];
   }
-  for (int i = threadIdx.x; i < FEAT; i += LOSS_WAVES * 64) out[A * FEAT + i] = red[MAXA * FEAT + i];
+  for (int i = threadIdx.x; i < FEAT; i += WAVES * 64) out[A * FEAT + i] = red[MAXA * FEAT + i];
   if (threadIdx.x == 0) out[(A + 1) * FEAT + A] = red[SCAL + MAXA];
   if (threadIdx.x < 3) out[(A + 1) * FEAT + A + 1 + threadIdx.x] = red[SCAL + MAXA + 1 + threadIdx.x];
 }
@@ -574,43 +633,34 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   }
 }
 
-// grads[head params] = sum over workgroups (fixed order); grads[n_params+0..2] = loss shares
+// grads[head params] = sum over workgroups (fixed order, ppo_math.h sum_partials8: the arithmetic of the earlier one-thread-per-element
+// form, so the gradients are bit-identical to it); grads[n_params+0..2] = loss shares, by the last workgroup (one wave per loss).
 __global__ __launch_bounds__(256) void heads_reduce_kernel(const float* __restrict__ hpart, int64_t hstride, int nwg,
                                                            ParamLayout L, ddrl_config cfg, float inv_b,
                                                            float* __restrict__ grads) {
+  __shared__ double sh[8][RED_OUT];
   const int A = L.A;
-  const int total = (A + 1) * FEAT + A + 1 + 3;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
   const int nloss0 = (A + 1) * FEAT + A + 1;
-  if (i >= nloss0) {
-    double s = 0.0;
-    for (int w = 0; w < nwg; ++w) s += (double)hpart[(int64_t)w * hstride + i];
-    const int k = i - nloss0;
+  if (blockIdx.x == gridDim.x - 1) {
+    const int k = threadIdx.x >> 6;
+    if (k >= 3) return;
+    const double s = wave_sum_partials(hpart, hstride, nwg, nloss0 + k);
     double r;
     if (k == 0) r = -s * (double)inv_b;            // actor_loss = -mean(term)
     else if (k == 1) r = s * (double)inv_b * (cfg.smooth_l1_loss ? 1.0 : 0.5);  // v_loss = mean(err^2)/2
     else r = s * (double)inv_b;                    // entropy = mean(H)
-    grads[L.n_params + k] = (float)r;
+    if ((threadIdx.x & 63) == 0) grads[L.n_params + k] = (float)r;
     return;
   }
-  // eight independent partial sums (workgroups w = q mod 8), combined in a fixed order: the 256 loads of a thread are in flight
-  // eight at a time instead of one dependent add after the other (0.12 -> 0.03 ms)
-  // (summed in double and rounded once, as the split-K slabs in optim.hip)
-  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int w = 0;
-  for (; w + 8 <= nwg; w += 8) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) ps[q] += (double)hpart[(int64_t)(w + q) * hstride + i];
-  }
-  for (; w < nwg; ++w) ps[0] += (double)hpart[(int64_t)w * hstride + i];
-  const float s = (float)(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
+  const int i = blockIdx.x * RED_OUT + (threadIdx.x & (RED_OUT - 1));
+  const float sum = sum_partials8(hpart, hstride, nwg, min(i, nloss0 - 1), sh);
+  if (threadIdx.x >= RED_OUT || i >= nloss0) return;
   int64_t dst;
   if (i < A * FEAT) dst = L.actor_w + i;
   else if (i < (A + 1) * FEAT) dst = L.critic_w + (i - A * FEAT);
   else if (i < (A + 1) * FEAT + A) dst = L.actor_b + (i - (A + 1) * FEAT);
   else dst = L.critic_b;
-  grads[dst] = s;
+  grads[dst] = sum;
 }
 
 __global__ __launch_bounds__(256) void categorical_stats_kernel(const float* __restrict__ probs, int n, int A,
@@ -677,17 +727,18 @@ void launch_heads_loss(const HeadsCall& c, const float* actions, const float* ol
                        const float* rets, float inv_b, float* grads, hipStream_t st) {
   const int64_t hs = hpart_stride(c.L->A);
   const bool large = c.L->A > MAXA_SMALL;
-  // A <= 6 (Pong's six actions): two rows fewer of weights, gradient accumulators and per-sample logits in registers than the A <= 8 form
-  auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : (c.L->A <= 6 ? heads_loss_kernel<6, false> : heads_loss_kernel<MAXA_SMALL, false>);
-  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3(LOSS_WAVES * 64), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT, c.params,
+  // A <= 6 (Pong's six actions): the four samples' 7 x 4 dot products are reduced together (TR in the kernel), weight rows in LDS, eight waves
+  const bool six = c.L->A <= 6;
+  auto kern = large ? heads_loss_kernel<MAXA_LARGE, true> : (six ? heads_loss_kernel<6, LOSS_WAVES6 == 8, true, LOSS_WAVES6> : heads_loss_kernel<MAXA_SMALL, false>);
+  hipLaunchKernelGGL(kern, dim3(HEAD_WG), dim3((six ? LOSS_WAVES6 : LOSS_WAVES) * 64), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT, c.params,
                      *c.L, *c.cfg, c.n, actions, old_logps, advs, rets, inv_b, c.ws->dh,
                      c.dh_es != HeadsCall::ES_UNSET ? c.dh_es : c.max_batch * FEAT, c.ws->dlogits, c.ws->dvalue, c.ws->hpart, hs,
                      c.normalise_dh ? c.ws->gsc : nullptr, c.max_batch, c.ws->amax);
   if (large)
     hipLaunchKernelGGL(head_wgrad_kernel<MAXA_LARGE>, dim3(HEAD_WG), dim3(256), 0, st, c.ws->h, c.ws->dlogits, c.n,
                        c.L->A, c.ws->hpart, hs);
-  const int total = (c.L->A + 1) * FEAT + c.L->A + 1 + 3;
-  hipLaunchKernelGGL(heads_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, c.ws->hpart, hs, HEAD_WG, *c.L,
+  const int nsum = (c.L->A + 1) * FEAT + c.L->A + 1;  // gradient elements; + one workgroup for the three loss sums
+  hipLaunchKernelGGL(heads_reduce_kernel, dim3((nsum + RED_OUT - 1) / RED_OUT + 1), dim3(256), 0, st, c.ws->hpart, hs, HEAD_WG, *c.L,
                      *c.cfg, inv_b, grads);
 }
 
