@@ -176,7 +176,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
   double s = 0.0;
-  for (int sp = 0; sp < nsplit; ++sp) s += (double)part[((int64_t)sp * 2 + e) * count + i];
+  int sp = 0;
+  for (; sp + 8 <= nsplit; sp += 8) {  // slab order; the loads of a round are requested before its adds
+    float x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = part[((int64_t)(sp + t) * 2 + e) * count + i];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += (double)x[t];
+  }
+  for (; sp < nsplit; ++sp) s += (double)part[((int64_t)sp * 2 + e) * count + i];
   grads[(e ? off1 : off0) + i] = (float)s;
 }
 // Many slabs of few elements (conv1: 1,024 slabs x 8,224 values): 16 lane groups walk the slabs in
