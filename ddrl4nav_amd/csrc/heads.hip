@@ -714,11 +714,19 @@ void launch_categorical_sample(const float* probs, int n, int A, uint64_t seed, 
 
 void launch_heads_act(const HeadsCall& c, const float* act_in, uint64_t seed, uint64_t stream_id, float* probs,
                       float* value, float* action_out, float* logp_out, hipStream_t st) {
-  int wgs = (c.n + 3) / 4;
+#ifndef DDRL_HEADS_ACT_WAVES
+#define DDRL_HEADS_ACT_WAVES 1
+#endif
+  // register-resident head weights (A <= 8): ONE wave per workgroup, so that the samples of a small acting batch spread over the CUs (each
+  // wave pulls 57 KB of split-K partials through its CU's path to L2; four per CU were 64 busy CUs of 256); A > 8 shares the LDS copy of
+  // the head weights between four waves
+  const bool small = c.L->A <= MAXA_SMALL;
+  const int wpw = small ? DDRL_HEADS_ACT_WAVES : 4;
+  int wgs = (c.n + wpw - 1) / wpw;
   if (wgs > 1024) wgs = 1024;
   const int nsplit = c.plain_features ? 1 : fc_forward_splits(c.n);
-  auto kern = c.L->A <= MAXA_SMALL ? heads_act_kernel<MAXA_SMALL, false> : heads_act_kernel<MAXA_LARGE, true>;
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT,
+  auto kern = small ? heads_act_kernel<MAXA_SMALL, false> : heads_act_kernel<MAXA_LARGE, true>;
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpw), 0, st, c.ws->h, c.h_es != HeadsCall::ES_UNSET ? c.h_es : c.max_batch * FEAT,
                      nsplit > 1 ? c.ws->wpart : nullptr, nsplit > 1 ? nsplit : 0, c.params, *c.L, c.n,
                      act_in, seed, stream_id, probs, value, action_out, logp_out);
 }
