@@ -12,10 +12,10 @@ namespace ddrl {
 // --------------------------------------------------------------------------------------------
 // conv1 weights as the NPL planes of engine2.h's plane scheme (default: two scaled fp16 planes, h0 + h1 = w S to 22 bits; the
 // kernel names keep their history).  Layout: common.h wp1b.
-__global__ __launch_bounds__(256) void pack_conv1_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
-                                                              const float* __restrict__ amax) {
+__device__ __forceinline__ void pack_conv1_planes_body(const float* __restrict__ params, const ParamLayout& L, unsigned short* __restrict__ dst,
+                                                       const float* __restrict__ amax, int bx) {
   const int rows = 32 * L.NE;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = bx * 256 + threadIdx.x;
   if (idx >= L.C * 4 * 2 * rows * 8) return;  // [channel C][ky pair 4][plane][lane half 2][row][kx 8]
   const int j = idx & 7, row = (idx >> 3) % rows, r = (idx >> 3) / rows;
   const int h = r & 1, g = (r >> 1) & 3, c = r >> 3;
@@ -29,12 +29,12 @@ __global__ __launch_bounds__(256) void pack_conv1_planes_kernel(const float* __r
 }
 
 // dense-layer weights as NPL planes (see pack_conv1_planes_kernel): wlb[e][plane][n][k]
-__global__ __launch_bounds__(256) void pack_fc_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst,
-                                                           unsigned short* __restrict__ dst_t, const float* __restrict__ amax) {
+__device__ __forceinline__ void pack_fc_planes_body(const float* __restrict__ params, const ParamLayout& L, unsigned short* __restrict__ dst,
+                                                    unsigned short* __restrict__ dst_t, const float* __restrict__ amax,
+                                                    unsigned short (&tile)[NPL][32][33], int bx, int by, int e) {
   // one 32 (n) x 32 (k) tile per workgroup: the planes go out row-major as they come in and, through LDS, transposed for the data
   // gradient ([plane][k][n]) -- both in 64-byte runs (element-wise the transposed copy was 2-byte stores 1 KB apart: 36 us per pack)
-  __shared__ unsigned short tile[NPL][32][33];
-  const int e = blockIdx.z, k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int k0 = bx * 32, n0 = by * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float sc = plane_scale(amax[amax_idx(AMAX_WL, e)]);
   const float* src = params + L.enc_base[e] + L.enc.lw;
@@ -61,9 +61,8 @@ __global__ __launch_bounds__(256) void pack_fc_planes_kernel(const float* __rest
 }
 
 // conv2 weights as NPL planes: wp2b[e][in channel][plane][oc][tap = ky * 4 + kx]
-__global__ __launch_bounds__(256) void pack_conv2_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
-  const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (oc, ch, tap) in parameter order
+__device__ __forceinline__ void pack_conv2_planes_body(const float* __restrict__ params, const ParamLayout& L, unsigned short* __restrict__ dst, const float* __restrict__ amax, int bx, int e) {
+  const int i = bx * 256 + threadIdx.x;  // (oc, ch, tap) in parameter order
   if (i >= 64 * 32 * 16) return;
   const int tap = i & 15, ch = (i >> 4) & 31, oc = i >> 9;
   const float w = params[L.enc_base[e] + L.enc.c2w + i];
@@ -75,9 +74,8 @@ __global__ __launch_bounds__(256) void pack_conv2_planes_kernel(const float* __r
 }
 
 // conv3 weights as NPL planes: wp3b[e][k-block = ic / 8][tap pair][plane][oc][tap parity][ic % 8]; the tenth tap is zero
-__global__ __launch_bounds__(256) void pack_conv3_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
-  const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb, kg, oc, h, c)
+__device__ __forceinline__ void pack_conv3_planes_body(const float* __restrict__ params, const ParamLayout& L, unsigned short* __restrict__ dst, const float* __restrict__ amax, int bx, int e) {
+  const int i = bx * 256 + threadIdx.x;  // (kb, kg, oc, h, c)
   if (i >= 8 * 5 * 64 * 16) return;
   const int c = i & 7, h = (i >> 3) & 1, oc = (i >> 4) & 63, kg = (i >> 10) % 5, kb = (i >> 10) / 5;
   const int tap = 2 * kg + h;
@@ -91,9 +89,8 @@ __global__ __launch_bounds__(256) void pack_conv3_planes_kernel(const float* __r
 
 // conv2 weights for the plane-product data gradient: wd2b[e][a][kb 8][u 2][plane][row = c * 32 + ic][v][o]
 //   = W2[oc = 8 kb + o][ic][2 u + a][2 v + c]
-__global__ __launch_bounds__(256) void pack_dgrad2_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
-  const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (a, kb, u, row, v, o)
+__device__ __forceinline__ void pack_dgrad2_planes_body(const float* __restrict__ params, const ParamLayout& L, unsigned short* __restrict__ dst, const float* __restrict__ amax, int bx, int e) {
+  const int i = bx * 256 + threadIdx.x;  // (a, kb, u, row, v, o)
   if (i >= 2 * 8 * 2 * 64 * 16) return;
   const int o = i & 7, v = (i >> 3) & 1, row = (i >> 4) & 63, u = (i >> 10) & 1, kb = (i >> 11) & 7, a = i >> 14;
   const int c = row >> 5, ic = row & 31, oc = 8 * kb + o;
@@ -106,9 +103,8 @@ __global__ __launch_bounds__(256) void pack_dgrad2_planes_kernel(const float* __
 }
 
 // conv3 weights for the data gradient on planes (conv2.hip conv_dgrad3_planes_kernel): k-blocks of 16 oc, one k-group per tap
-__global__ __launch_bounds__(256) void pack_dgrad3_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ dst, const float* __restrict__ amax) {
-  const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;  // (kb 4, tap 9, ic 64, h 2, o 8): wd3b[e][kb][tap][plane][ic][h][o] = W3[oc = 16 kb + 8 h + o][ic][tap]
+__device__ __forceinline__ void pack_dgrad3_planes_body(const float* __restrict__ params, const ParamLayout& L, unsigned short* __restrict__ dst, const float* __restrict__ amax, int bx, int e) {
+  const int i = bx * 256 + threadIdx.x;  // (kb 4, tap 9, ic 64, h 2, o 8): wd3b[e][kb][tap][plane][ic][h][o] = W3[oc = 16 kb + 8 h + o][ic][tap]
   if (i >= 4 * 9 * 64 * 16) return;
   const int o = i & 7, h = (i >> 3) & 1, ic = (i >> 4) & 63, tap = (i >> 10) % 9, kb = (i >> 10) / 9;
   const float w = params[L.enc_base[e] + L.enc.c3w + ((16 * kb + 8 * h + o) * 64 + ic) * 9 + tap];
@@ -119,50 +115,93 @@ __global__ __launch_bounds__(256) void pack_dgrad3_planes_kernel(const float* __
   for (int p = 0; p < NPL; ++p) d[p * 64 * 16] = pl[p];
 }
 
-// largest magnitude of linear.weight / conv2.weight / conv3.weight / conv1.weight per encoder -> Workspace::amax weight slots
-// (the power-of-two scale of their fp16 planes, engine2.h plane scheme); grid (64, 4 tensors, NE), slots zeroed before
+// Weight magnitudes, ONE launch (round 6: was weights_amax + a1_bound, 24 + 5 us):
+//   blocks [0, WA_BLOCKS x NE): largest magnitude of linear.weight / conv2.weight / conv3.weight / conv1.weight per encoder -> Workspace::amax
+//     weight slots (the power-of-two scale of their fp16 planes, engine2.h plane scheme), slots zeroed before.  The dense layer's 1.6 M
+//     values get 128 workgroups, eight independent loads per thread and round (64 workgroups walking them one dependent maximum after
+//     the other: 13.5 MB in 24 us);
+//   then 8 blocks per encoder: upper bound of |a1| -> slot AMAX_A1 (common.h): max over oc of sum_k |w1[oc][k]| + |b1[oc]|, one wave per oc.
+constexpr int WA_NBLK[4] = {128, 8, 8, 4};  // slots AMAX_WL, AMAX_W2, AMAX_W3, AMAX_W1
+constexpr int WA_BLOCKS = 128 + 8 + 8 + 4, A1B_BLOCKS = 8;
 __global__ __launch_bounds__(256) void weights_amax_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ amax) {
-  const int t = blockIdx.y, e = blockIdx.z;  // t = slot
+  int bid = blockIdx.x;
+  if (bid >= WA_BLOCKS * L.NE) {  // the bound of a1
+    bid -= WA_BLOCKS * L.NE;
+    const int e = bid / A1B_BLOCKS, oc = (bid % A1B_BLOCKS) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, K = L.C * 64;
+    const float* wsrc = params + L.enc_base[e] + L.enc.c1w + (int64_t)oc * K;
+    float s = 0.0f;
+    for (int k = lane; k < K; k += 64) s += fabsf(wsrc[k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    amax_update(s + fabsf(params[L.enc_base[e] + L.enc.c1b + oc]), amax + amax_idx(AMAX_A1, e));
+    return;
+  }
+  const int e = bid / WA_BLOCKS;
+  int b = bid % WA_BLOCKS, t = 0;
+  while (b >= WA_NBLK[t]) b -= WA_NBLK[t], ++t;  // t = slot
+  const int nb = WA_NBLK[t];
   const int64_t off = t == AMAX_WL ? L.enc.lw : t == AMAX_W2 ? L.enc.c2w : t == AMAX_W3 ? L.enc.c3w : L.enc.c1w;
   const int64_t cnt = t == AMAX_WL ? (int64_t)FEAT * FLAT : t == AMAX_W2 ? (int64_t)C2_OC * C2_K : t == AMAX_W3 ? (int64_t)C3_OC * C3_K
                                                                                                               : (int64_t)C1_OC * L.C * 64;
   const float* src = params + L.enc_base[e] + off;
   float m = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+  const int64_t stride = (int64_t)nb * 256;
+  int64_t i = (int64_t)b * 256 + threadIdx.x;
+  for (; i + 7 * stride < cnt; i += 8 * stride) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(x[u]));
+  }
+  for (; i < cnt; i += stride) m = fmaxf(m, fabsf(src[i]));
   // one atomic per WORKGROUP: every wave of the grid looks at the (freshly zeroed) slot at the same moment, so the "look first" of
-  // amax_update saves nothing here and 2,048 atomics on eight addresses took 35 of this kernel's 42 us
+  // amax_update saves nothing here and 2,048 atomics on eight addresses took 35 of an earlier form's 42 us
   __shared__ float wm[4];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) atomicMax((unsigned*)(amax + amax_idx(t, e)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
-// upper bound of |a1| per encoder -> slot AMAX_A1 (common.h): max over oc of sum_k |w1[oc][k]| + |b1[oc]|; grid (32 oc, NE), one wave
-__global__ __launch_bounds__(64) void a1_bound_kernel(const float* __restrict__ params, ParamLayout L, float* __restrict__ amax) {
-  const int oc = blockIdx.x, e = blockIdx.y, K = L.C * 64;
-  const float* wsrc = params + L.enc_base[e] + L.enc.c1w + (int64_t)oc * K;
-  float s = 0.0f;
-  for (int k = threadIdx.x; k < K; k += 64) s += fabsf(wsrc[k]);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-  amax_update(s + fabsf(params[L.enc_base[e] + L.enc.c1b + oc]), amax + amax_idx(AMAX_A1, e));
+// Every derived weight layout in ONE launch (round 6: six launches of 4-10 us and their boundaries): block ranges in the order below
+constexpr int PK_D3 = 4 * 9 * 64 * 16 / 256, PK_D2 = 2 * 8 * 2 * 64 * 16 / 256, PK_C3 = 8 * 5 * 64 * 16 / 256, PK_C2 = 64 * 32 * 16 / 256;
+constexpr int PK_FC = (FLAT / 32) * (FEAT / 32);
+static_assert(FLAT % 32 == 0 && FEAT % 32 == 0, "whole 32 x 32 tiles");
+__global__ __launch_bounds__(256) void pack_all_planes_kernel(const float* __restrict__ params, ParamLayout L, unsigned short* __restrict__ wd3b,
+                                                             unsigned short* __restrict__ wd2b, unsigned short* __restrict__ wp3b,
+                                                             unsigned short* __restrict__ wp2b, unsigned short* __restrict__ wlb,
+                                                             unsigned short* __restrict__ wdlb, unsigned short* __restrict__ wp1b,
+                                                             const float* __restrict__ amax) {
+  __shared__ unsigned short tile[NPL][32][33];
+  int b = blockIdx.x;
+  const int ne = L.NE;
+  if (b < PK_FC * ne) {  // the dense layer first: its 3,136 workgroups are the bulk
+    const int e = b / PK_FC, r = b % PK_FC;
+    pack_fc_planes_body(params, L, wlb, wdlb, amax, tile, r % (FLAT / 32), r / (FLAT / 32), e);
+    return;
+  }
+  b -= PK_FC * ne;
+  if (b < PK_D3 * ne) return pack_dgrad3_planes_body(params, L, wd3b, amax, b % PK_D3, b / PK_D3);
+  b -= PK_D3 * ne;
+  if (b < PK_D2 * ne) return pack_dgrad2_planes_body(params, L, wd2b, amax, b % PK_D2, b / PK_D2);
+  b -= PK_D2 * ne;
+  if (b < PK_C3 * ne) return pack_conv3_planes_body(params, L, wp3b, amax, b % PK_C3, b / PK_C3);
+  b -= PK_C3 * ne;
+  if (b < PK_C2 * ne) return pack_conv2_planes_body(params, L, wp2b, amax, b % PK_C2, b / PK_C2);
+  b -= PK_C2 * ne;
+  pack_conv1_planes_body(params, L, wp1b, amax, b);
 }
 
 void launch_pack_weights(const Workspace& w, const ParamLayout& L, const float* params, hipStream_t st) {
   static_assert(AMAX_WL == 0 && AMAX_W2 == 1 && AMAX_W3 == 2 && AMAX_W1 == 3 && AMAX_A1 == 4 && AMAX_FIRST_ACT == 5,
                 "weight slots and the bound of a1 come first");
   (void)hipMemsetAsync(w.amax, 0, AMAX_FIRST_ACT * 2 * sizeof(float), st);
-  hipLaunchKernelGGL(weights_amax_kernel, dim3(64, AMAX_A1, L.NE), dim3(256), 0, st, params, L, w.amax);
-  hipLaunchKernelGGL(a1_bound_kernel, dim3(32, L.NE), dim3(64), 0, st, params, L, w.amax);
-  hipLaunchKernelGGL(pack_dgrad3_planes_kernel, dim3(4 * 9 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd3b, w.amax);
-  hipLaunchKernelGGL(pack_dgrad2_planes_kernel, dim3(2 * 8 * 2 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wd2b, w.amax);
-  hipLaunchKernelGGL(pack_conv3_planes_kernel, dim3(8 * 5 * 64 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp3b, w.amax);
-  hipLaunchKernelGGL(pack_conv2_planes_kernel, dim3(64 * 32 * 16 / 256, L.NE), dim3(256), 0, st, params, L, w.wp2b, w.amax);
-  static_assert(FLAT % 32 == 0 && FEAT % 32 == 0, "whole 32 x 32 tiles");
-  hipLaunchKernelGGL(pack_fc_planes_kernel, dim3(FLAT / 32, FEAT / 32, L.NE), dim3(256), 0, st, params, L, w.wlb, w.wdlb, w.amax);
-  hipLaunchKernelGGL(pack_conv1_planes_kernel, dim3((L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256), dim3(256), 0, st, params, L, w.wp1b, w.amax);
+  hipLaunchKernelGGL(weights_amax_kernel, dim3((WA_BLOCKS + A1B_BLOCKS) * L.NE), dim3(256), 0, st, params, L, w.amax);
+  const int c1_blocks = (L.C * 4 * 2 * 32 * L.NE * 8 + 255) / 256;
+  hipLaunchKernelGGL(pack_all_planes_kernel, dim3((PK_FC + PK_D3 + PK_D2 + PK_C3 + PK_C2) * L.NE + c1_blocks), dim3(256), 0, st, params, L,
+                     w.wd3b, w.wd2b, w.wp3b, w.wp2b, w.wlb, w.wdlb, w.wp1b, w.amax);
 }
 
 // --------------------------------------------------------------------------------------------
