@@ -136,7 +136,7 @@ def test_gae_golden_f2_bit_exact(hp, golden):
         assert np.array_equal(ret.cpu().numpy(), g[kr])
 
 
-@pytest.mark.parametrize("n", [3, 130, 512])
+@pytest.mark.parametrize("n", [1, 3, 130, 257, 512])
 def test_fused_acting_forward(onet, n):
     """ddrl_forward of at most 512 samples runs conv1-conv3 in one kernel that keeps a1 / a2 on chip (csrc/act.hip), one workgroup
     per (sample, encoder).  (a) The variant that also stores a1 / a2 (ddrl_debug_keep_activations) gives bit-identical outputs;
@@ -150,7 +150,8 @@ def test_fused_acting_forward(onet, n):
         rng = np.random.default_rng(900 + n)
         frames = rng.integers(0, 256, size=(n, 4, 84, 84), dtype=np.uint8)
         frames[0] = 0
-        frames[1] = 255
+        if n > 1:
+            frames[1] = 255
         acts = rng.integers(0, 6, size=n).astype(np.float32)
         fd, ad = dev(frames), dev(acts)
         p0, v0, _, l0 = (t.clone() for t in h.forward(fd, act=ad))
@@ -163,15 +164,27 @@ def test_fused_acting_forward(onet, n):
         p1, v1, _, l1 = h.forward(fd, act=ad)
         assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(l0, l1)
         a1k = h.debug_buffer(0, (32, 20, 20), n, 1).cpu().numpy()
+        a1a = h.debug_buffer(0, (32, 20, 20), n, 0).cpu().numpy()
+        a2k = [h.debug_buffer(1, (64, 9, 9), n, e).cpu().numpy() for e in (0, 1)]
+        a3c = h.debug_buffer(2, (64, 7, 7), n, 1).cpu().numpy()
         h.keep_activations(False)
         x = O.frames_to_f32(frames)
         with torch.no_grad():
             oprobs, _, _, ov = onet(x)
             enc = onet.actor.pre
             r3 = torch.nn.functional.leaky_relu(enc.conv3(torch.nn.functional.leaky_relu(enc.conv2(torch.nn.functional.leaky_relu(enc.conv1(x))))))
-            c1 = torch.nn.functional.leaky_relu(onet.critic.pre.conv1(x))
+            lr = torch.nn.functional.leaky_relu
+            c1 = lr(onet.critic.pre.conv1(x))
+            r1 = lr(enc.conv1(x))
+            r2, c2 = lr(enc.conv2(r1)), lr(onet.critic.pre.conv2(c1))
+            c3 = lr(onet.critic.pre.conv3(c2))
         np.testing.assert_allclose(a3, r3.numpy(), rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(a1k, c1.numpy(), rtol=1e-5, atol=2e-6)
+        # every stage of both encoders (round 6: the kernel's tiles, K halves and hand-over buffers are per stage)
+        np.testing.assert_allclose(a1a, r1.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a2k[0], r2.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a2k[1], c2.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a3c, c3.numpy(), rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(p0.cpu().numpy(), oprobs.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(v0.cpu().numpy(), ov.numpy().reshape(-1), rtol=1e-5, atol=2e-6)
         # (c): the batch-tiled kernels on the same samples (padded to 600 with copies)
