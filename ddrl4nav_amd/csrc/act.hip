@@ -3,14 +3,15 @@
 // Reference: AtariPreNet.forward (nn/atari_encoder.py:25-32) inside ForwardThread.run (server/forward.py:128-149): a few hundred
 // samples per call, latency-bound.  The training kernels of conv2.hip tile the BATCH (3-5 samples per workgroup, k loop of 8-16
 // barrier pairs); run on 256 samples they are five dependent launches of 15-25 us, each a serial chain on one wave per SIMD.
-// Here one workgroup of eight waves owns ONE (sample, encoder) pair from the frame bytes to a3, on 67 KB of LDS and <= 128 registers,
-// so that TWO workgroups share a CU (256 environments x 2 encoders = 512 workgroups = one round on 256 CUs):
+// Here one workgroup of eight waves owns ONE (sample, encoder) pair from the frame bytes to a3, on 62 KB of LDS and <= 128 registers,
+// so that TWO workgroups share a CU (256 environments x 2 encoders = 512 workgroups = one round on 256 CUs; LDS = frames + conv1 weights
+// + biases = 61.7 KB):
 //
 //   frames (u8, 28 KB)  -> LDS as they are; a fragment's eight bytes become fp16 operands when it is read (1024 + b is 0x6400 | b:
 //          one v_perm_b32 and one v_pk_add_f16 per pixel pair, exact)
 //   conv1  32 x 32 x 16 MFMA, A = 32 output pixels, B = the 32 output channels (this encoder's weight planes, 32 KB of LDS); wave = two
 //          pixel tiles, kept in registers until every wave is done with the frames and the conv1 weights
-//          -> bias, leaky, split into two scaled fp16 planes -> LDS [plane][channel][20 rows of pitch 52 B]  66.6 KB, OVER frames + weights
+//          -> bias, leaky, split into two scaled fp16 planes -> LDS [plane][channel][20 rows of pitch 44 B]  56.3 KB, OVER frames + weights
 //   conv2  16 x 16 x 32 MFMA: wave = (32 output channels = two tiles, one HALF of K, three of the six column tiles); its weight
 //          fragments come straight from L2 into registers, streamed in groups; the two K halves meet through 24 KB of LDS (each wave
 //          hands over the output-channel tile its partner finishes) -> bias, leaky, per-SAMPLE plane scale (the workgroup's own maximum)
@@ -63,8 +64,10 @@ struct ActG {
   static constexpr int THREADS = 512;
   static constexpr int FR_CH = 7056, FR_ROW = 84, FR_BYTES = 4 * FR_CH;                 // frame bytes as they are
   static constexpr int W1_OFF = FR_BYTES, W1_BYTES = 4 * 4 * NPL * 2 * 32 * 16;          // conv1 weight planes of this encoder
-  static constexpr int A1_ROW = 52, A1_CH = 20 * A1_ROW, A1_PLANE = 32 * A1_CH, A1_OFF = 0, A1_BYTES = NPL * A1_PLANE;  // conv2.hip Fwd2B row pitch
-  static constexpr int BIAS_OFF = A1_BYTES, MAX_OFF = BIAS_OFF + 160 * 4, LDS_BYTES = MAX_OFF + 16 * 4;
+  // a1 rows of 20 pixels = 40 B at pitch 44: measured best of 40 / 44 / 48 / 52 (the training kernel's, conflict-free for ITS 32-lane column
+  // tiles) / 56 / 60 for the 16-lane tiles of this kernel's conv2 (30.6 us against 31.3-33.4, profiles/r06_act_convs_ab.txt)
+  static constexpr int A1_ROW = 44, A1_CH = 20 * A1_ROW, A1_PLANE = 32 * A1_CH, A1_OFF = 0, A1_BYTES = NPL * A1_PLANE;
+  static constexpr int BIAS_OFF = A1_BYTES > W1_OFF + W1_BYTES ? A1_BYTES : W1_OFF + W1_BYTES, MAX_OFF = BIAS_OFF + 160 * 4, LDS_BYTES = MAX_OFF + 16 * 4;
   static constexpr int A2_KB = 81 * 16, A2_PLANE = 8 * A2_KB, A2_OFF = 0;                // conv2.hip Fwd3B with all 8 k-blocks resident
   static constexpr int GK = 2;                                     // k-steps per weight group (16 registers per k-step: two tiles x two planes)
   static constexpr int NB = 2;                                     // groups in registers: the one in use + NB - 1 requested (3, 4: no gain)
