@@ -945,7 +945,7 @@ def test_eighteen_actions_golden_f12(golden):
     h.close()
 
 
-@pytest.mark.parametrize("A", [2, 9, 13, 18])
+@pytest.mark.parametrize("A", [2, 5, 6, 7, 8, 9, 13, 18])  # <= 6: reduced-together dot products, LDS weights; 7-8: register weights; > 8: LDS weights + head_wgrad
 def test_action_counts_vs_oracle(A):
     from ddrl4nav_amd.engine import HotPath
     n = 70
